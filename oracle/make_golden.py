@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""oracle/make_golden.py -- generates tests/golden/*.npz.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container (needs /root/reference and oracle/_ref, see
+oracle/Makefile).  It imports the reference's *unmodified* Python model plugins
+(model/model_surf.py, model/model_rf.py, model/model_rf_swd_vs_thk.py) and samplers
+from /root/reference and feeds them
+
+  * ``model.lib.libsurf`` = the reference's own pybind11 extension, built from
+    src/SWD as is (oracle/_ref/libsurf*.so)                      -> "reference" fixtures
+  * ``model.lib.librf``   = oracle.RefRFCore: the compiled reference propagator /
+    partials core (RFModule.f90) + numpy irfft for the 15-line tail the reference
+    delegates to FFTW3 (absent here)                              -> "hybrid" fixtures
+
+Every array written is data (inputs and outputs); no reference source text is stored.
+Usage:  python3 oracle/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc  # noqa: E402
+
+
+def import_reference():
+    """Import the reference Python with model.lib.{libsurf,librf} injected."""
+    ref_surf = orc.ref_libsurf()
+    ref_rf = orc.RefRFCore()
+    pkg = types.ModuleType("model")
+    pkg.__path__ = [os.path.join(REF, "model")]
+    libpkg = types.ModuleType("model.lib")
+    libpkg.libsurf = ref_surf
+    libpkg.librf = ref_rf
+    sys.modules["model"] = pkg
+    sys.modules["model.lib"] = libpkg
+    sys.modules["model.lib.libsurf"] = ref_surf
+    sys.modules["model.lib.librf"] = ref_rf
+    import importlib
+    m_surf = importlib.import_module("model.model_surf")
+    m_rf = importlib.import_module("model.model_rf")
+    m_joint = importlib.import_module("model.model_rf_swd_vs_thk")
+    return ref_surf, ref_rf, m_surf, m_rf, m_joint
+
+
+def emp(vs):
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    return vp, rho
+
+
+def models():
+    """Named (thk, vs, periods) cases: SURVEY.md section 8(c) items (i)-(vii)."""
+    out = {}
+    out["yaml7"] = (np.array([6., 6, 13., 5, 10, 30, 0]),
+                    np.array([3.2, 2.8, 3.46, 3.3, 3.9, 4.5, 4.7]), np.arange(5., 41.))
+    out["cfg1_10"] = (np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]), np.linspace(2.9, 4.6, 10),
+                      np.arange(5., 41.))
+    t40 = np.linspace(5, 44, 40)
+    thk30 = np.full(30, 2.0); thk30[-1] = 0.0
+    vs30 = np.linspace(2.8, 4.6, 30)
+    out["grad30"] = (thk30, vs30, t40)
+    thk50 = np.full(50, 1.2); thk50[-1] = 0.0
+    out["grad50"] = (thk50, np.linspace(2.8, 4.6, 50), t40)
+    rng = np.random.default_rng(991206)
+    for i in range(8):   # sorted-prior draws inside the main_base.py:64-77 bounds
+        lo = np.maximum(0.2 * vs30, 1.5); hi = np.minimum(1.8 * vs30, 5.0)
+        v = lo + (hi - lo) * rng.random(30)
+        h = thk30 * (0.8 + 0.4 * rng.random(30))
+        idx = np.argsort(v)
+        out[f"prior30_{i}"] = (h[idx] * (thk30 > 0), v[idx], t40)
+    for i in range(4):   # +-10 % perturbations (low-velocity zones allowed)
+        v = vs30 * (0.9 + 0.2 * rng.random(30))
+        h = thk30 * (0.8 + 0.4 * rng.random(30))
+        out[f"lvz30_{i}"] = (h, v, t40)
+    for i in range(6):   # "wild" unsorted models: exercises reversed dispersion / failures
+        lo = np.maximum(0.2 * vs30, 1.5); hi = np.minimum(1.8 * vs30, 5.0)
+        v = lo + (hi - lo) * rng.random(30)
+        h = thk30 * (0.8 + 0.4 * rng.random(30))
+        out[f"wild30_{i}"] = (h, v, t40)
+    rng = np.random.default_rng(5)   # velocity-inversion models: root search fails on many
+    for i in range(48):
+        n = int(rng.integers(3, 12))
+        v = np.sort(1.5 + 3.5 * rng.random(n))[::-1].copy()
+        h = 0.5 + 5 * rng.random(n); h[-1] = 0.0
+        t = np.sort(0.2 + 30 * rng.random(12))
+        if i in (0, 1, 2, 3, 20, 22, 43):
+            out[f"inverted_{i}"] = (h, v, t)
+    return out
+
+
+def gen_swd(ref_surf, M):
+    g = {}
+    for name, (thk, vs, t) in M.items():
+        vp, rho = emp(vs)
+        g[f"{name}/thk"], g[f"{name}/vs"], g[f"{name}/t"] = thk, vs, t
+        for wt in ("Rc", "Rg"):
+            if wt == "Rg" and name.startswith(("wild", "inverted", "prior30_4", "prior30_5", "prior30_6", "prior30_7")):
+                continue
+            c, flag = ref_surf.forward(thk, vp, vs, rho, t, wt)
+            g[f"{name}/{wt}/fwd_c"], g[f"{name}/{wt}/fwd_flag"] = c, np.array(flag)
+            c, ka, kb, kr, kh, flag = ref_surf.adjoint_kernel(thk, vp, vs, rho, t, wt)
+            g[f"{name}/{wt}/c"], g[f"{name}/{wt}/flag"] = c, np.array(flag)
+            if flag:
+                g[f"{name}/{wt}/dcda"], g[f"{name}/{wt}/dcdb"] = ka, kb
+                g[f"{name}/{wt}/dcdr"], g[f"{name}/{wt}/dcdh"] = kr, kh
+    np.savez_compressed(os.path.join(OUT, "swd_reference.npz"), **g)
+    print("swd_reference.npz:", len(g), "arrays")
+
+
+RF_CASES = {  # name -> (model, nt, dt)
+    "yaml7_nt125": ("yaml7", 125, 0.4),
+    "grad30_nt512": ("grad30", 512, 0.1),
+    "prior30_0_nt512": ("prior30_0", 512, 0.1),
+    "lvz30_0_nt512": ("lvz30_0", 512, 0.1),
+    "grad50_nt512": ("grad50", 512, 0.1),
+    "grad30_nt2048": ("grad30", 2048, 0.025),
+}
+RAY_P, GAUSS, TSHIFT, WATER = 0.045, 1.5, 5.0, 0.001
+
+
+def gen_rf(ref_rf, M):
+    core, trace = {}, {}
+    rng = np.random.default_rng(7)
+    for name, (mname, nt, dt) in RF_CASES.items():
+        thk, vs, _ = M[mname]
+        vp, rho = emp(vs)
+        n = len(vs)
+        qa = np.full(n, 9999.0)
+        w, sigma, nft, R21, R22, R21m, R22m = ref_rf.spectra(thk, rho, vp, vs, qa, qa, RAY_P, nt, dt, 1)
+        stride = 1 if nt <= 128 else (8 if nt <= 512 else 64)
+        sel = np.unique(np.concatenate((np.arange(0, len(w), stride), [len(w) - 1])))
+        for k, v in (("thk", thk), ("vs", vs), ("nt", np.array(nt)), ("dt", np.array(dt)),
+                     ("freq_index", sel), ("w", w[sel]), ("sigma", np.array(sigma)),
+                     ("R21", R21[sel]), ("R22", R22[sel]), ("R21_m", R21m[sel]), ("R22_m", R22m[sel])):
+            core[f"{name}/{k}"] = v
+        rf, kl = ref_rf.kernel_all(thk, rho, vp, vs, qa, qa, RAY_P, nt, dt, GAUSS, TSHIFT, "freq", WATER, "P")
+        rf_fwd = ref_rf.forward(thk, rho, vp, vs, qa, qa, RAY_P, nt, dt, GAUSS, TSHIFT, "freq", WATER, "P")
+        r = rng.standard_normal(nt)
+        for k, v in (("thk", thk), ("vs", vs), ("nt", np.array(nt)), ("dt", np.array(dt)),
+                     ("rf", rf), ("rf_forward", rf_fwd), ("r", r), ("kl_dot_r", kl @ r)):
+            trace[f"{name}/{k}"] = v
+        if nt <= 128:
+            trace[f"{name}/kl"] = kl
+        else:
+            tsel = np.arange(0, nt, max(1, nt // 64))
+            trace[f"{name}/kl_t_index"] = tsel
+            trace[f"{name}/kl_sub"] = kl[:, :, tsel]
+    for d in (core, trace):
+        d["ray_p"], d["gauss"], d["time_shift"], d["water"] = (np.array(v) for v in (RAY_P, GAUSS, TSHIFT, WATER))
+    np.savez_compressed(os.path.join(OUT, "rf_core_reference.npz"), **core)
+    np.savez_compressed(os.path.join(OUT, "rf_trace_hybrid.npz"), **trace)
+    print("rf_core_reference.npz:", len(core), "arrays; rf_trace_hybrid.npz:", len(trace), "arrays")
+
+
+PLUGIN_CASES = {  # name -> (model, nt, dt, use tRg)
+    "yaml7": ("yaml7", 125, 0.4, True),
+    "cfg1_10": ("cfg1_10", 125, 0.4, True),
+    "cfg2_30": ("grad30", 512, 0.1, False),
+    "cfg2_30_rg": ("grad30", 512, 0.1, True),
+    "cfg4_50": ("grad50", 512, 0.1, False),
+}
+
+
+def gen_plugin(m_surf, m_rf, m_joint, M):
+    g = {}
+    rng = np.random.default_rng(20240607)
+    for name, (mname, nt, dt, with_rg) in PLUGIN_CASES.items():
+        thk, vs, t = M[mname]
+        n = len(vs)
+        swd = m_surf.SurfWD(tRc=t, tRg=t if with_rg else None, tLc=None, tLg=None)
+        rf = m_rf.ReceiverFunc(RAY_P, nt, dt, GAUSS, TSHIFT, WATER, "P", "freq")
+        joint = m_joint.Joint_RF_SWD(1.0, 1.0, rf, swd)
+        x0 = np.hstack((vs, thk))
+        drf, dswd, flag = joint.forward(x0)
+        assert flag
+        joint.set_obsdata(drf, dswd)
+        nx = 3 if n <= 10 else 2
+        xs = np.zeros((nx, 2 * n))
+        for i in range(nx):
+            xs[i, :n] = vs * (1 + 0.04 * (rng.random(n) - 0.5))
+            xs[i, n:] = thk * (1 + 0.1 * (rng.random(n) - 0.5))
+        g[f"{name}/x0"], g[f"{name}/x"], g[f"{name}/t"] = x0, xs, t
+        g[f"{name}/nt"], g[f"{name}/dt"], g[f"{name}/with_rg"] = np.array(nt), np.array(dt), np.array(with_rg)
+        g[f"{name}/dobs"] = joint.dobs
+        for i in range(nx):
+            ms, gs, ds, fs = swd.misfit_and_grad(xs[i])
+            mr, gr, dr = rf.misfit_and_grad(xs[i])
+            mj, gj, dj, fj = joint.misfit_and_grad(xs[i])
+            for k, v in (("swd_misfit", ms), ("swd_grad", gs), ("swd_d", ds), ("swd_flag", fs),
+                         ("rf_misfit", mr), ("rf_grad", gr), ("rf_d", dr),
+                         ("joint_misfit", mj), ("joint_grad", gj), ("joint_d", dj), ("joint_flag", fj)):
+                g[f"{name}/{i}/{k}"] = np.asarray(v)
+    g["ray_p"], g["gauss"], g["time_shift"], g["water"] = (np.array(v) for v in (RAY_P, GAUSS, TSHIFT, WATER))
+    np.savez_compressed(os.path.join(OUT, "plugin_hybrid.npz"), **g)
+    print("plugin_hybrid.npz:", len(g), "arrays")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
+    M = models()
+    gen_swd(ref_surf, M)
+    gen_rf(ref_rf, M)
+    gen_plugin(m_surf, m_rf, m_joint, M)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,396 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+Python face of the CPU oracle for the misfit+gradient hot path of nqdu/RfSurfHmc.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module; the product package ``rfsurfhmc_amd`` never does.
+
+Three layers, each citing the reference file:line it restates:
+
+* ``libsurf`` / ``librf`` -- objects with the call signatures of the reference's
+  pybind11 extensions (src/SWD/main.cpp:14-93, src/RF/main.cpp:17-212), backed by
+  the plain-C restatement in ``oracle/liboracle.so`` (swd_oracle.c, rf_oracle.c).
+* ``SurfWD`` / ``ReceiverFunc`` / ``Joint_RF_SWD`` -- numpy restatement of the model
+  plugins (model/model_surf.py:155-228, model/model_rf.py:137-198,
+  model/model_rf_swd_vs_thk.py:66-86): empirical vp(vs), rho(vp), chain rule, K.r.
+* ``ref_libsurf()`` / ``RefRFCore`` -- the reference itself, built from its own
+  sources into ``oracle/_ref`` by ``oracle/Makefile`` (complete for src/SWD; the
+  propagator/partials core only for src/RF, whose FFTW wrapper cannot be built
+  here).  They validate the restatement and serve as CPU baseline.
+
+Parity pin status: SWD -- pinned to the compiled reference (bit-exact phase
+velocities, kernels to 1e-12) and to golden vectors generated from it.  RF --
+every per-frequency quantity (R21, R22 and the 4*nlayer partials) pinned to the
+compiled reference core; the 15-line water-level/IFFT tail is pinned only by the
+known answers recorded in SURVEY.md section 8(c) and numpy's irfft.
+"""
+from __future__ import annotations
+
+import ctypes
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DP = ctypes.POINTER(ctypes.c_double)
+_FP = ctypes.POINTER(ctypes.c_float)
+
+
+def _d(a):
+    return a.ctypes.data_as(_DP)
+
+
+def _f(a):
+    return a.ctypes.data_as(_FP)
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so (always) and oracle/_ref (only where the reference is present)."""
+    subprocess.run(["make", "-s", "-C", _HERE, "oracle"], check=True)
+    if ref and os.path.isdir("/root/reference/src"):
+        subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
+
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = ctypes.CDLL(path)
+        L.orc_nextpow2.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+# --------------------------------------------------------------------------
+# B1 level: same call signatures as the reference's pybind11 modules
+# --------------------------------------------------------------------------
+_WAVETYPES = {"Rc": 0, "Rg": 1}
+
+
+class _LibSurf:
+    """Restatement of libsurf (src/SWD/main.cpp:14-93), Rayleigh + flat earth only."""
+
+    nsec = 0  # secular-function evaluations of the last call (work accounting)
+
+    @staticmethod
+    def _prep(thk, vp, vs, rho, period):
+        f32 = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
+               for a in (thk, vp, vs, rho)]  # forcecast to float32, main.cpp:9
+        t = np.ascontiguousarray(np.asarray(period, dtype=np.float64))
+        return f32, t
+
+    def forward(self, thk, vp, vs, rho, period, wavetype, mode=0, sphere=False):
+        if wavetype not in _WAVETYPES or mode != 0 or sphere:
+            raise NotImplementedError("oracle covers Rc/Rg, fundamental mode, flat earth")
+        (h, a, b, r), t = self._prep(thk, vp, vs, rho, period)
+        n, nt = len(h), len(t)
+        cg = np.zeros(nt)
+        L = lib()
+        if wavetype == "Rc":
+            nsec = ctypes.c_long(0)
+            ierr = L.orc_surfdisp_rc(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt,
+                                     ctypes.byref(nsec))
+            _LibSurf.nsec = nsec.value
+        else:
+            ierr = L.orc_rayleigh_group(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt)
+        return cg, ierr != 1
+
+    def adjoint_kernel(self, thk, vp, vs, rho, period, wavetype, mode=0, sphere=False):
+        if wavetype not in _WAVETYPES or mode != 0 or sphere:
+            raise NotImplementedError("oracle covers Rc/Rg, fundamental mode, flat earth")
+        (h, a, b, r), t = self._prep(thk, vp, vs, rho, period)
+        n, nt = len(h), len(t)
+        c = np.zeros(nt)
+        ka, kb, kr, kh = (np.zeros((nt, n)) for _ in range(4))
+        nsec = ctypes.c_long(0)
+        ierr = lib().orc_surf_kernel(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(c), nt,
+                                     _d(ka), _d(kb), _d(kr), _d(kh), _WAVETYPES[wavetype],
+                                     ctypes.byref(nsec))
+        _LibSurf.nsec = nsec.value
+        return c, ka, kb, kr, kh, ierr != 1
+
+
+def _rf_type(rf_type, time_shift):
+    if rf_type in ("P", "p"):
+        return 1, time_shift
+    if rf_type in ("S", "s"):
+        return 2, -time_shift  # main.cpp:35
+    raise ValueError("rf_type should be one of [P,p,S,s]")
+
+
+class _LibRF:
+    """Restatement of librf (src/RF/main.cpp:17-212), frequency-domain method only."""
+
+    @staticmethod
+    def _prep(*arrs):
+        return [np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in arrs]
+
+    def forward(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+                method="time", water=0.001, rf_type="P"):
+        if method == "time":
+            raise NotImplementedError("oracle covers the frequency-domain method only")
+        irf, t0 = _rf_type(rf_type, time_shift)
+        thk, rho, vp, vs, qa, qb = self._prep(thk, rho, vp, vs, qa, qb)
+        rf = np.zeros(nt)
+        c = ctypes.c_double
+        lib().orc_rf_freq(_d(thk), _d(vp), _d(vs), _d(rho), _d(qa), _d(qb), len(thk), int(nt),
+                          c(dt), c(ray_p), c(gauss), c(t0), c(water), irf, _d(rf))
+        return rf
+
+    def kernel_all(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+                   method="time", water=0.001, rf_type="P"):
+        if method == "time":
+            raise NotImplementedError("oracle covers the frequency-domain method only")
+        irf, t0 = _rf_type(rf_type, time_shift)
+        thk, rho, vp, vs, qa, qb = self._prep(thk, rho, vp, vs, qa, qb)
+        n = len(thk)
+        rf = np.zeros(nt)
+        kl = np.zeros((4, n, nt))
+        c = ctypes.c_double
+        lib().orc_rf_par_freq_all(_d(thk), _d(vp), _d(vs), _d(rho), _d(qa), _d(qb), n, int(nt),
+                                  c(dt), c(ray_p), c(gauss), c(t0), c(water), irf, _d(rf), _d(kl))
+        return rf, kl
+
+    def kernel(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+               method="time", water=0.001, rf_type="P", par_type="vs"):
+        idx = {"rho": 0, "vp": 1, "alpha": 1, "vs": 2, "beta": 2, "h": 3, "thick": 3}[par_type]
+        rf, kl = self.kernel_all(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+                                 method, water, rf_type)
+        return rf, kl[idx].copy()
+
+
+libsurf = _LibSurf()
+librf = _LibRF()
+
+
+# --------------------------------------------------------------------------
+# B2 level: numpy restatement of the model plugins
+# --------------------------------------------------------------------------
+def empirical_relation(vs):
+    """model/model_surf.py:47-79 == model/model_rf.py:52-77: (vp, rho, dadb, drda)."""
+    vp = 0.9409 + 2.0947 * vs - 0.8206 * vs**2 + 0.2683 * vs**3 - 0.0251 * vs**4
+    rho = 1.6612 * vp - 0.4721 * vp**2 + 0.0671 * vp**3 - 0.0043 * vp**4 + 0.000106 * vp**5
+    drda = 1.6612 - 0.4721 * 2 * vp + 0.0671 * 3 * vp**2 - 0.0043 * 4 * vp**3 + 0.000106 * 5 * vp**4
+    dadb = 2.0947 - 0.8206 * 2 * vs + 0.2683 * 3 * vs**2 - 0.0251 * 4 * vs**3
+    return vp, rho, dadb, drda
+
+
+class SurfWD:
+    """model/model_surf.py (Rayleigh blocks).  ``lib`` = any object with the libsurf API."""
+
+    def __init__(self, tRc=None, tRg=None, lib=None, mode=0, sphere=False):
+        self.lib = lib if lib is not None else libsurf
+        self.mode, self.sphere = mode, sphere
+        self.tRc = np.asarray(tRc, dtype=float) if tRc is not None and len(tRc) > 0 else None
+        self.tRg = np.asarray(tRg, dtype=float) if tRg is not None and len(tRg) > 0 else None
+        self.ntRc = 0 if self.tRc is None else len(self.tRc)
+        self.ntRg = 0 if self.tRg is None else len(self.tRg)
+        self.nt = self.ntRc + self.ntRg
+
+    def set_obsdata(self, dobs):
+        self.dobs = dobs
+
+    def forward(self, x):
+        """model_surf.py:81-133 -- note every block is computed at tRc (quirk :114-130)."""
+        n = len(x) // 2
+        vs, thk = x[:n], x[n:]
+        vp, rho, _, _ = empirical_relation(vs)
+        d = np.zeros(self.nt)
+        if self.ntRc > 0:
+            d[:self.ntRc], flag = self.lib.forward(thk, vp, vs, rho, self.tRc, "Rc", self.mode, self.sphere)
+            if not flag:
+                return d, flag
+        if self.ntRg > 0:
+            k1 = self.ntRc
+            d[k1:k1 + self.ntRg], flag = self.lib.forward(thk, vp, vs, rho, self.tRc, "Rg", self.mode, self.sphere)
+            if not flag:
+                return d, flag
+        return d, True
+
+    def misfit_and_grad(self, x):
+        """model_surf.py:155-228."""
+        n = len(x) // 2
+        vs, thk = x[:n], x[n:]
+        vp, rho, dadb, drda = empirical_relation(vs)
+        kernel = np.zeros((self.nt, n))
+        kernel_thk = np.zeros((self.nt, n))
+        d = np.zeros(self.nt)
+        k1 = 0
+        for periods, wt in ((self.tRc, "Rc"), (self.tRg, "Rg")):
+            if periods is None:
+                continue
+            k2 = k1 + len(periods)
+            cg, dcda, dcdb, dcdr, dcdh, flag = self.lib.adjoint_kernel(
+                thk, vp, vs, rho, periods, wt, self.mode, self.sphere)
+            if not flag:
+                return 0.0, np.zeros(n), np.zeros(self.nt), False
+            d[k1:k2] = cg
+            kernel[k1:k2] = dcdb + dcda * dadb + dcdr * drda * dadb
+            kernel_thk[k1:k2] = dcdh
+            k1 = k2
+        r = d - self.dobs
+        grad = np.hstack((r @ kernel, r @ kernel_thk))
+        return 0.5 * np.sum(r**2), grad, d, True
+
+
+class ReceiverFunc:
+    """model/model_rf.py.  ``lib`` = any object with the librf API."""
+
+    def __init__(self, ray_p, nt, dt, gauss, time_shift, water_level=0.001, type_="P",
+                 method="freq", lib=None):
+        self.lib = lib if lib is not None else librf
+        self.ray_p, self.nt, self.dt, self.gauss = ray_p, nt, dt, gauss
+        self.time_shift, self.water_level, self.rf_type, self.method = time_shift, water_level, type_, method
+
+    def set_obsdata(self, dobs):
+        self.dobs = dobs
+
+    def forward(self, x):
+        """model_rf.py:79-116."""
+        n = len(x) // 2
+        vs, thk = x[:n], x[n:]
+        vp, rho, _, _ = empirical_relation(vs)
+        qa = thk * 0 + 9999.0
+        return self.lib.forward(thk, rho, vp, vs, qa, qa.copy(), self.ray_p, self.nt, self.dt,
+                                self.gauss, self.time_shift, self.method, self.water_level, self.rf_type)
+
+    def misfit_and_grad(self, x):
+        """model_rf.py:137-198 (3-tuple, no flag)."""
+        n = len(x) // 2
+        vs, thk = x[:n], x[n:]
+        vp, rho, dadb, drda = empirical_relation(vs)
+        qa = thk * 0 + 9999.0
+        d, kl = self.lib.kernel_all(thk, rho, vp, vs, qa, qa.copy(), self.ray_p, self.nt, self.dt,
+                                    self.gauss, self.time_shift, self.method, self.water_level,
+                                    self.rf_type)
+        krho, kvp, kvs, kthk = kl[0], kl[1], kl[2], kl[3]
+        kernel = kvs + dadb[:, None] * kvp + (drda * dadb)[:, None] * krho
+        r = d - self.dobs
+        grad = np.hstack((kernel @ r, kthk @ r))
+        return 0.5 * np.sum(r**2), grad, d
+
+
+class Joint_RF_SWD:
+    """model/model_rf_swd_vs_thk.py."""
+
+    def __init__(self, sigma1, sigma2, rfmodel, swdmodel):
+        self.sigma1, self.sigma2, self.rfmodel, self.swdmodel = sigma1, sigma2, rfmodel, swdmodel
+        self.ndata = rfmodel.nt + swdmodel.nt
+
+    def set_obsdata(self, rfobs, swdobs):
+        self.rfmodel.set_obsdata(np.asarray(rfobs) * 1.0)
+        self.swdmodel.set_obsdata(np.asarray(swdobs) * 1.0)
+        self.dobs = np.concatenate((self.rfmodel.dobs, self.swdmodel.dobs))
+
+    def forward(self, x):
+        drf = self.rfmodel.forward(x)
+        dswd, flag = self.swdmodel.forward(x)
+        return drf, dswd, flag
+
+    def misfit_and_grad(self, x):
+        """model_rf_swd_vs_thk.py:66-86."""
+        misfitr, gradr, dr = self.rfmodel.misfit_and_grad(x)
+        misfits, grads, ds, flag = self.swdmodel.misfit_and_grad(x)
+        if not flag:
+            return 0.0, np.zeros(gradr.shape), self.dobs, flag
+        wt = (self.sigma1 / self.sigma2) ** 2 * dr.size / ds.size
+        return misfitr + wt * misfits, gradr + wt * grads, np.concatenate((dr, ds)), True
+
+
+# --------------------------------------------------------------------------
+# the reference itself (oracle/_ref), when it has been built
+# --------------------------------------------------------------------------
+def ref_available() -> bool:
+    d = os.path.join(_HERE, "_ref")
+    return os.path.isdir(d) and any(f.startswith("libsurf") for f in os.listdir(d)) \
+        and os.path.exists(os.path.join(d, "librf_core_ref.so"))
+
+
+def ref_libsurf():
+    """The reference's own pybind11 module ``libsurf`` (complete build of src/SWD)."""
+    d = os.path.join(_HERE, "_ref")
+    name = [f for f in os.listdir(d) if f.startswith("libsurf") and f.endswith(".so")][0]
+    spec = importlib.util.spec_from_file_location("libsurf", os.path.join(d, name))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class RefRFCore:
+    """Compiled reference RF core (RFModule.f90 procedures) behind oracle/ref_probe.c.
+
+    ``kernel_all``/``forward`` combine the reference's per-frequency R21/R22/partials
+    with this file's restatement of the reference's 15-line tail (RFModule.f90:392-425)
+    using numpy's irfft -- a HYBRID, labelled as such wherever its output is stored.
+    """
+
+    def __init__(self):
+        self.L = ctypes.CDLL(os.path.join(_HERE, "_ref", "librf_core_ref.so"))
+        self.L.refprobe_nextpow2.restype = ctypes.c_int
+
+    @staticmethod
+    def _atten(v, q):
+        return np.ascontiguousarray(v * (1.0 + 1j / (2.0 * q) + 1.0 / (8.0 * q**2)))
+
+    def spectra(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, rf_type=1, partials=True):
+        thk, rho, vp, vs, qa, qb = (np.ascontiguousarray(np.asarray(a, dtype=float))
+                                    for a in (thk, rho, vp, vs, qa, qb))
+        n = len(thk)
+        nft = self.L.refprobe_nextpow2(int(nt))
+        n2 = nft // 2 + 1
+        al, be = self._atten(vp, qa), self._atten(vs, qb)
+        pi32 = float(np.float32(np.arctan(np.float32(1.0)) * np.float32(4.0)))
+        sigma = 1.0 / dt / nft * 4.0
+        w = np.array([1.0 / nft / dt * it * 2.0 * pi32 for it in range(n2)])
+        R21 = np.zeros(n2, complex)
+        R22 = np.zeros(n2, complex)
+        R21m = np.zeros((n2, 4, n), complex)
+        R22m = np.zeros((n2, 4, n), complex)
+        c = ctypes.c_double
+        for it in range(n2):
+            if partials:
+                self.L.refprobe_rf_response_par_all(
+                    c(w[it]), c(-sigma), c(ray_p), n, _d(thk), _d(al), _d(be), _d(vp), _d(vs),
+                    _d(rho), rf_type, _d(R21[it:]), _d(R22[it:]), _d(R21m[it]), _d(R22m[it]))
+            else:
+                self.L.refprobe_rf_response(
+                    c(w[it]), c(-sigma), c(ray_p), n, _d(thk), _d(al), _d(be), _d(rho), rf_type,
+                    _d(R21[it:]), _d(R22[it:]))
+        return w, sigma, nft, R21, R22, R21m, R22m
+
+    @staticmethod
+    def _tail(spec, nft, nt, dt, sigma, t0):
+        tr = np.fft.irfft(spec, nft, axis=-1)[..., :nt]
+        return tr / dt * np.exp(sigma * (-t0 + np.arange(nt) * dt))
+
+    def kernel_all(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+                   method="freq", water=0.001, rf_type="P"):
+        irf, t0 = _rf_type(rf_type, time_shift)
+        w, sigma, nft, R21, R22, R21m, R22m = self.spectra(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf)
+        g = np.exp(-(w / 2 / gauss) ** 2) * np.exp(-1j * w * t0)
+        wa = (R21 * np.conj(R21)).real
+        fai = np.maximum(wa, water * wa.max())
+        rf = self._tail(np.conj(R21) * R22 * g / fai, nft, nt, dt, sigma, t0)
+        sq = R21**2
+        wa = (sq * np.conj(sq)).real
+        fai = np.maximum(wa, water * wa.max())
+        spec = (np.conj(sq) * g / fai)[:, None, None] * (R22m * R21[:, None, None] - R21m * R22[:, None, None])
+        kl = self._tail(np.moveaxis(spec, 0, -1), nft, nt, dt, sigma, t0)
+        return rf, np.ascontiguousarray(kl)
+
+    def forward(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+                method="freq", water=0.001, rf_type="P"):
+        irf, t0 = _rf_type(rf_type, time_shift)
+        w, sigma, nft, R21, R22, _, _ = self.spectra(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf,
+                                                     partials=False)
+        g = np.exp(-(w / 2 / gauss) ** 2) * np.exp(-1j * w * t0)
+        wa = (R21 * np.conj(R21)).real
+        fai = np.maximum(wa, water * wa.max())
+        return self._tail(np.conj(R21) * R22 * g / fai, nft, nt, dt, sigma, t0)

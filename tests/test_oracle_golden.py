@@ -1,0 +1,148 @@
+"""The CPU oracle (oracle/*.c + oracle/oracle.py) against the committed golden vectors.
+
+swd_reference / rf_core_reference were produced by the compiled reference itself,
+rf_trace_hybrid / plugin_hybrid by the reference's Python plugins on top of it
+(oracle/make_golden.py).  Tolerances are written next to each check.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def _cases(g, suffix):
+    return sorted({k.split("/")[0] for k in g.files if k.endswith(suffix)})
+
+
+def test_swd_oracle_matches_reference_fixtures(orc, golden):
+    g = golden["swd_reference"]
+    nfail = 0
+    for name in _cases(g, "/thk"):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], g[f"{name}/t"]
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        for wt in ("Rc", "Rg"):
+            if f"{name}/{wt}/c" not in g.files:
+                continue
+            c, flag = orc.libsurf.forward(thk, vp, vs, rho, t, wt)
+            assert flag == bool(g[f"{name}/{wt}/fwd_flag"]), (name, wt)
+            if wt == "Rc":      # float32-rounded roots: bit-exact, including the zeros after a failure
+                assert np.array_equal(c, g[f"{name}/{wt}/fwd_c"]), (name, wt)
+            elif flag:
+                assert rel(c, g[f"{name}/{wt}/fwd_c"]) < 1e-12
+            c, ka, kb, kr, kh, flag = orc.libsurf.adjoint_kernel(thk, vp, vs, rho, t, wt)
+            assert flag == bool(g[f"{name}/{wt}/flag"]), (name, wt)
+            if not flag:
+                nfail += 1
+                continue
+            assert rel(c, g[f"{name}/{wt}/c"]) < 1e-12
+            for arr, key in ((ka, "dcda"), (kb, "dcdb"), (kr, "dcdr"), (kh, "dcdh")):
+                assert rel(arr, g[f"{name}/{wt}/{key}"]) < 1e-9, (name, wt, key)  # observed <= 2e-11
+    assert nfail >= 3   # the fixtures hold root-search failures on purpose
+
+
+def test_survey_known_answers(orc):
+    """values observed from the reference on the param.yaml model."""
+    thk = np.array([6., 6, 13., 5, 10, 30, 0]); vs = np.array([3.2, 2.8, 3.46, 3.3, 3.9, 4.5, 4.7])
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    t = np.arange(5., 41.)
+    c, _ = orc.libsurf.forward(thk, vp, vs, rho, t, "Rc")
+    np.testing.assert_allclose(c[:6], [2.811252593994, 2.802712202072, 2.807658672333, 2.823679924011,
+                                       2.847761392593, 2.876952648163], rtol=0, atol=5e-13)
+    np.testing.assert_allclose(c[-3:], [3.850313663483, 3.867150306702, 3.882736682892], rtol=0, atol=5e-13)
+    g, _ = orc.libsurf.forward(thk, vp, vs, rho, t, "Rg")
+    np.testing.assert_allclose(g[:6], [2.892628565236, 2.811591938622, 2.733002076117, 2.668179646898,
+                                       2.623189957961, 2.597865924490], rtol=0, atol=5e-12)
+    _, _, kb, _, _, _ = orc.libsurf.adjoint_kernel(thk, vp, vs, rho, t, "Rc")
+    np.testing.assert_allclose(kb[0], [4.180354642102e-01, 3.241766678501e-01, 3.022816772550e-02,
+                                       7.717666538807e-05, 3.931093706971e-06, 7.434082888798e-09,
+                                       1.085835992717e-17], rtol=2e-12)
+    qa = np.full(7, 9999.)
+    rf = orc.librf.forward(thk, rho, vp, vs, qa, qa, 0.045, 125, 0.4, 1.5, 5.0, "freq", 0.001, "P")
+    np.testing.assert_allclose(rf[8:16], [1.750384485169e-04, 2.704993610476e-03, 2.454749574455e-02,
+                                          1.064170021474e-01, 2.228427016323e-01, 2.188586786966e-01,
+                                          9.057466370315e-02, 1.807677009266e-02], rtol=2e-12)
+
+
+def test_rf_core_oracle_matches_reference_fixtures(orc, golden):
+    """Per-frequency R21, R22 and the 4*nlayer partials against the compiled reference core."""
+    g = golden["rf_core_reference"]
+    L = orc.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    c = ctypes.c_double
+    for name in _cases(g, "/R21"):
+        thk, vs = np.ascontiguousarray(g[f"{name}/thk"]), np.ascontiguousarray(g[f"{name}/vs"])
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        vp, rho = np.ascontiguousarray(vp), np.ascontiguousarray(rho)
+        n = len(vs)
+        q = np.full(n, 9999.)
+        al = np.ascontiguousarray(vp * (1 + 1j / (2 * q) + 1 / (8 * q**2)))
+        be = np.ascontiguousarray(vs * (1 + 1j / (2 * q) + 1 / (8 * q**2)))
+        w, sigma = g[f"{name}/w"], float(g[f"{name}/sigma"])
+        idx = np.arange(len(w)) if n <= 30 else np.arange(0, len(w), 4)
+        for i in idx:
+            R21 = np.zeros(1, complex); R22 = np.zeros(1, complex)
+            R21m = np.zeros((4, n), complex); R22m = np.zeros((4, n), complex)
+            L.orcprobe_rf_response_par_all(c(w[i]), c(-sigma), c(float(g["ray_p"])), n, P(thk), P(al), P(be),
+                                           P(vp), P(vs), P(rho), 1, P(R21), P(R22), P(R21m), P(R22m))
+            assert rel(R21, g[f"{name}/R21"][i]) < 1e-10 and rel(R22, g[f"{name}/R22"][i]) < 1e-10
+            assert rel(R21m, g[f"{name}/R21_m"][i]) < 1e-9 and rel(R22m, g[f"{name}/R22_m"][i]) < 1e-9
+
+
+@pytest.mark.parametrize("case", ["yaml7_nt125", "grad30_nt512", "lvz30_0_nt512"])
+def test_rf_trace_oracle_matches_hybrid_fixtures(orc, golden, case):
+    g = golden["rf_trace_hybrid"]
+    thk, vs = g[f"{case}/thk"], g[f"{case}/vs"]
+    nt, dt = int(g[f"{case}/nt"]), float(g[f"{case}/dt"])
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    q = np.full(len(vs), 9999.)
+    args = (thk, rho, vp, vs, q, q, float(g["ray_p"]), nt, dt, float(g["gauss"]), float(g["time_shift"]),
+            "freq", float(g["water"]), "P")
+    rf, kl = orc.librf.kernel_all(*args)
+    assert rel(rf, g[f"{case}/rf"]) < 1e-10
+    assert rel(orc.librf.forward(*args), g[f"{case}/rf_forward"]) < 1e-10
+    assert rel(kl @ g[f"{case}/r"], g[f"{case}/kl_dot_r"]) < 1e-9
+    if f"{case}/kl" in g.files:
+        assert rel(kl, g[f"{case}/kl"]) < 1e-9
+    else:
+        assert rel(kl[:, :, g[f"{case}/kl_t_index"]], g[f"{case}/kl_sub"]) < 1e-9
+
+
+def test_irfft_restatement_matches_numpy(orc):
+    """fftpack.f90:23-42 semantics: c2r ignores Im(DC), Im(Nyquist); then 1/n."""
+    rng = np.random.default_rng(0)
+    L = orc.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    for n in (8, 128, 512, 2048):
+        spec = np.ascontiguousarray(rng.standard_normal(n // 2 + 1) + 1j * rng.standard_normal(n // 2 + 1))
+        out = np.zeros(n)
+        L.orc_irfft(spec.ctypes.data_as(dp), out.ctypes.data_as(dp), n)
+        assert rel(out, np.fft.irfft(spec, n)) < 1e-13
+
+
+@pytest.mark.parametrize("case", ["yaml7", "cfg1_10", "cfg2_30"])
+def test_plugin_oracle_matches_hybrid_fixtures(orc, golden, case):
+    """misfit_and_grad of SurfWD / ReceiverFunc / Joint_RF_SWD (reference Python on the reference core)."""
+    g = golden["plugin_hybrid"]
+    t, nt, dt = g[f"{case}/t"], int(g[f"{case}/nt"]), float(g[f"{case}/dt"])
+    swd = orc.SurfWD(tRc=t, tRg=t if bool(g[f"{case}/with_rg"]) else None)
+    rf = orc.ReceiverFunc(float(g["ray_p"]), nt, dt, float(g["gauss"]), float(g["time_shift"]),
+                          float(g["water"]), "P", "freq")
+    joint = orc.Joint_RF_SWD(1.0, 1.0, rf, swd)
+    dobs = g[f"{case}/dobs"]
+    joint.set_obsdata(dobs[:nt], dobs[nt:])
+    drf, dswd, flag = joint.forward(g[f"{case}/x0"])
+    assert flag and rel(np.concatenate((drf, dswd)), dobs) < 1e-10
+    for i, x in enumerate(g[f"{case}/x"]):
+        ms, gs, ds, fs = swd.misfit_and_grad(x)
+        mr, gr, dr = rf.misfit_and_grad(x)
+        mj, gj, dj, fj = joint.misfit_and_grad(x)
+        assert fs == bool(g[f"{case}/{i}/swd_flag"]) and fj == bool(g[f"{case}/{i}/joint_flag"])
+        for got, key in ((ms, "swd_misfit"), (gs, "swd_grad"), (ds, "swd_d"), (mr, "rf_misfit"),
+                         (gr, "rf_grad"), (dr, "rf_d"), (mj, "joint_misfit"), (gj, "joint_grad"),
+                         (dj, "joint_d")):
+            assert rel(got, g[f"{case}/{i}/{key}"]) < 1e-8, (case, i, key)  # observed <= 1e-10

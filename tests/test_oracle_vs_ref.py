@@ -1,0 +1,64 @@
+"""The C restatement against the reference itself (oracle/_ref, built from the reference's
+own sources by oracle/Makefile).  Skipped where oracle/_ref has not been built."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def test_swd_restatement_vs_compiled_reference_random_models(orc):
+    ref = O.ref_libsurf()
+    rng = np.random.default_rng(11)
+    t = np.linspace(5, 44, 40)
+    for i in range(40):
+        n = int(rng.integers(4, 40))
+        vs = 1.5 + 3.3 * rng.random(n)
+        if i % 2 == 0:
+            vs = np.sort(vs)
+        thk = 0.5 + 4 * rng.random(n); thk[-1] = 0
+        vp, rho, _, _ = O.empirical_relation(vs)
+        wt = "Rc" if i % 4 else "Rg"
+        c0, f0 = ref.forward(thk, vp, vs, rho, t, wt)
+        c1, f1 = orc.libsurf.forward(thk, vp, vs, rho, t, wt)
+        assert f0 == f1
+        if wt == "Rc":
+            assert np.array_equal(c0, c1)       # float32-rounded roots: bit-exact
+        r0 = ref.adjoint_kernel(thk, vp, vs, rho, t, wt)
+        r1 = orc.libsurf.adjoint_kernel(thk, vp, vs, rho, t, wt)
+        assert r0[5] == r1[5]
+        if r0[5]:
+            for a, b in zip(r1[:5], r0[:5]):
+                assert rel(a, b) < 1e-9
+
+
+def test_rf_routines_vs_compiled_reference(orc):
+    R = O.RefRFCore().L
+    L = orc.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    c = ctypes.c_double
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        al = np.array([5.0 + 2 * rng.random() + 3e-4j]); be = np.array([2.5 + 1.5 * rng.random() + 2e-4j])
+        rho, h = 2.0 + rng.random(), 0.5 + 5 * rng.random()
+        w, s, p = 6 * rng.random(), -0.08, 0.03 + 0.05 * rng.random()
+        for ip in range(5):
+            a = np.zeros(16, complex); b = np.zeros(16, complex)
+            R.refprobe_rf_matrix_a(c(w), c(s), c(p), c(h), P(al), P(be), c(rho), ip, P(a))
+            L.orcprobe_rf_matrix_a(c(w), c(s), c(p), c(h), P(al), P(be), c(rho), ip, P(b))
+            assert rel(b, a) < 1e-12
+            R.refprobe_rf_e_inv(c(w), c(s), c(p), P(al), P(be), c(rho), ip, P(a))
+            L.orcprobe_rf_e_inv(c(w), c(s), c(p), P(al), P(be), c(rho), ip, P(b))
+            A, B = a.reshape(4, 4).T, b.reshape(4, 4).T
+            if ip == 2:     # reference rows 1,3 use an unassigned variable (RFModule.f90:933,980)
+                assert np.all(A[1] == 0) and np.all(B[1] == 0) and np.all(A[3] == 0) and np.all(B[3] == 0)
+            else:
+                assert rel(B, A) < 1e-12
