@@ -1,0 +1,145 @@
+/*
+ * rfsurf.h -- C ABI of librfsurf_hip.so: the MI355X (gfx950) implementation of the
+ * misfit + gradient hot path of nqdu/RfSurfHmc.
+ *
+ * Every entry point names the reference interface it replaces (file:line under the
+ * reference tree).  Conventions:
+ *   - plain C, no exceptions; every call returns 0 on success or a negative rfs_status;
+ *     rfs_last_error() gives the message.  Nothing ever calls exit() (the reference's
+ *     bindings do: src/SWD/main.cpp:24, src/RF/main.cpp:40,162).
+ *   - re-entrant: all state lives in the rfs_ctx (the reference Fortran keeps module
+ *     globals and SAVEd variables, sregn96.f90:61-95, surfdisp96.f:423).
+ *   - batched: one call evaluates `nchain` independent models ("chains").
+ *   - arrays are contiguous, chain-major, float64 unless stated; "host" entry points take
+ *     host pointers and copy; "_dev" entry points take DEVICE pointers and enqueue on the
+ *     context's stream without synchronising.
+ *   - there is NO CPU fallback: if no gfx950 device is usable rfs_create fails.
+ */
+#ifndef RFSURF_H
+#define RFSURF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rfs_ctx rfs_ctx;
+
+typedef enum {
+    RFS_OK = 0,
+    RFS_ERR_ARG = -1,         /* bad argument (also: unsupported enum value) */
+    RFS_ERR_HIP = -2,         /* HIP runtime / rocFFT failure */
+    RFS_ERR_STATE = -3,       /* call out of order (e.g. joint eval before joint setup) */
+    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (Love, sphere, time-domain RF) */
+} rfs_status;
+
+/* wavetype codes of libsurf (src/SWD/main.cpp:17-24): strings "Rc","Rg","Lc","Lg" */
+enum { RFS_WAVE_RC = 0, RFS_WAVE_RG = 1, RFS_WAVE_LC = 2, RFS_WAVE_LG = 3 };
+/* rf_type codes (src/RF/main.cpp:28-41): "P"/"p" -> 1, "S"/"s" -> 2 */
+enum { RFS_RF_P = 1, RFS_RF_S = 2 };
+/* method codes (src/RF/main.cpp:44,52): "time" -> 0, anything else -> 1 (frequency domain) */
+enum { RFS_RF_TIME = 0, RFS_RF_FREQ = 1 };
+
+/* Receiver-function scalars: the arguments of librf.forward / kernel_all
+ * (src/RF/main.cpp:17-22, 140-146) and the keys of param.yaml's `rf:` block. */
+typedef struct {
+    double ray_p;       /* s/km */
+    int32_t nt;         /* samples returned; FFT length = next power of two (deconit.f90:1-13) */
+    double dt;          /* s */
+    double gauss;       /* Gaussian f0 */
+    double time_shift;  /* s; negated internally for rf_type S (main.cpp:35) */
+    double water;       /* water level */
+    int32_t rf_type;    /* RFS_RF_P / RFS_RF_S */
+    int32_t method;     /* RFS_RF_FREQ only */
+} rfs_rf_params;
+
+/* -------- lifetime ------------------------------------------------------------------ */
+/* device: HIP device ordinal (>= 0).  max_chains / max_layers size the workspaces. */
+int rfs_create(rfs_ctx** ctx, int device, int max_chains, int max_layers);
+void rfs_destroy(rfs_ctx* ctx);
+const char* rfs_last_error(const rfs_ctx* ctx);
+/* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) for all work. */
+int rfs_set_stream(rfs_ctx* ctx, void* hip_stream);
+/* Block until everything enqueued by this context has finished. */
+int rfs_synchronize(rfs_ctx* ctx);
+
+/* -------- B1: what libsurf exports (src/SWD/main.cpp:86-93) --------------------------- */
+/* libsurf.forward(thk,vp,vs,rho,period,wavetype,mode,sphere) -> (c[nper], bool)
+ * (src/SWD/main.cpp:14-59; _surfdisp surfdisp.cpp:62-109; _RayleighGroup :151-173).
+ * Model arrays [nchain][nlayer] are rounded to float32 first, as the binding does (main.cpp:9).
+ * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1). */
+int rfs_swd_forward(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
+                    const double* vs, const double* rho, int nper, const double* period,
+                    int wavetype, int mode, int sphere, double* c, int32_t* flag);
+/* libsurf.adjoint_kernel(...) -> (c, dcda, dcdb, dcdr, dcdh, bool)
+ * (src/SWD/main.cpp:61-82; _SurfKernel surfdisp.cpp:190-297; sregn96 / sregnpu
+ * sregn96.f90:1637-1888).  Kernel arrays: [nchain][nper][nlayer]. */
+int rfs_swd_kernel(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
+                   const double* vs, const double* rho, int nper, const double* period,
+                   int wavetype, int mode, int sphere, double* c, double* dcda, double* dcdb,
+                   double* dcdr, double* dcdh, int32_t* flag);
+
+/* -------- B1: what librf exports (src/RF/main.cpp:193-212) ---------------------------- */
+/* librf.forward(thk,rho,vp,vs,qa,qb,ray_p,nt,dt,gauss,time_shift,method,water,rf_type)
+ * -> rf[nt]   (src/RF/main.cpp:17-62 -> cal_rf_freq RFModule.f90:193-255).  rf: [nchain][nt] */
+int rfs_rf_forward(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* rho,
+                   const double* vp, const double* vs, const double* qa, const double* qb,
+                   const rfs_rf_params* par, double* rf);
+/* librf.kernel_all(...) -> (rf[nt], k[4][nlayer][nt]), parameter axis = [rho, vp, vs, thk]
+ * (src/RF/main.cpp:140-189 -> cal_rf_par_freq_all RFModule.f90:343-430).
+ * kl: [nchain][4][nlayer][nt] */
+int rfs_rf_kernel_all(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* rho,
+                      const double* vp, const double* vs, const double* qa, const double* qb,
+                      const rfs_rf_params* par, double* rf, double* kl);
+
+/* -------- B2: the model-plugin hot path ----------------------------------------------- */
+/* Configure what Joint_RF_SWD / ReceiverFunc / SurfWD hold (model/model_rf_swd_vs_thk.py:6-25,
+ * model/model_rf.py:5-30, model/model_surf.py:5-45): RF scalars (rf == NULL: SWD-only plugin),
+ * Rayleigh phase / group period lists (both 0: RF-only plugin), sigma1, sigma2, and the observed
+ * data dobs[nt + ntRc + ntRg] = [rf, Rc, Rg] (host pointer, copied). */
+int rfs_joint_setup(rfs_ctx* ctx, int nlayer, const rfs_rf_params* rf, int ntRc, const double* tRc,
+                    int ntRg, const double* tRg, double sigma1, double sigma2, const double* dobs);
+/* misfit_and_grad(x) for nchain models at once (model_rf_swd_vs_thk.py:66-86, model_rf.py:137-198,
+ * model_surf.py:155-228).  x: [nchain][2*nlayer] = [vs(0..n-1), thk(0..n-1)].
+ * Outputs: misfit[nchain], grad[nchain][2*nlayer], dsyn[nchain][ndata], flag[nchain]
+ * (flag 0 reproduces the plugins' failure returns: misfit 0, grad 0, dsyn = dobs for the joint
+ * plugin / zeros for the SWD-only plugin).  DEVICE pointers; asynchronous on the ctx stream. */
+int rfs_joint_misfit_grad_dev(rfs_ctx* ctx, int nchain, const double* x, double* misfit,
+                              double* grad, double* dsyn, int32_t* flag);
+/* Same with HOST pointers (copies in and out, synchronises). */
+int rfs_joint_misfit_grad(rfs_ctx* ctx, int nchain, const double* x, double* misfit, double* grad,
+                          double* dsyn, int32_t* flag);
+/* forward(x) of the plugins (model_rf_swd_vs_thk.py:27-49): synthetics only.
+ * Note the reference quirk kept here: every SWD block is computed at tRc (model_surf.py:114-130)
+ * when `quirk_trc_everywhere` != 0. */
+int rfs_joint_forward(rfs_ctx* ctx, int nchain, const double* x, int quirk_trc_everywhere,
+                      double* dsyn, int32_t* flag);
+
+/* -------- caller of the path: leapfrog trajectory (pyhmc/hmc.py:121-201) --------------- */
+/* One device-resident trajectory for nchain chains: given x0, p0 (DEVICE, [nchain][2n], p0 already
+ * drawn), per-chain dt and L, and bounds[2n][2], run the reference's leapfrog with mirror
+ * reflection (hmc.py:121-137, 164-183; hmcda.py:246-271).  Outputs (DEVICE): xnew, Ucur, Unew,
+ * Hcur, Hnew, dsyn_cur, dsyn_new [nchain][ndata], ok[nchain] (0 where the reference would return
+ * early: flag False or NaN in x / grad / dsyn). */
+int rfs_leapfrog_dev(rfs_ctx* ctx, int nchain, const double* x0, const double* p0, const double* dt,
+                     const int32_t* L, int32_t Lmax /* max over chains of L, known to the host that drew L */,
+                     const double* bounds, double* xnew, double* Ucur,
+                     double* Unew, double* Hcur, double* Hnew, double* dsyn_cur, double* dsyn_new,
+                     int32_t* ok);
+
+/* -------- introspection ---------------------------------------------------------------- */
+int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg of the current joint setup */
+/* Average HIP-event time (ms) of the kernels launched by the last rfs_joint_misfit_grad_dev call
+ * when timing was enabled with rfs_enable_timing(ctx, 1); index = rfs_kernel_id. */
+typedef enum {
+    RFS_K_PREP = 0, RFS_K_RF_PASS_A, RFS_K_RF_MID, RFS_K_RF_PASS_B, RFS_K_SWD_ROOTS, RFS_K_SWD_EIGEN,
+    RFS_K_COMBINE, RFS_K_COUNT
+} rfs_kernel_id;
+int rfs_enable_timing(rfs_ctx* ctx, int on);
+int rfs_last_kernel_ms(rfs_ctx* ctx, float* ms /* [RFS_K_COUNT] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFSURF_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of include/rfsurf.h (librfsurf_hip.so).  No fallback: a missing library or
+a missing GPU raises."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "librfsurf_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+RFS_WAVE = {"Rc": 0, "Rg": 1, "Lc": 2, "Lg": 3}
+K_NAMES = ["prep", "rf_pass_a", "rf_mid", "rf_pass_b", "swd_roots", "swd_eigen", "combine"]
+
+
+class RfParams(ctypes.Structure):
+    _fields_ = [("ray_p", ctypes.c_double), ("nt", ctypes.c_int32), ("dt", ctypes.c_double),
+                ("gauss", ctypes.c_double), ("time_shift", ctypes.c_double), ("water", ctypes.c_double),
+                ("rf_type", ctypes.c_int32), ("method", ctypes.c_int32)]
+
+
+class RfsError(RuntimeError):
+    pass
+
+
+# every symbol include/rfsurf.h declares: (restype, argtypes)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_d = ctypes.c_double
+SIGNATURES = {
+    "rfs_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i]),
+    "rfs_destroy": (None, [_vp]),
+    "rfs_last_error": (ctypes.c_char_p, [_vp]),
+    "rfs_set_stream": (_i, [_vp, _vp]),
+    "rfs_synchronize": (_i, [_vp]),
+    "rfs_swd_forward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "rfs_swd_kernel": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rfs_rf_forward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(RfParams), _vp]),
+    "rfs_rf_kernel_all": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(RfParams), _vp, _vp]),
+    "rfs_joint_setup": (_i, [_vp, _i, ctypes.POINTER(RfParams), _i, _vp, _i, _vp, _d, _d, _vp]),
+    "rfs_joint_misfit_grad_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rfs_joint_misfit_grad": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rfs_joint_forward": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "rfs_leapfrog_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp] + [_vp] * 8),
+    "rfs_ndata": (_i, [_vp]),
+    "rfs_enable_timing": (_i, [_vp, _i]),
+    "rfs_last_kernel_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
+}
+
+_LIB = None
+
+
+def load() -> ctypes.CDLL:
+    """Load librfsurf_hip.so and bind every declared symbol; raises if the library is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIBPATH):
+            raise RfsError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = ctypes.CDLL(LIBPATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def hptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """Owns one rfs_ctx (device buffers, rocFFT plans, streams)."""
+
+    def __init__(self, device: int = 0, max_chains: int = 8192, max_layers: int = 128):
+        self.L = load()
+        h = ctypes.c_void_p()
+        rc = self.L.rfs_create(ctypes.byref(h), int(device), int(max_chains), int(max_layers))
+        if rc != 0:
+            raise RfsError(f"rfs_create failed ({rc}): no usable gfx950 device {device}? (no CPU fallback)")
+        self.h = h
+        self.device = device
+        self.max_chains = max_chains
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise RfsError(f"librfsurf_hip error {rc}: {self.L.rfs_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rfs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _DEFAULT:
+        _DEFAULT[device] = Context(device=device, max_chains=1 << 20, max_layers=128)
+    return _DEFAULT[device]

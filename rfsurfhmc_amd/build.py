@@ -1,0 +1,34 @@
+"""Build librfsurf_hip.so for gfx950 with hipcc (in-tree, so the .so travels with gpurun)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librfsurf_hip.so")
+SOURCES = ["rfsurf_hip.hip"]
+HEADERS = ["cplx.hpp", "rf_math.hpp", "swd_math.hpp", "rfsurf_kernels.hpp", "../../include/rfsurf.h"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... -> rfsurfhmc_amd/librfsurf_hip.so"""
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           os.path.join(CSRC, "rfsurf_hip.hip"), "-o", LIB, "-L/opt/rocm/lib", "-lrocfft",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=False))

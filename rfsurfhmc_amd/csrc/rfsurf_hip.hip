@@ -1,0 +1,655 @@
+// librfsurf_hip.so -- C ABI (include/rfsurf.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared rfsurf_hip.hip -lrocfft  (see build.py)
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/rfsurf.h"
+#include "rfsurf_kernels.hpp"
+
+using namespace rfs;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct FftPlan { rocfft_plan plan = nullptr; rocfft_execution_info info = nullptr; void* work = nullptr; };
+
+}  // namespace
+
+struct rfs_ctx {
+    int device = 0, max_chains = 0, max_layers = 0;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::string err;
+    // joint configuration
+    bool configured = false;
+    int n = 0, mode = 0, ntRc = 0, ntRg = 0, ndata = 0;
+    bool has_rf = false, has_swd = false;
+    RfFreq f{};
+    double wt = 1.0;
+    Buf d_tRc, d_tRg, d_dobs;
+    // workspaces
+    Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag,
+        cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
+    // leapfrog state
+    Buf lx, lp, lU, lgrad, ldsyn, lflag;
+    std::map<std::tuple<int, size_t, int>, FftPlan> plans;
+    // timing
+    bool timing = false;
+    hipEvent_t tev[2 * RFS_K_COUNT] = {};
+    float last_ms[RFS_K_COUNT] = {};
+};
+
+namespace {
+
+bool g_rocfft_ready = false;
+
+int fail(rfs_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(c, RFS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+#define FFTCHK(c, call)                                                                         \
+    do {                                                                                        \
+        rocfft_status s_ = (call);                                                              \
+        if (s_ != rocfft_status_success)                                                        \
+            return fail(c, RFS_ERR_HIP, std::string(#call) + ": rocfft status " + std::to_string((int)s_)); \
+    } while (0)
+
+int ensure(rfs_ctx* c, Buf& b, size_t bytes) {
+    if (bytes <= b.cap) return RFS_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return RFS_OK;
+}
+#define ENSURE(c, b, bytes) do { int r_ = ensure(c, b, bytes); if (r_) return r_; } while (0)
+#define TRY(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
+
+int get_plan(rfs_ctx* c, int nft, size_t batch, int inverse, FftPlan** out) {
+    auto key = std::make_tuple(nft, batch, inverse);
+    auto it = c->plans.find(key);
+    if (it == c->plans.end()) {
+        if (!g_rocfft_ready) { FFTCHK(c, rocfft_setup()); g_rocfft_ready = true; }
+        FftPlan P;
+        rocfft_plan_description d = nullptr;
+        FFTCHK(c, rocfft_plan_description_create(&d));
+        size_t n2 = (size_t)nft / 2 + 1, one = 1;
+        if (inverse)
+            FFTCHK(c, rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved,
+                                                              rocfft_array_type_real, nullptr, nullptr, 1, &one, n2, 1, &one, (size_t)nft));
+        else
+            FFTCHK(c, rocfft_plan_description_set_data_layout(d, rocfft_array_type_real,
+                                                              rocfft_array_type_hermitian_interleaved, nullptr, nullptr, 1, &one, (size_t)nft, 1, &one, n2));
+        size_t len = (size_t)nft;
+        FFTCHK(c, rocfft_plan_create(&P.plan, rocfft_placement_notinplace,
+                                     inverse ? rocfft_transform_type_real_inverse : rocfft_transform_type_real_forward,
+                                     rocfft_precision_double, 1, &len, batch, d));
+        rocfft_plan_description_destroy(d);
+        FFTCHK(c, rocfft_execution_info_create(&P.info));
+        size_t wb = 0;
+        FFTCHK(c, rocfft_plan_get_work_buffer_size(P.plan, &wb));
+        if (wb) {
+            HIPCHK(c, hipMalloc(&P.work, wb));
+            FFTCHK(c, rocfft_execution_info_set_work_buffer(P.info, P.work, wb));
+        }
+        it = c->plans.emplace(key, P).first;
+    }
+    FFTCHK(c, rocfft_execution_info_set_stream(it->second.info, c->stream));
+    *out = &it->second;
+    return RFS_OK;
+}
+
+int run_fft(rfs_ctx* c, int nft, size_t batch, int inverse, void* in, void* out) {
+    FftPlan* P = nullptr;
+    TRY(get_plan(c, nft, batch, inverse, &P));
+    void* ib[1] = {in};
+    void* ob[1] = {out};
+    FFTCHK(c, rocfft_execute(P->plan, ib, ob, P->info));
+    return RFS_OK;
+}
+
+struct KTimer {   // brackets a group of launches with HIP events on the stream they run on
+    rfs_ctx* c; int id; hipStream_t s;
+    KTimer(rfs_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) { if (c->timing) hipEventRecord(c->tev[2 * id], s); }
+    ~KTimer() { if (c->timing) hipEventRecord(c->tev[2 * id + 1], s); }
+};
+
+int check_rf(rfs_ctx* c, const rfs_rf_params* p) {
+    if (!p) return fail(c, RFS_ERR_ARG, "rf params missing");
+    if (p->method == RFS_RF_TIME) return fail(c, RFS_ERR_UNSUPPORTED, "time-domain RF (iterative deconvolution) is out of scope");
+    if (p->rf_type != RFS_RF_P && p->rf_type != RFS_RF_S) return fail(c, RFS_ERR_ARG, "rf_type should be one of [P,p,S,s]");
+    if (p->nt < 2 || p->dt <= 0 || p->ray_p <= 0) return fail(c, RFS_ERR_ARG, "bad rf scalars");
+    return RFS_OK;
+}
+
+RfFreq make_freq(const rfs_rf_params& p, int fwd_order) {
+    RfFreq f{};
+    f.nft = rf_nextpow2(p.nt); f.n2 = f.nft / 2 + 1; f.n2p = (f.n2 + 15) / 16 * 16;
+    f.nt = p.nt; f.dt = p.dt; f.p = p.ray_p; f.f0 = p.gauss; f.water = p.water;
+    f.rf_type = p.rf_type;
+    f.t0 = (p.rf_type == RFS_RF_S) ? -p.time_shift : p.time_shift;     // src/RF/main.cpp:35
+    f.sigma = 1.0 / p.dt / f.nft * 4.;                                  // RFModule.f90:381
+    f.fwd_order = fwd_order;
+    return f;
+}
+
+int rf_block(const RfFreq& f) {
+    int m = f.n2 - 1;
+    if (m >= 256) return 256;
+    return m < 64 ? 64 : (m / 64) * 64;
+}
+int rf_chunks(const RfFreq& f) { int bs = rf_block(f); return (f.n2 - 1 + bs - 1) / bs; }
+int rf_nparts(const RfFreq& f) { return rf_chunks(f) * (rf_block(f) / 64) + 1; }
+
+// pass A (+ scratch) for nchain chains; lc must be ready
+int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch) {
+    ENSURE(c, c->RR, (size_t)nchain * 4 * f.n2p * sizeof(double));
+    if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.n2p * sizeof(double));
+    double* Rs = scratch ? c->Rs.as<double>() : nullptr;
+    dim3 grid(rf_chunks(f), nchain);
+    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f,
+                       c->lc.as<RfLayer>(), c->RR.as<double>(), Rs);
+    hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
+                       c->lc.as<RfLayer>(), c->RR.as<double>(), Rs);
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+// spectrum -> rf(t): writes dsyn (stride ndata) and optionally misfit/weighted residual
+int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dobs, int ndata, double* dsyn,
+               bool adjoint) {
+    ENSURE(c, c->wmax2, (size_t)nchain * sizeof(double));
+    ENSURE(c, c->spec, (size_t)nchain * f.n2 * sizeof(cplx));
+    ENSURE(c, c->tser, (size_t)nchain * f.nft * sizeof(double));
+    hipLaunchKernelGGL(k_rf_mid1, dim3(nchain), dim3(256), 0, c->stream, n, f, c->RR.as<double>(),
+                       c->wmax2.as<double>(), c->spec.as<cplx>());
+    HIPCHK(c, hipGetLastError());
+    TRY(run_fft(c, f.nft, nchain, 1, c->spec.p, c->tser.p));
+    double* wres = nullptr; double* mrf = nullptr;
+    if (adjoint) {
+        ENSURE(c, c->wres, (size_t)nchain * f.nft * sizeof(double));
+        ENSURE(c, c->mrf, (size_t)nchain * sizeof(double));
+        ENSURE(c, c->W, (size_t)nchain * f.n2 * sizeof(cplx));
+        wres = c->wres.as<double>(); mrf = c->mrf.as<double>();
+    }
+    hipLaunchKernelGGL(k_rf_mid2, dim3(nchain), dim3(256), 0, c->stream, f, c->tser.as<double>(), dobs, ndata,
+                       dsyn, mrf, wres);
+    HIPCHK(c, hipGetLastError());
+    if (adjoint) TRY(run_fft(c, f.nft, nchain, 0, c->wres.p, c->W.p));
+    return RFS_OK;
+}
+
+int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f) {
+    int npart = rf_nparts(f);
+    ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
+    dim3 grid(rf_chunks(f), nchain);
+    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, c->lc.as<RfLayer>(),
+                       c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
+                       c->PG.as<double>());
+    hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
+                       c->lc.as<RfLayer>(), c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(),
+                       c->wmax2.as<double>(), npart, c->PG.as<double>());
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+SwdSeqs make_seqs(int ntRc, const double* d_tRc, int ntRg, const double* d_tRg, bool group_passes) {
+    SwdSeqs Q{};
+    int off = 0;
+    if (ntRc > 0) { Q.s[Q.nseq++] = SwdSeq{d_tRc, ntRc, 1.0, off}; off += ntRc; }
+    if (ntRg > 0) {
+        Q.s[Q.nseq++] = SwdSeq{d_tRg, ntRg, 1.0, off}; off += ntRg;
+        if (group_passes) {
+            Q.s[Q.nseq++] = SwdSeq{d_tRg, ntRg, 1.0 + 0.05, off}; off += ntRg;   // surfdisp.cpp:236
+            Q.s[Q.nseq++] = SwdSeq{d_tRg, ntRg, 1.0 - 0.05, off}; off += ntRg;   // surfdisp.cpp:237
+        }
+    }
+    Q.nper_total = off;
+    return Q;
+}
+
+SwdRows make_rows(int ntRc, int ntRg, const double* d_tRg) {
+    SwdRows R{};
+    R.ntRc = ntRc; R.ntRg = ntRg; R.off_rg = ntRc; R.off_rg1 = ntRc + ntRg; R.off_rg2 = ntRc + 2 * ntRg;
+    R.tRg = d_tRg;
+    return R;
+}
+
+// root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
+int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, bool kernels) {
+    ENSURE(c, c->croot, (size_t)Q.nper_total * nchain * sizeof(double));
+    ENSURE(c, c->sflag, (size_t)4 * nchain * sizeof(int));
+    {
+        KTimer t(c, RFS_K_SWD_ROOTS, s);
+        int nthreads = Q.nseq * nchain;
+        hipLaunchKernelGGL(k_swd_roots, dim3((nthreads + 63) / 64), dim3(64), 0, s, nchain, n, Q,
+                           c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>());
+        HIPCHK(c, hipGetLastError());
+    }
+    if (kernels) {
+        size_t nitem = (size_t)Q.nper_total * nchain;
+        ENSURE(c, c->cds, nitem * 6 * n * sizeof(double));
+        ENSURE(c, c->krn, nitem * 4 * n * sizeof(double));
+        ENSURE(c, c->ugr, nitem * sizeof(double));
+        KTimer t(c, RFS_K_SWD_EIGEN, s);
+        hipLaunchKernelGGL(k_swd_eigen, dim3((unsigned)((nitem + 63) / 64)), dim3(64), 0, s, nchain, n, Q,
+                           c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>(), c->cds.as<double>(),
+                           c->krn.as<double>(), c->ugr.as<double>());
+        HIPCHK(c, hipGetLastError());
+    }
+    return RFS_OK;
+}
+
+int check_batch(rfs_ctx* c, int nchain, int nlayer) {
+    if (!c) return RFS_ERR_ARG;
+    if (nchain < 1 || nchain > c->max_chains) return fail(c, RFS_ERR_ARG, "nchain outside [1, max_chains]");
+    if (nlayer < 2 || nlayer > c->max_layers || nlayer > MAXL) return fail(c, RFS_ERR_ARG, "nlayer outside [2, min(max_layers,128)]");
+    return RFS_OK;
+}
+
+int upload(rfs_ctx* c, Buf& b, const void* host, size_t bytes) {
+    ENSURE(c, b, bytes);
+    HIPCHK(c, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return RFS_OK;
+}
+
+// the whole misfit+gradient evaluation on device pointers
+int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn, int32_t* flag) {
+    const int n = c->n;
+    HIPCHK(c, hipSetDevice(c->device));
+    ENSURE(c, c->cr, (size_t)nchain * 2 * n * sizeof(double));
+    if (c->has_rf) ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
+    if (c->has_swd) ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float));
+    {
+        KTimer t(c, RFS_K_PREP, c->stream);
+        int nth = nchain * n;
+        hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, x,
+                           (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd,
+                           c->mdl.as<float>());
+        HIPCHK(c, hipGetLastError());
+    }
+    SwdSeqs Q = make_seqs(c->ntRc, c->d_tRc.as<double>(), c->ntRg, c->d_tRg.as<double>(), true);
+    if (c->has_swd) {           // the latency-bound root search runs beside the RF kernels
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        TRY(launch_swd(c, c->stream2, nchain, n, Q, true));
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    }
+    if (c->has_rf) {
+        { KTimer t(c, RFS_K_RF_PASS_A, c->stream); TRY(launch_passA(c, nchain, n, c->f, true)); }
+        { KTimer t(c, RFS_K_RF_MID, c->stream);
+          TRY(launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true)); }
+        { KTimer t(c, RFS_K_RF_PASS_B, c->stream); TRY(launch_passB(c, nchain, n, c->f)); }
+    }
+    if (c->has_swd) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    {
+        KTimer t(c, RFS_K_COMBINE, c->stream);
+        SwdRows R = make_rows(c->ntRc, c->ntRg, c->d_tRg.as<double>());
+        int nt = c->has_rf ? c->f.nt : 0;
+        hipLaunchKernelGGL(k_joint_combine, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n, c->mode,
+                           nt, R, c->has_rf ? rf_nparts(c->f) : 0, c->wt, c->PG.as<double>(), c->mrf.as<double>(),
+                           c->cr.as<double>(), c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(),
+                           c->sflag.as<int>(), Q.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag);
+        HIPCHK(c, hipGetLastError());
+    }
+    return RFS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
+    if (!out || max_chains < 1 || max_layers < 2) return RFS_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return RFS_ERR_HIP;
+    rfs_ctx* c = new rfs_ctx();
+    c->device = device; c->max_chains = max_chains; c->max_layers = max_layers;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 2 * RFS_K_COUNT; i++) ok = hipEventCreate(&c->tev[i]) == hipSuccess;
+    if (!ok) { delete c; return RFS_ERR_HIP; }
+    c->own_stream = true;
+    *out = c;
+    return RFS_OK;
+}
+
+void rfs_destroy(rfs_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    Buf* bufs[] = {&c->d_tRc, &c->d_tRg, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
+                   &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
+                   &c->croot, &c->sflag, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
+                   &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
+                   &c->ldsyn, &c->lflag};
+    for (Buf* b : bufs) if (b->p) hipFree(b->p);
+    for (auto& kv : c->plans) {
+        if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
+        if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
+        if (kv.second.work) hipFree(kv.second.work);
+    }
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    for (auto e : c->tev) if (e) hipEventDestroy(e);
+    delete c;
+}
+
+const char* rfs_last_error(const rfs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rfs_set_stream(rfs_ctx* c, void* s) {
+    if (!c) return RFS_ERR_ARG;
+    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)s; c->own_stream = false;
+    return RFS_OK;
+}
+
+int rfs_synchronize(rfs_ctx* c) {
+    if (!c) return RFS_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RFS_OK;
+}
+
+int rfs_enable_timing(rfs_ctx* c, int on) { if (!c) return RFS_ERR_ARG; c->timing = on != 0; return RFS_OK; }
+
+int rfs_last_kernel_ms(rfs_ctx* c, float* ms) {
+    if (!c || !ms) return RFS_ERR_ARG;
+    TRY(rfs_synchronize(c));
+    for (int i = 0; i < RFS_K_COUNT; i++) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, c->tev[2 * i], c->tev[2 * i + 1]) != hipSuccess) t = -1.f;
+        ms[i] = t;
+    }
+    return RFS_OK;
+}
+
+int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
+
+// ---------------------------------------------------------------- B1 / libsurf
+static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* vp, const double* vs,
+                  const double* rho, int nper, const double* period, int wavetype, int mode, int sphere,
+                  bool kernels, double* cout, double* dcda, double* dcdb, double* dcdr, double* dcdh, int32_t* flag) {
+    TRY(check_batch(c, nchain, nlayer));
+    if (wavetype == RFS_WAVE_LC || wavetype == RFS_WAVE_LG) return fail(c, RFS_ERR_UNSUPPORTED, "Love waves are out of scope");
+    if (wavetype != RFS_WAVE_RC && wavetype != RFS_WAVE_RG) return fail(c, RFS_ERR_ARG, "wavetype should be one of [Rc,Rg,Lc,Lg]");
+    if (mode != 0) return fail(c, RFS_ERR_UNSUPPORTED, "higher modes are out of scope");
+    if (sphere) return fail(c, RFS_ERR_UNSUPPORTED, "earth flattening is out of scope");
+    if (nper < 1 || !period || !thk || !vp || !vs || !rho || !cout || !flag) return fail(c, RFS_ERR_ARG, "null/empty argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = nlayer;
+    size_t mb = (size_t)nchain * n * sizeof(double);
+    TRY(upload(c, c->b1a, thk, mb)); TRY(upload(c, c->b1b, vp, mb));
+    TRY(upload(c, c->b1c, vs, mb)); TRY(upload(c, c->b1d, rho, mb));
+    TRY(upload(c, c->bt, period, (size_t)nper * sizeof(double)));
+    ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float));
+    int nth = nchain * n;
+    hipLaunchKernelGGL(k_prep_swd_b1, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->b1a.as<double>(),
+                       c->b1b.as<double>(), c->b1c.as<double>(), c->b1d.as<double>(), c->mdl.as<float>());
+    bool rg = wavetype == RFS_WAVE_RG;
+    // forward "Rg" = _RayleighGroup (surfdisp.cpp:151-173): roots at T only, U from sregn96
+    SwdSeqs Q = rg ? make_seqs(0, nullptr, nper, c->bt.as<double>(), kernels) : make_seqs(nper, c->bt.as<double>(), 0, nullptr, false);
+    TRY(launch_swd(c, c->stream, nchain, n, Q, kernels || rg));
+    SwdRows R = rg ? make_rows(0, nper, c->bt.as<double>()) : make_rows(nper, 0, nullptr);
+    size_t cb = (size_t)nchain * nper * sizeof(double), kb = cb * n;
+    ENSURE(c, c->b1e, cb);
+    double* dk[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (kernels) {
+        ENSURE(c, c->klbuf, 4 * kb);
+        for (int i = 0; i < 4; i++) dk[i] = c->klbuf.as<double>() + (size_t)i * nchain * nper * n;
+    }
+    int ng = nchain * nper;
+    hipLaunchKernelGGL(k_swd_export, dim3((ng + 127) / 128), dim3(128), 0, c->stream, nchain, n, R, 0, nper,
+                       c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->b1e.as<double>(),
+                       dk[0], dk[1], dk[2], dk[3]);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> sf((size_t)Q.nseq * nchain);
+    HIPCHK(c, hipMemcpy(sf.data(), c->sflag.p, sf.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cout, c->b1e.p, cb, hipMemcpyDeviceToHost));
+    if (kernels) {
+        HIPCHK(c, hipMemcpy(dcda, dk[0], kb, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(dcdb, dk[1], kb, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dcdr, dk[2], kb, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(dcdh, dk[3], kb, hipMemcpyDeviceToHost));
+    }
+    for (int ch = 0; ch < nchain; ch++) {
+        int ok = 1;
+        for (int s = 0; s < Q.nseq; s++) ok = ok && sf[(size_t)s * nchain + ch];
+        flag[ch] = ok;
+        if (!ok && rg) for (int k = 0; k < nper; k++) cout[(size_t)ch * nper + k] = 0.0;
+    }
+    return RFS_OK;
+}
+
+int rfs_swd_forward(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* vp, const double* vs,
+                    const double* rho, int nper, const double* period, int wavetype, int mode, int sphere,
+                    double* cout, int32_t* flag) {
+    return swd_b1(c, nchain, nlayer, thk, vp, vs, rho, nper, period, wavetype, mode, sphere, false, cout,
+                  nullptr, nullptr, nullptr, nullptr, flag);
+}
+
+int rfs_swd_kernel(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* vp, const double* vs,
+                   const double* rho, int nper, const double* period, int wavetype, int mode, int sphere,
+                   double* cout, double* dcda, double* dcdb, double* dcdr, double* dcdh, int32_t* flag) {
+    if (!dcda || !dcdb || !dcdr || !dcdh) return fail(c, RFS_ERR_ARG, "null kernel output");
+    return swd_b1(c, nchain, nlayer, thk, vp, vs, rho, nper, period, wavetype, mode, sphere, true, cout,
+                  dcda, dcdb, dcdr, dcdh, flag);
+}
+
+// ---------------------------------------------------------------- B1 / librf
+static int rf_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* rho, const double* vp,
+                 const double* vs, const double* qa, const double* qb, const rfs_rf_params* par, double* rf, double* kl) {
+    TRY(check_batch(c, nchain, nlayer));
+    TRY(check_rf(c, par));
+    if (!thk || !rho || !vp || !vs || !qa || !qb || !rf) return fail(c, RFS_ERR_ARG, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = nlayer;
+    RfFreq f = make_freq(*par, kl ? 0 : 1);
+    size_t mb = (size_t)nchain * n * sizeof(double);
+    TRY(upload(c, c->b1a, thk, mb)); TRY(upload(c, c->b1b, rho, mb)); TRY(upload(c, c->b1c, vp, mb));
+    TRY(upload(c, c->b1d, vs, mb)); TRY(upload(c, c->b1e, qa, mb)); TRY(upload(c, c->b1f, qb, mb));
+    ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
+    int nth = nchain * n;
+    hipLaunchKernelGGL(k_prep_rf_b1, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->b1a.as<double>(),
+                       c->b1b.as<double>(), c->b1c.as<double>(), c->b1d.as<double>(), c->b1e.as<double>(),
+                       c->b1f.as<double>(), f.p, c->lc.as<RfLayer>());
+    TRY(launch_passA(c, nchain, n, f, kl != nullptr));
+    ENSURE(c, c->b1g, (size_t)nchain * f.nt * sizeof(double));
+    TRY(launch_mid(c, nchain, n, f, nullptr, f.nt, c->b1g.as<double>(), false));
+    if (kl) {
+        size_t ntr = (size_t)nchain * 4 * n;
+        ENSURE(c, c->specp, ntr * f.n2 * sizeof(cplx));
+        ENSURE(c, c->tserp, ntr * f.nft * sizeof(double));
+        ENSURE(c, c->klbuf, ntr * f.nt * sizeof(double));
+        dim3 grid(rf_chunks(f), nchain);
+        hipLaunchKernelGGL(k_rf_partial_spectra<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f,
+                           c->lc.as<RfLayer>(), c->RR.as<double>(), c->Rs.as<double>(), c->wmax2.as<double>(),
+                           c->specp.as<cplx>());
+        hipLaunchKernelGGL(k_rf_partial_spectra<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
+                           c->lc.as<RfLayer>(), c->RR.as<double>(), c->Rs.as<double>(), c->wmax2.as<double>(),
+                           c->specp.as<cplx>());
+        HIPCHK(c, hipGetLastError());
+        TRY(run_fft(c, f.nft, ntr, 1, c->specp.p, c->tserp.p));
+        size_t tot = ntr * f.nt;
+        hipLaunchKernelGGL(k_rf_scale_kl, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, ntr, f,
+                           c->tserp.as<double>(), c->klbuf.as<double>());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(rf, c->b1g.p, (size_t)nchain * f.nt * sizeof(double), hipMemcpyDeviceToHost));
+    if (kl) HIPCHK(c, hipMemcpy(kl, c->klbuf.p, (size_t)nchain * 4 * n * f.nt * sizeof(double), hipMemcpyDeviceToHost));
+    return RFS_OK;
+}
+
+int rfs_rf_forward(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* rho, const double* vp,
+                   const double* vs, const double* qa, const double* qb, const rfs_rf_params* par, double* rf) {
+    return rf_b1(c, nchain, nlayer, thk, rho, vp, vs, qa, qb, par, rf, nullptr);
+}
+
+int rfs_rf_kernel_all(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* rho, const double* vp,
+                      const double* vs, const double* qa, const double* qb, const rfs_rf_params* par, double* rf,
+                      double* kl) {
+    if (!kl) return fail(c, RFS_ERR_ARG, "null kernel output");
+    return rf_b1(c, nchain, nlayer, thk, rho, vp, vs, qa, qb, par, rf, kl);
+}
+
+// ---------------------------------------------------------------- B2 / plugins
+int rfs_joint_setup(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, int ntRc, const double* tRc, int ntRg,
+                    const double* tRg, double sigma1, double sigma2, const double* dobs) {
+    if (!c) return RFS_ERR_ARG;
+    c->configured = false;
+    if (nlayer < 2 || nlayer > c->max_layers || nlayer > MAXL) return fail(c, RFS_ERR_ARG, "nlayer outside [2, min(max_layers,128)]");
+    if (ntRc < 0 || ntRg < 0 || (ntRc > 0 && !tRc) || (ntRg > 0 && !tRg)) return fail(c, RFS_ERR_ARG, "bad period lists");
+    if (!rf && ntRc + ntRg == 0) return fail(c, RFS_ERR_ARG, "neither RF nor SWD data configured");
+    if (rf) TRY(check_rf(c, rf));
+    HIPCHK(c, hipSetDevice(c->device));
+    c->n = nlayer; c->has_rf = rf != nullptr; c->has_swd = ntRc + ntRg > 0;
+    c->mode = (c->has_rf && c->has_swd) ? 0 : (c->has_rf ? 1 : 2);
+    c->ntRc = ntRc; c->ntRg = ntRg;
+    int nt = 0;
+    if (rf) { c->f = make_freq(*rf, 0); nt = rf->nt; }
+    c->ndata = nt + ntRc + ntRg;
+    // wt = (sigma1/sigma2)^2 n1/n2, model_rf_swd_vs_thk.py:79
+    c->wt = c->has_swd && c->has_rf ? (sigma1 / sigma2) * (sigma1 / sigma2) * nt / (double)(ntRc + ntRg) : 1.0;
+    if (ntRc) TRY(upload(c, c->d_tRc, tRc, (size_t)ntRc * sizeof(double)));
+    if (ntRg) TRY(upload(c, c->d_tRg, tRg, (size_t)ntRg * sizeof(double)));
+    ENSURE(c, c->d_dobs, (size_t)c->ndata * sizeof(double));
+    if (dobs) HIPCHK(c, hipMemcpyAsync(c->d_dobs.p, dobs, (size_t)c->ndata * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(c->d_dobs.p, 0, (size_t)c->ndata * sizeof(double), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // dummies so that unused pointers are never null-dereferenced in combine
+    ENSURE(c, c->PG, 8); ENSURE(c, c->mrf, 8); ENSURE(c, c->krn, 8); ENSURE(c, c->croot, 8); ENSURE(c, c->ugr, 8);
+    ENSURE(c, c->sflag, 16);
+    c->configured = true;
+    return RFS_OK;
+}
+
+int rfs_joint_misfit_grad_dev(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn,
+                              int32_t* flag) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (!x || !misfit || !grad || !flag) return fail(c, RFS_ERR_ARG, "null argument");
+    return joint_eval(c, nchain, x, misfit, grad, dsyn, flag);
+}
+
+int rfs_joint_misfit_grad(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn,
+                          int32_t* flag) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (!x || !misfit || !grad || !flag) return fail(c, RFS_ERR_ARG, "null argument");
+    const int n = c->n;
+    TRY(upload(c, c->x, x, (size_t)nchain * 2 * n * sizeof(double)));
+    ENSURE(c, c->misfit, (size_t)nchain * sizeof(double)); ENSURE(c, c->grad, (size_t)nchain * 2 * n * sizeof(double));
+    ENSURE(c, c->dsyn, (size_t)nchain * c->ndata * sizeof(double)); ENSURE(c, c->flag, (size_t)nchain * sizeof(int));
+    TRY(joint_eval(c, nchain, c->x.as<double>(), c->misfit.as<double>(), c->grad.as<double>(), c->dsyn.as<double>(),
+                   c->flag.as<int>()));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(misfit, c->misfit.p, (size_t)nchain * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(grad, c->grad.p, (size_t)nchain * 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (dsyn) HIPCHK(c, hipMemcpy(dsyn, c->dsyn.p, (size_t)nchain * c->ndata * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(flag, c->flag.p, (size_t)nchain * sizeof(int), hipMemcpyDeviceToHost));
+    return RFS_OK;
+}
+
+int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double* dsyn, int32_t* flag) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (!x || !dsyn || !flag) return fail(c, RFS_ERR_ARG, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->n;
+    TRY(upload(c, c->x, x, (size_t)nchain * 2 * n * sizeof(double)));
+    ENSURE(c, c->dsyn, (size_t)nchain * c->ndata * sizeof(double)); ENSURE(c, c->flag, (size_t)nchain * sizeof(int));
+    ENSURE(c, c->cr, (size_t)nchain * 2 * n * sizeof(double));
+    if (c->has_rf) ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
+    if (c->has_swd) ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float));
+    int nth = nchain * n;
+    hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->x.as<double>(),
+                       (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd, c->mdl.as<float>());
+    int nt = c->has_rf ? c->f.nt : 0;
+    if (c->has_rf) {
+        RfFreq f = c->f; f.fwd_order = 1;
+        TRY(launch_passA(c, nchain, n, f, false));
+        TRY(launch_mid(c, nchain, n, f, nullptr, c->ndata, c->dsyn.as<double>(), false));
+    }
+    if (c->has_swd) {
+        // model_surf.py:114-130 computes every block at tRc; quirk != 0 keeps that
+        const double* tg = (quirk && c->ntRc > 0) ? c->d_tRc.as<double>() : c->d_tRg.as<double>();
+        int ntg = (quirk && c->ntRc > 0) ? (c->ntRg < c->ntRc ? c->ntRg : c->ntRc) : c->ntRg;
+        if (quirk && c->ntRc > 0 && c->ntRg > 0 && c->ntRg != c->ntRc)
+            return fail(c, RFS_ERR_UNSUPPORTED, "forward quirk needs len(tRg) == len(tRc), as the reference does");
+        SwdSeqs Q = make_seqs(c->ntRc, c->d_tRc.as<double>(), ntg, tg, false);
+        TRY(launch_swd(c, c->stream, nchain, n, Q, ntg > 0));
+        SwdRows R = make_rows(c->ntRc, ntg, tg);
+        hipLaunchKernelGGL(k_swd_forward_out, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, nt, R,
+                           c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(), Q.nseq,
+                           c->dsyn.as<double>(), c->flag.as<int>());
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->flag.p, 0, (size_t)nchain * sizeof(int), c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dsyn, c->dsyn.p, (size_t)nchain * c->ndata * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(flag, c->flag.p, (size_t)nchain * sizeof(int), hipMemcpyDeviceToHost));
+    if (!c->has_swd) for (int i = 0; i < nchain; i++) flag[i] = 1;
+    return RFS_OK;
+}
+
+// ---------------------------------------------------------------- leapfrog
+int rfs_leapfrog_dev(rfs_ctx* c, int nchain, const double* x0, const double* p0, const double* dt, const int32_t* L,
+                     int32_t Lmax, const double* bounds, double* xnew, double* Ucur, double* Unew, double* Hcur,
+                     double* Hnew, double* dsyn_cur, double* dsyn_new, int32_t* ok) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (!x0 || !p0 || !dt || !L || !bounds || !xnew || !Ucur || !Unew || !Hcur || !Hnew || !dsyn_cur || !dsyn_new || !ok || Lmax < 1)
+        return fail(c, RFS_ERR_ARG, "null argument");
+    const int n = c->n, nx = 2 * n, nd = c->ndata;
+    ENSURE(c, c->lx, (size_t)nchain * nx * sizeof(double)); ENSURE(c, c->lp, (size_t)nchain * nx * sizeof(double));
+    ENSURE(c, c->lU, (size_t)nchain * sizeof(double)); ENSURE(c, c->lgrad, (size_t)nchain * nx * sizeof(double));
+    ENSURE(c, c->ldsyn, (size_t)nchain * nd * sizeof(double)); ENSURE(c, c->lflag, (size_t)nchain * sizeof(int));
+    double *x = c->lx.as<double>(), *p = c->lp.as<double>(), *U = c->lU.as<double>(), *g = c->lgrad.as<double>(),
+           *d = c->ldsyn.as<double>();
+    int* fl = c->lflag.as<int>();
+    TRY(joint_eval(c, nchain, x0, U, g, d, fl));
+    hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, x0, p0, dt, U, g, d, fl, x, p,
+                       Ucur, Hcur, Unew, dsyn_cur, dsyn_new, ok);
+    // failed chains keep xnew = x0, Hnew = +inf (reference returns (xcur, inf, dobs, False))
+    HIPCHK(c, hipMemcpyAsync(xnew, x0, (size_t)nchain * nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    int nth = nchain * nx;
+    for (int step = 0; step < Lmax; step++) {
+        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, step, dt, L, bounds, x, p, ok);
+        TRY(joint_eval(c, nchain, x, U, g, d, fl));
+        hipLaunchKernelGGL(k_leap_kick, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, step, dt, L, x, U, g, d, fl, p,
+                           Unew, Hnew, dsyn_new, xnew, ok);
+    }
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+}  // extern "C"

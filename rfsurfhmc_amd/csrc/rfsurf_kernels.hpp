@@ -1,0 +1,713 @@
+// HIP kernels (gfx950, wave64) for the RF + SWD misfit/gradient hot path.
+// Lane-level math lives in rf_math.hpp / swd_math.hpp; the kernels below only map
+// (chain, frequency | period) work items onto wavefronts, move data and reduce.
+//
+// Data layout in HBM (all f64 unless noted; nchain = chains of the current call):
+//   x        [chain][2n]                 model vectors (vs, thk)                     (input)
+//   lc       [chain][n] RfLayer          frequency-independent RF layer constants
+//   cr       [chain][2][n]               chain-rule factors dadb, drda*dadb
+//   mdl      [4][n][chain] f32           SWD model (thk, vp, vs, rho) rounded to float32,
+//                                        chain-minor so that "lane = chain" loads coalesce
+//   RR       [chain][4][n2p]             Re/Im R21, Re/Im R22 per frequency
+//   Rs       [chain][n-1][8][n2p]        pass-A row vectors r_j (scratch, frequency-minor)
+//   spec     [chain][n2] complex         RF spectrum -> rocFFT c2r -> tser [chain][nft]
+//   wres     [chain][nft]                weighted residual -> rocFFT r2c -> W [chain][n2] complex
+//   PG       [chain][npart][4][n]        per-wave partial gradient sums (deterministic reduce)
+//   croot    [seq][nper][chain]          phase velocities per root-search sequence
+//   cds      [n][6][item]                compound up-sweep scratch of the eigenfunction pass
+//   krn      [item-class][4][n][chain]   scaled kernels d(c)/d(alpha,beta,rho,interface)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rf_math.hpp"
+#include "swd_math.hpp"
+
+namespace rfs {
+
+constexpr int MAXL = 128;   // layers per model (two register slots in the pass-B reduction)
+
+struct RfFreq {             // frequency axis + RF scalars shared by the RF kernels
+    double dt, sigma, p, f0, t0, water;
+    int nft, n2, n2p, nt, rf_type, fwd_order;
+};
+
+__device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
+    // RFModule.f90:384  w = 1/nft/dt*(it-1)*2*pi   (cal_rf_freq :231 uses 1/dt/nft order)
+    if (f.fwd_order) return (1.0 / f.dt / f.nft) * k * 2 * RF_PI32;
+    return 1.0 / f.nft / f.dt * k * 2.0 * RF_PI32;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// K_PREP: one thread per (chain, layer).  model_rf.py:52-77 / model_surf.py:47-79 empirical
+// relations, RfLayer constants, float32 SWD model.
+// ---------------------------------------------------------------------------------------
+__global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, int has_rf, double ray_p,
+                             RfLayer* __restrict__ lc, double* __restrict__ cr, int has_swd,
+                             float* __restrict__ mdl)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchain * n) return;
+    int chain = g / n, j = g - chain * n;
+    double vs = x[(size_t)chain * 2 * n + j], thk = x[(size_t)chain * 2 * n + n + j];
+    double vp = 0.9409 + 2.0947 * vs - 0.8206 * (vs * vs) + 0.2683 * (vs * vs * vs) - 0.0251 * (vs * vs * vs * vs);
+    double vp2 = vp * vp;
+    double rho = 1.6612 * vp - 0.4721 * vp2 + 0.0671 * (vp2 * vp) - 0.0043 * (vp2 * vp2) + 0.000106 * (vp2 * vp2 * vp);
+    double drda = 1.6612 - 0.4721 * 2 * vp + 0.0671 * 3 * vp2 - 0.0043 * 4 * (vp2 * vp) + 0.000106 * 5 * (vp2 * vp2);
+    double dadb = 2.0947 - 0.8206 * 2 * vs + 0.2683 * 3 * (vs * vs) - 0.0251 * 4 * (vs * vs * vs);
+    cr[((size_t)chain * 2 + 0) * n + j] = dadb;
+    cr[((size_t)chain * 2 + 1) * n + j] = drda * dadb;
+    if (has_rf) rf_make_layer(lc[(size_t)chain * n + j], thk, rho, vp, vs, 9999.0, 9999.0, ray_p);
+    if (has_swd) {
+        size_t s = (size_t)n * nchain;
+        mdl[0 * s + (size_t)j * nchain + chain] = (float)thk;
+        mdl[1 * s + (size_t)j * nchain + chain] = (float)vp;
+        mdl[2 * s + (size_t)j * nchain + chain] = (float)vs;
+        mdl[3 * s + (size_t)j * nchain + chain] = (float)rho;
+    }
+}
+
+// B1 variants: explicit thk, rho, vp, vs (, qa, qb) arrays [chain][n]
+__global__ void k_prep_rf_b1(int nchain, int n, const double* thk, const double* rho, const double* vp,
+                             const double* vs, const double* qa, const double* qb, double ray_p,
+                             RfLayer* __restrict__ lc)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchain * n) return;
+    rf_make_layer(lc[g], thk[g], rho[g], vp[g], vs[g], qa[g], qb[g], ray_p);
+}
+
+__global__ void k_prep_swd_b1(int nchain, int n, const double* thk, const double* vp, const double* vs,
+                              const double* rho, float* __restrict__ mdl)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchain * n) return;
+    int chain = g / n, j = g - chain * n;
+    size_t s = (size_t)n * nchain, o = (size_t)j * nchain + chain;
+    mdl[0 * s + o] = (float)thk[g]; mdl[1 * s + o] = (float)vp[g];
+    mdl[2 * s + o] = (float)vs[g];  mdl[3 * s + o] = (float)rho[g];
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 pass A: lane = frequency (TAIL=false: block = one chain's 64..256 frequencies, layer
+// constants are wave-uniform -> scalar loads) or lane = chain at the last frequency
+// (TAIL=true: n2 = nft/2 + 1 is odd, the Nyquist bin is swept "chain-wide" instead).
+// ---------------------------------------------------------------------------------------
+template <bool TAIL>
+__global__ void __launch_bounds__(256)
+k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
+           double* __restrict__ Rs)
+{
+    int chain, k;
+    if (TAIL) {
+        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1;
+        if (chain >= nchain) return;
+    } else {
+        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k >= f.n2 - 1) return;
+    }
+    const RfLayer* L = lc + (size_t)chain * n;
+    cplx omega = C(rf_wk(f, k), -f.sigma);
+    V4 r = rf_einv_row(L[n - 1], f.rf_type);
+    const size_t n2p = f.n2p;
+    double* rs = Rs ? Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k : nullptr;
+    for (int j = n - 2; j >= 0; j--) {
+        if (rs) {
+            double* o = rs + (size_t)j * 8 * n2p;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { o[(2 * i) * n2p] = r.v[i].re; o[(2 * i + 1) * n2p] = r.v[i].im; }
+        }
+        RfHyp H; RfA A;
+        rf_hyp(L[j], omega, H);
+        rf_build_A(L[j], H, A);
+        r = rf_row_times_A(r, A);
+    }
+    int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
+    cplx r21 = r.v[c21];
+    cplx r22 = (f.rf_type == 1) ? mul_i(r.v[c22]) : -mul_i(r.v[c22]);
+    if (r21.re != r21.re || r21.im != r21.im) r21 = C(0.0);      // NaN scrub, RFModule.f90:662-667
+    if (r22.re != r22.re || r22.im != r22.im) r22 = C(0.0);
+    double* o = RR + (size_t)chain * 4 * n2p + k;
+    o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 mid 1: per chain -- water level (max over all frequencies, RFModule.f90:396-398,
+// 411-413) and the RF spectrum S = conj(R21) R22 G e^{-i w t0} / fai (:401), with the
+// imaginary parts of DC / Nyquist zeroed (FFTW's c2r ignores them, rocFFT must not see them).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rf_mid1(int n, RfFreq f, const double* __restrict__ RR, double* __restrict__ wmax2, cplx* __restrict__ spec)
+{
+    __shared__ double red[8];
+    int chain = blockIdx.x, tid = threadIdx.x;
+    const double* rr = RR + (size_t)chain * 4 * f.n2p;
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = tid; k < f.n2; k += blockDim.x) {
+        cplx r21 = C(rr[k], rr[f.n2p + k]);
+        double wa = (r21 * conj(r21)).re;
+        cplx sq = r21 * r21;
+        double wb = (sq * conj(sq)).re;
+        m1 = fmax(m1, wa); m2 = fmax(m2, wb);
+    }
+    m1 = wave_max(m1); m2 = wave_max(m2);
+    int wv = tid >> 6, nw = blockDim.x >> 6;
+    if ((tid & 63) == 0) { red[wv] = m1; red[4 + wv] = m2; }
+    __syncthreads();
+    m1 = red[0]; m2 = red[4];
+    for (int i = 1; i < nw; i++) { m1 = fmax(m1, red[i]); m2 = fmax(m2, red[4 + i]); }
+    if (tid == 0) wmax2[chain] = m2;
+    for (int k = tid; k < f.n2; k += blockDim.x) {
+        cplx r21 = C(rr[k], rr[f.n2p + k]), r22 = C(rr[2 * f.n2p + k], rr[3 * f.n2p + k]);
+        double w = rf_wk(f, k);
+        double wa = (r21 * conj(r21)).re;
+        double fai = fmax(wa, f.water * m1);
+        double g = exp(-((w / 2 / f.f0) * (w / 2 / f.f0)));
+        double s, c; sincos(w * f.t0, &s, &c);
+        cplx S = (conj(r21) * r22) * (g / fai) * C(c, -s);
+        if (k == 0 || k == f.n2 - 1) S.im = 0.0;
+        spec[(size_t)chain * f.n2 + k] = S;
+    }
+}
+
+// K2 mid 2: per chain -- rf(t) = irfft(S)(t)/dt * exp(sigma (t dt - t0)) (:404-407), residual,
+// misfit, and the weighted residual whose forward FFT feeds the adjoint pass.
+__global__ void __launch_bounds__(256)
+k_rf_mid2(RfFreq f, const double* __restrict__ tser, const double* __restrict__ dobs, int ndata,
+          double* __restrict__ dsyn, double* __restrict__ misfit_rf, double* __restrict__ wres)
+{
+    __shared__ double red[4];
+    int chain = blockIdx.x, tid = threadIdx.x;
+    const double* ts = tser + (size_t)chain * f.nft;
+    double acc = 0.0;
+    for (int t = tid; t < f.nft; t += blockDim.x) {
+        double wv = 0.0;
+        if (t < f.nt) {
+            double e = exp(f.sigma * (-f.t0 + t * f.dt));
+            double rf = ts[t] / f.nft / f.dt * e;
+            if (dsyn) dsyn[(size_t)chain * ndata + t] = rf;
+            if (dobs) {
+                double r = rf - dobs[t];
+                acc += r * r;
+                wv = r / f.dt * e;
+            }
+        }
+        if (wres) wres[(size_t)chain * f.nft + t] = wv;
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0 && misfit_rf) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+        misfit_rf[chain] = 0.5 * s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 pass B (adjoint): lane = frequency / lane = chain as in pass A.  Each lane forms its
+// adjoint weights (u, v) from R21, R22, the water-levelled |R21^2|^2 and W = rfft(weighted
+// residual), sweeps the column y top-down and emits Re(r_j . dA_j/dm . y_j) for the four
+// parameter classes; a wave butterfly sums over the 64 frequencies of the wave and lane
+// (j mod 64) keeps layer j's sum, so nothing is written until the sweep ends.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, cplx r22, cplx W, double wm2)
+{
+    double w = rf_wk(f, k);
+    cplx sq = r21 * r21;
+    double fai2 = fmax((sq * conj(sq)).re, f.water * wm2);
+    double g = exp(-((w / 2 / f.f0) * (w / 2 / f.f0)));
+    double s, c; sincos(w * f.t0, &s, &c);
+    double ck = (k == 0 || k == f.n2 - 1) ? 1.0 : 2.0;
+    cplx Q = (conj(sq) * C(c, -s)) * conj(W) * (ck * g / fai2 / f.nft);
+    V4 y;
+    if (f.rf_type == 1) { y.v[0] = -(Q * r22); y.v[1] = mul_i(Q * r21); }
+    else { y.v[0] = -mul_i(Q * r21); y.v[1] = -(Q * r22); }
+    y.v[2] = C(0.0); y.v[3] = C(0.0);
+    return y;
+}
+
+template <bool TAIL>
+__global__ void __launch_bounds__(256)
+k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
+           const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
+           int npart, double* __restrict__ PG)
+{
+    int chain, k, part;
+    bool live = true;
+    if (TAIL) {
+        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1; part = npart - 1;
+        if (chain >= nchain) return;
+    } else {
+        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
+        part = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (k >= f.n2 - 1) { live = false; k = f.n2 - 2; }
+    }
+    const RfLayer* L = lc + (size_t)chain * n;
+    const size_t n2p = f.n2p;
+    const double* rr = RR + (size_t)chain * 4 * n2p + k;
+    cplx r21 = C(rr[0], rr[n2p]), r22 = C(rr[2 * n2p], rr[3 * n2p]);
+    cplx omega = C(rf_wk(f, k), -f.sigma), kk = f.p * omega;
+    V4 y = rf_adjoint_seed(f, k, r21, r22, W[(size_t)chain * f.n2 + k], wmax2[chain]);
+    if (!live) { y.v[0] = C(0.0); y.v[1] = C(0.0); }
+    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
+    double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    const int lane = threadIdx.x & 63;
+    double* pg = PG + ((size_t)chain * npart + part) * 4 * n;
+    for (int j = 0; j < n; j++) {
+        cplx T[4];
+        if (j < n - 1) {
+            const double* o = rs + (size_t)j * 8 * n2p;
+            V4 r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
+            RfHyp H; RfA A;
+            rf_hyp(L[j], omega, H);
+            rf_layer_partials(L[j], H, kk, r, y, T);
+            rf_build_A(L[j], H, A);
+            y = rf_A_times_col(A, y);
+        } else {
+            rf_half_partials(L[j], omega, f.rf_type, y, T);
+        }
+#pragma unroll
+        for (int ip = 0; ip < 4; ip++) {
+            double v = T[ip].re;
+            if (v != v) v = 0.0;                                  // NaN scrub (:698-703)
+            if (TAIL) {
+                pg[(size_t)ip * n + j] = v;
+            } else {
+                v = wave_sum(v);
+                if (lane == (j & 63)) acc[ip][j >> 6] = v;
+            }
+        }
+    }
+    if (!TAIL) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            int j = s * 64 + lane;
+            if (j < n) {
+#pragma unroll
+                for (int ip = 0; ip < 4; ip++) pg[(size_t)ip * n + j] = acc[ip][s];
+            }
+        }
+    }
+}
+
+// B1 kernel_all: materialise the partial spectra S_{p,j,k} (RFModule.f90:416-419) by running the
+// column sweep twice (unit seeds for R21 and R22).  specp: [chain][4][n][n2] complex.
+template <bool TAIL>
+__global__ void __launch_bounds__(256)
+k_rf_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
+                     const double* __restrict__ Rs, const double* __restrict__ wmax2, cplx* __restrict__ specp)
+{
+    int chain, k;
+    if (TAIL) {
+        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1;
+        if (chain >= nchain) return;
+    } else {
+        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k >= f.n2 - 1) return;
+    }
+    const RfLayer* L = lc + (size_t)chain * n;
+    const size_t n2p = f.n2p;
+    const double* rr = RR + (size_t)chain * 4 * n2p + k;
+    cplx r21 = C(rr[0], rr[n2p]), r22 = C(rr[2 * n2p], rr[3 * n2p]);
+    double w = rf_wk(f, k);
+    cplx omega = C(w, -f.sigma), kk = f.p * omega;
+    cplx sq = r21 * r21;
+    double fai2 = fmax((sq * conj(sq)).re, f.water * wmax2[chain]);
+    double g = exp(-((w / 2 / f.f0) * (w / 2 / f.f0)));
+    double s, c; sincos(w * f.t0, &s, &c);
+    cplx Q = (conj(sq) * C(c, -s)) * (g / fai2);
+    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
+    const int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
+    cplx* out = specp + (size_t)chain * 4 * n * f.n2 + k;
+    for (int which = 0; which < 2; which++) {
+        V4 y; y.v[0] = y.v[1] = y.v[2] = y.v[3] = C(0.0);
+        y.v[which == 0 ? c21 : c22] = C(1.0);
+        for (int j = 0; j < n; j++) {
+            cplx T[4];
+            if (j < n - 1) {
+                const double* o = rs + (size_t)j * 8 * n2p;
+                V4 r;
+#pragma unroll
+                for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
+                RfHyp H; RfA A;
+                rf_hyp(L[j], omega, H);
+                rf_layer_partials(L[j], H, kk, r, y, T);
+                rf_build_A(L[j], H, A);
+                y = rf_A_times_col(A, y);
+            } else {
+                rf_half_partials(L[j], omega, f.rf_type, y, T);
+            }
+            for (int ip = 0; ip < 4; ip++) {
+                cplx t = T[ip];
+                if (t.re != t.re || t.im != t.im) t = C(0.0);
+                cplx* o = out + ((size_t)ip * n + j) * f.n2;
+                if (which == 0) {
+                    *o = -(Q * (t * r22));                       // - R21_m * R22
+                } else {
+                    cplx r22m = (f.rf_type == 1) ? mul_i(t) : -mul_i(t);
+                    cplx S = *o + Q * (r22m * r21);
+                    if (k == 0 || k == f.n2 - 1) S.im = 0.0;
+                    *o = S;
+                }
+            }
+        }
+    }
+}
+
+// scale batched inverse FFT output into kl[chain][4][n][nt]
+__global__ void k_rf_scale_kl(size_t ntrace, RfFreq f, const double* __restrict__ tser, double* __restrict__ kl)
+{
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntrace * f.nt) return;
+    size_t tr = g / f.nt; int t = (int)(g - tr * f.nt);
+    kl[g] = tser[tr * f.nft + t] / f.nft / f.dt * exp(f.sigma * (-f.t0 + t * f.dt));
+}
+
+// ---------------------------------------------------------------------------------------
+// K3 root search: lane = (sequence, chain); the whole per-period hand-over of the reference
+// runs sequentially inside the lane, all 64 lanes evaluate the secular function together.
+// Sequences: 0 = tRc, 1 = tRg, 2 = 1.05 tRg, 3 = 0.95 tRg (surfdisp.cpp:235-241).
+// ---------------------------------------------------------------------------------------
+struct SwdSeq { const double* t; int nper; double scale; int croot_off; };   // croot_off in periods
+struct SwdSeqs { SwdSeq s[4]; int nseq; int nper_total; };
+
+__global__ void __launch_bounds__(64)
+k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double* __restrict__ croot,
+            int* __restrict__ sflag)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int seq = g / nchain, chain = g - seq * nchain;
+    bool live = seq < Q.nseq;
+    if (!live) { seq = 0; chain = 0; }
+    const size_t s = (size_t)n * nchain;
+    SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+    const SwdSeq sq = Q.s[seq];
+    const double* tp = sq.t; const double sc = sq.scale;
+    auto T = [&](int k) { return tp[k] * sc; };
+    double* cr = croot + (size_t)sq.croot_off * nchain + chain;
+    auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
+    RootSearch rs;
+    rs.begin(M, T, sq.nper);
+    if (!live) rs.done = 1;
+    while (__any(!rs.done)) {
+        if (!rs.done) {
+            double del = swd_secular(M, rs.omega / rs.creq, rs.omega);
+            rs.advance(del, T, out);
+        }
+    }
+    if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4 eigenfunction kernels: lane = (item, chain), item = (sequence, period).  Writes the
+// SCALED phase-velocity kernels (d c / d alpha, beta, rho and the interface partial) and U.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_swd_eigen(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ croot,
+            const int* __restrict__ sflag, double* __restrict__ cds, double* __restrict__ krn,
+            double* __restrict__ ugr)
+{
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nitem = (size_t)Q.nper_total * nchain;
+    if (g >= nitem) return;
+    int e = (int)(g / nchain), chain = (int)(g - (size_t)e * nchain);
+    int seq = 0;
+    while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
+    if (!sflag[(size_t)seq * nchain + chain]) return;
+    int k = e - Q.s[seq].croot_off;
+    double t = Q.s[seq].t[k] * Q.s[seq].scale;
+    double cp = croot[(size_t)e * nchain + chain];
+    const size_t s = (size_t)n * nchain;
+    SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+    double omega = 2.0 * SR_PI32 / t, wvno = omega / cp;
+    double* sc = cds + g;
+    auto store = [&](int m, const double* cd, double exe) {
+        double* o = sc + (size_t)m * 6 * nitem;
+#pragma unroll
+        for (int i = 0; i < 5; i++) o[(size_t)i * nitem] = cd[i];
+        o[(size_t)5 * nitem] = exe;
+    };
+    sr_up(M, omega, wvno, store);
+    auto load = [&](int m, double* cd, double& exe) {
+        const double* o = sc + (size_t)m * 6 * nitem;
+#pragma unroll
+        for (int i = 0; i < 5; i++) cd[i] = o[(size_t)i * nitem];
+        exe = o[(size_t)5 * nitem];
+    };
+    double* ko = krn + (size_t)e * 4 * s + chain;       // [e][q][m][chain]
+    auto emit = [&](int m, double da, double db, double dr, double dh) {
+        ko[0 * s + (size_t)m * nchain] = da; ko[1 * s + (size_t)m * nchain] = db;
+        ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
+    };
+    SrTotals R = sr_down_energy(M, omega, wvno, load, emit);
+    double sca = 1.0 / (R.ugr * R.sumi0);
+    for (int m = 0; m < n; m++) {
+        ko[0 * s + (size_t)m * nchain] *= sca; ko[1 * s + (size_t)m * nchain] *= sca;
+        ko[2 * s + (size_t)m * nchain] *= sca;
+        double dfac = R.fac * ko[3 * s + (size_t)m * nchain];
+        ko[3 * s + (size_t)m * nchain] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;   // sregn96.f90:1529-1531
+    }
+    double u = R.ugr;
+    if (fabs(u) < 1.0e-36) u = 0.0;                                             // :1703
+    ugr[g] = u;
+}
+
+// Kernel value q (0 alpha, 1 beta, 2 rho, 3 interface) of data row `row` at layer m:
+// phase rows read sequence-0 items directly, group rows combine the three passes as
+// sregnpu does (sregn96.f90:1839-1844), first term from the t2 = 0.95 T pass (quirk).
+struct SwdRows { int ntRc, ntRg; int off_rg, off_rg1, off_rg2; const double* tRg; };
+
+__device__ __forceinline__ double swd_kernel_value(const SwdRows& R, int row, int q, int m, int chain,
+                                                   int nchain, int n, const double* __restrict__ krn,
+                                                   const double* __restrict__ croot, const double* __restrict__ ugr)
+{
+    const size_t s = (size_t)n * nchain;
+    if (row < R.ntRc) return krn[((size_t)row * 4 + q) * s + (size_t)m * nchain + chain];
+    int k = row - R.ntRc;
+    int e0 = R.off_rg + k, e1 = R.off_rg1 + k, e2 = R.off_rg2 + k;
+    double t = R.tRg[k], t1 = t * (1.0 + 0.05), t2 = t * (1.0 - 0.05);
+    double uc1 = ugr[(size_t)e0 * nchain + chain] / croot[(size_t)e0 * nchain + chain];
+    double k1 = krn[((size_t)e1 * 4 + q) * s + (size_t)m * nchain + chain];
+    double k2 = krn[((size_t)e2 * 4 + q) * s + (size_t)m * nchain + chain];
+    return uc1 * (2.0 - uc1) * k2 - uc1 * uc1 * t * (k2 - k1) / (t2 - t1);
+}
+
+// B1 export: [chain][row][layer] arrays for libsurf.adjoint_kernel (thickness kernel =
+// suffix sum of the interface partials, sregn96.f90:1727-1731, 1871-1878).
+__global__ void k_swd_export(int nchain, int n, SwdRows R, int row0, int nrow, const double* __restrict__ krn,
+                             const double* __restrict__ croot, const double* __restrict__ ugr,
+                             double* c, double* dcda, double* dcdb, double* dcdr, double* dcdh)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchain * nrow) return;
+    int chain = g / nrow, r = g - chain * nrow, row = row0 + r;
+    if (c) {
+        if (row < R.ntRc) c[g] = croot[(size_t)row * nchain + chain];
+        else c[g] = ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
+    }
+    if (!dcda) return;
+    double suf = 0.0;
+    for (int m = n - 1; m >= 0; m--) {
+        size_t o = (size_t)g * n + m;
+        dcda[o] = swd_kernel_value(R, row, 0, m, chain, nchain, n, krn, croot, ugr);
+        dcdb[o] = swd_kernel_value(R, row, 1, m, chain, nchain, n, krn, croot, ugr);
+        dcdr[o] = swd_kernel_value(R, row, 2, m, chain, nchain, n, krn, croot, ugr);
+        dcdh[o] = suf;
+        suf += swd_kernel_value(R, row, 3, m, chain, nchain, n, krn, croot, ugr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5 combine: one block per chain, thread = layer.  Chain rule, K.r contractions, weighted
+// joint misfit/gradient and the plugins' failure returns.
+// mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198),
+//       2 SWD only (model_surf.py:155-228)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MAXL)
+k_joint_combine(int nchain, int n, int mode, int nt, SwdRows R, int npart, double wt,
+                const double* __restrict__ PG, const double* __restrict__ misfit_rf,
+                const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
+                const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
+                const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
+                double* __restrict__ dsyn, int* __restrict__ flag)
+{
+    __shared__ double hsum[MAXL];
+    __shared__ double msw;
+    int chain = blockIdx.x, j = threadIdx.x;
+    const int nswd = R.ntRc + R.ntRg, ndata = nt + nswd;
+    bool ok = true;
+    if (mode != 1) for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
+    double g_vs = 0.0, g_thk = 0.0, hj = 0.0;
+    double dadb = 0.0, drdadb = 0.0;
+    if (j < n) { dadb = cr[((size_t)chain * 2) * n + j]; drdadb = cr[((size_t)chain * 2 + 1) * n + j]; }
+    if (mode != 2 && j < n) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        const double* pg = PG + (size_t)chain * npart * 4 * n;
+        for (int p = 0; p < npart; p++) {
+            s0 += pg[((size_t)p * 4 + 0) * n + j]; s1 += pg[((size_t)p * 4 + 1) * n + j];
+            s2 += pg[((size_t)p * 4 + 2) * n + j]; s3 += pg[((size_t)p * 4 + 3) * n + j];
+        }
+        g_vs = s2 + dadb * s1 + drdadb * s0;          // kvs + dadb kvp + drda dadb krho (model_rf.py:189)
+        g_thk = s3;
+    }
+    double m_swd = 0.0, gs_vs = 0.0;
+    if (mode != 1 && ok) {
+        for (int row = 0; row < nswd; row++) {
+            double d = (row < R.ntRc) ? croot[(size_t)row * nchain + chain]
+                                      : ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
+            double r = d - dobs[nt + row];
+            m_swd += r * r;
+            if (j < n) {
+                double ka = swd_kernel_value(R, row, 0, j, chain, nchain, n, krn, croot, ugr);
+                double kb = swd_kernel_value(R, row, 1, j, chain, nchain, n, krn, croot, ugr);
+                double kr = swd_kernel_value(R, row, 2, j, chain, nchain, n, krn, croot, ugr);
+                double kh = swd_kernel_value(R, row, 3, j, chain, nchain, n, krn, croot, ugr);
+                gs_vs += r * (kb + ka * dadb + kr * drdadb);     // model_surf.py:184
+                hj += r * kh;
+            }
+            if (j == 0 && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
+        }
+        m_swd *= 0.5;
+    }
+    hsum[j] = hj;
+    if (j == 0) msw = m_swd;
+    __syncthreads();
+    double gs_thk = 0.0;
+    if (j < n) for (int m = j + 1; m < n; m++) gs_thk += hsum[m];   // interface -> thickness partials
+    if (!ok) {
+        // failure returns: joint -> (0, zeros, dobs, False); SWD only -> (0, zeros, zeros, False)
+        if (j < n) { grad[(size_t)chain * 2 * n + j] = 0.0; grad[(size_t)chain * 2 * n + n + j] = 0.0; }
+        if (dsyn) for (int i = j; i < ndata; i += blockDim.x)
+            dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
+        if (j == 0) { misfit[chain] = 0.0; flag[chain] = 0; }
+        return;
+    }
+    double w = (mode == 0) ? wt : 1.0;
+    if (j < n) {
+        grad[(size_t)chain * 2 * n + j] = g_vs + w * gs_vs;
+        grad[(size_t)chain * 2 * n + n + j] = g_thk + w * gs_thk;
+    }
+    if (j == 0) {
+        double mr = (mode != 2) ? misfit_rf[chain] : 0.0;
+        misfit[chain] = mr + w * msw;
+        flag[chain] = 1;
+    }
+}
+
+// synthetics only (forward of the plugins): SWD part of dsyn + flag
+__global__ void k_swd_forward_out(int nchain, int nt, SwdRows R, const double* __restrict__ croot,
+                                  const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
+                                  double* __restrict__ dsyn, int* __restrict__ flag)
+{
+    int chain = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= nchain) return;
+    const int nswd = R.ntRc + R.ntRg, ndata = nt + nswd;
+    int ok = 1;
+    for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
+    for (int row = 0; row < nswd; row++) {
+        double d = 0.0;
+        if (ok) d = (row < R.ntRc) ? croot[(size_t)row * nchain + chain]
+                                   : ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
+        dsyn[(size_t)chain * ndata + nt + row] = d;
+    }
+    flag[chain] = ok;
+}
+
+// ---------------------------------------------------------------------------------------
+// K6 leapfrog pieces (pyhmc/hmc.py:121-201).  One thread per (chain, component) / per chain.
+// state: 1 = running, 0 = failed (reference returns early), frozen chains keep their result.
+// ---------------------------------------------------------------------------------------
+__global__ void k_leap_begin(int nchain, int nx, int ndata, const double* x0, const double* p0, const double* dt,
+                             const double* U, const double* grad, const double* dsyn, const int* flag,
+                             double* x, double* p, double* Ucur, double* Hcur, double* Unew,
+                             double* dsyn_cur, double* dsyn_new, int* ok)
+{
+    __shared__ double red[4];
+    __shared__ int bad;
+    int chain = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    double k = 0.0;
+    int mybad = 0;
+    for (int i = tid; i < ndata; i += blockDim.x) {
+        double d = dsyn[(size_t)chain * ndata + i];
+        if (d != d) mybad = 1;
+        dsyn_cur[(size_t)chain * ndata + i] = d; dsyn_new[(size_t)chain * ndata + i] = d;
+    }
+    for (int i = tid; i < nx; i += blockDim.x) {
+        double pv = p0[(size_t)chain * nx + i];
+        k += pv * pv;
+        x[(size_t)chain * nx + i] = x0[(size_t)chain * nx + i];
+        p[(size_t)chain * nx + i] = pv - dt[chain] * grad[(size_t)chain * nx + i] * 0.5;   // hmc.py:164
+    }
+    if (mybad) atomicOr(&bad, 1);
+    k = wave_sum(k);
+    if ((tid & 63) == 0) red[tid >> 6] = k;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+        int good = flag[chain] && !bad;                                   // hmc.py:155-156
+        Ucur[chain] = U[chain]; Unew[chain] = U[chain];
+        Hcur[chain] = 0.5 * s + U[chain];                                 // hmc.py:153,157
+        ok[chain] = good;
+    }
+}
+
+// x += dt p ; mirror reflection at the bounds (hmc.py:121-137, 166-169); only chains still
+// inside their trajectory (step < L) and not failed move.
+__global__ void k_leap_drift(int nchain, int nx, int step, const double* dt, const int* L, const double* bounds,
+                             double* x, double* p, int* ok)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchain * nx) return;
+    int chain = g / nx, i = g - chain * nx;
+    if (!ok[chain] || step >= L[chain]) return;
+    double xv = x[g] + dt[chain] * p[g], pv = p[g];
+    double lo = bounds[2 * i], hi = bounds[2 * i + 1];
+    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
+        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
+        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
+    }
+    x[g] = xv; p[g] = pv;
+}
+
+// kick after the evaluation at the new x (hmc.py:170-183); finishes the trajectory at step L-1
+__global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const double* dt, const int* L,
+                            const double* x, const double* U, const double* grad, const double* dsyn,
+                            const int* flag, double* p, double* Unew, double* Hnew, double* dsyn_new,
+                            double* xnew, int* ok)
+{
+    __shared__ double red[4];
+    __shared__ int bad;
+    int chain = blockIdx.x, tid = threadIdx.x;
+    if (!ok[chain] || step >= L[chain]) return;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    int mybad = 0;
+    for (int i = tid; i < nx; i += blockDim.x) {
+        double xv = x[(size_t)chain * nx + i], gv = grad[(size_t)chain * nx + i];
+        if (xv != xv || gv != gv) mybad = 1;
+    }
+    for (int i = tid; i < ndata; i += blockDim.x) {
+        double d = dsyn[(size_t)chain * ndata + i];
+        if (d != d) mybad = 1;
+    }
+    if (mybad) atomicOr(&bad, 1);
+    __syncthreads();
+    int fail = bad || !flag[chain];
+    if (fail) { if (tid == 0) ok[chain] = 0; return; }
+    bool last = (step == L[chain] - 1);
+    double k = 0.0;
+    for (int i = tid; i < nx; i += blockDim.x) {
+        double pv = p[(size_t)chain * nx + i] - dt[chain] * grad[(size_t)chain * nx + i] * (last ? 0.5 : 1.0);
+        p[(size_t)chain * nx + i] = pv;
+        k += pv * pv;
+        if (last) xnew[(size_t)chain * nx + i] = x[(size_t)chain * nx + i];
+    }
+    if (last) for (int i = tid; i < ndata; i += blockDim.x)
+        dsyn_new[(size_t)chain * ndata + i] = dsyn[(size_t)chain * ndata + i];
+    k = wave_sum(k);
+    if ((tid & 63) == 0) red[tid >> 6] = k;
+    __syncthreads();
+    if (tid == 0 && last) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+        Unew[chain] = U[chain];
+        Hnew[chain] = 0.5 * s + U[chain];                                 // hmc.py:186-190
+    }
+}
+
+}  // namespace rfs

@@ -1,0 +1,628 @@
+// Rayleigh-wave dispersion math for one lane: Dunkin secular function, the
+// reference-semantics root search as a request/advance state machine, and the
+// eigenfunction / Frechet-kernel sweeps.
+//
+// What it reproduces (reference file:line under src/SWD):
+//   secular function   surfdisp96.f:791-1088 (dltar4, var, dnka, normc)
+//   root search        surfdisp96.f:54-368, 375-396, 398-491, 568-701 and the
+//                      per-period retry of surfdisp.cpp:93-100
+//   eigenfunctions     sregn96.f90:196-402 (svfunc), 404-492 (up), 993-1063 (down),
+//                      494-650 (dnka), 917-991 (hska), 831-915 (varsv), 652-829 (evalg)
+//   energy / kernels   sregn96.f90:1065-1201 (energy), 1203-1323 (intijr),
+//                      1325-1403 (f/g/h1/h2), 1436-1535 (getdcdh), 1537-1589 (getmat)
+//
+// How it is re-designed for a 64-wide wavefront:
+//   * the root search is a state machine (RootSearch::advance) that only ever
+//     REQUESTS "evaluate the secular function at c"; the kernel evaluates it for all
+//     64 lanes at one call site, so lanes in different phases (bracketing scan,
+//     bisection, Neville step, different periods, retry mode) never diverge inside
+//     the expensive layer loop;
+//   * the Neville table lives in registers (predicated static-index updates);
+//   * the eigenfunction pass stores only the compound up-sweep (6 doubles / layer) in a
+//     coalesced HBM scratch and fuses down-sweep + eigenfunctions + energy integrals +
+//     interface terms into ONE top-down sweep with O(1) state; the six layer integrals
+//     share one E/E^-1/potential evaluation (the reference re-runs evalg six times).
+//
+// Model values are float32 in memory (the reference force-casts its inputs,
+// src/SWD/main.cpp:9) and are widened to f64 on load, like dble(b(m)) in the Fortran.
+#pragma once
+#include "cplx.hpp"
+
+namespace rfs {
+
+// strided float32 layer arrays: element m of lane's model at ptr[m * stride]
+struct SwdModel {
+    const float* d; const float* a; const float* b; const float* rho;
+    long stride;
+    int n;
+    RFS_HD double D(int m) const { return (double)d[m * stride]; }
+    RFS_HD double A(int m) const { return (double)a[m * stride]; }
+    RFS_HD double B(int m) const { return (double)b[m * stride]; }
+    RFS_HD double R(int m) const { return (double)rho[m * stride]; }
+    RFS_HD float Bf(int m) const { return b[m * stride]; }
+    RFS_HD float Af(int m) const { return a[m * stride]; }
+    RFS_HD float Rf(int m) const { return rho[m * stride]; }
+};
+
+RFS_HD double sgn1(double x) { return copysign(1.0, x); }
+
+// ---------------------------------------------------------------------------
+// Dunkin secular function  (surfdisp96.f:791-891 with var :894-1011, dnka :1044-1088,
+// normc :1015-1040 fused per layer).  Only e(1) is returned; its sign drives the search.
+// ---------------------------------------------------------------------------
+RFS_HD double swd_secular(const SwdModel& M, double wvno, double omga) {
+    double omega = omga < 1.0e-4 ? 1.0e-4 : omga;
+    const double wvno2 = wvno * wvno;
+    const int last = M.n - 1;
+    double e0, e1, e2, e3, e4;
+    {
+        double xka = omega / M.A(last), xkb = omega / M.B(last);
+        double ra = sqrt((wvno + xka) * fabs(wvno - xka));
+        double rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
+        double t = M.B(last) / omega;
+        double gammk = 2.0 * t * t, gam = gammk * wvno2, gamm1 = gam - 1.0;
+        double rho1 = M.R(last);
+        e0 = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+        e1 = -rho1 * ra;
+        e2 = rho1 * (gamm1 - gammk * ra * rb);
+        e3 = rho1 * rb;
+        e4 = wvno2 - ra * rb;
+    }
+    for (int m = last - 1; m >= 0; m--) {
+        double xka = omega / M.A(m), xkb = omega / M.B(m);
+        double t = M.B(m) / omega;
+        double gammk = 2.0 * t * t, gam = gammk * wvno2;
+        double ra = sqrt((wvno + xka) * fabs(wvno - xka));
+        double rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
+        double dpth = M.D(m), rho = M.R(m);
+        double p = ra * dpth, q = rb * dpth;
+        // ---- var ----
+        double pex = 0.0, sex = 0.0, cosp, w, x, cosq, y, z;
+        if (wvno < xka) {
+            double s, c; sincos(p, &s, &c);
+            w = s / ra; x = -ra * s; cosp = c;
+        } else if (wvno == xka) {
+            cosp = 1.0; w = dpth; x = 0.0;
+        } else {
+            pex = p;
+            double fac = (p < 16.0) ? exp(-2.0 * p) : 0.0;
+            cosp = (1.0 + fac) * 0.5;
+            double sinp = (1.0 - fac) * 0.5;
+            w = sinp / ra; x = ra * sinp;
+        }
+        if (wvno < xkb) {
+            double s, c; sincos(q, &s, &c);
+            y = s / rb; z = -rb * s; cosq = c;
+        } else if (wvno == xkb) {
+            cosq = 1.0; y = dpth; z = 0.0;
+        } else {
+            sex = q;
+            double fac = (q < 16.0) ? exp(-2.0 * q) : 0.0;
+            cosq = (1.0 + fac) * 0.5;
+            double sinq = (1.0 - fac) * 0.5;
+            y = sinq / rb; z = rb * sinq;
+        }
+        double exa = pex + sex;
+        double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+        double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
+        double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
+        // ---- dnka ----
+        double gamm1 = gam - 1.0, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1;
+        double gm1sq = gamm1 * gamm1, rho2 = rho * rho, a0pq = a0 - cpcq;
+        double c11 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - wvno2 * gm1sq * wy;
+        double c12 = (wvno2 * cpy - cqx) / rho;
+        double c13 = -(twgm1 * a0pq + gammk * xz + wvno2 * gamm1 * wy) / rho;
+        double c14 = (cpz - wvno2 * cqw) / rho;
+        double c15 = -(2.0 * wvno2 * a0pq + xz + wvno2 * wvno2 * wy) / rho2;
+        double c21 = (gmgmk * cpz - gm1sq * cqw) * rho;
+        double c22 = cpcq;
+        double c23 = gammk * cpz - gamm1 * cqw;
+        double c24 = -wz;
+        double c41 = (gm1sq * cpy - gmgmk * cqx) * rho;
+        double c42 = -xy;
+        double c43 = gamm1 * cpy - gammk * cqx;
+        double c51 = -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;
+        double c53 = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) * rho;
+        double tt = -2.0 * wvno2;
+        double c31 = tt * c53, c32 = tt * c43, c33 = a0 + 2.0 * (cpcq - c11), c34 = tt * c23, c35 = tt * c13;
+        // ee(i) = sum_j e(j) ca(j,i); ca(2,5)=ca(1,4), ca(4,4)=ca(2,2), ca(4,5)=ca(1,2),
+        // ca(5,2)=ca(4,1), ca(5,4)=ca(2,1), ca(5,5)=ca(1,1)
+        double n0 = e0 * c11 + e1 * c21 + e2 * c31 + e3 * c41 + e4 * c51;
+        double n1 = e0 * c12 + e1 * c22 + e2 * c32 + e3 * c42 + e4 * c41;
+        double n2 = e0 * c13 + e1 * c23 + e2 * c33 + e3 * c43 + e4 * c53;
+        double n3 = e0 * c14 + e1 * c24 + e2 * c34 + e3 * c22 + e4 * c21;
+        double n4 = e0 * c15 + e1 * c14 + e2 * c35 + e3 * c12 + e4 * c11;
+        // ---- normc ----
+        double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+        if (t1 < 1.0e-40) t1 = 1.0;
+        e0 = n0 / t1; e1 = n1 / t1; e2 = n2 / t1; e3 = n3 / t1; e4 = n4 / t1;
+    }
+    return e0;
+}
+
+// surfdisp96.f:375-396  gtsolh (single precision throughout)
+RFS_HD float swd_gtsolh(float a, float b) {
+    float c = 0.95f * b;
+    for (int i = 0; i < 5; i++) {
+        float gamma = b / a, kappa = c / b;
+        float k2 = kappa * kappa;
+        float gk = gamma * kappa, gk2 = gk * gk;
+        float fac1 = sqrtf(1.0f - gk2), fac2 = sqrtf(1.0f - k2);
+        float fr = (2.0f - k2) * (2.0f - k2) - 4.0f * fac1 * fac2;
+        float frp = -4.0f * (2.0f - k2) * kappa + 4.0f * fac2 * gamma * gamma * kappa / fac1 +
+                    4.0f * fac1 * kappa / fac2;
+        frp = frp / b;
+        c = c - fr / frp;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------
+// Root search state machine.  Usage:
+//     rs.begin(model, periods, kmax);
+//     while (!rs.done) { double del = swd_secular(M, rs.omega / rs.creq, rs.omega); rs.advance(del); }
+// Results: rs.flag (1 ok / 0 failed), cg[k] written through the Out functor as the
+// float32-rounded phase velocity (surfdisp96.f:302,307), zeros after a failure.
+// ---------------------------------------------------------------------------
+struct RootSearch {
+    enum { PH_START, PH_SCAN, PH_HALF0, PH_HALF_OUT, PH_HALF_B, PH_NEV };
+    static constexpr double TWOPI = 2.0 * 3.141592653589793;
+    // per-model constants
+    double cc, dc, cm; float betmx;
+    int kmax;
+    // state
+    int k, phase, ifirst, retry, idir, done, flag;
+    double omega, creq;
+    double c1, c2, del1, del2, clow, del1st, cprev;
+    double c3, del3;
+    int nev, m, nctrl;
+    double x[12], y[12];
+    long nsec;
+
+    template <class PeriodFn>
+    RFS_HD void start_period(const PeriodFn& T) {
+        if (retry || k == 0) { c1 = cc; clow = cc; ifirst = 1; }       // surfdisp96.f:257-260
+        else { ifirst = 0; c1 = cprev - 1.5 * dc; clow = cm; }         // :272-275 (onea = 1.5)
+        omega = TWOPI / T(k);
+        creq = c1; phase = PH_START;
+    }
+
+    template <class PeriodFn>
+    RFS_HD void begin(const SwdModel& M, const PeriodFn& T, int kmax_) {
+        // surfdisp96.f:149-160 extremal velocities, :203-222 start value
+        float bmx = -1.e20f, bmn = 1.e20f; int jmn = 0, jsol = 1;
+        for (int i = 0; i < M.n; i++) {
+            float b = M.Bf(i), a = M.Af(i);
+            if (b > 0.01f && b < bmn) { bmn = b; jmn = i; jsol = 1; }
+            else if (b <= 0.01f && a < bmn) { bmn = a; jmn = i; jsol = 0; }
+            if (b > bmx) bmx = b;
+        }
+        float cc1 = (jsol == 0) ? bmn : swd_gtsolh(M.Af(jmn), M.Bf(jmn));
+        cc1 = 0.95f * cc1; cc1 = 0.90f * cc1;
+        cc = (double)cc1; dc = (double)0.005f; cm = cc; betmx = bmx;
+        kmax = kmax_; k = 0; retry = 0; done = 0; flag = 1; nsec = 0;
+        del1st = 0.0; cprev = 0.0; m = 1; nev = 1; nctrl = 1;
+        for (int i = 0; i < 12; i++) { x[i] = 0.0; y[i] = 0.0; }
+        if (kmax <= 0) { done = 1; return; }
+        start_period(T);
+    }
+
+    RFS_HD void request_half(int next_phase) { c3 = 0.5 * (c1 + c2); creq = c3; phase = next_phase; }
+
+    // consume del = secular(creq) and run until the next request (or completion)
+    template <class PeriodFn, class OutFn>
+    RFS_HD void advance(double del, const PeriodFn& T, const OutFn& out) {
+        nsec++;
+        enum { GO_SCAN, GO_LOOPTOP, GO_A1, GO_FINISH, GO_FAIL, GO_RETURN } go = GO_RETURN;
+        switch (phase) {
+        case PH_START:                                   // getsol head, surfdisp96.f:433-447
+            del1 = del;
+            if (ifirst == 1) del1st = del1;
+            if (ifirst == 1) idir = +1;
+            else idir = (sgn1(del1st) * sgn1(del1) >= 0.0) ? +1 : -1;
+            go = GO_SCAN; break;
+        case PH_SCAN:                                    // :470-479
+            del2 = del;
+            if (sgn1(del1) != sgn1(del2)) { request_half(PH_HALF0); return; }
+            c1 = c2; del1 = del2;
+            if (c1 < cm || c1 >= ((double)betmx + dc)) go = GO_FAIL; else go = GO_SCAN;
+            break;
+        case PH_HALF0: del3 = del; nev = 1; nctrl = 1; go = GO_LOOPTOP; break;      // nevill :590-594
+        case PH_HALF_OUT: del3 = del; go = GO_A1; break;
+        case PH_HALF_B: del3 = del; nev = 1; m = 1; go = GO_LOOPTOP; break;
+        case PH_NEV: del3 = del; nev = 2; m = m + 1; if (m > 10) m = 10; go = GO_LOOPTOP; break;
+        }
+        for (;;) {
+            if (go == GO_SCAN) {                         // getsol loop 1000, :457-469
+                c2 = (idir > 0) ? c1 + dc : c1 - dc;
+                if (c2 <= clow) { idir = +1; c1 = clow; c2 = c1 + dc; }   // del1 kept (quirk)
+                creq = c2; phase = PH_SCAN; return;
+            } else if (go == GO_LOOPTOP) {               // nevill :595-607
+                nctrl = nctrl + 1;
+                if (nctrl >= 100) { go = GO_FINISH; continue; }
+                if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) { nev = 0; request_half(PH_HALF_OUT); return; }
+                go = GO_A1;
+            } else if (go == GO_A1) {                    // nevill :608-681
+                double s13 = del1 - del3, s32 = del3 - del2;
+                if (sgn1(del3) * sgn1(del1) < 0.0) { c2 = c3; del2 = del3; }
+                else { c1 = c3; del1 = del3; }
+                if (fabs(c1 - c2) <= 1.0e-6 * c1) { go = GO_FINISH; continue; }
+                if (sgn1(s13) != sgn1(s32)) nev = 0;
+                const double pct = (double)0.01f;        // default-real literal 0.01 (:637,639)
+                double ss1 = fabs(del1), s1 = pct * ss1, ss2 = fabs(del2), s2 = pct * ss2;
+                if (s1 > ss2 || s2 > ss1 || nev == 0) { request_half(PH_HALF_B); return; }
+                double ym1;
+                if (nev == 2) {
+#pragma unroll
+                    for (int i = 2; i <= 11; i++) if (i == m + 1) { x[i] = c3; y[i] = del3; }
+                    ym1 = del3;
+                } else {
+                    x[1] = c1; y[1] = del1; x[2] = c2; y[2] = del2; m = 1; ym1 = del2;
+                }
+                bool bail = false;
+#pragma unroll
+                for (int j = 10; j >= 1; j--) {
+                    if (j <= m && !bail) {
+                        double denom = ym1 - y[j];
+                        if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
+                        else x[j] = (-y[j] * x[j + 1] + ym1 * x[j]) / denom;
+                    }
+                }
+                if (bail) { request_half(PH_HALF_B); return; }
+                c3 = x[1]; creq = c3; phase = PH_NEV; return;
+            } else if (go == GO_FINISH) {                // getsol :483-487
+                c1 = c3;
+                if (c1 > (double)betmx) { go = GO_FAIL; continue; }
+                out(k, (double)(float)c1);
+                cprev = c1;
+                k = k + 1;
+                if (k >= kmax) { done = 1; return; }
+                start_period(T); return;
+            } else {                                     // GO_FAIL
+                if (!retry) {                            // surfdisp96.f:317-362 + surfdisp.cpp:93-100
+                    retry = 1;
+                    for (int i = k; i < kmax; i++) out(i, 0.0);
+                    start_period(T); return;
+                }
+                flag = 0; done = 1; return;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Eigenfunction pass.  float32 pi as in sregn96.f90:1654.
+// ---------------------------------------------------------------------------
+constexpr double SR_PI32 = 3.1415927410125732;
+
+struct SvTrig { double cosp, rsinp, sinpr, cossv, rsinsv, sinsvr, pex, svex; };
+
+// sregn96.f90:831-915 varsv for an elastic layer, specialised to the only two cases that
+// occur (vertical wavenumbers are square roots of REAL numbers: pure real or pure imaginary).
+RFS_HD void sv_trig_one(double nu2, double d, double& cosx, double& rsinx, double& sinxr, double& ex) {
+    const double tiny = (double)1.0e-5f;
+    if (nu2 >= 0.0) {                      // evanescent: nu real
+        double nu = sqrt(nu2), pr = nu * d;
+        double fac = (pr < 30.0) ? exp(-2.0 * pr) : 0.0;
+        cosx = 0.5 * (1.0 + fac);
+        double sh = 0.5 * (1.0 - fac);
+        rsinx = nu * sh;
+        sinxr = (fabs(pr) < tiny && nu < tiny) ? d : sh / nu;
+        ex = pr;
+    } else {                               // propagating: nu = i*kap
+        double kap = sqrt(-nu2), s, c;
+        sincos(kap * d, &s, &c);
+        cosx = c;                          // pfac = exp(0) = 1
+        rsinx = -kap * s;
+        sinxr = (kap < tiny) ? d : s / kap;
+        ex = 0.0;
+    }
+}
+
+RFS_HD void sv_trig(double wvno2, double omega, double a, double b, double d, SvTrig& t) {
+    double xka = omega / a, xkb = omega / b;
+    sv_trig_one(wvno2 - xka * xka, d, t.cosp, t.rsinp, t.sinpr, t.pex);
+    sv_trig_one(wvno2 - xkb * xkb, d, t.cossv, t.rsinsv, t.sinsvr, t.svex);
+}
+
+// cd <- normalise(cd . CA) with CA the hspec96-convention compound matrix (sregn96.f90:494-650);
+// returns the log of the normalisation (normc :1405-1434).
+RFS_HD double sr_compound_step(double cd[5], const SvTrig& t, float rhof, float bf, double wvno,
+                               double wvno2, double om2) {
+    double exa = t.pex + t.svex;
+    double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+    double cpcq = t.cosp * t.cossv, cpy = t.cosp * t.sinsvr, cpz = t.cosp * t.rsinsv;
+    double cqw = t.cossv * t.sinpr, cqx = t.cossv * t.rsinp;
+    double xy = t.rsinp * t.sinsvr, xz = t.rsinp * t.rsinsv, wy = t.sinpr * t.sinsvr, wz = t.sinpr * t.rsinsv;
+    double rho = (double)rhof, rho2 = (double)(rhof * rhof);      // float32 rho*rho (:508,596)
+    double gam = (double)((2.0f * bf) * bf) * wvno2 / om2;        // float32 2*b*b (:597)
+    double gam2 = gam * gam, gamm1 = gam - 1.0, gamm2 = gamm1 * gamm1;
+    double cqww2 = cqw * wvno2, cqxw2 = cqx / wvno2, gg1 = gam * gamm1;
+    double a0c = 2.0 * (a0 - cpcq);
+    double xz2 = xz / wvno2, gxz2 = gam * xz2, g2xz2 = gam2 * xz2;
+    double a0cgg1 = a0c * (gam + gamm1);
+    double wy2 = wy * wvno2, g2wy2 = gamm2 * wy2, g1wy2 = gamm1 * wy2;
+    double rom = rho * om2;
+    double temp = a0c * gg1 + g2xz2 + g2wy2;
+    double c33 = a0 + temp + temp;
+    double c11 = cpcq - temp;
+    double c12 = (-cqx + wvno2 * cpy) / rom;
+    temp = 0.5 * a0cgg1 + gxz2 + g1wy2;
+    double c13 = wvno * temp / rom;
+    double c14 = (-cqww2 + cpz) / rom;
+    temp = wvno2 * (a0c + wy2) + xz;
+    double c15 = -temp / (rho2 * om2 * om2);
+    double c21 = (-gamm2 * cqw + gam2 * cpz / wvno2) * rom;
+    double c22 = cpcq;
+    double c23 = (gamm1 * cqww2 - gam * cpz) / wvno;
+    double c24 = -wz;
+    temp = 0.5 * a0cgg1 * gg1 + gam2 * gxz2 + gamm2 * g1wy2;
+    double c31 = -2.0 * temp * rom / wvno;
+    double c32 = -wvno * (gam * cqxw2 - gamm1 * cpy) * 2.0;
+    double c34 = -2.0 * c23, c35 = -2.0 * c13;
+    double c41 = (-gam2 * cqxw2 + gamm2 * cpy) * rom;
+    double c42 = -xy;
+    double c43 = -c32 / 2.0;
+    temp = gamm2 * (a0c * gam2 + g2wy2) + gam2 * g2xz2;
+    double c51 = -rho2 * om2 * om2 * temp / wvno2;
+    double c53 = -c31 / 2.0;
+    // ca(2,5)=ca(1,4) ca(4,4)=ca(2,2) ca(4,5)=ca(1,2) ca(5,2)=ca(4,1) ca(5,4)=ca(2,1) ca(5,5)=ca(1,1)
+    double n0 = cd[0] * c11 + cd[1] * c21 + cd[2] * c31 + cd[3] * c41 + cd[4] * c51;
+    double n1 = cd[0] * c12 + cd[1] * c22 + cd[2] * c32 + cd[3] * c42 + cd[4] * c41;
+    double n2 = cd[0] * c13 + cd[1] * c23 + cd[2] * c33 + cd[3] * c43 + cd[4] * c53;
+    double n3 = cd[0] * c14 + cd[1] * c24 + cd[2] * c34 + cd[3] * c22 + cd[4] * c21;
+    double n4 = cd[0] * c15 + cd[1] * c14 + cd[2] * c35 + cd[3] * c12 + cd[4] * c11;
+    double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    cd[0] = n0 / t1; cd[1] = n1 / t1; cd[2] = n2 / t1; cd[3] = n3 / t1; cd[4] = n4 / t1;
+    return log(t1);
+}
+
+// vv <- normalise(AA . vv) with AA the Haskell matrix (sregn96.f90:917-991); returns log-norm.
+RFS_HD double sr_haskell_step(double vv[4], const SvTrig& t, float rhof, float bf, double wvno,
+                              double wvno2, double om2) {
+    double dfac = ((t.pex - t.svex) > 70.0) ? 0.0 : exp(t.svex - t.pex);
+    double cossv = dfac * t.cossv, rsinsv = dfac * t.rsinsv, sinsvr = dfac * t.sinsvr;
+    double cosp = t.cosp, rsinp = t.rsinp, sinpr = t.sinpr;
+    double gam = (double)((2.0f * bf) * bf) * wvno2 / om2, gamm1 = gam - 1.0;
+    double rom = (double)rhof * om2;
+    double a11 = cossv + gam * (cosp - cossv);
+    double a12 = -wvno * gamm1 * sinpr + gam * rsinsv / wvno;
+    double a13 = -wvno * (cosp - cossv) / rom;
+    double a14 = (wvno2 * sinpr - rsinsv) / rom;
+    double a21 = gam * rsinp / wvno - wvno * gamm1 * sinsvr;
+    double a22 = cosp - gam * (cosp - cossv);
+    double a23 = (-rsinp + wvno2 * sinsvr) / rom;
+    double a31 = rom * gam * gamm1 * (cosp - cossv) / wvno;
+    double a32 = rom * (-gamm1 * gamm1 * sinpr + gam * gam * rsinsv / wvno2);
+    double a41 = rom * (gam * gam * rsinp / wvno2 - gamm1 * gamm1 * sinsvr);
+    // a24=-a13 a33=a22 a34=-a12 a42=-a31 a43=-a21 a44=a11
+    double n0 = a11 * vv[0] + a12 * vv[1] + a13 * vv[2] + a14 * vv[3];
+    double n1 = a21 * vv[0] + a22 * vv[1] + a23 * vv[2] - a13 * vv[3];
+    double n2 = a31 * vv[0] + a32 * vv[1] + a22 * vv[2] - a12 * vv[3];
+    double n3 = a41 * vv[0] - a31 * vv[1] - a21 * vv[2] + a11 * vv[3];
+    double t1 = fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3)));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    vv[0] = n0 / t1; vv[1] = n1 / t1; vv[2] = n2 / t1; vv[3] = n3 / t1;
+    return log(t1);
+}
+
+// Half-space compound vector (evalg, jbdry=0, elastic: sregn96.f90:760-776), real parts (up :442-446).
+RFS_HD void sr_halfspace_vector(double a, double b, double rho, double wvno, double om, double cd[5]) {
+    double wvno2 = wvno * wvno, om2 = om * om;
+    double xka = om / a, xkb = om / b;
+    cplx ra = csqrt_p(C(wvno2 - xka * xka)), rb = csqrt_p(C(wvno2 - xkb * xkb));
+    double gam = b * wvno / om; gam = 2.0 * (gam * gam);
+    double gamm1 = gam - 1.0;
+    cplx rarb = ra * rb;
+    cplx den = (-rho * rho * om2 * om2 * wvno2) * rarb;
+    cplx g0 = (rho * rho) * om2 * om2 * ((-gam * gam) * rarb + wvno2 * gamm1 * gamm1);
+    cplx g1 = (-rho * wvno2 * om2) * ra;
+    cplx g2 = (-rho) * ((-gam) * rarb + wvno2 * gamm1) * (om2 * wvno);
+    cplx g3 = (rho * wvno2 * om2) * rb;
+    cplx g4 = wvno2 * (wvno2 - rarb);
+    cplx iden = inv(den);
+    cd[0] = (0.25 * g0 * iden).re; cd[1] = (0.25 * g1 * iden).re; cd[2] = (0.25 * g2 * iden).re;
+    cd[3] = (0.25 * g3 * iden).re; cd[4] = (0.25 * g4 * iden).re;
+}
+
+// Up-sweep (sregn96.f90:404-492): Store(m, cd[5], exe) is called for m = n-1 .. 0.
+template <class StoreFn>
+RFS_HD void sr_up(const SwdModel& M, double omega, double wvno, const StoreFn& store) {
+    const int n = M.n;
+    double wvno2 = wvno * wvno, om2 = omega * omega;
+    double cd[5];
+    sr_halfspace_vector(M.A(n - 1), M.B(n - 1), M.R(n - 1), wvno, omega, cd);
+    double exsum = 0.0;
+    store(n - 1, cd, 0.0);
+    for (int m = n - 2; m >= 0; m--) {
+        SvTrig t;
+        sv_trig(wvno2, omega, M.A(m), M.B(m), M.D(m), t);
+        double exn = sr_compound_step(cd, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
+        exsum = exsum + t.pex + t.svex + exn;
+        store(m, cd, exsum);
+    }
+}
+
+struct Eig4 { double ur, uz, tz, tr; };
+
+// E and E^-1 of an elastic layer plus the closed-form integrals shared by the six
+// intijr calls (sregn96.f90:719-758, 1203-1323, 1325-1403).
+struct LayerInt { double i11, i13, i22, i24, i33, i44; };
+
+RFS_HD void sr_layer_integrals(double a, double b, double rho, double d, bool halfspace,
+                               double wvno, double om, const Eig4& top, const Eig4& bot, LayerInt& I) {
+    double wvno2 = wvno * wvno, om2 = om * om;
+    double xka = om / a, xkb = om / b;
+    cplx ra = csqrt_p(C(wvno2 - xka * xka)), rb = csqrt_p(C(wvno2 - xkb * xkb));
+    double gam = b * wvno / om; gam = 2.0 * (gam * gam);
+    double gamm1 = gam - 1.0;
+    double rom = rho * om2;
+    cplx ira = inv(ra), irb = inv(rb);
+    // E columns: [PU, SvU, PD, SvD]; rows: Ur, Uz, Tz, Tr
+    cplx e12 = rb, e21 = ra;
+    double e11 = wvno, e22 = wvno, e31 = rom * gamm1, e42 = rom * gamm1;
+    cplx e32 = (rom * gam / wvno) * rb, e41 = (rom * gam / wvno) * ra;
+    // E^-1 rows 1..4 (columns Ur, Uz, Tz, Tr)
+    double hg = 0.5 * gam / wvno, hr = 0.5 / rom;
+    cplx i12 = (-0.5 * gamm1) * ira, i14 = (0.5 * wvno / rom) * ira;
+    cplx i21 = (-0.5 * gamm1) * irb, i23 = (0.5 * wvno / rom) * irb;
+    // downgoing potentials at the top of the layer (rows 3,4)
+    cplx km1pd = C(hg * top.ur) - i12 * top.uz - C(hr * top.tz) - i14 * top.tr;
+    cplx km1sd = C(hg * top.uz) - i21 * top.ur - i23 * top.tz - C(hr * top.tr);
+    // row-wise potential-weighted E entries: row i -> (P_i, S_i, p_i, s_i)
+    // E(i,3) = +-E(i,1), E(i,4) = +-E(i,2): rows 1,4: (e,  e2, e, -e2)... written out explicitly
+    cplx P[4], S[4], p[4], s[4];
+    cplx c_ur_pu = C(e11), c_ur_su = e12, c_ur_pd = C(e11), c_ur_sd = -e12;
+    cplx c_uz_pu = e21, c_uz_su = C(e22), c_uz_pd = -e21, c_uz_sd = C(e22);
+    cplx c_tz_pu = C(e31), c_tz_su = e32, c_tz_pd = C(e31), c_tz_sd = -e32;
+    cplx c_tr_pu = e41, c_tr_su = C(e42), c_tr_pd = -e41, c_tr_sd = C(e42);
+    if (!halfspace) {
+        cplx kmpu = C(hg * bot.ur) + i12 * bot.uz - C(hr * bot.tz) + i14 * bot.tr;
+        cplx kmsu = i21 * bot.ur + C(hg * bot.uz) + i23 * bot.tz - C(hr * bot.tr);
+        P[0] = c_ur_pu * kmpu; S[0] = c_ur_su * kmsu; p[0] = c_ur_pd * km1pd; s[0] = c_ur_sd * km1sd;
+        P[1] = c_uz_pu * kmpu; S[1] = c_uz_su * kmsu; p[1] = c_uz_pd * km1pd; s[1] = c_uz_sd * km1sd;
+        P[2] = c_tz_pu * kmpu; S[2] = c_tz_su * kmsu; p[2] = c_tz_pd * km1pd; s[2] = c_tz_sd * km1sd;
+        P[3] = c_tr_pu * kmpu; S[3] = c_tr_su * kmsu; p[3] = c_tr_pd * km1pd; s[3] = c_tr_sd * km1sd;
+        // f, g, h1, h2 with the reference's guards
+        cplx FA, GA, FB, GB, H1, H2;
+        cplx ea = (ra.re * d < 75.0) ? cexp_p(-(d * ra)) : C(0.0);
+        cplx eb = (rb.re * d < 75.0) ? cexp_p(-(d * rb)) : C(0.0);
+        cplx ea40 = (ra.re * d < 40.0) ? ea : C(0.0), eb40 = (rb.re * d < 40.0) ? eb : C(0.0);
+        FA = (sqrt(norm2(ra)) < 1.0e-8) ? C(d) : (1.0 - ea40 * ea40) * (0.5 * ira);
+        FB = (sqrt(norm2(rb)) < 1.0e-8) ? C(d) : (1.0 - eb40 * eb40) * (0.5 * irb);
+        GA = d * ea; GB = d * eb;
+        cplx rsum = ra + rb, rdif = ra - rb;
+        cplx esum = ((rsum.re * d) < 40.0) ? ea * eb : C(0.0);
+        H1 = (sqrt(norm2(rsum)) < 1.0e-8) ? C(d) : (1.0 - esum) * inv(rsum);
+        H2 = (sqrt(norm2(rdif)) < 1.0e-8) ? C(d) : (eb40 - ea40) * inv(rdif);
+#define RFS_INT(i, j)                                                                              \
+        (((P[i] * P[j] + p[i] * p[j]) * FA + (S[i] * S[j] + s[i] * s[j]) * FB +                     \
+          H1 * ((P[i] * S[j] + S[i] * P[j]) + (p[i] * s[j] + s[i] * p[j])) +                       \
+          H2 * ((P[i] * s[j] + s[i] * P[j]) + (p[i] * S[j] + S[i] * p[j])) +                       \
+          GA * (P[i] * p[j] + p[i] * P[j]) + GB * (S[i] * s[j] + s[i] * S[j])).re)
+        I.i11 = RFS_INT(0, 0); I.i13 = RFS_INT(0, 2); I.i22 = RFS_INT(1, 1);
+        I.i24 = RFS_INT(1, 3); I.i33 = RFS_INT(2, 2); I.i44 = RFS_INT(3, 3);
+#undef RFS_INT
+    } else {
+        p[0] = c_ur_pd * km1pd; s[0] = c_ur_sd * km1sd;
+        p[1] = c_uz_pd * km1pd; s[1] = c_uz_sd * km1sd;
+        p[2] = c_tz_pd * km1pd; s[2] = c_tz_sd * km1sd;
+        p[3] = c_tr_pd * km1pd; s[3] = c_tr_sd * km1sd;
+        cplx fa = 0.5 * ira, fb = 0.5 * irb, fab = inv(ra + rb);
+#define RFS_INTH(i, j) ((p[i] * p[j] * fa + (p[i] * s[j] + s[i] * p[j]) * fab + s[i] * s[j] * fb).re)
+        I.i11 = RFS_INTH(0, 0); I.i13 = RFS_INTH(0, 2); I.i22 = RFS_INTH(1, 1);
+        I.i24 = RFS_INTH(1, 3); I.i33 = RFS_INTH(2, 2); I.i44 = RFS_INTH(3, 3);
+#undef RFS_INTH
+    }
+}
+
+// Interface term of getdcdh (sregn96.f90:1436-1535, all-solid model) WITHOUT the final `fac`:
+// (m == 0: "above" is vacuum).
+RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, double lam_m,
+                                double rho_u, double mu_u, double lam_u, const Eig4& u,
+                                double om2, double wvno, double wvno2) {
+    double tur = u.ur, tuz = u.uz, ttz = u.tz, ttr = u.tr;
+    double xl2mp = lam_m + mu_m + mu_m;
+    double duzdzp = (ttz + wvno * lam_m * tur) / xl2mp;
+    double durdzp = (mu_m == 0.0) ? wvno * tuz : (ttr / mu_m) - wvno * tuz;
+    double drho, dmu, dl2mu, g5, g6;
+    if (top_surface) {
+        drho = rho_m; dmu = mu_m; dl2mu = lam_m + mu_m + mu_m;
+        g5 = xl2mp * duzdzp * duzdzp;
+        g6 = mu_m * durdzp * durdzp;
+    } else {
+        drho = rho_m - rho_u; dmu = mu_m - mu_u;
+        dl2mu = (lam_m - lam_u) + dmu + dmu;
+        double xl2mm = lam_u + mu_u + mu_u;
+        double durdzm = (mu_u == 0.0) ? wvno * tuz : (ttr / mu_u) - wvno * tuz;
+        double duzdzm = (ttz + wvno * lam_u * tur) / xl2mm;
+        g5 = xl2mp * duzdzp * duzdzp - xl2mm * duzdzm * duzdzm;
+        g6 = mu_m * durdzp * durdzp - mu_u * durdzm * durdzm;
+    }
+    double g1 = om2 * drho * tuz * tuz;
+    double g2 = om2 * (tur * tur * drho);
+    double g3 = -wvno2 * dmu * tuz * tuz;
+    double g4 = -wvno2 * (tur * tur * dl2mu);
+    return g1 + g2 + g3 + g4 + g5 + g6;
+}
+
+// Down-sweep fused with eigenfunctions, energy integrals and interface terms.
+// Load(m, cd[5], exe) returns what sr_up stored.  Emit(m, da, db, dr, dh) receives the RAW
+// per-layer factors (before the 1/(U I0) and `fac` scalings); the caller rescales them with
+// the returned (ugr, sumi0, fac) -- see sr_finish_scale.
+struct SrTotals { double ugr, sumi0, fac; };
+
+template <class LoadFn, class EmitFn>
+RFS_HD SrTotals sr_down_energy(const SwdModel& M, double omega, double wvno, const LoadFn& load,
+                               const EmitFn& emit) {
+    const int n = M.n;
+    const double om2 = omega * omega, wvno2 = wvno * wvno, c = omega / wvno;
+    double cd[5], exe0, exe_m;
+    load(0, cd, exe0);
+    const double f1213 = -cd[1];
+    Eig4 top{cd[2] / cd[1], 1.0, 0.0, 0.0};
+    double vv[4] = {1.0, 0.0, 0.0, 0.0};
+    double exa = 0.0;
+    double sumi0 = 0.0, sumi1 = 0.0, sumi2 = 0.0, sumi3 = 0.0;
+    double rho_u = 0.0, mu_u = 0.0, lam_u = 0.0;
+    for (int m = 0; m < n; m++) {
+        const bool half = (m == n - 1);
+        double a = M.A(m), b = M.B(m), rho = M.R(m), d = M.D(m);
+        double mu = rho * (b * b), lam = rho * (a * a) - 2 * mu;
+        Eig4 bot = top;
+        if (!half) {
+            SvTrig t;
+            sv_trig(wvno2, omega, a, b, d, t);
+            double ex2 = sr_haskell_step(vv, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
+            exa = exa + t.pex + ex2;
+            load(m + 1, cd, exe_m);
+            // svfunc :283-315
+            double cd1 = cd[0], cd2 = cd[1], cd3 = cd[2], cd4 = -cd[2], cd5 = cd[3], cd6 = cd[4];
+            double tz1 = -vv[3], tz2 = -vv[2], tz3 = vv[1], tz4 = vv[0];
+            double uu1 = tz2 * cd6 - tz3 * cd5 + tz4 * cd4;
+            double uu2 = -tz1 * cd6 + tz3 * cd3 - tz4 * cd2;
+            double uu3 = tz1 * cd5 - tz2 * cd3 + tz4 * cd1;
+            double uu4 = -tz1 * cd4 + tz2 * cd2 - tz3 * cd1;
+            double ext = exa + exe_m - exe0;
+            if (ext > -80.0 && ext < 80.0) {
+                double fact = exp(ext);
+                bot = Eig4{uu1 * fact / f1213, uu2 * fact / f1213, uu3 * fact / f1213, uu4 * fact / f1213};
+            } else {
+                bot = Eig4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        LayerInt I;
+        sr_layer_integrals(a, b, rho, d, half, wvno, omega, top, bot, I);
+        // getmat :1566-1586 (isotropic)
+        double TL = rho * b * b, TC = rho * a * a, TA = TC, TF = TA - 2. * TL;
+        double a12 = -wvno, a14 = 1.0 / TL, a21 = wvno * TF / TC, a23 = 1.0 / TC;
+        double URUR = I.i11, UZUZ = I.i22;
+        double DURDUR = a12 * a12 * I.i22 + 2. * a12 * a14 * I.i24 + a14 * a14 * I.i44;
+        double DUZDUZ = a21 * a21 * I.i11 + 2. * a21 * a23 * I.i13 + a23 * a23 * I.i33;
+        double URDUZ = a21 * I.i11 + a23 * I.i13;
+        double UZDUR = a12 * I.i22 + a14 * I.i24;
+        sumi0 += rho * (URUR + UZUZ);
+        sumi1 += TL * UZUZ + TA * URUR;
+        sumi2 += TL * UZDUR - TF * URDUZ;
+        sumi3 += TL * DURDUR + TC * DUZDUZ;
+        double facah = rho * a * (URUR - 2. * URDUZ / wvno);
+        double facav = rho * a * DUZDUZ / wvno2;
+        double facbv = rho * b * (UZUZ + 2. * UZDUR / wvno + DURDUR / wvno2 + 4. * URDUZ / wvno);
+        double facr = -0.5 * c * c * (URUR + UZUZ);
+        double da = facah + facav, db = facbv;
+        double dr = 0.5 * (a * facav + a * facah + b * facbv) / rho + facr;
+        double dh = sr_interface_term(m == 0, rho, mu, lam, rho_u, mu_u, lam_u, top, om2, wvno, wvno2);
+        emit(m, da, db, dr, dh);
+        rho_u = rho; mu_u = mu; lam_u = lam;
+        top = bot;
+    }
+    SrTotals T;
+    T.ugr = (wvno * sumi1 + sumi2) / (omega * sumi0);
+    double are = wvno / (2.0 * omega * T.ugr * sumi0);
+    T.sumi0 = sumi0;
+    T.fac = are * c / wvno2;
+    return T;
+}
+
+}  // namespace rfs

@@ -1,0 +1,88 @@
+"""Shared machinery of the three model plugins: one rfs_ctx configured with the plugin's data
+(rfs_joint_setup) and batched misfit_and_grad / forward over it."""
+import ctypes
+
+import numpy as np
+
+from .._lib import Context, RfParams, hptr
+
+
+class FusedPlugin:
+    """x may be 1-D [2n] (reference call shape: scalars / 1-D arrays come back) or 2-D [nchain, 2n]."""
+
+    _ctx = None
+    device = 0
+
+    def _rf_params(self):
+        return None
+
+    def _periods(self):
+        return None, None
+
+    def _sigmas(self):
+        return 1.0, 1.0
+
+    def _configure(self, nlayer, dobs):
+        if self._ctx is None:
+            self._ctx = Context(device=self.device, max_chains=1 << 20, max_layers=128)
+        ctx = self._ctx
+        rf = self._rf_params()
+        tRc, tRg = self._periods()
+        tRc = np.ascontiguousarray(tRc, dtype=np.float64) if tRc is not None else np.zeros(0)
+        tRg = np.ascontiguousarray(tRg, dtype=np.float64) if tRg is not None else np.zeros(0)
+        s1, s2 = self._sigmas()
+        d = None if dobs is None else np.ascontiguousarray(dobs, dtype=np.float64)
+        ctx.check(ctx.L.rfs_joint_setup(ctx.h, int(nlayer), ctypes.byref(rf) if rf is not None else None,
+                                        len(tRc), hptr(tRc) if len(tRc) else None,
+                                        len(tRg), hptr(tRg) if len(tRg) else None,
+                                        float(s1), float(s2), hptr(d) if d is not None else None))
+        self._cfg = (int(nlayer), None if d is None else d.tobytes())
+        self._keep = (tRc, tRg, d)
+
+    def _ensure(self, nlayer):
+        dobs = getattr(self, "dobs", None)
+        key = (int(nlayer), None if dobs is None else np.ascontiguousarray(dobs, dtype=np.float64).tobytes())
+        if getattr(self, "_cfg", None) != key:
+            self._configure(nlayer, dobs)
+        return self._ctx
+
+    def _eval(self, x):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        single = x.ndim == 1
+        x2 = np.atleast_2d(x)
+        nchain, nx = x2.shape
+        ctx = self._ensure(nx // 2)
+        nd = ctx.L.rfs_ndata(ctx.h)
+        misfit = np.zeros(nchain); grad = np.zeros((nchain, nx)); dsyn = np.zeros((nchain, nd))
+        flag = np.zeros(nchain, dtype=np.int32)
+        ctx.check(ctx.L.rfs_joint_misfit_grad(ctx.h, nchain, hptr(x2), hptr(misfit), hptr(grad), hptr(dsyn),
+                                              hptr(flag)))
+        return single, misfit, grad, dsyn, flag.astype(bool)
+
+    def _forward(self, x, quirk=True):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        single = x.ndim == 1
+        x2 = np.atleast_2d(x)
+        nchain, nx = x2.shape
+        ctx = self._ensure(nx // 2)
+        nd = ctx.L.rfs_ndata(ctx.h)
+        dsyn = np.zeros((nchain, nd)); flag = np.zeros(nchain, dtype=np.int32)
+        ctx.check(ctx.L.rfs_joint_forward(ctx.h, nchain, hptr(x2), int(quirk), hptr(dsyn), hptr(flag)))
+        return single, dsyn, flag.astype(bool)
+
+    # ---- device-resident path (torch CUDA tensors in, torch tensors out; no host copies) ----
+    def misfit_and_grad_device(self, x):
+        """x: torch.float64 CUDA tensor [nchain, 2n] -> (misfit, grad, dsyn, flag) CUDA tensors."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.is_contiguous()
+        nchain, nx = x.shape
+        ctx = self._ensure(nx // 2)
+        ctx.check(ctx.L.rfs_set_stream(ctx.h, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        nd = ctx.L.rfs_ndata(ctx.h)
+        misfit = torch.empty(nchain, dtype=torch.float64, device=x.device)
+        grad = torch.empty(nchain, nx, dtype=torch.float64, device=x.device)
+        dsyn = torch.empty(nchain, nd, dtype=torch.float64, device=x.device)
+        flag = torch.empty(nchain, dtype=torch.int32, device=x.device)
+        ctx.check(ctx.L.rfs_joint_misfit_grad_dev(ctx.h, nchain, x.data_ptr(), misfit.data_ptr(), grad.data_ptr(),
+                                                  dsyn.data_ptr(), flag.data_ptr()))
+        return misfit, grad, dsyn, flag

@@ -1,0 +1,58 @@
+// tests/hostsim/hostsim_rf.cpp -- TEST HARNESS ONLY (never shipped, never a fallback).
+// Compiles the device math headers of rfsurfhmc_amd/csrc for the host with g++ so the
+// lane-level algorithms can be checked against the oracle in the CPU-only container.
+// The product path is the HIP library; nothing in rfsurfhmc_amd/ loads this file.
+#include <vector>
+#include "../../rfsurfhmc_amd/csrc/rf_math.hpp"
+
+using namespace rfs;
+
+extern "C" {
+
+// One frequency: R21, R22 and the reference-shaped partials R21_m/R22_m [4][n] (complex as
+// interleaved doubles), computed with the O(n) row/column sweeps of rf_math.hpp.
+void hs_rf_response_par_all(int n, const double* thk, const double* rho, const double* vp,
+                            const double* vs, const double* qa, const double* qb, double p,
+                            double w_re, double w_im, int rf_type, double* R21, double* R22,
+                            double* R21m, double* R22m)
+{
+    std::vector<RfLayer> L(n);
+    for (int j = 0; j < n; j++) rf_make_layer(L[j], thk[j], rho[j], vp[j], vs[j], qa[j], qb[j], p);
+    cplx omega = C(w_re, w_im), k = omega * p;
+    std::vector<V4> rs(n);
+    V4 r = rf_einv_row(L[n - 1], rf_type);
+    for (int j = n - 2; j >= 0; j--) {
+        rs[j] = r;
+        RfHyp H; RfA A;
+        rf_hyp(L[j], omega, H);
+        rf_build_A(L[j], H, A);
+        r = rf_row_times_A(r, A);
+    }
+    int c21 = (rf_type == 1) ? 0 : 1, c22 = (rf_type == 1) ? 1 : 0;
+    cplx r21 = r.v[c21];
+    cplx r22 = (rf_type == 1) ? mul_i(r.v[c22]) : -mul_i(r.v[c22]);
+    R21[0] = r21.re; R21[1] = r21.im; R22[0] = r22.re; R22[1] = r22.im;
+    for (int which = 0; which < 2; which++) {
+        V4 y; for (int i = 0; i < 4; i++) y.v[i] = C(0.0);
+        y.v[which == 0 ? c21 : c22] = C(1.0);
+        double* out = which == 0 ? R21m : R22m;
+        for (int j = 0; j < n; j++) {
+            cplx T[4];
+            if (j < n - 1) {
+                RfHyp H; RfA A;
+                rf_hyp(L[j], omega, H);
+                rf_layer_partials(L[j], H, k, rs[j], y, T);
+                rf_build_A(L[j], H, A);
+                y = rf_A_times_col(A, y);
+            } else {
+                rf_half_partials(L[j], omega, rf_type, y, T);
+            }
+            for (int ip = 0; ip < 4; ip++) {
+                cplx t = T[ip];
+                if (which == 1) t = (rf_type == 1) ? mul_i(t) : -mul_i(t);
+                out[2 * (ip * n + j)] = t.re; out[2 * (ip * n + j) + 1] = t.im;
+            }
+        }
+    }
+}
+}
