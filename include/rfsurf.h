@@ -130,14 +130,21 @@ int rfs_leapfrog_dev(rfs_ctx* ctx, int nchain, const double* x0, const double* p
 
 /* -------- introspection ---------------------------------------------------------------- */
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg of the current joint setup */
-/* Average HIP-event time (ms) of the kernels launched by the last rfs_joint_misfit_grad_dev call
- * when timing was enabled with rfs_enable_timing(ctx, 1); index = rfs_kernel_id. */
+/* Tuning knobs (no effect on results beyond last-bit rounding):
+ *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic, else a power
+ *                          of two <= 64 (1 = the sequential lane-per-chain kernel). */
+int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
+/* Kernel groups of one rfs_joint_misfit_grad_dev call.  With timing enabled every group of every
+ * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on
+ * (the root search / eigenfunction groups run on the context's second stream); nothing
+ * synchronises until rfs_kernel_ms_sum() sums the elapsed times (ms) and launch counts per
+ * group and resets the accumulators. */
 typedef enum {
     RFS_K_PREP = 0, RFS_K_RF_PASS_A, RFS_K_RF_MID, RFS_K_RF_PASS_B, RFS_K_SWD_ROOTS, RFS_K_SWD_EIGEN,
     RFS_K_COMBINE, RFS_K_COUNT
 } rfs_kernel_id;
 int rfs_enable_timing(rfs_ctx* ctx, int on);
-int rfs_last_kernel_ms(rfs_ctx* ctx, float* ms /* [RFS_K_COUNT] */);
+int rfs_kernel_ms_sum(rfs_ctx* ctx, double* ms /* [RFS_K_COUNT] */, int32_t* count /* [RFS_K_COUNT] */);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,28 @@
 
 namespace rfs {
 
+// reciprocal square root: v_rsq_f64 + refinement on the device, 1/sqrt on the host harness
+RFS_HD double rsqrt_p(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return rsqrt(x);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
+// reciprocal to ~1 ulp: hardware estimate + two Newton steps on the device (shorter dependent
+// chain than the IEEE division expansion); plain division on the host harness
+RFS_HD double rcp_p(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = ::fma(::fma(-x, r, 1.0), r, r);
+    r = ::fma(::fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
 struct cplx {
     double re, im;
 };

@@ -41,15 +41,19 @@ struct rfs_ctx {
     double wt = 1.0;
     Buf d_tRc, d_tRg, d_dobs;
     // workspaces
+    int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    Buf mdlc;
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
     // leapfrog state
     Buf lx, lp, lU, lgrad, ldsyn, lflag;
     std::map<std::tuple<int, size_t, int>, FftPlan> plans;
     // timing
+    // timing: every bracketed launch group gets its own event pair, recorded on the stream the
+    // kernels run on; nothing synchronises until rfs_kernel_ms_sum() is called
     bool timing = false;
-    hipEvent_t tev[2 * RFS_K_COUNT] = {};
-    float last_ms[RFS_K_COUNT] = {};
+    std::vector<hipEvent_t> tev[RFS_K_COUNT];
+    size_t tused[RFS_K_COUNT] = {};
 };
 
 namespace {
@@ -128,9 +132,15 @@ int run_fft(rfs_ctx* c, int nft, size_t batch, int inverse, void* in, void* out)
 }
 
 struct KTimer {   // brackets a group of launches with HIP events on the stream they run on
-    rfs_ctx* c; int id; hipStream_t s;
-    KTimer(rfs_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) { if (c->timing) hipEventRecord(c->tev[2 * id], s); }
-    ~KTimer() { if (c->timing) hipEventRecord(c->tev[2 * id + 1], s); }
+    rfs_ctx* c; int id; hipStream_t s; hipEvent_t e1 = nullptr;
+    KTimer(rfs_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
+        if (!c->timing) return;
+        auto& pool = c->tev[id];
+        size_t& u = c->tused[id];
+        while (pool.size() < u + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pool.push_back(e); }
+        hipEventRecord(pool[u], s); e1 = pool[u + 1]; u += 2;
+    }
+    ~KTimer() { if (e1) hipEventRecord(e1, s); }
 };
 
 int check_rf(rfs_ctx* c, const rfs_rf_params* p) {
@@ -240,9 +250,31 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
     ENSURE(c, c->sflag, (size_t)4 * nchain * sizeof(int));
     {
         KTimer t(c, RFS_K_SWD_ROOTS, s);
-        int nthreads = Q.nseq * nchain;
-        hipLaunchKernelGGL(k_swd_roots, dim3((nthreads + 63) / 64), dim3(64), 0, s, nchain, n, Q,
-                           c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>());
+        int nitem = Q.nseq * nchain;
+        int G = c->swd_lanes;
+        if (G <= 0) {           // enough waves to fill the chip, but no more lanes per chain than layers
+            G = 1;
+            while (G < 32 && (size_t)nitem * G < (size_t)4 * 1024 * 64 && 2 * G <= n - 1) G *= 2;
+        }
+        size_t lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
+        while (G > 1 && G < 64 && (lds > 60 * 1024 || (n - 1 + G - 1) / G > 8)) {
+            G *= 2; lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
+        }
+        if (G == 1) {
+            hipLaunchKernelGGL(k_swd_roots, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
+                               c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>());
+        } else {
+            int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
+            dim3 grid((nitem + NG - 1) / NG);
+#define RFS_LAUNCH_SPLIT(LPL)                                                                              \
+            hipLaunchKernelGGL(k_swd_roots_split<LPL>, grid, dim3(64), lds, s, nchain, n, G, Q,             \
+                               c->mdl.as<float>(), c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>())
+            if (lpl <= 1) RFS_LAUNCH_SPLIT(1);
+            else if (lpl <= 2) RFS_LAUNCH_SPLIT(2);
+            else if (lpl <= 4) RFS_LAUNCH_SPLIT(4);
+            else RFS_LAUNCH_SPLIT(8);
+#undef RFS_LAUNCH_SPLIT
+        }
         HIPCHK(c, hipGetLastError());
     }
     if (kernels) {
@@ -278,13 +310,13 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     HIPCHK(c, hipSetDevice(c->device));
     ENSURE(c, c->cr, (size_t)nchain * 2 * n * sizeof(double));
     if (c->has_rf) ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
-    if (c->has_swd) ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float));
+    if (c->has_swd) { ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float)); ENSURE(c, c->mdlc, (size_t)6 * n * nchain * sizeof(double)); }
     {
         KTimer t(c, RFS_K_PREP, c->stream);
         int nth = nchain * n;
         hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, x,
                            (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd,
-                           c->mdl.as<float>());
+                           c->mdl.as<float>(), c->mdlc.as<double>());
         HIPCHK(c, hipGetLastError());
     }
     SwdSeqs Q = make_seqs(c->ntRc, c->d_tRc.as<double>(), c->ntRg, c->d_tRg.as<double>(), true);
@@ -329,7 +361,6 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
               hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; ok && i < 2 * RFS_K_COUNT; i++) ok = hipEventCreate(&c->tev[i]) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
     c->own_stream = true;
     *out = c;
@@ -344,7 +375,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
                    &c->croot, &c->sflag, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
-                   &c->ldsyn, &c->lflag};
+                   &c->ldsyn, &c->lflag, &c->mdlc};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& kv : c->plans) {
         if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
@@ -355,7 +386,7 @@ void rfs_destroy(rfs_ctx* c) {
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
-    for (auto e : c->tev) if (e) hipEventDestroy(e);
+    for (auto& pool : c->tev) for (auto e : pool) hipEventDestroy(e);
     delete c;
 }
 
@@ -375,20 +406,38 @@ int rfs_synchronize(rfs_ctx* c) {
     return RFS_OK;
 }
 
-int rfs_enable_timing(rfs_ctx* c, int on) { if (!c) return RFS_ERR_ARG; c->timing = on != 0; return RFS_OK; }
+int rfs_enable_timing(rfs_ctx* c, int on) {
+    if (!c) return RFS_ERR_ARG;
+    c->timing = on != 0;
+    for (auto& u : c->tused) u = 0;
+    return RFS_OK;
+}
 
-int rfs_last_kernel_ms(rfs_ctx* c, float* ms) {
-    if (!c || !ms) return RFS_ERR_ARG;
+int rfs_kernel_ms_sum(rfs_ctx* c, double* ms, int32_t* count) {
+    if (!c || !ms || !count) return RFS_ERR_ARG;
     TRY(rfs_synchronize(c));
     for (int i = 0; i < RFS_K_COUNT; i++) {
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, c->tev[2 * i], c->tev[2 * i + 1]) != hipSuccess) t = -1.f;
-        ms[i] = t;
+        double tot = 0.0;
+        for (size_t k = 0; k + 1 < c->tused[i]; k += 2) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, c->tev[i][k], c->tev[i][k + 1]) == hipSuccess) tot += t;
+        }
+        ms[i] = tot; count[i] = (int32_t)(c->tused[i] / 2);
+        c->tused[i] = 0;
     }
     return RFS_OK;
 }
 
 int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
+
+int rfs_set_option(rfs_ctx* c, const char* name, int value) {
+    if (!c || !name) return RFS_ERR_ARG;
+    if (!strcmp(name, "swd_lanes_per_chain")) {
+        if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(c, RFS_ERR_ARG, "swd_lanes_per_chain must be 0 or a power of two <= 64");
+        c->swd_lanes = value; return RFS_OK;
+    }
+    return fail(c, RFS_ERR_ARG, std::string("unknown option ") + name);
+}
 
 // ---------------------------------------------------------------- B1 / libsurf
 static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* vp, const double* vs,
@@ -407,9 +456,11 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
     TRY(upload(c, c->b1c, vs, mb)); TRY(upload(c, c->b1d, rho, mb));
     TRY(upload(c, c->bt, period, (size_t)nper * sizeof(double)));
     ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float));
+    ENSURE(c, c->mdlc, (size_t)6 * n * nchain * sizeof(double));
     int nth = nchain * n;
     hipLaunchKernelGGL(k_prep_swd_b1, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->b1a.as<double>(),
-                       c->b1b.as<double>(), c->b1c.as<double>(), c->b1d.as<double>(), c->mdl.as<float>());
+                       c->b1b.as<double>(), c->b1c.as<double>(), c->b1d.as<double>(), c->mdl.as<float>(),
+                       c->mdlc.as<double>());
     bool rg = wavetype == RFS_WAVE_RG;
     // forward "Rg" = _RayleighGroup (surfdisp.cpp:151-173): roots at T only, U from sregn96
     SwdSeqs Q = rg ? make_seqs(0, nullptr, nper, c->bt.as<double>(), kernels) : make_seqs(nper, c->bt.as<double>(), 0, nullptr, false);
@@ -587,10 +638,11 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
     ENSURE(c, c->dsyn, (size_t)nchain * c->ndata * sizeof(double)); ENSURE(c, c->flag, (size_t)nchain * sizeof(int));
     ENSURE(c, c->cr, (size_t)nchain * 2 * n * sizeof(double));
     if (c->has_rf) ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
-    if (c->has_swd) ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float));
+    if (c->has_swd) { ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float)); ENSURE(c, c->mdlc, (size_t)6 * n * nchain * sizeof(double)); }
     int nth = nchain * n;
     hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->x.as<double>(),
-                       (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd, c->mdl.as<float>());
+                       (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd, c->mdl.as<float>(),
+                       c->mdlc.as<double>());
     int nt = c->has_rf ? c->f.nt : 0;
     if (c->has_rf) {
         RfFreq f = c->f; f.fwd_order = 1;

@@ -47,13 +47,23 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// f64 per-layer constants of the split secular function, from the float32-rounded model:
+// mdlc[(m*6 + q)*nchain + chain], q = d, 1/alpha, 1/beta, beta, rho, 1/rho
+__device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int m, int chain, int nchain,
+                                                 float d, float a, float b, float rho)
+{
+    double* o = mdlc + (size_t)m * 6 * nchain + chain;
+    o[0] = (double)d; o[(size_t)nchain] = 1.0 / (double)a; o[(size_t)2 * nchain] = 1.0 / (double)b;
+    o[(size_t)3 * nchain] = (double)b; o[(size_t)4 * nchain] = (double)rho; o[(size_t)5 * nchain] = 1.0 / (double)rho;
+}
+
 // ---------------------------------------------------------------------------------------
 // K_PREP: one thread per (chain, layer).  model_rf.py:52-77 / model_surf.py:47-79 empirical
 // relations, RfLayer constants, float32 SWD model.
 // ---------------------------------------------------------------------------------------
 __global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, int has_rf, double ray_p,
                              RfLayer* __restrict__ lc, double* __restrict__ cr, int has_swd,
-                             float* __restrict__ mdl)
+                             float* __restrict__ mdl, double* __restrict__ mdlc)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * n) return;
@@ -73,6 +83,7 @@ __global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, in
         mdl[1 * s + (size_t)j * nchain + chain] = (float)vp;
         mdl[2 * s + (size_t)j * nchain + chain] = (float)vs;
         mdl[3 * s + (size_t)j * nchain + chain] = (float)rho;
+        swd_store_layerc(mdlc, j, chain, nchain, (float)thk, (float)vp, (float)vs, (float)rho);
     }
 }
 
@@ -87,7 +98,7 @@ __global__ void k_prep_rf_b1(int nchain, int n, const double* thk, const double*
 }
 
 __global__ void k_prep_swd_b1(int nchain, int n, const double* thk, const double* vp, const double* vs,
-                              const double* rho, float* __restrict__ mdl)
+                              const double* rho, float* __restrict__ mdl, double* __restrict__ mdlc)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * n) return;
@@ -95,6 +106,7 @@ __global__ void k_prep_swd_b1(int nchain, int n, const double* thk, const double
     size_t s = (size_t)n * nchain, o = (size_t)j * nchain + chain;
     mdl[0 * s + o] = (float)thk[g]; mdl[1 * s + o] = (float)vp[g];
     mdl[2 * s + o] = (float)vs[g];  mdl[3 * s + o] = (float)rho[g];
+    swd_store_layerc(mdlc, j, chain, nchain, (float)thk[g], (float)vp[g], (float)vs[g], (float)rho[g]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -408,6 +420,84 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
         }
     }
     if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
+}
+
+// K3 (split): G lanes per (sequence, chain).  Every lane of a group runs the same search state
+// machine (identical inputs -> identical state, no broadcast needed); per secular-function
+// evaluation the group's lanes share the layer loop: lane g builds the vector-independent part
+// (15 numbers) of layers g, g+G, ... into LDS, then every lane runs the short sequential
+// vector recurrence reading the group's entries back (LDS broadcast).  This cuts the serial
+// instruction count per evaluation ~G-fold where it matters (sqrt/sincos/exp live in the
+// layer part) and turns 128 latency-bound waves into 128*G waves.
+template <int LPL>   // layers per lane held in registers: (n-1) <= G*LPL
+__global__ void __launch_bounds__(64)
+k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__ mdl,
+                  const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
+{
+    extern __shared__ double ent_lds[];          // [(m*15 + i)*NG + grp]
+    const int NG = 64 / G;
+    const int lane = threadIdx.x, grp = lane / G, lg = lane - grp * G;
+    int item = blockIdx.x * NG + grp;            // (sequence, chain) handled by this group
+    int seq = item / nchain, chain = item - seq * nchain;
+    bool live = seq < Q.nseq;
+    if (!live) { seq = 0; chain = 0; }
+    const size_t s = (size_t)n * nchain;
+    SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+    const SwdSeq sq = Q.s[seq];
+    const double* tp = sq.t; const double sc = sq.scale;
+    auto T = [&](int k) { return tp[k] * sc; };
+    double* cr = croot + (size_t)sq.croot_off * nchain + chain;
+    const bool writer = live && lg == 0;
+    auto out = [&](int k, double v) { if (writer) cr[(size_t)k * nchain] = v; };
+    RootSearch rs;
+    rs.begin(M, T, sq.nper);
+    if (!live) rs.done = 1;
+    const double* lc0 = mdlc + chain;
+    auto loadL = [&](int m) {
+        const double* o = lc0 + (size_t)m * 6 * nchain;
+        return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                         o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+    };
+    const SwdLayerC Lhalf = loadL(n - 1);
+    SwdLayerC Lmine[LPL];                        // this lane's layers lg, lg+G, ... stay in registers
+#pragma unroll
+    for (int q = 0; q < LPL; q++) { int m = lg + q * G; Lmine[q] = loadL(m < n - 1 ? m : n - 2); }
+    while (__any(!rs.done)) {
+        double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
+        double wvno = rs.omega / rs.creq, wvno2 = wvno * wvno, iomega = 1.0 / omega;
+        if (!rs.done) {
+#pragma unroll
+            for (int q = 0; q < LPL; q++) {
+                int m = lg + q * G;
+                if (m < n - 1) {
+                    double ent[SWD_NENT];
+                    swd_layer_entries(Lmine[q], wvno, wvno2, omega, iomega, ent);
+#pragma unroll
+                    for (int i = 0; i < SWD_NENT; i++) ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp] = ent[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (!rs.done) {
+            double e[5];
+            swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+            const double tt = -2.0 * wvno2;
+            double cur[SWD_NENT], nxt[SWD_NENT];
+#pragma unroll
+            for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)((n - 2) * SWD_NENT + i) * NG + grp];
+            for (int m = n - 2; m >= 0; m--) {
+                int mp = m > 0 ? m - 1 : 0;             // prefetch the next layer's entries
+#pragma unroll
+                for (int i = 0; i < SWD_NENT; i++) nxt[i] = ent_lds[(size_t)(mp * SWD_NENT + i) * NG + grp];
+                swd_apply_layer(e, cur, tt);
+#pragma unroll
+                for (int i = 0; i < SWD_NENT; i++) cur[i] = nxt[i];
+            }
+            rs.advance(e[0], T, out);
+        }
+        __syncthreads();
+    }
+    if (writer) sflag[(size_t)seq * nchain + chain] = rs.flag;
 }
 
 // ---------------------------------------------------------------------------------------

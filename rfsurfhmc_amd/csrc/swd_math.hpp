@@ -140,6 +140,93 @@ RFS_HD double swd_secular(const SwdModel& M, double wvno, double omga) {
     return e0;
 }
 
+// ---------------------------------------------------------------------------
+// Split form of the same secular function for "several lanes per chain" root searches:
+//   swd_layer_entries  -- everything of one layer that does NOT depend on the propagated
+//                         vector (var + dnka): 15 numbers, computed by any lane;
+//   swd_halfspace_e    -- the half-space start vector;
+//   swd_apply_layer    -- e <- normc(e . CA), the only sequential part (25 FMA + normalise).
+// Divisions are replaced by per-layer reciprocals (SwdLayerC) and rsqrt; results agree with
+// swd_secular to a few ulp (the root search only needs the sign and the smooth magnitude).
+// ---------------------------------------------------------------------------
+struct SwdLayerC { double d, ia, ib, b, rho, irho; };   // thickness, 1/alpha, 1/beta, beta, rho, 1/rho
+
+constexpr int SWD_NENT = 15;
+
+RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, double& cosx, double& w, double& x) {
+    // var (surfdisp96.f:941-1002) for one wave type: returns cos, sin/r, +-r*sin and the exponent
+    double v = (wvno + xk) * fabs(wvno - xk);
+    if (wvno == xk) { cosx = 1.0; w = dpth; x = 0.0; ex = 0.0; return; }
+    double ir = rsqrt_p(v), r = v * ir, p = r * dpth;
+    if (wvno < xk) {
+        double s, c; sincos(p, &s, &c);
+        w = s * ir; x = -r * s; cosx = c; ex = 0.0;
+    } else {
+        double fac = (p < 16.0) ? exp(-2.0 * p) : 0.0;
+        cosx = (1.0 + fac) * 0.5;
+        double sh = (1.0 - fac) * 0.5;
+        w = sh * ir; x = r * sh; ex = p;
+    }
+}
+
+RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega,
+                              double ent[SWD_NENT]) {
+    double xka = omega * L.ia, xkb = omega * L.ib;
+    double t = L.b * iomega;
+    double gammk = 2.0 * t * t, gam = gammk * wvno2;
+    double pex, sex, cosp, w, x, cosq, y, z;
+    swd_trig_split(wvno, xka, L.d, pex, cosp, w, x);
+    swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z);
+    double exa = pex + sex;
+    double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+    double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
+    double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
+    double gamm1 = gam - 1.0, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1;
+    double gm1sq = gamm1 * gamm1, rho = L.rho, ir = L.irho, rho2 = rho * rho, ir2 = ir * ir, a0pq = a0 - cpcq;
+    double c11 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - wvno2 * gm1sq * wy;
+    ent[0] = c11;
+    ent[1] = (wvno2 * cpy - cqx) * ir;                                              // c12
+    ent[2] = -(twgm1 * a0pq + gammk * xz + wvno2 * gamm1 * wy) * ir;                // c13
+    ent[3] = (cpz - wvno2 * cqw) * ir;                                              // c14
+    ent[4] = -(2.0 * wvno2 * a0pq + xz + wvno2 * wvno2 * wy) * ir2;                 // c15
+    ent[5] = (gmgmk * cpz - gm1sq * cqw) * rho;                                     // c21
+    ent[6] = cpcq;                                                                  // c22
+    ent[7] = gammk * cpz - gamm1 * cqw;                                             // c23
+    ent[8] = -wz;                                                                   // c24
+    ent[9] = (gm1sq * cpy - gmgmk * cqx) * rho;                                     // c41
+    ent[10] = -xy;                                                                  // c42
+    ent[11] = gamm1 * cpy - gammk * cqx;                                            // c43
+    ent[12] = -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;          // c51
+    ent[13] = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) * rho;    // c53
+    ent[14] = a0 + 2.0 * (cpcq - c11);                                              // c33
+}
+
+RFS_HD void swd_halfspace_e(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double e[5]) {
+    double xka = omega * L.ia, xkb = omega * L.ib;
+    double ra = sqrt((wvno + xka) * fabs(wvno - xka));
+    double rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
+    double t = L.b * iomega;
+    double gammk = 2.0 * t * t, gam = gammk * wvno2, gamm1 = gam - 1.0, rho1 = L.rho;
+    e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+    e[1] = -rho1 * ra;
+    e[2] = rho1 * (gamm1 - gammk * ra * rb);
+    e[3] = rho1 * rb;
+    e[4] = wvno2 - ra * rb;
+}
+
+RFS_HD void swd_apply_layer(double e[5], const double c[SWD_NENT], double tt /* -2 wvno^2 */) {
+    double e2t = e[2] * tt;
+    double n0 = e[0] * c[0] + e[1] * c[5] + e2t * c[13] + e[3] * c[9] + e[4] * c[12];
+    double n1 = e[0] * c[1] + e[1] * c[6] + e2t * c[11] + e[3] * c[10] + e[4] * c[9];
+    double n2 = e[0] * c[2] + e[1] * c[7] + e[2] * c[14] + e[3] * c[11] + e[4] * c[13];
+    double n3 = e[0] * c[3] + e[1] * c[8] + e2t * c[7] + e[3] * c[6] + e[4] * c[5];
+    double n4 = e[0] * c[4] + e[1] * c[3] + e2t * c[2] + e[3] * c[1] + e[4] * c[0];
+    double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    double it1 = rcp_p(t1);
+    e[0] = n0 * it1; e[1] = n1 * it1; e[2] = n2 * it1; e[3] = n3 * it1; e[4] = n4 * it1;
+}
+
 // surfdisp96.f:375-396  gtsolh (single precision throughout)
 RFS_HD float swd_gtsolh(float a, float b) {
     float c = 0.95f * b;

@@ -86,3 +86,26 @@ class FusedPlugin:
         ctx.check(ctx.L.rfs_joint_misfit_grad_dev(ctx.h, nchain, x.data_ptr(), misfit.data_ptr(), grad.data_ptr(),
                                                   dsyn.data_ptr(), flag.data_ptr()))
         return misfit, grad, dsyn, flag
+
+    def leapfrog_device(self, x0, p0, dt, L, bounds):
+        """Device-resident leapfrog trajectories (pyhmc/hmc.py:140-190) for all chains at once.
+
+        x0, p0: float64 CUDA [nchain, 2n]; dt: float64 CUDA [nchain]; L: int32 CUDA [nchain];
+        bounds: float64 CUDA [2n, 2].  Returns dict(xnew, Ucur, Unew, Hcur, Hnew, dsyn_cur, dsyn_new, ok)."""
+        import torch
+        nchain, nx = x0.shape
+        ctx = self._ensure(nx // 2)
+        dev = x0.device
+        ctx.check(ctx.L.rfs_set_stream(ctx.h, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        nd = ctx.L.rfs_ndata(ctx.h)
+        f64 = dict(dtype=torch.float64, device=dev)
+        out = dict(xnew=torch.empty(nchain, nx, **f64), Ucur=torch.empty(nchain, **f64),
+                   Unew=torch.empty(nchain, **f64), Hcur=torch.empty(nchain, **f64),
+                   Hnew=torch.full((nchain,), float("inf"), **f64), dsyn_cur=torch.empty(nchain, nd, **f64),
+                   dsyn_new=torch.empty(nchain, nd, **f64), ok=torch.empty(nchain, dtype=torch.int32, device=dev))
+        Lmax = int(L.max().item())
+        ctx.check(ctx.L.rfs_leapfrog_dev(ctx.h, nchain, x0.data_ptr(), p0.data_ptr(), dt.data_ptr(), L.data_ptr(),
+                                         Lmax, bounds.data_ptr(), out["xnew"].data_ptr(), out["Ucur"].data_ptr(),
+                                         out["Unew"].data_ptr(), out["Hcur"].data_ptr(), out["Hnew"].data_ptr(),
+                                         out["dsyn_cur"].data_ptr(), out["dsyn_new"].data_ptr(), out["ok"].data_ptr()))
+        return out

@@ -1,0 +1,124 @@
+"""HamitonianMC -- batched mirror of the reference sampler pyhmc/hmc.py.
+
+Same constructor arguments, ``init(model, boundaries, rank, **hmc_block)`` keys and ``sample()``
+contract; additionally ``nchains`` chains advance together, each trajectory running on the GPU
+through rfs_leapfrog_dev (leapfrog + mirror + misfit/gradient, nothing returns to the host
+inside a trajectory).  Chain c of a sampler created with ``myrank=r`` reproduces the reference's
+MPI rank ``r*nchains + c``: same RNG stream (seed + rank), same draw order per iteration --
+randint(L), randn(n)*0.5, [trajectory], rand() -- and the rand() is skipped when the trajectory
+fails, as in the reference (hmc.py:156,173,177,179)."""
+import sys
+
+import numpy as np
+
+from ._batched import ChainRNG, initial_models, save_chain_results
+
+
+class HamitonianMC:
+    def __init__(self, UserDefinedModel, boundaries, dt, Lrange, nbest_model, seed, nsamples, ndraws,
+                 myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True):
+        self.myrank = myrank
+        self.nchains = int(nchains)
+        self.first_chain = myrank * self.nchains
+        self.seed = seed
+        self.boundaries = np.asarray(boundaries, dtype=np.float64)
+        self.Lrange = Lrange
+        self.dt = dt
+        self.model = UserDefinedModel
+        self.nbest_model = nbest_model
+        self.nsamples = nsamples
+        self.ndraws = ndraws
+        self.name, self.outdir = name, outdir
+        self.store_syn, self.verbose = store_syn, verbose
+        self.rng = ChainRNG(seed, self.first_chain, self.nchains)
+        self.ii = 0
+        self.trace = None          # optional list collecting per-iteration records (tests)
+
+    @classmethod
+    def init(cls, UserDefinedModel, boundaries, rank, **kargs):
+        """pyhmc/hmc.py:63-72 (+ optional key ``nchains``)."""
+        return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["Lrange"], kargs["nbest"], kargs["seed"],
+                   kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
+                   nchains=kargs.get("nchains", 1))
+
+    def _device(self):
+        import torch
+        return torch.device("cuda", getattr(self.model, "device", 0) or 0)
+
+    def _leapfrog(self, x, active, L):
+        """One trajectory for the chains in ``active`` (pyhmc/hmc.py:140-201).  Returns per-chain
+        (xnew, U, dsyn, accept) with the reference's failure return (xcur, inf, dobs, False)."""
+        import torch
+        dev = self._device()
+        n = x.shape[1]
+        p0 = self.rng.randn(active, n) * 0.5                                  # hmc.py:146
+        xd = torch.from_numpy(np.ascontiguousarray(x[active])).to(dev)
+        pd = torch.from_numpy(np.ascontiguousarray(p0)).to(dev)
+        dtd = torch.full((len(active),), float(self.dt), dtype=torch.float64, device=dev)
+        Ld = torch.from_numpy(np.ascontiguousarray(L)).to(dev)
+        bd = torch.from_numpy(np.ascontiguousarray(self.boundaries)).to(dev)
+        out = self.model.leapfrog_device(xd, pd, dtd, Ld, bd)
+        ok = out["ok"].cpu().numpy().astype(bool)
+        Hcur, Hnew = out["Hcur"].cpu().numpy(), out["Hnew"].cpu().numpy()
+        xnew, Unew = out["xnew"].cpu().numpy(), out["Unew"].cpu().numpy()
+        Ucur = out["Ucur"].cpu().numpy()
+        dnew, dcur = out["dsyn_new"].cpu().numpy(), out["dsyn_cur"].cpu().numpy()
+        u = np.full(len(active), np.nan)
+        u[ok] = self.rng.rand([active[i] for i in np.nonzero(ok)[0]])        # hmc.py:193, skipped on failure
+        with np.errstate(over="ignore", invalid="ignore"):
+            accept = ok & (u < np.exp(-(Hnew - Hcur)))
+        xres = np.where(accept[:, None], xnew, x[active])
+        Ures = np.where(accept, Unew, np.where(ok, Ucur, np.inf))
+        dres = np.where(accept[:, None], dnew, np.where(ok[:, None], dcur, self.model.dobs[None, :]))
+        if self.trace is not None:
+            self.trace.append(dict(active=list(active), L=L.copy(), p0=p0, xend=xnew, Unew=Unew, Hcur=Hcur,
+                                   Hnew=Hnew, u=u, ok=ok, accept=accept))
+        return xres, Ures, dres, accept
+
+    def sample(self, x_init=None):
+        """pyhmc/hmc.py:228-276.  Returns misfit[nsamples] (nchains == 1) or [nchains, nsamples]."""
+        nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+        self.initmodel = x.copy()
+        nx = x.shape[1]
+        ndata = self.model.dobs.shape[0]
+        misfit = np.zeros((nc, ns))
+        x_cache = np.zeros((nc, ns, nx))
+        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+        i = np.zeros(nc, dtype=int)
+        ncount = np.zeros(nc, dtype=int)
+        total = nd_ + ns
+        U = np.zeros(nc)
+        while np.any(i < total):
+            active = [c for c in range(nc) if i[c] < total]
+            L = self.rng.randint(active, self.Lrange[0], self.Lrange[1] + 1)  # hmc.py:248
+            xa, Ua, da, acc = self._leapfrog(x, active, L)
+            for k, c in enumerate(active):
+                x[c] = xa[k]; U[c] = Ua[k]
+                if acc[k]:
+                    if i[c] >= nd_:
+                        misfit[c, i[c] - nd_] = Ua[k]
+                        x_cache[c, i[c] - nd_] = xa[k]
+                        if syndata is not None:
+                            syndata[c, i[c] - nd_] = da[k]
+                    i[c] += 1
+                    self.ii += 1
+                ncount[c] += 1
+                if self.verbose and (i[c] % 50 == 0 or i[c] == ns - 1):
+                    print("chain {}: {:.2%}, misfit={:.3} -- accept ratio {:.2%}".format(
+                        self.first_chain + c, i[c] / total, U[c], i[c] / ncount[c]))
+                    sys.stdout.flush()
+        self.accept_ratio = i / np.maximum(ncount, 1)
+        # mean of the nbest lowest-misfit samples, one more evaluation (hmc.py:266-275)
+        xmean = np.zeros((nc, nx))
+        for c in range(nc):
+            idx = np.argsort(misfit[c])
+            xmean[c] = np.mean(x_cache[c, idx[:self.nbest_model]], axis=0)
+        res = self.model.misfit_and_grad(xmean)
+        synmean = res[2]
+        self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
+        if self.outdir is not None:
+            for c in range(nc):
+                save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c], self.model.dobs,
+                                   xmean[c], synmean[c], x_cache[c], None if syndata is None else syndata[c])
+        return misfit[0] if nc == 1 else misfit

@@ -1,0 +1,174 @@
+"""HMCDualAveraging -- batched mirror of the reference sampler pyhmc/hmcda.py (HMC with
+dual-averaging step-size adaptation).  Per-chain dt and L = max(1, int(lambda/dt)) are handled by
+the device trajectory (rfs_leapfrog_dev takes dt[chain], L[chain]).  Draw order per chain and
+iteration as in the reference: randn(n)*0.5, [trajectory], rand() -- the rand() is always drawn
+(hmcda.py:311)."""
+import sys
+
+import numpy as np
+
+from ._batched import ChainRNG, initial_models, save_chain_results
+
+
+def _mirror(x, p, boundaries):
+    """pyhmc/hmcda.py:152-168 on [nchain, n] arrays."""
+    x, p = x.copy(), p.copy()
+    high, low = boundaries[:, 1][None, :], boundaries[:, 0][None, :]
+    idx1, idx2 = x > high, x < low
+    while np.any(idx1 | idx2):
+        x = np.where(idx1, 2 * high - x, x); p = np.where(idx1, -p, p)
+        idx2 = x < low
+        x = np.where(idx2, 2 * low - x, x); p = np.where(idx2, -p, p)
+        idx1, idx2 = x > high, x < low
+    return x, p
+
+
+class HMCDualAveraging:
+    def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
+                 myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True):
+        self.model = UserDefinedModel
+        self.boundaries = np.asarray(boundaries, dtype=np.float64)
+        self.dt, self.L = dt, L0
+        self.nbest_model, self.nsamples, self.ndraws = nbest_model, nsamples, ndraws
+        if ndraws < 0.1 * nsamples:                                           # hmcda.py:57-60
+            raise ValueError(f"in dual averaging, ndraws should > nsamples * 0.1 (ndraws = {ndraws}, nsamples = {nsamples})")
+        self.myrank, self.nchains = myrank, int(nchains)
+        self.first_chain = myrank * self.nchains
+        self.seed, self.name, self.outdir = seed, name, outdir
+        self.store_syn, self.verbose = store_syn, verbose
+        self.delta = target_ratio                                             # hmcda.py:70-76
+        self._h0, self._gamma, self._t0, self._kappa = 0.0, 0.05, 10.0, 0.75
+        self._lambda = L0 * self.dt
+        self.rng = ChainRNG(seed, self.first_chain, self.nchains)
+        self.ii = 0
+        self.trace = None
+
+    @classmethod
+    def init(cls, UserDefinedModel, boundaries, rank, **kargs):
+        """pyhmc/hmcda.py:84-97 (+ optional key ``nchains``)."""
+        return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["L0"], kargs["nbest"], kargs["target_ratio"],
+                   kargs["seed"], kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
+                   nchains=kargs.get("nchains", 1))
+
+    def _device(self):
+        import torch
+        return torch.device("cuda", getattr(self.model, "device", 0) or 0)
+
+    def _find_initial_dt(self, dt0, x):
+        """pyhmc/hmcda.py:170-220, all chains at once (masked): in effect dt is doubled while the
+        one-step acceptance stays above 0.5, at most 20 times."""
+        nc, n = x.shape
+        idx = list(range(nc))
+        xcur = x.copy()
+        dt = np.full(nc, float(dt0))
+        pcur = self.rng.randn(idx, n) * 0.5
+        U, grad, _, flag = self.model.misfit_and_grad(xcur)
+        Hcur = U + 0.5 * np.sum(pcur * pcur, axis=1)
+        a = np.zeros(nc)
+        pcur = pcur - 0.5 * dt[:, None] * grad
+        live = np.ones(nc, dtype=bool)
+        for it in range(20):
+            xn, pn = _mirror(xcur + dt[:, None] * pcur, pcur, self.boundaries)
+            xcur = np.where(live[:, None], xn, xcur); pcur = np.where(live[:, None], pn, pcur)
+            U, grad, _, flag = self.model.misfit_and_grad(xcur)
+            if np.any(live & ~flag):
+                raise RuntimeError("error in chain %d!" % (self.first_chain + int(np.nonzero(live & ~flag)[0][0])))
+            pcur = np.where(live[:, None], pcur - 0.5 * dt[:, None] * grad, pcur)
+            Hnew = U + 0.5 * np.sum(pcur * pcur, axis=1)
+            ediff = -(Hnew - Hcur)
+            if it == 0:
+                a = 2.0 * (ediff > np.log(0.5)) - 1.0
+            stop = live & (ediff < np.log(0.5))
+            go = live & ~stop
+            pcur = np.where(go[:, None], pcur - 0.5 * dt[:, None] * grad, pcur)
+            Hcur = np.where(go, Hnew, Hcur)
+            dt = np.where(go, dt * 2.0 ** a, dt)
+            live = go
+            if not live.any():
+                break
+        if self.verbose:
+            for c in range(nc):
+                print(f"chain {self.first_chain + c}: change dt from {dt0} to {dt[c]}")
+        return dt
+
+    def _leapfrog(self, x, dt, L):
+        """pyhmc/hmcda.py:222-278 for all chains: returns (xnew, Unew, dsyn_new, alpha)."""
+        import torch
+        dev = self._device()
+        nc, n = x.shape
+        idx = list(range(nc))
+        p0 = self.rng.randn(idx, n) * 0.5
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        out = self.model.leapfrog_device(t(x), t(p0), t(dt.astype(np.float64)), t(L.astype(np.int32)), t(self.boundaries))
+        ok = out["ok"].cpu().numpy().astype(bool)
+        Hcur, Hnew = out["Hcur"].cpu().numpy(), out["Hnew"].cpu().numpy()
+        with np.errstate(over="ignore", invalid="ignore"):
+            alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
+        xnew = np.where(ok[:, None], out["xnew"].cpu().numpy(), x)
+        Unew = np.where(ok, out["Unew"].cpu().numpy(), np.inf)
+        dnew = np.where(ok[:, None], out["dsyn_new"].cpu().numpy(), self.model.dobs[None, :])
+        if self.trace is not None:
+            self.trace.append(dict(L=L.copy(), dt=dt.copy(), p0=p0, xend=xnew.copy(), Unew=Unew.copy(), Hcur=Hcur,
+                                   Hnew=Hnew, alpha=alpha.copy(), ok=ok))
+        return xnew, Unew, dnew, alpha
+
+    def sample(self, x_init=None):
+        """pyhmc/hmcda.py:280-369."""
+        nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+        self.initmodel = x.copy()
+        nx = x.shape[1]
+        ndata = self.model.dobs.shape[0]
+        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+        dt = self._find_initial_dt(self.dt, x)
+        dtbar = dt * 1.0
+        h0 = np.full(nc, self._h0)
+        mu = np.log(10 * self.dt)
+        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        total = nd_ + ns
+        idx_all = list(range(nc))
+        while np.any(i < total):
+            live = i < total
+            L = np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)     # hmcda.py:307
+            x1, U, dsyn, alpha = self._leapfrog(x, dt, L)
+            u = self.rng.rand(idx_all)
+            acc = live & (u < alpha)
+            for c in np.nonzero(acc)[0]:
+                x[c] = x1[c]
+                if i[c] >= nd_:
+                    misfit[c, i[c] - nd_] = U[c]; x_cache[c, i[c] - nd_] = x1[c]
+                    if syndata is not None:
+                        syndata[c, i[c] - nd_] = dsyn[c]
+                i[c] += 1; self.ii += 1
+            # dual averaging (hmcda.py:329-345)
+            adapt = live & (ncount < nd_)
+            m = ncount + 1.0
+            fac = 1.0 / (m + self._t0)
+            h_new = (1 - fac) * h0 + fac * (self.delta - alpha)
+            logdt = mu - np.sqrt(m) / self._gamma * h_new
+            fac2 = m ** (-self._kappa)
+            dtbar_new = np.exp(fac2 * logdt + (1 - fac2) * np.log(dtbar))
+            h0 = np.where(adapt, h_new, h0)
+            dt = np.where(adapt, np.exp(logdt), np.where(live, dtbar, dt))
+            dtbar = np.where(adapt, dtbar_new, dtbar)
+            ncount = ncount + live
+            if self.verbose:
+                for c in np.nonzero(live)[0]:
+                    if i[c] % 50 == 0 or i[c] == ns - 1:
+                        print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
+                            self.first_chain + c, i[c] / total, dt[c], U[c], i[c] / ncount[c]))
+                sys.stdout.flush()
+        self.dt_final, self.accept_ratio = dt, i / np.maximum(ncount, 1)
+        nbests = 10                                                           # hard-coded, hmcda.py:359
+        xmean = np.zeros((nc, nx))
+        for c in range(nc):
+            idx = np.argsort(misfit[c])
+            xmean[c] = np.mean(x_cache[c, idx[:nbests]], axis=0)
+        synmean = self.model.misfit_and_grad(xmean)[2]
+        self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
+        if self.outdir is not None:
+            for c in range(nc):
+                save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c], self.model.dobs,
+                                   xmean[c], synmean[c], x_cache[c], None if syndata is None else syndata[c])
+        return misfit[0] if nc == 1 else misfit

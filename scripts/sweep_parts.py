@@ -1,0 +1,34 @@
+"""Standalone timings: RF-only plugin, SWD-only plugin for several lanes-per-chain, joint."""
+import sys, time, ctypes; sys.path.insert(0, '.')
+import numpy as np, torch
+import bench
+from rfsurfhmc_amd._lib import K_NAMES
+from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+from rfsurfhmc_amd.model.model_surf import SurfWD
+from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+nchain = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+t = np.linspace(5, 44, 40)
+rf = ReceiverFunc(0.045, 512, 0.1, 1.5, 5.0, 0.001, "P", "freq"); swd = SurfWD(tRc=t)
+joint = Joint_RF_SWD(1.0, 1.0, rf, swd)
+drf, dswd, flag = joint.forward(bench.true_model()); joint.set_obsdata(drf, dswd)
+x = torch.from_numpy(bench.make_models(nchain, 991206)).cuda()
+def run(model, label, G=None, reps=5):
+    ctx = model._ensure(30)
+    if G is not None: ctx.check(ctx.L.rfs_set_option(ctx.h, b"swd_lanes_per_chain", G))
+    for _ in range(2): out = model.misfit_and_grad_device(x)
+    torch.cuda.synchronize(); ctx.L.rfs_synchronize(ctx.h)
+    ctx.L.rfs_enable_timing(ctx.h, 1)
+    t0 = time.perf_counter()
+    for _ in range(reps): out = model.misfit_and_grad_device(x)
+    ctx.L.rfs_synchronize(ctx.h); torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    ms = np.zeros(7); cnt = np.zeros(7, dtype=np.int32)
+    ctx.L.rfs_kernel_ms_sum(ctx.h, ms.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p))
+    ctx.L.rfs_enable_timing(ctx.h, 0)
+    print(f"{label:14s} step {el*1e3:7.2f} ms  {nchain/el:10.0f} evals/s  " +
+          " ".join(f"{k}={ms[i]/max(cnt[i],1):.2f}" for i, k in enumerate(K_NAMES) if cnt[i]))
+run(rf, "RF only")
+for G in (1, 4, 8, 16):
+    run(swd, f"SWD only G={G}", G)
+for G in (1, 8):
+    run(joint, f"joint G={G}", G)

@@ -23,6 +23,32 @@ int hs_swd_rootsearch(int n, const float* thk, const float* vp, const float* vs,
     return rs.flag;
 }
 
+// same search driven by the split secular function (what the multi-lane GPU kernel evaluates)
+int hs_swd_rootsearch_split(int n, const float* thk, const float* vp, const float* vs, const float* rho,
+                            int kmax, const double* t, double* cg, long* nsec)
+{
+    SwdModel M{thk, vp, vs, rho, 1, n};
+    std::vector<SwdLayerC> LC(n);
+    for (int m = 0; m < n; m++)
+        LC[m] = SwdLayerC{(double)thk[m], 1.0 / (double)vp[m], 1.0 / (double)vs[m], (double)vs[m], (double)rho[m], 1.0 / (double)rho[m]};
+    RootSearch rs;
+    auto T = [&](int k) { return t[k]; };
+    auto out = [&](int k, double v) { cg[k] = v; };
+    rs.begin(M, T, kmax);
+    while (!rs.done) {
+        double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega, wvno = rs.omega / rs.creq;
+        double wvno2 = wvno * wvno, iomega = 1.0 / omega, e[5], ent[SWD_NENT];
+        swd_halfspace_e(LC[n - 1], wvno, wvno2, omega, iomega, e);
+        for (int m = n - 2; m >= 0; m--) {
+            swd_layer_entries(LC[m], wvno, wvno2, omega, iomega, ent);
+            swd_apply_layer(e, ent, -2.0 * wvno2);
+        }
+        rs.advance(e[0], T, out);
+    }
+    if (nsec) *nsec = rs.nsec;
+    return rs.flag;
+}
+
 // sregn96 equivalent: scaled kernels, dcdh suffix-summed; returns group velocity
 double hs_sregn96(int n, const float* thk, const float* vp, const float* vs, const float* rho,
                   double t, double cp, double* dcda, double* dcdb, double* dcdh, double* dcdr)
