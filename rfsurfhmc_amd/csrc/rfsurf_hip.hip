@@ -252,15 +252,32 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         int nitem = Q.nseq * nchain;
         int G = c->swd_lanes;
-        if (G <= 0) {           // enough waves to fill the chip, but no more lanes per chain than layers
-            G = 1;
-            while (G < 32 && (size_t)nitem * G < (size_t)4 * 1024 * 64 && 2 * G <= n - 1) G *= 2;
+        if (G <= 0) {           // about one wave per SIMD (1024 of them): G = 65536 / items, within [4, 32]
+            G = 4;
+            while (G < 32 && (size_t)nitem * G * 2 <= 65536 && 2 * G <= n - 1) G *= 2;
         }
         size_t lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
         while (G > 1 && G < 64 && (lds > 60 * 1024 || (n - 1 + G - 1) / G > 8)) {
             G *= 2; lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
         }
-        if (G == 1) {
+        if (c->swd_lanes == 0 && nitem >= 1024 && n - 1 <= 16 * COOP_NP) {
+            // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
+            int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
+            size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64) * sizeof(double);
+            dim3 grid((nitem + 63) / 64);
+#define RFS_LAUNCH_COOP(NCH)                                                                                   \
+            do {                                                                                               \
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NCH>,                              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));          \
+                hipLaunchKernelGGL(k_swd_roots_coop<NCH>, grid, dim3(512), lds2, s, nchain, n, Q,               \
+                                   c->mdl.as<float>(), c->mdlc.as<double>(), c->croot.as<double>(),             \
+                                   c->sflag.as<int>());                                                         \
+            } while (0)
+            if (nch <= 5) RFS_LAUNCH_COOP(5);
+            else if (nch <= 8) RFS_LAUNCH_COOP(8);
+            else RFS_LAUNCH_COOP(16);
+#undef RFS_LAUNCH_COOP
+        } else if (G == 1) {
             hipLaunchKernelGGL(k_swd_roots, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
                                c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>());
         } else {

@@ -500,6 +500,103 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
     if (writer) sflag[(size_t)seq * nchain + chain] = rs.flag;
 }
 
+// K3 (cooperative): one 512-thread block = 64 (sequence, chain) items.  Wave 0 is the CONSUMER:
+// lane = item, it owns the search state machines and runs the short sequential vector recurrence.
+// Waves 1..7 are PRODUCERS: wave p builds, for all 64 items at once (lane = item, so every lane of
+// a wave works on the same layer index -> little branch divergence, coalesced constants), the
+// vector-independent entries of one layer per chunk of 7 layers into a double-buffered LDS ring,
+// one chunk ahead of the consumer.  Nothing is computed twice, and the serial path per secular
+// evaluation shrinks to (one layer's entries) + (the 25-FMA recurrence over all layers).
+constexpr int COOP_NP = 7;                       // producer waves = layers per chunk
+template <int NCH>                               // chunks held in registers: (n-1) <= NCH*COOP_NP
+__global__ void __launch_bounds__(512)
+k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
+                 const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
+{
+    extern __shared__ double lds[];
+    double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
+    int* go = (int*)(lds + 4 * 64);              // block-wide "another evaluation follows"
+    double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][15][64]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int item = blockIdx.x * 64 + lane;
+    int seq = item / nchain, chain = item - seq * nchain;
+    const bool live = seq < Q.nseq;
+    if (!live) { seq = 0; chain = 0; }
+    const int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
+    const double* lc0 = mdlc + chain;
+    auto loadL = [&](int m) {
+        const double* o = lc0 + (size_t)m * 6 * nchain;
+        return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                         o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+    };
+    if (wave == 0) {
+        const size_t s = (size_t)n * nchain;
+        SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        const SwdSeq sq = Q.s[seq];
+        const double* tp = sq.t; const double sc = sq.scale;
+        auto T = [&](int k) { return tp[k] * sc; };
+        double* cr = croot + (size_t)sq.croot_off * nchain + chain;
+        auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
+        RootSearch rs;
+        rs.begin(M, T, sq.nper);
+        if (!live) rs.done = 1;
+        const SwdLayerC Lhalf = loadL(n - 1);
+        for (;;) {
+            int more = __any(!rs.done);
+            double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
+            double wvno = rs.omega / rs.creq, wvno2 = wvno * wvno, iomega = 1.0 / omega;
+            req[lane] = wvno; req[64 + lane] = wvno2; req[128 + lane] = omega; req[192 + lane] = iomega;
+            if (lane == 0) *go = more;
+            __syncthreads();                                     // B0
+            if (!more) break;
+            double e[5];
+            swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+            const double tt = -2.0 * wvno2;
+            for (int c = 0; c < nch; c++) {
+                __syncthreads();                                 // chunk c is in buffer c&1
+                const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + lane;
+                for (int i = 0; i < COOP_NP; i++) {
+                    int m = (n - 2) - (c * COOP_NP + i);
+                    if (m < 0) break;
+                    double cur[SWD_NENT];
+#pragma unroll
+                    for (int q = 0; q < SWD_NENT; q++) cur[q] = eb[(size_t)(i * SWD_NENT + q) * 64];
+                    swd_apply_layer(e, cur, tt);
+                }
+            }
+            if (!rs.done) rs.advance(e[0], T, out);
+        }
+        if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
+    } else {
+        const int p = wave - 1;
+        SwdLayerC Lmine[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int m = (n - 2) - (c * COOP_NP + p);
+            Lmine[c] = loadL(m >= 0 ? m : 0);
+        }
+        for (;;) {
+            __syncthreads();                                     // B0
+            if (!*go) break;
+            double wvno = req[lane], wvno2 = req[64 + lane], omega = req[128 + lane], iomega = req[192 + lane];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (c < nch) {
+                    int m = (n - 2) - (c * COOP_NP + p);
+                    if (m >= 0) {
+                        double e15[SWD_NENT];
+                        swd_layer_entries(Lmine[c], wvno, wvno2, omega, iomega, e15);
+                        double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + (size_t)p * SWD_NENT * 64 + lane;
+#pragma unroll
+                        for (int q = 0; q < SWD_NENT; q++) eb[(size_t)q * 64] = e15[q];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K4 eigenfunction kernels: lane = (item, chain), item = (sequence, period).  Writes the
 // SCALED phase-velocity kernels (d c / d alpha, beta, rho and the interface partial) and U.
