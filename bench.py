@@ -146,8 +146,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
         # the path's only collective: gather the per-chain misfits on rank 0 (after the timed region)
-        gathered = [torch.empty_like(misfit) for _ in range(world)] if rank == 0 else None
-        dist.gather(misfit, gathered, dst=0)
+        from rfsurfhmc_amd.chains import gather_misfits
+        gathered = gather_misfits(misfit)
+        assert rank != 0 or gathered.shape[0] == nchain * world
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

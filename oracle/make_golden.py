@@ -202,6 +202,79 @@ def gen_plugin(m_surf, m_rf, m_joint, M):
     print("plugin_hybrid.npz:", len(g), "arrays")
 
 
+class _H5Stub:
+    """h5py is absent here; the reference samplers only write through it (pyhmc/hmc.py:58,203-226)."""
+    class File:
+        def __init__(self, *a, **k):
+            self.d = {}
+        def create_group(self, name):
+            return None
+        def create_dataset(self, name, dtype=None, shape=None, data=None):
+            self.d[name] = np.zeros(shape) if data is None else np.array(data)
+        def __getitem__(self, k):
+            return self.d[k]
+        def close(self):
+            pass
+
+
+def gen_sampler(m_surf, m_rf, m_joint, M):
+    """Reference HamitonianMC / HMCDualAveraging (unmodified pyhmc/*.py) on the param.yaml joint problem,
+    a few iterations, with every random draw and every trajectory result recorded."""
+    import importlib
+    mod = types.ModuleType("h5py"); mod.File = _H5Stub.File
+    sys.modules["h5py"] = mod
+    pk = types.ModuleType("pyhmc"); pk.__path__ = [os.path.join(REF, "pyhmc")]
+    sys.modules["pyhmc"] = pk
+    hmc = importlib.import_module("pyhmc.hmc"); hmcda = importlib.import_module("pyhmc.hmcda")
+    thk, vs, t = M["yaml7"]
+    swd = m_surf.SurfWD(tRc=t, tRg=t, tLc=None, tLg=None)
+    rf = m_rf.ReceiverFunc(RAY_P, 125, 0.4, GAUSS, TSHIFT, WATER, "P", "freq")
+    joint = m_joint.Joint_RF_SWD(1.0, 1.0, rf, swd)
+    x0 = np.hstack((vs, thk))
+    drf, dswd, _ = joint.forward(x0)
+    joint.set_obsdata(drf, dswd)
+    n = len(x0)
+    bounds = np.ones((n, 2))                      # main_base.py:64-77
+    for i in range(len(thk)):
+        bounds[i, 0] = max(vs[i] - vs[i] * 0.8, 1.5); bounds[i, 1] = min(vs[i] + vs[i] * 0.8, 5.0)
+        bounds[i + len(thk), 0] = thk[i] - thk[i] * 0.2; bounds[i + len(thk), 1] = thk[i] + thk[i] * 0.2
+    bounds[-1, :] = 0.0, 2.0
+    g = {"x0": x0, "dobs": joint.dobs, "bounds": bounds, "t": t}
+    for tag, rank in (("hmc_r0", 0), ("hmc_r1", 1)):
+        ch = hmc.HamitonianMC(joint, bounds, 0.1, [5, 20], 2, 991206, 6, 3, rank, "g", "/tmp")
+        rec = []
+        orig = ch._leapfrog
+        def wrapped(xcur, dt, L, _orig=orig, _rec=rec):
+            out = _orig(xcur, dt, L)
+            _rec.append((L, out[0].copy(), out[1], out[3]))
+            return out
+        ch._leapfrog = wrapped
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            mis = ch.sample()
+        g[f"{tag}/initmodel"] = ch.fio["initmodel"]
+        g[f"{tag}/L"] = np.array([r[0] for r in rec]); g[f"{tag}/x"] = np.array([r[1] for r in rec])
+        g[f"{tag}/U"] = np.array([r[2] for r in rec]); g[f"{tag}/accept"] = np.array([r[3] for r in rec])
+        g[f"{tag}/misfit"] = mis
+    ch = hmcda.HMCDualAveraging(joint, bounds, 0.1, 10, 2, 0.65, 991206, 6, 3, 0, "g", "/tmp")
+    rec = []
+    orig = ch._leapfrog
+    def wrapped_da(xcur, dt, L, _orig=orig, _rec=rec):
+        out = _orig(xcur, dt, L)
+        _rec.append((L, dt, out[0].copy(), out[1], out[3]))
+        return out
+    ch._leapfrog = wrapped_da
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        mis = ch.sample()
+    g["da_r0/initmodel"] = ch.fio["initmodel"]
+    g["da_r0/L"] = np.array([r[0] for r in rec]); g["da_r0/dt"] = np.array([r[1] for r in rec])
+    g["da_r0/x"] = np.array([r[2] for r in rec]); g["da_r0/U"] = np.array([r[3] for r in rec])
+    g["da_r0/alpha"] = np.array([r[4] for r in rec]); g["da_r0/misfit"] = mis
+    np.savez_compressed(os.path.join(OUT, "sampler_hybrid.npz"), **g)
+    print("sampler_hybrid.npz:", len(g), "arrays;", len(g["hmc_r0/L"]), "HMC iterations,", len(rec), "DA iterations")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
@@ -209,6 +282,7 @@ def main():
     gen_swd(ref_surf, M)
     gen_rf(ref_rf, M)
     gen_plugin(m_surf, m_rf, m_joint, M)
+    gen_sampler(m_surf, m_rf, m_joint, M)
 
 
 if __name__ == "__main__":

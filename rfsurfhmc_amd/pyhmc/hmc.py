@@ -72,7 +72,7 @@ class HamitonianMC:
         dres = np.where(accept[:, None], dnew, np.where(ok[:, None], dcur, self.model.dobs[None, :]))
         if self.trace is not None:
             self.trace.append(dict(active=list(active), L=L.copy(), p0=p0, xend=xnew, Unew=Unew, Hcur=Hcur,
-                                   Hnew=Hnew, u=u, ok=ok, accept=accept))
+                                   Hnew=Hnew, u=u, ok=ok, accept=accept, xres=xres.copy(), Ures=Ures.copy()))
         return xres, Ures, dres, accept
 
     def sample(self, x_init=None):
