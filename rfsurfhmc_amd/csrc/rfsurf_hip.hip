@@ -260,10 +260,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
         while (G > 1 && G < 64 && (lds > 60 * 1024 || (n - 1 + G - 1) / G > 8)) {
             G *= 2; lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
         }
-        if (c->swd_lanes == 0 && nitem >= 1024 && n - 1 <= 16 * COOP_NP) {
+        int npm = 0;
+        for (int q = 0; q < Q.nseq; q++) npm = Q.s[q].nper > npm ? Q.s[q].nper : npm;
+        if (c->swd_lanes == 0 && nitem >= 1024 && n - 1 <= 16 * COOP_NP && Q.nseq * npm <= 4096) {
             // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
             int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
-            size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64) * sizeof(double);
+            int npmax = 0;
+            for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
+            size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + Q.nseq * npmax) * sizeof(double);
             dim3 grid((nitem + 63) / 64);
 #define RFS_LAUNCH_COOP(NCH)                                                                                   \
             do {                                                                                               \

@@ -517,12 +517,20 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
     int* go = (int*)(lds + 4 * 64);              // block-wide "another evaluation follows"
     double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][15][64]
+    double* tper = ent + 2 * COOP_NP * SWD_NENT * 64;   // [nseq][nper_max] scaled periods (no global loads in the loop)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int item = blockIdx.x * 64 + lane;
     int seq = item / nchain, chain = item - seq * nchain;
     const bool live = seq < Q.nseq;
     if (!live) { seq = 0; chain = 0; }
     const int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
+    int npmax = 0;
+    for (int q = 0; q < Q.nseq; q++) npmax = max(npmax, Q.s[q].nper);
+    for (int i = threadIdx.x; i < Q.nseq * npmax; i += blockDim.x) {
+        int q = i / npmax, k = i - q * npmax;
+        tper[i] = (k < Q.s[q].nper) ? Q.s[q].t[k] * Q.s[q].scale : 1.0;
+    }
+    __syncthreads();
     const double* lc0 = mdlc + chain;
     auto loadL = [&](int m) {
         const double* o = lc0 + (size_t)m * 6 * nchain;
@@ -533,8 +541,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         const SwdSeq sq = Q.s[seq];
-        const double* tp = sq.t; const double sc = sq.scale;
-        auto T = [&](int k) { return tp[k] * sc; };
+        const double* tp = tper + seq * npmax;
+        auto T = [&](int k) { return tp[k]; };
         double* cr = croot + (size_t)sq.croot_off * nchain + chain;
         auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
         RootSearch rs;
@@ -555,13 +563,17 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
             for (int c = 0; c < nch; c++) {
                 __syncthreads();                                 // chunk c is in buffer c&1
                 const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + lane;
-                for (int i = 0; i < COOP_NP; i++) {
-                    int m = (n - 2) - (c * COOP_NP + i);
-                    if (m < 0) break;
-                    double cur[SWD_NENT];
+                const int nl = min(COOP_NP, (n - 1) - c * COOP_NP);      // layers in this chunk
+                double cur[SWD_NENT], nxt[SWD_NENT];
 #pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) cur[q] = eb[(size_t)(i * SWD_NENT + q) * 64];
+                for (int q = 0; q < SWD_NENT; q++) cur[q] = eb[(size_t)q * 64];
+                for (int i = 0; i < nl; i++) {
+                    const int ip = (i + 1 < nl) ? i + 1 : i;     // prefetch the next layer's entries
+#pragma unroll
+                    for (int q = 0; q < SWD_NENT; q++) nxt[q] = eb[(size_t)(ip * SWD_NENT + q) * 64];
                     swd_apply_layer(e, cur, tt);
+#pragma unroll
+                    for (int q = 0; q < SWD_NENT; q++) cur[q] = nxt[q];
                 }
             }
             if (!rs.done) rs.advance(e[0], T, out);

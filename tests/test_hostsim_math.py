@@ -1,0 +1,88 @@
+"""CPU build of the device math headers (tests/hostsim/*.cpp, a TEST HARNESS -- never shipped and never a
+fallback) against the oracle and the golden vectors: lets the lane-level algorithms of the HIP kernels be
+checked in the GPU-less container."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+
+
+@pytest.fixture(scope="module")
+def hs():
+    libs = {}
+    for name in ("rf", "swd"):
+        so = os.path.join(HERE, f"libhostsim_{name}.so")
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so,
+                        os.path.join(HERE, f"hostsim_{name}.cpp")], check=True)
+        libs[name] = ctypes.CDLL(so)
+    libs["swd"].hs_sregn96.restype = ctypes.c_double
+    return libs
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+DP = ctypes.POINTER(ctypes.c_double)
+FP = ctypes.POINTER(ctypes.c_float)
+P = lambda a: a.ctypes.data_as(DP)
+F = lambda a: a.ctypes.data_as(FP)
+
+
+def test_rf_row_column_sweeps_equal_reference_partials(hs, orc, golden):
+    """O(n) row/column sweeps (rf_math.hpp) == the reference's O(n^2) partial products, per frequency."""
+    g = golden["rf_core_reference"]
+    c = ctypes.c_double
+    for name in ("yaml7_nt125", "grad30_nt512", "lvz30_0_nt512", "grad50_nt512"):
+        thk, vs = np.ascontiguousarray(g[f"{name}/thk"]), np.ascontiguousarray(g[f"{name}/vs"])
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        vp, rho = np.ascontiguousarray(vp), np.ascontiguousarray(rho)
+        n = len(vs); q = np.full(n, 9999.)
+        w, sigma = g[f"{name}/w"], float(g[f"{name}/sigma"])
+        for i in range(0, len(w), 3):
+            R21 = np.zeros(1, complex); R22 = np.zeros(1, complex)
+            R21m = np.zeros((4, n), complex); R22m = np.zeros((4, n), complex)
+            hs["rf"].hs_rf_response_par_all(n, P(thk), P(rho), P(vp), P(vs), P(q), P(q), c(float(g["ray_p"])),
+                                            c(w[i]), c(-sigma), 1, P(R21), P(R22), P(R21m), P(R22m))
+            assert rel(R21, g[f"{name}/R21"][i]) < 1e-10 and rel(R22, g[f"{name}/R22"][i]) < 1e-10
+            assert rel(R21m, g[f"{name}/R21_m"][i]) < 1e-9 and rel(R22m, g[f"{name}/R22_m"][i]) < 1e-9
+
+
+@pytest.mark.parametrize("entry", ["hs_swd_rootsearch", "hs_swd_rootsearch_split"])
+def test_root_search_state_machine(hs, orc, golden, entry):
+    """Request/advance state machine (+ the split secular function of the multi-lane kernels)."""
+    g = golden["swd_reference"]
+    nexact = ntot = 0
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], np.ascontiguousarray(g[f"{name}/t"])
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        f = [np.ascontiguousarray(x.astype(np.float32)) for x in (thk, vp, vs, rho)]
+        cg = np.zeros(len(t)); ns = ctypes.c_long(0)
+        flag = getattr(hs["swd"], entry)(len(vs), *[F(x) for x in f], len(t), P(t), P(cg), ctypes.byref(ns))
+        ref = g[f"{name}/Rc/fwd_c"]
+        assert bool(flag) == bool(g[f"{name}/Rc/fwd_flag"]), name
+        if entry == "hs_swd_rootsearch":
+            assert np.array_equal(cg, ref), name              # same arithmetic as the reference: bit-exact
+        else:                                                 # reciprocal-multiply form: reference's own 1e-6 c tolerance
+            assert np.all(np.abs(cg - ref) <= 1.2e-6 * np.abs(ref)), name
+        nexact += int((cg == ref).sum()); ntot += len(ref)
+    assert nexact >= 0.99 * ntot
+
+
+def test_fused_eigenfunction_sweep(hs, orc, golden):
+    g = golden["swd_reference"]
+    c = ctypes.c_double
+    for name in ("yaml7", "grad30", "lvz30_1", "prior30_2", "grad50"):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], g[f"{name}/t"]
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        f = [np.ascontiguousarray(x.astype(np.float32)) for x in (thk, vp, vs, rho)]
+        n = len(vs)
+        for i in range(0, len(t), 5):
+            k = [np.zeros(n) for _ in range(4)]
+            hs["swd"].hs_sregn96(n, *[F(x) for x in f], c(t[i]), c(g[f"{name}/Rc/c"][i]), *[P(x) for x in k])
+            for got, key in zip(k, ("dcda", "dcdb", "dcdh", "dcdr")):
+                assert rel(got, g[f"{name}/Rc/{key}"][i]) < 1e-8, (name, i, key)
