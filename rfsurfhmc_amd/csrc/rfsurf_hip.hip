@@ -267,7 +267,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
             int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
             int npmax = 0;
             for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
-            size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + Q.nseq * npmax) * sizeof(double);
+            size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + 24 * 64 + Q.nseq * npmax) * sizeof(double);
             dim3 grid((nitem + 63) / 64);
 #define RFS_LAUNCH_COOP(NCH)                                                                                   \
             do {                                                                                               \

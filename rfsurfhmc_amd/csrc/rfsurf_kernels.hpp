@@ -482,18 +482,14 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
             double e[5];
             swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
             const double tt = -2.0 * wvno2;
-            double cur[SWD_NENT], nxt[SWD_NENT];
-#pragma unroll
-            for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)((n - 2) * SWD_NENT + i) * NG + grp];
             for (int m = n - 2; m >= 0; m--) {
-                int mp = m > 0 ? m - 1 : 0;             // prefetch the next layer's entries
+                double cur[SWD_NENT];
 #pragma unroll
-                for (int i = 0; i < SWD_NENT; i++) nxt[i] = ent_lds[(size_t)(mp * SWD_NENT + i) * NG + grp];
-                swd_apply_layer(e, cur, tt);
-#pragma unroll
-                for (int i = 0; i < SWD_NENT; i++) cur[i] = nxt[i];
+                for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp];
+                swd_apply_layer_raw(e, cur, tt);
+                if ((m & 7) == 0) swd_rescale_pow2(e);
             }
-            rs.advance(e[0], T, out);
+            rs.advance(swd_finish(e), T, out);
         }
         __syncthreads();
     }
@@ -517,7 +513,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
     int* go = (int*)(lds + 4 * 64);              // block-wide "another evaluation follows"
     double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][15][64]
-    double* tper = ent + 2 * COOP_NP * SWD_NENT * 64;   // [nseq][nper_max] scaled periods (no global loads in the loop)
+    double* nev = ent + 2 * COOP_NP * SWD_NENT * 64;    // [24][64] Neville tables of the 64 state machines
+    double* tper = nev + 24 * 64;                       // [nseq][nper_max] scaled periods (no global loads in the loop)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int item = blockIdx.x * 64 + lane;
     int seq = item / nchain, chain = item - seq * nchain;
@@ -538,6 +535,9 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
     if (wave == 0) {
+        // the consumer is the block's critical path and shares its SIMD with one producer wave:
+        // static priority lets its dependent chain issue first, the producer fills the gaps
+        __builtin_amdgcn_s_setprio(3);
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         const SwdSeq sq = Q.s[seq];
@@ -545,7 +545,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         auto T = [&](int k) { return tp[k]; };
         double* cr = croot + (size_t)sq.croot_off * nchain + chain;
         auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
-        RootSearch rs;
+        RootSearchT<NevTabMem> rs;
+        rs.tab.base = nev + lane; rs.tab.stride = 64;
         rs.begin(M, T, sq.nper);
         if (!live) rs.done = 1;
         const SwdLayerC Lhalf = loadL(n - 1);
@@ -564,19 +565,15 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                 __syncthreads();                                 // chunk c is in buffer c&1
                 const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + lane;
                 const int nl = min(COOP_NP, (n - 1) - c * COOP_NP);      // layers in this chunk
-                double cur[SWD_NENT], nxt[SWD_NENT];
-#pragma unroll
-                for (int q = 0; q < SWD_NENT; q++) cur[q] = eb[(size_t)q * 64];
                 for (int i = 0; i < nl; i++) {
-                    const int ip = (i + 1 < nl) ? i + 1 : i;     // prefetch the next layer's entries
+                    double cur[SWD_NENT];
 #pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) nxt[q] = eb[(size_t)(ip * SWD_NENT + q) * 64];
-                    swd_apply_layer(e, cur, tt);
-#pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) cur[q] = nxt[q];
+                    for (int q = 0; q < SWD_NENT; q++) cur[q] = eb[(size_t)(i * SWD_NENT + q) * 64];
+                    swd_apply_layer_raw(e, cur, tt);
                 }
+                swd_rescale_pow2(e);                             // once per chunk of 7 layers
             }
-            if (!rs.done) rs.advance(e[0], T, out);
+            if (!rs.done) rs.advance(swd_finish(e), T, out);
         }
         if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
     } else {

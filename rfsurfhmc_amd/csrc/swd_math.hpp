@@ -227,6 +227,33 @@ RFS_HD void swd_apply_layer(double e[5], const double c[SWD_NENT], double tt /* 
     e[0] = n0 * it1; e[1] = n1 * it1; e[2] = n2 * it1; e[3] = n3 * it1; e[4] = n4 * it1;
 }
 
+// The per-layer normc (surfdisp96.f:1015-1040) only rescales the vector by a positive number, and the
+// value the search uses is e(1) of the LAST normalised vector, i.e. v(1)/max|v| of the raw product
+// v = e_half . CA_{n-2} ... CA_0: intermediate normalisations cancel exactly.  The raw recurrence
+// therefore drops the max/reciprocal chain from every layer (25 FMAs remain); an exact power-of-two
+// rescale every few layers keeps the range, and swd_finish applies the one normalisation that matters.
+RFS_HD void swd_apply_layer_raw(double e[5], const double c[SWD_NENT], double tt /* -2 wvno^2 */) {
+    double e2t = e[2] * tt;
+    double n0 = e[0] * c[0] + e[1] * c[5] + e2t * c[13] + e[3] * c[9] + e[4] * c[12];
+    double n1 = e[0] * c[1] + e[1] * c[6] + e2t * c[11] + e[3] * c[10] + e[4] * c[9];
+    double n2 = e[0] * c[2] + e[1] * c[7] + e[2] * c[14] + e[3] * c[11] + e[4] * c[13];
+    double n3 = e[0] * c[3] + e[1] * c[8] + e2t * c[7] + e[3] * c[6] + e[4] * c[5];
+    double n4 = e[0] * c[4] + e[1] * c[3] + e2t * c[2] + e[3] * c[1] + e[4] * c[0];
+    e[0] = n0; e[1] = n1; e[2] = n2; e[3] = n3; e[4] = n4;
+}
+RFS_HD void swd_rescale_pow2(double e[5]) {
+    double t1 = fmax(fmax(fmax(fabs(e[0]), fabs(e[1])), fmax(fabs(e[2]), fabs(e[3]))), fabs(e[4]));
+    int ex = 0;
+    if (t1 > 0.0 && t1 < 1.0e300) frexp(t1, &ex);
+    e[0] = ldexp(e[0], -ex); e[1] = ldexp(e[1], -ex); e[2] = ldexp(e[2], -ex);
+    e[3] = ldexp(e[3], -ex); e[4] = ldexp(e[4], -ex);
+}
+RFS_HD double swd_finish(const double e[5]) {
+    double t1 = fmax(fmax(fmax(fabs(e[0]), fabs(e[1])), fmax(fabs(e[2]), fabs(e[3]))), fabs(e[4]));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    return e[0] / t1;
+}
+
 // surfdisp96.f:375-396  gtsolh (single precision throughout)
 RFS_HD float swd_gtsolh(float a, float b) {
     float c = 0.95f * b;
@@ -251,7 +278,27 @@ RFS_HD float swd_gtsolh(float a, float b) {
 // Results: rs.flag (1 ok / 0 failed), cg[k] written through the Out functor as the
 // float32-rounded phase velocity (surfdisp96.f:302,307), zeros after a failure.
 // ---------------------------------------------------------------------------
-struct RootSearch {
+// Neville table storage: registers (static-index predicated updates) by default; the cooperative
+// kernel keeps it in LDS (dynamic indexing, 48 fewer live VGPRs across the divergent state machine).
+struct NevTabReg {
+    double x[12], y[12];
+    static constexpr bool kDynamic = false;
+    RFS_HD double gx(int i) const { return x[i]; }
+    RFS_HD double gy(int i) const { return y[i]; }
+    RFS_HD void sx(int i, double v) { x[i] = v; }
+    RFS_HD void sy(int i, double v) { y[i] = v; }
+};
+struct NevTabMem {             // x(i) at base[i*stride], y(i) at base[(12+i)*stride]
+    double* base; int stride;
+    static constexpr bool kDynamic = true;
+    RFS_HD double gx(int i) const { return base[i * stride]; }
+    RFS_HD double gy(int i) const { return base[(12 + i) * stride]; }
+    RFS_HD void sx(int i, double v) { base[i * stride] = v; }
+    RFS_HD void sy(int i, double v) { base[(12 + i) * stride] = v; }
+};
+
+template <class Tab = NevTabReg>
+struct RootSearchT {
     enum { PH_START, PH_SCAN, PH_HALF0, PH_HALF_OUT, PH_HALF_B, PH_NEV };
     static constexpr double TWOPI = 2.0 * 3.141592653589793;
     // per-model constants
@@ -263,7 +310,7 @@ struct RootSearch {
     double c1, c2, del1, del2, clow, del1st, cprev;
     double c3, del3;
     int nev, m, nctrl;
-    double x[12], y[12];
+    Tab tab;
     long nsec;
 
     template <class PeriodFn>
@@ -289,7 +336,7 @@ struct RootSearch {
         cc = (double)cc1; dc = (double)0.005f; cm = cc; betmx = bmx;
         kmax = kmax_; k = 0; retry = 0; done = 0; flag = 1; nsec = 0;
         del1st = 0.0; cprev = 0.0; m = 1; nev = 1; nctrl = 1;
-        for (int i = 0; i < 12; i++) { x[i] = 0.0; y[i] = 0.0; }
+        if (!Tab::kDynamic) for (int i = 0; i < 12; i++) { tab.sx(i, 0.0); tab.sy(i, 0.0); }
         if (kmax <= 0) { done = 1; return; }
         start_period(T);
     }
@@ -339,24 +386,34 @@ struct RootSearch {
                 double ss1 = fabs(del1), s1 = pct * ss1, ss2 = fabs(del2), s2 = pct * ss2;
                 if (s1 > ss2 || s2 > ss1 || nev == 0) { request_half(PH_HALF_B); return; }
                 double ym1;
-                if (nev == 2) {
-#pragma unroll
-                    for (int i = 2; i <= 11; i++) if (i == m + 1) { x[i] = c3; y[i] = del3; }
-                    ym1 = del3;
-                } else {
-                    x[1] = c1; y[1] = del1; x[2] = c2; y[2] = del2; m = 1; ym1 = del2;
-                }
                 bool bail = false;
-#pragma unroll
-                for (int j = 10; j >= 1; j--) {
-                    if (j <= m && !bail) {
-                        double denom = ym1 - y[j];
+                if (Tab::kDynamic) {
+                    if (nev == 2) { tab.sx(m + 1, c3); tab.sy(m + 1, del3); ym1 = del3; }
+                    else { tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2; }
+                    for (int j = m; j >= 1 && !bail; j--) {
+                        double yj = tab.gy(j), denom = ym1 - yj;
                         if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
-                        else x[j] = (-y[j] * x[j + 1] + ym1 * x[j]) / denom;
+                        else tab.sx(j, (-yj * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
+                    }
+                } else {
+                    if (nev == 2) {
+#pragma unroll
+                        for (int i = 2; i <= 11; i++) if (i == m + 1) { tab.sx(i, c3); tab.sy(i, del3); }
+                        ym1 = del3;
+                    } else {
+                        tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2;
+                    }
+#pragma unroll
+                    for (int j = 10; j >= 1; j--) {
+                        if (j <= m && !bail) {
+                            double denom = ym1 - tab.gy(j);
+                            if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
+                            else tab.sx(j, (-tab.gy(j) * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
+                        }
                     }
                 }
                 if (bail) { request_half(PH_HALF_B); return; }
-                c3 = x[1]; creq = c3; phase = PH_NEV; return;
+                c3 = tab.gx(1); creq = c3; phase = PH_NEV; return;
             } else if (go == GO_FINISH) {                // getsol :483-487
                 c1 = c3;
                 if (c1 > (double)betmx) { go = GO_FAIL; continue; }
@@ -376,6 +433,8 @@ struct RootSearch {
         }
     }
 };
+using RootSearch = RootSearchT<NevTabReg>;
+
 
 // ---------------------------------------------------------------------------
 // Eigenfunction pass.  float32 pi as in sregn96.f90:1654.

@@ -41,9 +41,10 @@ int hs_swd_rootsearch_split(int n, const float* thk, const float* vp, const floa
         swd_halfspace_e(LC[n - 1], wvno, wvno2, omega, iomega, e);
         for (int m = n - 2; m >= 0; m--) {
             swd_layer_entries(LC[m], wvno, wvno2, omega, iomega, ent);
-            swd_apply_layer(e, ent, -2.0 * wvno2);
+            swd_apply_layer_raw(e, ent, -2.0 * wvno2);
+            if ((m & 7) == 0) swd_rescale_pow2(e);
         }
-        rs.advance(e[0], T, out);
+        rs.advance(swd_finish(e), T, out);
     }
     if (nsec) *nsec = rs.nsec;
     return rs.flag;
