@@ -577,6 +577,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         }
         if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
     } else {
+        __builtin_amdgcn_s_setprio(2);           // the search is the step's critical path: outrank co-resident RF waves
         const int p = wave - 1;
         SwdLayerC Lmine[NCH];
 #pragma unroll

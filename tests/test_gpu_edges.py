@@ -1,0 +1,122 @@
+"""-m gpu: shapes at the edges of the C ABI (smallest / largest models, tiny and odd FFT lengths, single
+periods, every root-search kernel variant, argument errors) against the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def _model(n, rng, sort=True):
+    vs = 2.2 + 2.4 * rng.random(n)
+    if sort:
+        vs = np.sort(vs)
+    thk = 0.8 + 3.0 * rng.random(n); thk[-1] = 0.0
+    return vs, thk
+
+
+@pytest.mark.parametrize("n", [2, 3, 33, 64, 65, 128])
+def test_layer_count_extremes_b2(orc, n):
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    rng = np.random.default_rng(n)
+    vs, thk = _model(n, rng)
+    if n > 40:
+        thk[:-1] *= 40.0 / n            # keep the stack ~60 km thick
+    t = np.array([6.0, 11.0, 23.0])
+    nt = 100
+    j = Joint_RF_SWD(1.0, 2.0, ReceiverFunc(0.05, nt, 0.25, 2.0, 3.0, 0.01, "P", "freq"), SurfWD(tRc=t, tRg=t))
+    o = orc.Joint_RF_SWD(1.0, 2.0, orc.ReceiverFunc(0.05, nt, 0.25, 2.0, 3.0, 0.01, "P", "freq"), orc.SurfWD(tRc=t, tRg=t))
+    x0 = np.hstack((vs, thk))
+    drf, dswd, fl = o.forward(x0)
+    assert fl
+    j.set_obsdata(drf, dswd); o.set_obsdata(drf, dswd)
+    x = x0 * (1 + 0.02 * (rng.random(2 * n) - 0.5))
+    m, g, d, f = j.misfit_and_grad(x)
+    mo, go, do, fo = o.misfit_and_grad(x)
+    assert f == fo
+    assert rel(d, do) < 1e-6 and abs(m - mo) <= 1e-5 * abs(mo) and rel(g, go) < 1e-5, (n, rel(g, go))
+
+
+@pytest.mark.parametrize("nt,dt", [(3, 1.0), (16, 0.5), (33, 0.5), (64, 0.4), (127, 0.3), (129, 0.3), (1000, 0.05)])
+def test_fft_length_extremes_b1(orc, nt, dt):
+    """nft = 4 ... 1024: fewer frequencies than a wavefront, one partial block, several blocks."""
+    from rfsurfhmc_amd.model.lib import librf
+    rng = np.random.default_rng(nt)
+    vs, thk = _model(6, rng)
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    q = np.full(6, 9999.)
+    args = (thk, rho, vp, vs, q, q, 0.06, nt, dt, 1.2, 2.0, "freq", 0.005, "P")
+    rf, kl = librf.kernel_all(*args)
+    rfo, klo = orc.librf.kernel_all(*args)
+    assert rf.shape == (nt,) and kl.shape == (4, 6, nt)
+    assert rel(rf, rfo) < 1e-9 and rel(kl, klo) < 1e-8
+    assert rel(librf.forward(*args), orc.librf.forward(*args)) < 1e-9
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64, 0])
+def test_every_root_search_kernel_agrees(orc, lanes):
+    """lane-per-chain, G-lanes-per-chain (LDS) and cooperative kernels return the same roots and flags."""
+    from rfsurfhmc_amd._lib import Context, hptr
+    rng = np.random.default_rng(77)
+    nchain, n = 1100, 12                      # > 1024 sequences so that lanes=0 picks the cooperative kernel
+    vs = np.sort(2.0 + 2.6 * rng.random((nchain, n)), axis=1)
+    vs[5] = vs[5, ::-1]                       # a velocity-inversion model
+    thk = 1.0 + 3 * rng.random((nchain, n)); thk[:, -1] = 0
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    t = np.linspace(3, 35, 7)
+    ctx = Context(0, max_chains=4096)
+    ctx.check(ctx.L.rfs_set_option(ctx.h, b"swd_lanes_per_chain", lanes))
+    c = np.zeros((nchain, len(t))); flag = np.zeros(nchain, dtype=np.int32)
+    a = [np.ascontiguousarray(v) for v in (thk, vp, vs, rho)]
+    ctx.check(ctx.L.rfs_swd_forward(ctx.h, nchain, n, hptr(a[0]), hptr(a[1]), hptr(a[2]), hptr(a[3]), len(t), hptr(t),
+                                    0, 0, 0, hptr(c), hptr(flag)))
+    for i in list(range(0, nchain, 97)) + [5]:
+        co, fo = orc.libsurf.forward(thk[i], vp[i], vs[i], rho[i], t, "Rc")
+        assert bool(flag[i]) == fo
+        assert np.all(np.abs(c[i] - co) <= 1.2e-6 * np.abs(co) + 1e-300), (lanes, i)
+    ctx.close()
+
+
+def test_single_period_and_group_only(orc):
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    rng = np.random.default_rng(5)
+    vs, thk = _model(9, rng)
+    x = np.hstack((vs, thk))
+    for kw in (dict(tRc=[17.0]), dict(tRg=[8.0, 21.0]), dict(tRc=[9.0], tRg=[9.0])):
+        s = SurfWD(**kw); o = orc.SurfWD(**kw)
+        d0, fl = o.forward(x)
+        dobs = d0 * 1.01
+        s.set_obsdata(dobs); o.set_obsdata(dobs)
+        m, g, d, f = s.misfit_and_grad(x)
+        mo, go, do, fo = o.misfit_and_grad(x)
+        assert f and fo and rel(d, do) < 1e-6 and abs(m - mo) < 1e-5 * mo and rel(g, go) < 1e-5, kw
+
+
+def test_argument_errors_are_reported_not_fatal():
+    from rfsurfhmc_amd._lib import Context, RfParams, RfsError, hptr
+    ctx = Context(0, max_chains=8, max_layers=16)
+    L = ctx.L
+    x = np.zeros((1, 8)); out = np.zeros(64); fl = np.zeros(1, dtype=np.int32)
+    assert L.rfs_joint_misfit_grad(ctx.h, 1, hptr(x), hptr(out), hptr(out), hptr(out), hptr(fl)) == -3     # no setup yet
+    t = np.array([5.0, 10.0])
+    assert L.rfs_joint_setup(ctx.h, 40, None, 2, hptr(t), 0, None, 1.0, 1.0, None) == -1                    # > max_layers
+    assert L.rfs_joint_setup(ctx.h, 4, None, 0, None, 0, None, 1.0, 1.0, None) == -1                        # no data at all
+    par = RfParams(0.05, 64, 0.2, 1.5, 2.0, 0.001, 1, 0)                                                    # method "time"
+    assert L.rfs_joint_setup(ctx.h, 4, ctypes.byref(par), 0, None, 0, None, 1.0, 1.0, None) == -4
+    par.method, par.rf_type = 1, 7
+    assert L.rfs_joint_setup(ctx.h, 4, ctypes.byref(par), 0, None, 0, None, 1.0, 1.0, None) == -1
+    a = np.ones((1, 4))
+    assert L.rfs_swd_forward(ctx.h, 1, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 2, 0, 0, hptr(out), hptr(fl)) == -4   # Love
+    assert L.rfs_swd_forward(ctx.h, 1, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 0, 0, 1, hptr(out), hptr(fl)) == -4   # sphere
+    assert L.rfs_swd_forward(ctx.h, 9, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 0, 0, 0, hptr(out), hptr(fl)) == -1   # > max_chains
+    assert b"max_chains" in L.rfs_last_error(ctx.h)
+    with pytest.raises(RfsError):
+        ctx.check(-1)
+    ctx.close()
