@@ -132,7 +132,11 @@ int rfs_leapfrog_dev(rfs_ctx* ctx, int nchain, const double* x0, const double* p
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):
  *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic, else a power
- *                          of two <= 64 (1 = the sequential lane-per-chain kernel). */
+ *                          of two <= 64 (1 = the sequential lane-per-chain kernel).
+ *   "cu_split"             0 = RF kernels on the caller's stream, sharing CUs with the root search;
+ *                          1 (default) / 2 = when the cooperative root search fits on half of the CUs, it and
+ *                          the RF kernels run on disjoint halves of the CU mask (contiguous halves / even-odd
+ *                          bits); the eigenfunction pass and the combine use the whole chip. */
 int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
 /* Kernel groups of one rfs_joint_misfit_grad_dev call.  With timing enabled every group of every
  * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on

@@ -29,9 +29,13 @@ struct FftPlan { rocfft_plan plan = nullptr; rocfft_execution_info info = nullpt
 
 struct rfs_ctx {
     int device = 0, max_chains = 0, max_layers = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    // user/main stream; SWD search stream; CU-partitioned pair (search on one half of the chip, RF on the other)
+    hipStream_t stream = nullptr, stream2 = nullptr, stream2m = nullptr, stream3 = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int cu_split = 1;          // 0: never partition; 1/2: partition (contiguous / even-odd mask bits) when the
+                               // cooperative search fits on half of the CUs
+    int ncu = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     std::string err;
     // joint configuration
     bool configured = false;
@@ -143,6 +147,21 @@ struct KTimer {   // brackets a group of launches with HIP events on the stream 
     ~KTimer() { if (e1) hipEventRecord(e1, s); }
 };
 
+int make_partition_streams(rfs_ctx* c) {
+    if (c->stream2m) { hipStreamDestroy(c->stream2m); c->stream2m = nullptr; }
+    if (c->stream3) { hipStreamDestroy(c->stream3); c->stream3 = nullptr; }
+    if (c->cu_split == 0) return RFS_OK;
+    int ncu = c->ncu, nw = (ncu + 31) / 32;
+    std::vector<uint32_t> ma(nw, 0), mb(nw, 0);
+    for (int i = 0; i < ncu; i++) {
+        bool a = (c->cu_split == 1) ? (i < ncu / 2) : ((i & 1) == 0);
+        (a ? ma : mb)[i / 32] |= 1u << (i % 32);
+    }
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream2m, nw, ma.data()));
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream3, nw, mb.data()));
+    return RFS_OK;
+}
+
 int check_rf(rfs_ctx* c, const rfs_rf_params* p) {
     if (!p) return fail(c, RFS_ERR_ARG, "rf params missing");
     if (p->method == RFS_RF_TIME) return fail(c, RFS_ERR_UNSUPPORTED, "time-domain RF (iterative deconvolution) is out of scope");
@@ -245,10 +264,10 @@ SwdRows make_rows(int ntRc, int ntRg, const double* d_tRg) {
 }
 
 // root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
-int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, bool kernels) {
+int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, bool kernels, bool roots = true) {
     ENSURE(c, c->croot, (size_t)Q.nper_total * nchain * sizeof(double));
     ENSURE(c, c->sflag, (size_t)4 * nchain * sizeof(int));
-    {
+    if (roots) {
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         int nitem = Q.nseq * nchain;
         int G = c->swd_lanes;
@@ -341,19 +360,40 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         HIPCHK(c, hipGetLastError());
     }
     SwdSeqs Q = make_seqs(c->ntRc, c->d_tRc.as<double>(), c->ntRg, c->d_tRg.as<double>(), true);
-    if (c->has_swd) {           // the latency-bound root search runs beside the RF kernels
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        TRY(launch_swd(c, c->stream2, nchain, n, Q, true));
-        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    hipStream_t user = c->stream;
+    // CU partition: the cooperative search occupies one CU per 64 sequences; when that fits on half of the
+    // chip it runs there undisturbed and the RF kernels take the other half (measured +11 % at config 2)
+    const int nblk = (Q.nseq * nchain + 63) / 64;
+    int npmax = 0;
+    for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
+    // ... but only while the RF kernels on half a chip stay shorter than the search (both scale with the layer
+    // count; RF with chains x frequencies, the search with the number of periods): calibrated at config 2
+    const double rf_half = c->has_rf ? (nchain / 8192.0) * ((c->f.n2 - 1) / 256.0) : 0.0;
+    const bool part = c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
+                      c->swd_lanes == 0 && Q.nseq * nchain >= 1024 && nblk <= c->ncu / 2 &&
+                      rf_half <= 1.1 * (npmax / 40.0);
+    if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
+        hipStream_t ss = part ? c->stream2m : c->stream2;
+        HIPCHK(c, hipEventRecord(c->ev_fork, user));
+        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
+        TRY(launch_swd(c, ss, nchain, n, Q, !part));
+        HIPCHK(c, hipEventRecord(c->ev_join, ss));
+    } else if (c->has_swd) {
+        TRY(launch_swd(c, user, nchain, n, Q, true));
     }
     if (c->has_rf) {
-        { KTimer t(c, RFS_K_RF_PASS_A, c->stream); TRY(launch_passA(c, nchain, n, c->f, true)); }
-        { KTimer t(c, RFS_K_RF_MID, c->stream);
-          TRY(launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true)); }
-        { KTimer t(c, RFS_K_RF_PASS_B, c->stream); TRY(launch_passB(c, nchain, n, c->f)); }
+        if (part) { HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); c->stream = c->stream3; }
+        int rc = RFS_OK;
+        { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nchain, n, c->f, true); }
+        if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
+          rc = launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true); }
+        if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nchain, n, c->f); }
+        c->stream = user;
+        if (rc) return rc;
+        if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
-    if (c->has_swd) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
+    if (part) TRY(launch_swd(c, user, nchain, n, Q, true, false));      // eigenfunction pass on the whole chip
     {
         KTimer t(c, RFS_K_COMBINE, c->stream);
         SwdRows R = make_rows(c->ntRc, c->ntRg, c->d_tRg.as<double>());
@@ -381,9 +421,14 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
     c->own_stream = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return RFS_ERR_HIP; }
+    c->ncu = prop.multiProcessorCount;
+    if (make_partition_streams(c) != RFS_OK) c->cu_split = 0;      // masks unsupported: fall back to shared CUs
     *out = c;
     return RFS_OK;
 }
@@ -405,6 +450,9 @@ void rfs_destroy(rfs_ctx* c) {
     }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->stream2m) hipStreamDestroy(c->stream2m);
+    if (c->stream3) hipStreamDestroy(c->stream3);
+    if (c->ev_join3) hipEventDestroy(c->ev_join3);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     for (auto& pool : c->tev) for (auto e : pool) hipEventDestroy(e);
@@ -423,6 +471,8 @@ int rfs_set_stream(rfs_ctx* c, void* s) {
 int rfs_synchronize(rfs_ctx* c) {
     if (!c) return RFS_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream2m) HIPCHK(c, hipStreamSynchronize(c->stream2m));
+    if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RFS_OK;
 }
@@ -456,6 +506,13 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_lanes_per_chain")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(c, RFS_ERR_ARG, "swd_lanes_per_chain must be 0 or a power of two <= 64");
         c->swd_lanes = value; return RFS_OK;
+    }
+    if (!strcmp(name, "cu_split")) {
+        if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "cu_split must be 0, 1 or 2");
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->cu_split = value;
+        return make_partition_streams(c);
     }
     return fail(c, RFS_ERR_ARG, std::string("unknown option ") + name);
 }
