@@ -281,9 +281,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
         }
         int npm = 0;
         for (int q = 0; q < Q.nseq; q++) npm = Q.s[q].nper > npm ? Q.s[q].nper : npm;
-        if (c->swd_lanes == 0 && nitem >= 1024 && n - 1 <= 16 * COOP_NP && Q.nseq * npm <= 4096) {
+        if (c->swd_lanes == 0 && nitem >= 1024 && n - 2 <= 16 * COOP_NP && n >= 3 && Q.nseq * npm <= 4096) {
             // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
-            int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
+            int nch = (n - 2 + COOP_NP - 1) / COOP_NP;
             int npmax = 0;
             for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
             size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + 24 * 64 + Q.nseq * npmax) * sizeof(double);
@@ -296,7 +296,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
                                    c->mdl.as<float>(), c->mdlc.as<double>(), c->croot.as<double>(),             \
                                    c->sflag.as<int>());                                                         \
             } while (0)
-            if (nch <= 5) RFS_LAUNCH_COOP(5);
+            if (nch <= 4) RFS_LAUNCH_COOP(4);
+            else if (nch <= 5) RFS_LAUNCH_COOP(5);
             else if (nch <= 8) RFS_LAUNCH_COOP(8);
             else RFS_LAUNCH_COOP(16);
 #undef RFS_LAUNCH_COOP

@@ -520,7 +520,10 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     int seq = item / nchain, chain = item - seq * nchain;
     const bool live = seq < Q.nseq;
     if (!live) { seq = 0; chain = 0; }
-    const int nch = (n - 1 + COOP_NP - 1) / COOP_NP;
+    // the consumer itself builds the deepest finite layer (n-2) while the producers work on chunk 0, so the
+    // producers share layers n-3 .. 0: 4 chunks of 7 for a 30-layer model instead of 5
+    const int nprod = n - 2;                     // layers handled by the producers
+    const int nch = (nprod + COOP_NP - 1) / COOP_NP;
     int npmax = 0;
     for (int q = 0; q < Q.nseq; q++) npmax = max(npmax, Q.s[q].nper);
     for (int i = threadIdx.x; i < Q.nseq * npmax; i += blockDim.x) {
@@ -549,7 +552,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         rs.tab.base = nev + lane; rs.tab.stride = 64;
         rs.begin(M, T, sq.nper);
         if (!live) rs.done = 1;
-        const SwdLayerC Lhalf = loadL(n - 1);
+        const SwdLayerC Lhalf = loadL(n - 1), Ldeep = loadL(n - 2);
         for (;;) {
             int more = __any(!rs.done);
             double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
@@ -561,10 +564,15 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
             double e[5];
             swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
             const double tt = -2.0 * wvno2;
+            {                                                    // deepest layer: built here, beside chunk 0
+                double d15[SWD_NENT];
+                swd_layer_entries(Ldeep, wvno, wvno2, omega, iomega, d15);
+                swd_apply_layer_raw(e, d15, tt);
+            }
             for (int c = 0; c < nch; c++) {
                 __syncthreads();                                 // chunk c is in buffer c&1
                 const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + lane;
-                const int nl = min(COOP_NP, (n - 1) - c * COOP_NP);      // layers in this chunk
+                const int nl = min(COOP_NP, nprod - c * COOP_NP);        // layers in this chunk
                 for (int i = 0; i < nl; i++) {
                     double cur[SWD_NENT];
 #pragma unroll
@@ -582,7 +590,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         SwdLayerC Lmine[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            int m = (n - 2) - (c * COOP_NP + p);
+            int m = (n - 3) - (c * COOP_NP + p);
             Lmine[c] = loadL(m >= 0 ? m : 0);
         }
         for (;;) {
@@ -592,7 +600,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 if (c < nch) {
-                    int m = (n - 2) - (c * COOP_NP + p);
+                    int m = (n - 3) - (c * COOP_NP + p);
                     if (m >= 0) {
                         double e15[SWD_NENT];
                         swd_layer_entries(Lmine[c], wvno, wvno2, omega, iomega, e15);

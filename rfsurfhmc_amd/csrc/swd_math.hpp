@@ -343,94 +343,107 @@ struct RootSearchT {
 
     RFS_HD void request_half(int next_phase) { c3 = 0.5 * (c1 + c2); creq = c3; phase = next_phase; }
 
-    // consume del = secular(creq) and run until the next request (or completion)
+    // consume del = secular(creq) and run until the next request (or completion).
+    // Forward-only staging (phase dispatch -> LOOPTOP -> A1 -> FINISH -> FAIL -> SCAN / new period): every
+    // transition of getsol / nevill moves forward through these stages, so there is no loop over states and
+    // the wavefront executes each stage at most once per call whatever mixture of phases its lanes are in.
     template <class PeriodFn, class OutFn>
     RFS_HD void advance(double del, const PeriodFn& T, const OutFn& out) {
         nsec++;
-        enum { GO_SCAN, GO_LOOPTOP, GO_A1, GO_FINISH, GO_FAIL, GO_RETURN } go = GO_RETURN;
-        switch (phase) {
-        case PH_START:                                   // getsol head, surfdisp96.f:433-447
+        bool st_scan = false, st_looptop = false, st_a1 = false, st_finish = false, st_fail = false;
+        bool st_half = false, st_newperiod = false;
+        int half_phase = PH_HALF0;
+        if (phase == PH_START) {                         // getsol head, surfdisp96.f:433-447
             del1 = del;
             if (ifirst == 1) del1st = del1;
             if (ifirst == 1) idir = +1;
             else idir = (sgn1(del1st) * sgn1(del1) >= 0.0) ? +1 : -1;
-            go = GO_SCAN; break;
-        case PH_SCAN:                                    // :470-479
+            st_scan = true;
+        } else if (phase == PH_SCAN) {                   // :470-479
             del2 = del;
-            if (sgn1(del1) != sgn1(del2)) { request_half(PH_HALF0); return; }
-            c1 = c2; del1 = del2;
-            if (c1 < cm || c1 >= ((double)betmx + dc)) go = GO_FAIL; else go = GO_SCAN;
-            break;
-        case PH_HALF0: del3 = del; nev = 1; nctrl = 1; go = GO_LOOPTOP; break;      // nevill :590-594
-        case PH_HALF_OUT: del3 = del; go = GO_A1; break;
-        case PH_HALF_B: del3 = del; nev = 1; m = 1; go = GO_LOOPTOP; break;
-        case PH_NEV: del3 = del; nev = 2; m = m + 1; if (m > 10) m = 10; go = GO_LOOPTOP; break;
+            if (sgn1(del1) != sgn1(del2)) { st_half = true; half_phase = PH_HALF0; }
+            else {
+                c1 = c2; del1 = del2;
+                if (c1 < cm || c1 >= ((double)betmx + dc)) st_fail = true; else st_scan = true;
+            }
+        } else if (phase == PH_HALF0) { del3 = del; nev = 1; nctrl = 1; st_looptop = true; }   // nevill :590-594
+        else if (phase == PH_HALF_OUT) { del3 = del; st_a1 = true; }
+        else if (phase == PH_HALF_B) { del3 = del; nev = 1; m = 1; st_looptop = true; }
+        else { del3 = del; nev = 2; m = m + 1; if (m > 10) m = 10; st_looptop = true; }         // PH_NEV
+
+        if (st_looptop) {                                // nevill :595-607
+            nctrl = nctrl + 1;
+            if (nctrl >= 100) st_finish = true;
+            else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) { nev = 0; st_half = true; half_phase = PH_HALF_OUT; }
+            else st_a1 = true;
         }
-        for (;;) {
-            if (go == GO_SCAN) {                         // getsol loop 1000, :457-469
-                c2 = (idir > 0) ? c1 + dc : c1 - dc;
-                if (c2 <= clow) { idir = +1; c1 = clow; c2 = c1 + dc; }   // del1 kept (quirk)
-                creq = c2; phase = PH_SCAN; return;
-            } else if (go == GO_LOOPTOP) {               // nevill :595-607
-                nctrl = nctrl + 1;
-                if (nctrl >= 100) { go = GO_FINISH; continue; }
-                if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) { nev = 0; request_half(PH_HALF_OUT); return; }
-                go = GO_A1;
-            } else if (go == GO_A1) {                    // nevill :608-681
-                double s13 = del1 - del3, s32 = del3 - del2;
-                if (sgn1(del3) * sgn1(del1) < 0.0) { c2 = c3; del2 = del3; }
-                else { c1 = c3; del1 = del3; }
-                if (fabs(c1 - c2) <= 1.0e-6 * c1) { go = GO_FINISH; continue; }
+        if (st_a1) {                                     // nevill :608-681
+            double s13 = del1 - del3, s32 = del3 - del2;
+            if (sgn1(del3) * sgn1(del1) < 0.0) { c2 = c3; del2 = del3; }
+            else { c1 = c3; del1 = del3; }
+            if (fabs(c1 - c2) <= 1.0e-6 * c1) st_finish = true;
+            else {
                 if (sgn1(s13) != sgn1(s32)) nev = 0;
                 const double pct = (double)0.01f;        // default-real literal 0.01 (:637,639)
                 double ss1 = fabs(del1), s1 = pct * ss1, ss2 = fabs(del2), s2 = pct * ss2;
-                if (s1 > ss2 || s2 > ss1 || nev == 0) { request_half(PH_HALF_B); return; }
-                double ym1;
-                bool bail = false;
-                if (Tab::kDynamic) {
-                    if (nev == 2) { tab.sx(m + 1, c3); tab.sy(m + 1, del3); ym1 = del3; }
-                    else { tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2; }
-                    for (int j = m; j >= 1 && !bail; j--) {
-                        double yj = tab.gy(j), denom = ym1 - yj;
-                        if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
-                        else tab.sx(j, (-yj * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
-                    }
-                } else {
-                    if (nev == 2) {
-#pragma unroll
-                        for (int i = 2; i <= 11; i++) if (i == m + 1) { tab.sx(i, c3); tab.sy(i, del3); }
-                        ym1 = del3;
-                    } else {
-                        tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2;
-                    }
-#pragma unroll
-                    for (int j = 10; j >= 1; j--) {
-                        if (j <= m && !bail) {
-                            double denom = ym1 - tab.gy(j);
+                if (s1 > ss2 || s2 > ss1 || nev == 0) { st_half = true; half_phase = PH_HALF_B; }
+                else {
+                    double ym1;
+                    bool bail = false;
+                    if (Tab::kDynamic) {
+                        if (nev == 2) { tab.sx(m + 1, c3); tab.sy(m + 1, del3); ym1 = del3; }
+                        else { tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2; }
+                        for (int j = m; j >= 1 && !bail; j--) {
+                            double yj = tab.gy(j), denom = ym1 - yj;
                             if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
-                            else tab.sx(j, (-tab.gy(j) * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
+                            else tab.sx(j, (-yj * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
+                        }
+                    } else {
+                        if (nev == 2) {
+#pragma unroll
+                            for (int i = 2; i <= 11; i++) if (i == m + 1) { tab.sx(i, c3); tab.sy(i, del3); }
+                            ym1 = del3;
+                        } else {
+                            tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2;
+                        }
+#pragma unroll
+                        for (int j = 10; j >= 1; j--) {
+                            if (j <= m && !bail) {
+                                double denom = ym1 - tab.gy(j);
+                                if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
+                                else tab.sx(j, (-tab.gy(j) * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
+                            }
                         }
                     }
+                    if (bail) { st_half = true; half_phase = PH_HALF_B; }
+                    else { c3 = tab.gx(1); creq = c3; phase = PH_NEV; }
                 }
-                if (bail) { request_half(PH_HALF_B); return; }
-                c3 = tab.gx(1); creq = c3; phase = PH_NEV; return;
-            } else if (go == GO_FINISH) {                // getsol :483-487
-                c1 = c3;
-                if (c1 > (double)betmx) { go = GO_FAIL; continue; }
+            }
+        }
+        if (st_finish) {                                 // getsol :483-487
+            c1 = c3;
+            if (c1 > (double)betmx) st_fail = true;
+            else {
                 out(k, (double)(float)c1);
                 cprev = c1;
                 k = k + 1;
-                if (k >= kmax) { done = 1; return; }
-                start_period(T); return;
-            } else {                                     // GO_FAIL
-                if (!retry) {                            // surfdisp96.f:317-362 + surfdisp.cpp:93-100
-                    retry = 1;
-                    for (int i = k; i < kmax; i++) out(i, 0.0);
-                    start_period(T); return;
-                }
-                flag = 0; done = 1; return;
+                if (k >= kmax) done = 1; else st_newperiod = true;
             }
         }
+        if (st_fail) {
+            if (!retry) {                                // surfdisp96.f:317-362 + surfdisp.cpp:93-100
+                retry = 1;
+                for (int i = k; i < kmax; i++) out(i, 0.0);
+                st_newperiod = true;
+            } else { flag = 0; done = 1; }
+        }
+        if (st_half) request_half(half_phase);
+        if (st_scan) {                                   // getsol loop 1000, :457-469
+            c2 = (idir > 0) ? c1 + dc : c1 - dc;
+            if (c2 <= clow) { idir = +1; c1 = clow; c2 = c1 + dc; }   // del1 kept (quirk)
+            creq = c2; phase = PH_SCAN;
+        }
+        if (st_newperiod) start_period(T);
     }
 };
 using RootSearch = RootSearchT<NevTabReg>;
