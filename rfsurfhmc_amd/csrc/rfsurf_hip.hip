@@ -283,7 +283,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
         for (int q = 0; q < Q.nseq; q++) npm = Q.s[q].nper > npm ? Q.s[q].nper : npm;
         if (c->swd_lanes == 0 && nitem >= 1024 && n - 2 <= 16 * COOP_NP && n >= 3 && Q.nseq * npm <= 4096) {
             // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
-            int nch = (n - 2 + COOP_NP - 1) / COOP_NP;
+            int nch = (n - 1 - COOP_CL + COOP_NP - 1) / COOP_NP;
             int npmax = 0;
             for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
             size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + 24 * 64 + Q.nseq * npmax) * sizeof(double);

@@ -504,6 +504,10 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
 // one chunk ahead of the consumer.  Nothing is computed twice, and the serial path per secular
 // evaluation shrinks to (one layer's entries) + (the 25-FMA recurrence over all layers).
 constexpr int COOP_NP = 7;                       // producer waves = layers per chunk
+#ifndef RFS_COOP_CL
+#define RFS_COOP_CL 1
+#endif
+constexpr int COOP_CL = RFS_COOP_CL;             // 1: the consumer builds the deepest finite layer itself
 template <int NCH>                               // chunks held in registers: (n-1) <= NCH*COOP_NP
 __global__ void __launch_bounds__(512)
 k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
@@ -522,7 +526,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     if (!live) { seq = 0; chain = 0; }
     // the consumer itself builds the deepest finite layer (n-2) while the producers work on chunk 0, so the
     // producers share layers n-3 .. 0: 4 chunks of 7 for a 30-layer model instead of 5
-    const int nprod = n - 2;                     // layers handled by the producers
+    const int nprod = n - 1 - COOP_CL;           // layers handled by the producers
     const int nch = (nprod + COOP_NP - 1) / COOP_NP;
     int npmax = 0;
     for (int q = 0; q < Q.nseq; q++) npmax = max(npmax, Q.s[q].nper);
@@ -564,7 +568,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
             double e[5];
             swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
             const double tt = -2.0 * wvno2;
-            {                                                    // deepest layer: built here, beside chunk 0
+            if (COOP_CL) {                                       // deepest layer: built here, beside chunk 0
                 double d15[SWD_NENT];
                 swd_layer_entries(Ldeep, wvno, wvno2, omega, iomega, d15);
                 swd_apply_layer_raw(e, d15, tt);
@@ -573,11 +577,22 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                 __syncthreads();                                 // chunk c is in buffer c&1
                 const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + lane;
                 const int nl = min(COOP_NP, nprod - c * COOP_NP);        // layers in this chunk
-                for (int i = 0; i < nl; i++) {
-                    double cur[SWD_NENT];
+                // software pipeline: the LDS reads of layer i+1 are in flight while layer i's 25 FMAs issue
+                double bufA[SWD_NENT], bufB[SWD_NENT];
 #pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) cur[q] = eb[(size_t)(i * SWD_NENT + q) * 64];
-                    swd_apply_layer_raw(e, cur, tt);
+                for (int q = 0; q < SWD_NENT; q++) bufA[q] = eb[(size_t)q * 64];
+#pragma unroll
+                for (int i = 0; i < COOP_NP; i += 2) {
+                    if (i + 1 < nl) {
+#pragma unroll
+                        for (int q = 0; q < SWD_NENT; q++) bufB[q] = eb[(size_t)((i + 1) * SWD_NENT + q) * 64];
+                    }
+                    if (i < nl) swd_apply_layer_raw(e, bufA, tt);
+                    if (i + 2 < nl) {
+#pragma unroll
+                        for (int q = 0; q < SWD_NENT; q++) bufA[q] = eb[(size_t)((i + 2) * SWD_NENT + q) * 64];
+                    }
+                    if (i + 1 < nl) swd_apply_layer_raw(e, bufB, tt);
                 }
                 swd_rescale_pow2(e);                             // once per chunk of 7 layers
             }
@@ -590,7 +605,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         SwdLayerC Lmine[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            int m = (n - 3) - (c * COOP_NP + p);
+            int m = (n - 2 - COOP_CL) - (c * COOP_NP + p);
             Lmine[c] = loadL(m >= 0 ? m : 0);
         }
         for (;;) {
@@ -600,7 +615,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 if (c < nch) {
-                    int m = (n - 3) - (c * COOP_NP + p);
+                    int m = (n - 2 - COOP_CL) - (c * COOP_NP + p);
                     if (m >= 0) {
                         double e15[SWD_NENT];
                         swd_layer_entries(Lmine[c], wvno, wvno2, omega, iomega, e15);
