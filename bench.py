@@ -160,6 +160,16 @@ def main():
     dom = max(per_launch_ms, key=per_launch_ms.get)
     dom_ms = per_launch_ms[dom]
     achieved = ALG_BYTES_PER_EVAL * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM bytes per launch of that kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only
+    # valid for the configuration it was collected on
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj.get("chains") == nchain and dom in tj:
+            traffic = tj[dom]
+    except Exception:
+        traffic = None
     res = {
         "metric": "leapfrog steps/sec (= forward+grad evals/sec) per GPU and whole node, 30-layer model",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,7 +179,8 @@ def main():
                    "chains_per_gpu": nchain, "nlayer": N_LAYER, "nt": NT, "nper": NPER,
                    "parallelism": f"independent chains x{world}", "root_search_failures": nfail},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_EVAL * nchain,
                      "avg_launch_ms": dom_ms,
                      "note": "path is FP64-VALU/transcendental bound (SURVEY 8(d)); see fp64_vector"},
         "fp64_vector": {"achieved_tflops": ALG_FLOPS_PER_EVAL * value / world / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
