@@ -399,10 +399,15 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         KTimer t(c, RFS_K_COMBINE, c->stream);
         SwdRows R = make_rows(c->ntRc, c->ntRg, c->d_tRg.as<double>());
         int nt = c->has_rf ? c->f.nt : 0;
-        hipLaunchKernelGGL(k_joint_combine, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n, c->mode,
-                           nt, R, c->has_rf ? rf_nparts(c->f) : 0, c->wt, c->PG.as<double>(), c->mrf.as<double>(),
-                           c->cr.as<double>(), c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(),
-                           c->sflag.as<int>(), Q.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag);
+        if (c->has_rf)
+            hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
+                               (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
+                               c->cr.as<double>(), misfit, grad, flag);
+        if (c->has_swd)
+            hipLaunchKernelGGL(k_swd_combine, dim3((nchain + 63) / 64), dim3(64, 4), (size_t)n * 64 * sizeof(double),
+                               c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),
+                               c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),
+                               Q.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag);
         HIPCHK(c, hipGetLastError());
     }
     return RFS_OK;

@@ -730,78 +730,95 @@ __global__ void k_swd_export(int nchain, int n, SwdRows R, int row0, int nrow, c
 }
 
 // ---------------------------------------------------------------------------------------
-// K5 combine: one block per chain, thread = layer.  Chain rule, K.r contractions, weighted
-// joint misfit/gradient and the plugins' failure returns.
-// mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198),
-//       2 SWD only (model_surf.py:155-228)
-// ---------------------------------------------------------------------------------------
+// K5 split in two so that every large array is read coalesced:
+//   k_rf_reduce   block = chain, thread = layer : fixed-order sum of the pass-B partials + chain rule -> grad
+//   k_swd_combine block = 64 chains x 4 layer groups, lane = chain : K.r over the periods (krn is chain-minor),
+//                 interface -> thickness suffix sums, weighting, misfit, failure returns
+// mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198), 2 SWD only (model_surf.py:155-228)
 __global__ void __launch_bounds__(MAXL)
-k_joint_combine(int nchain, int n, int mode, int nt, SwdRows R, int npart, double wt,
-                const double* __restrict__ PG, const double* __restrict__ misfit_rf,
-                const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
-                const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
-                const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
-                double* __restrict__ dsyn, int* __restrict__ flag)
+k_rf_reduce(int nchain, int n, int rf_only, int npart, const double* __restrict__ PG,
+            const double* __restrict__ misfit_rf, const double* __restrict__ cr,
+            double* __restrict__ misfit, double* __restrict__ grad, int* __restrict__ flag)
 {
-    __shared__ double hsum[MAXL];
-    __shared__ double msw;
     int chain = blockIdx.x, j = threadIdx.x;
-    const int nswd = R.ntRc + R.ntRg, ndata = nt + nswd;
-    bool ok = true;
-    if (mode != 1) for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
-    double g_vs = 0.0, g_thk = 0.0, hj = 0.0;
-    double dadb = 0.0, drdadb = 0.0;
-    if (j < n) { dadb = cr[((size_t)chain * 2) * n + j]; drdadb = cr[((size_t)chain * 2 + 1) * n + j]; }
-    if (mode != 2 && j < n) {
+    if (j < n) {
+        double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         const double* pg = PG + (size_t)chain * npart * 4 * n;
         for (int p = 0; p < npart; p++) {
             s0 += pg[((size_t)p * 4 + 0) * n + j]; s1 += pg[((size_t)p * 4 + 1) * n + j];
             s2 += pg[((size_t)p * 4 + 2) * n + j]; s3 += pg[((size_t)p * 4 + 3) * n + j];
         }
-        g_vs = s2 + dadb * s1 + drdadb * s0;          // kvs + dadb kvp + drda dadb krho (model_rf.py:189)
-        g_thk = s3;
+        grad[(size_t)chain * 2 * n + j] = s2 + dadb * s1 + drdadb * s0;       // model_rf.py:189
+        grad[(size_t)chain * 2 * n + n + j] = s3;
     }
-    double m_swd = 0.0, gs_vs = 0.0;
-    if (mode != 1 && ok) {
-        for (int row = 0; row < nswd; row++) {
-            double d = (row < R.ntRc) ? croot[(size_t)row * nchain + chain]
-                                      : ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
-            double r = d - dobs[nt + row];
-            m_swd += r * r;
-            if (j < n) {
+    if (rf_only && j == 0) { misfit[chain] = misfit_rf[chain]; flag[chain] = 1; }
+}
+
+__global__ void __launch_bounds__(256)
+k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const double* __restrict__ misfit_rf,
+              const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
+              const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
+              const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
+              double* __restrict__ dsyn, int* __restrict__ flag)
+{
+    extern __shared__ double hs[];               // [n][64] interface partial sums
+    const int tx = threadIdx.x, ty = threadIdx.y, TY = blockDim.y;
+    int chain = blockIdx.x * 64 + tx;
+    const bool inb = chain < nchain;
+    if (!inb) chain = nchain - 1;
+    const int nswd = R.ntRc + R.ntRg, ndata = nt + nswd;
+    bool ok = true;
+    for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
+    const double w = (mode == 0) ? wt : 1.0;
+    double m_swd = 0.0;
+    for (int j = ty; j < n; j += TY) {
+        double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
+        double gs = 0.0, hj = 0.0;
+        if (ok) {
+            for (int row = 0; row < nswd; row++) {
+                double d = (row < R.ntRc) ? croot[(size_t)row * nchain + chain]
+                                          : ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
+                double r = d - dobs[nt + row];
+                if (j == ty && ty == 0) {
+                    m_swd += r * r;
+                    if (inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
+                }
                 double ka = swd_kernel_value(R, row, 0, j, chain, nchain, n, krn, croot, ugr);
                 double kb = swd_kernel_value(R, row, 1, j, chain, nchain, n, krn, croot, ugr);
                 double kr = swd_kernel_value(R, row, 2, j, chain, nchain, n, krn, croot, ugr);
                 double kh = swd_kernel_value(R, row, 3, j, chain, nchain, n, krn, croot, ugr);
-                gs_vs += r * (kb + ka * dadb + kr * drdadb);     // model_surf.py:184
+                gs += r * (kb + ka * dadb + kr * drdadb);                    // model_surf.py:184
                 hj += r * kh;
             }
-            if (j == 0 && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
         }
-        m_swd *= 0.5;
+        hs[(size_t)j * 64 + tx] = hj;
+        if (inb) {
+            size_t o = (size_t)chain * 2 * n + j;
+            if (!ok) grad[o] = 0.0;
+            else grad[o] = ((mode == 0) ? grad[o] : 0.0) + w * gs;
+        }
     }
-    hsum[j] = hj;
-    if (j == 0) msw = m_swd;
     __syncthreads();
-    double gs_thk = 0.0;
-    if (j < n) for (int m = j + 1; m < n; m++) gs_thk += hsum[m];   // interface -> thickness partials
+    for (int j = ty; j < n; j += TY) {
+        double t = 0.0;
+        for (int m = j + 1; m < n; m++) t += hs[(size_t)m * 64 + tx];       // interface -> thickness partials
+        if (inb) {
+            size_t o = (size_t)chain * 2 * n + n + j;
+            if (!ok) grad[o] = 0.0;
+            else grad[o] = ((mode == 0) ? grad[o] : 0.0) + w * t;
+        }
+    }
+    if (!inb) return;
     if (!ok) {
         // failure returns: joint -> (0, zeros, dobs, False); SWD only -> (0, zeros, zeros, False)
-        if (j < n) { grad[(size_t)chain * 2 * n + j] = 0.0; grad[(size_t)chain * 2 * n + n + j] = 0.0; }
-        if (dsyn) for (int i = j; i < ndata; i += blockDim.x)
-            dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
-        if (j == 0) { misfit[chain] = 0.0; flag[chain] = 0; }
+        if (dsyn) for (int i = ty; i < ndata; i += TY) dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
+        if (ty == 0) { misfit[chain] = 0.0; flag[chain] = 0; }
         return;
     }
-    double w = (mode == 0) ? wt : 1.0;
-    if (j < n) {
-        grad[(size_t)chain * 2 * n + j] = g_vs + w * gs_vs;
-        grad[(size_t)chain * 2 * n + n + j] = g_thk + w * gs_thk;
-    }
-    if (j == 0) {
-        double mr = (mode != 2) ? misfit_rf[chain] : 0.0;
-        misfit[chain] = mr + w * msw;
+    if (ty == 0) {
+        double mr = (mode == 0) ? misfit_rf[chain] : 0.0;
+        misfit[chain] = mr + w * (0.5 * m_swd);
         flag[chain] = 1;
     }
 }
