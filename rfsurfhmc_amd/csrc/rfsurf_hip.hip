@@ -296,8 +296,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
                                    c->mdl.as<float>(), c->mdlc.as<double>(), c->croot.as<double>(),             \
                                    c->sflag.as<int>());                                                         \
             } while (0)
-            if (nch <= 4) RFS_LAUNCH_COOP(4);
-            else if (nch <= 5) RFS_LAUNCH_COOP(5);
+            if (nch <= 5) RFS_LAUNCH_COOP(5);
             else if (nch <= 8) RFS_LAUNCH_COOP(8);
             else RFS_LAUNCH_COOP(16);
 #undef RFS_LAUNCH_COOP

@@ -503,29 +503,32 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
 // vector-independent entries of one layer per chunk of 7 layers into a double-buffered LDS ring,
 // one chunk ahead of the consumer.  Nothing is computed twice, and the serial path per secular
 // evaluation shrinks to (one layer's entries) + (the 25-FMA recurrence over all layers).
-constexpr int COOP_NP = 7;                       // producer waves = layers per chunk
-#ifndef RFS_COOP_CL
-#define RFS_COOP_CL 1
+#ifndef RFS_COOP_NC
+#define RFS_COOP_NC 1
 #endif
-constexpr int COOP_CL = RFS_COOP_CL;             // 1: the consumer builds the deepest finite layer itself
-template <int NCH>                               // chunks held in registers: (n-1) <= NCH*COOP_NP
+constexpr int COOP_NC = RFS_COOP_NC;             // consumer waves (each owns 64/COOP_NC of the block's items)
+constexpr int COOP_NP = 8 - COOP_NC;             // producer waves = layers per chunk
+constexpr int COOP_CL = 1;                       // the consumers build the deepest finite layer themselves
+template <int NCH>                               // chunks held in registers: (n-1-COOP_CL) <= NCH*COOP_NP
 __global__ void __launch_bounds__(512)
 k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                  const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
 {
     extern __shared__ double lds[];
     double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
-    int* go = (int*)(lds + 4 * 64);              // block-wide "another evaluation follows"
+    int* go = (int*)(lds + 4 * 64);              // go[w]: consumer w has another evaluation
     double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][15][64]
     double* nev = ent + 2 * COOP_NP * SWD_NENT * 64;    // [24][64] Neville tables of the 64 state machines
     double* tper = nev + 24 * 64;                       // [nseq][nper_max] scaled periods (no global loads in the loop)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int item = blockIdx.x * 64 + lane;
+    constexpr int IPC = 64 / COOP_NC;            // items per consumer wave
+    // block-lane = which of the block's 64 items this thread works on
+    const int bl = (wave < COOP_NC) ? wave * IPC + (lane % IPC) : lane;
+    int item = blockIdx.x * 64 + bl;
     int seq = item / nchain, chain = item - seq * nchain;
-    const bool live = seq < Q.nseq;
-    if (!live) { seq = 0; chain = 0; }
-    // the consumer itself builds the deepest finite layer (n-2) while the producers work on chunk 0, so the
-    // producers share layers n-3 .. 0: 4 chunks of 7 for a 30-layer model instead of 5
+    bool live = seq < Q.nseq;
+    if (wave < COOP_NC && lane >= IPC) live = false;     // upper lanes of a consumer wave idle
+    if (seq >= Q.nseq) { seq = 0; chain = 0; }
     const int nprod = n - 1 - COOP_CL;           // layers handled by the producers
     const int nch = (nprod + COOP_NP - 1) / COOP_NP;
     int npmax = 0;
@@ -534,6 +537,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         int q = i / npmax, k = i - q * npmax;
         tper[i] = (k < Q.s[q].nper) ? Q.s[q].t[k] * Q.s[q].scale : 1.0;
     }
+    if (threadIdx.x < 8) go[threadIdx.x] = 0;
     __syncthreads();
     const double* lc0 = mdlc + chain;
     auto loadL = [&](int m) {
@@ -541,9 +545,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
-    if (wave == 0) {
-        // the consumer is the block's critical path and shares its SIMD with one producer wave:
-        // static priority lets its dependent chain issue first, the producer fills the gaps
+    if (wave < COOP_NC) {
+        // the consumers are the block's critical path: static priority lets their dependent chains issue first
         __builtin_amdgcn_s_setprio(3);
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
@@ -553,7 +556,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         double* cr = croot + (size_t)sq.croot_off * nchain + chain;
         auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
         RootSearchT<NevTabMem> rs;
-        rs.tab.base = nev + lane; rs.tab.stride = 64;
+        rs.tab.base = nev + bl; rs.tab.stride = 64;
         rs.begin(M, T, sq.nper);
         if (!live) rs.done = 1;
         const SwdLayerC Lhalf = loadL(n - 1), Ldeep = loadL(n - 2);
@@ -561,10 +564,13 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
             int more = __any(!rs.done);
             double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
             double wvno = rs.omega / rs.creq, wvno2 = wvno * wvno, iomega = 1.0 / omega;
-            req[lane] = wvno; req[64 + lane] = wvno2; req[128 + lane] = omega; req[192 + lane] = iomega;
-            if (lane == 0) *go = more;
+            if (lane < IPC) { req[bl] = wvno; req[64 + bl] = wvno2; req[128 + bl] = omega; req[192 + bl] = iomega; }
+            if (lane == 0) go[wave] = more;
             __syncthreads();                                     // B0
-            if (!more) break;
+            int any_more = 0;
+#pragma unroll
+            for (int w = 0; w < COOP_NC; w++) any_more |= go[w];
+            if (!any_more) break;
             double e[5];
             swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
             const double tt = -2.0 * wvno2;
@@ -575,7 +581,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
             }
             for (int c = 0; c < nch; c++) {
                 __syncthreads();                                 // chunk c is in buffer c&1
-                const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + lane;
+                const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + bl;
                 const int nl = min(COOP_NP, nprod - c * COOP_NP);        // layers in this chunk
                 // software pipeline: the LDS reads of layer i+1 are in flight while layer i's 25 FMAs issue
                 double bufA[SWD_NENT], bufB[SWD_NENT];
@@ -594,14 +600,15 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                     }
                     if (i + 1 < nl) swd_apply_layer_raw(e, bufB, tt);
                 }
-                swd_rescale_pow2(e);                             // once per chunk of 7 layers
+                swd_rescale_pow2(e);                             // once per chunk
             }
             if (!rs.done) rs.advance(swd_finish(e), T, out);
+            if (COOP_NC > 1) __syncthreads();                    // B_end: go[] may be rewritten
         }
         if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
     } else {
         __builtin_amdgcn_s_setprio(2);           // the search is the step's critical path: outrank co-resident RF waves
-        const int p = wave - 1;
+        const int p = wave - COOP_NC;
         SwdLayerC Lmine[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -610,7 +617,10 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         }
         for (;;) {
             __syncthreads();                                     // B0
-            if (!*go) break;
+            int any_more = 0;
+#pragma unroll
+            for (int w = 0; w < COOP_NC; w++) any_more |= go[w];
+            if (!any_more) break;
             double wvno = req[lane], wvno2 = req[64 + lane], omega = req[128 + lane], iomega = req[192 + lane];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -626,6 +636,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                     __syncthreads();
                 }
             }
+            if (COOP_NC > 1) __syncthreads();                    // B_end
         }
     }
 }
