@@ -369,7 +369,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     // ... but only while the RF kernels on half a chip stay shorter than the search (both scale with the layer
     // count; RF with chains x frequencies, the search with the number of periods): calibrated at config 2
     const double rf_half = c->has_rf ? (nchain / 8192.0) * ((c->f.n2 - 1) / 256.0) : 0.0;
-    const bool part = c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
+    // (not on the context's own stream: there the extra masked streams were measured to share a hardware
+    // queue with it and serialise -- the host-pointer entries keep the shared-CU schedule)
+    const bool part = !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
                       c->swd_lanes == 0 && Q.nseq * nchain >= 1024 && nblk <= c->ncu / 2 &&
                       rf_half <= 1.1 * (npmax / 40.0);
     if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
