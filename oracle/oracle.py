@@ -71,13 +71,15 @@ def lib() -> ctypes.CDLL:
 # --------------------------------------------------------------------------
 # B1 level: same call signatures as the reference's pybind11 modules
 # --------------------------------------------------------------------------
-_WAVETYPES = {"Rc": 0, "Rg": 1}
+_WAVETYPES = {"Rc": 0, "Rg": 1, "Lc": 2, "Lg": 3}
 
 
 class _LibSurf:
-    """Restatement of libsurf (src/SWD/main.cpp:14-93), Rayleigh + flat earth only."""
+    """Restatement of libsurf (src/SWD/main.cpp:14-93): Rc/Rg/Lc/Lg, flat or spherical earth,
+    fundamental mode.  Love kernels leave dcda at zero (the reference never writes it:
+    surfdisp.cpp:258-296)."""
 
-    nsec = 0  # secular-function evaluations of the last call (work accounting)
+    nsec = 0  # secular-function evaluations of the last Rc/Rg flat call (work accounting)
 
     @staticmethod
     def _prep(thk, vp, vs, rho, period):
@@ -87,33 +89,39 @@ class _LibSurf:
         return f32, t
 
     def forward(self, thk, vp, vs, rho, period, wavetype, mode=0, sphere=False):
-        if wavetype not in _WAVETYPES or mode != 0 or sphere:
-            raise NotImplementedError("oracle covers Rc/Rg, fundamental mode, flat earth")
+        if wavetype not in _WAVETYPES or mode != 0:
+            raise NotImplementedError("oracle covers Rc/Rg/Lc/Lg, fundamental mode")
         (h, a, b, r), t = self._prep(thk, vp, vs, rho, period)
         n, nt = len(h), len(t)
         cg = np.zeros(nt)
         L = lib()
-        if wavetype == "Rc":
+        if wavetype == "Rc" and not sphere:
             nsec = ctypes.c_long(0)
             ierr = L.orc_surfdisp_rc(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt,
                                      ctypes.byref(nsec))
             _LibSurf.nsec = nsec.value
         else:
-            ierr = L.orc_rayleigh_group(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt)
+            ierr = L.orc_swd_forward(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt,
+                                     _WAVETYPES[wavetype], int(bool(sphere)))
         return cg, ierr != 1
 
     def adjoint_kernel(self, thk, vp, vs, rho, period, wavetype, mode=0, sphere=False):
-        if wavetype not in _WAVETYPES or mode != 0 or sphere:
-            raise NotImplementedError("oracle covers Rc/Rg, fundamental mode, flat earth")
+        if wavetype not in _WAVETYPES or mode != 0:
+            raise NotImplementedError("oracle covers Rc/Rg/Lc/Lg, fundamental mode")
         (h, a, b, r), t = self._prep(thk, vp, vs, rho, period)
         n, nt = len(h), len(t)
         c = np.zeros(nt)
         ka, kb, kr, kh = (np.zeros((nt, n)) for _ in range(4))
-        nsec = ctypes.c_long(0)
-        ierr = lib().orc_surf_kernel(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(c), nt,
-                                     _d(ka), _d(kb), _d(kr), _d(kh), _WAVETYPES[wavetype],
-                                     ctypes.byref(nsec))
-        _LibSurf.nsec = nsec.value
+        if wavetype in ("Rc", "Rg") and not sphere:
+            nsec = ctypes.c_long(0)
+            ierr = lib().orc_surf_kernel(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(c), nt,
+                                         _d(ka), _d(kb), _d(kr), _d(kh), _WAVETYPES[wavetype],
+                                         ctypes.byref(nsec))
+            _LibSurf.nsec = nsec.value
+        else:
+            ierr = lib().orc_swd_kernel(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(c), nt,
+                                        _d(ka), _d(kb), _d(kr), _d(kh), _WAVETYPES[wavetype],
+                                        int(bool(sphere)))
         return c, ka, kb, kr, kh, ierr != 1
 
 

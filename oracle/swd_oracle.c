@@ -129,11 +129,51 @@ typedef struct {
     int n;
     const float *d, *a, *b, *rho;
     long nsec; /* secular-function evaluation counter (for work accounting) */
+    int ifunc; /* 1 Love (dltar1), 2 Rayleigh (dltar4): surfdisp96.f:705-723 */
 } sd_model;
+
+/* surfdisp96.f:727-787  dltar1 (Love, Haskell-Thompson from the half-space up; llw = 1) */
+static double sd_dltar1(double wvno, double omega, sd_model *M)
+{
+    int mmax = M->n;
+    M->nsec++;
+    double beta1 = (double)M->b[mmax - 1], rho1 = (double)M->rho[mmax - 1];
+    double xkb = omega / beta1;
+    double wvnop = wvno + xkb, wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double e1 = rho1 * rb, e2 = 1.0 / (beta1 * beta1);
+    for (int m = mmax - 2; m >= 0; m--) {
+        beta1 = (double)M->b[m]; rho1 = (double)M->rho[m];
+        double xmu = rho1 * beta1 * beta1;
+        xkb = omega / beta1;
+        wvnop = wvno + xkb; wvnom = fabs(wvno - xkb);
+        rb = sqrt(wvnop * wvnom);
+        double q = (double)M->d[m] * rb, y, z, cosq;
+        if (wvno < xkb) {
+            double sinq = sin(q); y = sinq / rb; z = -rb * sinq; cosq = cos(q);
+        } else if (wvno == xkb) {
+            cosq = 1.0; y = (double)M->d[m]; z = 0.0;
+        } else {
+            double fac = 0.0;
+            if (q < 16) fac = exp(-2.0 * q);
+            cosq = (1.0 + fac) * 0.5;
+            double sinq = (1.0 - fac) * 0.5;
+            y = sinq / rb; z = rb * sinq;
+        }
+        double e10 = e1 * cosq + e2 * xmu * z;
+        double e20 = e1 * y / xmu + e2 * cosq;
+        double xnor = fabs(e10), ynor = fabs(e20);
+        if (ynor > xnor) xnor = ynor;
+        if (xnor < 1.0e-40) xnor = 1.0;
+        e1 = e10 / xnor; e2 = e20 / xnor;
+    }
+    return e1;
+}
 
 /* surfdisp96.f:791-891  dltar4 (no water layer: llw = 1) */
 static double sd_dltar4(double wvno, double omga, sd_model *M)
 {
+    if (M->ifunc == 1) return sd_dltar1(wvno, omga, M);
     double e[5], ee[5], ca[5][5];
     int mmax = M->n;
     M->nsec++;
@@ -313,11 +353,52 @@ static int sd_getsol(double t1, double *c1io, double clow, double dc, double cm,
  * surfdisp96.f:54-368  surfdisp96 for iwave=2 (Rayleigh), igr=0, iflsph=0,
  * mode=1 (fundamental).  Returns ierr; cg[k] = float32-rounded phase velocity.
  */
+/* surfdisp96.f:495-564  sphere: earth-flattening of the float32 work arrays (note ar = 6370 here,
+ * 6371 in sregn96/slegn96; d(mmax) is forced to 1 first; powers in single precision) */
+static void sd_sphere(int ifunc, int iflag, float *d, float *a, float *b, float *rho, float *rtp,
+                      float *dtp, float *btp, int mmax, float *dhalf)
+{
+    double ar = 6370.0, dr = 0.0, r0 = ar, r1, z0, z1, tmp;
+    d[mmax - 1] = 1.0f;
+    if (iflag == 0) {
+        for (int i = 0; i < mmax; i++) { dtp[i] = d[i]; rtp[i] = rho[i]; }
+        for (int i = 0; i < mmax; i++) {
+            dr = dr + (double)d[i];
+            r1 = ar - dr;
+            z0 = ar * log(ar / r0);
+            z1 = ar * log(ar / r1);
+            d[i] = (float)(z1 - z0);
+            tmp = (ar + ar) / (r0 + r1);
+            a[i] = (float)((double)a[i] * tmp);
+            b[i] = (float)((double)b[i] * tmp);
+            btp[i] = (float)tmp;
+            r0 = r1;
+        }
+        *dhalf = d[mmax - 1];
+    } else {
+        d[mmax - 1] = *dhalf;
+        for (int i = 0; i < mmax; i++) {
+            if (ifunc == 1) {       /* btp**(-5): integer power by squaring, then reciprocal */
+                float x2 = btp[i] * btp[i], x4 = x2 * x2, x5 = btp[i] * x4;
+                rho[i] = rtp[i] * (1.0f / x5);
+            }
+            else if (ifunc == 2) rho[i] = rtp[i] * powf(btp[i], -2.275f);
+        }
+    }
+    d[mmax - 1] = 0.0f;
+}
+
 static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
                          const float *rhom, int nlayer, int kmax, const double *t,
-                         double *cg, long *nsec)
+                         double *cg, long *nsec, int iwave, int iflsph)
 {
-    sd_model M = { nlayer, thkm, vpm, vsm, rhom, 0 };
+    float *wk = (float *)malloc(sizeof(float) * 7 * (size_t)nlayer);
+    float *wd = wk, *wa = wk + nlayer, *wb = wk + 2 * nlayer, *wr = wk + 3 * nlayer;
+    float *rtp = wk + 4 * nlayer, *dtp = wk + 5 * nlayer, *btp = wk + 6 * nlayer, dhalf = 0.0f;
+    for (int i = 0; i < nlayer; i++) { wb[i] = vsm[i]; wa[i] = vpm[i]; wd[i] = thkm[i]; wr[i] = rhom[i]; }
+    if (iflsph == 1) sd_sphere(0, 0, wd, wa, wb, wr, rtp, dtp, btp, nlayer, &dhalf);
+    thkm = wd; vpm = wa; vsm = wb; rhom = wr;
+    sd_model M = { nlayer, thkm, vpm, vsm, rhom, 0, iwave };
     int ierr = 0;
     float betmx = -1.e20f, betmn = 1.e20f;
     int jmn = 0, jsol = 1;
@@ -326,6 +407,7 @@ static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
         else if (vsm[i] <= 0.01f && vpm[i] < betmn) { betmn = vpm[i]; jmn = i; jsol = 0; }
         if (vsm[i] > betmx) betmx = vsm[i];
     }
+    if (iflsph == 1) sd_sphere(iwave, 1, wd, wa, wb, wr, rtp, dtp, btp, nlayer, &dhalf);
     float ddc = 0.005f, sone = 1.5f;
     double one = 1.0e-2; (void)one;
     double onea = (double)sone;
@@ -356,7 +438,37 @@ static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
         for (int i = k; i < kmax; i++) cg[i] = 0.0;
     }
     free(c);
+    free(wk);
     if (nsec) *nsec += M.nsec;
+    return ierr;
+}
+
+/* surfdisp.cpp:16-49  _flat2sphere: wave 'L' or 'R', kind 'c' (phase) or 'g' (group) */
+static double sd_flat2sphere(double t, double c, char wave, char kind)
+{
+    double ar = 6371.0, omega = 2.0 * 3.14159265358979323846 / t, tm;
+    if (wave == 'L') tm = 1. + pow(1.5 * c / (ar * omega), 2);
+    else tm = 1. + pow(0.5 * c / (ar * omega), 2);
+    tm = sqrt(tm);
+    return (kind == 'c') ? c / tm : c * tm;
+}
+
+/* surfdisp.cpp:62-109  _surfdisp for phase velocities: iwave 1 Love / 2 Rayleigh */
+static int sd_surfdisp(const float *thk, const float *vp, const float *vs, const float *rho,
+                       int nlayer, const double *t, double *cg, int kmax, int iwave, int sphere,
+                       int keep_flat, long *nsec)
+{
+    int ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, kmax, t, cg, nsec, iwave, sphere);
+    if (ierr != 0) {
+        for (int i = 0; i < kmax; i++) {
+            if (cg[i] == 0.0 || isnan(cg[i])) {
+                ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, 1, &t[i], &cg[i], nsec, iwave, sphere);
+                if (ierr != 0) return ierr;
+            }
+        }
+    }
+    if (sphere && !keep_flat)
+        for (int i = 0; i < kmax; i++) cg[i] = sd_flat2sphere(t[i], cg[i], iwave == 1 ? 'L' : 'R', 'c');
     return ierr;
 }
 
@@ -364,16 +476,14 @@ static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
 int orc_surfdisp_rc(const float *thk, const float *vp, const float *vs, const float *rho,
                     int nlayer, const double *t, double *cg, int kmax, long *nsec)
 {
-    int ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, kmax, t, cg, nsec);
-    if (ierr != 0) {
-        for (int i = 0; i < kmax; i++) {
-            if (cg[i] == 0.0 || isnan(cg[i])) {
-                ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, 1, &t[i], &cg[i], nsec);
-                if (ierr != 0) return ierr;
-            }
-        }
-    }
-    return ierr;
+    return sd_surfdisp(thk, vp, vs, rho, nlayer, t, cg, kmax, 2, 0, 1, nsec);
+}
+
+/* general phase-velocity entry: wave 1 Love / 2 Rayleigh, sphere 0/1, keep_flat 0/1 */
+int orc_surfdisp(const float *thk, const float *vp, const float *vs, const float *rho, int nlayer,
+                 const double *t, double *cg, int kmax, int iwave, int sphere, int keep_flat, long *nsec)
+{
+    return sd_surfdisp(thk, vp, vs, rho, nlayer, t, cg, kmax, iwave, sphere, keep_flat, nsec);
 }
 
 /* ================================================================== */
@@ -382,6 +492,7 @@ int orc_surfdisp_rc(const float *thk, const float *vp, const float *vs, const fl
 
 typedef struct {
     int mmax;
+    double vtp[ORC_MAXL], dtp[ORC_MAXL], rtp[ORC_MAXL];   /* earth-flattening factors (bldsph) */
     double zd[ORC_MAXL], zrho[ORC_MAXL], za[ORC_MAXL], zb[ORC_MAXL];
     double xmu[ORC_MAXL], xlam[ORC_MAXL];
     double ur[ORC_MAXL], uz[ORC_MAXL], tz[ORC_MAXL], tr[ORC_MAXL];
@@ -810,13 +921,38 @@ static void sr_energy(sr_state *S, double om, double wvno)
     sr_getdcdh(S, om2, wvno, wvno2, fac);
 }
 
+/* sregn96.f90:133-187  bldsph (Rayleigh: density exponent -2.275, ar = 6371) */
+static void sr_bldsph(sr_state *S)
+{
+    double ar = 6371.0, dr = 0.0, r0 = ar, r1, z0, z1, tmp;
+    int mmax = S->mmax;
+    for (int i = 0; i < mmax; i++) {
+        if (i == mmax - 1) dr = dr + 1.0; else dr = dr + S->zd[i];
+        r1 = ar - dr;
+        z0 = ar * log(ar / r0);
+        z1 = ar * log(ar / r1);
+        tmp = (2.0 * ar) / (r0 + r1);
+        S->vtp[i] = tmp;
+        S->rtp[i] = pow(tmp, (double)-2.275f);    /* default-real exponent literal */
+        S->dtp[i] = ar / r0;
+        S->za[i] = S->za[i] * tmp; S->zb[i] = S->zb[i] * tmp;
+        S->zrho[i] = S->zrho[i] * S->rtp[i];
+        S->zd[i] = z1 - z0;
+        r0 = r1;
+    }
+    S->zd[mmax - 1] = 0.0;
+}
+
 static void sr_load_model(sr_state *S, const float *thk, const float *vp, const float *vs,
-                          const float *rhom, int nlayer)
+                          const float *rhom, int nlayer, int iflsph)
 {
     S->mmax = nlayer;
     for (int i = 0; i < nlayer; i++) {
         S->zb[i] = (double)vs[i]; S->za[i] = (double)vp[i];
         S->zrho[i] = (double)rhom[i]; S->zd[i] = (double)thk[i];
+    }
+    if (iflsph > 0) sr_bldsph(S);
+    for (int i = 0; i < nlayer; i++) {
         S->xmu[i] = S->zrho[i] * (S->zb[i] * S->zb[i]);
         S->xlam[i] = S->zrho[i] * (S->za[i] * S->za[i]) - 2 * S->xmu[i];
     }
@@ -836,45 +972,63 @@ static void sr_suffix_sum(double *dcdh, int mmax)
     dcdh[mmax - 1] = 0.0;
 }
 
-/* sregn96.f90:1637-1745  sregn96 (flat earth) */
+/* sregn96.f90:1637-1745  sregn96; *cp is replaced by the spherical phase velocity when iflsph > 0 */
+void orc_sregn96s(const float *thk, const float *vp, const float *vs, const float *rhom,
+                  int nlayer, double t, double *cp, double *cg, double *dc2da, double *dc2db,
+                  double *dc2dh, double *dc2dr, int iflsph)
+{
+    sr_state *S = (sr_state *)calloc(1, sizeof(sr_state));
+    sr_load_model(S, thk, vp, vs, rhom, nlayer, iflsph);
+    double twopi = 2.0 * SR_PI;
+    double omega = twopi / t;
+    double c = *cp;
+    double wvno = omega / c;
+    sr_svfunc(S, omega, wvno);
+    sr_energy(S, omega, wvno);
+    if (fabs(S->ugr) < 1.0e-36) S->ugr = 0.0;
+    double csph = c, usph = S->ugr;
+    if (iflsph > 0) {           /* sprayl, sregn96.f90:1591-1635 */
+        double ar = 6371.0, tm = sqrt(1. + (c / (2. * ar * omega)) * (c / (2. * ar * omega)));
+        for (int i = 0; i < nlayer; i++) {
+            S->dcda[i] = S->dcda[i] * S->vtp[i] / (tm * tm * tm);
+            S->dcdb[i] = S->dcdb[i] * S->vtp[i] / (tm * tm * tm);
+            S->dcdh[i] = S->dcdh[i] * S->dtp[i] / (tm * tm * tm);
+            S->dcdr[i] = S->dcdr[i] * S->rtp[i] / (tm * tm * tm);
+        }
+        usph = S->ugr * tm; csph = c / tm;
+    }
+    sr_suffix_sum(S->dcdh, nlayer);
+    for (int i = 0; i < nlayer; i++) {
+        dc2da[i] = S->dcda[i]; dc2db[i] = S->dcdb[i];
+        dc2dr[i] = S->dcdr[i]; dc2dh[i] = S->dcdh[i];
+    }
+    *cp = csph; *cg = usph;
+    free(S);
+}
+
 void orc_sregn96(const float *thk, const float *vp, const float *vs, const float *rhom,
                  int nlayer, double t, double cp, double *cg, double *ur, double *uz,
                  double *tr, double *tz, double *dc2da, double *dc2db, double *dc2dh,
                  double *dc2dr)
 {
-    sr_state *S = (sr_state *)calloc(1, sizeof(sr_state));
-    sr_load_model(S, thk, vp, vs, rhom, nlayer);
-    double twopi = 2.0 * SR_PI;
-    double omega = twopi / t;
-    double c = cp;
-    double wvno = omega / c;
-    sr_svfunc(S, omega, wvno);
-    sr_energy(S, omega, wvno);
-    if (fabs(S->ugr) < 1.0e-36) S->ugr = 0.0;
-    sr_suffix_sum(S->dcdh, nlayer);
-    for (int i = 0; i < nlayer; i++) {
-        dc2da[i] = S->dcda[i]; dc2db[i] = S->dcdb[i];
-        dc2dr[i] = S->dcdr[i]; dc2dh[i] = S->dcdh[i];
-        if (ur) { ur[i] = S->ur[i]; uz[i] = S->uz[i]; tr[i] = S->tr[i]; tz[i] = S->tz[i]; }
-    }
-    *cg = S->ugr;
-    free(S);
+    (void)ur; (void)uz; (void)tr; (void)tz;
+    orc_sregn96s(thk, vp, vs, rhom, nlayer, t, &cp, cg, dc2da, dc2db, dc2dh, dc2dr, 0);
 }
 
-/* sregn96.f90:1747-1888  sregnpu (flat earth).  The first term of du/dm uses the
- * module arrays dcda.. which at that point hold the t2 pass (quirk, :1841-1844). */
-void orc_sregnpu(const float *thk, const float *vp, const float *vs, const float *rhom,
-                 int nlayer, double t, double cp, double *cg, double t1, double cp1,
-                 double t2, double cp2, double *dc2da, double *dc2db, double *dc2dh,
-                 double *dc2dr, double *du2da, double *du2db, double *du2dh, double *du2dr)
+/* sregn96.f90:1747-1888  sregnpu.  The first term of du/dm uses the module arrays dcda.. which at
+ * that point hold the t2 pass (quirk, :1841-1844).  *cp, *cg become spherical when iflsph > 0. */
+void orc_sregnpus(const float *thk, const float *vp, const float *vs, const float *rhom,
+                  int nlayer, double t, double *cp, double *cg, double t1, double cp1,
+                  double t2, double cp2, double *dc2da, double *dc2db, double *dc2dh,
+                  double *dc2dr, double *du2da, double *du2db, double *du2dh, double *du2dr, int iflsph)
 {
     sr_state *S = (sr_state *)calloc(1, sizeof(sr_state));
     double *w = (double *)calloc((size_t)8 * nlayer, sizeof(double));
     double *a1 = w, *b1 = w + nlayer, *r1 = w + 2 * nlayer, *h1 = w + 3 * nlayer;
     double *a2 = w + 4 * nlayer, *b2 = w + 5 * nlayer, *r2 = w + 6 * nlayer, *h2 = w + 7 * nlayer;
-    sr_load_model(S, thk, vp, vs, rhom, nlayer);
+    sr_load_model(S, thk, vp, vs, rhom, nlayer, iflsph);
     double twopi = 2.0 * SR_PI;
-    double omega = twopi / t, wvno = omega / cp;
+    double omega = twopi / t, wvno = omega / *cp;
     sr_svfunc(S, omega, wvno); sr_energy(S, omega, wvno);
     *cg = S->ugr;
     for (int i = 0; i < nlayer; i++) {
@@ -890,12 +1044,266 @@ void orc_sregnpu(const float *thk, const float *vp, const float *vs, const float
     for (int i = 0; i < nlayer; i++) {
         a2[i] = S->dcda[i]; b2[i] = S->dcdb[i]; r2[i] = S->dcdr[i]; h2[i] = S->dcdh[i];
     }
-    double uc1 = *cg / cp;
+    double uc1 = *cg / *cp;
     for (int i = 0; i < nlayer; i++) {
         du2da[i] = uc1 * (2.0 - uc1) * S->dcda[i] - uc1 * uc1 * t * (a2[i] - a1[i]) / (t2 - t1);
         du2db[i] = uc1 * (2.0 - uc1) * S->dcdb[i] - uc1 * uc1 * t * (b2[i] - b1[i]) / (t2 - t1);
         du2dr[i] = uc1 * (2.0 - uc1) * S->dcdr[i] - uc1 * uc1 * t * (r2[i] - r1[i]) / (t2 - t1);
         du2dh[i] = uc1 * (2.0 - uc1) * S->dcdh[i] - uc1 * uc1 * t * (h2[i] - h1[i]) / (t2 - t1);
+    }
+    if (iflsph > 0) {           /* sregn96.f90:1848-1868 */
+        double ar = 6371.0;
+        omega = twopi / t;
+        double tm = sqrt(1. + (*cp / (2. * ar * omega)) * (*cp / (2. * ar * omega)));
+        double tm1 = (0.5 / (ar * omega)) * (0.5 / (ar * omega)) / tm;
+        for (int i = 0; i < nlayer; i++) {
+            du2da[i] = (tm * du2da[i] + *cg * *cp * dc2da[i] * tm1) * S->vtp[i];
+            du2db[i] = (tm * du2db[i] + *cg * *cp * dc2db[i] * tm1) * S->vtp[i];
+            du2dr[i] = (tm * du2dr[i] + *cg * *cp * dc2dr[i] * tm1) * S->rtp[i];
+            du2dh[i] = (tm * du2dh[i] + *cg * *cp * dc2dh[i] * tm1) * S->dtp[i];
+            dc2da[i] = dc2da[i] / (tm * tm * tm) * S->vtp[i];
+            dc2db[i] = dc2db[i] / (tm * tm * tm) * S->vtp[i];
+            dc2dr[i] = dc2dr[i] / (tm * tm * tm) * S->rtp[i];
+            dc2dh[i] = dc2dh[i] / (tm * tm * tm) * S->dtp[i];
+        }
+        *cp = *cp / tm; *cg = *cg * tm;
+    }
+    sr_suffix_sum(dc2dh, nlayer);
+    sr_suffix_sum(du2dh, nlayer);
+    free(w); free(S);
+}
+
+void orc_sregnpu(const float *thk, const float *vp, const float *vs, const float *rhom,
+                 int nlayer, double t, double cp, double *cg, double t1, double cp1,
+                 double t2, double cp2, double *dc2da, double *dc2db, double *dc2dh,
+                 double *dc2dr, double *du2da, double *du2db, double *du2dh, double *du2dr)
+{
+    orc_sregnpus(thk, vp, vs, rhom, nlayer, t, &cp, cg, t1, cp1, t2, cp2, dc2da, dc2db, dc2dh, dc2dr,
+                 du2da, du2db, du2dh, du2dr, 0);
+}
+
+/* ================================================================== */
+/*                      slegn96.f90 restatement (Love)                 */
+/* ================================================================== */
+typedef struct {
+    int mmax;
+    double zd[ORC_MAXL], zb[ORC_MAXL], zrho[ORC_MAXL], xmu[ORC_MAXL];
+    double vtp[ORC_MAXL], dtp[ORC_MAXL], rtp[ORC_MAXL];
+    double uu[ORC_MAXL], tt[ORC_MAXL], exl[ORC_MAXL];
+    double dcdb[ORC_MAXL], dcdh[ORC_MAXL], dcdr[ORC_MAXL];
+    double sumi0, sumi1, sumi2, ugr;
+} sl_state;
+
+/* slegn96.f90:107-167  bldsph (Love: density exponent -5) */
+static void sl_bldsph(sl_state *S)
+{
+    double ar = 6371.0, dr = 0.0, r0 = ar, r1, z0, z1, tmp;
+    int mmax = S->mmax;
+    S->zd[mmax - 1] = 1.0;
+    for (int i = 0; i < mmax; i++) {
+        dr = dr + S->zd[i];
+        r1 = ar - dr;
+        z0 = ar * log(ar / r0);
+        z1 = ar * log(ar / r1);
+        S->dtp[i] = ar / r0;
+        tmp = (2.0 * ar) / (r0 + r1);
+        S->vtp[i] = tmp;
+        { double t2 = tmp * tmp, t4 = t2 * t2; S->rtp[i] = 1.0 / (tmp * t4); }   /* tmp**(-5) */
+        S->zb[i] = S->zb[i] * tmp;
+        S->zrho[i] = S->zrho[i] * S->rtp[i];
+        S->zd[i] = z1 - z0;
+        r0 = r1;
+    }
+    S->zd[mmax - 1] = 0.0;
+}
+
+typedef struct { double cosq, yl, zl, mu, rb, xkb, eexl; } sl_var;
+
+/* slegn96.f90:248-328  varl */
+static void sl_varl(const sl_state *S, int m, double omega, double wvno, double dpth, sl_var *v)
+{
+    v->xkb = omega / S->zb[m];
+    double wvnop = wvno + v->xkb, wvnom = fabs(wvno - v->xkb);
+    v->rb = sqrt(wvnop * wvnom);
+    double q = v->rb * dpth;
+    v->mu = S->zrho[m] * S->zb[m] * S->zb[m];
+    v->eexl = 0.0;
+    if (wvno < v->xkb) {
+        double sinq = sin(q); v->yl = sinq / v->rb; v->zl = -v->rb * sinq; v->cosq = cos(q);
+    } else if (wvno == v->xkb) {
+        v->cosq = 1.0; v->yl = dpth; v->zl = 0.0;
+    } else {
+        v->eexl = q;
+        double fac = 0.0;
+        if (q < 18.0) fac = exp(-2.0 * q);
+        v->cosq = (1.0 + fac) * 0.5;
+        double sinq = (1.0 - fac) * 0.5;
+        v->yl = sinq / v->rb; v->zl = v->rb * sinq;
+    }
+}
+
+/* slegn96.f90:372-445  up  +  :179-246 shfunc (all-solid model) */
+static void sl_shfunc(sl_state *S, double omega, double wvno)
+{
+    int mmax = S->mmax;
+    sl_var v;
+    if (S->zb[mmax - 1] > 0.01) {
+        sl_varl(S, mmax - 1, omega, wvno, 0.0, &v);
+        S->uu[mmax - 1] = 1.0; S->tt[mmax - 1] = -S->xmu[mmax - 1] * v.rb;
+    } else { S->uu[mmax - 1] = 1.0; S->tt[mmax - 1] = 0.0; }
+    S->exl[mmax - 1] = 0.0;
+    for (int k = mmax - 2; k >= 0; k--) {
+        sl_varl(S, k, omega, wvno, S->zd[k], &v);
+        double a11 = v.cosq, a22 = v.cosq, a12 = -(v.yl / v.mu), a21 = -(v.zl * v.mu);
+        double amp0 = a11 * S->uu[k + 1] + a12 * S->tt[k + 1];
+        double str0 = a21 * S->uu[k + 1] + a22 * S->tt[k + 1];
+        double rr = fabs(amp0), ss = fabs(str0);
+        if (ss > rr) rr = ss;
+        if (rr < 1.0e-30) rr = 1.0;
+        S->exl[k] = log(rr) + v.eexl;
+        S->uu[k] = amp0 / rr; S->tt[k] = str0 / rr;
+    }
+    double ext = 0.0, umax = S->uu[0];
+    S->tt[0] = 0.0;
+    for (int k = 1; k < mmax; k++) {
+        ext = ext + S->exl[k - 1];
+        double fact = 0.0;
+        if (ext < 80.0) fact = 1. / exp(ext);
+        S->uu[k] = S->uu[k] * fact; S->tt[k] = S->tt[k] * fact;
+        if (fabs(S->uu[k]) > fabs(umax)) umax = S->uu[k];
+    }
+    if (S->uu[0] != 0.0) umax = S->uu[0];
+    if (fabs(umax) > 0.0)
+        for (int k = 0; k < mmax; k++) { S->uu[k] = S->uu[k] / umax; S->tt[k] = S->tt[k] / umax; }
+}
+
+/* slegn96.f90:447-629  energy */
+static void sl_energy(sl_state *S, double omega, double wvno)
+{
+    int mmax = S->mmax;
+    double c = omega / wvno, omega2 = omega * omega, wvno2 = wvno * wvno;
+    S->sumi0 = S->sumi1 = S->sumi2 = 0.0;
+    for (int k = 0; k < mmax; k++) {
+        double TN = S->zrho[k] * S->zb[k] * S->zb[k], TL = TN, VSHH = S->zb[k], VSHV = S->zb[k];
+        double drho = S->zrho[k], dpth = S->zd[k], dmu = S->xmu[k], upup, dupdup;
+        sl_var v;
+        sl_varl(S, k, omega, wvno, dpth, &v);
+        double rb = v.rb;
+        if (rb < 1.0e-10) rb = 1.0e-10;
+        if (k == mmax - 1) {
+            upup = (0.5 / rb) * S->uu[mmax - 1] * S->uu[mmax - 1];
+            dupdup = (0.5 * rb) * S->uu[mmax - 1] * S->uu[mmax - 1];
+        } else {
+            zc nub = rb + 0.0 * I;
+            if (wvno < v.xkb) nub = 0.0 + rb * I;
+            zc xnub = dmu * nub;
+            zc ei11 = 0.5 / wvno, ei12 = 0.5 / (wvno * xnub), ei21 = 0.5 / wvno, ei22 = -0.5 / (wvno * xnub);
+            zc el11 = wvno, el12 = wvno;
+            zc km1dn = ei21 * S->uu[k] + ei22 * S->tt[k];
+            zc kmup = ei11 * S->uu[k + 1] + ei12 * S->tt[k + 1];
+            zc f3 = nub * dpth, exqq = 0.0;
+            if (creal(f3) < 40.0) exqq = cexp(-2.0 * f3);
+            zc f = (1.0 - exqq) / (2.0 * nub);
+            exqq = 0.0;
+            if (creal(f3) < 75.0) exqq = cexp(-f3);
+            zc g = dpth * exqq;
+            zc f1 = f * (el11 * el11 * kmup * kmup + el12 * el12 * km1dn * km1dn);
+            zc f2 = g * (el11 * el12 + el11 * el12) * kmup * km1dn;
+            upup = creal(f1 + f2);
+            dupdup = creal(nub * nub * (f1 - f2));
+        }
+        S->sumi0 += drho * upup; S->sumi1 += TN * upup; S->sumi2 += TL * dupdup;
+        double DCDBH = c * drho * VSHH * upup, DCDBV = c * drho * VSHV * dupdup / wvno2;
+        S->dcdb[k] = DCDBH + DCDBV;
+        S->dcdr[k] = 0.5 * c * (-c * c * upup + VSHH * VSHH * upup + VSHV * VSHV * dupdup / wvno2);
+    }
+    for (int k = 0; k < mmax; k++) { S->dcdb[k] /= S->sumi1; S->dcdr[k] /= S->sumi1; }
+    S->ugr = S->sumi1 / (c * S->sumi0);
+    double ale = 0.5 / S->sumi1, fac = ale * c / wvno2;
+    for (int k = 0; k < mmax; k++) {
+        double drho, dmu, dvdz;
+        if (k == 0) { drho = S->zrho[k]; dmu = S->xmu[k]; dvdz = 0.0; }
+        else {
+            drho = S->zrho[k] - S->zrho[k - 1]; dmu = S->xmu[k] - S->xmu[k - 1];
+            dvdz = S->tt[k] * S->tt[k] * (1.0 / S->xmu[k] - 1.0 / S->xmu[k - 1]);
+        }
+        double dfac = fac * (S->uu[k] * S->uu[k] * (omega2 * drho - wvno2 * dmu) + dvdz);
+        S->dcdh[k] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;
+    }
+}
+
+static void sl_load(sl_state *S, const float *thk, const float *vs, const float *rhom, int nlayer, int iflsph)
+{
+    S->mmax = nlayer;
+    for (int i = 0; i < nlayer; i++) { S->zb[i] = vs[i]; S->zrho[i] = rhom[i]; S->zd[i] = thk[i]; }
+    if (iflsph > 0) sl_bldsph(S);
+    for (int i = 0; i < nlayer; i++) S->xmu[i] = S->zrho[i] * (S->zb[i] * S->zb[i]);
+}
+
+/* slegn96.f90:672-783  slegn96; pi is the default-real literal 3.1415926535898 -> float32 pi (:689) */
+void orc_slegn96(const float *thk, const float *vs, const float *rhom, int nlayer, double t, double *cp,
+                 double *cg, double *dc2db, double *dc2dh, double *dc2dr, int iflsph)
+{
+    sl_state *S = (sl_state *)calloc(1, sizeof(sl_state));
+    sl_load(S, thk, vs, rhom, nlayer, iflsph);
+    double omega = 2.0 * SR_PI / t, c = *cp, wvno = omega / c;
+    sl_shfunc(S, omega, wvno);
+    sl_energy(S, omega, wvno);
+    double csph = c, usph = S->ugr;
+    if (iflsph > 0) {           /* splove, slegn96.f90:631-670 */
+        double a = 6371.0, tm = sqrt(1. + (3.0 * c / (2. * a * omega)) * (3.0 * c / (2. * a * omega)));
+        for (int i = 0; i < nlayer; i++) {
+            S->dcdb[i] = S->dcdb[i] * S->vtp[i] / (tm * tm * tm);
+            S->dcdh[i] = S->dcdh[i] * S->dtp[i] / (tm * tm * tm);
+            S->dcdr[i] = S->dcdr[i] * S->rtp[i] / (tm * tm * tm);
+        }
+        csph = c / tm; usph = S->ugr * tm;
+    }
+    sr_suffix_sum(S->dcdh, nlayer);
+    for (int i = 0; i < nlayer; i++) { dc2db[i] = S->dcdb[i]; dc2dr[i] = S->dcdr[i]; dc2dh[i] = S->dcdh[i]; }
+    *cp = csph; *cg = usph;
+    free(S);
+}
+
+/* slegn96.f90:785-919  slegnpu */
+void orc_slegnpu(const float *thk, const float *vs, const float *rhom, int nlayer, double t, double *cp,
+                 double *cg, double t1, double cp1, double t2, double cp2, double *dc2db, double *dc2dh,
+                 double *dc2dr, double *du2db, double *du2dh, double *du2dr, int iflsph)
+{
+    sl_state *S = (sl_state *)calloc(1, sizeof(sl_state));
+    double *w = (double *)calloc((size_t)6 * nlayer, sizeof(double));
+    double *b1 = w, *r1 = w + nlayer, *h1 = w + 2 * nlayer, *b2 = w + 3 * nlayer, *r2 = w + 4 * nlayer, *h2 = w + 5 * nlayer;
+    sl_load(S, thk, vs, rhom, nlayer, iflsph);
+    double twopi = 2.0 * SR_PI, omega = twopi / t, wvno = omega / *cp;
+    sl_shfunc(S, omega, wvno); sl_energy(S, omega, wvno);
+    *cg = S->ugr;
+    for (int i = 0; i < nlayer; i++) { dc2db[i] = S->dcdb[i]; dc2dr[i] = S->dcdr[i]; dc2dh[i] = S->dcdh[i]; }
+    omega = twopi / t1; wvno = omega / cp1;
+    sl_shfunc(S, omega, wvno); sl_energy(S, omega, wvno);
+    for (int i = 0; i < nlayer; i++) { b1[i] = S->dcdb[i]; r1[i] = S->dcdr[i]; h1[i] = S->dcdh[i]; }
+    omega = twopi / t2; wvno = omega / cp2;
+    sl_shfunc(S, omega, wvno); sl_energy(S, omega, wvno);
+    for (int i = 0; i < nlayer; i++) { b2[i] = S->dcdb[i]; r2[i] = S->dcdr[i]; h2[i] = S->dcdh[i]; }
+    double uc1 = *cg / *cp;
+    for (int i = 0; i < nlayer; i++) {
+        du2db[i] = uc1 * (2.0 - uc1) * S->dcdb[i] - uc1 * uc1 * t * (b2[i] - b1[i]) / (t2 - t1);
+        du2dr[i] = uc1 * (2.0 - uc1) * S->dcdr[i] - uc1 * uc1 * t * (r2[i] - r1[i]) / (t2 - t1);
+        du2dh[i] = uc1 * (2.0 - uc1) * S->dcdh[i] - uc1 * uc1 * t * (h2[i] - h1[i]) / (t2 - t1);
+    }
+    if (iflsph > 0) {
+        double ar = 6371.0;
+        omega = twopi / t;
+        double tm = sqrt(1. + (3.0 * *cp / (2. * ar * omega)) * (3.0 * *cp / (2. * ar * omega)));
+        double tm1 = (1.5 / (ar * omega)) * (1.5 / (ar * omega)) / tm;
+        for (int i = 0; i < nlayer; i++) {
+            du2db[i] = (tm * du2db[i] + *cg * *cp * dc2db[i] * tm1) * S->vtp[i];
+            du2dr[i] = (tm * du2dr[i] + *cg * *cp * dc2dr[i] * tm1) * S->rtp[i];
+            du2dh[i] = (tm * du2dh[i] + *cg * *cp * dc2dh[i] * tm1) * S->dtp[i];
+            dc2db[i] = dc2db[i] / (tm * tm * tm) * S->vtp[i];
+            dc2dr[i] = dc2dr[i] / (tm * tm * tm) * S->rtp[i];
+            dc2dh[i] = dc2dh[i] / (tm * tm * tm) * S->dtp[i];
+        }
+        *cp = *cp / tm; *cg = *cg * tm;
     }
     sr_suffix_sum(dc2dh, nlayer);
     sr_suffix_sum(du2dh, nlayer);
@@ -915,6 +1323,82 @@ int orc_rayleigh_group(const float *thk, const float *vp, const float *vs, const
                         w, w + nlayer, w + 2 * nlayer, w + 3 * nlayer);
     }
     free(cp); free(w);
+    return ierr;
+}
+
+/*
+ * General entries for all four wavetypes (0 Rc, 1 Rg, 2 Lc, 3 Lg) and sphere 0/1:
+ *   orc_swd_forward = libsurf.forward  (src/SWD/main.cpp:14-59: _surfdisp keep_flat=false, _RayleighGroup,
+ *                     _LoveGroup surfdisp.cpp:119-173)
+ *   orc_swd_kernel  = libsurf.adjoint_kernel (main.cpp:61-82 -> _SurfKernel surfdisp.cpp:190-297);
+ *                     Love leaves dcda untouched in the reference (uninitialised memory): zeros here.
+ */
+int orc_swd_forward(const float *thk, const float *vp, const float *vs, const float *rho, int nlayer,
+                    const double *t, double *cg, int kmax, int wavetype, int sphere)
+{
+    if (wavetype == 0) return sd_surfdisp(thk, vp, vs, rho, nlayer, t, cg, kmax, 2, sphere, 0, NULL);
+    if (wavetype == 2) return sd_surfdisp(thk, vp, vs, rho, nlayer, t, cg, kmax, 1, sphere, 0, NULL);
+    double *cp = (double *)calloc((size_t)kmax, sizeof(double));
+    double *w = (double *)calloc((size_t)4 * nlayer, sizeof(double));
+    int ierr;
+    if (wavetype == 1) {
+        ierr = sd_surfdisp(thk, vp, vs, rho, nlayer, t, cp, kmax, 2, sphere, 1, NULL);
+        if (ierr != 1)
+            for (int i = 0; i < kmax; i++)
+                orc_sregn96s(thk, vp, vs, rho, nlayer, t[i], &cp[i], &cg[i], w, w + nlayer, w + 2 * nlayer, w + 3 * nlayer, sphere);
+    } else {
+        float *vpl = (float *)calloc((size_t)(nlayer > kmax ? nlayer : kmax), sizeof(float));
+        for (int i = 0; i < nlayer; i++) vpl[i] = (float)(1.732 * vs[i]);      /* surfdisp.cpp:132 */
+        ierr = sd_surfdisp(thk, vpl, vs, rho, nlayer, t, cp, kmax, 1, sphere, 1, NULL);
+        if (ierr != 1)
+            for (int i = 0; i < kmax; i++)
+                orc_slegn96(thk, vs, rho, nlayer, t[i], &cp[i], &cg[i], w, w + nlayer, w + 2 * nlayer, sphere);
+        free(vpl);
+    }
+    free(cp); free(w);
+    return ierr;
+}
+
+int orc_swd_kernel(const float *thk, const float *vp, const float *vs, const float *rho, int nlayer,
+                   const double *t, double *c, int nt, double *dcda, double *dcdb, double *dcdr,
+                   double *dcdh, int wavetype, int sphere)
+{
+    int ierr;
+    int iwave = (wavetype < 2) ? 2 : 1;
+    if (wavetype == 0 || wavetype == 2) {
+        ierr = sd_surfdisp(thk, vp, vs, rho, nlayer, t, c, nt, iwave, sphere, 1, NULL);
+        if (ierr == 1) return ierr;
+        for (int i = 0; i < nt; i++) {
+            int k = i * nlayer;
+            double cg;
+            if (wavetype == 0) orc_sregn96s(thk, vp, vs, rho, nlayer, t[i], &c[i], &cg, dcda + k, dcdb + k, dcdh + k, dcdr + k, sphere);
+            else { orc_slegn96(thk, vs, rho, nlayer, t[i], &c[i], &cg, dcdb + k, dcdh + k, dcdr + k, sphere);
+                   for (int j = 0; j < nlayer; j++) dcda[k + j] = 0.0; }
+        }
+        return ierr;
+    }
+    double *buf = (double *)calloc((size_t)5 * nt + (size_t)4 * nlayer, sizeof(double));
+    double *cp = buf, *cp1 = buf + nt, *cp2 = buf + 2 * nt, *t1 = buf + 3 * nt, *t2 = buf + 4 * nt, *tmp = buf + 5 * nt;
+    for (int i = 0; i < nt; i++) { t1[i] = t[i] * (1.0 + 0.05); t2[i] = t[i] * (1.0 - 0.05); }
+    ierr = sd_surfdisp(thk, vp, vs, rho, nlayer, t, cp, nt, iwave, sphere, 1, NULL);
+    int ierr1 = sd_surfdisp(thk, vp, vs, rho, nlayer, t1, cp1, nt, iwave, sphere, 1, NULL);
+    int ierr2 = sd_surfdisp(thk, vp, vs, rho, nlayer, t2, cp2, nt, iwave, sphere, 1, NULL);
+    ierr = (wavetype == 1) ? ((ierr + ierr1 + ierr2) > 0) : (ierr || ierr1 || ierr2);
+    if (ierr != 1) {
+        for (int i = 0; i < nt; i++) {
+            int k = i * nlayer;
+            if (wavetype == 1)
+                orc_sregnpus(thk, vp, vs, rho, nlayer, t[i], &cp[i], &c[i], t1[i], cp1[i], t2[i], cp2[i],
+                             tmp, tmp + nlayer, tmp + 2 * nlayer, tmp + 3 * nlayer,
+                             dcda + k, dcdb + k, dcdh + k, dcdr + k, sphere);
+            else {
+                orc_slegnpu(thk, vs, rho, nlayer, t[i], &cp[i], &c[i], t1[i], cp1[i], t2[i], cp2[i],
+                            tmp, tmp + nlayer, tmp + 2 * nlayer, dcdb + k, dcdh + k, dcdr + k, sphere);
+                for (int j = 0; j < nlayer; j++) dcda[k + j] = 0.0;
+            }
+        }
+    }
+    free(buf);
     return ierr;
 }
 
