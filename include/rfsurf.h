@@ -31,7 +31,7 @@ typedef enum {
     RFS_ERR_ARG = -1,         /* bad argument (also: unsupported enum value) */
     RFS_ERR_HIP = -2,         /* HIP runtime / rocFFT failure */
     RFS_ERR_STATE = -3,       /* call out of order (e.g. joint eval before joint setup) */
-    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (Love, sphere, time-domain RF) */
+    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (higher modes, time-domain RF) */
 } rfs_status;
 
 /* wavetype codes of libsurf (src/SWD/main.cpp:17-24): strings "Rc","Rg","Lc","Lg" */
@@ -66,15 +66,20 @@ int rfs_synchronize(rfs_ctx* ctx);
 
 /* -------- B1: what libsurf exports (src/SWD/main.cpp:86-93) --------------------------- */
 /* libsurf.forward(thk,vp,vs,rho,period,wavetype,mode,sphere) -> (c[nper], bool)
- * (src/SWD/main.cpp:14-59; _surfdisp surfdisp.cpp:62-109; _RayleighGroup :151-173).
+ * (src/SWD/main.cpp:14-59; _surfdisp surfdisp.cpp:62-109; _LoveGroup :119-141; _RayleighGroup :151-173).
+ * All four wavetypes; sphere != 0 applies the earth-flattening transformation (surfdisp96.f:495-564 for the
+ * root search, bldsph / sprayl / splove for group velocities) and returns spherical velocities
+ * (_flat2sphere surfdisp.cpp:16-49).  mode must be 0 (fundamental).
  * Model arrays [nchain][nlayer] are rounded to float32 first, as the binding does (main.cpp:9).
- * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1). */
+ * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1).
+ * "Lg" searches with vp = 1.732 vs as _LoveGroup does (it ignores the caller's vp). */
 int rfs_swd_forward(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
                     const double* vs, const double* rho, int nper, const double* period,
                     int wavetype, int mode, int sphere, double* c, int32_t* flag);
 /* libsurf.adjoint_kernel(...) -> (c, dcda, dcdb, dcdr, dcdh, bool)
  * (src/SWD/main.cpp:61-82; _SurfKernel surfdisp.cpp:190-297; sregn96 / sregnpu
- * sregn96.f90:1637-1888).  Kernel arrays: [nchain][nper][nlayer]. */
+ * sregn96.f90:1637-1888; slegn96 / slegnpu slegn96.f90:672-919).  Kernel arrays: [nchain][nper][nlayer].
+ * Love types: dcda is written as zeros (the reference leaves that array uninitialised, surfdisp.cpp:258-296). */
 int rfs_swd_kernel(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
                    const double* vs, const double* rho, int nper, const double* period,
                    int wavetype, int mode, int sphere, double* c, double* dcda, double* dcdb,
@@ -100,6 +105,18 @@ int rfs_rf_kernel_all(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, c
  * data dobs[nt + ntRc + ntRg] = [rf, Rc, Rg] (host pointer, copied). */
 int rfs_joint_setup(rfs_ctx* ctx, int nlayer, const rfs_rf_params* rf, int ntRc, const double* tRc,
                     int ntRg, const double* tRg, double sigma1, double sigma2, const double* dobs);
+/* Same with the full SurfWD state (model/model_surf.py:5-29): the four period blocks Rc, Rg, Lc, Lg (data order
+ * of dobs / dsyn), sphere, mode.  t* are the periods each block is EVALUATED at in misfit_and_grad: the
+ * reference evaluates its Lc and Lg blocks at tRc (model_surf.py:199-216) -- a caller that wants that passes
+ * tRc there.  swd == NULL: RF-only plugin. */
+typedef struct {
+    int32_t ntRc, ntRg, ntLc, ntLg;
+    const double *tRc, *tRg, *tLc, *tLg;
+    int32_t sphere;     /* 0 flat earth, != 0 earth flattening */
+    int32_t mode;       /* 0 = fundamental (only value supported) */
+} rfs_swd_params;
+int rfs_joint_setup2(rfs_ctx* ctx, int nlayer, const rfs_rf_params* rf, const rfs_swd_params* swd,
+                     double sigma1, double sigma2, const double* dobs);
 /* misfit_and_grad(x) for nchain models at once (model_rf_swd_vs_thk.py:66-86, model_rf.py:137-198,
  * model_surf.py:155-228).  x: [nchain][2*nlayer] = [vs(0..n-1), thk(0..n-1)].
  * Outputs: misfit[nchain], grad[nchain][2*nlayer], dsyn[nchain][ndata], flag[nchain]
@@ -129,7 +146,7 @@ int rfs_leapfrog_dev(rfs_ctx* ctx, int nchain, const double* x0, const double* p
                      int32_t* ok);
 
 /* -------- introspection ---------------------------------------------------------------- */
-int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg of the current joint setup */
+int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):
  *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic, else a power
  *                          of two <= 64 (1 = the sequential lane-per-chain kernel).

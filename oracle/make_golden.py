@@ -275,11 +275,62 @@ def gen_sampler(m_surf, m_rf, m_joint, M):
     print("sampler_hybrid.npz:", len(g), "arrays;", len(g["hmc_r0/L"]), "HMC iterations,", len(rec), "DA iterations")
 
 
+WIDE_MODELS = ("yaml7", "cfg1_10", "grad30", "prior30_0", "prior30_1", "lvz30_0", "lvz30_1", "wild30_0", "wild30_1",
+               "inverted_0", "inverted_1", "inverted_20")
+
+
+def gen_swd_wide(ref_surf, m_surf, M):
+    """All four libsurf wavetypes x sphere in {False, True} from the compiled reference (Rc/Rg flat are already in
+    swd_reference.npz).  Every case has len(t) >= nlayer: _LoveGroup (surfdisp.cpp:131-132) sizes its vp array by
+    the number of periods and reads it by layer, i.e. it is only well defined then.  dcda of the Love types is
+    not stored: the reference never writes it (surfdisp.cpp:258-296)."""
+    g = {}
+    for name in WIDE_MODELS:
+        thk, vs, t = M[name]
+        assert len(t) >= len(vs)
+        vp, rho = emp(vs)
+        g[f"{name}/thk"], g[f"{name}/vs"], g[f"{name}/t"] = thk, vs, t
+        for wt in ("Rc", "Rg", "Lc", "Lg"):
+            for sph in (False, True):
+                if wt[0] == "R" and not sph:
+                    continue
+                key = f"{name}/{wt}/{int(sph)}"
+                c, flag = ref_surf.forward(thk, vp, vs, rho, t, wt, 0, sph)
+                g[f"{key}/fwd_c"], g[f"{key}/fwd_flag"] = c, np.array(flag)
+                c, ka, kb, kr, kh, flag = ref_surf.adjoint_kernel(thk, vp, vs, rho, t, wt, 0, sph)
+                g[f"{key}/c"], g[f"{key}/flag"] = c, np.array(flag)
+                if flag:
+                    if wt[0] == "R":
+                        g[f"{key}/dcda"] = ka
+                    g[f"{key}/dcdb"], g[f"{key}/dcdr"], g[f"{key}/dcdh"] = kb, kr, kh
+    # plugin level: the reference's own SurfWD.forward (all blocks at tRc) on the reference libsurf, and the
+    # oracle's numpy restatement of SurfWD.misfit_and_grad on the reference libsurf (Love dcda := 0)
+    for name, tsel in (("yaml7", slice(0, 36, 3)), ("grad30", slice(0, 40, 2))):
+        thk, vs, t = M[name]
+        t = t[tsel]
+        x0 = np.hstack((vs, thk))
+        x1 = np.hstack((vs * 1.03, thk * 0.97))
+        for sph in (False, True):
+            key = f"plugin/{name}/{int(sph)}"
+            ref = m_surf.SurfWD(mode=0, sphere=sph, tRc=t, tRg=t, tLc=t, tLg=t)
+            d0, flag = ref.forward(x0)
+            assert flag
+            hyb = orc.SurfWD(tRc=t, tRg=t, tLc=t, tLg=t, lib=ref_surf, sphere=sph)
+            hyb.set_obsdata(d0)
+            mf, grad, d1, flag = hyb.misfit_and_grad(x1)
+            assert flag
+            g[f"{key}/t"], g[f"{key}/x0"], g[f"{key}/x1"] = t, x0, x1
+            g[f"{key}/fwd_d"], g[f"{key}/misfit"], g[f"{key}/grad"], g[f"{key}/dsyn"] = d0, np.array(mf), grad, d1
+    np.savez_compressed(os.path.join(OUT, "swd_love_sphere_reference.npz"), **g)
+    print("swd_love_sphere_reference.npz:", len(g), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
     M = models()
     gen_swd(ref_surf, M)
+    gen_swd_wide(ref_surf, m_surf, M)
     gen_rf(ref_rf, M)
     gen_plugin(m_surf, m_rf, m_joint, M)
     gen_sampler(m_surf, m_rf, m_joint, M)

@@ -191,39 +191,40 @@ def empirical_relation(vs):
 
 
 class SurfWD:
-    """model/model_surf.py (Rayleigh blocks).  ``lib`` = any object with the libsurf API."""
+    """model/model_surf.py.  ``lib`` = any object with the libsurf API.  Keeps the reference's period quirks:
+    forward() computes every block at tRc (:104-131); misfit_and_grad() computes Lc and Lg at tRc (:199-216)."""
 
-    def __init__(self, tRc=None, tRg=None, lib=None, mode=0, sphere=False):
+    def __init__(self, tRc=None, tRg=None, lib=None, mode=0, sphere=False, tLc=None, tLg=None):
         self.lib = lib if lib is not None else libsurf
         self.mode, self.sphere = mode, sphere
-        self.tRc = np.asarray(tRc, dtype=float) if tRc is not None and len(tRc) > 0 else None
-        self.tRg = np.asarray(tRg, dtype=float) if tRg is not None and len(tRg) > 0 else None
-        self.ntRc = 0 if self.tRc is None else len(self.tRc)
-        self.ntRg = 0 if self.tRg is None else len(self.tRg)
-        self.nt = self.ntRc + self.ntRg
+        for name, t in (("tRc", tRc), ("tRg", tRg), ("tLc", tLc), ("tLg", tLg)):
+            arr = np.asarray(t, dtype=float) if t is not None and len(t) > 0 else None
+            setattr(self, name, arr)
+            setattr(self, "n" + name, 0 if arr is None else len(arr))
+        self.nt = self.ntRc + self.ntRg + self.ntLc + self.ntLg
 
     def set_obsdata(self, dobs):
         self.dobs = dobs
 
     def forward(self, x):
-        """model_surf.py:81-133 -- note every block is computed at tRc (quirk :114-130)."""
+        """model_surf.py:81-133 -- note every block is computed at tRc (quirk :104-131)."""
         n = len(x) // 2
         vs, thk = x[:n], x[n:]
         vp, rho, _, _ = empirical_relation(vs)
         d = np.zeros(self.nt)
-        if self.ntRc > 0:
-            d[:self.ntRc], flag = self.lib.forward(thk, vp, vs, rho, self.tRc, "Rc", self.mode, self.sphere)
+        k1 = 0
+        for nrow, wt in ((self.ntRc, "Rc"), (self.ntRg, "Rg"), (self.ntLc, "Lc"), (self.ntLg, "Lg")):
+            if nrow == 0:
+                continue
+            d[k1:k1 + nrow], flag = self.lib.forward(thk, vp, vs, rho, self.tRc, wt, self.mode, self.sphere)
             if not flag:
                 return d, flag
-        if self.ntRg > 0:
-            k1 = self.ntRc
-            d[k1:k1 + self.ntRg], flag = self.lib.forward(thk, vp, vs, rho, self.tRc, "Rg", self.mode, self.sphere)
-            if not flag:
-                return d, flag
+            k1 += nrow
         return d, True
 
     def misfit_and_grad(self, x):
-        """model_surf.py:155-228."""
+        """model_surf.py:155-228.  Love kernels: dcda is uninitialised memory in the reference
+        (surfdisp.cpp:258-296); it is taken as zero here."""
         n = len(x) // 2
         vs, thk = x[:n], x[n:]
         vp, rho, dadb, drda = empirical_relation(vs)
@@ -231,14 +232,17 @@ class SurfWD:
         kernel_thk = np.zeros((self.nt, n))
         d = np.zeros(self.nt)
         k1 = 0
-        for periods, wt in ((self.tRc, "Rc"), (self.tRg, "Rg")):
-            if periods is None:
+        for nrow, periods, wt in ((self.ntRc, self.tRc, "Rc"), (self.ntRg, self.tRg, "Rg"),
+                                  (self.ntLc, self.tRc, "Lc"), (self.ntLg, self.tRc, "Lg")):
+            if nrow == 0:
                 continue
-            k2 = k1 + len(periods)
+            k2 = k1 + nrow
             cg, dcda, dcdb, dcdr, dcdh, flag = self.lib.adjoint_kernel(
                 thk, vp, vs, rho, periods, wt, self.mode, self.sphere)
             if not flag:
                 return 0.0, np.zeros(n), np.zeros(self.nt), False
+            if wt[0] == "L":
+                dcda = np.zeros_like(dcdb)
             d[k1:k2] = cg
             kernel[k1:k2] = dcdb + dcda * dadb + dcdr * drda * dadb
             kernel_thk[k1:k2] = dcdh

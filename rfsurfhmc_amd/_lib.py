@@ -22,6 +22,12 @@ class RfParams(ctypes.Structure):
                 ("rf_type", ctypes.c_int32), ("method", ctypes.c_int32)]
 
 
+class SwdParams(ctypes.Structure):
+    _fields_ = [("ntRc", ctypes.c_int32), ("ntRg", ctypes.c_int32), ("ntLc", ctypes.c_int32), ("ntLg", ctypes.c_int32),
+                ("tRc", ctypes.c_void_p), ("tRg", ctypes.c_void_p), ("tLc", ctypes.c_void_p), ("tLg", ctypes.c_void_p),
+                ("sphere", ctypes.c_int32), ("mode", ctypes.c_int32)]
+
+
 class RfsError(RuntimeError):
     pass
 
@@ -41,6 +47,7 @@ SIGNATURES = {
     "rfs_rf_forward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(RfParams), _vp]),
     "rfs_rf_kernel_all": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(RfParams), _vp, _vp]),
     "rfs_joint_setup": (_i, [_vp, _i, ctypes.POINTER(RfParams), _i, _vp, _i, _vp, _d, _d, _vp]),
+    "rfs_joint_setup2": (_i, [_vp, _i, ctypes.POINTER(RfParams), ctypes.POINTER(SwdParams), _d, _d, _vp]),
     "rfs_joint_misfit_grad_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rfs_joint_misfit_grad": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rfs_joint_forward": (_i, [_vp, _i, _vp, _i, _vp, _vp]),

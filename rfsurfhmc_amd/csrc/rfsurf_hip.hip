@@ -39,14 +39,16 @@ struct rfs_ctx {
     std::string err;
     // joint configuration
     bool configured = false;
-    int n = 0, mode = 0, ntRc = 0, ntRg = 0, ndata = 0;
+    int n = 0, mode = 0, ndata = 0;
+    int ntw[4] = {0, 0, 0, 0};   // rows of the Rc, Rg, Lc, Lg blocks
+    int sphere = 0;
     bool has_rf = false, has_swd = false;
     RfFreq f{};
     double wt = 1.0;
-    Buf d_tRc, d_tRg, d_dobs;
+    Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
-    Buf mdlc;
+    Buf mdlc, mdlSR, mdlL, sphR, sphL;   // per-family search models / bldsph arrays (sphere, Love)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
     // leapfrog state
@@ -241,33 +243,76 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f) {
     return RFS_OK;
 }
 
-SwdSeqs make_seqs(int ntRc, const double* d_tRc, int ntRg, const double* d_tRg, bool group_passes) {
-    SwdSeqs Q{};
+// Sequences and data rows of one evaluation.  Rayleigh sequences come first (seq 0..), then Love; items
+// (periods of all sequences) are numbered in the same order, so both families share croot / krn / ugr.
+// group_passes: group blocks get the three root searches T, 1.05 T, 0.95 T of surfdisp.cpp:235-241;
+// otherwise (forward) only T.  love_group_vp: Lg searches with vp = 1.732 vs (_LoveGroup, surfdisp.cpp:132).
+struct SwdPlan {
+    SwdSeqs QR{}, QL{};
+    SwdRows R{};
+    int nseq = 0, nitems = 0;
+    bool any_love() const { return QL.nseq > 0; }
+};
+
+SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, int sphere, int fwd,
+                  bool love_group_vp, const double* sphR, const double* sphL) {
+    SwdPlan P;
     int off = 0;
-    if (ntRc > 0) { Q.s[Q.nseq++] = SwdSeq{d_tRc, ntRc, 1.0, off}; off += ntRc; }
-    if (ntRg > 0) {
-        Q.s[Q.nseq++] = SwdSeq{d_tRg, ntRg, 1.0, off}; off += ntRg;
-        if (group_passes) {
-            Q.s[Q.nseq++] = SwdSeq{d_tRg, ntRg, 1.0 + 0.05, off}; off += ntRg;   // surfdisp.cpp:236
-            Q.s[Q.nseq++] = SwdSeq{d_tRg, ntRg, 1.0 - 0.05, off}; off += ntRg;   // surfdisp.cpp:237
+    int boff[4] = {0, 0, 0, 0};
+    for (int type = 0; type < 4; type++) {
+        if (nt[type] <= 0) continue;
+        SwdSeqs& Q = (type < 2) ? P.QR : P.QL;
+        boff[type] = off;
+        int alt = (type == 3 && love_group_vp) ? 1 : 0;
+        Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0, off, alt}; off += nt[type];
+        Q.nper_total += nt[type];
+        if ((type & 1) && group_passes) {
+            Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0 + 0.05, off, alt}; off += nt[type];
+            Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0 - 0.05, off, alt}; off += nt[type];
+            Q.nper_total += 2 * nt[type];
         }
     }
-    Q.nper_total = off;
-    return Q;
+    P.nseq = P.QR.nseq + P.QL.nseq; P.nitems = off;
+    for (int type = 0; type < 4; type++) {
+        if (nt[type] <= 0) continue;
+        SwdBlk B{type, nt[type], boff[type], boff[type] + nt[type], boff[type] + 2 * nt[type], t[type]};
+        P.R.b[P.R.nblk++] = B;
+        P.R.nswd += nt[type];
+    }
+    P.R.sphere = sphere; P.R.fwd = fwd; P.R.sphR = sphR; P.R.sphL = sphL;
+    return P;
 }
 
-SwdRows make_rows(int ntRc, int ntRg, const double* d_tRg) {
-    SwdRows R{};
-    R.ntRc = ntRc; R.ntRg = ntRg; R.off_rg = ntRc; R.off_rg1 = ntRc + ntRg; R.off_rg2 = ntRc + 2 * ntRg;
-    R.tRg = d_tRg;
-    return R;
+// per-family search models (earth flattening, Love); mdl must be ready on stream s
+int launch_family_prep(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, int sphere) {
+    const bool wantR = P.QR.nseq > 0, wantL = P.QL.nseq > 0;
+    if (!(sphere && wantR) && !wantL) return RFS_OK;
+    size_t nn = (size_t)n * nchain;
+    if (sphere && wantR) { ENSURE(c, c->mdlSR, 4 * nn * sizeof(float)); ENSURE(c, c->sphR, 7 * nn * sizeof(double)); }
+    if (wantL) { ENSURE(c, c->mdlL, 5 * nn * sizeof(float)); if (sphere) ENSURE(c, c->sphL, 7 * nn * sizeof(double)); }
+    hipLaunchKernelGGL(k_prep_swd_family, dim3((nchain + 63) / 64), dim3(64), 0, s, nchain, n, c->mdl.as<float>(), sphere,
+                       (int)wantR, (int)wantL, c->mdlSR.as<float>(), c->mdlc.as<double>(), c->sphR.as<double>(),
+                       c->mdlL.as<float>(), c->sphL.as<double>());
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
 }
 
 // root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
-int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, bool kernels, bool roots = true) {
-    ENSURE(c, c->croot, (size_t)Q.nper_total * nchain * sizeof(double));
-    ENSURE(c, c->sflag, (size_t)4 * nchain * sizeof(int));
-    if (roots) {
+int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, bool kernels, bool roots = true) {
+    const SwdSeqs& Q = P.QR;
+    const int sphere = P.R.sphere;
+    ENSURE(c, c->croot, (size_t)P.nitems * nchain * sizeof(double));
+    ENSURE(c, c->sflag, (size_t)8 * nchain * sizeof(int));
+    const float* mdlR = sphere ? c->mdlSR.as<float>() : c->mdl.as<float>();
+    int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
+    if (roots && P.QL.nseq > 0) {       // Love: cheap 2-vector recurrence, lane = (sequence, chain)
+        KTimer t(c, RFS_K_SWD_ROOTS, s);
+        int nitem = P.QL.nseq * nchain;
+        hipLaunchKernelGGL(k_swd_roots<true>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, P.QL,
+                           c->mdlL.as<float>(), c->croot.as<double>(), sflagL);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (roots && Q.nseq > 0) {
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         int nitem = Q.nseq * nchain;
         int G = c->swd_lanes;
@@ -293,7 +338,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
                 HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NCH>,                              \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));          \
                 hipLaunchKernelGGL(k_swd_roots_coop<NCH>, grid, dim3(512), lds2, s, nchain, n, Q,               \
-                                   c->mdl.as<float>(), c->mdlc.as<double>(), c->croot.as<double>(),             \
+                                   mdlR, c->mdlc.as<double>(), c->croot.as<double>(),                           \
                                    c->sflag.as<int>());                                                         \
             } while (0)
             if (nch <= 5) RFS_LAUNCH_COOP(5);
@@ -301,14 +346,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
             else RFS_LAUNCH_COOP(16);
 #undef RFS_LAUNCH_COOP
         } else if (G == 1) {
-            hipLaunchKernelGGL(k_swd_roots, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
-                               c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>());
+            hipLaunchKernelGGL(k_swd_roots<false>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
+                               mdlR, c->croot.as<double>(), c->sflag.as<int>());
         } else {
             int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
             dim3 grid((nitem + NG - 1) / NG);
 #define RFS_LAUNCH_SPLIT(LPL)                                                                              \
             hipLaunchKernelGGL(k_swd_roots_split<LPL>, grid, dim3(64), lds, s, nchain, n, G, Q,             \
-                               c->mdl.as<float>(), c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>())
+                               mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>())
             if (lpl <= 1) RFS_LAUNCH_SPLIT(1);
             else if (lpl <= 2) RFS_LAUNCH_SPLIT(2);
             else if (lpl <= 4) RFS_LAUNCH_SPLIT(4);
@@ -318,14 +363,24 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, b
         HIPCHK(c, hipGetLastError());
     }
     if (kernels) {
-        size_t nitem = (size_t)Q.nper_total * nchain;
-        ENSURE(c, c->cds, nitem * 6 * n * sizeof(double));
-        ENSURE(c, c->krn, nitem * 4 * n * sizeof(double));
-        ENSURE(c, c->ugr, nitem * sizeof(double));
+        size_t ntot = (size_t)P.nitems * nchain;
+        ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
+        ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
+        ENSURE(c, c->ugr, ntot * sizeof(double));
         KTimer t(c, RFS_K_SWD_EIGEN, s);
-        hipLaunchKernelGGL(k_swd_eigen, dim3((unsigned)((nitem + 63) / 64)), dim3(64), 0, s, nchain, n, Q,
-                           c->mdl.as<float>(), c->croot.as<double>(), c->sflag.as<int>(), c->cds.as<double>(),
-                           c->krn.as<double>(), c->ugr.as<double>());
+#define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL)                                                                  \
+        hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)QQ.nper_total * nchain + 63) / 64)),   \
+                           dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(),     \
+                           SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>())
+        if (P.QR.nper_total > 0) {
+            if (sphere) RFS_LAUNCH_EIGEN(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>());
+            else RFS_LAUNCH_EIGEN(false, false, P.QR, nullptr, c->sflag.as<int>());
+        }
+        if (P.QL.nper_total > 0) {
+            if (sphere) RFS_LAUNCH_EIGEN(true, true, P.QL, c->sphL.as<double>(), sflagL);
+            else RFS_LAUNCH_EIGEN(true, false, P.QL, nullptr, sflagL);
+        }
+#undef RFS_LAUNCH_EIGEN
         HIPCHK(c, hipGetLastError());
     }
     return RFS_OK;
@@ -359,7 +414,15 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            c->mdl.as<float>(), c->mdlc.as<double>());
         HIPCHK(c, hipGetLastError());
     }
-    SwdSeqs Q = make_seqs(c->ntRc, c->d_tRc.as<double>(), c->ntRg, c->d_tRg.as<double>(), true);
+    const double* tw[4] = {c->d_tw[0].as<double>(), c->d_tw[1].as<double>(), c->d_tw[2].as<double>(), c->d_tw[3].as<double>()};
+    if (c->has_swd) {
+        size_t nn = (size_t)n * nchain;
+        if (c->sphere && c->ntw[0] + c->ntw[1] > 0) ENSURE(c, c->sphR, 7 * nn * sizeof(double));
+        if (c->sphere && c->ntw[2] + c->ntw[3] > 0) ENSURE(c, c->sphL, 7 * nn * sizeof(double));
+    }
+    SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>());
+    const SwdSeqs& Q = P.QR;
+    if (c->has_swd) { KTimer t(c, RFS_K_PREP, c->stream); TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere)); }
     hipStream_t user = c->stream;
     // CU partition: the cooperative search occupies one CU per 64 sequences; when that fits on half of the
     // chip it runs there undisturbed and the RF kernels take the other half (measured +11 % at config 2)
@@ -378,10 +441,10 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         hipStream_t ss = part ? c->stream2m : c->stream2;
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
-        TRY(launch_swd(c, ss, nchain, n, Q, !part));
+        TRY(launch_swd(c, ss, nchain, n, P, !part));
         HIPCHK(c, hipEventRecord(c->ev_join, ss));
     } else if (c->has_swd) {
-        TRY(launch_swd(c, user, nchain, n, Q, true));
+        TRY(launch_swd(c, user, nchain, n, P, true));
     }
     if (c->has_rf) {
         if (part) { HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); c->stream = c->stream3; }
@@ -395,20 +458,24 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
     if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
-    if (part) TRY(launch_swd(c, user, nchain, n, Q, true, false));      // eigenfunction pass on the whole chip
+    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false));      // eigenfunction pass on the whole chip
     {
         KTimer t(c, RFS_K_COMBINE, c->stream);
-        SwdRows R = make_rows(c->ntRc, c->ntRg, c->d_tRg.as<double>());
+        const SwdRows& R = P.R;
         int nt = c->has_rf ? c->f.nt : 0;
         if (c->has_rf)
             hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
                                (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
                                c->cr.as<double>(), misfit, grad, flag);
-        if (c->has_swd)
-            hipLaunchKernelGGL(k_swd_combine, dim3((nchain + 63) / 64), dim3(64, 4), (size_t)n * 64 * sizeof(double),
-                               c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),
-                               c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),
-                               Q.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag);
+        if (c->has_swd) {
+#define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
+            hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 63) / 64), dim3(64, 4), (size_t)n * 64 * sizeof(double), \
+                               c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),     \
+                               c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),      \
+                               P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag)
+            if (c->sphere) RFS_LAUNCH_COMBINE(true); else RFS_LAUNCH_COMBINE(false);
+#undef RFS_LAUNCH_COMBINE
+        }
         HIPCHK(c, hipGetLastError());
     }
     return RFS_OK;
@@ -444,7 +511,7 @@ void rfs_destroy(rfs_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    Buf* bufs[] = {&c->d_tRc, &c->d_tRg, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
+    Buf* bufs[] = {&c->d_tw[0], &c->d_tw[1], &c->d_tw[2], &c->d_tw[3], &c->mdlSR, &c->mdlL, &c->sphR, &c->sphL, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
                    &c->croot, &c->sflag, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
@@ -529,10 +596,9 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
                   const double* rho, int nper, const double* period, int wavetype, int mode, int sphere,
                   bool kernels, double* cout, double* dcda, double* dcdb, double* dcdr, double* dcdh, int32_t* flag) {
     TRY(check_batch(c, nchain, nlayer));
-    if (wavetype == RFS_WAVE_LC || wavetype == RFS_WAVE_LG) return fail(c, RFS_ERR_UNSUPPORTED, "Love waves are out of scope");
-    if (wavetype != RFS_WAVE_RC && wavetype != RFS_WAVE_RG) return fail(c, RFS_ERR_ARG, "wavetype should be one of [Rc,Rg,Lc,Lg]");
+    if (wavetype < RFS_WAVE_RC || wavetype > RFS_WAVE_LG) return fail(c, RFS_ERR_ARG, "wavetype should be one of [Rc,Rg,Lc,Lg]");
     if (mode != 0) return fail(c, RFS_ERR_UNSUPPORTED, "higher modes are out of scope");
-    if (sphere) return fail(c, RFS_ERR_UNSUPPORTED, "earth flattening is out of scope");
+    sphere = sphere ? 1 : 0;
     if (nper < 1 || !period || !thk || !vp || !vs || !rho || !cout || !flag) return fail(c, RFS_ERR_ARG, "null/empty argument");
     HIPCHK(c, hipSetDevice(c->device));
     const int n = nlayer;
@@ -546,11 +612,16 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
     hipLaunchKernelGGL(k_prep_swd_b1, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->b1a.as<double>(),
                        c->b1b.as<double>(), c->b1c.as<double>(), c->b1d.as<double>(), c->mdl.as<float>(),
                        c->mdlc.as<double>());
-    bool rg = wavetype == RFS_WAVE_RG;
-    // forward "Rg" = _RayleighGroup (surfdisp.cpp:151-173): roots at T only, U from sregn96
-    SwdSeqs Q = rg ? make_seqs(0, nullptr, nper, c->bt.as<double>(), kernels) : make_seqs(nper, c->bt.as<double>(), 0, nullptr, false);
-    TRY(launch_swd(c, c->stream, nchain, n, Q, kernels || rg));
-    SwdRows R = rg ? make_rows(0, nper, c->bt.as<double>()) : make_rows(nper, 0, nullptr);
+    const bool rg = (wavetype & 1) != 0;       // group velocity: _RayleighGroup / _LoveGroup (surfdisp.cpp:119-173)
+    int ntw[4] = {0, 0, 0, 0};
+    const double* tw[4] = {nullptr, nullptr, nullptr, nullptr};
+    ntw[wavetype] = nper; tw[wavetype] = c->bt.as<double>();
+    size_t nn = (size_t)n * nchain;
+    if (sphere) ENSURE(c, (wavetype < 2) ? c->sphR : c->sphL, 7 * nn * sizeof(double));
+    // forward: roots at T only (+ U from sregn96 / slegn96 for the group types); kernel: three passes for groups
+    SwdPlan P = make_plan(ntw, tw, kernels, sphere, kernels ? 0 : 1, !kernels, c->sphR.as<double>(), c->sphL.as<double>());
+    TRY(launch_family_prep(c, c->stream, nchain, n, P, sphere));
+    TRY(launch_swd(c, c->stream, nchain, n, P, kernels || rg));
     size_t cb = (size_t)nchain * nper * sizeof(double), kb = cb * n;
     ENSURE(c, c->b1e, cb);
     double* dk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -559,12 +630,13 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
         for (int i = 0; i < 4; i++) dk[i] = c->klbuf.as<double>() + (size_t)i * nchain * nper * n;
     }
     int ng = nchain * nper;
-    hipLaunchKernelGGL(k_swd_export, dim3((ng + 127) / 128), dim3(128), 0, c->stream, nchain, n, R, 0, nper,
+    ENSURE(c, c->krn, 8); ENSURE(c, c->ugr, 8);
+    hipLaunchKernelGGL(sphere ? k_swd_export<true> : k_swd_export<false>, dim3((ng + 127) / 128), dim3(128), 0, c->stream, nchain, n, P.R,
                        c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->b1e.as<double>(),
                        dk[0], dk[1], dk[2], dk[3]);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<int> sf((size_t)Q.nseq * nchain);
+    std::vector<int> sf((size_t)P.nseq * nchain);
     HIPCHK(c, hipMemcpy(sf.data(), c->sflag.p, sf.size() * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(cout, c->b1e.p, cb, hipMemcpyDeviceToHost));
     if (kernels) {
@@ -573,7 +645,7 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
     }
     for (int ch = 0; ch < nchain; ch++) {
         int ok = 1;
-        for (int s = 0; s < Q.nseq; s++) ok = ok && sf[(size_t)s * nchain + ch];
+        for (int s = 0; s < P.nseq; s++) ok = ok && sf[(size_t)s * nchain + ch];
         flag[ch] = ok;
         if (!ok && rg) for (int k = 0; k < nper; k++) cout[(size_t)ch * nper + k] = 0.0;
     }
@@ -653,25 +725,40 @@ int rfs_rf_kernel_all(rfs_ctx* c, int nchain, int nlayer, const double* thk, con
 }
 
 // ---------------------------------------------------------------- B2 / plugins
-int rfs_joint_setup(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, int ntRc, const double* tRc, int ntRg,
-                    const double* tRg, double sigma1, double sigma2, const double* dobs) {
+int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_swd_params* swd, double sigma1,
+                     double sigma2, const double* dobs) {
     if (!c) return RFS_ERR_ARG;
     c->configured = false;
     if (nlayer < 2 || nlayer > c->max_layers || nlayer > MAXL) return fail(c, RFS_ERR_ARG, "nlayer outside [2, min(max_layers,128)]");
-    if (ntRc < 0 || ntRg < 0 || (ntRc > 0 && !tRc) || (ntRg > 0 && !tRg)) return fail(c, RFS_ERR_ARG, "bad period lists");
-    if (!rf && ntRc + ntRg == 0) return fail(c, RFS_ERR_ARG, "neither RF nor SWD data configured");
+    int ntw[4] = {0, 0, 0, 0};
+    const double* tw[4] = {nullptr, nullptr, nullptr, nullptr};
+    int sphere = 0;
+    if (swd) {
+        ntw[0] = swd->ntRc; ntw[1] = swd->ntRg; ntw[2] = swd->ntLc; ntw[3] = swd->ntLg;
+        tw[0] = swd->tRc; tw[1] = swd->tRg; tw[2] = swd->tLc; tw[3] = swd->tLg;
+        if (swd->mode != 0) return fail(c, RFS_ERR_UNSUPPORTED, "higher modes are out of scope");
+        sphere = swd->sphere ? 1 : 0;
+    }
+    int nswd = 0;
+    for (int i = 0; i < 4; i++) {
+        if (ntw[i] < 0 || (ntw[i] > 0 && !tw[i])) return fail(c, RFS_ERR_ARG, "bad period lists");
+        nswd += ntw[i];
+    }
+    if (!rf && nswd == 0) return fail(c, RFS_ERR_ARG, "neither RF nor SWD data configured");
     if (rf) TRY(check_rf(c, rf));
     HIPCHK(c, hipSetDevice(c->device));
-    c->n = nlayer; c->has_rf = rf != nullptr; c->has_swd = ntRc + ntRg > 0;
+    c->n = nlayer; c->has_rf = rf != nullptr; c->has_swd = nswd > 0;
     c->mode = (c->has_rf && c->has_swd) ? 0 : (c->has_rf ? 1 : 2);
-    c->ntRc = ntRc; c->ntRg = ntRg;
+    c->sphere = sphere;
     int nt = 0;
     if (rf) { c->f = make_freq(*rf, 0); nt = rf->nt; }
-    c->ndata = nt + ntRc + ntRg;
+    c->ndata = nt + nswd;
     // wt = (sigma1/sigma2)^2 n1/n2, model_rf_swd_vs_thk.py:79
-    c->wt = c->has_swd && c->has_rf ? (sigma1 / sigma2) * (sigma1 / sigma2) * nt / (double)(ntRc + ntRg) : 1.0;
-    if (ntRc) TRY(upload(c, c->d_tRc, tRc, (size_t)ntRc * sizeof(double)));
-    if (ntRg) TRY(upload(c, c->d_tRg, tRg, (size_t)ntRg * sizeof(double)));
+    c->wt = c->has_swd && c->has_rf ? (sigma1 / sigma2) * (sigma1 / sigma2) * nt / (double)nswd : 1.0;
+    for (int i = 0; i < 4; i++) {
+        c->ntw[i] = ntw[i];
+        if (ntw[i]) TRY(upload(c, c->d_tw[i], tw[i], (size_t)ntw[i] * sizeof(double)));
+    }
     ENSURE(c, c->d_dobs, (size_t)c->ndata * sizeof(double));
     if (dobs) HIPCHK(c, hipMemcpyAsync(c->d_dobs.p, dobs, (size_t)c->ndata * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else HIPCHK(c, hipMemsetAsync(c->d_dobs.p, 0, (size_t)c->ndata * sizeof(double), c->stream));
@@ -681,6 +768,13 @@ int rfs_joint_setup(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, int ntRc, c
     ENSURE(c, c->sflag, 16);
     c->configured = true;
     return RFS_OK;
+}
+
+int rfs_joint_setup(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, int ntRc, const double* tRc, int ntRg,
+                    const double* tRg, double sigma1, double sigma2, const double* dobs) {
+    rfs_swd_params swd{};
+    swd.ntRc = ntRc; swd.tRc = tRc; swd.ntRg = ntRg; swd.tRg = tRg;
+    return rfs_joint_setup2(c, nlayer, rf, (ntRc > 0 || ntRg > 0) ? &swd : nullptr, sigma1, sigma2, dobs);
 }
 
 int rfs_joint_misfit_grad_dev(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn,
@@ -735,16 +829,27 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
         TRY(launch_mid(c, nchain, n, f, nullptr, c->ndata, c->dsyn.as<double>(), false));
     }
     if (c->has_swd) {
-        // model_surf.py:114-130 computes every block at tRc; quirk != 0 keeps that
-        const double* tg = (quirk && c->ntRc > 0) ? c->d_tRc.as<double>() : c->d_tRg.as<double>();
-        int ntg = (quirk && c->ntRc > 0) ? (c->ntRg < c->ntRc ? c->ntRg : c->ntRc) : c->ntRg;
-        if (quirk && c->ntRc > 0 && c->ntRg > 0 && c->ntRg != c->ntRc)
-            return fail(c, RFS_ERR_UNSUPPORTED, "forward quirk needs len(tRg) == len(tRc), as the reference does");
-        SwdSeqs Q = make_seqs(c->ntRc, c->d_tRc.as<double>(), ntg, tg, false);
-        TRY(launch_swd(c, c->stream, nchain, n, Q, ntg > 0));
-        SwdRows R = make_rows(c->ntRc, ntg, tg);
-        hipLaunchKernelGGL(k_swd_forward_out, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, nt, R,
-                           c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(), Q.nseq,
+        // model_surf.py:104-131 computes every block at tRc; quirk != 0 keeps that (the reference then needs
+        // every block to have len(tRc) rows, otherwise its slice assignment raises)
+        const double* tw[4]; int ntw[4];
+        for (int i = 0; i < 4; i++) {
+            ntw[i] = c->ntw[i];
+            tw[i] = c->d_tw[i].as<double>();
+            if (quirk && c->ntw[0] > 0 && ntw[i] > 0) {
+                if (ntw[i] != c->ntw[0])
+                    return fail(c, RFS_ERR_UNSUPPORTED, "forward quirk needs every block as long as tRc, as the reference does");
+                tw[i] = c->d_tw[0].as<double>();
+            }
+        }
+        size_t nn = (size_t)n * nchain;
+        if (c->sphere && ntw[0] + ntw[1] > 0) ENSURE(c, c->sphR, 7 * nn * sizeof(double));
+        if (c->sphere && ntw[2] + ntw[3] > 0) ENSURE(c, c->sphL, 7 * nn * sizeof(double));
+        SwdPlan P = make_plan(ntw, tw, false, c->sphere, 1, true, c->sphR.as<double>(), c->sphL.as<double>());
+        TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
+        TRY(launch_swd(c, c->stream, nchain, n, P, ntw[1] + ntw[3] > 0));
+        ENSURE(c, c->ugr, 8);
+        hipLaunchKernelGGL(k_swd_forward_out, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, nt, P.R,
+                           c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(), P.nseq,
                            c->dsyn.as<double>(), c->flag.as<int>());
     } else {
         HIPCHK(c, hipMemsetAsync(c->flag.p, 0, (size_t)nchain * sizeof(int), c->stream));

@@ -109,6 +109,49 @@ __global__ void k_prep_swd_b1(int nchain, int n, const double* thk, const double
     swd_store_layerc(mdlc, j, chain, nchain, (float)thk[g], (float)vp[g], (float)vs[g], (float)rho[g]);
 }
 
+// Per-family SWD models, one thread per chain (sequential over the layers: the flattening accumulates depth).
+//   sphere && wantR : mdlSR = float32 flattened Rayleigh model for the root search (+ its f64 layer constants in
+//                     mdlc, replacing the flat ones), sphR = [7][n][chain] f64 bldsph arrays zd,za,zb,zrho,vtp,dtp,rtp
+//   wantL           : mdlL = [5][n][chain] float32 Love search model d,a,b,rho,a' (flat copy or flattened);
+//                     a' = P velocity 1.732 vs of _LoveGroup (surfdisp.cpp:132); sphere: sphL like sphR
+__global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ mdl, int sphere, int wantR, int wantL,
+                                  float* __restrict__ mdlSR, double* __restrict__ mdlc, double* __restrict__ sphR,
+                                  float* __restrict__ mdlL, double* __restrict__ sphL)
+{
+    int chain = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= nchain) return;
+    const size_t s = (size_t)n * nchain;
+    const long st = nchain;
+    const float *d = mdl + chain, *a = mdl + s + chain, *b = mdl + 2 * s + chain, *r = mdl + 3 * s + chain;
+    if (sphere && wantR) {
+        float *od = mdlSR + chain, *oa = mdlSR + s + chain, *ob = mdlSR + 2 * s + chain, *orr = mdlSR + 3 * s + chain;
+        swd_flatten_f32(false, n, d, a, b, r, st, od, oa, ob, orr, st);
+        for (int m = 0; m < n; m++) swd_store_layerc(mdlc, m, chain, nchain, od[m * st], oa[m * st], ob[m * st], orr[m * st]);
+        double* z = sphR + chain;
+        swd_bldsph(false, n, d, a, b, r, st, z, z + s, z + 2 * s, z + 3 * s, z + 4 * s, z + 5 * s, z + 6 * s, st);
+    }
+    if (wantL) {
+        float *od = mdlL + chain, *oa = mdlL + s + chain, *ob = mdlL + 2 * s + chain, *orr = mdlL + 3 * s + chain,
+              *oa2 = mdlL + 4 * s + chain;
+        for (int m = 0; m < n; m++) oa2[m * st] = (float)(1.732 * b[m * st]);
+        if (sphere) {
+            swd_flatten_f32(true, n, d, a, b, r, st, od, oa, ob, orr, st);
+            const double ar = 6370.0;                       // a' goes through the same velocity mapping as a
+            double dr = 0.0, r0 = ar;
+            for (int m = 0; m < n; m++) {
+                dr = dr + (double)((m == n - 1) ? 1.0f : d[m * st]);
+                double r1 = ar - dr, tmp = (ar + ar) / (r0 + r1);
+                oa2[m * st] = (float)((double)oa2[m * st] * tmp);
+                r0 = r1;
+            }
+            double* z = sphL + chain;
+            swd_bldsph(true, n, d, a, b, r, st, z, z + s, z + 2 * s, z + 3 * s, z + 4 * s, z + 5 * s, z + 6 * s, st);
+        } else {
+            for (int m = 0; m < n; m++) { od[m * st] = d[m * st]; oa[m * st] = a[m * st]; ob[m * st] = b[m * st]; orr[m * st] = r[m * st]; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K1 pass A: lane = frequency (TAIL=false: block = one chain's 64..256 frequencies, layer
 // constants are wave-uniform -> scalar loads) or lane = chain at the last frequency
@@ -392,9 +435,10 @@ __global__ void k_rf_scale_kl(size_t ntrace, RfFreq f, const double* __restrict_
 // runs sequentially inside the lane, all 64 lanes evaluate the secular function together.
 // Sequences: 0 = tRc, 1 = tRg, 2 = 1.05 tRg, 3 = 0.95 tRg (surfdisp.cpp:235-241).
 // ---------------------------------------------------------------------------------------
-struct SwdSeq { const double* t; int nper; double scale; int croot_off; };   // croot_off in periods
-struct SwdSeqs { SwdSeq s[4]; int nseq; int nper_total; };
+struct SwdSeq { const double* t; int nper; double scale; int croot_off; int alt_vp; };   // croot_off in periods
+struct SwdSeqs { SwdSeq s[4]; int nseq; int nper_total; };   // one wave family (Rayleigh or Love) per launch
 
+template <bool LOVE>
 __global__ void __launch_bounds__(64)
 k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double* __restrict__ croot,
             int* __restrict__ sflag)
@@ -404,8 +448,9 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
     bool live = seq < Q.nseq;
     if (!live) { seq = 0; chain = 0; }
     const size_t s = (size_t)n * nchain;
-    SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
     const SwdSeq sq = Q.s[seq];
+    // Love group forward (_LoveGroup) searches with vp = 1.732 vs: array 4 of the Love model
+    SwdModel M{mdl + chain, mdl + (LOVE && sq.alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
     const double* tp = sq.t; const double sc = sq.scale;
     auto T = [&](int k) { return tp[k] * sc; };
     double* cr = croot + (size_t)sq.croot_off * nchain + chain;
@@ -415,7 +460,8 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
     if (!live) rs.done = 1;
     while (__any(!rs.done)) {
         if (!rs.done) {
-            double del = swd_secular(M, rs.omega / rs.creq, rs.omega);
+            double wvno = rs.omega / rs.creq;
+            double del = LOVE ? swd_secular_love(M, wvno, rs.omega) : swd_secular(M, wvno, rs.omega);
             rs.advance(del, T, out);
         }
     }
@@ -642,101 +688,175 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 }
 
 // ---------------------------------------------------------------------------------------
-// K4 eigenfunction kernels: lane = (item, chain), item = (sequence, period).  Writes the
-// SCALED phase-velocity kernels (d c / d alpha, beta, rho and the interface partial) and U.
+// K4 eigenfunction kernels: lane = (item, chain), item = (sequence, period) of one wave family.
+// Writes the phase-velocity kernels of the (flat or flattened) model -- d c / d alpha, beta, rho and
+// the interface partial -- and U.  LOVE: slegn96 (alpha kernel = 0); SPH: f64 bldsph model.
+// Scratch / outputs are indexed by the GLOBAL item e (both families share croot, krn, ugr, cds).
 // ---------------------------------------------------------------------------------------
+template <bool LOVE, class Mdl>
+__device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, size_t ntot, double t, double cp,
+                                               double* __restrict__ sc, double* __restrict__ ko,
+                                               double* __restrict__ uout)
+{
+    const size_t s = (size_t)n * nchain;
+    const double omega = 2.0 * SR_PI32 / t, wvno = omega / cp;
+    if (LOVE) {
+        sl_up(M, omega, wvno, [&](int m, double uu, double tt, double exl) {
+            double* o = sc + (size_t)m * 6 * ntot;
+            o[0] = uu; o[ntot] = tt; o[2 * ntot] = exl;
+        });
+        SlTotals R = sl_down_energy(M, omega, wvno,
+            [&](int m, double& uu, double& tt, double& exl) {
+                const double* o = sc + (size_t)m * 6 * ntot;
+                uu = o[0]; tt = o[ntot]; exl = o[2 * ntot];
+            },
+            [&](int m, double db, double dr, double dh) {
+                ko[0 * s + (size_t)m * nchain] = 0.0; ko[1 * s + (size_t)m * nchain] = db;
+                ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
+            });
+        for (int m = 0; m < n; m++) {
+            ko[1 * s + (size_t)m * nchain] /= R.sumi1; ko[2 * s + (size_t)m * nchain] /= R.sumi1;
+            double dfac = R.fac * ko[3 * s + (size_t)m * nchain];
+            ko[3 * s + (size_t)m * nchain] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;   // slegn96.f90:598-602
+        }
+        *uout = R.ugr;
+    } else {
+        auto store = [&](int m, const double* cd, double exe) {
+            double* o = sc + (size_t)m * 6 * ntot;
+#pragma unroll
+            for (int i = 0; i < 5; i++) o[(size_t)i * ntot] = cd[i];
+            o[(size_t)5 * ntot] = exe;
+        };
+        sr_up(M, omega, wvno, store);
+        auto load = [&](int m, double* cd, double& exe) {
+            const double* o = sc + (size_t)m * 6 * ntot;
+#pragma unroll
+            for (int i = 0; i < 5; i++) cd[i] = o[(size_t)i * ntot];
+            exe = o[(size_t)5 * ntot];
+        };
+        auto emit = [&](int m, double da, double db, double dr, double dh) {
+            ko[0 * s + (size_t)m * nchain] = da; ko[1 * s + (size_t)m * nchain] = db;
+            ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
+        };
+        SrTotals R = sr_down_energy(M, omega, wvno, load, emit);
+        double sca = 1.0 / (R.ugr * R.sumi0);
+        for (int m = 0; m < n; m++) {
+            ko[0 * s + (size_t)m * nchain] *= sca; ko[1 * s + (size_t)m * nchain] *= sca;
+            ko[2 * s + (size_t)m * nchain] *= sca;
+            double dfac = R.fac * ko[3 * s + (size_t)m * nchain];
+            ko[3 * s + (size_t)m * nchain] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;   // sregn96.f90:1529-1531
+        }
+        double u = R.ugr;
+        if (fabs(u) < 1.0e-36) u = 0.0;                                             // :1703
+        *uout = u;
+    }
+}
+
+template <bool LOVE, bool SPH>
 __global__ void __launch_bounds__(64)
-k_swd_eigen(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ croot,
-            const int* __restrict__ sflag, double* __restrict__ cds, double* __restrict__ krn,
-            double* __restrict__ ugr)
+k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
+            const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
+            double* __restrict__ krn, double* __restrict__ ugr)
 {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nitem = (size_t)Q.nper_total * nchain;
-    if (g >= nitem) return;
-    int e = (int)(g / nchain), chain = (int)(g - (size_t)e * nchain);
+    if (g >= (size_t)Q.nper_total * nchain) return;
+    int el = (int)(g / nchain), chain = (int)(g - (size_t)el * nchain);
+    int e = Q.s[0].croot_off + el;
     int seq = 0;
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
     if (!sflag[(size_t)seq * nchain + chain]) return;
     int k = e - Q.s[seq].croot_off;
     double t = Q.s[seq].t[k] * Q.s[seq].scale;
-    double cp = croot[(size_t)e * nchain + chain];
+    const size_t gi = (size_t)e * nchain + chain;
+    double cp = croot[gi];
     const size_t s = (size_t)n * nchain;
-    SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
-    double omega = 2.0 * SR_PI32 / t, wvno = omega / cp;
-    double* sc = cds + g;
-    auto store = [&](int m, const double* cd, double exe) {
-        double* o = sc + (size_t)m * 6 * nitem;
-#pragma unroll
-        for (int i = 0; i < 5; i++) o[(size_t)i * nitem] = cd[i];
-        o[(size_t)5 * nitem] = exe;
-    };
-    sr_up(M, omega, wvno, store);
-    auto load = [&](int m, double* cd, double& exe) {
-        const double* o = sc + (size_t)m * 6 * nitem;
-#pragma unroll
-        for (int i = 0; i < 5; i++) cd[i] = o[(size_t)i * nitem];
-        exe = o[(size_t)5 * nitem];
-    };
     double* ko = krn + (size_t)e * 4 * s + chain;       // [e][q][m][chain]
-    auto emit = [&](int m, double da, double db, double dr, double dh) {
-        ko[0 * s + (size_t)m * nchain] = da; ko[1 * s + (size_t)m * nchain] = db;
-        ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
-    };
-    SrTotals R = sr_down_energy(M, omega, wvno, load, emit);
-    double sca = 1.0 / (R.ugr * R.sumi0);
-    for (int m = 0; m < n; m++) {
-        ko[0 * s + (size_t)m * nchain] *= sca; ko[1 * s + (size_t)m * nchain] *= sca;
-        ko[2 * s + (size_t)m * nchain] *= sca;
-        double dfac = R.fac * ko[3 * s + (size_t)m * nchain];
-        ko[3 * s + (size_t)m * nchain] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;   // sregn96.f90:1529-1531
+    if (SPH) {
+        SwdModelD M{sph + chain, sph + s + chain, sph + 2 * s + chain, sph + 3 * s + chain, nchain, n};
+        swd_eigen_lane<LOVE>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
+    } else {
+        SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        swd_eigen_lane<LOVE>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
     }
-    double u = R.ugr;
-    if (fabs(u) < 1.0e-36) u = 0.0;                                             // :1703
-    ugr[g] = u;
 }
 
-// Kernel value q (0 alpha, 1 beta, 2 rho, 3 interface) of data row `row` at layer m:
-// phase rows read sequence-0 items directly, group rows combine the three passes as
-// sregnpu does (sregn96.f90:1839-1844), first term from the t2 = 0.95 T pass (quirk).
-struct SwdRows { int ntRc, ntRg; int off_rg, off_rg1, off_rg2; const double* tRg; };
+// Data rows.  Up to four blocks in data order (Rc, Rg, Lc, Lg); a phase block reads the items of its
+// sequence directly, a group block combines the three passes T, 1.05 T, 0.95 T as sregnpu / slegnpu do
+// (sregn96.f90:1839-1844, slegn96.f90:875-878; first term from the 0.95 T pass: quirk).  With
+// sphere != 0 the flat-model kernels are mapped back with vtp / dtp / rtp and tm (sprayl, splove and
+// the tail of sregnpu / slegnpu); fwd != 0 selects the phase-velocity conversion of libsurf.forward
+// (_flat2sphere) instead of sprayl's.
+struct SwdBlk { int type, nrow, off, off1, off2; const double* t; };    // type 0 Rc, 1 Rg, 2 Lc, 3 Lg; off* in items
+struct SwdRows { SwdBlk b[4]; int nblk, nswd, sphere, fwd; const double* sphR; const double* sphL; };
 
-__device__ __forceinline__ double swd_kernel_value(const SwdRows& R, int row, int q, int m, int chain,
+template <bool SPH>
+__device__ __forceinline__ double swd_data_value(const SwdRows& R, const SwdBlk& B, int k, int chain, int nchain,
+                                                 const double* __restrict__ croot, const double* __restrict__ ugr)
+{
+    const bool love = B.type >= 2;
+    const size_t i0 = (size_t)(B.off + k) * nchain + chain;
+    if (!(B.type & 1)) {
+        const double c = croot[i0];
+        if (!SPH) return c;
+        const double t = B.t[k];
+        return R.fwd ? c / f2s_tm(love, t, c) : c / sr_tm(love, c, 2.0 * SR_PI32 / t);
+    }
+    const double u = ugr[i0];
+    if (!SPH) return u;
+    return u * sr_tm(love, croot[i0], 2.0 * SR_PI32 / B.t[k]);
+}
+
+// kernel q (0 alpha, 1 beta, 2 rho, 3 interface) of row k of block B at layer m
+template <bool SPH>
+__device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBlk& B, int k, int q, int m, int chain,
                                                    int nchain, int n, const double* __restrict__ krn,
                                                    const double* __restrict__ croot, const double* __restrict__ ugr)
 {
-    const size_t s = (size_t)n * nchain;
-    if (row < R.ntRc) return krn[((size_t)row * 4 + q) * s + (size_t)m * nchain + chain];
-    int k = row - R.ntRc;
-    int e0 = R.off_rg + k, e1 = R.off_rg1 + k, e2 = R.off_rg2 + k;
-    double t = R.tRg[k], t1 = t * (1.0 + 0.05), t2 = t * (1.0 - 0.05);
-    double uc1 = ugr[(size_t)e0 * nchain + chain] / croot[(size_t)e0 * nchain + chain];
-    double k1 = krn[((size_t)e1 * 4 + q) * s + (size_t)m * nchain + chain];
-    double k2 = krn[((size_t)e2 * 4 + q) * s + (size_t)m * nchain + chain];
-    return uc1 * (2.0 - uc1) * k2 - uc1 * uc1 * t * (k2 - k1) / (t2 - t1);
+    const size_t s = (size_t)n * nchain, lm = (size_t)m * nchain + chain;
+    const bool love = B.type >= 2;
+    const int e0 = B.off + k;
+    const double k0 = krn[((size_t)e0 * 4 + q) * s + lm];
+    double fac = 1.0;
+    if (SPH) fac = (love ? R.sphL : R.sphR)[(size_t)((q < 2) ? 4 : (q == 2 ? 6 : 5)) * s + lm];
+    if (!(B.type & 1)) {
+        if (!SPH) return k0;
+        double tm = sr_tm(love, croot[(size_t)e0 * nchain + chain], 2.0 * SR_PI32 / B.t[k]);
+        return k0 * fac / (tm * tm * tm);
+    }
+    const int e1 = B.off1 + k, e2 = B.off2 + k;
+    const double t = B.t[k], t1 = t * (1.0 + 0.05), t2 = t * (1.0 - 0.05);
+    const double cg = ugr[(size_t)e0 * nchain + chain], cp = croot[(size_t)e0 * nchain + chain];
+    const double uc1 = cg / cp;
+    const double k1 = krn[((size_t)e1 * 4 + q) * s + lm];
+    const double k2 = krn[((size_t)e2 * 4 + q) * s + lm];
+    const double du = uc1 * (2.0 - uc1) * k2 - uc1 * uc1 * t * (k2 - k1) / (t2 - t1);
+    if (!SPH) return du;
+    const double omega = 2.0 * SR_PI32 / t, tm = sr_tm(love, cp, omega), tm1 = sr_tm1(love, omega, tm);
+    return (tm * du + cg * cp * k0 * tm1) * fac;
 }
 
 // B1 export: [chain][row][layer] arrays for libsurf.adjoint_kernel (thickness kernel =
-// suffix sum of the interface partials, sregn96.f90:1727-1731, 1871-1878).
-__global__ void k_swd_export(int nchain, int n, SwdRows R, int row0, int nrow, const double* __restrict__ krn,
+// suffix sum of the interface partials, sregn96.f90:1727-1731, 1871-1878); single block.
+template <bool SPH>
+__global__ void k_swd_export(int nchain, int n, SwdRows R, const double* __restrict__ krn,
                              const double* __restrict__ croot, const double* __restrict__ ugr,
                              double* c, double* dcda, double* dcdb, double* dcdr, double* dcdh)
 {
+    const SwdBlk B = R.b[0];
+    const int nrow = B.nrow;
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nrow) return;
-    int chain = g / nrow, r = g - chain * nrow, row = row0 + r;
-    if (c) {
-        if (row < R.ntRc) c[g] = croot[(size_t)row * nchain + chain];
-        else c[g] = ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
-    }
+    int chain = g / nrow, k = g - chain * nrow;
+    if (c) c[g] = swd_data_value<SPH>(R, B, k, chain, nchain, croot, ugr);
     if (!dcda) return;
     double suf = 0.0;
     for (int m = n - 1; m >= 0; m--) {
         size_t o = (size_t)g * n + m;
-        dcda[o] = swd_kernel_value(R, row, 0, m, chain, nchain, n, krn, croot, ugr);
-        dcdb[o] = swd_kernel_value(R, row, 1, m, chain, nchain, n, krn, croot, ugr);
-        dcdr[o] = swd_kernel_value(R, row, 2, m, chain, nchain, n, krn, croot, ugr);
+        dcda[o] = swd_kernel_value<SPH>(R, B, k, 0, m, chain, nchain, n, krn, croot, ugr);
+        dcdb[o] = swd_kernel_value<SPH>(R, B, k, 1, m, chain, nchain, n, krn, croot, ugr);
+        dcdr[o] = swd_kernel_value<SPH>(R, B, k, 2, m, chain, nchain, n, krn, croot, ugr);
         dcdh[o] = suf;
-        suf += swd_kernel_value(R, row, 3, m, chain, nchain, n, krn, croot, ugr);
+        suf += swd_kernel_value<SPH>(R, B, k, 3, m, chain, nchain, n, krn, croot, ugr);
     }
 }
 
@@ -766,6 +886,7 @@ k_rf_reduce(int nchain, int n, int rf_only, int npart, const double* __restrict_
     if (rf_only && j == 0) { misfit[chain] = misfit_rf[chain]; flag[chain] = 1; }
 }
 
+template <bool SPH>
 __global__ void __launch_bounds__(256)
 k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const double* __restrict__ misfit_rf,
               const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
@@ -778,7 +899,7 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
     int chain = blockIdx.x * 64 + tx;
     const bool inb = chain < nchain;
     if (!inb) chain = nchain - 1;
-    const int nswd = R.ntRc + R.ntRg, ndata = nt + nswd;
+    const int nswd = R.nswd, ndata = nt + nswd;
     bool ok = true;
     for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
     const double w = (mode == 0) ? wt : 1.0;
@@ -787,20 +908,23 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
         double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
         double gs = 0.0, hj = 0.0;
         if (ok) {
-            for (int row = 0; row < nswd; row++) {
-                double d = (row < R.ntRc) ? croot[(size_t)row * nchain + chain]
-                                          : ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
-                double r = d - dobs[nt + row];
-                if (j == ty && ty == 0) {
-                    m_swd += r * r;
-                    if (inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
+            int row = 0;
+            for (int b = 0; b < R.nblk; b++) {
+                const SwdBlk B = R.b[b];
+                for (int k = 0; k < B.nrow; k++, row++) {
+                    double d = swd_data_value<SPH>(R, B, k, chain, nchain, croot, ugr);
+                    double r = d - dobs[nt + row];
+                    if (j == ty && ty == 0) {
+                        m_swd += r * r;
+                        if (inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
+                    }
+                    double ka = swd_kernel_value<SPH>(R, B, k, 0, j, chain, nchain, n, krn, croot, ugr);
+                    double kb = swd_kernel_value<SPH>(R, B, k, 1, j, chain, nchain, n, krn, croot, ugr);
+                    double kr = swd_kernel_value<SPH>(R, B, k, 2, j, chain, nchain, n, krn, croot, ugr);
+                    double kh = swd_kernel_value<SPH>(R, B, k, 3, j, chain, nchain, n, krn, croot, ugr);
+                    gs += r * (kb + ka * dadb + kr * drdadb);                    // model_surf.py:184
+                    hj += r * kh;
                 }
-                double ka = swd_kernel_value(R, row, 0, j, chain, nchain, n, krn, croot, ugr);
-                double kb = swd_kernel_value(R, row, 1, j, chain, nchain, n, krn, croot, ugr);
-                double kr = swd_kernel_value(R, row, 2, j, chain, nchain, n, krn, croot, ugr);
-                double kh = swd_kernel_value(R, row, 3, j, chain, nchain, n, krn, croot, ugr);
-                gs += r * (kb + ka * dadb + kr * drdadb);                    // model_surf.py:184
-                hj += r * kh;
             }
         }
         hs[(size_t)j * 64 + tx] = hj;
@@ -841,14 +965,15 @@ __global__ void k_swd_forward_out(int nchain, int nt, SwdRows R, const double* _
 {
     int chain = blockIdx.x * blockDim.x + threadIdx.x;
     if (chain >= nchain) return;
-    const int nswd = R.ntRc + R.ntRg, ndata = nt + nswd;
+    const int nswd = R.nswd, ndata = nt + nswd;
     int ok = 1;
     for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
-    for (int row = 0; row < nswd; row++) {
-        double d = 0.0;
-        if (ok) d = (row < R.ntRc) ? croot[(size_t)row * nchain + chain]
-                                   : ugr[(size_t)(R.off_rg + row - R.ntRc) * nchain + chain];
-        dsyn[(size_t)chain * ndata + nt + row] = d;
+    int row = 0;
+    for (int b = 0; b < R.nblk; b++) {
+        const SwdBlk B = R.b[b];
+        for (int k = 0; k < B.nrow; k++, row++)
+            dsyn[(size_t)chain * ndata + nt + row] = !ok ? 0.0 : R.sphere ? swd_data_value<true>(R, B, k, chain, nchain, croot, ugr)
+                                                                         : swd_data_value<false>(R, B, k, chain, nchain, croot, ugr);
     }
     flag[chain] = ok;
 }

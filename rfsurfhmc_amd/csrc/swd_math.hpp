@@ -44,7 +44,57 @@ struct SwdModel {
     RFS_HD float Rf(int m) const { return rho[m * stride]; }
 };
 
+// f64 layer arrays of an earth-flattened model (bldsph, sregn96.f90:133-187 / slegn96.f90:107-167);
+// the float32 views are sngl(zrho(m)), sngl(zb(m)) as the Fortran passes them to dnka / hska.
+struct SwdModelD {
+    const double* d; const double* a; const double* b; const double* rho;
+    long stride;
+    int n;
+    RFS_HD double D(int m) const { return d[m * stride]; }
+    RFS_HD double A(int m) const { return a[m * stride]; }
+    RFS_HD double B(int m) const { return b[m * stride]; }
+    RFS_HD double R(int m) const { return rho[m * stride]; }
+    RFS_HD float Bf(int m) const { return (float)b[m * stride]; }
+    RFS_HD float Rf(int m) const { return (float)rho[m * stride]; }
+};
+
 RFS_HD double sgn1(double x) { return copysign(1.0, x); }
+
+// ---------------------------------------------------------------------------
+// Love secular function (surfdisp96.f:727-787 dltar1, all-solid model): 2-vector recurrence
+// from the half-space up, normalised per layer; e(1) at the surface is the period equation.
+// ---------------------------------------------------------------------------
+RFS_HD double swd_secular_love(const SwdModel& M, double wvno, double omega) {
+    const int last = M.n - 1;
+    double beta1 = M.B(last), rho1 = M.R(last);
+    double xkb = omega / beta1;
+    double rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
+    double e1 = rho1 * rb, e2 = 1.0 / (beta1 * beta1);
+    for (int m = last - 1; m >= 0; m--) {
+        beta1 = M.B(m); rho1 = M.R(m);
+        double xmu = rho1 * beta1 * beta1;
+        xkb = omega / beta1;
+        rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
+        double dm = M.D(m), q = dm * rb, y, z, cosq;
+        if (wvno < xkb) {
+            double sn, cs; sincos(q, &sn, &cs);
+            y = sn / rb; z = -rb * sn; cosq = cs;
+        } else if (wvno == xkb) {
+            cosq = 1.0; y = dm; z = 0.0;
+        } else {
+            double fac = (q < 16.0) ? exp(-2.0 * q) : 0.0;
+            cosq = (1.0 + fac) * 0.5;
+            double sinq = (1.0 - fac) * 0.5;
+            y = sinq / rb; z = rb * sinq;
+        }
+        double e10 = e1 * cosq + e2 * xmu * z;
+        double e20 = e1 * y / xmu + e2 * cosq;
+        double xnor = fmax(fabs(e10), fabs(e20));
+        if (xnor < 1.0e-40) xnor = 1.0;
+        e1 = e10 / xnor; e2 = e20 / xnor;
+    }
+    return e1;
+}
 
 // ---------------------------------------------------------------------------
 // Dunkin secular function  (surfdisp96.f:791-891 with var :894-1011, dnka :1044-1088,
@@ -323,6 +373,7 @@ struct RootSearchT {
 
     template <class PeriodFn>
     RFS_HD void begin(const SwdModel& M, const PeriodFn& T, int kmax_) {
+        // (the P velocity only enters through the water-layer test and the half-space start value gtsolh)
         // surfdisp96.f:149-160 extremal velocities, :203-222 start value
         float bmx = -1.e20f, bmn = 1.e20f; int jmn = 0, jsol = 1;
         for (int i = 0; i < M.n; i++) {
@@ -586,8 +637,8 @@ RFS_HD void sr_halfspace_vector(double a, double b, double rho, double wvno, dou
 }
 
 // Up-sweep (sregn96.f90:404-492): Store(m, cd[5], exe) is called for m = n-1 .. 0.
-template <class StoreFn>
-RFS_HD void sr_up(const SwdModel& M, double omega, double wvno, const StoreFn& store) {
+template <class Mdl, class StoreFn>
+RFS_HD void sr_up(const Mdl& M, double omega, double wvno, const StoreFn& store) {
     const int n = M.n;
     double wvno2 = wvno * wvno, om2 = omega * omega;
     double cd[5];
@@ -712,8 +763,8 @@ RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, dou
 // the returned (ugr, sumi0, fac) -- see sr_finish_scale.
 struct SrTotals { double ugr, sumi0, fac; };
 
-template <class LoadFn, class EmitFn>
-RFS_HD SrTotals sr_down_energy(const SwdModel& M, double omega, double wvno, const LoadFn& load,
+template <class Mdl, class LoadFn, class EmitFn>
+RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const LoadFn& load,
                                const EmitFn& emit) {
     const int n = M.n;
     const double om2 = omega * omega, wvno2 = wvno * wvno, c = omega / wvno;
@@ -782,6 +833,211 @@ RFS_HD SrTotals sr_down_energy(const SwdModel& M, double omega, double wvno, con
     T.sumi0 = sumi0;
     T.fac = are * c / wvno2;
     return T;
+}
+
+// ---------------------------------------------------------------------------
+// Love eigenfunctions and kernels (slegn96.f90): varl :248-328, up :372-445, shfunc :179-246,
+// energy :447-629 -- all-solid model.  Same two-sweep layout as the Rayleigh pass: the up-sweep
+// stores (uu, tt, exl) per layer, the top-down sweep rebuilds the true amplitudes, the layer
+// integrals and the interface terms with O(1) state.
+// ---------------------------------------------------------------------------
+struct SlVar { double cosq, yl, zl, mu, rb, xkb, eexl; };
+
+template <class Mdl>
+RFS_HD void sl_varl(const Mdl& M, int m, double omega, double wvno, double dpth, SlVar& v) {
+    double b = M.B(m);
+    v.xkb = omega / b;
+    v.rb = sqrt((wvno + v.xkb) * fabs(wvno - v.xkb));
+    double q = v.rb * dpth;
+    v.mu = M.R(m) * b * b;
+    v.eexl = 0.0;
+    if (wvno < v.xkb) {
+        double sn, cs; sincos(q, &sn, &cs);
+        v.yl = sn / v.rb; v.zl = -v.rb * sn; v.cosq = cs;
+    } else if (wvno == v.xkb) {
+        v.cosq = 1.0; v.yl = dpth; v.zl = 0.0;
+    } else {
+        v.eexl = q;
+        double fac = (q < 18.0) ? exp(-2.0 * q) : 0.0;
+        v.cosq = (1.0 + fac) * 0.5;
+        double sinq = (1.0 - fac) * 0.5;
+        v.yl = sinq / v.rb; v.zl = v.rb * sinq;
+    }
+}
+
+// Store(m, uu, tt, exl) for m = n-1 .. 0
+template <class Mdl, class StoreFn>
+RFS_HD void sl_up(const Mdl& M, double omega, double wvno, const StoreFn& store) {
+    const int n = M.n;
+    SlVar v;
+    double uu = 1.0, tt = 0.0;
+    if (M.B(n - 1) > 0.01) {
+        sl_varl(M, n - 1, omega, wvno, 0.0, v);
+        double bl = M.B(n - 1);
+        tt = -(M.R(n - 1) * (bl * bl)) * v.rb;                 // -xmu(mmax)*rb
+    }
+    store(n - 1, uu, tt, 0.0);
+    for (int k = n - 2; k >= 0; k--) {
+        sl_varl(M, k, omega, wvno, M.D(k), v);
+        double a11 = v.cosq, a12 = -(v.yl / v.mu), a21 = -(v.zl * v.mu);
+        double amp0 = a11 * uu + a12 * tt;
+        double str0 = a21 * uu + a11 * tt;
+        double rr = fmax(fabs(amp0), fabs(str0));
+        if (rr < 1.0e-30) rr = 1.0;
+        uu = amp0 / rr; tt = str0 / rr;
+        store(k, uu, tt, log(rr) + v.eexl);
+    }
+}
+
+struct SlTotals { double ugr, sumi1, fac; };
+
+// Load(m, uu, tt, exl) returns what sl_up stored.  Emit(m, db, dr, dh) receives dc/db and dc/drho BEFORE the
+// division by I1 and the interface term before `fac` (slegn96.f90:564-607); the caller rescales.
+template <class Mdl, class LoadFn, class EmitFn>
+RFS_HD SlTotals sl_down_energy(const Mdl& M, double omega, double wvno, const LoadFn& load, const EmitFn& emit) {
+    const int n = M.n;
+    const double c = omega / wvno, omega2 = omega * omega, wvno2 = wvno * wvno;
+    // shfunc :212-240: amplitudes from the extended floating-point form, normalised to uu(1) (or, if that
+    // vanishes, to the largest amplitude)
+    double u0, t0, e0;
+    load(0, u0, t0, e0);
+    double umax = u0;
+    if (u0 == 0.0) {
+        double ext = 0.0, eprev = e0;
+        for (int k = 1; k < n; k++) {
+            double uk, tk, ek; load(k, uk, tk, ek);
+            ext += eprev; eprev = ek;
+            double fact = (ext < 80.0) ? 1. / exp(ext) : 0.0;
+            uk *= fact;
+            if (fabs(uk) > fabs(umax)) umax = uk;
+        }
+    }
+    const bool scale = fabs(umax) > 0.0;
+    double ut = scale ? u0 / umax : u0, tt_top = 0.0;          // tt(1) = 0 is forced (:214)
+    double ext = 0.0, eprev = e0;
+    double sumi0 = 0.0, sumi1 = 0.0, sumi2 = 0.0;
+    double rho_u = 0.0, mu_u = 0.0;
+    for (int k = 0; k < n; k++) {
+        double b = M.B(k), drho = M.R(k), dpth = M.D(k);
+        double TN = drho * b * b, dmu = drho * (b * b);         // TN = zrho*zb*zb, xmu = zrho*zb**2
+        double ub = 0.0, tb = 0.0;
+        if (k < n - 1) {
+            double ek; load(k + 1, ub, tb, ek);
+            ext += eprev; eprev = ek;
+            double fact = (ext < 80.0) ? 1. / exp(ext) : 0.0;
+            ub *= fact; tb *= fact;
+            if (scale) { ub /= umax; tb /= umax; }
+        }
+        SlVar v;
+        sl_varl(M, k, omega, wvno, dpth, v);
+        double rb = v.rb < 1.0e-10 ? 1.0e-10 : v.rb;
+        double upup, dupdup;
+        if (k == n - 1) {
+            upup = (0.5 / rb) * ut * ut;
+            dupdup = (0.5 * rb) * ut * ut;
+        } else {
+            cplx nub = (wvno < v.xkb) ? cplx{0.0, rb} : cplx{rb, 0.0};
+            cplx xnub = dmu * nub;
+            cplx iw = inv(wvno * xnub);
+            double h = 0.5 / wvno;
+            cplx km1dn = C(h * ut) - (0.5 * iw) * tt_top;       // einvl(2,1) uu(k) + einvl(2,2) tt(k)
+            cplx kmup = C(h * ub) + (0.5 * iw) * tb;            // einvl(1,1) uu(k1) + einvl(1,2) tt(k1)
+            cplx f3 = dpth * nub;
+            cplx ex2 = (f3.re < 40.0) ? cexp_p(-2.0 * f3) : C(0.0);
+            cplx f = (1.0 - ex2) * inv(2.0 * nub);
+            cplx ex1 = (f3.re < 75.0) ? cexp_p(-f3) : C(0.0);
+            cplx g = dpth * ex1;
+            cplx f1 = f * ((wvno * wvno) * (kmup * kmup) + (wvno * wvno) * (km1dn * km1dn));
+            cplx f2 = g * (2.0 * (wvno * wvno)) * (kmup * km1dn);
+            upup = (f1 + f2).re;
+            dupdup = (nub * nub * (f1 - f2)).re;
+        }
+        sumi0 += drho * upup; sumi1 += TN * upup; sumi2 += TN * dupdup;
+        double db = c * drho * b * upup + c * drho * b * dupdup / wvno2;
+        double dr = 0.5 * c * (-c * c * upup + b * b * upup + b * b * dupdup / wvno2);
+        double drh, dm, dvdz;
+        if (k == 0) { drh = drho; dm = dmu; dvdz = 0.0; }
+        else { drh = drho - rho_u; dm = dmu - mu_u; dvdz = tt_top * tt_top * (1.0 / dmu - 1.0 / mu_u); }
+        double dh = ut * ut * (omega2 * drh - wvno2 * dm) + dvdz;
+        emit(k, db, dr, dh);
+        rho_u = drho; mu_u = dmu;
+        ut = ub; tt_top = tb;
+    }
+    SlTotals T;
+    T.ugr = sumi1 / (c * sumi0);
+    T.sumi1 = sumi1;
+    T.fac = (0.5 / sumi1) * c / wvno2;
+    return T;
+}
+
+// ---------------------------------------------------------------------------
+// Earth flattening of the model.
+//   swd_flatten_f32  surfdisp96.f:495-564 `sphere` (iflag 0 then 1; ar = 6370, geometry in f64, model arrays
+//                    float32): what the root search sees
+//   swd_bldsph       sregn96.f90:133-187 / slegn96.f90:107-167 (ar = 6371, all f64): what the eigenfunction
+//                    pass sees, plus the factors vtp, dtp, rtp that map flat kernels back to the sphere
+// Arrays are strided (element m at p[m * stride]).
+// ---------------------------------------------------------------------------
+RFS_HD void swd_flatten_f32(bool love, int n, const float* d, const float* a, const float* b, const float* rho,
+                            long si, float* od, float* oa, float* ob, float* orho, long so) {
+    const double ar = 6370.0;
+    double dr = 0.0, r0 = ar;
+    for (int i = 0; i < n; i++) {
+        float di = (i == n - 1) ? 1.0f : d[i * si];
+        dr = dr + (double)di;
+        double r1 = ar - dr;
+        double z0 = ar * log(ar / r0), z1 = ar * log(ar / r1);
+        double tmp = (ar + ar) / (r0 + r1);
+        od[i * so] = (i == n - 1) ? 0.0f : (float)(z1 - z0);
+        oa[i * so] = (float)((double)a[i * si] * tmp);
+        ob[i * so] = (float)((double)b[i * si] * tmp);
+        float btp = (float)tmp, r = rho[i * si];
+        if (love) { float x2 = btp * btp, x4 = x2 * x2, x5 = btp * x4; orho[i * so] = r * (1.0f / x5); }   // btp**(-5)
+        else orho[i * so] = r * (float)pow((double)btp, (double)-2.275f);                                 // btp**(-2.275)
+        r0 = r1;
+    }
+}
+
+RFS_HD void swd_bldsph(bool love, int n, const float* d, const float* a, const float* b, const float* rho, long si,
+                       double* zd, double* za, double* zb, double* zrho, double* vtp, double* dtp, double* rtp,
+                       long so) {
+    const double ar = 6371.0;
+    double dr = 0.0, r0 = ar;
+    for (int i = 0; i < n; i++) {
+        dr = dr + ((i == n - 1) ? 1.0 : (double)d[i * si]);
+        double r1 = ar - dr;
+        double z0 = ar * log(ar / r0), z1 = ar * log(ar / r1);
+        double tmp = (2.0 * ar) / (r0 + r1);
+        double rt;
+        if (love) { double t2 = tmp * tmp, t4 = t2 * t2; rt = 1.0 / (tmp * t4); }    // tmp**(-5)
+        else rt = pow(tmp, (double)-2.275f);                                          // tmp**(-2.275)
+        vtp[i * so] = tmp; rtp[i * so] = rt; dtp[i * so] = ar / r0;
+        za[i * so] = (double)a[i * si] * tmp;
+        zb[i * so] = (double)b[i * si] * tmp;
+        zrho[i * so] = (double)rho[i * si] * rt;
+        zd[i * so] = (i == n - 1) ? 0.0 : z1 - z0;
+        r0 = r1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Earth-flattening corrections applied to flat-model results.
+//   sr_tm     sprayl / sregnpu (sregn96.f90:1625, 1851) and splove / slegnpu (slegn96.f90:661, 884):
+//             tm = sqrt(1 + (k c / (2 a w))^2), k = 1 Rayleigh / 3 Love, w from the float32 pi
+//   f2s_tm    _flat2sphere (surfdisp.cpp:16-49): same quantity, f64 pi, used by libsurf.forward for phase blocks
+// ---------------------------------------------------------------------------
+RFS_HD double sr_tm(bool love, double c, double omega) {
+    double x = love ? 3.0 * c / (2. * 6371.0 * omega) : c / (2. * 6371.0 * omega);
+    return sqrt(1. + x * x);
+}
+RFS_HD double sr_tm1(bool love, double omega, double tm) {
+    double x = (love ? 1.5 : 0.5) / (6371.0 * omega);
+    return x * x / tm;
+}
+RFS_HD double f2s_tm(bool love, double t, double c) {
+    double omega = 2.0 * 3.14159265358979323846 / t;
+    double x = (love ? 1.5 : 0.5) * c / (6371.0 * omega);
+    return sqrt(1. + x * x);
 }
 
 }  // namespace rfs

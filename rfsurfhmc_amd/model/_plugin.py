@@ -4,7 +4,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import Context, RfParams, hptr
+from .._lib import Context, RfParams, SwdParams, hptr
 
 
 class FusedPlugin:
@@ -16,8 +16,9 @@ class FusedPlugin:
     def _rf_params(self):
         return None
 
-    def _periods(self):
-        return None, None
+    def _swd_config(self):
+        """(tRc, tRg, tLc, tLg, sphere): the periods each SWD block is evaluated at in misfit_and_grad."""
+        return None, None, None, None, False
 
     def _sigmas(self):
         return 1.0, 1.0
@@ -27,17 +28,20 @@ class FusedPlugin:
             self._ctx = Context(device=self.device, max_chains=1 << 20, max_layers=128)
         ctx = self._ctx
         rf = self._rf_params()
-        tRc, tRg = self._periods()
-        tRc = np.ascontiguousarray(tRc, dtype=np.float64) if tRc is not None else np.zeros(0)
-        tRg = np.ascontiguousarray(tRg, dtype=np.float64) if tRg is not None else np.zeros(0)
+        *tw, sphere = self._swd_config()
+        tw = [np.ascontiguousarray(t, dtype=np.float64) if t is not None else np.zeros(0) for t in tw]
         s1, s2 = self._sigmas()
         d = None if dobs is None else np.ascontiguousarray(dobs, dtype=np.float64)
-        ctx.check(ctx.L.rfs_joint_setup(ctx.h, int(nlayer), ctypes.byref(rf) if rf is not None else None,
-                                        len(tRc), hptr(tRc) if len(tRc) else None,
-                                        len(tRg), hptr(tRg) if len(tRg) else None,
-                                        float(s1), float(s2), hptr(d) if d is not None else None))
+        swd = None
+        if sum(len(t) for t in tw) > 0:
+            swd = SwdParams(*[len(t) for t in tw], *[t.ctypes.data if len(t) else None for t in tw],
+                            int(bool(sphere)), 0)
+        ctx.check(ctx.L.rfs_joint_setup2(ctx.h, int(nlayer), ctypes.byref(rf) if rf is not None else None,
+                                         ctypes.byref(swd) if swd is not None else None,
+                                         float(s1), float(s2), hptr(d) if d is not None else None))
+        tRc, tRg = tw[0], tw[1]
         self._cfg = (int(nlayer), None if d is None else d.tobytes())
-        self._keep = (tRc, tRg, d)
+        self._keep = (tw, d)
 
     def _ensure(self, nlayer):
         dobs = getattr(self, "dobs", None)

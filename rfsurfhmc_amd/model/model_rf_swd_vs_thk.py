@@ -16,8 +16,8 @@ class Joint_RF_SWD(FusedPlugin):
     def _rf_params(self):
         return self.rfmodel._rf_params()
 
-    def _periods(self):
-        return self.swdmodel.tRc, self.swdmodel.tRg
+    def _swd_config(self):
+        return self.swdmodel._swd_config()
 
     def _sigmas(self):
         return self.sigma1, self.sigma2
@@ -32,7 +32,7 @@ class Joint_RF_SWD(FusedPlugin):
 
     def forward(self, x):
         """(drf, dswd, flag) -- model_rf_swd_vs_thk.py:27-49."""
-        single, dsyn, flag = self._forward(x, quirk=True)
+        single, dsyn, flag = self._forward(x, quirk=self.swdmodel.reference_periods)
         n1 = self.rfmodel.nt
         if single:
             return dsyn[0, :n1], dsyn[0, n1:], bool(flag[0])

@@ -1,33 +1,48 @@
 """SurfWD -- host-side mirror of the reference plugin model/model_surf.py (same constructor,
 ``init(**kargs)`` keys, ``set_obsdata``, ``set_thk``, ``forward``, ``misfit``, ``misfit_and_grad``),
-evaluated on the GPU through the fused B2 entry points.  Rayleigh blocks (tRc, tRg) only."""
+evaluated on the GPU through the fused B2 entry points.  All four blocks (tRc, tRg, tLc, tLg),
+flat or spherical earth, fundamental mode.
+
+Reference behaviour kept by default (``reference_periods=True``): forward() evaluates EVERY block at
+tRc (model_surf.py:104-131) and misfit_and_grad() evaluates the Lc and Lg blocks at tRc
+(model_surf.py:199-216), so those blocks need len(tRc) rows -- the reference raises otherwise, and so
+does this class.  ``reference_periods=False`` evaluates every block at its own periods."""
 import numpy as np
 
 from ._plugin import FusedPlugin
 
 
 class SurfWD(FusedPlugin):
-    def __init__(self, mode=0, sphere=False, tRc=None, tRg=None, tLc=None, tLg=None, device=0):
-        if mode != 0 or sphere:
-            raise NotImplementedError("fundamental mode, flat earth only")
-        if (tLc is not None and len(tLc) > 0) or (tLg is not None and len(tLg) > 0):
-            raise NotImplementedError("Love-wave data are out of scope")
-        self.mode, self.sphere, self.device = mode, sphere, device
-        self.tRc = np.asarray(tRc, dtype=float) if tRc is not None and len(tRc) > 0 else None
-        self.tRg = np.asarray(tRg, dtype=float) if tRg is not None and len(tRg) > 0 else None
-        self.tLc = self.tLg = None
-        self.ntRc = 0 if self.tRc is None else len(self.tRc)
-        self.ntRg = 0 if self.tRg is None else len(self.tRg)
-        self.ntLc = self.ntLg = 0
-        self.nt = self.ntRc + self.ntRg
+    def __init__(self, mode=0, sphere=False, tRc=None, tRg=None, tLc=None, tLg=None, device=0,
+                 reference_periods=True):
+        if mode != 0:
+            raise NotImplementedError("fundamental mode only")
+        self.mode, self.sphere, self.device = mode, bool(sphere), device
+        self.reference_periods = reference_periods
+        for name, t in (("tRc", tRc), ("tRg", tRg), ("tLc", tLc), ("tLg", tLg)):
+            arr = np.asarray(t, dtype=float) if t is not None and len(t) > 0 else None
+            setattr(self, name, arr)
+            setattr(self, "n" + name, 0 if arr is None else len(arr))
+        self.nt = self.ntRc + self.ntRg + self.ntLc + self.ntLg
 
     @classmethod
     def init(cls, **kargs):
         """model_surf.py:31-38: keys tRc, tRg, tLc, tLg of param.yaml's swd block."""
         return cls(tRc=kargs["tRc"], tRg=kargs["tRg"], tLc=kargs.get("tLc"), tLg=kargs.get("tLg"))
 
-    def _periods(self):
-        return self.tRc, self.tRg
+    def _love_eval_periods(self, t, name):
+        if t is None or not self.reference_periods:
+            return t
+        if self.tRc is None:     # the reference hands None to the pybind11 binding here
+            raise TypeError(f"the reference evaluates its {name} block at tRc, which is not set "
+                            "(pass reference_periods=False to use the block's own periods)")
+        if len(t) != self.ntRc:  # d[k1:k2] = cg with len(cg) == len(tRc)
+            raise ValueError(f"could not broadcast input array from shape ({self.ntRc},) into shape ({len(t)},)")
+        return self.tRc
+
+    def _swd_config(self):
+        return (self.tRc, self.tRg, self._love_eval_periods(self.tLc, "Lc"),
+                self._love_eval_periods(self.tLg, "Lg"), self.sphere)
 
     def set_obsdata(self, dobs):
         self.dobs = dobs
@@ -37,7 +52,7 @@ class SurfWD(FusedPlugin):
 
     def forward(self, x):
         """(d[nt], flag) -- model_surf.py:81-133 (every block computed at tRc, as the reference does)."""
-        single, dsyn, flag = self._forward(x, quirk=True)
+        single, dsyn, flag = self._forward(x, quirk=self.reference_periods)
         return (dsyn[0], bool(flag[0])) if single else (dsyn, flag)
 
     def misfit(self, x):

@@ -74,4 +74,97 @@ double hs_sregn96(int n, const float* thk, const float* vp, const float* vs, con
     dcdh[n - 1] = 0.0;
     return T.ugr;
 }
+
+// Love / spherical-earth variants --------------------------------------------------------------
+// root search on the (optionally earth-flattened) float32 model; love: dltar1 instead of dltar4
+int hs_rootsearch_general(int n, const float* thk, const float* vp, const float* vs, const float* rho,
+                          int kmax, const double* t, double* cg, int love, int sphere)
+{
+    std::vector<float> w(4 * n);
+    const float *d = thk, *a = vp, *b = vs, *r = rho;
+    if (sphere) {
+        swd_flatten_f32(love != 0, n, thk, vp, vs, rho, 1, &w[0], &w[n], &w[2 * n], &w[3 * n], 1);
+        d = &w[0]; a = &w[n]; b = &w[2 * n]; r = &w[3 * n];
+    }
+    SwdModel M{d, a, b, r, 1, n};
+    RootSearch rs;
+    auto T = [&](int k) { return t[k]; };
+    auto out = [&](int k, double v) { cg[k] = v; };
+    rs.begin(M, T, kmax);
+    while (!rs.done) {
+        double wvno = rs.omega / rs.creq;
+        double del = love ? swd_secular_love(M, wvno, rs.omega) : swd_secular(M, wvno, rs.omega);
+        rs.advance(del, T, out);
+    }
+    return rs.flag;
+}
+
+}  // extern "C"
+
+template <class Mdl>
+static double rayleigh_flat_kernels(const Mdl& M, int n, double omega, double wvno, double* dcda, double* dcdb,
+                                    double* dcdh, double* dcdr)
+{
+    std::vector<double> cds(6 * n);
+    sr_up(M, omega, wvno, [&](int m, const double* cd, double exe) {
+        for (int i = 0; i < 5; i++) cds[6 * m + i] = cd[i];
+        cds[6 * m + 5] = exe;
+    });
+    SrTotals T = sr_down_energy(M, omega, wvno,
+        [&](int m, double* cd, double& exe) { for (int i = 0; i < 5; i++) cd[i] = cds[6 * m + i]; exe = cds[6 * m + 5]; },
+        [&](int m, double da, double db, double dr, double dh) { dcda[m] = da; dcdb[m] = db; dcdr[m] = dr; dcdh[m] = dh; });
+    double s = 1.0 / (T.ugr * T.sumi0);
+    for (int m = 0; m < n; m++) {
+        dcda[m] *= s; dcdb[m] *= s; dcdr[m] *= s;
+        double dfac = T.fac * dcdh[m];
+        dcdh[m] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;
+    }
+    return T.ugr;
+}
+
+template <class Mdl>
+static double love_flat_kernels(const Mdl& M, int n, double omega, double wvno, double* dcdb, double* dcdh, double* dcdr)
+{
+    std::vector<double> sc(3 * n);
+    sl_up(M, omega, wvno, [&](int m, double uu, double tt, double exl) { sc[3 * m] = uu; sc[3 * m + 1] = tt; sc[3 * m + 2] = exl; });
+    SlTotals T = sl_down_energy(M, omega, wvno,
+        [&](int m, double& uu, double& tt, double& exl) { uu = sc[3 * m]; tt = sc[3 * m + 1]; exl = sc[3 * m + 2]; },
+        [&](int m, double db, double dr, double dh) { dcdb[m] = db; dcdr[m] = dr; dcdh[m] = dh; });
+    for (int m = 0; m < n; m++) {
+        dcdb[m] /= T.sumi1; dcdr[m] /= T.sumi1;
+        double dfac = T.fac * dcdh[m];
+        dcdh[m] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;
+    }
+    return T.ugr;
+}
+
+extern "C" {
+// sregn96 / slegn96 with iflsph: kernels of the (possibly flattened) model mapped back to the sphere, thickness
+// kernels suffix-summed; *cp in = flat phase velocity, out = spherical; returns U (spherical)
+double hs_eigen_general(int n, const float* thk, const float* vp, const float* vs, const float* rho, double t,
+                        double* cp, double* dcda, double* dcdb, double* dcdh, double* dcdr, int love, int sphere)
+{
+    double omega = 2.0 * SR_PI32 / t, wvno = omega / *cp, u;
+    std::vector<double> z(7 * n);
+    for (int m = 0; m < n; m++) dcda[m] = 0.0;
+    if (sphere) {
+        swd_bldsph(love != 0, n, thk, vp, vs, rho, 1, &z[0], &z[n], &z[2 * n], &z[3 * n], &z[4 * n], &z[5 * n], &z[6 * n], 1);
+        SwdModelD M{&z[0], &z[n], &z[2 * n], &z[3 * n], 1, n};
+        u = love ? love_flat_kernels(M, n, omega, wvno, dcdb, dcdh, dcdr)
+                 : rayleigh_flat_kernels(M, n, omega, wvno, dcda, dcdb, dcdh, dcdr);
+        double tm = sr_tm(love != 0, *cp, omega), tm3 = tm * tm * tm;
+        for (int m = 0; m < n; m++) {
+            dcda[m] = dcda[m] * z[4 * n + m] / tm3; dcdb[m] = dcdb[m] * z[4 * n + m] / tm3;
+            dcdh[m] = dcdh[m] * z[5 * n + m] / tm3; dcdr[m] = dcdr[m] * z[6 * n + m] / tm3;
+        }
+        *cp = *cp / tm; u = u * tm;
+    } else {
+        SwdModel M{thk, vp, vs, rho, 1, n};
+        u = love ? love_flat_kernels(M, n, omega, wvno, dcdb, dcdh, dcdr)
+                 : rayleigh_flat_kernels(M, n, omega, wvno, dcda, dcdb, dcdh, dcdr);
+    }
+    for (int i = 0; i < n - 1; i++) { double sum = 0.0; for (int j = i + 1; j < n; j++) sum += dcdh[j]; dcdh[i] = sum; }
+    dcdh[n - 1] = 0.0;
+    return u;
+}
 }

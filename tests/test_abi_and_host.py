@@ -43,7 +43,9 @@ def test_no_cpu_fallback(hiplib):
     with pytest.raises(ValueError):
         libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Xx")       # bad wavetype
     with pytest.raises(NotImplementedError):
-        libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Lc")       # out of scope
+        libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Lc", mode=1)   # out of scope
+    with pytest.raises(hiplib.RfsError):                                                         # Love: device only
+        libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Lc", sphere=True)
 
 
 def test_product_never_imports_the_oracle():

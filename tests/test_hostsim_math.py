@@ -86,3 +86,47 @@ def test_fused_eigenfunction_sweep(hs, orc, golden):
             hs["swd"].hs_sregn96(n, *[F(x) for x in f], c(t[i]), c(g[f"{name}/Rc/c"][i]), *[P(x) for x in k])
             for got, key in zip(k, ("dcda", "dcdb", "dcdh", "dcdr")):
                 assert rel(got, g[f"{name}/Rc/{key}"][i]) < 1e-8, (name, i, key)
+
+
+def test_love_and_sphere_device_math(hs, golden):
+    """Host build of the Love / earth-flattening device math (swd_math.hpp: swd_secular_love, swd_flatten_f32,
+    swd_bldsph, sl_up, sl_down_energy, sr_tm) against the compiled reference's fixtures: flat roots from the
+    request/advance state machine, kernels at the reference's own roots."""
+    g = golden["swd_love_sphere_reference"]
+    from oracle import oracle as O
+    H = hs["swd"]
+    H.hs_eigen_general.restype = ctypes.c_double
+    nroot = nexact = 0
+    for name in sorted({k.split("/")[0] for k in g.files if k.endswith("/thk")}):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], np.ascontiguousarray(g[f"{name}/t"])
+        vp, rho, _, _ = O.empirical_relation(vs)
+        h, a, b, r = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)) for x in (thk, vp, vs, rho)]
+        n, nt = len(h), len(t)
+        for love, wt in ((0, "Rc"), (1, "Lc")):
+            for sph in (0, 1):
+                if not love and not sph:
+                    continue
+                key = f"{name}/{wt}/{sph}"
+                c = np.zeros(nt)
+                flag = H.hs_rootsearch_general(n, F(h), F(a), F(b), F(r), nt, P(t), P(c), love, sph)
+                assert bool(flag) == bool(g[f"{key}/flag"]), key
+                if not flag:
+                    continue
+                # adjoint_kernel's c is the spherical phase velocity c_flat / tm: convert the flat roots through the
+                # eigen entry below and compare there; count bit-exact matches of the converted value
+                for k in range(0, nt, 5):
+                    ka, kb, kh, kr = (np.zeros(n) for _ in range(4))
+                    cp = ctypes.c_double(c[k])
+                    H.hs_eigen_general(n, F(h), F(a), F(b), F(r), ctypes.c_double(t[k]), ctypes.byref(cp),
+                                       P(ka), P(kb), P(kh), P(kr), love, sph)
+                    nroot += 1
+                    nexact += int(cp.value == g[f"{key}/c"][k])
+                    assert abs(cp.value - g[f"{key}/c"][k]) <= 1.2e-6 * cp.value, key     # nevill's own tolerance
+                    if cp.value != g[f"{key}/c"][k]:
+                        continue                                                          # kernels at another root
+                    for arr, kk in ((ka, "dcda"), (kb, "dcdb"), (kr, "dcdr"), (kh, "dcdh")):
+                        if love and kk == "dcda":
+                            continue
+                        ref = g[f"{key}/{kk}"][k]
+                        assert np.abs(arr - ref).max() <= 2e-8 * np.abs(ref).max(), (key, kk, k)
+    assert nroot > 100 and nexact >= 0.97 * nroot

@@ -146,3 +146,58 @@ def test_plugin_oracle_matches_hybrid_fixtures(orc, golden, case):
                          (gr, "rf_grad"), (dr, "rf_d"), (mj, "joint_misfit"), (gj, "joint_grad"),
                          (dj, "joint_d")):
             assert rel(got, g[f"{case}/{i}/{key}"]) < 1e-8, (case, i, key)  # observed <= 1e-10
+
+
+WIDE = [(wt, sph) for wt in ("Rc", "Rg", "Lc", "Lg") for sph in (0, 1) if not (wt[0] == "R" and sph == 0)]
+
+
+def test_swd_oracle_love_and_sphere_match_reference_fixtures(orc, golden):
+    """All four libsurf wavetypes, flat and spherical earth (swd_love_sphere_reference.npz, produced by the
+    compiled reference): phase velocities bit-exact (float32-rounded roots; the sphere conversion is a few
+    flops), group velocities and kernels to rounding."""
+    g = golden["swd_love_sphere_reference"]
+    nfail = ncase = 0
+    for name in sorted({k.split("/")[0] for k in g.files if k.endswith("/thk")}):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], g[f"{name}/t"]
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        for wt, sph in WIDE:
+            key = f"{name}/{wt}/{sph}"
+            c, flag = orc.libsurf.forward(thk, vp, vs, rho, t, wt, 0, bool(sph))
+            assert flag == bool(g[f"{key}/fwd_flag"]), key
+            if flag:
+                if wt[1] == "c":
+                    assert rel(c, g[f"{key}/fwd_c"]) < 4e-16, key
+                else:
+                    assert rel(c, g[f"{key}/fwd_c"]) < 1e-10, key       # group velocities: f64 energy integrals
+            c, ka, kb, kr, kh, flag = orc.libsurf.adjoint_kernel(thk, vp, vs, rho, t, wt, 0, bool(sph))
+            assert flag == bool(g[f"{key}/flag"]), key
+            ncase += 1
+            if not flag:
+                nfail += 1
+                continue
+            assert rel(c, g[f"{key}/c"]) < 1e-9, key
+            for arr, kk in ((ka, "dcda"), (kb, "dcdb"), (kr, "dcdr"), (kh, "dcdh")):
+                if wt[0] == "L" and kk == "dcda":
+                    assert not np.any(arr)                               # defined as zero (reference: uninitialised)
+                    continue
+                assert rel(arr, g[f"{key}/{kk}"]) < 1e-8, (key, kk)      # observed <= 3e-9 (Rg, sphere)
+    assert ncase >= 60 and nfail >= 3
+
+
+def test_surfwd_plugin_with_love_blocks_and_sphere(orc, golden):
+    """SurfWD with all four blocks: forward() of the reference's own Python plugin on the reference libsurf, and
+    misfit_and_grad of the numpy restatement on the reference libsurf, against the oracle end to end."""
+    g = golden["swd_love_sphere_reference"]
+    for name in ("yaml7", "grad30"):
+        for sph in (0, 1):
+            key = f"plugin/{name}/{sph}"
+            t = g[f"{key}/t"]
+            m = orc.SurfWD(tRc=t, tRg=t, tLc=t, tLg=t, sphere=bool(sph))
+            d, flag = m.forward(g[f"{key}/x0"])
+            assert flag and rel(d, g[f"{key}/fwd_d"]) < 1e-10
+            m.set_obsdata(g[f"{key}/fwd_d"])
+            mf, grad, dsyn, flag = m.misfit_and_grad(g[f"{key}/x1"])
+            assert flag
+            assert rel(dsyn, g[f"{key}/dsyn"]) < 1e-9
+            assert abs(mf - float(g[f"{key}/misfit"])) <= 1e-8 * float(g[f"{key}/misfit"])
+            assert rel(grad, g[f"{key}/grad"]) < 1e-7
