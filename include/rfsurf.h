@@ -31,7 +31,7 @@ typedef enum {
     RFS_ERR_ARG = -1,         /* bad argument (also: unsupported enum value) */
     RFS_ERR_HIP = -2,         /* HIP runtime / rocFFT failure */
     RFS_ERR_STATE = -3,       /* call out of order (e.g. joint eval before joint setup) */
-    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (higher modes, time-domain RF) */
+    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (higher modes; time-domain RF longer than 4096 samples) */
 } rfs_status;
 
 /* wavetype codes of libsurf (src/SWD/main.cpp:17-24): strings "Rc","Rg","Lc","Lg" */
@@ -39,7 +39,10 @@ enum { RFS_WAVE_RC = 0, RFS_WAVE_RG = 1, RFS_WAVE_LC = 2, RFS_WAVE_LG = 3 };
 /* rf_type codes (src/RF/main.cpp:28-41): "P"/"p" -> 1, "S"/"s" -> 2 */
 enum { RFS_RF_P = 1, RFS_RF_S = 2 };
 /* method codes (src/RF/main.cpp:44,52): "time" -> 0, anything else -> 1 (frequency domain) */
-enum { RFS_RF_TIME = 0, RFS_RF_FREQ = 1 };
+/* method: "time" = iterative time-domain deconvolution (deconit.f90), "freq" = water-level spectral division.
+ * RFS_RF_TIME_PAR is "time" on the frequency axis of the single-parameter entry librf.kernel (cal_rf_par_time,
+ * RFModule.f90:27,47: float32 pi) -- kernel_all (cal_rf_par_time_all :96,112) uses the f64 pi. */
+enum { RFS_RF_TIME = 0, RFS_RF_FREQ = 1, RFS_RF_TIME_PAR = 2 };
 
 /* Receiver-function scalars: the arguments of librf.forward / kernel_all
  * (src/RF/main.cpp:17-22, 140-146) and the keys of param.yaml's `rf:` block. */
@@ -51,7 +54,7 @@ typedef struct {
     double time_shift;  /* s; negated internally for rf_type S (main.cpp:35) */
     double water;       /* water level */
     int32_t rf_type;    /* RFS_RF_P / RFS_RF_S */
-    int32_t method;     /* RFS_RF_FREQ only */
+    int32_t method;     /* RFS_RF_TIME / RFS_RF_FREQ (/ RFS_RF_TIME_PAR); water is unused by the time method */
 } rfs_rf_params;
 
 /* -------- lifetime ------------------------------------------------------------------ */

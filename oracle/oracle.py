@@ -133,8 +133,136 @@ def _rf_type(rf_type, time_shift):
     raise ValueError("rf_type should be one of [P,p,S,s]")
 
 
+# --------------------------------------------------------------------------
+# Time-domain receiver functions: iterative spike deconvolution (src/RF/deconit.f90) and its callers
+# cal_rf_time / cal_rf_par_time(_all) (RFModule.f90:11-191).
+# PARITY UNPINNED for this part: the reference computes every FFT through FFTW3 (src/RF/fftpack.f90), which
+# this image lacks, so neither the reference's librf nor its deconit can be built here; what follows is a
+# statement-by-statement numpy restatement (numpy.fft in place of the FFTW wrappers).  The per-frequency
+# R21 / R22 / partials that feed it ARE pinned (compiled reference core, RefRFCore).
+# --------------------------------------------------------------------------
+PI32 = float(np.float32(np.arctan(np.float32(1.0))) * np.float32(4.0))     # atan(1.0) * 4. in default real
+
+
+def _rfft(x, n):            # fftpack.f90:1-21
+    return np.fft.rfft(x, n)
+
+
+def _irfft(X, n):           # fftpack.f90:23-42 (c2r, then / n)
+    return np.fft.irfft(X, n)
+
+
+def gauss_filter(nt, dt, f0):
+    """deconit.f90:15-32."""
+    freq = np.arange(nt // 2 + 1) / (nt * dt)
+    return np.exp(-0.25 * (2 * PI32 * freq / f0) ** 2)
+
+
+def apply_gaussian(x, dt, f0):
+    """deconit.f90:34-52."""
+    n = len(x)
+    return _irfft(_rfft(x, n) * gauss_filter(n, dt, f0), n)
+
+
+def shift_data(x, dt, tshift):
+    """deconit.f90:54-72."""
+    n = len(x)
+    i = np.arange(n // 2 + 1)
+    return _irfft(_rfft(x, n) * np.exp(-1j * i / (n * dt) * PI32 * 2 * tshift), n)
+
+
+def deconit(u, w, dt, tshift, f0, return_spikes=False):
+    """deconit.f90:135-197: Ligorria & Ammon iterative time-domain deconvolution, at most 200 spikes."""
+    nt = len(u)
+    nft = 1
+    while nft < nt:
+        nft *= 2
+    uflt = np.zeros(nft); wflt = np.zeros(nft)
+    wflt[:nt] = w; uflt[:nt] = u
+    wcopy = wflt.copy()
+    uflt = apply_gaussian(uflt, dt, f0)
+    wflt = apply_gaussian(wflt, dt, f0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invpw = 1. / np.sum(wflt ** 2) / dt
+        invpu = 1. / np.sum(uflt ** 2) / dt
+    p = np.zeros(nft)
+    sumsq_i = 1.0
+    minderr = 0.001
+    d_error = 100 * invpw + minderr
+    rflt = uflt.copy()
+    wf = _rfft(wflt, nft); wc = _rfft(wcopy, nft)
+    spikes = []
+    for _ in range(200):
+        if abs(d_error) <= minderr:
+            break
+        cuw = _irfft(_rfft(rflt, nft) * np.conj(wf), nft) * dt            # mycorrelate
+        idx = int(np.argmax(np.abs(cuw[:nft // 2])))                      # maxloc: first maximum
+        p[idx] = p[idx] + cuw[idx] * invpw / dt
+        spikes.append(idx)
+        temp1 = apply_gaussian(p.copy(), dt, f0)
+        temp2 = _irfft(_rfft(temp1, nft) * wc, nft)                       # myconvolve
+        rflt = uflt - temp2 * dt
+        with np.errstate(invalid="ignore"):
+            sumsq = np.sum(rflt ** 2) * dt * invpu
+        d_error = 100. * (sumsq_i - sumsq)
+        sumsq_i = sumsq
+    out = shift_data(apply_gaussian(p, dt, f0), dt, tshift)[:nt]
+    return (out, spikes) if return_spikes else out
+
+
+def rf_time_from_spectra(R21, R22, nft, nt, dt, f0, tshift):
+    """tail of cal_rf_time, RFModule.f90:180-186."""
+    ux = _irfft(R22, nft); uz = _irfft(R21, nft)
+    return deconit(ux, uz, dt, tshift, f0)[:nt]
+
+
+def rf_par_time_from_spectra(R21, R22, R21m, R22m, nft, nt, dt, f0, tshift):
+    """tail of cal_rf_par_time_all, RFModule.f90:120-137.  R21m/R22m: [n2, 4, nlayer]."""
+    rf = rf_time_from_spectra(R21, R22, nft, nt, dt, f0, tshift)
+    uz = _irfft(R21 ** 2, nft)
+    n = R21m.shape[2]
+    kl = np.zeros((4, n, nt))
+    for ip in range(4):
+        for j in range(n):
+            num = R22m[:, ip, j] * R21 - R21m[:, ip, j] * R22
+            kl[ip, j] = deconit(_irfft(num, nft), uz, dt, tshift, f0)[:nt]
+    return rf, kl
+
+
+def _time_axis(nft, dt, n2, which):
+    """omega(it): cal_rf_time :173 and cal_rf_par_time :47 use atan(1.0)*4.0 (float32 pi),
+    cal_rf_par_time_all :112 uses atan(1.0_dp)*4.0_dp."""
+    it = np.arange(n2)
+    if which == "forward":
+        return (1.0 / dt / nft) * it * 2 * PI32
+    if which == "kernel":
+        return 1.0 / nft / dt * it * 2.0 * PI32
+    return 1.0 / nft / dt * it * 2.0 * (np.arctan(1.0) * 4.0)
+
+
 class _LibRF:
-    """Restatement of librf (src/RF/main.cpp:17-212), frequency-domain method only."""
+    """Restatement of librf (src/RF/main.cpp:17-212): frequency-domain method in C (rf_oracle.c); time-domain
+    method = C restatement of the propagator stack + the numpy restatement of deconit above."""
+
+    def _spectra_time(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf, which, partials):
+        n = len(thk)
+        nft = lib().orc_nextpow2(int(nt))
+        n2 = nft // 2 + 1
+        al = np.ascontiguousarray(vp * (1.0 + 1j / (2.0 * qa) + 1.0 / (8.0 * qa**2)))
+        be = np.ascontiguousarray(vs * (1.0 + 1j / (2.0 * qb) + 1.0 / (8.0 * qb**2)))
+        w = _time_axis(nft, dt, n2, which)
+        R21 = np.zeros(n2, complex); R22 = np.zeros(n2, complex)
+        R21m = np.zeros((n2, 4, n), complex); R22m = np.zeros((n2, 4, n), complex)
+        c = ctypes.c_double
+        for it in range(n2):
+            if partials:
+                lib().orcprobe_rf_response_par_all(c(w[it]), c(0.0), c(ray_p), n, _d(thk), _d(al), _d(be), _d(vp),
+                                                   _d(vs), _d(rho), irf, _d(R21[it:]), _d(R22[it:]), _d(R21m[it]),
+                                                   _d(R22m[it]))
+            else:
+                lib().orcprobe_rf_response(c(w[it]), c(0.0), c(ray_p), n, _d(thk), _d(al), _d(be), _d(rho), irf,
+                                           _d(R21[it:]), _d(R22[it:]))
+        return nft, R21, R22, R21m, R22m
 
     @staticmethod
     def _prep(*arrs):
@@ -142,10 +270,11 @@ class _LibRF:
 
     def forward(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
                 method="time", water=0.001, rf_type="P"):
-        if method == "time":
-            raise NotImplementedError("oracle covers the frequency-domain method only")
         irf, t0 = _rf_type(rf_type, time_shift)
         thk, rho, vp, vs, qa, qb = self._prep(thk, rho, vp, vs, qa, qb)
+        if method == "time":
+            nft, R21, R22, _, _ = self._spectra_time(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf, "forward", False)
+            return rf_time_from_spectra(R21, R22, nft, int(nt), dt, gauss, t0)
         rf = np.zeros(nt)
         c = ctypes.c_double
         lib().orc_rf_freq(_d(thk), _d(vp), _d(vs), _d(rho), _d(qa), _d(qb), len(thk), int(nt),
@@ -154,10 +283,12 @@ class _LibRF:
 
     def kernel_all(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
                    method="time", water=0.001, rf_type="P"):
-        if method == "time":
-            raise NotImplementedError("oracle covers the frequency-domain method only")
         irf, t0 = _rf_type(rf_type, time_shift)
         thk, rho, vp, vs, qa, qb = self._prep(thk, rho, vp, vs, qa, qb)
+        if method == "time":
+            nft, R21, R22, R21m, R22m = self._spectra_time(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf,
+                                                           getattr(self, "_axis", "kernel_all"), True)
+            return rf_par_time_from_spectra(R21, R22, R21m, R22m, nft, int(nt), dt, gauss, t0)
         n = len(thk)
         rf = np.zeros(nt)
         kl = np.zeros((4, n, nt))
@@ -169,8 +300,12 @@ class _LibRF:
     def kernel(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
                method="time", water=0.001, rf_type="P", par_type="vs"):
         idx = {"rho": 0, "vp": 1, "alpha": 1, "vs": 2, "beta": 2, "h": 3, "thick": 3}[par_type]
-        rf, kl = self.kernel_all(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
-                                 method, water, rf_type)
+        self._axis = "kernel"          # cal_rf_par_time's frequency axis uses the float32 pi (RFModule.f90:27,47)
+        try:
+            rf, kl = self.kernel_all(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
+                                     method, water, rf_type)
+        finally:
+            self._axis = "kernel_all"
         return rf, kl[idx].copy()
 
 
@@ -351,6 +486,30 @@ class RefRFCore:
     def _atten(v, q):
         return np.ascontiguousarray(v * (1.0 + 1j / (2.0 * q) + 1.0 / (8.0 * q**2)))
 
+    def spectra_time(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, rf_type, which, partials):
+        """R21, R22 (and partials) on the real frequency axis of the time-domain method, from the compiled
+        reference propagator core."""
+        thk, rho, vp, vs, qa, qb = (np.ascontiguousarray(np.asarray(a, dtype=float))
+                                    for a in (thk, rho, vp, vs, qa, qb))
+        n = len(thk)
+        nft = self.L.refprobe_nextpow2(int(nt))
+        n2 = nft // 2 + 1
+        al, be = self._atten(vp, qa), self._atten(vs, qb)
+        w = _time_axis(nft, dt, n2, which)
+        R21 = np.zeros(n2, complex); R22 = np.zeros(n2, complex)
+        R21m = np.zeros((n2, 4, n), complex); R22m = np.zeros((n2, 4, n), complex)
+        c = ctypes.c_double
+        for it in range(n2):
+            if partials:
+                self.L.refprobe_rf_response_par_all(
+                    c(w[it]), c(0.0), c(ray_p), n, _d(thk), _d(al), _d(be), _d(vp), _d(vs),
+                    _d(rho), rf_type, _d(R21[it:]), _d(R22[it:]), _d(R21m[it]), _d(R22m[it]))
+            else:
+                self.L.refprobe_rf_response(
+                    c(w[it]), c(0.0), c(ray_p), n, _d(thk), _d(al), _d(be), _d(rho), rf_type,
+                    _d(R21[it:]), _d(R22[it:]))
+        return nft, R21, R22, R21m, R22m
+
     def spectra(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, rf_type=1, partials=True):
         thk, rho, vp, vs, qa, qb = (np.ascontiguousarray(np.asarray(a, dtype=float))
                                     for a in (thk, rho, vp, vs, qa, qb))
@@ -385,6 +544,9 @@ class RefRFCore:
     def kernel_all(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
                    method="freq", water=0.001, rf_type="P"):
         irf, t0 = _rf_type(rf_type, time_shift)
+        if method == "time":
+            nft, R21, R22, R21m, R22m = self.spectra_time(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf, "kernel_all", True)
+            return rf_par_time_from_spectra(R21, R22, R21m, R22m, nft, int(nt), dt, gauss, t0)
         w, sigma, nft, R21, R22, R21m, R22m = self.spectra(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf)
         g = np.exp(-(w / 2 / gauss) ** 2) * np.exp(-1j * w * t0)
         wa = (R21 * np.conj(R21)).real
@@ -400,6 +562,9 @@ class RefRFCore:
     def forward(self, thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift,
                 method="freq", water=0.001, rf_type="P"):
         irf, t0 = _rf_type(rf_type, time_shift)
+        if method == "time":
+            nft, R21, R22, _, _ = self.spectra_time(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf, "forward", False)
+            return rf_time_from_spectra(R21, R22, nft, int(nt), dt, gauss, t0)
         w, sigma, nft, R21, R22, _, _ = self.spectra(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, irf,
                                                      partials=False)
         g = np.exp(-(w / 2 / gauss) ** 2) * np.exp(-1j * w * t0)

@@ -225,6 +225,12 @@ RFS_HD void rf_half_partials(const RfLayer& L, cplx omega, int rf_type, const V4
     double sa = (ta.re > 0.0 || (ta.re == 0.0 && ta.im >= 0.0)) ? 1.0 : -1.0;
     double sb = (tb.re > 0.0 || (tb.re == 0.0 && tb.im >= 0.0)) ? 1.0 : -1.0;
     cplx koa = sa * L.iva, kob = sb * L.ivb;          // k / v_alpha, k / v_beta
+    if (omega.re == 0.0 && omega.im == 0.0) {
+        // DC of the time-domain method: the reference forms gamma = 2 k^2 beta^2 / omega^2 = 0/0 (RFModule.f90:941),
+        // every half-space partial becomes NaN and is zeroed (:698-703); the callers' NaN scrub does the same
+        T[0] = T[1] = T[2] = C(__builtin_nan(""), __builtin_nan("")); T[3] = C(0.0);
+        return;
+    }
     cplx g = L.gam, g1 = L.gam1, g3 = L.gam3;
     cplx frho = (g * (0.5 * L.imu2)) / L.rho;         // gamma / (4 rho mu)
     cplx fb = g * L.ib;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -12,6 +13,7 @@
 
 #include "../../include/rfsurf.h"
 #include "rfsurf_kernels.hpp"
+#include "rf_time_kernels.hpp"
 
 using namespace rfs;
 
@@ -48,6 +50,8 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
+    double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL;   // per-family search models / bldsph arrays (sphere, Love)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
@@ -166,7 +170,9 @@ int make_partition_streams(rfs_ctx* c) {
 
 int check_rf(rfs_ctx* c, const rfs_rf_params* p) {
     if (!p) return fail(c, RFS_ERR_ARG, "rf params missing");
-    if (p->method == RFS_RF_TIME) return fail(c, RFS_ERR_UNSUPPORTED, "time-domain RF (iterative deconvolution) is out of scope");
+    if (p->method != RFS_RF_TIME && p->method != RFS_RF_FREQ && p->method != RFS_RF_TIME_PAR) return fail(c, RFS_ERR_ARG, "bad rf method");
+    if (p->method != RFS_RF_FREQ && rf_nextpow2(p->nt) > 4096)
+        return fail(c, RFS_ERR_UNSUPPORTED, "time-domain RF: at most 4096 samples");
     if (p->rf_type != RFS_RF_P && p->rf_type != RFS_RF_S) return fail(c, RFS_ERR_ARG, "rf_type should be one of [P,p,S,s]");
     if (p->nt < 2 || p->dt <= 0 || p->ray_p <= 0) return fail(c, RFS_ERR_ARG, "bad rf scalars");
     return RFS_OK;
@@ -180,6 +186,11 @@ RfFreq make_freq(const rfs_rf_params& p, int fwd_order) {
     f.t0 = (p.rf_type == RFS_RF_S) ? -p.time_shift : p.time_shift;     // src/RF/main.cpp:35
     f.sigma = 1.0 / p.dt / f.nft * 4.;                                  // RFModule.f90:381
     f.fwd_order = fwd_order;
+    f.method = p.method; f.pi64 = 0;
+    if (p.method != RFS_RF_FREQ) {       // real frequency axis (cal_rf_time :173, cal_rf_par_time_all :112)
+        f.sigma = 0.0;
+        f.pi64 = (!fwd_order && p.method == RFS_RF_TIME) ? 1 : 0;
+    }
     return f;
 }
 
@@ -240,6 +251,102 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f) {
                        c->lc.as<RfLayer>(), c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(),
                        c->wmax2.as<double>(), npart, c->PG.as<double>());
     HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+// ------------------------------------------------------------------ time-domain RF (rf_time_kernels.hpp)
+int rft_pulse(rfs_ctx* c, const RfFreq& f) {     // gauss + shift pulse of deconit's tail, cached per (nft, dt, f0, t0)
+    double key[4] = {(double)f.nft, f.dt, f.f0, f.t0};
+    if (c->pulse_ts.p && std::memcmp(key, c->pulse_key, sizeof(key)) == 0) return RFS_OK;
+    ENSURE(c, c->pulse_spec, (size_t)f.n2 * sizeof(cplx));
+    ENSURE(c, c->pulse_ts, (size_t)f.nft * sizeof(double));
+    hipLaunchKernelGGL(k_rft_pulse_spec, dim3((f.n2 + 255) / 256), dim3(256), 0, c->stream, f, c->pulse_spec.as<cplx>());
+    HIPCHK(c, hipGetLastError());
+    TRY(run_fft(c, f.nft, 1, 1, c->pulse_spec.p, c->pulse_ts.p));
+    std::memcpy(c->pulse_key, key, sizeof(key));
+    return RFS_OK;
+}
+
+template <int WPB>
+int rft_launch_deconv(rfs_ctx* c, int ntrace, int tpc, const RfFreq& f, const double* cuw0, size_t cuw_stride,
+                      const double* aw, size_t aw_stride, const double* S0, int nS0, size_t s0c, size_t s0p,
+                      const double* Cres, double* Pout, double* gout) {
+    int npl = f.nft / 128; if (npl < 1) npl = 1;
+    dim3 grid((ntrace + WPB - 1) / WPB), block(64 * WPB);
+    size_t lds = (size_t)f.nft * sizeof(double);
+#define RFS_DECONV(NPL)                                                                                          \
+    hipLaunchKernelGGL((k_rft_deconv<NPL, WPB>), grid, block, lds, c->stream, ntrace, tpc, f, cuw0, cuw_stride,  \
+                       aw, aw_stride, S0, nS0, s0c, s0p, Cres, Pout, gout, (int*)nullptr)
+    switch (npl) {
+        case 1: RFS_DECONV(1); break;
+        case 2: RFS_DECONV(2); break;
+        case 4: RFS_DECONV(4); break;
+        case 8: RFS_DECONV(8); break;
+        case 16: RFS_DECONV(16); break;
+        default: RFS_DECONV(32); break;
+    }
+#undef RFS_DECONV
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+// after pass A: chain-level spectra + their inverse transforms, forward-trace deconvolution, rf(t) -> out
+int rft_forward(rfs_ctx* c, int nchain, const RfFreq& f, double* out, size_t ostride) {
+    const size_t nft = f.nft, half = nft / 2;
+    ENSURE(c, c->spec3, (size_t)nchain * 3 * f.n2 * sizeof(cplx));
+    ENSURE(c, c->ts3, (size_t)nchain * 3 * nft * sizeof(double));
+    ENSURE(c, c->S0f, (size_t)nchain * sizeof(double));
+    ENSURE(c, c->Pbuf, (size_t)nchain * half * sizeof(double));
+    TRY(rft_pulse(c, f));
+    hipLaunchKernelGGL(k_rft_chain_spectra, dim3(nchain), dim3(256), 0, c->stream, f, c->RR.as<double>(),
+                       c->spec3.as<cplx>(), c->S0f.as<double>());
+    HIPCHK(c, hipGetLastError());
+    TRY(run_fft(c, f.nft, (size_t)nchain * 3, 1, c->spec3.p, c->ts3.p));
+    TRY(rft_launch_deconv<1>(c, nchain, 1, f, c->ts3.as<double>() + nft, 3 * nft, c->ts3.as<double>(), 3 * nft,
+                             c->S0f.as<double>(), 1, 1, 0, nullptr, c->Pbuf.as<double>(), nullptr));
+    size_t lds = (nft + half + half / 2 + 1) * sizeof(double);
+    hipLaunchKernelGGL(k_rft_synth, dim3(nchain), dim3(256), lds, c->stream, nchain, f, c->Pbuf.as<double>(),
+                       c->pulse_ts.as<double>(), out, ostride);
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+// the 4n partial traces of every chain (after rft_forward): either their spike trains -> kl[chain][4][n][nt]
+// (B1 kernel_all) or, with Cres given, directly sum_t k(t) r(t) -> PG[chain][4][n] (B2 gradient).  Chains are
+// processed in chunks so that spectra + time series stay below ~6 GB.
+int rft_partials(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* Cres, double* PG, double* kl) {
+    const size_t nft = f.nft, half = nft / 2, ntr = (size_t)4 * n;
+    const int npart = rf_nparts(f);
+    size_t per_chain = ntr * (f.n2 * sizeof(cplx) + nft * sizeof(double));
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nchain, (size_t)6e9 / per_chain));
+    ENSURE(c, c->specp, (size_t)chunk * ntr * f.n2 * sizeof(cplx));
+    ENSURE(c, c->tserp, (size_t)chunk * ntr * nft * sizeof(double));
+    ENSURE(c, c->S0p, (size_t)chunk * npart * ntr * sizeof(double));
+    if (kl) ENSURE(c, c->Pbuf, std::max((size_t)nchain * half, (size_t)chunk * ntr * half) * sizeof(double));
+    for (int c0 = 0; c0 < nchain; c0 += chunk) {
+        int nc = std::min(chunk, nchain - c0);
+        dim3 grid(rf_chunks(f), nc);
+        hipLaunchKernelGGL(k_rft_partial_spectra<false>, grid, dim3(rf_block(f)), 0, c->stream, nc, n, f,
+                           c->lc.as<RfLayer>() + (size_t)c0 * n, c->RR.as<double>() + (size_t)c0 * 4 * f.n2p,
+                           c->Rs.as<double>() + (size_t)c0 * (n - 1) * 8 * f.n2p, npart, c->specp.as<cplx>(),
+                           c->S0p.as<double>());
+        hipLaunchKernelGGL(k_rft_partial_spectra<true>, dim3((nc + 63) / 64), dim3(64), 0, c->stream, nc, n, f,
+                           c->lc.as<RfLayer>() + (size_t)c0 * n, c->RR.as<double>() + (size_t)c0 * 4 * f.n2p,
+                           c->Rs.as<double>() + (size_t)c0 * (n - 1) * 8 * f.n2p, npart, c->specp.as<cplx>(),
+                           c->S0p.as<double>());
+        HIPCHK(c, hipGetLastError());
+        TRY(run_fft(c, f.nft, (size_t)nc * ntr, 1, c->specp.p, c->tserp.p));
+        TRY(rft_launch_deconv<4>(c, (int)(nc * ntr), (int)ntr, f, c->tserp.as<double>(), nft,
+                                 c->ts3.as<double>() + (size_t)c0 * 3 * nft + 2 * nft, 3 * nft, c->S0p.as<double>(),
+                                 npart, (size_t)npart * ntr, ntr, Cres ? Cres + (size_t)c0 * half : nullptr,
+                                 kl ? c->Pbuf.as<double>() : nullptr, PG ? PG + (size_t)c0 * ntr : nullptr));
+        if (kl) {
+            size_t lds = (nft + half + half / 2 + 1) * sizeof(double);
+            hipLaunchKernelGGL(k_rft_synth, dim3((unsigned)(nc * ntr)), dim3(256), lds, c->stream, (int)(nc * ntr), f,
+                               c->Pbuf.as<double>(), c->pulse_ts.as<double>(), kl + (size_t)c0 * ntr * f.nt, (size_t)f.nt);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
     return RFS_OK;
 }
 
@@ -434,7 +541,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     const double rf_half = c->has_rf ? (nchain / 8192.0) * ((c->f.n2 - 1) / 256.0) : 0.0;
     // (not on the context's own stream: there the extra masked streams were measured to share a hardware
     // queue with it and serialise -- the host-pointer entries keep the shared-CU schedule)
-    const bool part = !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
+    const bool rf_time = c->has_rf && c->f.method != RFS_RF_FREQ;
+    const bool part = !rf_time && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
                       c->swd_lanes == 0 && Q.nseq * nchain >= 1024 && nblk <= c->ncu / 2 &&
                       rf_half <= 1.1 * (npmax / 40.0);
     if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
@@ -450,9 +558,29 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (part) { HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); c->stream = c->stream3; }
         int rc = RFS_OK;
         { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nchain, n, c->f, true); }
+        if (rf_time) {
+            // model_rf.py:162-196 with method "time": rf and kernels from cal_rf_par_time_all; the gradient
+            // K.r is accumulated spike by spike (rf_time_kernels.hpp), no kernel trace is materialised
+            double* ds = dsyn;
+            if (!ds) { rc = rc ? rc : ensure(c, c->dsyn, (size_t)nchain * c->ndata * sizeof(double)); ds = c->dsyn.as<double>(); }
+            if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
+                rc = rft_forward(c, nchain, c->f, ds, (size_t)c->ndata);
+                if (!rc) rc = ensure(c, c->mrf, (size_t)nchain * sizeof(double));
+                if (!rc) rc = ensure(c, c->Cres, (size_t)nchain * (c->f.nft / 2) * sizeof(double));
+                if (!rc) {
+                    size_t lds = ((size_t)c->f.nft + c->f.nt) * sizeof(double);
+                    hipLaunchKernelGGL(k_rft_resid_cres, dim3(nchain), dim3(256), lds, c->stream, c->f, ds, c->ndata,
+                                       c->d_dobs.as<double>(), c->pulse_ts.as<double>(), c->mrf.as<double>(),
+                                       c->Cres.as<double>());
+                } }
+            if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream);
+                rc = ensure(c, c->PG, (size_t)nchain * 4 * n * sizeof(double));
+                if (!rc) rc = rft_partials(c, nchain, n, c->f, c->Cres.as<double>(), c->PG.as<double>(), nullptr); }
+        } else {
         if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
           rc = launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true); }
         if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nchain, n, c->f); }
+        }
         c->stream = user;
         if (rc) return rc;
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
@@ -465,7 +593,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         int nt = c->has_rf ? c->f.nt : 0;
         if (c->has_rf)
             hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
-                               (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
+                               (int)!c->has_swd, rf_time ? 1 : rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
                                c->cr.as<double>(), misfit, grad, flag);
         if (c->has_swd) {
 #define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
@@ -512,6 +640,7 @@ void rfs_destroy(rfs_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     Buf* bufs[] = {&c->d_tw[0], &c->d_tw[1], &c->d_tw[2], &c->d_tw[3], &c->mdlSR, &c->mdlL, &c->sphR, &c->sphL, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
+                   &c->spec3, &c->ts3, &c->S0f, &c->S0p, &c->pulse_spec, &c->pulse_ts, &c->Pbuf, &c->Cres,
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
                    &c->croot, &c->sflag, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
@@ -686,6 +815,13 @@ static int rf_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const do
                        c->b1f.as<double>(), f.p, c->lc.as<RfLayer>());
     TRY(launch_passA(c, nchain, n, f, kl != nullptr));
     ENSURE(c, c->b1g, (size_t)nchain * f.nt * sizeof(double));
+    if (f.method != RFS_RF_FREQ) {       // time domain: iterative deconvolution
+        TRY(rft_forward(c, nchain, f, c->b1g.as<double>(), (size_t)f.nt));
+        if (kl) {
+            ENSURE(c, c->klbuf, (size_t)nchain * 4 * n * f.nt * sizeof(double));
+            TRY(rft_partials(c, nchain, n, f, nullptr, nullptr, c->klbuf.as<double>()));
+        }
+    } else {
     TRY(launch_mid(c, nchain, n, f, nullptr, f.nt, c->b1g.as<double>(), false));
     if (kl) {
         size_t ntr = (size_t)nchain * 4 * n;
@@ -705,6 +841,7 @@ static int rf_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const do
         hipLaunchKernelGGL(k_rf_scale_kl, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, ntr, f,
                            c->tserp.as<double>(), c->klbuf.as<double>());
         HIPCHK(c, hipGetLastError());
+    }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(rf, c->b1g.p, (size_t)nchain * f.nt * sizeof(double), hipMemcpyDeviceToHost));
@@ -824,9 +961,10 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
                        c->mdlc.as<double>());
     int nt = c->has_rf ? c->f.nt : 0;
     if (c->has_rf) {
-        RfFreq f = c->f; f.fwd_order = 1;
+        RfFreq f = c->f; f.fwd_order = 1; f.pi64 = 0;      // cal_rf_freq / cal_rf_time frequency axis
         TRY(launch_passA(c, nchain, n, f, false));
-        TRY(launch_mid(c, nchain, n, f, nullptr, c->ndata, c->dsyn.as<double>(), false));
+        if (f.method != RFS_RF_FREQ) TRY(rft_forward(c, nchain, f, c->dsyn.as<double>(), (size_t)c->ndata));
+        else TRY(launch_mid(c, nchain, n, f, nullptr, c->ndata, c->dsyn.as<double>(), false));
     }
     if (c->has_swd) {
         // model_surf.py:104-131 computes every block at tRc; quirk != 0 keeps that (the reference then needs

@@ -28,12 +28,15 @@ constexpr int MAXL = 128;   // layers per model (two register slots in the pass-
 struct RfFreq {             // frequency axis + RF scalars shared by the RF kernels
     double dt, sigma, p, f0, t0, water;
     int nft, n2, n2p, nt, rf_type, fwd_order;
+    int method, pi64;       // method: RFS_RF_* ; pi64: f64 pi on the frequency axis (cal_rf_par_time_all only)
 };
 
 __device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
-    // RFModule.f90:384  w = 1/nft/dt*(it-1)*2*pi   (cal_rf_freq :231 uses 1/dt/nft order)
-    if (f.fwd_order) return (1.0 / f.dt / f.nft) * k * 2 * RF_PI32;
-    return 1.0 / f.nft / f.dt * k * 2.0 * RF_PI32;
+    // RFModule.f90:384  w = 1/nft/dt*(it-1)*2*pi   (cal_rf_freq :231 and cal_rf_time :173 use 1/dt/nft order);
+    // pi = atan(1.0)*4.0 in default real everywhere except cal_rf_par_time_all (:96 atan(1.0_dp)*4.0_dp)
+    const double pi = f.pi64 ? 3.14159265358979323846 : RF_PI32;
+    if (f.fwd_order) return (1.0 / f.dt / f.nft) * k * 2 * pi;
+    return 1.0 / f.nft / f.dt * k * 2.0 * pi;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

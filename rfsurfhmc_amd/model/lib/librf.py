@@ -3,23 +3,26 @@
 qa, qb, ray_p, nt, dt, gauss, time_shift, method, water, rf_type[, par_type]), executed by the
 HIP library.  2-D model arrays [nchain, nlayer] are accepted (outputs gain a chain axis).
 
+Both methods: "time" (iterative time-domain deconvolution, the reference's default) and anything else =
+"freq" (water-level spectral division), as src/RF/main.cpp:43,115,168 dispatch.
+
 Deliberate differences: bad rf_type / par_type raise ValueError instead of exit(-1)
-(main.cpp:40,101,162); method="time" (iterative deconvolution) raises NotImplementedError."""
+(main.cpp:40,101,162); time-domain traces longer than 4096 samples raise RfsError."""
 import numpy as np
 
 from ..._lib import RfParams, default_context, hptr
 
 
-def _params(ray_p, nt, dt, gauss, time_shift, method, water, rf_type):
+def _params(ray_p, nt, dt, gauss, time_shift, method, water, rf_type, single_par=False):
     if rf_type in ("P", "p"):
         irf = 1
     elif rf_type in ("S", "s"):
         irf = 2
     else:
         raise ValueError("rf_type should be one of [P,p,S,s]")
-    if method == "time":
-        raise NotImplementedError("time-domain RF (iterative deconvolution) is out of scope; use method='freq'")
-    return RfParams(float(ray_p), int(nt), float(dt), float(gauss), float(time_shift), float(water), irf, 1)
+    # RFS_RF_TIME = 0, RFS_RF_FREQ = 1, RFS_RF_TIME_PAR = 2 (frequency axis of cal_rf_par_time, RFModule.f90:27,47)
+    imeth = (2 if single_par else 0) if method == "time" else 1
+    return RfParams(float(ray_p), int(nt), float(dt), float(gauss), float(time_shift), float(water), irf, imeth)
 
 
 def _prep(*arrs):
@@ -42,9 +45,9 @@ def forward(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift, method="
 
 
 def kernel_all(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift, method="time", water=0.001,
-               rf_type="P", device=0):
+               rf_type="P", device=0, _single_par=False):
     """(rf[nt], k[4, nlayer, nt]), parameter axis [rho, vp, vs, thk] -- src/RF/main.cpp:140-189."""
-    par = _params(ray_p, nt, dt, gauss, time_shift, method, water, rf_type)
+    par = _params(ray_p, nt, dt, gauss, time_shift, method, water, rf_type, _single_par)
     (h, r, a, b, qa_, qb_), single = _prep(thk, rho, vp, vs, qa, qb)
     nchain, n = h.shape
     ctx = default_context(device)
@@ -63,5 +66,6 @@ def kernel(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift, method="t
     """(rf[nt], k[nlayer, nt]) for one parameter class -- src/RF/main.cpp:64-136."""
     if par_type not in _PAR:
         raise ValueError("par_type should be one of [vp,vs,rho,thick]")
-    rf, kl = kernel_all(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift, method, water, rf_type, device)
+    rf, kl = kernel_all(thk, rho, vp, vs, qa, qb, ray_p, nt, dt, gauss, time_shift, method, water, rf_type, device,
+                        _single_par=True)
     return rf, np.ascontiguousarray(kl[..., _PAR[par_type], :, :])

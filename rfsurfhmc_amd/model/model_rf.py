@@ -19,8 +19,6 @@ class ReceiverFunc(FusedPlugin):
                    kargs["water_level"], kargs["type"], kargs["method"])
 
     def _rf_params(self):
-        if self.method == "time":
-            raise NotImplementedError("time-domain RF (iterative deconvolution) is out of scope; use method: freq")
         if self.rf_type in ("P", "p"):
             irf = 1
         elif self.rf_type in ("S", "s"):
@@ -28,7 +26,8 @@ class ReceiverFunc(FusedPlugin):
         else:
             raise ValueError("rf_type should be one of [P,p,S,s]")
         return RfParams(float(self.ray_p), int(self.nt), float(self.dt), float(self.gauss),
-                        float(self.time_shift), float(self.water_level), irf, 1)
+                        float(self.time_shift), float(self.water_level), irf,
+                        0 if self.method == "time" else 1)      # src/RF/main.cpp:43,115: anything but "time" is "freq"
 
     def set_obsdata(self, dobs):
         self.dobs = dobs
