@@ -179,6 +179,26 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
 // Lane l owns lags j = i*64 + l.  Outputs (each optional): Pout[trace][nft/2] spike train, gout[trace] =
 // sum_spikes a * Cres[chain][lag], nit_out[trace] = iterations used.
 // ---------------------------------------------------------------------------------------
+// wave-wide max of a non-negative f64 on the VALU (DPP moves of the two halves; no LDS crossbar traffic, which
+// is what bounds a shuffle-based arg-max when 16+ waves per CU iterate this loop).  Result valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double rft_dpp_max(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(hi2, lo2));
+}
+__device__ __forceinline__ double rft_wave_max_uniform(double v) {
+    v = rft_dpp_max<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = rft_dpp_max<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = rft_dpp_max<0x114, 0xf>(v);     // row_shr:4
+    v = rft_dpp_max<0x118, 0xf>(v);     // row_shr:8
+    v = rft_dpp_max<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
+    v = rft_dpp_max<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 template <int NPL, int WPB>
 __global__ void __launch_bounds__(64 * WPB)
 k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict__ cuw0ts, size_t cuw_stride,
@@ -218,28 +238,35 @@ k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict
     }
     double S = S0, sumsq_i = 1.0, d_error = 100 * invpw + 0.001, gacc = 0.0;
     const double rA = 1.0 / aw[0];
+    const double ka = invpw / dt, ks = dt * invpu;                // per-iteration products of :177, :184 hoisted
     const double* cres = Cres ? Cres + (size_t)chain * half : nullptr;
     int it = 0;
     for (; it < 200; it++) {
         if (fabs(d_error) <= 0.001) break;                        // :172
-        // maxloc(abs(cuw(1:nft/2))): first maximum
-        double bv = -1.0, bs = 0.0; int bj = 0x7fffffff;
+        // maxloc(abs(cuw(1:nft/2))): the maximum (exact: max does not round), then its first position
+        double bv = -1.0;
 #pragma unroll
         for (int i = 0; i < NPL; i++) {
             int j = i * 64 + lane;
-            double v = fabs(cuw[i]);
-            if (j < half && v > bv) { bv = v; bs = cuw[i]; bj = j; }
+            if (j < half) bv = fmax(bv, fabs(cuw[i]));
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            double ov = __shfl_xor(bv, off, 64), os = __shfl_xor(bs, off, 64);
-            int oj = __shfl_xor(bj, off, 64);
-            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bs = os; bj = oj; }
-        }
+        bv = rft_wave_max_uniform(bv);
         if (!(bv > 0.0)) { it++; break; }                         // nothing left to fit: P can no longer change
-        bj = __builtin_amdgcn_readfirstlane(bj);
-        const double c = bs;
-        const double a = c * invpw / dt;                          // :177
+        int bj = -1; double c = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPL; i++) {
+            if (bj < 0) {
+                int j = i * 64 + lane;
+                unsigned long long hit = __ballot(j < half && fabs(cuw[i]) == bv);
+                if (hit) {
+                    int l = __ffsll((long long)hit) - 1;
+                    bj = i * 64 + l;
+                    c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cuw[i]), l),
+                                         __builtin_amdgcn_readlane(__double2loint(cuw[i]), l));
+                }
+            }
+        }
+        const double a = c * ka;                                  // cuw(idx) * invpw / dt, :177
         const double r = c * rA;
 #pragma unroll
         for (int i = 0; i < NPL; i++) {
@@ -249,7 +276,7 @@ k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict
         }
         if (cres) gacc += a * cres[bj];
         S -= a * c;
-        double sumsq = S * dt * invpu;                            // :184
+        double sumsq = S * ks;                                    // sum(rflt**2) * dt * invpu, :184
         d_error = 100. * (sumsq_i - sumsq);
         sumsq_i = sumsq;
     }
