@@ -1,6 +1,7 @@
 """Shared host logic of the batched samplers: per-chain legacy numpy RNG streams that reproduce
 the reference's draw order (pyhmc/hmc.py:43,61: ``np.random.seed(seed + rank)``; chain c here ==
-MPI rank c there), initial models, result store."""
+MPI rank c there), initial models, result store (per-chain files with the reference's member names, one
+batched file per rank, exporter between the two) and checkpoint / resume of a running sampler."""
 import os
 
 import numpy as np
@@ -21,6 +22,17 @@ class ChainRNG:
 
     def randint(self, idx, lo, hi):
         return np.array([self.rs[c].randint(lo, hi) for c in idx], dtype=np.int32)
+
+    def get_state(self):
+        """Arrays that restore every stream exactly (MT19937 key, position, cached Gaussian)."""
+        st = [r.get_state() for r in self.rs]
+        return {"rng_key": np.stack([t[1] for t in st]), "rng_pos": np.array([t[2] for t in st]),
+                "rng_has_gauss": np.array([t[3] for t in st]), "rng_gauss": np.array([t[4] for t in st])}
+
+    def set_state(self, d):
+        for c, r in enumerate(self.rs):
+            r.set_state(("MT19937", d["rng_key"][c], int(d["rng_pos"][c]), int(d["rng_has_gauss"][c]),
+                         float(d["rng_gauss"][c])))
 
 
 def set_initial_model(rs, boundaries):
@@ -63,3 +75,67 @@ def save_chain_results(outdir, name, rank, initmodel, obs, xmean, synmean, x_cac
     if syndata is not None:
         d["syn"] = syndata
     np.savez(os.path.join(outdir, f"{name}.{rank}.npz"), **d)
+
+
+def save_batched_results(outdir, name, rank, first_chain, initmodel, obs, xmean, synmean, x_cache, syndata, misfit):
+    """One file per rank, every chain inside ({name}.rank{rank}.npz): initmodel [nc, nx], obs [nd],
+    mean_model [nc, nx], mean_syn [nc, nd], model [nc, ns, nx], syn [nc, ns, nd] (optional), misfit [nc, ns].
+    The reference writes one HDF5 per MPI rank = per chain (pyhmc/hmc.py:203-226, 272-275); with thousands of
+    chains per GPU that is the wrong granularity -- export_chain() recreates a single chain's file on demand."""
+    os.makedirs(outdir, exist_ok=True)
+    d = {"first_chain": np.array(first_chain), "initmodel": initmodel, "obs": obs, "mean_model": xmean,
+         "mean_syn": synmean, "model": x_cache, "misfit": misfit}
+    if syndata is not None:
+        d["syn"] = syndata
+    path = os.path.join(outdir, f"{name}.rank{rank}.npz")
+    np.savez(path, **d)
+    return path
+
+
+def export_chain(batched_path, chain, outdir=None, name=None, fmt="npz"):
+    """Write chain ``chain`` (global chain number = the reference's MPI rank) of a batched result file in the
+    reference's per-rank layout: ``fmt="npz"`` -> {name}.{chain}.npz as save_chain_results writes it;
+    ``fmt="h5"`` -> {name}.{chain}.h5 with initmodel, obs, mean/{model,syn}, {i}/{model,syn}
+    (pyhmc/hmc.py:203-226), which needs h5py (not part of this image: ImportError says so)."""
+    z = np.load(batched_path)
+    c = int(chain) - int(z["first_chain"])
+    if not 0 <= c < z["model"].shape[0]:
+        raise IndexError(f"chain {chain} is not in {batched_path}")
+    outdir = os.path.dirname(batched_path) if outdir is None else outdir
+    name = os.path.basename(batched_path).split(".rank")[0] if name is None else name
+    syn = z["syn"][c] if "syn" in z.files else None
+    if fmt == "npz":
+        save_chain_results(outdir, name, chain, z["initmodel"][c], z["obs"], z["mean_model"][c], z["mean_syn"][c],
+                           z["model"][c], syn)
+        return os.path.join(outdir, f"{name}.{chain}.npz")
+    if fmt != "h5":
+        raise ValueError("fmt should be npz or h5")
+    import h5py
+    path = os.path.join(outdir, f"{name}.{chain}.h5")
+    with h5py.File(path, "w") as f:
+        f.create_dataset("initmodel", data=z["initmodel"][c])
+        f.create_dataset("obs", data=z["obs"])
+        f.create_dataset("mean/model", data=z["mean_model"][c])
+        f.create_dataset("mean/syn", data=z["mean_syn"][c])
+        for i in range(z["model"].shape[1]):
+            f.create_dataset(f"{i}/model", data=z["model"][c, i])
+            if syn is not None:
+                f.create_dataset(f"{i}/syn", data=syn[i])
+    return path
+
+
+def save_checkpoint(path, rng: ChainRNG, **state):
+    """Everything a sampler needs to continue bit-for-bit: its arrays + every chain's RNG stream.
+    Written to a temporary file first, then renamed (a killed job never leaves a torn checkpoint)."""
+    d = {k: np.asarray(v) for k, v in state.items() if v is not None}
+    d.update(rng.get_state())
+    tmp = path + ".tmp.npz"
+    np.savez(tmp, **d)
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path, rng: ChainRNG):
+    z = np.load(path)
+    rng.set_state(z)
+    return {k: z[k] for k in z.files if not k.startswith("rng_")}
+

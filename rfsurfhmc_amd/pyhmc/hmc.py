@@ -11,12 +11,14 @@ import sys
 
 import numpy as np
 
-from ._batched import ChainRNG, initial_models, save_chain_results
+from ._batched import (ChainRNG, initial_models, load_checkpoint, save_batched_results, save_chain_results,
+                       save_checkpoint)
 
 
 class HamitonianMC:
     def __init__(self, UserDefinedModel, boundaries, dt, Lrange, nbest_model, seed, nsamples, ndraws,
-                 myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True):
+                 myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0):
         self.myrank = myrank
         self.nchains = int(nchains)
         self.first_chain = myrank * self.nchains
@@ -30,6 +32,10 @@ class HamitonianMC:
         self.ndraws = ndraws
         self.name, self.outdir = name, outdir
         self.store_syn, self.verbose = store_syn, verbose
+        # result files: one per chain with the reference's names (default for a few chains) and / or one
+        # batched file per rank (always written when outdir is set); checkpoint: path of a resumable state file
+        self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
+        self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
         self.rng = ChainRNG(seed, self.first_chain, self.nchains)
         self.ii = 0
         self.trace = None          # optional list collecting per-iteration records (tests)
@@ -43,7 +49,8 @@ class HamitonianMC:
 
     def _device(self):
         import torch
-        return torch.device("cuda", getattr(self.model, "device", 0) or 0)
+        dev = getattr(self.model, "torch_device", None)       # host-logic tests plug in a CPU model here
+        return dev if dev is not None else torch.device("cuda", getattr(self.model, "device", 0) or 0)
 
     def _leapfrog(self, x, active, L):
         """One trajectory for the chains in ``active`` (pyhmc/hmc.py:140-201).  Returns per-chain
@@ -75,21 +82,34 @@ class HamitonianMC:
                                    Hnew=Hnew, u=u, ok=ok, accept=accept, xres=xres.copy(), Ures=Ures.copy()))
         return xres, Ures, dres, accept
 
-    def sample(self, x_init=None):
-        """pyhmc/hmc.py:228-276.  Returns misfit[nsamples] (nchains == 1) or [nchains, nsamples]."""
+    def sample(self, x_init=None, resume=False, max_trajectories=None):
+        """pyhmc/hmc.py:228-276.  Returns misfit[nsamples] (nchains == 1) or [nchains, nsamples].
+        ``resume``: continue from ``self.checkpoint`` (same results as an uninterrupted run);
+        ``max_trajectories``: stop after that many outer iterations (the checkpoint is written first)."""
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
-        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
-        self.initmodel = x.copy()
-        nx = x.shape[1]
         ndata = self.model.dobs.shape[0]
-        misfit = np.zeros((nc, ns))
-        x_cache = np.zeros((nc, ns, nx))
-        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
-        i = np.zeros(nc, dtype=int)
-        ncount = np.zeros(nc, dtype=int)
         total = nd_ + ns
-        U = np.zeros(nc)
+        if resume:
+            st = load_checkpoint(self.checkpoint, self.rng)
+            x, U, i, ncount = st["x"], st["U"], st["i"], st["ncount"]
+            misfit, x_cache, self.initmodel = st["misfit"], st["x_cache"], st["initmodel"]
+            syndata = st["syndata"] if "syndata" in st else None
+            self.ii = int(st["ii"])
+            nx = x.shape[1]
+        else:
+            x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+            self.initmodel = x.copy()
+            nx = x.shape[1]
+            misfit = np.zeros((nc, ns))
+            x_cache = np.zeros((nc, ns, nx))
+            syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+            i = np.zeros(nc, dtype=int)
+            ncount = np.zeros(nc, dtype=int)
+            U = np.zeros(nc)
+        ntraj = 0
         while np.any(i < total):
+            if max_trajectories is not None and ntraj >= max_trajectories:
+                break
             active = [c for c in range(nc) if i[c] < total]
             L = self.rng.randint(active, self.Lrange[0], self.Lrange[1] + 1)  # hmc.py:248
             xa, Ua, da, acc = self._leapfrog(x, active, L)
@@ -108,6 +128,14 @@ class HamitonianMC:
                     print("chain {}: {:.2%}, misfit={:.3} -- accept ratio {:.2%}".format(
                         self.first_chain + c, i[c] / total, U[c], i[c] / ncount[c]))
                     sys.stdout.flush()
+            ntraj += 1
+            if self.checkpoint and self.checkpoint_every and ntraj % self.checkpoint_every == 0:
+                self._save_checkpoint(x, U, i, ncount, misfit, x_cache, syndata)
+        if self.checkpoint and np.any(i < total):
+            self._save_checkpoint(x, U, i, ncount, misfit, x_cache, syndata)
+            self.finished = False
+            return misfit[0] if nc == 1 else misfit
+        self.finished = True
         self.accept_ratio = i / np.maximum(ncount, 1)
         # mean of the nbest lowest-misfit samples, one more evaluation (hmc.py:266-275)
         xmean = np.zeros((nc, nx))
@@ -118,7 +146,16 @@ class HamitonianMC:
         synmean = res[2]
         self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
         if self.outdir is not None:
-            for c in range(nc):
-                save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c], self.model.dobs,
-                                   xmean[c], synmean[c], x_cache[c], None if syndata is None else syndata[c])
+            self.result_file = save_batched_results(self.outdir, self.name, self.myrank, self.first_chain,
+                                                    self.initmodel, self.model.dobs, xmean, synmean, x_cache,
+                                                    syndata, misfit)
+            if self.per_chain_files:
+                for c in range(nc):
+                    save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c],
+                                       self.model.dobs, xmean[c], synmean[c], x_cache[c],
+                                       None if syndata is None else syndata[c])
         return misfit[0] if nc == 1 else misfit
+
+    def _save_checkpoint(self, x, U, i, ncount, misfit, x_cache, syndata):
+        save_checkpoint(self.checkpoint, self.rng, x=x, U=U, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,
+                        syndata=syndata, initmodel=self.initmodel, ii=self.ii)

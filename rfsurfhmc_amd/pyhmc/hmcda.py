@@ -7,7 +7,8 @@ import sys
 
 import numpy as np
 
-from ._batched import ChainRNG, initial_models, save_chain_results
+from ._batched import (ChainRNG, initial_models, load_checkpoint, save_batched_results, save_chain_results,
+                       save_checkpoint)
 
 
 def _mirror(x, p, boundaries):
@@ -25,7 +26,8 @@ def _mirror(x, p, boundaries):
 
 class HMCDualAveraging:
     def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
-                 myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True):
+                 myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0):
         self.model = UserDefinedModel
         self.boundaries = np.asarray(boundaries, dtype=np.float64)
         self.dt, self.L = dt, L0
@@ -36,6 +38,8 @@ class HMCDualAveraging:
         self.first_chain = myrank * self.nchains
         self.seed, self.name, self.outdir = seed, name, outdir
         self.store_syn, self.verbose = store_syn, verbose
+        self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
+        self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
         self.delta = target_ratio                                             # hmcda.py:70-76
         self._h0, self._gamma, self._t0, self._kappa = 0.0, 0.05, 10.0, 0.75
         self._lambda = L0 * self.dt
@@ -52,7 +56,8 @@ class HMCDualAveraging:
 
     def _device(self):
         import torch
-        return torch.device("cuda", getattr(self.model, "device", 0) or 0)
+        dev = getattr(self.model, "torch_device", None)       # host-logic tests plug in a CPU model here
+        return dev if dev is not None else torch.device("cuda", getattr(self.model, "device", 0) or 0)
 
     def _find_initial_dt(self, dt0, x):
         """pyhmc/hmcda.py:170-220, all chains at once (masked): in effect dt is doubled while the
@@ -112,23 +117,36 @@ class HMCDualAveraging:
                                    Hnew=Hnew, alpha=alpha.copy(), ok=ok))
         return xnew, Unew, dnew, alpha
 
-    def sample(self, x_init=None):
-        """pyhmc/hmcda.py:280-369."""
+    def sample(self, x_init=None, resume=False, max_trajectories=None):
+        """pyhmc/hmcda.py:280-369.  ``resume`` / ``max_trajectories``: see HamitonianMC.sample."""
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
-        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
-        self.initmodel = x.copy()
-        nx = x.shape[1]
         ndata = self.model.dobs.shape[0]
-        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
-        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
-        dt = self._find_initial_dt(self.dt, x)
-        dtbar = dt * 1.0
-        h0 = np.full(nc, self._h0)
         mu = np.log(10 * self.dt)
-        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
         total = nd_ + ns
+        if resume:
+            st = load_checkpoint(self.checkpoint, self.rng)
+            x, i, ncount = st["x"], st["i"], st["ncount"]
+            misfit, x_cache, self.initmodel = st["misfit"], st["x_cache"], st["initmodel"]
+            syndata = st["syndata"] if "syndata" in st else None
+            dt, dtbar, h0 = st["dt"], st["dtbar"], st["h0"]
+            self.ii = int(st["ii"])
+            nx = x.shape[1]
+        else:
+            x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+            self.initmodel = x.copy()
+            nx = x.shape[1]
+            misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+            syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+            dt = self._find_initial_dt(self.dt, x)
+            dtbar = dt * 1.0
+            h0 = np.full(nc, self._h0)
+            i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        ntraj = 0
         idx_all = list(range(nc))
+        U = np.zeros(nc)
         while np.any(i < total):
+            if max_trajectories is not None and ntraj >= max_trajectories:
+                break
             live = i < total
             L = np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)     # hmcda.py:307
             x1, U, dsyn, alpha = self._leapfrog(x, dt, L)
@@ -159,6 +177,14 @@ class HMCDualAveraging:
                         print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
                             self.first_chain + c, i[c] / total, dt[c], U[c], i[c] / ncount[c]))
                 sys.stdout.flush()
+            ntraj += 1
+            if self.checkpoint and self.checkpoint_every and ntraj % self.checkpoint_every == 0:
+                self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0)
+        if self.checkpoint and np.any(i < total):
+            self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0)
+            self.finished = False
+            return misfit[0] if nc == 1 else misfit
+        self.finished = True
         self.dt_final, self.accept_ratio = dt, i / np.maximum(ncount, 1)
         nbests = 10                                                           # hard-coded, hmcda.py:359
         xmean = np.zeros((nc, nx))
@@ -168,7 +194,16 @@ class HMCDualAveraging:
         synmean = self.model.misfit_and_grad(xmean)[2]
         self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
         if self.outdir is not None:
-            for c in range(nc):
-                save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c], self.model.dobs,
-                                   xmean[c], synmean[c], x_cache[c], None if syndata is None else syndata[c])
+            self.result_file = save_batched_results(self.outdir, self.name, self.myrank, self.first_chain,
+                                                    self.initmodel, self.model.dobs, xmean, synmean, x_cache,
+                                                    syndata, misfit)
+            if self.per_chain_files:
+                for c in range(nc):
+                    save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c],
+                                       self.model.dobs, xmean[c], synmean[c], x_cache[c],
+                                       None if syndata is None else syndata[c])
         return misfit[0] if nc == 1 else misfit
+
+    def _save_checkpoint(self, x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0):
+        save_checkpoint(self.checkpoint, self.rng, x=x, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,
+                        syndata=syndata, initmodel=self.initmodel, ii=self.ii, dt=dt, dtbar=dtbar, h0=h0)

@@ -1,0 +1,105 @@
+"""Host logic of the batched samplers that needs no GPU: result store (batched file, per-chain exporter with the
+reference's member names) and checkpoint / resume.  The model here is a TOY stand-in with the plugin interface
+(dobs, misfit_and_grad, leapfrog_device on CPU tensors) -- it exercises the samplers' bookkeeping, not the HIP path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+class ToyModel:
+    """U(x) = 0.5 |x - m|^2, synthetics = x; leapfrog with the reference's half-step scheme, no reflection."""
+    torch_device = torch.device("cpu")
+
+    def __init__(self, n):
+        self.m = np.linspace(1.0, 2.0, n)
+        self.dobs = self.m.copy()
+
+    def misfit_and_grad(self, x):
+        x = np.atleast_2d(x)
+        r = x - self.m
+        return 0.5 * np.sum(r * r, axis=1), r, x.copy(), np.ones(len(x), bool)
+
+    def leapfrog_device(self, x, p, dt, L, bounds):
+        x = x.clone(); p = p.clone()
+        m = torch.from_numpy(self.m)
+        U0 = 0.5 * ((x - m) ** 2).sum(1); H0 = U0 + 0.5 * (p * p).sum(1)
+        x0 = x.clone()
+        Lmax = int(L.max())
+        xn, Un, Hn = x.clone(), U0.clone(), H0.clone()
+        p = p - 0.5 * dt[:, None] * (x - m)
+        for s in range(Lmax):
+            live = (L > s)[:, None]
+            x = torch.where(live, x + dt[:, None] * p, x)
+            g = x - m
+            last = (L == s + 1)[:, None]
+            p = torch.where(live, p - torch.where(last, 0.5, 1.0) * dt[:, None] * g, p)
+            done = (L == s + 1)
+            U = 0.5 * (g * g).sum(1)
+            xn = torch.where(done[:, None], x, xn); Un = torch.where(done, U, Un)
+            Hn = torch.where(done, U + 0.5 * (p * p).sum(1), Hn)
+        return dict(ok=torch.ones(len(x), dtype=torch.int32), Hcur=H0, Hnew=Hn, xnew=xn, Unew=Un, Ucur=U0,
+                    dsyn_new=xn.clone(), dsyn_cur=x0)
+
+
+def _bounds(n):
+    return np.stack([np.full(n, -5.0), np.full(n, 5.0)], axis=1)
+
+
+def _make(kind, tmp, **kw):
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    n = 6
+    common = dict(myrank=1, name="toy", outdir=str(tmp), nchains=5, verbose=False, **kw)
+    if kind == "hmc":
+        return HamitonianMC(ToyModel(n), _bounds(n), 0.3, [3, 8], 4, 991206, 12, 4, **common)
+    return HMCDualAveraging(ToyModel(n), _bounds(n), 0.3, 5, 4, 0.65, 991206, 12, 4, **common)
+
+
+@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
+def test_resume_reproduces_an_uninterrupted_run(kind, tmp_path):
+    x0 = np.random.default_rng(3).uniform(0, 3, (5, 6))
+    full = _make(kind, tmp_path / "a")
+    mis_full = full.sample(x_init=x0)
+    ck = str(tmp_path / "state.npz")
+    part = _make(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2)
+    part.sample(x_init=x0, max_trajectories=7)
+    assert not part.finished and os.path.exists(ck)
+    rest = _make(kind, tmp_path / "b", checkpoint=ck)          # a fresh process: new object, same arguments
+    mis = rest.sample(resume=True)
+    assert rest.finished
+    assert np.array_equal(mis, mis_full)
+    assert np.array_equal(rest.x_cache, full.x_cache) and np.array_equal(rest.xmean, full.xmean)
+    a = np.load(full.result_file); b = np.load(rest.result_file)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_result_store_layouts(tmp_path):
+    from rfsurfhmc_amd.pyhmc._batched import export_chain
+    s = _make("hmc", tmp_path)
+    mis = s.sample()
+    z = np.load(s.result_file)
+    assert os.path.basename(s.result_file) == "toy.rank1.npz" and int(z["first_chain"]) == 5
+    assert z["model"].shape == (5, 12, 6) and z["syn"].shape == (5, 12, 6) and np.array_equal(z["misfit"], mis)
+    # per-chain files (written by default for a few chains): the reference's HDF5 member names as npz keys
+    for c in range(5, 10):
+        f = np.load(tmp_path / f"toy.{c}.npz")
+        assert set(f.files) == {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"}
+        assert np.array_equal(f["model"], z["model"][c - 5]) and np.array_equal(f["mean/model"], z["mean_model"][c - 5])
+    # exporter recreates one chain's file from the batched one
+    os.remove(tmp_path / "toy.7.npz")
+    p = export_chain(s.result_file, 7)
+    assert np.array_equal(np.load(p)["syn"], z["syn"][2])
+    with pytest.raises(IndexError):
+        export_chain(s.result_file, 99)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            export_chain(s.result_file, 7, fmt="h5")
+    # many chains: batched file only
+    big = _make("hmc", tmp_path / "big", per_chain_files=False)
+    big.sample()
+    assert sorted(os.listdir(tmp_path / "big")) == ["toy.rank1.npz"]
