@@ -148,6 +148,15 @@ int rfs_leapfrog_dev(rfs_ctx* ctx, int nchain, const double* x0, const double* p
                      double* Unew, double* Hcur, double* Hnew, double* dsyn_cur, double* dsyn_new,
                      int32_t* ok);
 
+/* Same, for chains SORTED BY DECREASING L: nactive[step] (HOST array [Lmax], non-increasing) = number of chains with
+ * L > step; step `step` then evaluates only the first nactive[step] chains instead of all of them.  With per-chain
+ * trajectory lengths (HMC draws L per chain, pyhmc/hmc.py:248; dual averaging derives it from the per-chain dt,
+ * pyhmc/hmcda.py:307) this removes the evaluations of chains that already finished.  nactive == NULL: as above. */
+int rfs_leapfrog_dev2(rfs_ctx* ctx, int nchain, const double* x0, const double* p0, const double* dt,
+                      const int32_t* L, int32_t Lmax, const int32_t* nactive, const double* bounds, double* xnew,
+                      double* Ucur, double* Unew, double* Hcur, double* Hnew, double* dsyn_cur, double* dsyn_new,
+                      int32_t* ok);
+
 /* -------- introspection ---------------------------------------------------------------- */
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):

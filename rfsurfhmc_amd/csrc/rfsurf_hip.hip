@@ -219,24 +219,27 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch) {
 // spectrum -> rf(t): writes dsyn (stride ndata) and optionally misfit/weighted residual
 int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dobs, int ndata, double* dsyn,
                bool adjoint) {
+    // rocFFT plans are per batch size; varying chain counts (length-sorted trajectories) are rounded up to a
+    // multiple of 256 so that a handful of cached plans serve them all (the padding transforms stale data)
+    const size_t nb = nchain > 256 ? ((size_t)nchain + 255) / 256 * 256 : (size_t)nchain;
     ENSURE(c, c->wmax2, (size_t)nchain * sizeof(double));
-    ENSURE(c, c->spec, (size_t)nchain * f.n2 * sizeof(cplx));
-    ENSURE(c, c->tser, (size_t)nchain * f.nft * sizeof(double));
+    ENSURE(c, c->spec, nb * f.n2 * sizeof(cplx));
+    ENSURE(c, c->tser, nb * f.nft * sizeof(double));
     hipLaunchKernelGGL(k_rf_mid1, dim3(nchain), dim3(256), 0, c->stream, n, f, c->RR.as<double>(),
                        c->wmax2.as<double>(), c->spec.as<cplx>());
     HIPCHK(c, hipGetLastError());
-    TRY(run_fft(c, f.nft, nchain, 1, c->spec.p, c->tser.p));
+    TRY(run_fft(c, f.nft, nb, 1, c->spec.p, c->tser.p));
     double* wres = nullptr; double* mrf = nullptr;
     if (adjoint) {
-        ENSURE(c, c->wres, (size_t)nchain * f.nft * sizeof(double));
+        ENSURE(c, c->wres, nb * f.nft * sizeof(double));
         ENSURE(c, c->mrf, (size_t)nchain * sizeof(double));
-        ENSURE(c, c->W, (size_t)nchain * f.n2 * sizeof(cplx));
+        ENSURE(c, c->W, nb * f.n2 * sizeof(cplx));
         wres = c->wres.as<double>(); mrf = c->mrf.as<double>();
     }
     hipLaunchKernelGGL(k_rf_mid2, dim3(nchain), dim3(256), 0, c->stream, f, c->tser.as<double>(), dobs, ndata,
                        dsyn, mrf, wres);
     HIPCHK(c, hipGetLastError());
-    if (adjoint) TRY(run_fft(c, f.nft, nchain, 0, c->wres.p, c->W.p));
+    if (adjoint) TRY(run_fft(c, f.nft, nb, 0, c->wres.p, c->W.p));
     return RFS_OK;
 }
 
@@ -1001,14 +1004,18 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
 }
 
 // ---------------------------------------------------------------- leapfrog
-int rfs_leapfrog_dev(rfs_ctx* c, int nchain, const double* x0, const double* p0, const double* dt, const int32_t* L,
-                     int32_t Lmax, const double* bounds, double* xnew, double* Ucur, double* Unew, double* Hcur,
-                     double* Hnew, double* dsyn_cur, double* dsyn_new, int32_t* ok) {
+int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0, const double* dt, const int32_t* L,
+                      int32_t Lmax, const int32_t* nactive, const double* bounds, double* xnew, double* Ucur,
+                      double* Unew, double* Hcur, double* Hnew, double* dsyn_cur, double* dsyn_new, int32_t* ok) {
     if (!c) return RFS_ERR_ARG;
     if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
     TRY(check_batch(c, nchain, c->n));
     if (!x0 || !p0 || !dt || !L || !bounds || !xnew || !Ucur || !Unew || !Hcur || !Hnew || !dsyn_cur || !dsyn_new || !ok || Lmax < 1)
         return fail(c, RFS_ERR_ARG, "null argument");
+    if (nactive)
+        for (int s = 0; s < Lmax; s++)
+            if (nactive[s] < 1 || nactive[s] > nchain || (s > 0 && nactive[s] > nactive[s - 1]))
+                return fail(c, RFS_ERR_ARG, "nactive must be non-increasing within [1, nchain]");
     const int n = c->n, nx = 2 * n, nd = c->ndata;
     ENSURE(c, c->lx, (size_t)nchain * nx * sizeof(double)); ENSURE(c, c->lp, (size_t)nchain * nx * sizeof(double));
     ENSURE(c, c->lU, (size_t)nchain * sizeof(double)); ENSURE(c, c->lgrad, (size_t)nchain * nx * sizeof(double));
@@ -1021,15 +1028,24 @@ int rfs_leapfrog_dev(rfs_ctx* c, int nchain, const double* x0, const double* p0,
                        Ucur, Hcur, Unew, dsyn_cur, dsyn_new, ok);
     // failed chains keep xnew = x0, Hnew = +inf (reference returns (xcur, inf, dobs, False))
     HIPCHK(c, hipMemcpyAsync(xnew, x0, (size_t)nchain * nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    int nth = nchain * nx;
     for (int step = 0; step < Lmax; step++) {
-        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, step, dt, L, bounds, x, p, ok);
-        TRY(joint_eval(c, nchain, x, U, g, d, fl));
-        hipLaunchKernelGGL(k_leap_kick, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, step, dt, L, x, U, g, d, fl, p,
+        // chains sorted by decreasing L: only the first nactive[step] are still inside their trajectory
+        const int na = nactive ? nactive[step] : nchain;
+        const int nth = na * nx;
+        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, na, nx, step, dt, L, bounds, x, p, ok);
+        TRY(joint_eval(c, na, x, U, g, d, fl));
+        hipLaunchKernelGGL(k_leap_kick, dim3(na), dim3(64), 0, c->stream, na, nx, nd, step, dt, L, x, U, g, d, fl, p,
                            Unew, Hnew, dsyn_new, xnew, ok);
     }
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
+}
+
+int rfs_leapfrog_dev(rfs_ctx* c, int nchain, const double* x0, const double* p0, const double* dt, const int32_t* L,
+                     int32_t Lmax, const double* bounds, double* xnew, double* Ucur, double* Unew, double* Hcur,
+                     double* Hnew, double* dsyn_cur, double* dsyn_new, int32_t* ok) {
+    return rfs_leapfrog_dev2(c, nchain, x0, p0, dt, L, Lmax, nullptr, bounds, xnew, Ucur, Unew, Hcur, Hnew, dsyn_cur,
+                             dsyn_new, ok);
 }
 
 }  // extern "C"

@@ -107,7 +107,11 @@ def test_leapfrog_kernel_per_chain_dt_and_L(orc, golden):
     p0 = rng.standard_normal((nc, nx)) * 0.5
     dt = np.array([0.1, 0.05, 0.2, 0.1, 0.02, 0.15]); L = np.array([3, 7, 1, 5, 9, 2], dtype=np.int32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    out = joint.leapfrog_device(t(x), t(p0), t(dt), t(L), t(bounds))
+    out = joint.leapfrog_device(t(x), t(p0), t(dt), t(L), t(bounds), sort_by_length=True)
+    # the length-sorted schedule (each step evaluates only the chains still inside their trajectory) changes nothing
+    plain = joint.leapfrog_device(t(x), t(p0), t(dt), t(L), t(bounds), sort_by_length=False)
+    for k in out:
+        assert torch.equal(out[k], plain[k]), k
     ok = out["ok"].cpu().numpy()
     for c in range(nc):
         ref = _ref_leapfrog(ojoint, bounds, x[c], p0[c], dt[c], int(L[c]))
