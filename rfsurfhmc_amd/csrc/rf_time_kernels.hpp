@@ -153,7 +153,7 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
             if (TAIL) {
                 sp[(size_t)ip * n + j] = e;
             } else {
-                e = wave_sum(e);
+                e = wave_sum_uniform(e);
                 if (lane == (j & 63)) acc[ip][j >> 6] = e;
             }
         }

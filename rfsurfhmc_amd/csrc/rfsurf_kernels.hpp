@@ -44,6 +44,25 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// Wave-wide sum on the VALU (DPP moves of the two 32-bit halves + v_add_f64): no LDS-crossbar (ds_bpermute) traffic
+// and a short dependent chain, which matters in the sweeps that reduce four values per layer at low occupancy.
+// The total is returned wave-uniform (read from lane 63).  Fixed summation order -> deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_uniform(double v) {
+    v = dpp_add_step<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]: pair sums
+    v = dpp_add_step<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]: quad sums (in all four lanes)
+    v = dpp_add_step<0x114, 0xf>(v);     // row_shr:4  (zero fill)
+    v = dpp_add_step<0x118, 0xf>(v);     // row_shr:8  -> row totals in lanes 12..15 of each row
+    v = dpp_add_step<0x142, 0xa>(v);     // row_bcast:15 into rows 1, 3
+    v = dpp_add_step<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -295,7 +314,7 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
 }
 
 template <bool TAIL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
 k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
            const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
            int npart, double* __restrict__ PG)
@@ -343,7 +362,7 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
             if (TAIL) {
                 pg[(size_t)ip * n + j] = v;
             } else {
-                v = wave_sum(v);
+                v = wave_sum_uniform(v);
                 if (lane == (j & 63)) acc[ip][j >> 6] = v;
             }
         }
