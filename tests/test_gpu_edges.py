@@ -123,3 +123,38 @@ def test_argument_errors_are_reported_not_fatal():
     with pytest.raises(RfsError):
         ctx.check(-1)
     ctx.close()
+
+
+def test_schedules_give_identical_results(orc):
+    """The joint evaluation on a caller-provided stream in its two schedules -- root search and RF kernels sharing the
+    CUs, or on disjoint halves of the CU mask -- returns the same misfit, gradient, synthetics and flags bit for bit
+    (Rc + Rg data, one velocity-inversion chain)."""
+    import torch
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    rng = np.random.default_rng(12)
+    nchain, n = 1536, 14
+    vs = np.sort(2.2 + 2.4 * rng.random((nchain, n)), axis=1)
+    vs[7] = vs[7, ::-1]
+    thk = 1.0 + 3 * rng.random((nchain, n)); thk[:, -1] = 0
+    x = np.hstack((vs, thk))
+    t = np.linspace(4, 36, 17)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(0.045, 128, 0.2, 1.5, 5.0, 0.001, "P", "freq"), SurfWD(tRc=t, tRg=t))
+    drf, dswd, flag = joint.forward(np.hstack((np.linspace(2.5, 4.5, n), np.r_[np.full(n - 1, 2.5), 0])))
+    assert flag
+    joint.set_obsdata(drf, dswd)
+    xd = torch.from_numpy(x).cuda()
+    ctx = joint._ensure(n)
+    res = {}
+    for name, cu in (("shared", 0), ("partitioned", 1), ("partitioned2", 2)):
+        ctx.check(ctx.L.rfs_set_option(ctx.h, b"cu_split", cu))
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out = joint.misfit_and_grad_device(xd)
+            torch.cuda.current_stream().synchronize()
+        ctx.check(ctx.L.rfs_synchronize(ctx.h))
+        res[name] = [o.cpu().numpy().copy() for o in out]
+    assert res["shared"][3].sum() >= nchain - 8 and np.all(np.isfinite(res["shared"][1]))
+    for name in ("partitioned", "partitioned2"):
+        for a, b in zip(res["shared"], res[name]):
+            assert np.array_equal(a, b), name
