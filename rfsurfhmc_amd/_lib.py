@@ -69,6 +69,13 @@ def load() -> ctypes.CDLL:
         if not os.path.exists(LIBPATH):
             raise RfsError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and must be the one that gets loaded
+        # (this library's DT_NEEDED libamdhip64.so.7 then resolves to it).  Loading /opt/rocm's copy first and
+        # torch's afterwards leaves two runtimes in the process and torch then finds "No HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIBPATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
