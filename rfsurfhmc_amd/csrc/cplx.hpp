@@ -34,6 +34,66 @@ RFS_HD double rcp_p(double x) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// exp and sincos for the argument ranges of this code, written for the f64 VALU: FMA-based Cody-Waite
+// reduction + one polynomial each.  The device library's versions carry double-double reductions and
+// (for sincos) the Payne-Hanek large-argument path; they cost ~45 / ~120 instructions per call against
+// ~20 / ~35 here, and the layer sweeps of every kernel are bounded by exactly those instructions.
+// Accuracy: < 1 ulp (exp) and < 1.5 ulp (sin, cos) on the stated ranges (tests/test_hostsim_math.py).
+// ---------------------------------------------------------------------------
+// exp(x) for |x| <= 700.  k = rint(x / ln 2), r = x - k ln2 in two FMA steps (|r| <= 0.3466), Taylor to
+// degree 13 (remainder < 4e-18 relative), scaled by 2^k.
+RFS_HD double fm_exp(double x) {
+    const double k = rint(x * 1.4426950408889634074);
+    double r = ::fma(-k, 6.93147180369123816490e-01, x);      // ln2 high part (fdlibm split)
+    r = ::fma(-k, 1.90821492927058770002e-10, r);             // ln2 low part
+    double p = 1.6059043836821613e-10;                        // 1/13!
+    p = ::fma(p, r, 2.0876756987868100e-09);                  // 1/12!
+    p = ::fma(p, r, 2.5052108385441720e-08);                  // 1/11!
+    p = ::fma(p, r, 2.7557319223985893e-07);                  // 1/10!
+    p = ::fma(p, r, 2.7557319223985888e-06);                  // 1/9!
+    p = ::fma(p, r, 2.4801587301587302e-05);                  // 1/8!
+    p = ::fma(p, r, 1.9841269841269841e-04);                  // 1/7!
+    p = ::fma(p, r, 1.3888888888888889e-03);                  // 1/6!
+    p = ::fma(p, r, 8.3333333333333332e-03);                  // 1/5!
+    p = ::fma(p, r, 4.1666666666666664e-02);                  // 1/4!
+    p = ::fma(p, r, 1.6666666666666666e-01);                  // 1/3!
+    p = ::fma(p, r, 0.5);
+    p = ::fma(p, r, 1.0);
+    p = ::fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+// sin and cos of x for |x| < 1e9 (phases here are layer thickness x vertical wavenumber: at most a few 1e3; no
+// large-argument path is carried).  n = rint(x 2/pi), r = x - n pi/2 with pi/2 split in three parts (each step
+// one FMA; the split is good to 2^-160, so the reduction error stays below 1e-30 n), fdlibm's kernel polynomials
+// on |r| <= pi/4, quadrant fix-up by n mod 4.  NaN / inf in -> NaN out.
+RFS_HD void fm_sincos(double x, double* sn, double* cs) {
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = ::fma(-n, 1.57079632679489655800e+00, x);      // pi/2 rounded to double
+    r = ::fma(-n, 6.12323399573676603587e-17, r);             // next 53 bits
+    r = ::fma(-n, -1.49738490485916983294e-33, r);            // and the next
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;                   // S6
+    ps = ::fma(ps, z, -2.50507602534068634195e-08);           // S5
+    ps = ::fma(ps, z, 2.75573137070700676789e-06);            // S4
+    ps = ::fma(ps, z, -1.98412698298579493134e-04);           // S3
+    ps = ::fma(ps, z, 8.33333333332248946124e-03);            // S2
+    ps = ::fma(ps, z, -1.66666666666666324348e-01);           // S1
+    const double s0 = ::fma(ps * z, r, r);                    // r + r^3 (S1 + ...)
+    double pc = -1.13596475577881948265e-11;                  // C6
+    pc = ::fma(pc, z, 2.08757232129817482790e-09);            // C5
+    pc = ::fma(pc, z, -2.75573143513906633035e-07);           // C4
+    pc = ::fma(pc, z, 2.48015872894767294178e-05);            // C3
+    pc = ::fma(pc, z, -1.38888888888741095749e-03);           // C2
+    pc = ::fma(pc, z, 4.16666666666666019037e-02);            // C1
+    const double c0 = ::fma(pc * z, z, ::fma(-0.5, z, 1.0));  // 1 - z/2 + z^2 (C1 + ...)
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 struct cplx {
     double re, im;
 };
@@ -75,8 +135,8 @@ RFS_HD cplx csqrt_p(cplx z) {
 }
 // exp(z)
 RFS_HD cplx cexp_p(cplx z) {
-    double e = exp(z.re), s, c;
-    sincos(z.im, &s, &c);
+    double e = fm_exp(z.re), s, c;
+    fm_sincos(z.im, &s, &c);
     return cplx{e * c, e * s};
 }
 

@@ -209,10 +209,10 @@ RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, doub
     if (wvno == xk) { cosx = 1.0; w = dpth; x = 0.0; ex = 0.0; return; }
     double ir = rsqrt_p(v), r = v * ir, p = r * dpth;
     if (wvno < xk) {
-        double s, c; sincos(p, &s, &c);
+        double s, c; fm_sincos(p, &s, &c);
         w = s * ir; x = -r * s; cosx = c; ex = 0.0;
     } else {
-        double fac = (p < 16.0) ? exp(-2.0 * p) : 0.0;
+        double fac = (p < 16.0) ? fm_exp(-2.0 * p) : 0.0;
         cosx = (1.0 + fac) * 0.5;
         double sh = (1.0 - fac) * 0.5;
         w = sh * ir; x = r * sh; ex = p;
@@ -228,7 +228,7 @@ RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, dou
     swd_trig_split(wvno, xka, L.d, pex, cosp, w, x);
     swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z);
     double exa = pex + sex;
-    double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+    double a0 = (exa < 60.0) ? fm_exp(-exa) : 0.0;
     double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
     double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
     double gamm1 = gam - 1.0, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1;
@@ -513,7 +513,7 @@ RFS_HD void sv_trig_one(double nu2, double d, double& cosx, double& rsinx, doubl
     const double tiny = (double)1.0e-5f;
     if (nu2 >= 0.0) {                      // evanescent: nu real
         double nu = sqrt(nu2), pr = nu * d;
-        double fac = (pr < 30.0) ? exp(-2.0 * pr) : 0.0;
+        double fac = (pr < 30.0) ? fm_exp(-2.0 * pr) : 0.0;
         cosx = 0.5 * (1.0 + fac);
         double sh = 0.5 * (1.0 - fac);
         rsinx = nu * sh;
@@ -521,7 +521,7 @@ RFS_HD void sv_trig_one(double nu2, double d, double& cosx, double& rsinx, doubl
         ex = pr;
     } else {                               // propagating: nu = i*kap
         double kap = sqrt(-nu2), s, c;
-        sincos(kap * d, &s, &c);
+        fm_sincos(kap * d, &s, &c);
         cosx = c;                          // pfac = exp(0) = 1
         rsinx = -kap * s;
         sinxr = (kap < tiny) ? d : s / kap;
@@ -540,7 +540,7 @@ RFS_HD void sv_trig(double wvno2, double omega, double a, double b, double d, Sv
 RFS_HD double sr_compound_step(double cd[5], const SvTrig& t, float rhof, float bf, double wvno,
                                double wvno2, double om2) {
     double exa = t.pex + t.svex;
-    double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+    double a0 = (exa < 60.0) ? fm_exp(-exa) : 0.0;
     double cpcq = t.cosp * t.cossv, cpy = t.cosp * t.sinsvr, cpz = t.cosp * t.rsinsv;
     double cqw = t.cossv * t.sinpr, cqx = t.cossv * t.rsinp;
     double xy = t.rsinp * t.sinsvr, xz = t.rsinp * t.rsinsv, wy = t.sinpr * t.sinsvr, wz = t.sinpr * t.rsinsv;
@@ -591,7 +591,7 @@ RFS_HD double sr_compound_step(double cd[5], const SvTrig& t, float rhof, float 
 // vv <- normalise(AA . vv) with AA the Haskell matrix (sregn96.f90:917-991); returns log-norm.
 RFS_HD double sr_haskell_step(double vv[4], const SvTrig& t, float rhof, float bf, double wvno,
                               double wvno2, double om2) {
-    double dfac = ((t.pex - t.svex) > 70.0) ? 0.0 : exp(t.svex - t.pex);
+    double dfac = ((t.pex - t.svex) > 70.0) ? 0.0 : fm_exp(t.svex - t.pex);
     double cossv = dfac * t.cossv, rsinsv = dfac * t.rsinsv, sinsvr = dfac * t.sinsvr;
     double cosp = t.cosp, rsinp = t.rsinp, sinpr = t.sinpr;
     double gam = (double)((2.0f * bf) * bf) * wvno2 / om2, gamm1 = gam - 1.0;
@@ -796,7 +796,7 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
             double uu4 = -tz1 * cd4 + tz2 * cd2 - tz3 * cd1;
             double ext = exa + exe_m - exe0;
             if (ext > -80.0 && ext < 80.0) {
-                double fact = exp(ext);
+                double fact = fm_exp(ext);
                 bot = Eig4{uu1 * fact / f1213, uu2 * fact / f1213, uu3 * fact / f1213, uu4 * fact / f1213};
             } else {
                 bot = Eig4{0.0, 0.0, 0.0, 0.0};

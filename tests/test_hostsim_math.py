@@ -130,3 +130,40 @@ def test_love_and_sphere_device_math(hs, golden):
                         ref = g[f"{key}/{kk}"][k]
                         assert np.abs(arr - ref).max() <= 2e-8 * np.abs(ref).max(), (key, kk, k)
     assert nroot > 100 and nexact >= 0.97 * nroot
+
+
+def test_fast_exp_and_sincos_accuracy(tmp_path):
+    """fm_exp / fm_sincos (cplx.hpp: the transcendental functions of every layer sweep) against long double libm
+    on the ranges they are used on: < 1 ulp (exp) and < 1.5 ulp (sin, cos); absolute error at multiples of pi/2."""
+    src = tmp_path / "fm.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cmath>
+#include <random>
+#include "%s/rfsurfhmc_amd/csrc/cplx.hpp"
+using namespace rfs;
+int main() {
+    std::mt19937_64 g(1);
+    const double h = 1.1102230246251565e-16;
+    double we = 0, ws = 0, wc = 0, wa = 0;
+    for (int i = 0; i < 2000000; i++) {
+        double u = (double)g() / 1.8446744073709552e19;
+        double x = -120.0 + 170.0 * u;
+        long double ref = expl((long double)x);
+        we = fmax(we, fabs((double)((fm_exp(x) - ref) / ref)) / h);
+        double scale = (i %% 3 == 0) ? 3.0 : (i %% 3 == 1 ? 300.0 : 1.0e5);
+        double y = (2 * u - 1) * scale, s, c;
+        fm_sincos(y, &s, &c);
+        long double rs = sinl((long double)y), rc = cosl((long double)y);
+        if (fabsl(rs) > 1e-3L) ws = fmax(ws, fabs((double)((s - rs) / rs)) / h);
+        if (fabsl(rc) > 1e-3L) wc = fmax(wc, fabs((double)((c - rc) / rc)) / h);
+        wa = fmax(wa, fmax(fabs((double)(s - rs)), fabs((double)(c - rc))));
+    }
+    printf("%%.4f %%.4f %%.4f %%.3e\n", we / 2, ws / 2, wc / 2, wa);
+    return 0;
+}
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    exe = tmp_path / "fm"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", str(src), "-o", str(exe)], check=True)
+    ue, us, uc, ab = map(float, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    assert ue < 1.0 and us < 1.5 and uc < 1.5 and ab < 2.5e-16, (ue, us, uc, ab)
