@@ -67,10 +67,15 @@ RFS_HD void rf_hyp(const RfLayer& L, cplx omega, RfHyp& H) {
     cplx ta = omega * L.pva, tb = omega * L.pvb;
     H.sa = (ta.re > 0.0 || (ta.re == 0.0 && ta.im >= 0.0)) ? 1.0 : -1.0;
     H.sb = (tb.re > 0.0 || (tb.re == 0.0 && tb.im >= 0.0)) ? 1.0 : -1.0;
-    cplx ea = cexp_p(L.h * ta), eb = cexp_p(L.h * tb);
-    cplx eai = inv(ea), ebi = inv(eb);
-    H.ca = 0.5 * (ea + eai); H.cb = 0.5 * (eb + ebi);
-    cplx sha = (0.5 * H.sa) * (ea - eai), shb = (0.5 * H.sb) * (eb - ebi);
+    // cosh / sinh of the complex arguments from ONE exp, one reciprocal and one sincos each:
+    // e^{a+ib} = e^a (c + i s), e^{-(a+ib)} = e^{-a} (c - i s)  ->  cosh = (ch c, sh s), sinh = (sh c, ch s)
+    double e1 = fm_exp(L.h * ta.re), s1, c1, e2 = fm_exp(L.h * tb.re), s2, c2;
+    fm_sincos(L.h * ta.im, &s1, &c1);
+    fm_sincos(L.h * tb.im, &s2, &c2);
+    double i1 = rcp_p(e1), i2 = rcp_p(e2);
+    double ch1 = 0.5 * (e1 + i1), sh1 = 0.5 * (e1 - i1), ch2 = 0.5 * (e2 + i2), sh2 = 0.5 * (e2 - i2);
+    H.ca = cplx{ch1 * c1, sh1 * s1}; H.cb = cplx{ch2 * c2, sh2 * s2};
+    cplx sha = H.sa * cplx{sh1 * c1, ch1 * s1}, shb = H.sb * cplx{sh2 * c2, ch2 * s2};
     H.xa = L.va * sha; H.ya = sha * L.iva;
     H.xb = L.vb * shb; H.yb = shb * L.ivb;
 }

@@ -203,20 +203,30 @@ struct SwdLayerC { double d, ia, ib, b, rho, irho; };   // thickness, 1/alpha, 1
 
 constexpr int SWD_NENT = 15;
 
-RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, double& cosx, double& w, double& x) {
-    // var (surfdisp96.f:941-1002) for one wave type: returns cos, sin/r, +-r*sin and the exponent
-    double v = (wvno + xk) * fabs(wvno - xk);
-    if (wvno == xk) { cosx = 1.0; w = dpth; x = 0.0; ex = 0.0; return; }
-    double ir = rsqrt_p(v), r = v * ir, p = r * dpth;
-    if (wvno < xk) {
-        double s, c; fm_sincos(p, &s, &c);
-        w = s * ir; x = -r * s; cosx = c; ex = 0.0;
+RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, double& cosx, double& w, double& x,
+                           double& eh) {
+    // var (surfdisp96.f:941-1002) for one wave type: returns cos, sin/r, +-r*sin, the exponent ex and
+    // eh = exp(-ex) (1 when oscillatory): exp(-2p) is formed as eh*eh and the layer's exp(-(pex+sex)) as the
+    // product of the two eh, so an evanescent wave type costs ONE exponential in all.
+    const double v = (wvno + xk) * fabs(wvno - xk);
+    const bool osc = wvno < xk;
+    const double ir = rsqrt_p(v), r = v * ir, p = r * dpth;
+    double cs, sn;
+    eh = 1.0;
+    if (osc) {
+        fm_sincos(p, &sn, &cs);
     } else {
-        double fac = (p < 16.0) ? fm_exp(-2.0 * p) : 0.0;
-        cosx = (1.0 + fac) * 0.5;
-        double sh = (1.0 - fac) * 0.5;
-        w = sh * ir; x = r * sh; ex = p;
+        eh = fm_exp(-p);
+        double fac = (p < 16.0) ? eh * eh : 0.0;
+        cs = (1.0 + fac) * 0.5;
+        sn = (1.0 - fac) * 0.5;
     }
+    const bool deg = (wvno == xk);                     // v = 0: ir = inf, r = p = NaN above
+    cosx = deg ? 1.0 : cs;
+    w = deg ? dpth : sn * ir;
+    x = deg ? 0.0 : (osc ? -r : r) * sn;
+    ex = (osc || deg) ? 0.0 : p;
+    if (deg) eh = 1.0;
 }
 
 RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega,
@@ -224,11 +234,11 @@ RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, dou
     double xka = omega * L.ia, xkb = omega * L.ib;
     double t = L.b * iomega;
     double gammk = 2.0 * t * t, gam = gammk * wvno2;
-    double pex, sex, cosp, w, x, cosq, y, z;
-    swd_trig_split(wvno, xka, L.d, pex, cosp, w, x);
-    swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z);
+    double pex, sex, cosp, w, x, cosq, y, z, eha, ehb;
+    swd_trig_split(wvno, xka, L.d, pex, cosp, w, x, eha);
+    swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z, ehb);
     double exa = pex + sex;
-    double a0 = (exa < 60.0) ? fm_exp(-exa) : 0.0;
+    double a0 = (exa < 60.0) ? eha * ehb : 0.0;
     double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
     double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
     double gamm1 = gam - 1.0, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1;
