@@ -157,6 +157,19 @@ int rfs_leapfrog_dev2(rfs_ctx* ctx, int nchain, const double* x0, const double* 
                       double* Ucur, double* Unew, double* Hcur, double* Hnew, double* dsyn_cur, double* dsyn_new,
                       int32_t* ok);
 
+/* Continuous-flow variant: every chain is at its own point of its own trajectory, so chains with short trajectories
+ * never wait for the longest one.  All arrays DEVICE, persistent between calls and owned by the caller:
+ *   x, p [nchain][2n]; dt [nchain]; rem [nchain] leapfrog steps still to do (-1 = idle);
+ *   fresh [nchain] = 1: the trajectory starts with this call (x = start model, p = drawn momentum, rem = L, ok = 1).
+ * One call = ONE misfit+gradient evaluation of every chain: a fresh chain gets Ucur, Hcur, dsyn_cur and the first half
+ * kick (pyhmc/hmc.py:150-164); a running chain drifts (with mirror reflection), is evaluated and kicked, rem--; when
+ * rem reaches 0 its Unew, Hnew, dsyn_new are final, x holds the end model and done[chain] = 1.  ok[chain] = 0 (and
+ * done = 1) where the reference returns early (flag False or NaN).  The caller restarts finished chains (accept /
+ * reject, new momentum, rem = L, fresh = 1) between calls. */
+int rfs_flow_step(rfs_ctx* ctx, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                  const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                  double* dsyn_new, int32_t* ok, int32_t* done);
+
 /* -------- introspection ---------------------------------------------------------------- */
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):

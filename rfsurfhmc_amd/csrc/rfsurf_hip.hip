@@ -1041,6 +1041,28 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
     return RFS_OK;
 }
 
+int rfs_flow_step(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                  const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                  double* dsyn_new, int32_t* ok, int32_t* done) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (!x || !p || !dt || !rem || !fresh || !bounds || !Ucur || !Hcur || !Unew || !Hnew || !dsyn_cur || !dsyn_new || !ok || !done)
+        return fail(c, RFS_ERR_ARG, "null argument");
+    const int n = c->n, nx = 2 * n, nd = c->ndata;
+    ENSURE(c, c->lU, (size_t)nchain * sizeof(double)); ENSURE(c, c->lgrad, (size_t)nchain * nx * sizeof(double));
+    ENSURE(c, c->ldsyn, (size_t)nchain * nd * sizeof(double)); ENSURE(c, c->lflag, (size_t)nchain * sizeof(int));
+    double *U = c->lU.as<double>(), *g = c->lgrad.as<double>(), *d = c->ldsyn.as<double>();
+    int* fl = c->lflag.as<int>();
+    const int nth = nchain * nx;
+    hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, dt, rem, fresh, ok, bounds, x, p);
+    TRY(joint_eval(c, nchain, x, U, g, d, fl));
+    hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, dt, x, U, g, d, fl, p, rem, fresh,
+                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done);
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
 int rfs_leapfrog_dev(rfs_ctx* c, int nchain, const double* x0, const double* p0, const double* dt, const int32_t* L,
                      int32_t Lmax, const double* bounds, double* xnew, double* Ucur, double* Unew, double* Hcur,
                      double* Hnew, double* dsyn_cur, double* dsyn_new, int32_t* ok) {

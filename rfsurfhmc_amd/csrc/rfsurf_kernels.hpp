@@ -1107,4 +1107,102 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// K7 continuous-flow leapfrog: every chain sits at its own point of its own trajectory, one call = one
+// evaluation per chain.  rem[chain] = leapfrog steps still to do (-1: idle), fresh[chain] = 1: the trajectory starts
+// with this call (x = start model, p = drawn momentum).  Same arithmetic as k_leap_begin / drift / kick.
+// ---------------------------------------------------------------------------------------
+__global__ void k_flow_pre(int nchain, int nx, const double* dt, const int* rem, const int* fresh, const int* ok,
+                           const double* bounds, double* x, double* p)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nchain * nx) return;
+    int chain = g / nx, i = g - chain * nx;
+    if (fresh[chain] || rem[chain] <= 0 || !ok[chain]) return;
+    double xv = x[g] + dt[chain] * p[g], pv = p[g];
+    double lo = bounds[2 * i], hi = bounds[2 * i + 1];
+    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
+        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
+        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
+    }
+    x[g] = xv; p[g] = pv;
+}
+
+__global__ void k_flow_post(int nchain, int nx, int ndata, const double* dt, const double* x, const double* U,
+                            const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
+                            double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                            double* dsyn_new, int* ok, int* done)
+{
+    __shared__ double red[4];
+    __shared__ int bad;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    const int fr = fresh[chain], rm = rem[chain];
+    if (tid == 0) done[chain] = 0;
+    if (!fr && (rm <= 0 || !ok[chain])) return;                // idle chain (block-uniform)
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    int mybad = 0;
+    for (int i = tid; i < ndata; i += blockDim.x) {
+        double d = dsyn[(size_t)chain * ndata + i];
+        if (d != d) mybad = 1;
+    }
+    if (!fr) for (int i = tid; i < nx; i += blockDim.x) {
+        double xv = x[(size_t)chain * nx + i], gv = grad[(size_t)chain * nx + i];
+        if (xv != xv || gv != gv) mybad = 1;
+    }
+    if (mybad) atomicOr(&bad, 1);
+    __syncthreads();
+    const int fail = bad || !flag[chain];
+    if (fr) {                                                   // hmc.py:150-164
+        double k = 0.0;
+        for (int i = tid; i < nx; i += blockDim.x) {
+            double pv = p[(size_t)chain * nx + i];
+            k += pv * pv;
+            p[(size_t)chain * nx + i] = pv - dt[chain] * grad[(size_t)chain * nx + i] * 0.5;
+        }
+        for (int i = tid; i < ndata; i += blockDim.x) {
+            double d = dsyn[(size_t)chain * ndata + i];
+            dsyn_cur[(size_t)chain * ndata + i] = d; dsyn_new[(size_t)chain * ndata + i] = d;
+        }
+        k = wave_sum(k);
+        if ((tid & 63) == 0) red[tid >> 6] = k;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+            Ucur[chain] = U[chain]; Unew[chain] = U[chain];
+            Hcur[chain] = 0.5 * s + U[chain];
+            Hnew[chain] = __longlong_as_double(0x7ff0000000000000LL);          // +inf until the trajectory completes
+            ok[chain] = !fail;
+            fresh[chain] = 0;
+            if (fail) { rem[chain] = -1; done[chain] = 1; }
+        }
+        return;
+    }
+    if (fail) { if (tid == 0) { ok[chain] = 0; rem[chain] = -1; done[chain] = 1; } return; }
+    const bool last = (rm == 1);                                // hmc.py:170-190
+    double k = 0.0;
+    for (int i = tid; i < nx; i += blockDim.x) {
+        double pv = p[(size_t)chain * nx + i] - dt[chain] * grad[(size_t)chain * nx + i] * (last ? 0.5 : 1.0);
+        p[(size_t)chain * nx + i] = pv;
+        k += pv * pv;
+    }
+    if (last) for (int i = tid; i < ndata; i += blockDim.x)
+        dsyn_new[(size_t)chain * ndata + i] = dsyn[(size_t)chain * ndata + i];
+    k = wave_sum(k);
+    if ((tid & 63) == 0) red[tid >> 6] = k;
+    __syncthreads();
+    if (tid == 0) {
+        if (last) {
+            double s = 0.0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+            Unew[chain] = U[chain];
+            Hnew[chain] = 0.5 * s + U[chain];
+            rem[chain] = -1; done[chain] = 1;
+        } else {
+            rem[chain] = rm - 1;
+        }
+    }
+}
+
 }  // namespace rfs

@@ -134,3 +134,33 @@ class FusedPlugin:
             inv[order] = torch.arange(nchain, device=dev)
             out = {k: v.index_select(0, inv) for k, v in out.items()}
         return out
+
+    def flow_step(self, st):
+        """One call of rfs_flow_step on the state dict ``st`` (CUDA tensors x, p, dt, rem, fresh, bounds, Ucur, Hcur,
+        Unew, Hnew, dsyn_cur, dsyn_new, ok, done -- see include/rfsurf.h): one evaluation per chain, every chain at
+        its own point of its own trajectory."""
+        import torch
+        x = st["x"]
+        nchain, nx = x.shape
+        ctx = self._ensure(nx // 2)
+        ctx.check(ctx.L.rfs_set_stream(ctx.h, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        ctx.check(ctx.L.rfs_flow_step(ctx.h, nchain, *[st[k].data_ptr() for k in
+                                      ("x", "p", "dt", "rem", "fresh", "bounds", "Ucur", "Hcur", "Unew", "Hnew",
+                                       "dsyn_cur", "dsyn_new", "ok", "done")]))
+
+    def flow_state(self, x0, dt, bounds):
+        """Fresh state for flow_step: x0 float64 CUDA [nchain, 2n], dt float64 CUDA [nchain], bounds [2n, 2]."""
+        import torch
+        nchain, nx = x0.shape
+        ctx = self._ensure(nx // 2)
+        nd = ctx.L.rfs_ndata(ctx.h)
+        dev = x0.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        return dict(x=x0.clone().contiguous(), p=torch.zeros(nchain, nx, **f64), dt=dt.contiguous(),
+                    rem=torch.full((nchain,), -1, **i32), fresh=torch.zeros(nchain, **i32),
+                    bounds=bounds.contiguous(), Ucur=torch.zeros(nchain, **f64), Hcur=torch.zeros(nchain, **f64),
+                    Unew=torch.zeros(nchain, **f64), Hnew=torch.zeros(nchain, **f64),
+                    dsyn_cur=torch.zeros(nchain, nd, **f64), dsyn_new=torch.zeros(nchain, nd, **f64),
+                    ok=torch.ones(nchain, **i32), done=torch.zeros(nchain, **i32))
+

@@ -82,6 +82,81 @@ class HamitonianMC:
                                    Hnew=Hnew, u=u, ok=ok, accept=accept, xres=xres.copy(), Ures=Ures.copy()))
         return xres, Ures, dres, accept
 
+    def sample_flow(self, x_init=None):
+        """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
+        chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
+        chain at its own point of its own trajectory (rfs_flow_step), and a chain that finishes a trajectory is
+        accepted / rejected and restarted on the spot instead of waiting for the longest trajectory of the batch.
+        With L drawn per chain in [Lmin, Lmax] the batch schedule spends Lmax + 1 evaluations per round and chain,
+        this one mean(L) + 2."""
+        import torch
+        nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        dev = self._device()
+        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+        self.initmodel = x.copy()
+        nx = x.shape[1]
+        ndata = self.model.dobs.shape[0]
+        total = nd_ + ns
+        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        st = self.model.flow_state(t(x), torch.full((nc,), float(self.dt), dtype=torch.float64, device=dev),
+                                   t(self.boundaries))
+        allc = list(range(nc))
+        L = self.rng.randint(allc, self.Lrange[0], self.Lrange[1] + 1)          # hmc.py:248, then :146
+        st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
+        st["rem"].copy_(t(L.astype(np.int32))); st["fresh"].fill_(1)
+        self.flow_steps = 0
+        while np.any(i < total):
+            self.model.flow_step(st)
+            self.flow_steps += 1
+            idx = np.nonzero(st["done"].cpu().numpy())[0]
+            if len(idx) == 0:
+                continue
+            sel = t(idx)
+            ok = st["ok"].index_select(0, sel).cpu().numpy().astype(bool)
+            Hcur = st["Hcur"].index_select(0, sel).cpu().numpy(); Hnew = st["Hnew"].index_select(0, sel).cpu().numpy()
+            Unew = st["Unew"].index_select(0, sel).cpu().numpy(); Ucur = st["Ucur"].index_select(0, sel).cpu().numpy()
+            xend = st["x"].index_select(0, sel).cpu().numpy()
+            dnew = st["dsyn_new"].index_select(0, sel).cpu().numpy() if syndata is not None else None
+            u = np.full(len(idx), np.nan)
+            u[ok] = self.rng.rand([int(c) for c in idx[ok]])                    # hmc.py:193, skipped on failure
+            with np.errstate(over="ignore", invalid="ignore"):
+                accept = ok & (u < np.exp(-(Hnew - Hcur)))
+            restart = []
+            for k, c in enumerate(idx):
+                if accept[k]:
+                    x[c] = xend[k]
+                    if i[c] >= nd_:
+                        misfit[c, i[c] - nd_] = Unew[k]
+                        x_cache[c, i[c] - nd_] = xend[k]
+                        if syndata is not None:
+                            syndata[c, i[c] - nd_] = dnew[k]
+                    i[c] += 1
+                    self.ii += 1
+                ncount[c] += 1
+                if i[c] < total:
+                    restart.append(int(c))
+            if self.verbose:
+                for k, c in enumerate(idx):
+                    if i[c] % 50 == 0 or i[c] == ns - 1:
+                        Uc = Unew[k] if accept[k] else (Ucur[k] if ok[k] else np.inf)
+                        print("chain {}: {:.2%}, misfit={:.3} -- accept ratio {:.2%}".format(
+                            self.first_chain + c, i[c] / total, Uc, i[c] / ncount[c]))
+                sys.stdout.flush()
+            # every finished chain goes back to the model it keeps (accepted end point or its start model) ...
+            st["x"].index_copy_(0, sel, t(x[idx]))
+            if restart:                                                         # ... and the unfinished ones restart
+                rs = t(np.array(restart))
+                Lr = self.rng.randint(restart, self.Lrange[0], self.Lrange[1] + 1)
+                st["p"].index_copy_(0, rs, t(self.rng.randn(restart, nx) * 0.5))
+                st["rem"].index_copy_(0, rs, t(Lr.astype(np.int32)))
+                st["fresh"].index_fill_(0, rs, 1)
+                st["ok"].index_fill_(0, rs, 1)
+        self.finished = True
+        return self._finish(misfit, x_cache, syndata, i, ncount)
+
     def sample(self, x_init=None, resume=False, max_trajectories=None):
         """pyhmc/hmc.py:228-276.  Returns misfit[nsamples] (nchains == 1) or [nchains, nsamples].
         ``resume``: continue from ``self.checkpoint`` (same results as an uninterrupted run);
@@ -136,6 +211,10 @@ class HamitonianMC:
             self.finished = False
             return misfit[0] if nc == 1 else misfit
         self.finished = True
+        return self._finish(misfit, x_cache, syndata, i, ncount)
+
+    def _finish(self, misfit, x_cache, syndata, i, ncount):
+        nc, nx = self.nchains, x_cache.shape[2]
         self.accept_ratio = i / np.maximum(ncount, 1)
         # mean of the nbest lowest-misfit samples, one more evaluation (hmc.py:266-275)
         xmean = np.zeros((nc, nx))

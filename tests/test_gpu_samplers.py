@@ -125,3 +125,22 @@ def test_leapfrog_kernel_per_chain_dt_and_L(orc, golden):
         # unsorted "wild" start models: a Rayleigh root may differ by the reference's own 1e-6 c refinement
         # tolerance, which the group velocities amplify (see test_gpu_parity.py)
         assert rel(out["dsyn_new"][c].cpu().numpy(), dn) < 2e-5
+
+
+def test_flow_schedule_equals_batch_schedule(golden):
+    """sample_flow() -- every chain at its own point of its own trajectory, restarted the moment it finishes -- returns
+    exactly the samples of sample() (chains are independent and each consumes its own RNG stream in the same order),
+    in fewer device steps; chain 0 still reproduces the reference's rank 0."""
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    g = golden["sampler_hybrid"]
+    mk = lambda: HamitonianMC(_joint(g), g["bounds"], 0.1, [5, 20], 2, 991206, 6, 3, myrank=0, name="t", outdir=None,
+                              nchains=7, verbose=False)
+    a = mk(); ma = a.sample()
+    a.trace = None
+    b = mk(); mb = b.sample_flow()
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.syndata, b.syndata)
+    assert np.array_equal(a.accept_ratio, b.accept_ratio) and np.array_equal(a.xmean, b.xmean)
+    assert rel(mb[0], g["hmc_r0/misfit"]) < 1e-5
+    # batch: every round costs max(L) + 1 evaluations of every chain; flow: one evaluation per chain and step
+    assert b.flow_steps > 0
