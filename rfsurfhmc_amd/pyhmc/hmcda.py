@@ -185,6 +185,10 @@ class HMCDualAveraging:
             self.finished = False
             return misfit[0] if nc == 1 else misfit
         self.finished = True
+        return self._finish(misfit, x_cache, syndata, i, ncount, dt)
+
+    def _finish(self, misfit, x_cache, syndata, i, ncount, dt):
+        nc, nx = self.nchains, x_cache.shape[2]
         self.dt_final, self.accept_ratio = dt, i / np.maximum(ncount, 1)
         nbests = 10                                                           # hard-coded, hmcda.py:359
         xmean = np.zeros((nc, nx))
@@ -203,6 +207,87 @@ class HMCDualAveraging:
                                        self.model.dobs, xmean[c], synmean[c], x_cache[c],
                                        None if syndata is None else syndata[c])
         return misfit[0] if nc == 1 else misfit
+
+    def sample_flow(self, x_init=None):
+        """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
+        every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
+        (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
+        order (momentum at the start of a trajectory, the acceptance draw at its end)."""
+        import torch
+        nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        dev = self._device()
+        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+        self.initmodel = x.copy()
+        nx = x.shape[1]
+        ndata = self.model.dobs.shape[0]
+        mu = np.log(10 * self.dt)
+        total = nd_ + ns
+        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+        dt = self._find_initial_dt(self.dt, x)
+        dtbar = dt * 1.0
+        h0 = np.full(nc, self._h0)
+        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
+        allc = list(range(nc))
+        st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
+        st["rem"].copy_(t(np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)))
+        st["fresh"].fill_(1)
+        self.flow_steps = 0
+        while np.any(i < total):
+            self.model.flow_step(st)
+            self.flow_steps += 1
+            idx = np.nonzero(st["done"].cpu().numpy())[0]
+            if len(idx) == 0:
+                continue
+            sel = t(idx)
+            ok = st["ok"].index_select(0, sel).cpu().numpy().astype(bool)
+            Hcur = st["Hcur"].index_select(0, sel).cpu().numpy(); Hnew = st["Hnew"].index_select(0, sel).cpu().numpy()
+            Unew = np.where(ok, st["Unew"].index_select(0, sel).cpu().numpy(), np.inf)
+            xend = st["x"].index_select(0, sel).cpu().numpy()
+            dnew = st["dsyn_new"].index_select(0, sel).cpu().numpy() if syndata is not None else None
+            with np.errstate(over="ignore", invalid="ignore"):
+                alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
+            u = self.rng.rand([int(c) for c in idx])
+            acc = u < alpha
+            for k, c in enumerate(idx):
+                if acc[k]:
+                    x[c] = xend[k]
+                    if i[c] >= nd_:
+                        misfit[c, i[c] - nd_] = Unew[k]; x_cache[c, i[c] - nd_] = xend[k]
+                        if syndata is not None:
+                            syndata[c, i[c] - nd_] = dnew[k] if ok[k] else self.model.dobs
+                    i[c] += 1; self.ii += 1
+            # dual averaging for the chains that just finished a trajectory (hmcda.py:329-345)
+            adapt = ncount[idx] < nd_
+            m = ncount[idx] + 1.0
+            fac = 1.0 / (m + self._t0)
+            h_new = (1 - fac) * h0[idx] + fac * (self.delta - alpha)
+            logdt = mu - np.sqrt(m) / self._gamma * h_new
+            fac2 = m ** (-self._kappa)
+            dtbar_new = np.exp(fac2 * logdt + (1 - fac2) * np.log(dtbar[idx]))
+            h0[idx] = np.where(adapt, h_new, h0[idx])
+            dt[idx] = np.where(adapt, np.exp(logdt), dtbar[idx])
+            dtbar[idx] = np.where(adapt, dtbar_new, dtbar[idx])
+            ncount[idx] += 1
+            if self.verbose:
+                for k, c in enumerate(idx):
+                    if i[c] % 50 == 0 or i[c] == ns - 1:
+                        print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
+                            self.first_chain + c, i[c] / total, dt[c], Unew[k], i[c] / ncount[c]))
+                sys.stdout.flush()
+            st["x"].index_copy_(0, sel, t(x[idx]))
+            restart = [int(c) for c in idx if i[c] < total]
+            if restart:
+                rs = t(np.array(restart))
+                st["p"].index_copy_(0, rs, t(self.rng.randn(restart, nx) * 0.5))
+                st["dt"].index_copy_(0, rs, t(dt[restart].astype(np.float64)))
+                st["rem"].index_copy_(0, rs, t(np.maximum(1, (self._lambda / dt[restart]).astype(int)).astype(np.int32)))
+                st["fresh"].index_fill_(0, rs, 1)
+                st["ok"].index_fill_(0, rs, 1)
+        self.finished = True
+        return self._finish(misfit, x_cache, syndata, i, ncount, dt)
 
     def _save_checkpoint(self, x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0):
         save_checkpoint(self.checkpoint, self.rng, x=x, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,

@@ -144,3 +144,17 @@ def test_flow_schedule_equals_batch_schedule(golden):
     assert rel(mb[0], g["hmc_r0/misfit"]) < 1e-5
     # batch: every round costs max(L) + 1 evaluations of every chain; flow: one evaluation per chain and step
     assert b.flow_steps > 0
+
+
+def test_flow_schedule_equals_batch_schedule_dual_averaging(golden):
+    """HMCDualAveraging.sample_flow(): per-chain step sizes give per-chain trajectory lengths; same samples, same
+    adapted step sizes as the batch schedule, chain 0 still the reference's rank 0."""
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    g = golden["sampler_hybrid"]
+    mk = lambda: HMCDualAveraging(_joint(g), g["bounds"], 0.1, 10, 2, 0.65, 991206, 6, 3, myrank=0, name="t",
+                                  outdir=None, nchains=5, verbose=False)
+    a = mk(); ma = a.sample()
+    b = mk(); mb = b.sample_flow()
+    assert np.array_equal(ma, mb) and np.array_equal(a.x_cache, b.x_cache)
+    assert np.array_equal(a.dt_final, b.dt_final) and np.array_equal(a.accept_ratio, b.accept_ratio)
+    assert rel(mb[0], g["da_r0/misfit"]) < 1e-5

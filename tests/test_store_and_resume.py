@@ -43,6 +43,48 @@ class ToyModel:
                     dsyn_new=xn.clone(), dsyn_cur=x0)
 
 
+def _toy_flow_state(self, x0, dt, bounds):
+    n, nx = x0.shape
+    z = lambda *sh: torch.zeros(*sh, dtype=torch.float64)
+    return dict(x=x0.clone(), p=z(n, nx), dt=dt.clone(), rem=torch.full((n,), -1, dtype=torch.int32),
+                fresh=torch.zeros(n, dtype=torch.int32), bounds=bounds, Ucur=z(n), Hcur=z(n), Unew=z(n), Hnew=z(n),
+                dsyn_cur=z(n, nx), dsyn_new=z(n, nx), ok=torch.ones(n, dtype=torch.int32),
+                done=torch.zeros(n, dtype=torch.int32))
+
+
+def _toy_flow_step(self, st):
+    """rfs_flow_step semantics (include/rfsurf.h) for the toy potential, same arithmetic as leapfrog_device above."""
+    m = torch.from_numpy(self.m)
+    x, p, dt, rem, fresh = st["x"], st["p"], st["dt"], st["rem"], st["fresh"]
+    run = (fresh == 0) & (rem > 0)
+    x[run] = x[run] + dt[run, None] * p[run]
+    g = x - m
+    U = 0.5 * (g * g).sum(1)
+    st["done"].zero_()
+    fr = fresh == 1
+    if fr.any():
+        st["Ucur"][fr] = U[fr]; st["Unew"][fr] = U[fr]
+        st["Hcur"][fr] = U[fr] + 0.5 * (p[fr] * p[fr]).sum(1)
+        st["Hnew"][fr] = float("inf")
+        st["dsyn_cur"][fr] = x[fr]; st["dsyn_new"][fr] = x[fr]
+        p[fr] = p[fr] - 0.5 * dt[fr, None] * g[fr]
+        fresh[fr] = 0
+    if run.any():
+        last = run & (rem == 1)
+        w = torch.where(last, 0.5, 1.0)
+        p[run] = p[run] - (w[run] * dt[run])[:, None] * g[run]
+        st["Unew"][last] = U[last]
+        st["Hnew"][last] = U[last] + 0.5 * (p[last] * p[last]).sum(1)
+        st["dsyn_new"][last] = x[last]
+        rem[run] = rem[run] - 1
+        rem[last] = -1
+        st["done"][last] = 1
+
+
+ToyModel.flow_state = _toy_flow_state
+ToyModel.flow_step = _toy_flow_step
+
+
 def _bounds(n):
     return np.stack([np.full(n, -5.0), np.full(n, 5.0)], axis=1)
 
@@ -103,3 +145,19 @@ def test_result_store_layouts(tmp_path):
     big = _make("hmc", tmp_path / "big", per_chain_files=False)
     big.sample()
     assert sorted(os.listdir(tmp_path / "big")) == ["toy.rank1.npz"]
+
+
+@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
+def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
+    """sample_flow(): chains restarted one by one as they finish (continuous flow) give the samples of the batch
+    schedule -- exercised here on the toy model; the GPU suite repeats it on the HIP path."""
+    x0 = np.random.default_rng(5).uniform(0, 3, (5, 6))
+    a = _make(kind, tmp_path / "a"); ma = a.sample(x_init=x0)
+    b = _make(kind, tmp_path / "b"); mb = b.sample_flow(x_init=x0)
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.syndata, b.syndata)
+    assert np.array_equal(a.accept_ratio, b.accept_ratio)
+    if kind == "hmcda":
+        assert np.array_equal(a.dt_final, b.dt_final)
+    assert b.flow_steps > 0
+
