@@ -43,22 +43,35 @@ RFS_HD double rcp_p(double x) {
 // ---------------------------------------------------------------------------
 // exp(x) for |x| <= 700.  k = rint(x / ln 2), r = x - k ln2 in two FMA steps (|r| <= 0.3466), Taylor to
 // degree 13 (remainder < 4e-18 relative), scaled by 2^k.
+// Polynomial coefficients live in constant memory: on the device they arrive in SGPRs through scalar loads and are
+// used as the scalar operand of v_fma_f64, instead of costing one v_mov_b64 each on the vector ALU that these
+// sweeps saturate (VOP3 has no 64-bit literals on gfx9).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RFS_CONST_TABLE __device__ __constant__
+#else
+#define RFS_CONST_TABLE static const
+#endif
+RFS_CONST_TABLE double FM_EXP_C[12] = {                   // 1/13! ... 1/2!
+    1.6059043836821613e-10, 2.0876756987868100e-09, 2.5052108385441720e-08, 2.7557319223985893e-07,
+    2.7557319223985888e-06, 2.4801587301587302e-05, 1.9841269841269841e-04, 1.3888888888888889e-03,
+    8.3333333333333332e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, 0.5};
+RFS_CONST_TABLE double FM_SIN_C[6] = {                    // fdlibm S6 ... S1
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,
+    -1.98412698298579493134e-04, 8.33333333332248946124e-03, -1.66666666666666324348e-01};
+RFS_CONST_TABLE double FM_COS_C[6] = {                    // fdlibm C6 ... C1
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07,
+    2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02};
+RFS_CONST_TABLE double FM_RED_C[6] = {                    // log2(e), ln2 hi, ln2 lo | 2/pi, pi/2 hi, mid  (lo below)
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    6.36619772367581382433e-01, 1.57079632679489655800e+00, 6.12323399573676603587e-17};
+
 RFS_HD double fm_exp(double x) {
-    const double k = rint(x * 1.4426950408889634074);
-    double r = ::fma(-k, 6.93147180369123816490e-01, x);      // ln2 high part (fdlibm split)
-    r = ::fma(-k, 1.90821492927058770002e-10, r);             // ln2 low part
-    double p = 1.6059043836821613e-10;                        // 1/13!
-    p = ::fma(p, r, 2.0876756987868100e-09);                  // 1/12!
-    p = ::fma(p, r, 2.5052108385441720e-08);                  // 1/11!
-    p = ::fma(p, r, 2.7557319223985893e-07);                  // 1/10!
-    p = ::fma(p, r, 2.7557319223985888e-06);                  // 1/9!
-    p = ::fma(p, r, 2.4801587301587302e-05);                  // 1/8!
-    p = ::fma(p, r, 1.9841269841269841e-04);                  // 1/7!
-    p = ::fma(p, r, 1.3888888888888889e-03);                  // 1/6!
-    p = ::fma(p, r, 8.3333333333333332e-03);                  // 1/5!
-    p = ::fma(p, r, 4.1666666666666664e-02);                  // 1/4!
-    p = ::fma(p, r, 1.6666666666666666e-01);                  // 1/3!
-    p = ::fma(p, r, 0.5);
+    const double k = rint(x * FM_RED_C[0]);
+    double r = ::fma(-k, FM_RED_C[1], x);                     // ln2 high part (fdlibm split)
+    r = ::fma(-k, FM_RED_C[2], r);                            // ln2 low part
+    double p = FM_EXP_C[0];
+#pragma unroll
+    for (int i = 1; i < 12; i++) p = ::fma(p, r, FM_EXP_C[i]);
     p = ::fma(p, r, 1.0);
     p = ::fma(p, r, 1.0);
     return ldexp(p, (int)k);
@@ -69,24 +82,15 @@ RFS_HD double fm_exp(double x) {
 // one FMA; the split is good to 2^-160, so the reduction error stays below 1e-30 n), fdlibm's kernel polynomials
 // on |r| <= pi/4, quadrant fix-up by n mod 4.  NaN / inf in -> NaN out.
 RFS_HD void fm_sincos(double x, double* sn, double* cs) {
-    const double n = rint(x * 6.36619772367581382433e-01);
-    double r = ::fma(-n, 1.57079632679489655800e+00, x);      // pi/2 rounded to double
-    r = ::fma(-n, 6.12323399573676603587e-17, r);             // next 53 bits
+    const double n = rint(x * FM_RED_C[3]);
+    double r = ::fma(-n, FM_RED_C[4], x);                     // pi/2 rounded to double
+    r = ::fma(-n, FM_RED_C[5], r);                            // next 53 bits
     r = ::fma(-n, -1.49738490485916983294e-33, r);            // and the next
     const double z = r * r;
-    double ps = 1.58969099521155010221e-10;                   // S6
-    ps = ::fma(ps, z, -2.50507602534068634195e-08);           // S5
-    ps = ::fma(ps, z, 2.75573137070700676789e-06);            // S4
-    ps = ::fma(ps, z, -1.98412698298579493134e-04);           // S3
-    ps = ::fma(ps, z, 8.33333333332248946124e-03);            // S2
-    ps = ::fma(ps, z, -1.66666666666666324348e-01);           // S1
+    double ps = FM_SIN_C[0], pc = FM_COS_C[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++) { ps = ::fma(ps, z, FM_SIN_C[i]); pc = ::fma(pc, z, FM_COS_C[i]); }
     const double s0 = ::fma(ps * z, r, r);                    // r + r^3 (S1 + ...)
-    double pc = -1.13596475577881948265e-11;                  // C6
-    pc = ::fma(pc, z, 2.08757232129817482790e-09);            // C5
-    pc = ::fma(pc, z, -2.75573143513906633035e-07);           // C4
-    pc = ::fma(pc, z, 2.48015872894767294178e-05);            // C3
-    pc = ::fma(pc, z, -1.38888888888741095749e-03);           // C2
-    pc = ::fma(pc, z, 4.16666666666666019037e-02);            // C1
     const double c0 = ::fma(pc * z, z, ::fma(-0.5, z, 1.0));  // 1 - z/2 + z^2 (C1 + ...)
     const int q = (int)n & 3;
     const double ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
