@@ -111,3 +111,31 @@ def test_plugin_time_misfit_and_grad(hip, orc):
         m0, g0, d0_, f0 = jo.misfit_and_grad(xs[i])
         assert f0 == bool(f1[i]) and rel(d1[i], d0_) < 2e-6
         assert abs(m1[i] - m0) <= 1e-5 * m0 and rel(g1[i], g0) < 1e-5
+
+
+@pytest.mark.parametrize("nt,dt", [(10, 1.0), (33, 0.5), (1000, 0.05)])
+def test_time_domain_length_extremes(hip, orc, nt, dt):
+    """FFT lengths 16 (fewer lags than a wavefront), 64 and 1024 (8 lags per lane)."""
+    thk, vs = YAML7
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    q = np.full(len(vs), 9999.)
+    args = (thk, rho, vp, vs, q, q, 0.045, nt, dt, 1.5, 3.0, "time", 0.001, "P")
+    rf0, kl0 = orc.librf.kernel_all(*args)
+    rf1, kl1 = hip.librf.kernel_all(*args)
+    assert rel(rf1, rf0) < 1e-8
+    for ip in range(4):
+        for j in range(len(vs)):
+            assert rel(kl1[ip, j], kl0[ip, j]) < 1e-7 or not np.any(kl0[ip, j]), (ip, j, rel(kl1[ip, j], kl0[ip, j]))
+
+
+def test_time_domain_two_layers_and_many_layers(hip, orc):
+    q2 = np.full(2, 9999.)
+    thk, vs = np.array([20.0, 0.0]), np.array([3.2, 4.4])
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    a = (thk, rho, vp, vs, q2, q2, 0.05, 64, 0.4, 1.5, 3.0, "time", 0.001, "P")
+    assert rel(hip.librf.kernel_all(*a)[1], orc.librf.kernel_all(*a)[1]) < 1e-7
+    n = 40
+    thk = np.full(n, 1.5); thk[-1] = 0; vs = np.linspace(2.6, 4.6, n)
+    vp, rho, _, _ = orc.empirical_relation(vs); q = np.full(n, 9999.)
+    a = (thk, rho, vp, vs, q, q, 0.045, 128, 0.2, 1.5, 5.0, "time", 0.001, "P")
+    assert rel(hip.librf.forward(*a), orc.librf.forward(*a)) < 1e-8
