@@ -1,0 +1,86 @@
+"""-m gpu: BASELINE.json configs[1] at FULL size (8192 chains x 30 layers, RF 512 samples + 40 Rayleigh periods, the
+bench workload) through properties that do not need 8192 oracle evaluations: batch invariance, permutation
+equivariance, spot checks against the oracle, directional derivatives, and the device-pointer / host-pointer entries
+agreeing."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def full():
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    t = np.linspace(5, 44, bench.NPER)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT, bench.WATER,
+                                                "P", "freq"), SurfWD(tRc=t))
+    drf, dswd, flag = joint.forward(bench.true_model())
+    assert flag
+    joint.set_obsdata(drf, dswd)
+    xs = bench.make_models(8192, 991206)
+    out = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(xs).cuda())]
+    return joint, xs, out, t, (drf, dswd)
+
+
+def test_full_batch_is_sane(full):
+    joint, xs, (mis, grad, dsyn, flag), t, _ = full
+    assert mis.shape == (8192,) and grad.shape == (8192, 60) and dsyn.shape == (8192, 552)
+    assert flag.all() and np.isfinite(mis).all() and np.isfinite(grad).all() and np.isfinite(dsyn).all()
+    assert np.all(mis > 0)
+    c = dsyn[:, 512:]
+    assert np.all(c > 1.0) and np.all(c < 5.0)                 # phase velocities of crustal models, km/s
+    assert np.array_equal(c, c.astype(np.float32).astype(np.float64))      # float32-rounded roots (surfdisp96.f:302)
+
+
+def test_batch_invariance_and_permutation(full):
+    """A chain's result does not depend on which other chains share the batch, its position, or the entry point."""
+    import torch
+    joint, xs, (mis, grad, dsyn, flag), t, _ = full
+    sub = np.r_[0:64, 4000:4064, 8128:8192]
+    o = [a.cpu().numpy() for a in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[sub])).cuda())]
+    assert np.array_equal(o[0], mis[sub]) and np.array_equal(o[1], grad[sub]) and np.array_equal(o[2], dsyn[sub])
+    perm = np.random.default_rng(0).permutation(8192)
+    o = [a.cpu().numpy() for a in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[perm])).cuda())]
+    assert np.array_equal(o[0], mis[perm]) and np.array_equal(o[1], grad[perm]) and np.array_equal(o[3], flag[perm])
+    m2, g2, d2, f2 = joint.misfit_and_grad(xs)                  # host-pointer entry (shared-CU schedule)
+    assert np.array_equal(m2, mis) and np.array_equal(g2, grad) and np.array_equal(d2, dsyn)
+
+
+def test_spot_checks_against_the_oracle(full, orc):
+    joint, xs, (mis, grad, dsyn, flag), t, (drf, dswd) = full
+    import bench
+    jo = orc.Joint_RF_SWD(1.0, 1.0, orc.ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT,
+                                                     bench.WATER, "P", "freq"), orc.SurfWD(tRc=t))
+    jo.set_obsdata(drf, dswd)
+    for i in (0, 1, 63, 64, 4095, 4096, 8000, 8191):
+        m0, g0, d0, f0 = jo.misfit_and_grad(xs[i])
+        assert f0
+        assert rel(dsyn[i], d0) < 1e-6                          # synthetics: float32 root rounding only
+        assert abs(mis[i] - m0) <= 1e-5 * m0                    # the north-star tolerance
+        assert rel(grad[i], g0) < 1e-5, (i, rel(grad[i], g0))
+
+
+def test_directional_derivatives(full):
+    """misfit(x + h v) - misfit(x - h v) = 2 h grad.v: the analytic gradient is the derivative of the misfit the same
+    kernels return (RF part smooth; the SWD synthetics are float32-rounded, so h is chosen well above 1e-7 / h noise)."""
+    import torch
+    joint, xs, (mis, grad, dsyn, flag), t, _ = full
+    rng = np.random.default_rng(1)
+    idx = rng.choice(8192, 256, replace=False)
+    v = rng.standard_normal((256, 60)); v[:, 59] = 0.0          # the half-space thickness is a dummy
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    h = 5e-4
+    mp = joint.misfit_and_grad_device(torch.from_numpy(xs[idx] + h * v).cuda())[0].cpu().numpy()
+    mm = joint.misfit_and_grad_device(torch.from_numpy(xs[idx] - h * v).cuda())[0].cpu().numpy()
+    fd = (mp - mm) / (2 * h)
+    an = np.sum(grad[idx] * v, axis=1)
+    err = np.abs(fd - an) / np.maximum(np.abs(an), 1e-3 * np.linalg.norm(grad[idx], axis=1))
+    assert np.median(err) < 5e-3 and np.quantile(err, 0.95) < 5e-2, (np.median(err), np.quantile(err, 0.95))
