@@ -98,10 +98,23 @@ int ensure(rfs_ctx* c, Buf& b, size_t bytes) {
 #define ENSURE(c, b, bytes) do { int r_ = ensure(c, b, bytes); if (r_) return r_; } while (0)
 #define TRY(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
 
+void drop_plans(rfs_ctx* c) {
+    for (auto& kv : c->plans) {
+        if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
+        if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
+        if (kv.second.work) hipFree(kv.second.work);
+    }
+    c->plans.clear();
+}
+
 int get_plan(rfs_ctx* c, int nft, size_t batch, int inverse, FftPlan** out) {
     auto key = std::make_tuple(nft, batch, inverse);
     auto it = c->plans.find(key);
     if (it == c->plans.end()) {
+        if (c->plans.size() >= 64) {       // callers quantise their batch sizes; this only bounds pathological use
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            drop_plans(c);
+        }
         if (!g_rocfft_ready) { FFTCHK(c, rocfft_setup()); g_rocfft_ready = true; }
         FftPlan P;
         rocfft_plan_description d = nullptr;
@@ -296,15 +309,16 @@ int rft_launch_deconv(rfs_ctx* c, int ntrace, int tpc, const RfFreq& f, const do
 // after pass A: chain-level spectra + their inverse transforms, forward-trace deconvolution, rf(t) -> out
 int rft_forward(rfs_ctx* c, int nchain, const RfFreq& f, double* out, size_t ostride) {
     const size_t nft = f.nft, half = nft / 2;
-    ENSURE(c, c->spec3, (size_t)nchain * 3 * f.n2 * sizeof(cplx));
-    ENSURE(c, c->ts3, (size_t)nchain * 3 * nft * sizeof(double));
+    const size_t nb = nchain > 256 ? ((size_t)nchain + 255) / 256 * 256 : (size_t)nchain;    // see launch_mid
+    ENSURE(c, c->spec3, nb * 3 * f.n2 * sizeof(cplx));
+    ENSURE(c, c->ts3, nb * 3 * nft * sizeof(double));
     ENSURE(c, c->S0f, (size_t)nchain * sizeof(double));
     ENSURE(c, c->Pbuf, (size_t)nchain * half * sizeof(double));
     TRY(rft_pulse(c, f));
     hipLaunchKernelGGL(k_rft_chain_spectra, dim3(nchain), dim3(256), 0, c->stream, f, c->RR.as<double>(),
                        c->spec3.as<cplx>(), c->S0f.as<double>());
     HIPCHK(c, hipGetLastError());
-    TRY(run_fft(c, f.nft, (size_t)nchain * 3, 1, c->spec3.p, c->ts3.p));
+    TRY(run_fft(c, f.nft, nb * 3, 1, c->spec3.p, c->ts3.p));
     TRY(rft_launch_deconv<1>(c, nchain, 1, f, c->ts3.as<double>() + nft, 3 * nft, c->ts3.as<double>(), 3 * nft,
                              c->S0f.as<double>(), 1, 1, 0, nullptr, c->Pbuf.as<double>(), nullptr));
     size_t lds = (nft + half + half / 2 + 1) * sizeof(double);
@@ -649,11 +663,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
-    for (auto& kv : c->plans) {
-        if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
-        if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
-        if (kv.second.work) hipFree(kv.second.work);
-    }
+    drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream2m) hipStreamDestroy(c->stream2m);
