@@ -139,3 +139,54 @@ def load_checkpoint(path, rng: ChainRNG):
     rng.set_state(z)
     return {k: z[k] for k in z.files if not k.startswith("rng_")}
 
+
+def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True):
+    """Drive model.flow_step (rfs_flow_step) until ``active()`` is False.
+
+    After every step the chains that finished a trajectory are handed to ``process_done(idx, res)`` (host side:
+    accept / reject, bookkeeping, RNG draws), which returns ``(xkeep[len(idx), nx], restart)`` with ``restart`` either
+    None or a dict(idx=..., p=..., rem=..., dt=optional) for the chains that start another trajectory.
+    pipeline=True: step s+1 is launched BEFORE the results of step s are processed, so the host work (one Python
+    loop over the finished chains with per-chain RNG streams) overlaps the GPU step; the chains that finished at
+    step s sit out step s+1 and restart with step s+2.  Each chain still sees exactly the same sequence of
+    trajectories and draws, so the samples do not depend on ``pipeline``.  Returns the number of device steps."""
+    import torch
+    dev = st["x"].device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def fetch():
+        idx = np.nonzero(st["done"].cpu().numpy())[0]
+        if len(idx) == 0:
+            return idx, None
+        sel = t(idx)
+        keys = ["ok", "Hcur", "Hnew", "Unew", "Ucur", "x"] + (["dsyn_new"] if fetch_syn else [])
+        res = {k: st[k].index_select(0, sel).cpu().numpy() for k in keys}
+        return idx, res
+
+    def apply(idx, xkeep, restart):
+        st["x"].index_copy_(0, t(idx), t(xkeep))
+        if restart is not None and len(restart["idx"]):
+            rs = t(np.asarray(restart["idx"]))
+            st["p"].index_copy_(0, rs, t(restart["p"]))
+            st["rem"].index_copy_(0, rs, t(np.asarray(restart["rem"], dtype=np.int32)))
+            if restart.get("dt") is not None:
+                st["dt"].index_copy_(0, rs, t(np.asarray(restart["dt"], dtype=np.float64)))
+            st["fresh"].index_fill_(0, rs, 1)
+            st["ok"].index_fill_(0, rs, 1)
+
+    steps = 0
+    model.flow_step(st); steps += 1
+    while True:
+        idx, res = fetch()                       # synchronises with the step just launched
+        more = active() or len(idx) > 0
+        if pipeline and more:
+            model.flow_step(st); steps += 1      # the finished chains idle in this step (rem = -1, fresh = 0)
+        if len(idx):
+            xkeep, restart = process_done(idx, res)
+            apply(idx, xkeep, restart)           # stream-ordered after the step launched above
+        if not active():
+            break
+        if not pipeline:
+            model.flow_step(st); steps += 1
+    return steps
+

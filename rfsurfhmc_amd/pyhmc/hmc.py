@@ -11,8 +11,8 @@ import sys
 
 import numpy as np
 
-from ._batched import (ChainRNG, initial_models, load_checkpoint, save_batched_results, save_chain_results,
-                       save_checkpoint)
+from ._batched import (ChainRNG, initial_models, load_checkpoint, run_flow, save_batched_results,
+                       save_chain_results, save_checkpoint)
 
 
 class HamitonianMC:
@@ -82,7 +82,7 @@ class HamitonianMC:
                                    Hnew=Hnew, u=u, ok=ok, accept=accept, xres=xres.copy(), Ures=Ures.copy()))
         return xres, Ures, dres, accept
 
-    def sample_flow(self, x_init=None):
+    def sample_flow(self, x_init=None, pipeline=True):
         """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
         chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
         chain at its own point of its own trajectory (rfs_flow_step), and a chain that finishes a trajectory is
@@ -107,19 +107,10 @@ class HamitonianMC:
         L = self.rng.randint(allc, self.Lrange[0], self.Lrange[1] + 1)          # hmc.py:248, then :146
         st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
         st["rem"].copy_(t(L.astype(np.int32))); st["fresh"].fill_(1)
-        self.flow_steps = 0
-        while np.any(i < total):
-            self.model.flow_step(st)
-            self.flow_steps += 1
-            idx = np.nonzero(st["done"].cpu().numpy())[0]
-            if len(idx) == 0:
-                continue
-            sel = t(idx)
-            ok = st["ok"].index_select(0, sel).cpu().numpy().astype(bool)
-            Hcur = st["Hcur"].index_select(0, sel).cpu().numpy(); Hnew = st["Hnew"].index_select(0, sel).cpu().numpy()
-            Unew = st["Unew"].index_select(0, sel).cpu().numpy(); Ucur = st["Ucur"].index_select(0, sel).cpu().numpy()
-            xend = st["x"].index_select(0, sel).cpu().numpy()
-            dnew = st["dsyn_new"].index_select(0, sel).cpu().numpy() if syndata is not None else None
+        def process_done(idx, res):
+            ok = res["ok"].astype(bool)
+            Hcur, Hnew, Unew, Ucur, xend = res["Hcur"], res["Hnew"], res["Unew"], res["Ucur"], res["x"]
+            dnew = res.get("dsyn_new")
             u = np.full(len(idx), np.nan)
             u[ok] = self.rng.rand([int(c) for c in idx[ok]])                    # hmc.py:193, skipped on failure
             with np.errstate(over="ignore", invalid="ignore"):
@@ -145,15 +136,16 @@ class HamitonianMC:
                         print("chain {}: {:.2%}, misfit={:.3} -- accept ratio {:.2%}".format(
                             self.first_chain + c, i[c] / total, Uc, i[c] / ncount[c]))
                 sys.stdout.flush()
-            # every finished chain goes back to the model it keeps (accepted end point or its start model) ...
-            st["x"].index_copy_(0, sel, t(x[idx]))
-            if restart:                                                         # ... and the unfinished ones restart
-                rs = t(np.array(restart))
+            # every finished chain goes back to the model it keeps (accepted end point or its start model) and the
+            # unfinished ones restart: randint(L) then randn(p0), the reference's draw order (hmc.py:248, :146)
+            rs = None
+            if restart:
                 Lr = self.rng.randint(restart, self.Lrange[0], self.Lrange[1] + 1)
-                st["p"].index_copy_(0, rs, t(self.rng.randn(restart, nx) * 0.5))
-                st["rem"].index_copy_(0, rs, t(Lr.astype(np.int32)))
-                st["fresh"].index_fill_(0, rs, 1)
-                st["ok"].index_fill_(0, rs, 1)
+                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * 0.5, rem=Lr)
+            return x[idx], rs
+
+        self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
+                                   fetch_syn=syndata is not None, pipeline=pipeline)
         self.finished = True
         return self._finish(misfit, x_cache, syndata, i, ncount)
 

@@ -7,8 +7,8 @@ import sys
 
 import numpy as np
 
-from ._batched import (ChainRNG, initial_models, load_checkpoint, save_batched_results, save_chain_results,
-                       save_checkpoint)
+from ._batched import (ChainRNG, initial_models, load_checkpoint, run_flow, save_batched_results,
+                       save_chain_results, save_checkpoint)
 
 
 def _mirror(x, p, boundaries):
@@ -208,7 +208,101 @@ class HMCDualAveraging:
                                        None if syndata is None else syndata[c])
         return misfit[0] if nc == 1 else misfit
 
-    def sample_flow(self, x_init=None):
+    def sample_flow(self, x_init=None, pipeline=True):
+        """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
+        every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
+        (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
+        order (momentum at the start of a trajectory, the acceptance draw at its end)."""
+        import torch
+        nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        dev = self._device()
+        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+        self.initmodel = x.copy()
+        nx = x.shape[1]
+        ndata = self.model.dobs.shape[0]
+        mu = np.log(10 * self.dt)
+        total = nd_ + ns
+        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+        dt = self._find_initial_dt(self.dt, x)
+        dtbar = dt * 1.0
+        h0 = np.full(nc, self._h0)
+        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
+        allc = list(range(nc))
+        st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
+        st["rem"].copy_(t(np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)))
+        st["fresh"].fill_(1)
+        def process_done(idx, res):
+            ok = res["ok"].astype(bool)
+            Hcur, Hnew, xend = res["Hcur"], res["Hnew"], res["x"]
+            Unew = np.where(ok, res["Unew"], np.inf)
+            dnew = res.get("dsyn_new")
+            with np.errstate(over="ignore", invalid="ignore"):
+                alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
+            u = self.rng.rand([int(c) for c in idx])
+            acc = u < alpha
+            for k, c in enumerate(idx):
+                if acc[k]:
+                    x[c] = xend[k]
+                    if i[c] >= nd_:
+                        misfit[c, i[c] - nd_] = Unew[k]; x_cache[c, i[c] - nd_] = xend[k]
+                        if syndata is not None:
+                            syndata[c, i[c] - nd_] = dnew[k] if ok[k] else self.model.dobs
+                    i[c] += 1; self.ii += 1
+            # dual averaging for the chains that just finished a trajectory (hmcda.py:329-345)
+            adapt = ncount[idx] < nd_
+            m = ncount[idx] + 1.0
+            fac = 1.0 / (m + self._t0)
+            h_new = (1 - fac) * h0[idx] + fac * (self.delta - alpha)
+            logdt = mu - np.sqrt(m) / self._gamma * h_new
+            fac2 = m ** (-self._kappa)
+            dtbar_new = np.exp(fac2 * logdt + (1 - fac2) * np.log(dtbar[idx]))
+            h0[idx] = np.where(adapt, h_new, h0[idx])
+            dt[idx] = np.where(adapt, np.exp(logdt), dtbar[idx])
+            dtbar[idx] = np.where(adapt, dtbar_new, dtbar[idx])
+            ncount[idx] += 1
+            if self.verbose:
+                for k, c in enumerate(idx):
+                    if i[c] % 50 == 0 or i[c] == ns - 1:
+                        print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
+                            self.first_chain + c, i[c] / total, dt[c], Unew[k], i[c] / ncount[c]))
+                sys.stdout.flush()
+            restart = [int(c) for c in idx if i[c] < total]
+            rs = None
+            if restart:
+                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * 0.5, dt=dt[restart],
+                          rem=np.maximum(1, (self._lambda / dt[restart]).astype(int)))
+            return x[idx], rs
+
+        self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
+                                   fetch_syn=syndata is not None, pipeline=pipeline)
+        self.finished = True
+        return self._finish(misfit, x_cache, syndata, i, ncount, dt)
+
+    def _finish(self, misfit, x_cache, syndata, i, ncount, dt):
+        nc, nx = self.nchains, x_cache.shape[2]
+        self.dt_final, self.accept_ratio = dt, i / np.maximum(ncount, 1)
+        nbests = 10                                                           # hard-coded, hmcda.py:359
+        xmean = np.zeros((nc, nx))
+        for c in range(nc):
+            idx = np.argsort(misfit[c])
+            xmean[c] = np.mean(x_cache[c, idx[:nbests]], axis=0)
+        synmean = self.model.misfit_and_grad(xmean)[2]
+        self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
+        if self.outdir is not None:
+            self.result_file = save_batched_results(self.outdir, self.name, self.myrank, self.first_chain,
+                                                    self.initmodel, self.model.dobs, xmean, synmean, x_cache,
+                                                    syndata, misfit)
+            if self.per_chain_files:
+                for c in range(nc):
+                    save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c],
+                                       self.model.dobs, xmean[c], synmean[c], x_cache[c],
+                                       None if syndata is None else syndata[c])
+        return misfit[0] if nc == 1 else misfit
+
+    def sample_flow(self, x_init=None, pipeline=True):
         """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
         every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
         (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's

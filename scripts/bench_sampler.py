@@ -39,11 +39,11 @@ from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 x_start = np.clip(x0[None, :] * (1 + 0.02 * np.random.default_rng(3).standard_normal((nchain, 2 * n))), lo, hi)
 x_start[:, :n] = np.sort(x_start[:, :n], axis=1)
-for mode in ("batch", "flow"):
+for mode in ("batch", "flow-serial", "flow"):
     s = HamitonianMC(joint, bounds, 0.002, [5, 20], 2, 991206, ns, 1, myrank=0, name="b", outdir=None,
                      nchains=nchain, verbose=False, store_syn=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    mis = s.sample(x_init=x_start) if mode == "batch" else s.sample_flow(x_init=x_start)
+    mis = s.sample(x_init=x_start) if mode == "batch" else s.sample_flow(x_init=x_start, pipeline=(mode == "flow"))
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     print(mode, "%.1f s for %d accepted samples x %d chains" % (el, ns + 1, nchain), "accept ratio %.2f" % s.accept_ratio.mean(),
           "" if mode == "batch" else "flow steps %d" % s.flow_steps, "checksum %.9e" % mis.sum())

@@ -154,7 +154,8 @@ def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
     x0 = np.random.default_rng(5).uniform(0, 3, (5, 6))
     a = _make(kind, tmp_path / "a"); ma = a.sample(x_init=x0)
     b = _make(kind, tmp_path / "b"); mb = b.sample_flow(x_init=x0)
-    assert np.array_equal(ma, mb)
+    c = _make(kind, tmp_path / "c"); mc = c.sample_flow(x_init=x0, pipeline=False)
+    assert np.array_equal(ma, mb) and np.array_equal(ma, mc) and c.flow_steps <= b.flow_steps
     assert np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.syndata, b.syndata)
     assert np.array_equal(a.accept_ratio, b.accept_ratio)
     if kind == "hmcda":
