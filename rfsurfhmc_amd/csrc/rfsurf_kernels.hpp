@@ -887,7 +887,7 @@ __global__ void k_swd_export(int nchain, int n, SwdRows R, const double* __restr
 // ---------------------------------------------------------------------------------------
 // K5 split in two so that every large array is read coalesced:
 //   k_rf_reduce   block = chain, thread = layer : fixed-order sum of the pass-B partials + chain rule -> grad
-//   k_swd_combine block = 64 chains x 4 layer groups, lane = chain : K.r over the periods (krn is chain-minor),
+//   k_swd_combine block = 64 chains x 16 layer groups (0.37 -> 0.17 ms against 4: the grid is only nchain/64 blocks), lane = chain : K.r over the periods (krn is chain-minor),
 //                 interface -> thickness suffix sums, weighting, misfit, failure returns
 // mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198), 2 SWD only (model_surf.py:155-228)
 __global__ void __launch_bounds__(MAXL)
@@ -911,7 +911,7 @@ k_rf_reduce(int nchain, int n, int rf_only, int npart, const double* __restrict_
 }
 
 template <bool SPH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const double* __restrict__ misfit_rf,
               const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
               const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
