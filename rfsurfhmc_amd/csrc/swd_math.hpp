@@ -221,12 +221,19 @@ RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, doub
         cs = (1.0 + fac) * 0.5;
         sn = (1.0 - fac) * 0.5;
     }
-    const bool deg = (wvno == xk);                     // v = 0: ir = inf, r = p = NaN above
-    cosx = deg ? 1.0 : cs;
-    w = deg ? dpth : sn * ir;
-    x = deg ? 0.0 : (osc ? -r : r) * sn;
-    ex = (osc || deg) ? 0.0 : p;
-    if (deg) eh = 1.0;
+    cosx = cs;
+    w = sn * ir;
+    x = (osc ? -r : r) * sn;
+    ex = osc ? 0.0 : p;
+    // wvno == xk exactly (v = 0: ir = inf, r = p = NaN above): the reference's middle branch.  On the device the
+    // fix-up is skipped wave-wide unless some lane needs it, which keeps ~20 selects out of the producers' hot loop.
+    const bool deg = (wvno == xk);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__any(deg))
+#endif
+    {
+        if (deg) { cosx = 1.0; w = dpth; x = 0.0; ex = 0.0; eh = 1.0; }
+    }
 }
 
 RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega,
