@@ -170,6 +170,11 @@ int rfs_flow_step(rfs_ctx* ctx, int nchain, double* x, double* p, const double* 
                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                   double* dsyn_new, int32_t* ok, int32_t* done);
 
+/* Diagonal inverse mass matrix of the leapfrog entries above (rfs_leapfrog_dev / dev2, rfs_flow_step): drift
+ * x += dt * minv * p, kinetic energy p.minv.p / 2; the caller draws p ~ N(0, M).  minv: HOST [2*nlayer], NULL =
+ * identity (the reference's `invert_Mass`, pyhmc/hmc.py:48).  Reset by rfs_joint_setup. */
+int rfs_set_inverse_mass(rfs_ctx* ctx, const double* minv);
+
 /* -------- introspection ---------------------------------------------------------------- */
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):

@@ -50,6 +50,7 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL;   // per-family search models / bldsph arrays (sphere, Love)
@@ -657,7 +658,7 @@ void rfs_destroy(rfs_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     Buf* bufs[] = {&c->d_tw[0], &c->d_tw[1], &c->d_tw[2], &c->d_tw[3], &c->mdlSR, &c->mdlL, &c->sphR, &c->sphL, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
-                   &c->spec3, &c->ts3, &c->S0f, &c->S0p, &c->pulse_spec, &c->pulse_ts, &c->Pbuf, &c->Cres,
+                   &c->d_minv, &c->spec3, &c->ts3, &c->S0f, &c->S0p, &c->pulse_spec, &c->pulse_ts, &c->Pbuf, &c->Cres,
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
                    &c->croot, &c->sflag, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
@@ -900,6 +901,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
     c->n = nlayer; c->has_rf = rf != nullptr; c->has_swd = nswd > 0;
     c->mode = (c->has_rf && c->has_swd) ? 0 : (c->has_rf ? 1 : 2);
     c->sphere = sphere;
+    c->has_minv = false;
     int nt = 0;
     if (rf) { c->f = make_freq(*rf, 0); nt = rf->nt; }
     c->ndata = nt + nswd;
@@ -1033,8 +1035,9 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
     double *x = c->lx.as<double>(), *p = c->lp.as<double>(), *U = c->lU.as<double>(), *g = c->lgrad.as<double>(),
            *d = c->ldsyn.as<double>();
     int* fl = c->lflag.as<int>();
+    const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
     TRY(joint_eval(c, nchain, x0, U, g, d, fl));
-    hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, x0, p0, dt, U, g, d, fl, x, p,
+    hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, x0, p0, dt, U, g, d, fl, x, p,
                        Ucur, Hcur, Unew, dsyn_cur, dsyn_new, ok);
     // failed chains keep xnew = x0, Hnew = +inf (reference returns (xcur, inf, dobs, False))
     HIPCHK(c, hipMemcpyAsync(xnew, x0, (size_t)nchain * nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1042,12 +1045,25 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
         // chains sorted by decreasing L: only the first nactive[step] are still inside their trajectory
         const int na = nactive ? nactive[step] : nchain;
         const int nth = na * nx;
-        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, na, nx, step, dt, L, bounds, x, p, ok);
+        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, na, nx, step, minv, dt, L, bounds, x, p, ok);
         TRY(joint_eval(c, na, x, U, g, d, fl));
-        hipLaunchKernelGGL(k_leap_kick, dim3(na), dim3(64), 0, c->stream, na, nx, nd, step, dt, L, x, U, g, d, fl, p,
+        hipLaunchKernelGGL(k_leap_kick, dim3(na), dim3(64), 0, c->stream, na, nx, nd, step, minv, dt, L, x, U, g, d, fl, p,
                            Unew, Hnew, dsyn_new, xnew, ok);
     }
     HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+int rfs_set_inverse_mass(rfs_ctx* c, const double* minv) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    if (!minv) { c->has_minv = false; return RFS_OK; }
+    for (int i = 0; i < 2 * c->n; i++)
+        if (!(minv[i] > 0.0) || minv[i] > 1.0e300) return fail(c, RFS_ERR_ARG, "inverse masses must be positive and finite");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(upload(c, c->d_minv, minv, (size_t)2 * c->n * sizeof(double)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->has_minv = true;
     return RFS_OK;
 }
 
@@ -1065,9 +1081,10 @@ int rfs_flow_step(rfs_ctx* c, int nchain, double* x, double* p, const double* dt
     double *U = c->lU.as<double>(), *g = c->lgrad.as<double>(), *d = c->ldsyn.as<double>();
     int* fl = c->lflag.as<int>();
     const int nth = nchain * nx;
-    hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, dt, rem, fresh, ok, bounds, x, p);
+    const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
+    hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p);
     TRY(joint_eval(c, nchain, x, U, g, d, fl));
-    hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, dt, x, U, g, d, fl, p, rem, fresh,
+    hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;

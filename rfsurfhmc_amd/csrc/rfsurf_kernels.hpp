@@ -1006,7 +1006,9 @@ __global__ void k_swd_forward_out(int nchain, int nt, SwdRows R, const double* _
 // K6 leapfrog pieces (pyhmc/hmc.py:121-201).  One thread per (chain, component) / per chain.
 // state: 1 = running, 0 = failed (reference returns early), frozen chains keep their result.
 // ---------------------------------------------------------------------------------------
-__global__ void k_leap_begin(int nchain, int nx, int ndata, const double* x0, const double* p0, const double* dt,
+// minv (may be null = identity): diagonal inverse mass, x' = M^-1 p and K = p.M^-1 p / 2 (the reference carries an
+// identity `invert_Mass` that only enters its kinetic energy, pyhmc/hmc.py:48,102-108).
+__global__ void k_leap_begin(int nchain, int nx, int ndata, const double* minv, const double* x0, const double* p0, const double* dt,
                              const double* U, const double* grad, const double* dsyn, const int* flag,
                              double* x, double* p, double* Ucur, double* Hcur, double* Unew,
                              double* dsyn_cur, double* dsyn_new, int* ok)
@@ -1025,7 +1027,7 @@ __global__ void k_leap_begin(int nchain, int nx, int ndata, const double* x0, co
     }
     for (int i = tid; i < nx; i += blockDim.x) {
         double pv = p0[(size_t)chain * nx + i];
-        k += pv * pv;
+        k += pv * pv * (minv ? minv[i] : 1.0);
         x[(size_t)chain * nx + i] = x0[(size_t)chain * nx + i];
         p[(size_t)chain * nx + i] = pv - dt[chain] * grad[(size_t)chain * nx + i] * 0.5;   // hmc.py:164
     }
@@ -1045,14 +1047,14 @@ __global__ void k_leap_begin(int nchain, int nx, int ndata, const double* x0, co
 
 // x += dt p ; mirror reflection at the bounds (hmc.py:121-137, 166-169); only chains still
 // inside their trajectory (step < L) and not failed move.
-__global__ void k_leap_drift(int nchain, int nx, int step, const double* dt, const int* L, const double* bounds,
-                             double* x, double* p, int* ok)
+__global__ void k_leap_drift(int nchain, int nx, int step, const double* minv, const double* dt, const int* L,
+                             const double* bounds, double* x, double* p, int* ok)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nx) return;
     int chain = g / nx, i = g - chain * nx;
     if (!ok[chain] || step >= L[chain]) return;
-    double xv = x[g] + dt[chain] * p[g], pv = p[g];
+    double xv = x[g] + dt[chain] * (p[g] * (minv ? minv[i] : 1.0)), pv = p[g];
     double lo = bounds[2 * i], hi = bounds[2 * i + 1];
     for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
         if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
@@ -1062,7 +1064,7 @@ __global__ void k_leap_drift(int nchain, int nx, int step, const double* dt, con
 }
 
 // kick after the evaluation at the new x (hmc.py:170-183); finishes the trajectory at step L-1
-__global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const double* dt, const int* L,
+__global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const double* minv, const double* dt, const int* L,
                             const double* x, const double* U, const double* grad, const double* dsyn,
                             const int* flag, double* p, double* Unew, double* Hnew, double* dsyn_new,
                             double* xnew, int* ok)
@@ -1091,7 +1093,7 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
     for (int i = tid; i < nx; i += blockDim.x) {
         double pv = p[(size_t)chain * nx + i] - dt[chain] * grad[(size_t)chain * nx + i] * (last ? 0.5 : 1.0);
         p[(size_t)chain * nx + i] = pv;
-        k += pv * pv;
+        k += pv * pv * (minv ? minv[i] : 1.0);
         if (last) xnew[(size_t)chain * nx + i] = x[(size_t)chain * nx + i];
     }
     if (last) for (int i = tid; i < ndata; i += blockDim.x)
@@ -1112,14 +1114,14 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
 // evaluation per chain.  rem[chain] = leapfrog steps still to do (-1: idle), fresh[chain] = 1: the trajectory starts
 // with this call (x = start model, p = drawn momentum).  Same arithmetic as k_leap_begin / drift / kick.
 // ---------------------------------------------------------------------------------------
-__global__ void k_flow_pre(int nchain, int nx, const double* dt, const int* rem, const int* fresh, const int* ok,
+__global__ void k_flow_pre(int nchain, int nx, const double* minv, const double* dt, const int* rem, const int* fresh, const int* ok,
                            const double* bounds, double* x, double* p)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nx) return;
     int chain = g / nx, i = g - chain * nx;
     if (fresh[chain] || rem[chain] <= 0 || !ok[chain]) return;
-    double xv = x[g] + dt[chain] * p[g], pv = p[g];
+    double xv = x[g] + dt[chain] * (p[g] * (minv ? minv[i] : 1.0)), pv = p[g];
     double lo = bounds[2 * i], hi = bounds[2 * i + 1];
     for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
         if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
@@ -1128,7 +1130,7 @@ __global__ void k_flow_pre(int nchain, int nx, const double* dt, const int* rem,
     x[g] = xv; p[g] = pv;
 }
 
-__global__ void k_flow_post(int nchain, int nx, int ndata, const double* dt, const double* x, const double* U,
+__global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, const double* x, const double* U,
                             const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
                             double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                             double* dsyn_new, int* ok, int* done)
@@ -1157,7 +1159,7 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* dt, con
         double k = 0.0;
         for (int i = tid; i < nx; i += blockDim.x) {
             double pv = p[(size_t)chain * nx + i];
-            k += pv * pv;
+            k += pv * pv * (minv ? minv[i] : 1.0);
             p[(size_t)chain * nx + i] = pv - dt[chain] * grad[(size_t)chain * nx + i] * 0.5;
         }
         for (int i = tid; i < ndata; i += blockDim.x) {
@@ -1185,7 +1187,7 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* dt, con
     for (int i = tid; i < nx; i += blockDim.x) {
         double pv = p[(size_t)chain * nx + i] - dt[chain] * grad[(size_t)chain * nx + i] * (last ? 0.5 : 1.0);
         p[(size_t)chain * nx + i] = pv;
-        k += pv * pv;
+        k += pv * pv * (minv ? minv[i] : 1.0);
     }
     if (last) for (int i = tid; i < ndata; i += blockDim.x)
         dsyn_new[(size_t)chain * ndata + i] = dsyn[(size_t)chain * ndata + i];

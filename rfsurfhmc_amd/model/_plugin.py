@@ -135,6 +135,20 @@ class FusedPlugin:
             out = {k: v.index_select(0, inv) for k, v in out.items()}
         return out
 
+    def set_inverse_mass(self, minv, nlayer=None):
+        """Diagonal inverse mass of the device leapfrog (rfs_set_inverse_mass): minv[2n] > 0, or None for the
+        reference's identity.  Has to be set again after set_obsdata / a change of layer count (the context is
+        reconfigured then)."""
+        if minv is None:
+            self._minv = None
+            if self._ctx is not None and getattr(self, "_cfg", None) is not None:
+                self._ctx.check(self._ctx.L.rfs_set_inverse_mass(self._ctx.h, None))
+            return
+        m = np.ascontiguousarray(np.asarray(minv, dtype=np.float64))
+        ctx = self._ensure(len(m) // 2 if nlayer is None else nlayer)
+        ctx.check(ctx.L.rfs_set_inverse_mass(ctx.h, hptr(m)))
+        self._minv = m
+
     def flow_step(self, st):
         """One call of rfs_flow_step on the state dict ``st`` (CUDA tensors x, p, dt, rem, fresh, bounds, Ucur, Hcur,
         Unew, Hnew, dsyn_cur, dsyn_new, ok, done -- see include/rfsurf.h): one evaluation per chain, every chain at

@@ -18,7 +18,7 @@ from ._batched import (ChainRNG, initial_models, load_checkpoint, run_flow, save
 class HamitonianMC:
     def __init__(self, UserDefinedModel, boundaries, dt, Lrange, nbest_model, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
-                 per_chain_files=None, checkpoint=None, checkpoint_every=0):
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None):
         self.myrank = myrank
         self.nchains = int(nchains)
         self.first_chain = myrank * self.nchains
@@ -36,6 +36,10 @@ class HamitonianMC:
         # batched file per rank (always written when outdir is set); checkpoint: path of a resumable state file
         self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
         self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
+        # diagonal inverse mass M^-1 (None = the reference's identity): momenta are drawn as 0.5 z sqrt(M), the
+        # device drifts with M^-1 p and uses K = p.M^-1 p / 2 (rfs_set_inverse_mass)
+        self.inverse_mass = None if inverse_mass is None else np.asarray(inverse_mass, dtype=np.float64)
+        self._pscale = 0.5 if self.inverse_mass is None else 0.5 / np.sqrt(self.inverse_mass)
         self.rng = ChainRNG(seed, self.first_chain, self.nchains)
         self.ii = 0
         self.trace = None          # optional list collecting per-iteration records (tests)
@@ -58,7 +62,7 @@ class HamitonianMC:
         import torch
         dev = self._device()
         n = x.shape[1]
-        p0 = self.rng.randn(active, n) * 0.5                                  # hmc.py:146
+        p0 = self.rng.randn(active, n) * self._pscale                                  # hmc.py:146
         xd = torch.from_numpy(np.ascontiguousarray(x[active])).to(dev)
         pd = torch.from_numpy(np.ascontiguousarray(p0)).to(dev)
         dtd = torch.full((len(active),), float(self.dt), dtype=torch.float64, device=dev)
@@ -91,6 +95,8 @@ class HamitonianMC:
         this one mean(L) + 2."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.inverse_mass is not None:
+            self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
         x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
         self.initmodel = x.copy()
@@ -105,7 +111,7 @@ class HamitonianMC:
                                    t(self.boundaries))
         allc = list(range(nc))
         L = self.rng.randint(allc, self.Lrange[0], self.Lrange[1] + 1)          # hmc.py:248, then :146
-        st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
+        st["p"].copy_(t(self.rng.randn(allc, nx) * self._pscale))
         st["rem"].copy_(t(L.astype(np.int32))); st["fresh"].fill_(1)
         def process_done(idx, res):
             ok = res["ok"].astype(bool)
@@ -141,7 +147,7 @@ class HamitonianMC:
             rs = None
             if restart:
                 Lr = self.rng.randint(restart, self.Lrange[0], self.Lrange[1] + 1)
-                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * 0.5, rem=Lr)
+                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, rem=Lr)
             return x[idx], rs
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
@@ -154,6 +160,8 @@ class HamitonianMC:
         ``resume``: continue from ``self.checkpoint`` (same results as an uninterrupted run);
         ``max_trajectories``: stop after that many outer iterations (the checkpoint is written first)."""
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.inverse_mass is not None:
+            self.model.set_inverse_mass(self.inverse_mass)
         ndata = self.model.dobs.shape[0]
         total = nd_ + ns
         if resume:

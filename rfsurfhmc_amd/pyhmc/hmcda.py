@@ -27,7 +27,7 @@ def _mirror(x, p, boundaries):
 class HMCDualAveraging:
     def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
-                 per_chain_files=None, checkpoint=None, checkpoint_every=0):
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None):
         self.model = UserDefinedModel
         self.boundaries = np.asarray(boundaries, dtype=np.float64)
         self.dt, self.L = dt, L0
@@ -40,6 +40,10 @@ class HMCDualAveraging:
         self.store_syn, self.verbose = store_syn, verbose
         self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
         self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
+        # diagonal inverse mass M^-1 (None = the reference's identity): momenta are drawn as 0.5 z sqrt(M), the
+        # device drifts with M^-1 p and uses K = p.M^-1 p / 2 (rfs_set_inverse_mass)
+        self.inverse_mass = None if inverse_mass is None else np.asarray(inverse_mass, dtype=np.float64)
+        self._pscale = 0.5 if self.inverse_mass is None else 0.5 / np.sqrt(self.inverse_mass)
         self.delta = target_ratio                                             # hmcda.py:70-76
         self._h0, self._gamma, self._t0, self._kappa = 0.0, 0.05, 10.0, 0.75
         self._lambda = L0 * self.dt
@@ -66,20 +70,21 @@ class HMCDualAveraging:
         idx = list(range(nc))
         xcur = x.copy()
         dt = np.full(nc, float(dt0))
-        pcur = self.rng.randn(idx, n) * 0.5
+        pcur = self.rng.randn(idx, n) * self._pscale
+        mi = 1.0 if self.inverse_mass is None else self.inverse_mass[None, :]      # K = p.M^-1 p / 2, x' = M^-1 p
         U, grad, _, flag = self.model.misfit_and_grad(xcur)
-        Hcur = U + 0.5 * np.sum(pcur * pcur, axis=1)
+        Hcur = U + 0.5 * np.sum(pcur * pcur * mi, axis=1)
         a = np.zeros(nc)
         pcur = pcur - 0.5 * dt[:, None] * grad
         live = np.ones(nc, dtype=bool)
         for it in range(20):
-            xn, pn = _mirror(xcur + dt[:, None] * pcur, pcur, self.boundaries)
+            xn, pn = _mirror(xcur + dt[:, None] * (pcur * mi), pcur, self.boundaries)
             xcur = np.where(live[:, None], xn, xcur); pcur = np.where(live[:, None], pn, pcur)
             U, grad, _, flag = self.model.misfit_and_grad(xcur)
             if np.any(live & ~flag):
                 raise RuntimeError("error in chain %d!" % (self.first_chain + int(np.nonzero(live & ~flag)[0][0])))
             pcur = np.where(live[:, None], pcur - 0.5 * dt[:, None] * grad, pcur)
-            Hnew = U + 0.5 * np.sum(pcur * pcur, axis=1)
+            Hnew = U + 0.5 * np.sum(pcur * pcur * mi, axis=1)
             ediff = -(Hnew - Hcur)
             if it == 0:
                 a = 2.0 * (ediff > np.log(0.5)) - 1.0
@@ -102,7 +107,7 @@ class HMCDualAveraging:
         dev = self._device()
         nc, n = x.shape
         idx = list(range(nc))
-        p0 = self.rng.randn(idx, n) * 0.5
+        p0 = self.rng.randn(idx, n) * self._pscale
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         out = self.model.leapfrog_device(t(x), t(p0), t(dt.astype(np.float64)), t(L.astype(np.int32)), t(self.boundaries))
         ok = out["ok"].cpu().numpy().astype(bool)
@@ -120,6 +125,8 @@ class HMCDualAveraging:
     def sample(self, x_init=None, resume=False, max_trajectories=None):
         """pyhmc/hmcda.py:280-369.  ``resume`` / ``max_trajectories``: see HamitonianMC.sample."""
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.inverse_mass is not None:
+            self.model.set_inverse_mass(self.inverse_mass)
         ndata = self.model.dobs.shape[0]
         mu = np.log(10 * self.dt)
         total = nd_ + ns
@@ -215,6 +222,8 @@ class HMCDualAveraging:
         order (momentum at the start of a trajectory, the acceptance draw at its end)."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.inverse_mass is not None:
+            self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
         x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
         self.initmodel = x.copy()
@@ -231,7 +240,7 @@ class HMCDualAveraging:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
         allc = list(range(nc))
-        st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
+        st["p"].copy_(t(self.rng.randn(allc, nx) * self._pscale))
         st["rem"].copy_(t(np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)))
         st["fresh"].fill_(1)
         def process_done(idx, res):
@@ -272,114 +281,12 @@ class HMCDualAveraging:
             restart = [int(c) for c in idx if i[c] < total]
             rs = None
             if restart:
-                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * 0.5, dt=dt[restart],
+                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, dt=dt[restart],
                           rem=np.maximum(1, (self._lambda / dt[restart]).astype(int)))
             return x[idx], rs
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
                                    fetch_syn=syndata is not None, pipeline=pipeline)
-        self.finished = True
-        return self._finish(misfit, x_cache, syndata, i, ncount, dt)
-
-    def _finish(self, misfit, x_cache, syndata, i, ncount, dt):
-        nc, nx = self.nchains, x_cache.shape[2]
-        self.dt_final, self.accept_ratio = dt, i / np.maximum(ncount, 1)
-        nbests = 10                                                           # hard-coded, hmcda.py:359
-        xmean = np.zeros((nc, nx))
-        for c in range(nc):
-            idx = np.argsort(misfit[c])
-            xmean[c] = np.mean(x_cache[c, idx[:nbests]], axis=0)
-        synmean = self.model.misfit_and_grad(xmean)[2]
-        self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
-        if self.outdir is not None:
-            self.result_file = save_batched_results(self.outdir, self.name, self.myrank, self.first_chain,
-                                                    self.initmodel, self.model.dobs, xmean, synmean, x_cache,
-                                                    syndata, misfit)
-            if self.per_chain_files:
-                for c in range(nc):
-                    save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c],
-                                       self.model.dobs, xmean[c], synmean[c], x_cache[c],
-                                       None if syndata is None else syndata[c])
-        return misfit[0] if nc == 1 else misfit
-
-    def sample_flow(self, x_init=None, pipeline=True):
-        """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
-        every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
-        (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
-        order (momentum at the start of a trajectory, the acceptance draw at its end)."""
-        import torch
-        nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
-        dev = self._device()
-        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
-        self.initmodel = x.copy()
-        nx = x.shape[1]
-        ndata = self.model.dobs.shape[0]
-        mu = np.log(10 * self.dt)
-        total = nd_ + ns
-        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
-        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
-        dt = self._find_initial_dt(self.dt, x)
-        dtbar = dt * 1.0
-        h0 = np.full(nc, self._h0)
-        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
-        allc = list(range(nc))
-        st["p"].copy_(t(self.rng.randn(allc, nx) * 0.5))
-        st["rem"].copy_(t(np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)))
-        st["fresh"].fill_(1)
-        self.flow_steps = 0
-        while np.any(i < total):
-            self.model.flow_step(st)
-            self.flow_steps += 1
-            idx = np.nonzero(st["done"].cpu().numpy())[0]
-            if len(idx) == 0:
-                continue
-            sel = t(idx)
-            ok = st["ok"].index_select(0, sel).cpu().numpy().astype(bool)
-            Hcur = st["Hcur"].index_select(0, sel).cpu().numpy(); Hnew = st["Hnew"].index_select(0, sel).cpu().numpy()
-            Unew = np.where(ok, st["Unew"].index_select(0, sel).cpu().numpy(), np.inf)
-            xend = st["x"].index_select(0, sel).cpu().numpy()
-            dnew = st["dsyn_new"].index_select(0, sel).cpu().numpy() if syndata is not None else None
-            with np.errstate(over="ignore", invalid="ignore"):
-                alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
-            u = self.rng.rand([int(c) for c in idx])
-            acc = u < alpha
-            for k, c in enumerate(idx):
-                if acc[k]:
-                    x[c] = xend[k]
-                    if i[c] >= nd_:
-                        misfit[c, i[c] - nd_] = Unew[k]; x_cache[c, i[c] - nd_] = xend[k]
-                        if syndata is not None:
-                            syndata[c, i[c] - nd_] = dnew[k] if ok[k] else self.model.dobs
-                    i[c] += 1; self.ii += 1
-            # dual averaging for the chains that just finished a trajectory (hmcda.py:329-345)
-            adapt = ncount[idx] < nd_
-            m = ncount[idx] + 1.0
-            fac = 1.0 / (m + self._t0)
-            h_new = (1 - fac) * h0[idx] + fac * (self.delta - alpha)
-            logdt = mu - np.sqrt(m) / self._gamma * h_new
-            fac2 = m ** (-self._kappa)
-            dtbar_new = np.exp(fac2 * logdt + (1 - fac2) * np.log(dtbar[idx]))
-            h0[idx] = np.where(adapt, h_new, h0[idx])
-            dt[idx] = np.where(adapt, np.exp(logdt), dtbar[idx])
-            dtbar[idx] = np.where(adapt, dtbar_new, dtbar[idx])
-            ncount[idx] += 1
-            if self.verbose:
-                for k, c in enumerate(idx):
-                    if i[c] % 50 == 0 or i[c] == ns - 1:
-                        print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
-                            self.first_chain + c, i[c] / total, dt[c], Unew[k], i[c] / ncount[c]))
-                sys.stdout.flush()
-            st["x"].index_copy_(0, sel, t(x[idx]))
-            restart = [int(c) for c in idx if i[c] < total]
-            if restart:
-                rs = t(np.array(restart))
-                st["p"].index_copy_(0, rs, t(self.rng.randn(restart, nx) * 0.5))
-                st["dt"].index_copy_(0, rs, t(dt[restart].astype(np.float64)))
-                st["rem"].index_copy_(0, rs, t(np.maximum(1, (self._lambda / dt[restart]).astype(int)).astype(np.int32)))
-                st["fresh"].index_fill_(0, rs, 1)
-                st["ok"].index_fill_(0, rs, 1)
         self.finished = True
         return self._finish(misfit, x_cache, syndata, i, ncount, dt)
 
