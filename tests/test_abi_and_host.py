@@ -82,3 +82,18 @@ def test_mirror_matches_reference_semantics():
     xm, pm = _mirror(x, p, b)
     assert np.allclose(xm, [[0.7, 2.5], [0.2, 2.5], [0.7, 2.8]])
     assert np.array_equal(pm, [[-1, -1], [-1, 1], [1, -1]])
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rfsurf.h is the boundary a C / cgo / JNI binding would include: it must compile as strict C99 (and as
+    C++) on its own, with no HIP or torch types in any signature."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "include/rfsurf.h"\n'
+                   'int probe(void) { rfs_swd_params s; rfs_rf_params r; (void)s; (void)r; return (int)RFS_K_COUNT; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", f"-I{ROOT}", str(src)],
+                   check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", f"-I{ROOT}", "-x", "c++", str(src)], check=True)
+    code = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rfsurf.h")).read(), flags=re.S)
+    assert "#include <stdint.h>" in code and code.count("#include") == 1          # no HIP / torch headers
+    assert not re.search(r"hipStream_t|hipEvent_t|at::|torch::|Tensor", code)
