@@ -158,3 +158,26 @@ def test_schedules_give_identical_results(orc):
     for name in ("partitioned", "partitioned2"):
         for a, b in zip(res["shared"], res[name]):
             assert np.array_equal(a, b), name
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """examples/c_client.c, compiled with gcc against librfsurf_hip.so, reproduces the values observed from the
+    reference on its param.yaml model."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rfsurfhmc_amd")
+    exe = str(tmp_path / "c_client")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", f"-I{root}", os.path.join(root, "examples", "c_client.c"),
+                    "-o", exe, f"-L{libdir}", "-l:librfsurf_hip.so", f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "flag 1"
+    c = np.array(out[1].split()[1:], dtype=float)
+    np.testing.assert_allclose(c, [2.811252593994, 2.802712202072, 2.807658672333, 2.823679924011, 2.847761392593,
+                                   2.876952648163], rtol=0, atol=5e-13)
+    kb = np.array(out[2].split()[1:], dtype=float)
+    np.testing.assert_allclose(kb, [4.180354642102e-01, 3.241766678501e-01, 3.022816772550e-02, 7.717666538807e-05,
+                                    3.931093706971e-06, 7.434082888798e-09, 1.085835992717e-17], rtol=2e-6)
+    rf = np.array(out[3].split()[1:], dtype=float)
+    np.testing.assert_allclose(rf, [1.750384485169e-04, 2.704993610476e-03, 2.454749574455e-02, 1.064170021474e-01,
+                                    2.228427016323e-01, 2.188586786966e-01, 9.057466370315e-02, 1.807677009266e-02], rtol=1e-9)
