@@ -120,6 +120,18 @@ def test_argument_errors_are_reported_not_fatal():
     assert L.rfs_swd_forward(ctx.h, 1, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 7, 0, 0, hptr(out), hptr(fl)) == -1   # bad wavetype
     assert L.rfs_swd_forward(ctx.h, 9, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 0, 0, 0, hptr(out), hptr(fl)) == -1   # > max_chains
     assert b"max_chains" in L.rfs_last_error(ctx.h)
+    # newer entries: state and argument errors
+    one = np.ones(8)
+    assert L.rfs_set_inverse_mass(ctx.h, hptr(one)) == -3                                                   # before any setup
+    dummy = ctypes.c_void_p(8)          # never dereferenced: the calls below fail before touching device memory
+    assert L.rfs_flow_step(ctx.h, 1, *([dummy] * 14)) == -3
+    assert L.rfs_joint_setup(ctx.h, 4, None, 2, hptr(t), 0, None, 1.0, 1.0, None) == 0
+    assert L.rfs_set_inverse_mass(ctx.h, hptr(np.r_[np.ones(7), -1.0])) == -1                               # non-positive mass
+    assert L.rfs_set_inverse_mass(ctx.h, hptr(one)) == 0 and L.rfs_set_inverse_mass(ctx.h, None) == 0
+    bad = np.array([1, 2], dtype=np.int32)                                                                  # nactive must not increase
+    assert L.rfs_leapfrog_dev2(ctx.h, 2, dummy, dummy, dummy, dummy, 2, hptr(bad), *([dummy] * 9)) == -1
+    assert L.rfs_flow_step(ctx.h, 1, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy,
+                           dummy, dummy, None) == -1                                                        # null output
     with pytest.raises(RfsError):
         ctx.check(-1)
     ctx.close()
