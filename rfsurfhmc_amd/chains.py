@@ -1,5 +1,6 @@
 """Multi-GPU layout of the path: independent chains shard across ranks, nothing is exchanged
-while sampling; the only collective is the final gather of per-chain results on rank 0.
+while sampling; the only collective on the path is the final gather of per-chain results on rank 0
+(plus, when the optional ensemble mass adaptation is on, two tiny all-reduces at each adaptation point).
 
 Mirrors the reference's whole distributed backend -- ``comm.bcast(dobs)``, ``comm.bcast(x)`` and
 ``comm.Gather(misfit)`` in main_base.py:59-60,90 -- with torch.distributed (backend "nccl" = RCCL
@@ -50,3 +51,22 @@ def gather_misfits(misfit, dst: int = 0):
     if rank != dst:
         return None
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def pooled_variance(x: np.ndarray) -> np.ndarray:
+    """Per-parameter variance of the current models over ALL chains of the job (x: this rank's [chains, nx]).
+    Two all-reduces of nx+1 doubles when a process group is up (mean first, then centred squares), plain numpy
+    otherwise.  The reference has no counterpart (its `invert_Mass` is the identity, pyhmc/hmc.py:48)."""
+    import torch
+    import torch.distributed as dist
+    x = np.asarray(x, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x.var(axis=0)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    s1 = torch.from_numpy(np.concatenate([[float(x.shape[0])], x.sum(axis=0)])).to(dev)
+    dist.all_reduce(s1)
+    s1 = s1.cpu().numpy()
+    n, mean = s1[0], s1[1:] / s1[0]
+    s2 = torch.from_numpy(((x - mean[None, :]) ** 2).sum(axis=0)).to(dev)
+    dist.all_reduce(s2)
+    return s2.cpu().numpy() / n

@@ -124,6 +124,20 @@ def export_chain(batched_path, chain, outdir=None, name=None, fmt="npz"):
     return path
 
 
+def ensemble_inverse_mass(x, clip=(1e-3, 1e3)):
+    """Diagonal M^-1 for the samplers from the spread of the chains themselves: the cross-chain variance of the
+    current models (thousands of chains make a history unnecessary), pooled over ranks, normalised to geometric
+    mean 1 so that the step size keeps its meaning, and clipped.  Parameters on which the chains do not differ
+    (variance 0) get the lower clip."""
+    from ..chains import pooled_variance
+    var = pooled_variance(x)
+    pos = var > 0
+    if not pos.any():
+        return np.ones_like(var)
+    g = np.exp(np.mean(np.log(var[pos])))
+    return np.clip(np.where(pos, var / g, clip[0]), clip[0], clip[1])
+
+
 def save_checkpoint(path, rng: ChainRNG, **state):
     """Everything a sampler needs to continue bit-for-bit: its arrays + every chain's RNG stream.
     Written to a temporary file first, then renamed (a killed job never leaves a torn checkpoint)."""

@@ -11,14 +11,14 @@ import sys
 
 import numpy as np
 
-from ._batched import (ChainRNG, initial_models, load_checkpoint, run_flow, save_batched_results,
+from ._batched import (ChainRNG, ensemble_inverse_mass, initial_models, load_checkpoint, run_flow, save_batched_results,
                        save_chain_results, save_checkpoint)
 
 
 class HamitonianMC:
     def __init__(self, UserDefinedModel, boundaries, dt, Lrange, nbest_model, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
-                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None):
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None):
         self.myrank = myrank
         self.nchains = int(nchains)
         self.first_chain = myrank * self.nchains
@@ -40,16 +40,24 @@ class HamitonianMC:
         # device drifts with M^-1 p and uses K = p.M^-1 p / 2 (rfs_set_inverse_mass)
         self.inverse_mass = None if inverse_mass is None else np.asarray(inverse_mass, dtype=np.float64)
         self._pscale = 0.5 if self.inverse_mass is None else 0.5 / np.sqrt(self.inverse_mass)
+        # mass_adapt: trajectory counts (inside the burn-in) at which M^-1 is re-estimated from the cross-chain
+        # variance of the current models (ensemble_inverse_mass); batch schedule only
+        self.mass_adapt = None if mass_adapt is None else frozenset(int(k) for k in mass_adapt)
         self.rng = ChainRNG(seed, self.first_chain, self.nchains)
         self.ii = 0
         self.trace = None          # optional list collecting per-iteration records (tests)
 
     @classmethod
     def init(cls, UserDefinedModel, boundaries, rank, **kargs):
-        """pyhmc/hmc.py:63-72 (+ optional key ``nchains``)."""
+        """pyhmc/hmc.py:63-72 (+ optional keys ``nchains``, ``mass_adapt``)."""
         return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["Lrange"], kargs["nbest"], kargs["seed"],
                    kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
-                   nchains=kargs.get("nchains", 1))
+                   nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"))
+
+    def _set_inverse_mass(self, minv):
+        self.inverse_mass = np.asarray(minv, dtype=np.float64)
+        self._pscale = 0.5 / np.sqrt(self.inverse_mass)
+        self.model.set_inverse_mass(self.inverse_mass)
 
     def _device(self):
         import torch
@@ -95,6 +103,8 @@ class HamitonianMC:
         this one mean(L) + 2."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.mass_adapt:
+            raise ValueError("mass_adapt needs the common trajectory boundaries of sample(); pass inverse_mass instead")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
@@ -171,6 +181,9 @@ class HamitonianMC:
             syndata = st["syndata"] if "syndata" in st else None
             self.ii = int(st["ii"])
             nx = x.shape[1]
+            ntraj = int(st["ntraj"]) if "ntraj" in st else 0
+            if "inverse_mass" in st:
+                self._set_inverse_mass(st["inverse_mass"])
         else:
             x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
             self.initmodel = x.copy()
@@ -181,10 +194,13 @@ class HamitonianMC:
             i = np.zeros(nc, dtype=int)
             ncount = np.zeros(nc, dtype=int)
             U = np.zeros(nc)
-        ntraj = 0
+            ntraj = 0
+        ntraj0 = ntraj
         while np.any(i < total):
-            if max_trajectories is not None and ntraj >= max_trajectories:
+            if max_trajectories is not None and ntraj - ntraj0 >= max_trajectories:
                 break
+            if self.mass_adapt and ntraj in self.mass_adapt:
+                self._set_inverse_mass(ensemble_inverse_mass(x))
             active = [c for c in range(nc) if i[c] < total]
             L = self.rng.randint(active, self.Lrange[0], self.Lrange[1] + 1)  # hmc.py:248
             xa, Ua, da, acc = self._leapfrog(x, active, L)
@@ -205,9 +221,9 @@ class HamitonianMC:
                     sys.stdout.flush()
             ntraj += 1
             if self.checkpoint and self.checkpoint_every and ntraj % self.checkpoint_every == 0:
-                self._save_checkpoint(x, U, i, ncount, misfit, x_cache, syndata)
+                self._save_checkpoint(x, U, i, ncount, misfit, x_cache, syndata, ntraj)
         if self.checkpoint and np.any(i < total):
-            self._save_checkpoint(x, U, i, ncount, misfit, x_cache, syndata)
+            self._save_checkpoint(x, U, i, ncount, misfit, x_cache, syndata, ntraj)
             self.finished = False
             return misfit[0] if nc == 1 else misfit
         self.finished = True
@@ -235,6 +251,7 @@ class HamitonianMC:
                                        None if syndata is None else syndata[c])
         return misfit[0] if nc == 1 else misfit
 
-    def _save_checkpoint(self, x, U, i, ncount, misfit, x_cache, syndata):
+    def _save_checkpoint(self, x, U, i, ncount, misfit, x_cache, syndata, ntraj):
         save_checkpoint(self.checkpoint, self.rng, x=x, U=U, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,
-                        syndata=syndata, initmodel=self.initmodel, ii=self.ii)
+                        syndata=syndata, initmodel=self.initmodel, ii=self.ii, ntraj=ntraj,
+                        inverse_mass=self.inverse_mass)

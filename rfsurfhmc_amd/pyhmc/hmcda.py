@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-from ._batched import (ChainRNG, initial_models, load_checkpoint, run_flow, save_batched_results,
+from ._batched import (ChainRNG, ensemble_inverse_mass, initial_models, load_checkpoint, run_flow, save_batched_results,
                        save_chain_results, save_checkpoint)
 
 
@@ -27,7 +27,7 @@ def _mirror(x, p, boundaries):
 class HMCDualAveraging:
     def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
-                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None):
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None):
         self.model = UserDefinedModel
         self.boundaries = np.asarray(boundaries, dtype=np.float64)
         self.dt, self.L = dt, L0
@@ -44,6 +44,9 @@ class HMCDualAveraging:
         # device drifts with M^-1 p and uses K = p.M^-1 p / 2 (rfs_set_inverse_mass)
         self.inverse_mass = None if inverse_mass is None else np.asarray(inverse_mass, dtype=np.float64)
         self._pscale = 0.5 if self.inverse_mass is None else 0.5 / np.sqrt(self.inverse_mass)
+        # mass_adapt: trajectory counts (inside the burn-in) at which M^-1 is re-estimated from the cross-chain
+        # variance of the current models (ensemble_inverse_mass); batch schedule only
+        self.mass_adapt = None if mass_adapt is None else frozenset(int(k) for k in mass_adapt)
         self.delta = target_ratio                                             # hmcda.py:70-76
         self._h0, self._gamma, self._t0, self._kappa = 0.0, 0.05, 10.0, 0.75
         self._lambda = L0 * self.dt
@@ -53,10 +56,15 @@ class HMCDualAveraging:
 
     @classmethod
     def init(cls, UserDefinedModel, boundaries, rank, **kargs):
-        """pyhmc/hmcda.py:84-97 (+ optional key ``nchains``)."""
+        """pyhmc/hmcda.py:84-97 (+ optional keys ``nchains``, ``mass_adapt``)."""
         return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["L0"], kargs["nbest"], kargs["target_ratio"],
                    kargs["seed"], kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
-                   nchains=kargs.get("nchains", 1))
+                   nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"))
+
+    def _set_inverse_mass(self, minv):
+        self.inverse_mass = np.asarray(minv, dtype=np.float64)
+        self._pscale = 0.5 / np.sqrt(self.inverse_mass)
+        self.model.set_inverse_mass(self.inverse_mass)
 
     def _device(self):
         import torch
@@ -138,6 +146,9 @@ class HMCDualAveraging:
             dt, dtbar, h0 = st["dt"], st["dtbar"], st["h0"]
             self.ii = int(st["ii"])
             nx = x.shape[1]
+            ntraj = int(st["ntraj"]) if "ntraj" in st else 0
+            if "inverse_mass" in st:
+                self._set_inverse_mass(st["inverse_mass"])
         else:
             x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
             self.initmodel = x.copy()
@@ -148,12 +159,15 @@ class HMCDualAveraging:
             dtbar = dt * 1.0
             h0 = np.full(nc, self._h0)
             i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
-        ntraj = 0
+            ntraj = 0
+        ntraj0 = ntraj
         idx_all = list(range(nc))
         U = np.zeros(nc)
         while np.any(i < total):
-            if max_trajectories is not None and ntraj >= max_trajectories:
+            if max_trajectories is not None and ntraj - ntraj0 >= max_trajectories:
                 break
+            if self.mass_adapt and ntraj in self.mass_adapt:        # dual averaging then re-tunes dt (burn-in)
+                self._set_inverse_mass(ensemble_inverse_mass(x))
             live = i < total
             L = np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)     # hmcda.py:307
             x1, U, dsyn, alpha = self._leapfrog(x, dt, L)
@@ -186,9 +200,9 @@ class HMCDualAveraging:
                 sys.stdout.flush()
             ntraj += 1
             if self.checkpoint and self.checkpoint_every and ntraj % self.checkpoint_every == 0:
-                self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0)
+                self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0, ntraj)
         if self.checkpoint and np.any(i < total):
-            self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0)
+            self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0, ntraj)
             self.finished = False
             return misfit[0] if nc == 1 else misfit
         self.finished = True
@@ -222,6 +236,8 @@ class HMCDualAveraging:
         order (momentum at the start of a trajectory, the acceptance draw at its end)."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.mass_adapt:
+            raise ValueError("mass_adapt needs the common trajectory boundaries of sample(); pass inverse_mass instead")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
@@ -290,6 +306,7 @@ class HMCDualAveraging:
         self.finished = True
         return self._finish(misfit, x_cache, syndata, i, ncount, dt)
 
-    def _save_checkpoint(self, x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0):
+    def _save_checkpoint(self, x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0, ntraj):
         save_checkpoint(self.checkpoint, self.rng, x=x, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,
-                        syndata=syndata, initmodel=self.initmodel, ii=self.ii, dt=dt, dtbar=dtbar, h0=h0)
+                        syndata=syndata, initmodel=self.initmodel, ii=self.ii, dt=dt, dtbar=dtbar, h0=h0, ntraj=ntraj,
+                        inverse_mass=self.inverse_mass)

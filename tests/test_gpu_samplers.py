@@ -205,3 +205,31 @@ def test_inverse_mass_matrix(orc, golden):
                      verbose=False, inverse_mass=minv)
     mis = s.sample_flow(x_init=x[:3])
     assert np.all(np.isfinite(mis)) and np.all(mis > 0)
+
+
+def test_ensemble_mass_adaptation_on_the_device(golden):
+    """mass_adapt on the real joint model: the estimate made from the chains' spread reaches the device
+    (rfs_set_inverse_mass), the run equals one that is handed the same M^-1 from the start of that trajectory on,
+    and both samplers finish with finite misfits."""
+    from rfsurfhmc_amd.pyhmc._batched import ensemble_inverse_mass
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    g = golden["sampler_hybrid"]
+    bounds = g["bounds"]
+    nc, nx = 32, len(g["x0"])
+    rng = np.random.default_rng(23)
+    x = np.tile(g["x0"], (nc, 1)) * (1 + 0.02 * rng.standard_normal((nc, nx)))
+    x[:, -1] = 1.0 + 0.1 * rng.standard_normal(nc)
+    x = np.clip(x, bounds[:, 0] + 1e-6, bounds[:, 1] - 1e-6)
+    kw = dict(myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+    a = HamitonianMC(_joint(g), bounds, 0.02, [3, 6], 2, 991206, 4, 2, mass_adapt=[0], **kw)
+    ma = a.sample(x_init=x)
+    minv = ensemble_inverse_mass(x)
+    assert np.array_equal(a.inverse_mass, minv) and abs(np.mean(np.log(minv))) < 1e-12
+    b = HamitonianMC(_joint(g), bounds, 0.02, [3, 6], 2, 991206, 4, 2, inverse_mass=minv, **kw)
+    mb = b.sample(x_init=x)
+    assert np.array_equal(ma, mb) and np.array_equal(a.x_cache, b.x_cache)
+    assert np.all(np.isfinite(ma)) and a.accept_ratio.mean() > 0.3
+    d = HMCDualAveraging(_joint(g), bounds, 0.02, 4, 2, 0.65, 991206, 4, 2, mass_adapt=[0, 2], **kw)
+    md = d.sample(x_init=x)
+    assert np.all(np.isfinite(md)) and d.inverse_mass is not None and np.all(d.dt_final > 0)
