@@ -139,3 +139,27 @@ def test_time_domain_two_layers_and_many_layers(hip, orc):
     vp, rho, _, _ = orc.empirical_relation(vs); q = np.full(n, 9999.)
     a = (thk, rho, vp, vs, q, q, 0.045, 128, 0.2, 1.5, 5.0, "time", 0.001, "P")
     assert rel(hip.librf.forward(*a), orc.librf.forward(*a)) < 1e-8
+
+
+def test_reference_smoke_script_configuration(hip, orc):
+    """The reference's only runnable check, test_forward.py:13-45: Joint_RF_SWD.forward on its 7-layer model with a
+    time-domain P receiver function (nt = 500 -> 512-point transforms, gauss 1.0) and 36 Rc + 36 Rg periods
+    (the script only plots; here the same call is compared with the oracle, whose SWD part is the compiled reference)."""
+    tRc = np.linspace(5, 40, 36)
+    args = (0.045, 500, 0.1, 1.0, 5.0, 0.001, "P", "time")
+    thk = np.array([6., 6, 13, 5, 10, 30, 0])
+    vs = np.array([3.2, 3.4, 3.46, 3.7, 3.9, 4.5, 4.7])
+    x = np.hstack((vs, thk))
+    mo_rf, mo_swd = orc.ReceiverFunc(*args), orc.SurfWD(tRc=tRc, tRg=tRc.copy())
+    mh_rf, mh_swd = hip.ReceiverFunc(*args), hip.SurfWD(tRc=tRc, tRg=tRc.copy())
+    for m in (mh_rf, mh_swd):
+        m.set_thk(thk)                                                    # test_forward.py:33-34
+    jo = orc.Joint_RF_SWD(1.0, 1.0, mo_rf, mo_swd)
+    jh = hip.Joint(1.0, 1.0, mh_rf, mh_swd)
+    dr0, ds0, f0 = jo.forward(x)
+    dr1, ds1, f1 = jh.forward(x)
+    assert f0 and f1 and dr1.shape == (500,) and ds1.shape == (72,)
+    assert rel(dr1, dr0) < 1e-9
+    assert np.array_equal(ds1[:36], ds0[:36])                             # float32-rounded phase velocities
+    assert rel(ds1[36:], ds0[36:]) < 1e-6
+    assert abs(np.argmax(dr1) * 0.1 - 5.0) < 0.15                         # direct P at the time shift
