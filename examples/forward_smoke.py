@@ -1,6 +1,6 @@
 """Forward smoke run in the role of the reference's test_forward.py: time-domain P receiver function + 36 Rc + 36 Rg
 periods for the 7-layer model, through the plugin classes (GPU).  Writes syn_test.npz (and syn_test.png when
-matplotlib is installed).  Run from the repo root: python examples/test_forward.py"""
+matplotlib is installed).  Run from the repo root: python examples/forward_smoke.py"""
 import os
 import sys
 import time
