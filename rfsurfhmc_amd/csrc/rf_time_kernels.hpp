@@ -179,42 +179,60 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
 // Lane l owns lags j = i*64 + l.  Outputs (each optional): Pout[trace][nft/2] spike train, gout[trace] =
 // sum_spikes a * Cres[chain][lag], nit_out[trace] = iterations used.
 // ---------------------------------------------------------------------------------------
-// wave-wide max of a non-negative f64 on the VALU (DPP moves of the two halves; no LDS crossbar traffic, which
-// is what bounds a shuffle-based arg-max when 16+ waves per CU iterate this loop).  Result valid in lane 63.
+// wave-wide max of a non-negative f64 on the VALU.  The bit pattern of a non-negative double orders like an unsigned
+// integer, so the maximum is taken in two 32-bit passes (high words, then the low words of the lanes that hold the
+// maximal high word): v_max_u32 takes a DPP operand directly, one instruction per butterfly step, where an f64 max
+// needs two DPP moves, a canonicalisation and the max (no LDS crossbar traffic either way).  Result is wave-uniform.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double rft_dpp_max(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    return fmax(v, __hiloint2double(hi2, lo2));
+__device__ __forceinline__ unsigned rft_dpp_umax(unsigned v) {
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);   // 0 = identity of umax
+    return o > v ? o : v;
 }
-__device__ __forceinline__ double rft_wave_max_uniform(double v) {
-    v = rft_dpp_max<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
-    v = rft_dpp_max<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
-    v = rft_dpp_max<0x114, 0xf>(v);     // row_shr:4
-    v = rft_dpp_max<0x118, 0xf>(v);     // row_shr:8
-    v = rft_dpp_max<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
-    v = rft_dpp_max<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
+__device__ __forceinline__ unsigned rft_wave_umax(unsigned v) {
+    v = rft_dpp_umax<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = rft_dpp_umax<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = rft_dpp_umax<0x114, 0xf>(v);     // row_shr:4
+    v = rft_dpp_umax<0x118, 0xf>(v);     // row_shr:8
+    v = rft_dpp_umax<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
+    v = rft_dpp_umax<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double rft_wave_max_uniform(double v) {      // v >= 0 (or NaN, which wins and ends the loop)
+    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+    const unsigned mh = rft_wave_umax(hi);
+    const unsigned ml = rft_wave_umax(hi == mh ? lo : 0u);
+    return __hiloint2double((int)mh, (int)ml);
+}
+__device__ __forceinline__ double rft_max_abs(double a, double b) {     // max(|a|, |b|) in one instruction
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-template <int NPL, int WPB>
+// FULL: nft >= 128, every lane owns exactly NPL lags (no guards, the NPL autocorrelation reads of an update are
+// issued together: consecutive lags of a lane are 512 B apart in the doubled LDS copy, which is what
+// ds_read2st64_b64 addresses).  WANT_P: the spike train is wanted (B1 kernels); the B2 gradient only needs gout.
+template <int NPL, int WPB, bool FULL, bool WANT_P>
 __global__ void __launch_bounds__(64 * WPB)
 k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict__ cuw0ts, size_t cuw_stride,
              const double* __restrict__ awts, size_t aw_stride, const double* __restrict__ S0parts, int nS0,
              size_t s0_chain_stride, size_t s0_part_stride, const double* __restrict__ Cres,
              double* __restrict__ Pout, double* __restrict__ gout, int* __restrict__ nit_out)
 {
-    extern __shared__ double aw[];                                // [nft] autocorrelation of wflt (unnormalised)
+    extern __shared__ double aw2[];                               // [2 nft] autocorrelation of wflt (unnormalised), twice
     const int trace0 = blockIdx.x * WPB;
     const int trace = trace0 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int chain = trace0 / trace_per_chain;
-    const int nft = f.nft, half = nft >> 1, mask = nft - 1;
+    const int nft = f.nft, half = nft >> 1;
+    double* cres_l = aw2 + 2 * nft;                               // [half] correlation of the residual with the pulse
     {
         const double* ag = awts + (size_t)chain * aw_stride;
-        for (int i = threadIdx.x; i < nft; i += 64 * WPB) aw[i] = ag[i];
+        for (int i = threadIdx.x; i < nft; i += 64 * WPB) { double v = ag[i]; aw2[i] = v; aw2[i + nft] = v; }
+        if (Cres) {
+            const double* cg = Cres + (size_t)chain * half;
+            for (int i = threadIdx.x; i < half; i += 64 * WPB) cres_l[i] = cg[i];
+        }
     }
     __syncthreads();
     if (trace >= ntrace) return;
@@ -227,28 +245,29 @@ k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict
         for (int p = 0; p < nS0; p++) S0 += sp[(size_t)p * s0_part_stride];
         S0 = S0 * inft;                                           // sum(uflt^2)
     }
-    const double Aw0 = aw[0] * inft;                              // sum(wflt^2)
+    const double Aw0 = aw2[0] * inft;                             // sum(wflt^2)
     const double invpw = 1. / Aw0 / dt, invpu = 1. / S0 / dt;     // deconit.f90:162-163
-    double cuw[NPL], P[NPL];
+    double cuw[NPL], P[WANT_P ? NPL : 1];
 #pragma unroll
     for (int i = 0; i < NPL; i++) {
         int j = i * 64 + lane;
-        cuw[i] = (j < half) ? cu[j] * inft * dt : 0.0;            // mycorrelate(...) * dt, :174-175
-        P[i] = 0.0;
+        cuw[i] = (FULL || j < half) ? cu[j] * inft * dt : 0.0;    // mycorrelate(...) * dt, :174-175
+        if (WANT_P) P[i] = 0.0;
     }
     double S = S0, sumsq_i = 1.0, d_error = 100 * invpw + 0.001, gacc = 0.0;
-    const double rA = 1.0 / aw[0];
+    const double rA = 1.0 / aw2[0];
     const double ka = invpw / dt, ks = dt * invpu;                // per-iteration products of :177, :184 hoisted
-    const double* cres = Cres ? Cres + (size_t)chain * half : nullptr;
+    const double* awl = aw2 + nft + lane;                         // lag (j - bj) mod nft of lane's lag i: awl[64 i - bj]
     int it = 0;
     for (; it < 200; it++) {
         if (fabs(d_error) <= 0.001) break;                        // :172
         // maxloc(abs(cuw(1:nft/2))): the maximum (exact: max does not round), then its first position
-        double bv = -1.0;
+        double bv;
+        if (NPL == 1) bv = fabs(cuw[0]);                          // idle lanes of a short trace hold 0
+        else {
+            bv = rft_max_abs(cuw[0], cuw[1]);
 #pragma unroll
-        for (int i = 0; i < NPL; i++) {
-            int j = i * 64 + lane;
-            if (j < half) bv = fmax(bv, fabs(cuw[i]));
+            for (int i = 2; i < NPL; i++) bv = rft_max_abs(bv, cuw[i]);
         }
         bv = rft_wave_max_uniform(bv);
         if (!(bv > 0.0)) { it++; break; }                         // nothing left to fit: P can no longer change
@@ -256,8 +275,7 @@ k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict
 #pragma unroll
         for (int i = 0; i < NPL; i++) {
             if (bj < 0) {
-                int j = i * 64 + lane;
-                unsigned long long hit = __ballot(j < half && fabs(cuw[i]) == bv);
+                unsigned long long hit = __builtin_amdgcn_ballot_w64((FULL || i * 64 + lane < half) && fabs(cuw[i]) == bv);
                 if (hit) {
                     int l = __ffsll((long long)hit) - 1;
                     bj = i * 64 + l;
@@ -266,25 +284,31 @@ k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict
                 }
             }
         }
+        const double cr = Cres ? cres_l[bj] : 0.0;                // fetched early, used after the update
         const double a = c * ka;                                  // cuw(idx) * invpw / dt, :177
         const double r = c * rA;
+        const double* ar = awl - bj;
 #pragma unroll
-        for (int i = 0; i < NPL; i++) {
-            int j = i * 64 + lane;
-            if (j == bj) P[i] += a;
-            if (j < half) cuw[i] -= r * aw[(j - bj) & mask];
+        for (int i = 0; i < NPL; i++)
+            if (FULL || i * 64 + lane < half) cuw[i] -= r * ar[64 * i];
+        if (WANT_P) {
+            const double ap = (lane == (bj & 63)) ? a : 0.0;      // bj is wave-uniform: one scalar-selected add
+            const int bi = bj >> 6;
+#pragma unroll
+            for (int i = 0; i < NPL; i++)
+                if (bi == i) P[i] += ap;
         }
-        if (cres) gacc += a * cres[bj];
+        gacc += a * cr;
         S -= a * c;
         double sumsq = S * ks;                                    // sum(rflt**2) * dt * invpu, :184
         d_error = 100. * (sumsq_i - sumsq);
         sumsq_i = sumsq;
     }
-    if (Pout) {
+    if (WANT_P) {
 #pragma unroll
         for (int i = 0; i < NPL; i++) {
             int j = i * 64 + lane;
-            if (j < half) Pout[(size_t)trace * half + j] = P[i];
+            if (FULL || j < half) Pout[(size_t)trace * half + j] = P[i];
         }
     }
     if (lane == 0) {

@@ -290,18 +290,26 @@ int rft_launch_deconv(rfs_ctx* c, int ntrace, int tpc, const RfFreq& f, const do
                       const double* Cres, double* Pout, double* gout) {
     int npl = f.nft / 128; if (npl < 1) npl = 1;
     dim3 grid((ntrace + WPB - 1) / WPB), block(64 * WPB);
-    size_t lds = (size_t)f.nft * sizeof(double);
-#define RFS_DECONV(NPL)                                                                                          \
-    hipLaunchKernelGGL((k_rft_deconv<NPL, WPB>), grid, block, lds, c->stream, ntrace, tpc, f, cuw0, cuw_stride,  \
-                       aw, aw_stride, S0, nS0, s0c, s0p, Cres, Pout, gout, (int*)nullptr)
-    switch (npl) {
-        case 1: RFS_DECONV(1); break;
-        case 2: RFS_DECONV(2); break;
-        case 4: RFS_DECONV(4); break;
-        case 8: RFS_DECONV(8); break;
-        case 16: RFS_DECONV(16); break;
-        default: RFS_DECONV(32); break;
+    size_t lds = ((size_t)2 * f.nft + (Cres ? f.nft / 2 : 0)) * sizeof(double);
+#define RFS_DECONV2(NPL, FULL, WANTP)                                                                            \
+    hipLaunchKernelGGL((k_rft_deconv<NPL, WPB, FULL, WANTP>), grid, block, lds, c->stream, ntrace, tpc, f, cuw0, \
+                       cuw_stride, aw, aw_stride, S0, nS0, s0c, s0p, Cres, Pout, gout, (int*)nullptr)
+#define RFS_DECONV(NPL, FULL) do { if (Pout) RFS_DECONV2(NPL, FULL, true); else RFS_DECONV2(NPL, FULL, false); } while (0)
+    if (lds > 64 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_rft_deconv<32, WPB, true, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_rft_deconv<32, WPB, true, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    switch (npl) {
+        case 1: if (f.nft >= 128) RFS_DECONV(1, true); else RFS_DECONV(1, false); break;
+        case 2: RFS_DECONV(2, true); break;
+        case 4: RFS_DECONV(4, true); break;
+        case 8: RFS_DECONV(8, true); break;
+        case 16: RFS_DECONV(16, true); break;
+        default: RFS_DECONV(32, true); break;
+    }
+#undef RFS_DECONV2
 #undef RFS_DECONV
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
