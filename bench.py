@@ -95,14 +95,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP extension has no CPU fallback")
+    torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")      # RCCL on ROCm
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP extension has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     from rfsurfhmc_amd._lib import K_NAMES
     from rfsurfhmc_amd.model.model_rf import ReceiverFunc

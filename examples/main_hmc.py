@@ -45,10 +45,10 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)                          # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")          # RCCL
-    torch.cuda.set_device(local)
 
     with open(args.param) as f:
         param = yaml.safe_load(f)
