@@ -113,9 +113,10 @@ def test_plugin_time_misfit_and_grad(hip, orc):
         assert abs(m1[i] - m0) <= 1e-5 * m0 and rel(g1[i], g0) < 1e-5
 
 
-@pytest.mark.parametrize("nt,dt", [(10, 1.0), (33, 0.5), (1000, 0.05)])
+@pytest.mark.parametrize("nt,dt", [(10, 1.0), (33, 0.5), (100, 0.4), (1000, 0.05), (2048, 0.025), (4096, 0.0125)])
 def test_time_domain_length_extremes(hip, orc, nt, dt):
-    """FFT lengths 16 (fewer lags than a wavefront), 64 and 1024 (8 lags per lane)."""
+    """FFT lengths 16 (fewer lags than a wavefront), 64, 128 (exactly one lag per lane), 1024 (8 lags per lane),
+    2048 and 4096 (the longest supported trace: 32 lags per lane, > 64 KB of LDS per block)."""
     thk, vs = YAML7
     vp, rho, _, _ = orc.empirical_relation(vs)
     q = np.full(len(vs), 9999.)
