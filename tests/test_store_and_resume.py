@@ -162,3 +162,38 @@ def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
         assert np.array_equal(a.dt_final, b.dt_final)
     assert b.flow_steps > 0
 
+
+
+def test_h5_exporter_writes_the_reference_member_names(tmp_path, monkeypatch):
+    """fmt="h5" with a recording stand-in for h5py (not in this image): the members are the ones the reference writes
+    and its plotting script reads -- initmodel, obs, mean/{model,syn}, {i}/{model,syn} (pyhmc/hmc.py:203-226,
+    src/plot_results.py:106-156)."""
+    import sys
+    import types
+    from rfsurfhmc_amd.pyhmc._batched import export_chain
+    written = {}
+
+    class File:
+        def __init__(self, path, mode):
+            assert mode == "w"
+            written["path"] = path
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def create_dataset(self, name, data=None):
+            written[name] = np.array(data)
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    s = _make("hmc", tmp_path)
+    s.sample()
+    z = np.load(s.result_file)
+    p = export_chain(s.result_file, 6, fmt="h5")
+    assert p == written.pop("path") and p.endswith("toy.6.h5")
+    want = {"initmodel", "obs", "mean/model", "mean/syn"} | {f"{i}/{k}" for i in range(12) for k in ("model", "syn")}
+    assert set(written) == want
+    assert np.array_equal(written["3/model"], z["model"][1, 3]) and np.array_equal(written["3/syn"], z["syn"][1, 3])
+    assert np.array_equal(written["mean/model"], z["mean_model"][1]) and np.array_equal(written["obs"], z["obs"])
