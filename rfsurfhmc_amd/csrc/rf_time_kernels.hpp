@@ -83,7 +83,7 @@ k_rft_chain_spectra(RfFreq f, const double* __restrict__ RR, cplx* __restrict__ 
 
 // Partial traces: spectrum of cuw0 for every (parameter class, layer),
 //   G^2 num' conj((R21^2)'),  num = R22_m R21 - R21_m R22   (RFModule.f90:131-133),
-// from ONE top-down sweep that carries the two unit-seed columns (dR21 and dR22) together, plus the
+// from ONE top-down sweep of one column (the two unit-seed columns for dR21 and dR22 combined up front), plus the
 // Parseval sums S0 = sum(uflt^2) per trace (wave butterflies, one partial per wave like pass B).
 // specp: [chain][4][n][n2] complex;  S0p: [chain][npart][4][n].
 template <bool TAIL>
@@ -114,14 +114,17 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
     const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
     const int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
     cplx* out = specp + (size_t)chain * 4 * n * f.n2 + k;
-    V4 y1, y2;
-    y1.v[0] = y1.v[1] = y1.v[2] = y1.v[3] = C(0.0); y2 = y1;
-    y1.v[c21] = C(1.0); y2.v[c22] = C(1.0);
+    // num is linear in the two unit-seed columns and both see the same layer matrices: carry their combination
+    // (+-i R21) e_c22 - R22 e_c21 through ONE sweep
+    V4 y;
+    y.v[0] = y.v[1] = y.v[2] = y.v[3] = C(0.0);
+    y.v[c22] = (f.rf_type == 1) ? mul_i(r21) : -mul_i(r21);
+    y.v[c21] = -r22;
     double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const int lane = threadIdx.x & 63;
     double* sp = S0p + ((size_t)chain * npart + part) * 4 * n;
     for (int j = 0; j < n; j++) {
-        cplx T1[4], T2[4];
+        cplx T[4];
         if (j < n - 1) {
             const double* o = rs + (size_t)j * 8 * n2p;
             V4 r;
@@ -129,22 +132,16 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
             for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
             RfHyp H; RfA A;
             rf_hyp(L[j], omega, H);
-            rf_layer_partials(L[j], H, kk, r, y1, T1);
-            rf_layer_partials(L[j], H, kk, r, y2, T2);
+            rf_layer_partials(L[j], H, kk, r, y, T);
             rf_build_A(L[j], H, A);
-            y1 = rf_A_times_col(A, y1);
-            y2 = rf_A_times_col(A, y2);
+            y = rf_A_times_col(A, y);
         } else {
-            rf_half_partials(L[j], omega, f.rf_type, y1, T1);
-            rf_half_partials(L[j], omega, f.rf_type, y2, T2);
+            rf_half_partials(L[j], omega, f.rf_type, y, T);
         }
 #pragma unroll
         for (int ip = 0; ip < 4; ip++) {
-            cplx t1 = T1[ip], t2 = T2[ip];
-            if (t1.re != t1.re || t1.im != t1.im) t1 = C(0.0);       // NaN scrub, RFModule.f90:698-703
-            if (t2.re != t2.re || t2.im != t2.im) t2 = C(0.0);
-            cplx r22m = (f.rf_type == 1) ? mul_i(t2) : -mul_i(t2);
-            cplx num = r22m * r21 - t1 * r22;
+            cplx num = T[ip];
+            if (num.re != num.re || num.im != num.im) num = C(0.0);  // NaN scrub, RFModule.f90:698-703
             if (edge) num.im = 0.0;
             cplx S = Q * num;
             if (edge) S.im = 0.0;

@@ -379,8 +379,8 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
     }
 }
 
-// B1 kernel_all: materialise the partial spectra S_{p,j,k} (RFModule.f90:416-419) by running the
-// column sweep twice (unit seeds for R21 and R22).  specp: [chain][4][n][n2] complex.
+// B1 kernel_all: materialise the partial spectra S_{p,j,k} (RFModule.f90:416-419) with one column sweep
+// (the two unit-seed columns for R21_m and R22_m combined up front).  specp: [chain][4][n][n2] complex.
 template <bool TAIL>
 __global__ void __launch_bounds__(256)
 k_rf_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
@@ -408,37 +408,34 @@ k_rf_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc
     const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
     const int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
     cplx* out = specp + (size_t)chain * 4 * n * f.n2 + k;
-    for (int which = 0; which < 2; which++) {
-        V4 y; y.v[0] = y.v[1] = y.v[2] = y.v[3] = C(0.0);
-        y.v[which == 0 ? c21 : c22] = C(1.0);
-        for (int j = 0; j < n; j++) {
-            cplx T[4];
-            if (j < n - 1) {
-                const double* o = rs + (size_t)j * 8 * n2p;
-                V4 r;
+    // num = R22_m R21 - R21_m R22 is linear in the two unit-seed columns, and both are carried through the stack by
+    // the same matrices: one sweep of the combined column  (+-i R21) e_c22 - R22 e_c21  yields num directly
+    V4 y; y.v[0] = y.v[1] = y.v[2] = y.v[3] = C(0.0);
+    y.v[c22] = (f.rf_type == 1) ? mul_i(r21) : -mul_i(r21);
+    y.v[c21] = -r22;
+    const bool edge = (k == 0 || k == f.n2 - 1);
+    for (int j = 0; j < n; j++) {
+        cplx T[4];
+        if (j < n - 1) {
+            const double* o = rs + (size_t)j * 8 * n2p;
+            V4 r;
 #pragma unroll
-                for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
-                RfHyp H; RfA A;
-                rf_hyp(L[j], omega, H);
-                rf_layer_partials(L[j], H, kk, r, y, T);
-                rf_build_A(L[j], H, A);
-                y = rf_A_times_col(A, y);
-            } else {
-                rf_half_partials(L[j], omega, f.rf_type, y, T);
-            }
-            for (int ip = 0; ip < 4; ip++) {
-                cplx t = T[ip];
-                if (t.re != t.re || t.im != t.im) t = C(0.0);
-                cplx* o = out + ((size_t)ip * n + j) * f.n2;
-                if (which == 0) {
-                    *o = -(Q * (t * r22));                       // - R21_m * R22
-                } else {
-                    cplx r22m = (f.rf_type == 1) ? mul_i(t) : -mul_i(t);
-                    cplx S = *o + Q * (r22m * r21);
-                    if (k == 0 || k == f.n2 - 1) S.im = 0.0;
-                    *o = S;
-                }
-            }
+            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
+            RfHyp H; RfA A;
+            rf_hyp(L[j], omega, H);
+            rf_layer_partials(L[j], H, kk, r, y, T);
+            rf_build_A(L[j], H, A);
+            y = rf_A_times_col(A, y);
+        } else {
+            rf_half_partials(L[j], omega, f.rf_type, y, T);
+        }
+#pragma unroll
+        for (int ip = 0; ip < 4; ip++) {
+            cplx t = T[ip];
+            if (t.re != t.re || t.im != t.im) t = C(0.0);             // NaN scrub (:698-703)
+            cplx S = Q * t;
+            if (edge) S.im = 0.0;
+            out[((size_t)ip * n + j) * f.n2] = S;
         }
     }
 }
