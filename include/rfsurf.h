@@ -74,7 +74,8 @@ int rfs_synchronize(rfs_ctx* ctx);
  * root search, bldsph / sprayl / splove for group velocities) and returns spherical velocities
  * (_flat2sphere surfdisp.cpp:16-49).  mode must be 0 (fundamental).
  * Model arrays [nchain][nlayer] are rounded to float32 first, as the binding does (main.cpp:9).
- * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1).
+ * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1); the c values of a failed chain are
+ * unspecified (the reference returns whatever roots it found before giving up, surfdisp.cpp:93-100).
  * "Lg" searches with vp = 1.732 vs as _LoveGroup does (it ignores the caller's vp). */
 int rfs_swd_forward(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
                     const double* vs, const double* rho, int nper, const double* period,
