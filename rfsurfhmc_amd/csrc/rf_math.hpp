@@ -82,41 +82,44 @@ RFS_HD void rf_hyp(const RfLayer& L, cplx omega, RfHyp& H) {
 
 struct V4 { cplx v[4]; };
 
-// Haskell layer matrix entries (RFModule.f90:746-763), 10 distinct values.
-struct RfA { cplx a11, a12, a13, a14, a21, a22, a23, a24, a31, a32, a41; };
+// Haskell layer matrix entries (RFModule.f90:746-763), 11 distinct values, WITHOUT their common factor gamma:
+// the products below apply it once to the resulting vector (4 complex multiplications instead of 11).
+struct RfA { cplx a11, a12, a13, a14, a21, a22, a23, a24, a31, a32, a41, g; };
 
 RFS_HD void rf_build_A(const RfLayer& L, const RfHyp& H, RfA& A) {
-    cplx g = L.gam, g1 = L.gam1;
+    cplx g1 = L.gam1;
     cplx dc = H.ca - H.cb;
-    A.a11 = g * (H.ca - g1 * H.cb);
-    A.a12 = g * (g1 * H.ya - H.xb);
-    A.a13 = g * (-(dc * L.imu2));
-    A.a14 = g * ((H.xb - H.ya) * L.imu2);
-    A.a21 = g * (g1 * H.yb - H.xa);
-    A.a22 = g * (H.cb - g1 * H.ca);
-    A.a23 = g * ((H.xa - H.yb) * L.imu2);
-    A.a24 = g * (dc * L.imu2);
-    A.a31 = g * (L.mu2 * (g1 * dc));
-    A.a32 = g * (L.mu2 * (g1 * g1 * H.ya - H.xb));
-    A.a41 = g * (L.mu2 * (g1 * g1 * H.yb - H.xa));
+    cplx dci = dc * L.imu2, g1sq = g1 * g1;
+    A.g = L.gam;
+    A.a11 = H.ca - g1 * H.cb;
+    A.a12 = g1 * H.ya - H.xb;
+    A.a13 = -dci;
+    A.a14 = (H.xb - H.ya) * L.imu2;
+    A.a21 = g1 * H.yb - H.xa;
+    A.a22 = H.cb - g1 * H.ca;
+    A.a23 = (H.xa - H.yb) * L.imu2;
+    A.a24 = dci;
+    A.a31 = L.mu2 * (g1 * dc);
+    A.a32 = L.mu2 * (g1sq * H.ya - H.xb);
+    A.a41 = L.mu2 * (g1sq * H.yb - H.xa);
     // a33 = a22, a34 = -a12, a42 = -a31, a43 = -a21, a44 = a11
 }
 
 RFS_HD V4 rf_row_times_A(const V4& r, const RfA& A) {   // r' = r . A
     V4 o;
-    o.v[0] = r.v[0] * A.a11 + r.v[1] * A.a21 + r.v[2] * A.a31 + r.v[3] * A.a41;
-    o.v[1] = r.v[0] * A.a12 + r.v[1] * A.a22 + r.v[2] * A.a32 - r.v[3] * A.a31;
-    o.v[2] = r.v[0] * A.a13 + r.v[1] * A.a23 + r.v[2] * A.a22 - r.v[3] * A.a21;
-    o.v[3] = r.v[0] * A.a14 + r.v[1] * A.a24 - r.v[2] * A.a12 + r.v[3] * A.a11;
+    o.v[0] = A.g * (r.v[0] * A.a11 + r.v[1] * A.a21 + r.v[2] * A.a31 + r.v[3] * A.a41);
+    o.v[1] = A.g * (r.v[0] * A.a12 + r.v[1] * A.a22 + r.v[2] * A.a32 - r.v[3] * A.a31);
+    o.v[2] = A.g * (r.v[0] * A.a13 + r.v[1] * A.a23 + r.v[2] * A.a22 - r.v[3] * A.a21);
+    o.v[3] = A.g * (r.v[0] * A.a14 + r.v[1] * A.a24 - r.v[2] * A.a12 + r.v[3] * A.a11);
     return o;
 }
 
 RFS_HD V4 rf_A_times_col(const RfA& A, const V4& y) {   // y' = A . y
     V4 o;
-    o.v[0] = A.a11 * y.v[0] + A.a12 * y.v[1] + A.a13 * y.v[2] + A.a14 * y.v[3];
-    o.v[1] = A.a21 * y.v[0] + A.a22 * y.v[1] + A.a23 * y.v[2] + A.a24 * y.v[3];
-    o.v[2] = A.a31 * y.v[0] + A.a32 * y.v[1] + A.a22 * y.v[2] - A.a12 * y.v[3];
-    o.v[3] = A.a41 * y.v[0] - A.a31 * y.v[1] - A.a21 * y.v[2] + A.a11 * y.v[3];
+    o.v[0] = A.g * (A.a11 * y.v[0] + A.a12 * y.v[1] + A.a13 * y.v[2] + A.a14 * y.v[3]);
+    o.v[1] = A.g * (A.a21 * y.v[0] + A.a22 * y.v[1] + A.a23 * y.v[2] + A.a24 * y.v[3]);
+    o.v[2] = A.g * (A.a31 * y.v[0] + A.a32 * y.v[1] + A.a22 * y.v[2] - A.a12 * y.v[3]);
+    o.v[3] = A.g * (A.a41 * y.v[0] - A.a31 * y.v[1] - A.a21 * y.v[2] + A.a11 * y.v[3]);
     return o;
 }
 
@@ -144,80 +147,66 @@ RFS_HD V4 rf_einv_row(const RfLayer& L, int rf_type) {
 RFS_HD void rf_layer_partials(const RfLayer& L, const RfHyp& H, cplx k, const V4& r,
                               const V4& y, cplx T[4]) {
     const cplx g = L.gam, g1 = L.gam1, g2 = L.gam2, g3 = L.gam3;
-    const cplx mu2 = L.mu2, imu2 = L.imu2;
     const cplx ca = H.ca, cb = H.cb, xa = H.xa, ya = H.ya, xb = H.xb, yb = H.yb;
     const cplx kh = L.h * k;
     const cplx dc = ca - cb;
-    cplx z0, z1, z2, z3;
-    // ---- rho (ipars = 1, :847-855) ----
+    // Every dA/dm has A's own pattern (a33 = a22, a34 = -a12, a42 = -a31, a43 = -a21, a44 = a11, a24 = -a13), so the
+    // outer product r_a y_b is folded ONCE into ten combinations shared by the four parameter classes; the entries
+    // of the third / fourth column and row carry 1/(2 mu) / 2 mu, applied to the combinations instead.
+    const cplx c11 = r.v[0] * y.v[0] + r.v[3] * y.v[3];
+    const cplx c22 = r.v[1] * y.v[1] + r.v[2] * y.v[2];
+    const cplx c12 = r.v[0] * y.v[1] - r.v[2] * y.v[3];
+    const cplx c21 = r.v[1] * y.v[0] - r.v[3] * y.v[2];
+    const cplx i13 = L.imu2 * (r.v[0] * y.v[2] - r.v[1] * y.v[3]);
+    const cplx i14 = L.imu2 * (r.v[0] * y.v[3]);
+    const cplx i23 = L.imu2 * (r.v[1] * y.v[2]);
+    const cplx m31 = L.mu2 * (r.v[2] * y.v[0] - r.v[3] * y.v[1]);
+    const cplx m32 = L.mu2 * (r.v[2] * y.v[1]);
+    const cplx m41 = L.mu2 * (r.v[3] * y.v[0]);
+    const cplx g1sq = g1 * g1;
+    // ---- rho (ipars = 1, :847-855): entries gamma/(2 rho mu) (.) and 2 mu gamma / rho (.) ----
     {
-        cplx f = g * imu2 / L.rho;          // gamma / (2 rho mu)
-        cplx q = (mu2 * g) / L.rho;         // 2 mu gamma / rho
-        cplx g1sq = g1 * g1;
-        cplx d13 = f * dc, d14 = f * (ya - xb), d23 = f * (yb - xa), d24 = -(f * dc);
-        cplx d31 = q * (g1 * dc), d32 = q * (g1sq * ya - xb), d41 = q * (g1sq * yb - xa), d42 = -d31;
-        z0 = d13 * y.v[2] + d14 * y.v[3];
-        z1 = d23 * y.v[2] + d24 * y.v[3];
-        z2 = d31 * y.v[0] + d32 * y.v[1];
-        z3 = d41 * y.v[0] + d42 * y.v[1];
-        T[0] = r.v[0] * z0 + r.v[1] * z1 + r.v[2] * z2 + r.v[3] * z3;
+        cplx t = dc * (i13 + g1 * m31) + (ya - xb) * i14 + (yb - xa) * i23 + (g1sq * ya - xb) * m32 + (g1sq * yb - xa) * m41;
+        T[0] = (g / L.rho) * t;
     }
     // ---- vp (ipars = 2, :829-844) ----
     {
         cplx ga = g2 * L.ia;
+        cplx khca = kh * ca;
         cplx P1 = (kh * ya) * ga;
-        cplx P2 = ((kh * ca - ya) * ga) * L.iva2;
-        cplx P3 = (kh * ca + ya) * ga;
-        cplx g1P1 = g1 * P1, g1P2 = g1 * P2;
-        z0 = P1 * y.v[0] + g1P2 * y.v[1] - (P1 * imu2) * y.v[2] - (P2 * imu2) * y.v[3];
-        z1 = -(P3 * y.v[0]) - g1P1 * y.v[1] + (P3 * imu2) * y.v[2] + (P1 * imu2) * y.v[3];
-        z2 = (mu2 * g1P1) * y.v[0] + (mu2 * (g1 * g1P2)) * y.v[1] - g1P1 * y.v[2] - g1P2 * y.v[3];
-        z3 = -((mu2 * P3) * y.v[0]) - (mu2 * g1P1) * y.v[1] + P3 * y.v[2] + P1 * y.v[3];
-        T[1] = L.sca * (r.v[0] * z0 + r.v[1] * z1 + r.v[2] * z2 + r.v[3] * z3);
+        cplx P2 = ((khca - ya) * ga) * L.iva2;
+        cplx P3 = (khca + ya) * ga;
+        cplx A1 = c11 - i13 + g1 * (m31 - c22);
+        cplx A2 = g1 * c12 - i14 + g1sq * m32;
+        cplx A3 = i23 - c21 - m41;
+        T[1] = L.sca * (P1 * A1 + P2 * A2 + P3 * A3);
     }
-    // ---- vs (ipars = 3, :811-826) ----
+    // ---- vs (ipars = 3, :811-826): common factor 2/beta ----
     {
-        cplx b = L.ib, b2 = 2.0 * b;
-        cplx imub = (2.0 * imu2) * b;                 // 1/(mu beta)
         cplx khyb = kh * yb, khcb = kh * cb;
         cplx e1 = khcb + yb, e2 = khcb - yb;
-        cplx d11 = b2 * (g * dc - g1 * khyb);
-        cplx d12 = b2 * (g * (ya - xb) - e1);
-        cplx d13 = khyb * imub;
-        cplx d14 = e1 * imub;
-        cplx d21 = ((yb - xa) + (g1 * g3) * e2) * (g * b2);
-        cplx d22 = b2 * (khyb - g * dc);
-        cplx d23 = -((e2 * (g * g3)) * imub);
-        cplx mb4 = (2.0 * mu2) * b;                   // 4 mu / beta
-        cplx d31 = mb4 * ((2.0 * g - 1.0) * dc - g1 * khyb);
-        cplx d32 = mb4 * ((2.0 * g) * (g1 * ya - xb) - e1);
-        cplx d41 = (mb4 * g) * (2.0 * (g1 * yb) - 2.0 * xa + (g1 * g1 * g3) * e2);
-        z0 = d11 * y.v[0] + d12 * y.v[1] + d13 * y.v[2] + d14 * y.v[3];
-        z1 = d21 * y.v[0] + d22 * y.v[1] + d23 * y.v[2] - d13 * y.v[3];
-        z2 = d31 * y.v[0] + d32 * y.v[1] + d22 * y.v[2] - d12 * y.v[3];
-        z3 = d41 * y.v[0] - d31 * y.v[1] - d21 * y.v[2] + d11 * y.v[3];
-        T[2] = L.scb * (r.v[0] * z0 + r.v[1] * z1 + r.v[2] * z2 + r.v[3] * z3);
+        cplx gdc = g * dc, g1khyb = g1 * khyb, g1g3 = g1 * g3;
+        cplx x11 = gdc - g1khyb;
+        cplx x12 = g * (ya - xb) - e1;
+        cplx x22 = khyb - gdc;
+        cplx x21 = (yb - xa) + g1g3 * e2;
+        cplx x31 = (2.0 * g - 1.0) * dc - g1khyb;
+        cplx x32 = (2.0 * g) * (g1 * ya - xb) - e1;
+        cplx x41 = 2.0 * (g1 * yb) - 2.0 * xa + (g1 * g1g3) * e2;
+        cplx t = x11 * c11 + x12 * c12 + x22 * c22 + khyb * i13 + e1 * i14 - (e2 * (g * g3)) * i23 + x31 * m31 + x32 * m32
+                 + g * (x21 * c21 + x41 * m41);
+        T[2] = (L.scb * (2.0 * L.ib)) * t;
     }
     // ---- thickness (ipars = 4, :858-874) ----
     {
         cplx na = (H.sa * k) * (L.va * L.va);         // v_alpha * va_k
         cplx nb = (H.sb * k) * (L.vb * L.vb);
         cplx kca = k * ca, kcb = k * cb, nbcb = nb * cb, naca = na * ca;
-        cplx h11 = (xa - g1 * xb) * k;
-        cplx h12 = g1 * kca - nbcb;
-        cplx h13 = ((xb - xa) * k) * imu2;
-        cplx h14 = (nbcb - kca) * imu2;
-        cplx h21 = g1 * kcb - naca;
-        cplx h22 = (xb - g1 * xa) * k;
-        cplx h23 = (naca - kcb) * imu2;
-        cplx h31 = (mu2 * g1) * (k * (xa - xb));
-        cplx h32 = mu2 * (g1 * g1 * kca - nbcb);
-        cplx h41 = mu2 * (g1 * g1 * kcb - naca);
-        z0 = h11 * y.v[0] + h12 * y.v[1] + h13 * y.v[2] + h14 * y.v[3];
-        z1 = h21 * y.v[0] + h22 * y.v[1] + h23 * y.v[2] - h13 * y.v[3];
-        z2 = h31 * y.v[0] + h32 * y.v[1] + h22 * y.v[2] - h12 * y.v[3];
-        z3 = h41 * y.v[0] - h31 * y.v[1] - h21 * y.v[2] + h11 * y.v[3];
-        T[3] = g * (r.v[0] * z0 + r.v[1] * z1 + r.v[2] * z2 + r.v[3] * z3);
+        cplx kdx = (xa - xb) * k;
+        cplx t = ((xa - g1 * xb) * k) * c11 + (g1 * kca - nbcb) * c12 - kdx * i13 + (nbcb - kca) * i14
+                 + (g1 * kcb - naca) * c21 + ((xb - g1 * xa) * k) * c22 + (naca - kcb) * i23
+                 + (g1 * kdx) * m31 + (g1sq * kca - nbcb) * m32 + (g1sq * kcb - naca) * m41;
+        T[3] = g * t;
     }
 }
 
