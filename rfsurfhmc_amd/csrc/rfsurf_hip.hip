@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -54,7 +55,7 @@ struct rfs_ctx {
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL;   // per-family search models / bldsph arrays (sphere, Love)
-    Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag,
+    Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
     // leapfrog state
     Buf lx, lp, lU, lgrad, ldsyn, lflag;
@@ -158,7 +159,7 @@ int run_fft(rfs_ctx* c, int nft, size_t batch, int inverse, void* in, void* out)
 struct KTimer {   // brackets a group of launches with HIP events on the stream they run on
     rfs_ctx* c; int id; hipStream_t s; hipEvent_t e1 = nullptr;
     KTimer(rfs_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
-        if (!c->timing) return;
+        if (!c->timing || id < 0) return;
         auto& pool = c->tev[id];
         size_t& u = c->tused[id];
         while (pool.size() < u + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pool.push_back(e); }
@@ -431,7 +432,10 @@ int launch_family_prep(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPl
 }
 
 // root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
-int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, bool kernels, bool roots = true) {
+// eigen_mode 0: every item; 1: EARLY launch of the Rayleigh items [0, early_items) beside a running search;
+// 2: MOP-UP of what the early launch left (k_swd_eigen)
+int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, bool kernels, bool roots = true,
+               int eigen_mode = 0, int early_items = 0) {
     const SwdSeqs& Q = P.QR;
     const int sphere = P.R.sphere;
     ENSURE(c, c->croot, (size_t)P.nitems * nchain * sizeof(double));
@@ -500,18 +504,21 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
         ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
         ENSURE(c, c->ugr, ntot * sizeof(double));
-        KTimer t(c, RFS_K_SWD_EIGEN, s);
-#define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL)                                                                  \
-        hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)QQ.nper_total * nchain + 63) / 64)),   \
+        KTimer t(c, eigen_mode == 1 ? -1 : RFS_K_SWD_EIGEN, s);     // the early launch hides behind the search: not timed
+#define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                                \
+        hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)),            \
                            dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(),     \
-                           SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>())
+                           SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (int)(EL1), EARLY, EDONE)
+        int* ed = eigen_mode ? c->edone.as<int>() : nullptr;
         if (P.QR.nper_total > 0) {
-            if (sphere) RFS_LAUNCH_EIGEN(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>());
-            else RFS_LAUNCH_EIGEN(false, false, P.QR, nullptr, c->sflag.as<int>());
+            const int el1 = eigen_mode == 1 ? early_items : P.QR.nper_total;
+            const int early = eigen_mode == 1;
+            if (sphere) RFS_LAUNCH_EIGEN(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>(), el1, early, ed);
+            else RFS_LAUNCH_EIGEN(false, false, P.QR, nullptr, c->sflag.as<int>(), el1, early, ed);
         }
-        if (P.QL.nper_total > 0) {
-            if (sphere) RFS_LAUNCH_EIGEN(true, true, P.QL, c->sphL.as<double>(), sflagL);
-            else RFS_LAUNCH_EIGEN(true, false, P.QL, nullptr, sflagL);
+        if (P.QL.nper_total > 0 && eigen_mode != 1) {
+            if (sphere) RFS_LAUNCH_EIGEN(true, true, P.QL, c->sphL.as<double>(), sflagL, P.QL.nper_total, 0, (int*)nullptr);
+            else RFS_LAUNCH_EIGEN(true, false, P.QL, nullptr, sflagL, P.QL.nper_total, 0, (int*)nullptr);
         }
 #undef RFS_LAUNCH_EIGEN
         HIPCHK(c, hipGetLastError());
@@ -571,6 +578,33 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     const bool part = !rf_time && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
                       c->swd_lanes == 0 && Q.nseq * nchain >= 1024 && nblk <= c->ncu / 2 &&
                       rf_half <= 1.1 * (npmax / 40.0);
+    // Early eigenfunction pass: with the partition on, the RF half of the chip finishes before the search does (config
+    // 2: 6.6 vs 7.5 ms).  The eigenfunction kernels of the first periods -- whose roots have long been final by then --
+    // fill that gap on the RF half; only the rest waits for the search (k_swd_eigen launch modes).  What is left for
+    // the mop-up should be whole rounds of the chip's wave slots (an eigenfunction wavefront runs ~0.4 ms however few
+    // there are), and the early part should end about when the search does.  Times calibrated at config 2; a wrong
+    // guess costs time, never results: a wavefront whose roots are not final is left to the mop-up launch.
+    int early_items = 0;
+    if (part && P.QR.nseq == 1 && P.QL.nseq == 0 && nchain % 64 == 0 && !getenv("RFS_NO_EARLY_EIGEN")) {
+        const double slack = 7.53 * (npmax / 40.0) - 6.59 * rf_half;             // ms, search end - RF end
+        const double cap = 1.3 * slack / (0.044 * (nchain / 8192.0));             // periods that fit (some overshoot pays)
+        const int ipr = std::max(1, c->ncu * 8 / (nchain / 64));                  // periods per full-chip round of slots
+        for (int r = 1; npmax - r * ipr > 0; r++)
+            if (npmax - r * ipr <= cap) { early_items = npmax - r * ipr; break; }
+        if (const char* e = getenv("RFS_EARLY_EIGEN_K")) early_items = atoi(e);
+        early_items = std::max(0, std::min(early_items, npmax - 1));
+    }
+    if (early_items > 0) {
+        const size_t ntot = (size_t)P.nitems * nchain;
+        ENSURE(c, c->croot, ntot * sizeof(double));
+        ENSURE(c, c->sflag, (size_t)8 * nchain * sizeof(int));
+        ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
+        ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
+        ENSURE(c, c->ugr, ntot * sizeof(double));
+        ENSURE(c, c->edone, (ntot / 64 + 1) * sizeof(int));
+        HIPCHK(c, hipMemsetAsync(c->croot.p, 0, ntot * sizeof(double), user));        // zero = root not final yet
+        HIPCHK(c, hipMemsetAsync(c->edone.p, 0, (ntot / 64 + 1) * sizeof(int), user));
+    }
     if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
         hipStream_t ss = part ? c->stream2m : c->stream2;
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
@@ -606,13 +640,14 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
           rc = launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true); }
         if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nchain, n, c->f); }
+        if (!rc && early_items > 0) rc = launch_swd(c, c->stream3, nchain, n, P, true, false, 1, early_items);
         }
         c->stream = user;
         if (rc) return rc;
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
     if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
-    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false));      // eigenfunction pass on the whole chip
+    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, early_items > 0 ? 2 : 0));   // (rest of the) eigenfunction pass, whole chip
     {
         KTimer t(c, RFS_K_COMBINE, c->stream);
         const SwdRows& R = P.R;
@@ -668,7 +703,7 @@ void rfs_destroy(rfs_ctx* c) {
     Buf* bufs[] = {&c->d_tw[0], &c->d_tw[1], &c->d_tw[2], &c->d_tw[3], &c->mdlSR, &c->mdlL, &c->sphR, &c->sphL, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
                    &c->d_minv, &c->spec3, &c->ts3, &c->S0f, &c->S0p, &c->pulse_spec, &c->pulse_ts, &c->Pbuf, &c->Cres,
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
-                   &c->croot, &c->sflag, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
+                   &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);

@@ -619,7 +619,11 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         const double* tp = tper + seq * npmax;
         auto T = [&](int k) { return tp[k]; };
         double* cr = croot + (size_t)sq.croot_off * nchain + chain;
-        auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
+        // agent-scope stores: an eigenfunction launch that runs beside this kernel on the other half of the chip may
+        // pick up finished periods (k_swd_eigen, early mode: a root is final once it is non-zero)
+        auto out = [&](int k, double v) {
+            if (live) __hip_atomic_store(&cr[(size_t)k * nchain], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
         RootSearchT<NevTabMem> rs;
         rs.tab.base = nev + bl; rs.tab.stride = 64;
         rs.begin(M, T, sq.nper);
@@ -773,23 +777,36 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
 
 // two waves per SIMD (a few spilled registers) hide the scratch round trip of the two sweeps better than one wave
 // with the whole register file: measured 1.27 -> 1.09 ms at 8192 chains x 40 periods x 30 layers (3 waves: 2.4 ms)
+// Launch modes.  Plain (early = 0, edone = nullptr): every item of the family.  EARLY (early = 1): items el0 .. el1-1
+// while the root search may still be running on other CUs -- the roots are read with agent-scope loads, a wavefront
+// whose 64 roots are not all final yet (zero = not written) leaves without a trace, one that is processed marks
+// edone[wave].  MOP-UP (early = 0, edone given): everything the early launch did not do.  nchain % 64 == 0 is
+// required when edone is used (a wavefront = 64 chains of one item).
 template <bool LOVE, bool SPH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
             const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
-            double* __restrict__ krn, double* __restrict__ ugr)
+            double* __restrict__ krn, double* __restrict__ ugr, int el0, int el1, int early, int* __restrict__ edone)
 {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)Q.nper_total * nchain) return;
-    int el = (int)(g / nchain), chain = (int)(g - (size_t)el * nchain);
+    if (g >= (size_t)(el1 - el0) * nchain) return;
+    int el = el0 + (int)(g / nchain), chain = (int)(g - (size_t)(el - el0) * nchain);
     int e = Q.s[0].croot_off + el;
     int seq = 0;
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
-    if (!sflag[(size_t)seq * nchain + chain]) return;
+    const size_t gi = (size_t)e * nchain + chain;
+    const size_t widx = ((size_t)el * nchain + chain) >> 6;
+    double cp;
+    if (early) {
+        cp = __hip_atomic_load(&croot[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!__all(cp != 0.0 && cp == cp)) return;
+    } else {
+        if (edone && edone[widx]) return;
+        if (!sflag[(size_t)seq * nchain + chain]) return;
+        cp = croot[gi];
+    }
     int k = e - Q.s[seq].croot_off;
     double t = Q.s[seq].t[k] * Q.s[seq].scale;
-    const size_t gi = (size_t)e * nchain + chain;
-    double cp = croot[gi];
     const size_t s = (size_t)n * nchain;
     double* ko = krn + (size_t)e * 4 * s + chain;       // [e][q][m][chain]
     if (SPH) {
@@ -799,6 +816,7 @@ k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         swd_eigen_lane<LOVE>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
     }
+    if (early && (threadIdx.x & 63) == 0) edone[widx] = 1;
 }
 
 // Data rows.  Up to four blocks in data order (Rc, Rg, Lc, Lg); a phase block reads the items of its

@@ -84,3 +84,35 @@ def test_directional_derivatives(full):
     an = np.sum(grad[idx] * v, axis=1)
     err = np.abs(fd - an) / np.maximum(np.abs(an), 1e-3 * np.linalg.norm(grad[idx], axis=1))
     assert np.median(err) < 5e-3 and np.quantile(err, 0.95) < 5e-2, (np.median(err), np.quantile(err, 0.95))
+
+
+def test_early_eigenfunction_launch_changes_nothing(monkeypatch):
+    """The eigenfunction kernels of the first periods run on the RF half of the chip while the root search is still
+    busy (k_swd_eigen early / mop-up modes): whatever number of periods goes early -- none, the calibrated choice, all
+    but one (many of which are not ready and fall to the mop-up) -- misfit, gradient, synthetics and flags are
+    bit-identical."""
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    t = np.linspace(5, 44, bench.NPER)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT, bench.WATER,
+                                                 "P", "freq"), SurfWD(tRc=t))
+    drf, dswd, flag = joint.forward(bench.true_model())
+    joint.set_obsdata(drf, dswd)
+    x = torch.from_numpy(bench.make_models(8192, 7)).cuda()
+    monkeypatch.setenv("RFS_NO_EARLY_EIGEN", "1")
+    ref = [o.clone() for o in joint.misfit_and_grad_device(x)]
+    torch.cuda.synchronize()
+    monkeypatch.delenv("RFS_NO_EARLY_EIGEN")
+    for k in (None, "1", "24", "39"):
+        if k is None:
+            monkeypatch.delenv("RFS_EARLY_EIGEN_K", raising=False)
+        else:
+            monkeypatch.setenv("RFS_EARLY_EIGEN_K", k)
+        for rep in range(2):
+            out = joint.misfit_and_grad_device(x)
+            torch.cuda.synchronize()
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), (k, rep)
