@@ -138,6 +138,7 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
         } else {
             rf_half_partials(L[j], omega, f.rf_type, y, T);
         }
+        double e4[4];
 #pragma unroll
         for (int ip = 0; ip < 4; ip++) {
             cplx num = T[ip];
@@ -147,12 +148,15 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
             if (edge) S.im = 0.0;
             double e = live ? ck * g2 * norm2(num) : 0.0;
             if (live) out[((size_t)ip * n + j) * f.n2] = S;
-            if (TAIL) {
-                sp[(size_t)ip * n + j] = e;
-            } else {
-                e = wave_sum_uniform(e);
-                if (lane == (j & 63)) acc[ip][j >> 6] = e;
-            }
+            e4[ip] = e;
+            if (TAIL) sp[(size_t)ip * n + j] = e;
+        }
+        if (!TAIL) {
+            double t4[4];
+            wave_sum4_uniform(e4, t4);
+#pragma unroll
+            for (int ip = 0; ip < 4; ip++)
+                if (lane == (j & 63)) acc[ip][j >> 6] = t4[ip];
         }
     }
     if (!TAIL) {

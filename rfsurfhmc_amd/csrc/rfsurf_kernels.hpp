@@ -63,6 +63,38 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// Four wave-wide sums at once: two transposing butterfly steps inside each quad leave every lane with ONE partial sum
+// (lane l of a quad holds value (l & 3)), so that only one value per lane instead of four goes through the four
+// cross-quad steps.  Returns the total of value q in out[q], wave-uniform.  About half the instructions of the
+// four separate sums of a pass-B layer; fixed order -> deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sum4_uniform(const double v[4], double out[4]) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    // step 1 (partner = lane ^ 1): even lanes collect values 0, 1; odd lanes values 2, 3
+    double ka = b0 ? v[2] : v[0], kb = b0 ? v[3] : v[1];
+    double sa = b0 ? v[0] : v[2], sb = b0 ? v[1] : v[3];
+    ka += dpp_xchg<0xb1>(sa); kb += dpp_xchg<0xb1>(sb);          // quad_perm [1,0,3,2]
+    // step 2 (partner = lane ^ 2): lanes 0,1 of a quad keep the first of their pair, lanes 2,3 the second
+    double k = b1 ? kb : ka, s2 = b1 ? ka : kb;
+    k += dpp_xchg<0x4e>(s2);                                      // quad_perm [2,3,0,1]
+    // lane l of every quad now holds the quad's sum of value q(l): l&3 = 0 -> v0, 1 -> v2, 2 -> v1, 3 -> v3
+    k = dpp_add_step<0x114, 0xf>(k);     // row_shr:4
+    k = dpp_add_step<0x118, 0xf>(k);     // row_shr:8  -> lanes 12..15 of each row: the row's four totals
+    // across the four rows the lanes must keep their identity (row_bcast would spread lane 15 only): two shuffles
+    k += __shfl_xor(k, 16, 64);
+    k += __shfl_xor(k, 32, 64);
+    const int lo = __double2loint(k), hi = __double2hiint(k);
+    out[0] = __hiloint2double(__builtin_amdgcn_readlane(hi, 12), __builtin_amdgcn_readlane(lo, 12));
+    out[2] = __hiloint2double(__builtin_amdgcn_readlane(hi, 13), __builtin_amdgcn_readlane(lo, 13));
+    out[1] = __hiloint2double(__builtin_amdgcn_readlane(hi, 14), __builtin_amdgcn_readlane(lo, 14));
+    out[3] = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -355,16 +387,20 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
         } else {
             rf_half_partials(L[j], omega, f.rf_type, y, T);
         }
+        double v4[4];
 #pragma unroll
         for (int ip = 0; ip < 4; ip++) {
             double v = T[ip].re;
             if (v != v) v = 0.0;                                  // NaN scrub (:698-703)
-            if (TAIL) {
-                pg[(size_t)ip * n + j] = v;
-            } else {
-                v = wave_sum_uniform(v);
-                if (lane == (j & 63)) acc[ip][j >> 6] = v;
-            }
+            v4[ip] = v;
+            if (TAIL) pg[(size_t)ip * n + j] = v;
+        }
+        if (!TAIL) {
+            double t4[4];
+            wave_sum4_uniform(v4, t4);
+#pragma unroll
+            for (int ip = 0; ip < 4; ip++)
+                if (lane == (j & 63)) acc[ip][j >> 6] = t4[ip];
         }
     }
     if (!TAIL) {
