@@ -184,7 +184,11 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *   "cu_split"             0 = RF kernels on the caller's stream, sharing CUs with the root search;
  *                          1 (default) / 2 = when the cooperative root search fits on half of the CUs, it and
  *                          the RF kernels run on disjoint halves of the CU mask (contiguous halves / even-odd
- *                          bits); the eigenfunction pass and the combine use the whole chip. */
+ *                          bits); the combine uses the whole chip.
+ *   "early_eigen_periods"  in a partitioned step the RF half finishes before the root search; the eigenfunction
+ *                          kernels of the first periods (whose roots are final by then) run there early and only
+ *                          the rest waits for the search.  -1 (default) = automatic count, 0 = off, k > 0 = the
+ *                          first k periods.  Results are bit-identical for every value. */
 int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
 /* Kernel groups of one rfs_joint_misfit_grad_dev call.  With timing enabled every group of every
  * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on

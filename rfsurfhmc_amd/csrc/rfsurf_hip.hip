@@ -5,7 +5,6 @@
 
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -35,6 +34,7 @@ struct rfs_ctx {
     // user/main stream; SWD search stream; CU-partitioned pair (search on one half of the chip, RF on the other)
     hipStream_t stream = nullptr, stream2 = nullptr, stream2m = nullptr, stream3 = nullptr;
     bool own_stream = false;
+    int early_eigen = -1;      // periods whose eigenfunction kernels run early on the RF half: -1 automatic, 0 off
     int cu_split = 1;          // 0: never partition; 1/2: partition (contiguous / even-odd mask bits) when the
                                // cooperative search fits on half of the CUs
     int ncu = 0;
@@ -585,13 +585,13 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     // there are), and the early part should end about when the search does.  Times calibrated at config 2; a wrong
     // guess costs time, never results: a wavefront whose roots are not final is left to the mop-up launch.
     int early_items = 0;
-    if (part && P.QR.nseq == 1 && P.QL.nseq == 0 && nchain % 64 == 0 && !getenv("RFS_NO_EARLY_EIGEN")) {
+    if (part && P.QR.nseq == 1 && P.QL.nseq == 0 && nchain % 64 == 0 && c->early_eigen != 0) {
         const double slack = 7.53 * (npmax / 40.0) - 6.59 * rf_half;             // ms, search end - RF end
         const double cap = 1.3 * slack / (0.044 * (nchain / 8192.0));             // periods that fit (some overshoot pays)
         const int ipr = std::max(1, c->ncu * 8 / (nchain / 64));                  // periods per full-chip round of slots
         for (int r = 1; npmax - r * ipr > 0; r++)
             if (npmax - r * ipr <= cap) { early_items = npmax - r * ipr; break; }
-        if (const char* e = getenv("RFS_EARLY_EIGEN_K")) early_items = atoi(e);
+        if (c->early_eigen > 0) early_items = c->early_eigen;
         early_items = std::max(0, std::min(early_items, npmax - 1));
     }
     if (early_items > 0) {
@@ -773,6 +773,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         HIPCHK(c, hipDeviceSynchronize());
         c->cu_split = value;
         return make_partition_streams(c);
+    }
+    if (!strcmp(name, "early_eigen_periods")) {
+        if (value < -1) return fail(c, RFS_ERR_ARG, "early_eigen_periods must be -1 (automatic), 0 (off) or a period count");
+        c->early_eigen = value; return RFS_OK;
     }
     return fail(c, RFS_ERR_ARG, std::string("unknown option ") + name);
 }

@@ -86,7 +86,7 @@ def test_directional_derivatives(full):
     assert np.median(err) < 5e-3 and np.quantile(err, 0.95) < 5e-2, (np.median(err), np.quantile(err, 0.95))
 
 
-def test_early_eigenfunction_launch_changes_nothing(monkeypatch):
+def test_early_eigenfunction_launch_changes_nothing():
     """The eigenfunction kernels of the first periods run on the RF half of the chip while the root search is still
     busy (k_swd_eigen early / mop-up modes): whatever number of periods goes early -- none, the calibrated choice, all
     but one (many of which are not ready and fall to the mop-up) -- misfit, gradient, synthetics and flags are
@@ -102,17 +102,17 @@ def test_early_eigenfunction_launch_changes_nothing(monkeypatch):
     drf, dswd, flag = joint.forward(bench.true_model())
     joint.set_obsdata(drf, dswd)
     x = torch.from_numpy(bench.make_models(8192, 7)).cuda()
-    monkeypatch.setenv("RFS_NO_EARLY_EIGEN", "1")
+    ctx = joint._ensure(bench.N_LAYER)
+    ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", 0))
     ref = [o.clone() for o in joint.misfit_and_grad_device(x)]
     torch.cuda.synchronize()
-    monkeypatch.delenv("RFS_NO_EARLY_EIGEN")
-    for k in (None, "1", "24", "39"):
-        if k is None:
-            monkeypatch.delenv("RFS_EARLY_EIGEN_K", raising=False)
-        else:
-            monkeypatch.setenv("RFS_EARLY_EIGEN_K", k)
-        for rep in range(2):
-            out = joint.misfit_and_grad_device(x)
-            torch.cuda.synchronize()
-            for a, b in zip(out, ref):
-                assert torch.equal(a, b), (k, rep)
+    try:
+        for k in (-1, 1, 24, 39):
+            ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", k))
+            for rep in range(2):
+                out = joint.misfit_and_grad_device(x)
+                torch.cuda.synchronize()
+                for a, b in zip(out, ref):
+                    assert torch.equal(a, b), (k, rep)
+    finally:
+        ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", -1))
