@@ -658,7 +658,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                                c->cr.as<double>(), misfit, grad, flag);
         if (c->has_swd) {
 #define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
-            hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 63) / 64), dim3(64, 16), (size_t)n * 64 * sizeof(double), \
+            hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 16), (size_t)n * 32 * sizeof(double), \
                                c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),     \
                                c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),      \
                                P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag)

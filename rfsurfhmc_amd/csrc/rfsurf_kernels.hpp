@@ -938,7 +938,7 @@ __global__ void k_swd_export(int nchain, int n, SwdRows R, const double* __restr
 // ---------------------------------------------------------------------------------------
 // K5 split in two so that every large array is read coalesced:
 //   k_rf_reduce   block = chain, thread = layer : fixed-order sum of the pass-B partials + chain rule -> grad
-//   k_swd_combine block = 64 chains x 16 layer groups (0.37 -> 0.17 ms against 4: the grid is only nchain/64 blocks), lane = chain : K.r over the periods (krn is chain-minor),
+//   k_swd_combine block = 32 chains x 32 layer slots, half-wave = 32 chains : K.r over the periods (krn is chain-minor),
 //                 interface -> thickness suffix sums, weighting, misfit, failure returns
 // mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198), 2 SWD only (model_surf.py:155-228)
 __global__ void __launch_bounds__(MAXL)
@@ -969,9 +969,11 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
               const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
               double* __restrict__ dsyn, int* __restrict__ flag)
 {
-    extern __shared__ double hs[];               // [n][64] interface partial sums
-    const int tx = threadIdx.x, ty = threadIdx.y, TY = blockDim.y;
-    int chain = blockIdx.x * 64 + tx;
+    extern __shared__ double hs[];               // [n][32] interface partial sums
+    // 32 chains x 32 layer slots per block: a wavefront = 32 consecutive chains (256 B segments of the chain-minor
+    // arrays) x 2 layer slots, so the grid has nchain/32 blocks -- one per CU at 8192 chains instead of one per two
+    const int tx = threadIdx.x & 31, slot = threadIdx.y * 2 + (threadIdx.x >> 5), NS = blockDim.y * 2;
+    int chain = blockIdx.x * 32 + tx;
     const bool inb = chain < nchain;
     if (!inb) chain = nchain - 1;
     const int nswd = R.nswd, ndata = nt + nswd;
@@ -979,7 +981,7 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
     for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
     const double w = (mode == 0) ? wt : 1.0;
     double m_swd = 0.0;
-    for (int j = ty; j < n; j += TY) {
+    for (int j = slot; j < n; j += NS) {
         double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
         double gs = 0.0, hj = 0.0;
         if (ok) {
@@ -989,7 +991,7 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
                 for (int k = 0; k < B.nrow; k++, row++) {
                     double d = swd_data_value<SPH>(R, B, k, chain, nchain, croot, ugr);
                     double r = d - dobs[nt + row];
-                    if (j == ty && ty == 0) {
+                    if (j == slot && slot == 0) {
                         m_swd += r * r;
                         if (inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
                     }
@@ -1002,7 +1004,7 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
                 }
             }
         }
-        hs[(size_t)j * 64 + tx] = hj;
+        hs[(size_t)j * 32 + tx] = hj;
         if (inb) {
             size_t o = (size_t)chain * 2 * n + j;
             if (!ok) grad[o] = 0.0;
@@ -1010,9 +1012,9 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
         }
     }
     __syncthreads();
-    for (int j = ty; j < n; j += TY) {
+    for (int j = slot; j < n; j += NS) {
         double t = 0.0;
-        for (int m = j + 1; m < n; m++) t += hs[(size_t)m * 64 + tx];       // interface -> thickness partials
+        for (int m = j + 1; m < n; m++) t += hs[(size_t)m * 32 + tx];       // interface -> thickness partials
         if (inb) {
             size_t o = (size_t)chain * 2 * n + n + j;
             if (!ok) grad[o] = 0.0;
@@ -1022,11 +1024,11 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
     if (!inb) return;
     if (!ok) {
         // failure returns: joint -> (0, zeros, dobs, False); SWD only -> (0, zeros, zeros, False)
-        if (dsyn) for (int i = ty; i < ndata; i += TY) dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
-        if (ty == 0) { misfit[chain] = 0.0; flag[chain] = 0; }
+        if (dsyn) for (int i = slot; i < ndata; i += NS) dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
+        if (slot == 0) { misfit[chain] = 0.0; flag[chain] = 0; }
         return;
     }
-    if (ty == 0) {
+    if (slot == 0) {
         double mr = (mode == 0) ? misfit_rf[chain] : 0.0;
         misfit[chain] = mr + w * (0.5 * m_swd);
         flag[chain] = 1;
