@@ -585,6 +585,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     // there are), and the early part should end about when the search does.  Times calibrated at config 2; a wrong
     // guess costs time, never results: a wavefront whose roots are not final is left to the mop-up launch.
     int early_items = 0;
+    bool rf_reduced = false;
     if (part && P.QR.nseq == 1 && P.QL.nseq == 0 && nchain % 64 == 0 && c->early_eigen != 0) {
         const double slack = 7.53 * (npmax / 40.0) - 6.59 * rf_half;             // ms, search end - RF end
         const double cap = 1.3 * slack / (0.044 * (nchain / 8192.0));             // periods that fit (some overshoot pays)
@@ -639,7 +640,13 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         } else {
         if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
           rc = launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true); }
-        if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nchain, n, c->f); }
+        if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nchain, n, c->f);
+            if (!rc && part) {      // the RF part of the gradient does not wait for the search: reduce it on the RF half
+                hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
+                                   (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
+                                   c->cr.as<double>(), misfit, grad, flag);
+                rf_reduced = true;
+            } }
         if (!rc && early_items > 0) rc = launch_swd(c, c->stream3, nchain, n, P, true, false, 1, early_items);
         }
         c->stream = user;
@@ -652,7 +659,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         KTimer t(c, RFS_K_COMBINE, c->stream);
         const SwdRows& R = P.R;
         int nt = c->has_rf ? c->f.nt : 0;
-        if (c->has_rf)
+        if (c->has_rf && !rf_reduced)
             hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
                                (int)!c->has_swd, rf_time ? 1 : rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
                                c->cr.as<double>(), misfit, grad, flag);
