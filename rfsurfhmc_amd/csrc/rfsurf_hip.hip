@@ -546,14 +546,6 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     ENSURE(c, c->cr, (size_t)nchain * 2 * n * sizeof(double));
     if (c->has_rf) ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
     if (c->has_swd) { ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float)); ENSURE(c, c->mdlc, (size_t)6 * n * nchain * sizeof(double)); }
-    {
-        KTimer t(c, RFS_K_PREP, c->stream);
-        int nth = nchain * n;
-        hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, x,
-                           (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd,
-                           c->mdl.as<float>(), c->mdlc.as<double>());
-        HIPCHK(c, hipGetLastError());
-    }
     const double* tw[4] = {c->d_tw[0].as<double>(), c->d_tw[1].as<double>(), c->d_tw[2].as<double>(), c->d_tw[3].as<double>()};
     if (c->has_swd) {
         size_t nn = (size_t)n * nchain;
@@ -562,7 +554,6 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     }
     SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>());
     const SwdSeqs& Q = P.QR;
-    if (c->has_swd) { KTimer t(c, RFS_K_PREP, c->stream); TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere)); }
     hipStream_t user = c->stream;
     // CU partition: the cooperative search occupies one CU per 64 sequences; when that fits on half of the
     // chip it runs there undisturbed and the RF kernels take the other half (measured +11 % at config 2)
@@ -603,8 +594,18 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
         ENSURE(c, c->ugr, ntot * sizeof(double));
         ENSURE(c, c->edone, (ntot / 64 + 1) * sizeof(int));
-        HIPCHK(c, hipMemsetAsync(c->croot.p, 0, ntot * sizeof(double), user));        // zero = root not final yet
-        HIPCHK(c, hipMemsetAsync(c->edone.p, 0, (ntot / 64 + 1) * sizeof(int), user));
+    }
+    {   // layer constants, search models -- and, for the early launch, the cleared root buffer (zero = not final) and done map
+        KTimer t(c, RFS_K_PREP, c->stream);
+        const size_t ntot = (size_t)P.nitems * nchain;
+        int nth = nchain * n;
+        hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, x,
+                           (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd,
+                           c->mdl.as<float>(), c->mdlc.as<double>(),
+                           early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
+                           early_items > 0 ? c->edone.as<int>() : (int*)nullptr, early_items > 0 ? ntot / 64 + 1 : (size_t)0);
+        HIPCHK(c, hipGetLastError());
+        if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
     }
     if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
         hipStream_t ss = part ? c->stream2m : c->stream2;
@@ -1027,7 +1028,7 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
     int nth = nchain * n;
     hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->x.as<double>(),
                        (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd, c->mdl.as<float>(),
-                       c->mdlc.as<double>());
+                       c->mdlc.as<double>(), (double*)nullptr, (size_t)0, (int*)nullptr, (size_t)0);
     int nt = c->has_rf ? c->f.nt : 0;
     if (c->has_rf) {
         RfFreq f = c->f; f.fwd_order = 1; f.pi64 = 0;      // cal_rf_freq / cal_rf_time frequency axis

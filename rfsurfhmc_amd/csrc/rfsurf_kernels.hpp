@@ -117,9 +117,14 @@ __device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int 
 // ---------------------------------------------------------------------------------------
 __global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, int has_rf, double ray_p,
                              RfLayer* __restrict__ lc, double* __restrict__ cr, int has_swd,
-                             float* __restrict__ mdl, double* __restrict__ mdlc)
+                             float* __restrict__ mdl, double* __restrict__ mdlc,
+                             double* __restrict__ zero_d, size_t nzero_d, int* __restrict__ zero_i, size_t nzero_i)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // per-step clearing for the early eigenfunction launch (roots: zero = not final; done map), folded in here
+    // instead of two memset launches in front of the fork
+    for (size_t i = g; i < nzero_d; i += (size_t)gridDim.x * blockDim.x) zero_d[i] = 0.0;
+    for (size_t i = g; i < nzero_i; i += (size_t)gridDim.x * blockDim.x) zero_i[i] = 0;
     if (g >= nchain * n) return;
     int chain = g / n, j = g - chain * n;
     double vs = x[(size_t)chain * 2 * n + j], thk = x[(size_t)chain * 2 * n + n + j];
