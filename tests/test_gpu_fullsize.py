@@ -116,3 +116,49 @@ def test_early_eigenfunction_launch_changes_nothing():
                     assert torch.equal(a, b), (k, rep)
     finally:
         ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", -1))
+
+
+def test_early_launch_with_failing_chains(orc):
+    """Chains whose root search fails (the reference fails on them too) inside a full-size batch: their later roots
+    never become final, so the early eigenfunction launch must leave those wavefronts to the mop-up.  Same flags as the
+    oracle, failure returns for them, and every chain bit-identical with the early launch off, automatic and maximal."""
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    t = np.linspace(5, 44, bench.NPER)
+    osw = orc.SurfWD(tRc=t)
+    rng = np.random.default_rng(12)
+    failing = []
+    while len(failing) < 6:
+        vs = 1.5 + 3.5 * rng.random(30); vs[-1] = 1.5
+        thk = 0.2 + 1.0 * rng.random(30); thk[-1] = 0.0
+        xm = np.hstack((vs, thk))
+        if not osw.forward(xm)[1]:
+            failing.append(xm)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT, bench.WATER,
+                                                 "P", "freq"), SurfWD(tRc=t))
+    drf, dswd, flag = joint.forward(bench.true_model())
+    joint.set_obsdata(drf, dswd)
+    xs = bench.make_models(8192, 3)
+    where = [0, 63, 64, 1000, 4097, 8191]
+    for w, xm in zip(where, failing):
+        xs[w] = xm
+    x = torch.from_numpy(xs).cuda()
+    ctx = joint._ensure(bench.N_LAYER)
+    outs = {}
+    try:
+        for k in (0, -1, 39):
+            ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", k))
+            outs[k] = [o.clone() for o in joint.misfit_and_grad_device(x)]
+            torch.cuda.synchronize()
+    finally:
+        ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", -1))
+    for k in (-1, 39):
+        for a, b in zip(outs[k], outs[0]):
+            assert torch.equal(a, b), k
+    misfit, grad, dsyn, fl = [o.cpu().numpy() for o in outs[0]]
+    assert sorted(np.nonzero(fl == 0)[0].tolist()) == where
+    for w in where:                                   # model_rf_swd_vs_thk.py:73-74: (0, zeros, dobs, False)
+        assert misfit[w] == 0.0 and not grad[w].any() and np.array_equal(dsyn[w], joint.dobs)
