@@ -194,7 +194,9 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on
  * (the root search / eigenfunction groups run on the context's second stream); nothing
  * synchronises until rfs_kernel_ms_sum() sums the elapsed times (ms) and launch counts per
- * group and resets the accumulators. */
+ * group and resets the accumulators.  rfs_enable_timing: on = 0 off, 1 every group, 2 * mask (mask bit = rfs_kernel_id)
+ * only those groups -- every event pair costs a few microseconds of the step, so a caller that needs one group's
+ * duration inside a timed region enables just that one. */
 typedef enum {
     RFS_K_PREP = 0, RFS_K_RF_PASS_A, RFS_K_RF_MID, RFS_K_RF_PASS_B, RFS_K_SWD_ROOTS, RFS_K_SWD_EIGEN,
     RFS_K_COMBINE, RFS_K_COUNT

@@ -64,6 +64,7 @@ struct rfs_ctx {
     // timing: every bracketed launch group gets its own event pair, recorded on the stream the
     // kernels run on; nothing synchronises until rfs_kernel_ms_sum() is called
     bool timing = false;
+    unsigned timing_mask = ~0u;     // groups that get event pairs while timing is on (bit = rfs_kernel_id)
     std::vector<hipEvent_t> tev[RFS_K_COUNT];
     size_t tused[RFS_K_COUNT] = {};
 };
@@ -159,7 +160,7 @@ int run_fft(rfs_ctx* c, int nft, size_t batch, int inverse, void* in, void* out)
 struct KTimer {   // brackets a group of launches with HIP events on the stream they run on
     rfs_ctx* c; int id; hipStream_t s; hipEvent_t e1 = nullptr;
     KTimer(rfs_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
-        if (!c->timing || id < 0) return;
+        if (!c->timing || id < 0 || !((c->timing_mask >> id) & 1u)) return;
         auto& pool = c->tev[id];
         size_t& u = c->tused[id];
         while (pool.size() < u + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pool.push_back(e); }
@@ -748,6 +749,7 @@ int rfs_synchronize(rfs_ctx* c) {
 int rfs_enable_timing(rfs_ctx* c, int on) {
     if (!c) return RFS_ERR_ARG;
     c->timing = on != 0;
+    c->timing_mask = (on == 0 || on == 1) ? ~0u : ((unsigned)on >> 1);      // on = 1: all groups; on = 2 * mask: those groups only
     for (auto& u : c->tused) u = 0;
     return RFS_OK;
 }
