@@ -458,13 +458,20 @@ struct RootSearchT {
                 else {
                     double ym1;
                     bool bail = false;
+                    double xn = 0.0;                     // x(j+1) of the running recurrence (kDynamic form)
                     if (Tab::kDynamic) {
-                        if (nev == 2) { tab.sx(m + 1, c3); tab.sy(m + 1, del3); ym1 = del3; }
-                        else { tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2; }
+                        // x(j+1) travels in a register and the operands of step j-1 are fetched before step j's
+                        // division: the memory round trip of the table leaves the dependent chain (same arithmetic)
+                        if (nev == 2) { tab.sx(m + 1, c3); tab.sy(m + 1, del3); ym1 = del3; xn = c3; }
+                        else { tab.sx(1, c1); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2); m = 1; ym1 = del2; xn = c2; }
+                        double yj = tab.gy(m), xj = tab.gx(m);
                         for (int j = m; j >= 1 && !bail; j--) {
-                            double yj = tab.gy(j), denom = ym1 - yj;
+                            double yn = 0.0, xq = 0.0;
+                            if (j > 1) { yn = tab.gy(j - 1); xq = tab.gx(j - 1); }
+                            double denom = ym1 - yj;
                             if (fabs(denom) < 1.0e-10 * fabs(ym1)) bail = true;
-                            else tab.sx(j, (-yj * tab.gx(j + 1) + ym1 * tab.gx(j)) / denom);
+                            else { xn = (-yj * xn + ym1 * xj) / denom; tab.sx(j, xn); }
+                            yj = yn; xj = xq;
                         }
                     } else {
                         if (nev == 2) {
@@ -484,7 +491,7 @@ struct RootSearchT {
                         }
                     }
                     if (bail) { st_half = true; half_phase = PH_HALF_B; }
-                    else { c3 = tab.gx(1); creq = c3; phase = PH_NEV; }
+                    else { c3 = Tab::kDynamic ? xn : tab.gx(1); creq = c3; phase = PH_NEV; }
                 }
             }
         }
