@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- leapfrog-step (= misfit+gradient evaluation) throughput of the HIP hot path.
+"""bench.py -- leapfrog-step throughput of the HIP hot path (BASELINE.json `metric`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--chains C]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,3,4}] [--chains C]
 
-Workload (BASELINE.json configs[1]): 8192 chains x 30-layer Vs+thk models per GPU, joint
-RF (P, nt=512, dt=0.1, Gaussian 1.5, shift 5 s, water 1e-3, freq method) + 40 Rayleigh phase
-periods linspace(5,44,40); synthetic sorted-prior models, dobs = forward(true model).
-A "step" = one evaluation of misfit+gradient for every chain of the rank (what one leapfrog step
-of every chain costs); inputs are resident in HBM when the timed region starts.
-Independent chains shard across ranks (weak scaling, no data-path collective); the only
-collective is the RCCL gather of the per-chain misfits after the timed region.
+--gpus N launches N ranks BY ITSELF (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for
+each, torch.distributed over RCCL); under `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE
+already in the environment) the process is one of those ranks.  Counterpart of the reference's
+`mpiexec -n N python main_base.py` (main_base.py:16-18,59-60,90).  The launching process never touches the GPU.
+
+Workloads (BASELINE.json `configs`; --config selects, configs[1] is the default and the headline):
+  1  configs[1]: 8192 chains x 30-layer Vs+thk models per GPU, joint RF (P, nt = 512, dt = 0.1, Gaussian 1.5,
+     shift 5 s, water 1e-3, freq method) + 40 Rayleigh phase periods linspace(5, 44, 40)
+  4  configs[4]: the same with a 2048-point RF trace (dt = 0.025 s)
+  3  configs[3]: HMCDualAveraging.sample_flow (main_DA.py), 8192 chains x 50 layers: a real sampler run with
+     per-chain dt and L = max(1, int(lambda / dt)), host accept / reject and dual averaging included
+Synthetic sorted-prior models, dobs = forward(true model).
+
+A "step" = ONE LEAPFROG STEP OF EVERY CHAIN of the rank through the C ABI (rfs_flow_step: drift with mirror
+reflection, misfit + gradient evaluation, kick; pyhmc/hmc.py:164-183); state resident in HBM when the timed
+region starts.  value = leapfrog steps (= evaluations) of all ranks / max-over-ranks wall time.  Independent
+chains shard across ranks (weak scaling, no data-path collective); the only collective is the RCCL gather of the
+per-chain misfits after the timed region (comm.Gather, main_base.py:90).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,30 +37,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_LAYER, NT, DT, NPER = 30, 512, 0.1, 40
 RAY_P, GAUSS, TSHIFT, WATER = 0.045, 1.5, 5.0, 0.001
-# algorithmic bytes / flops per evaluation at this shape (plugin contract:
-# x in; misfit, grad, dsyn, flag out)
-ALG_BYTES_PER_EVAL = 8 * 2 * N_LAYER + 8 + 8 * 2 * N_LAYER + 8 * (NT + NPER) + 4     # 5388
-ALG_FLOPS_PER_EVAL = 2.8e7
+NPER = 40
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64: 256 CUs
+METRIC = "leapfrog steps/sec (= forward+grad evals/sec) per GPU and whole node, 30-layer model"
+
+CONFIGS = {
+    1: dict(idx=1, n=30, nt=512, dt=0.1, sampler=None,
+            name="configs[1]: 8192 chains x 30-layer Vs+thk, joint RF(512 samples)+SWD(40 Rc periods) per GPU"),
+    4: dict(idx=4, n=30, nt=2048, dt=0.025, sampler=None,
+            name="configs[4]: frequency-domain RF with a 2048-point FFT, 8192 chains x 30 layers + 40 Rc periods per GPU"),
+    3: dict(idx=3, n=50, nt=512, dt=0.1, sampler="da",
+            name="configs[3]: main_DA.py dual averaging (HMCDualAveraging.sample_flow), 8192 chains x 50-layer model, "
+                 "joint RF(512)+SWD(40 Rc) per GPU, per-chain dt and L"),
+}
+# backwards-compatible module constants (scripts/ import them): the headline shape
+N_LAYER, NT, DT = 30, 512, 0.1
 
 
-def true_model():
-    thk = np.full(N_LAYER, 2.0); thk[-1] = 0.0
-    vs = np.linspace(2.8, 4.6, N_LAYER)
+def alg_bytes_per_eval(n, nt, nper=NPER):
+    """plugin contract -- x in; misfit, grad, dsyn, flag out."""
+    return 8 * 2 * n + 8 + 8 * 2 * n + 8 * (nt + nper) + 4          # 5388 at n = 30, nt = 512
+
+
+def alg_flops_per_eval(n, nt):
+    """Hand count of SURVEY.md section 8(d) for the minimal O(n) algorithm (each transcendental = 1 flop), split per
+    kernel group; SWD scales with the layer count, RF with layers x frequencies.  n = 30, nt = 512: 2.8e7."""
+    n2 = (1 << (nt - 1).bit_length()) // 2 + 1
+    s, r = n / 30.0, (n / 30.0) * (n2 / 257.0)
+    return {"swd_roots": 5.3e6 * s, "swd_eigen": 2.1e6 * s, "rf_pass_a": 0.6e7 * r, "rf_pass_b": 1.5e7 * r}
+
+
+ALG_BYTES_PER_EVAL = alg_bytes_per_eval(N_LAYER, NT)
+ALG_FLOPS_PER_EVAL = sum(alg_flops_per_eval(N_LAYER, NT).values())
+
+
+def true_model(n=N_LAYER):
+    thk = np.full(n, 60.0 / n); thk[-1] = 0.0
+    vs = np.linspace(2.8, 4.6, n)
     return np.hstack((vs, thk))
 
 
-def make_models(nchain, seed):
+def bounds_of(x0):
+    """Search range of main_base.py:64-77 / main_DA.py:64-77."""
+    n = len(x0) // 2
+    lo = np.r_[np.maximum(0.2 * x0[:n], 1.5), 0.8 * x0[n:]]
+    hi = np.r_[np.minimum(1.8 * x0[:n], 5.0), 1.2 * x0[n:]]
+    lo[-1], hi[-1] = 0.0, 2.0
+    return np.stack([lo, hi], axis=1)
+
+
+def make_models(nchain, seed, n=N_LAYER):
     """Sorted-prior initial models inside the main_base.py:64-77 bounds (pyhmc/hmc.py:74-93 rule)."""
-    x0 = true_model()
-    vs0, thk0 = x0[:N_LAYER], x0[N_LAYER:]
+    x0 = true_model(n)
+    vs0, thk0 = x0[:n], x0[n:]
     lo = np.maximum(vs0 - 0.8 * vs0, 1.5); hi = np.minimum(vs0 + 0.8 * vs0, 5.0)
     rng = np.random.default_rng(seed)
-    v = lo + (hi - lo) * rng.random((nchain, N_LAYER))
-    h = thk0 * (0.8 + 0.4 * rng.random((nchain, N_LAYER)))
+    v = lo + (hi - lo) * rng.random((nchain, n))
+    h = thk0 * (0.8 + 0.4 * rng.random((nchain, n)))
     h[:, -1] = 2.0 * rng.random(nchain)          # last thickness is a dummy in [0, 2]
     idx = np.argsort(v, axis=1)
     v = np.take_along_axis(v, idx, axis=1)
@@ -56,105 +103,292 @@ def make_models(nchain, seed):
     return np.hstack((v, h))
 
 
-def cpu_baseline(xs, dobs, budget_s=12.0):
-    """Reference CPU path timed on one host core: the reference's own compiled sources (oracle/_ref:
-    libsurf complete; RF propagator/partials core + numpy irfft tail) driven by the oracle's numpy
-    restatement of the plugins; falls back to the C restatement when oracle/_ref is absent."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_worker(args):
+    """One host core: the reference's own compiled sources (oracle/_ref: libsurf complete; RF propagator / partials
+    core from RFModule.f90 + numpy irfft for the 15-line tail) driven by the oracle's numpy restatement of the
+    plugins, one independent chain per process as the reference runs them (README.md:43-44).  Falls back to the C
+    restatement where oracle/_ref is absent."""
+    wid, n, nt, dt, dobs, xs, budget_s = args
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[wid % len(os.sched_getaffinity(0))]})
+    except Exception:
+        pass
     from oracle import oracle as O
-    O.build(ref=False)
     t = np.linspace(5, 44, NPER)
     if O.ref_available():
         kind, swd_lib, rf_lib = "reference", O.ref_libsurf(), O.RefRFCore()
     else:
         kind, swd_lib, rf_lib = "port", O.libsurf, O.librf
-    joint = O.Joint_RF_SWD(1.0, 1.0, O.ReceiverFunc(RAY_P, NT, DT, GAUSS, TSHIFT, WATER, "P", "freq", lib=rf_lib),
+    joint = O.Joint_RF_SWD(1.0, 1.0, O.ReceiverFunc(RAY_P, nt, dt, GAUSS, TSHIFT, WATER, "P", "freq", lib=rf_lib),
                            O.SurfWD(tRc=t, lib=swd_lib))
-    joint.set_obsdata(dobs[:NT], dobs[NT:])
-    n = 0
+    joint.set_obsdata(dobs[:nt], dobs[nt:])
+    joint.misfit_and_grad(xs[0])                     # first call: library loading, page faults
+    k = 0
     t0 = time.perf_counter()
-    while n < len(xs) and time.perf_counter() - t0 < budget_s:
-        joint.misfit_and_grad(xs[n])
-        n += 1
-    el = time.perf_counter() - t0
-    return {"value": n / el, "unit": "evals/s", "cores": 1, "kind": kind,
-            "sample": f"{n} joint misfit+grad evaluations of the bench's own 30-layer models on 1 host core in {el:.1f} s"
-                      + ("; reference = oracle/_ref (libsurf complete, RF core + numpy irfft tail)" if kind == "reference" else "")}
+    while time.perf_counter() - t0 < budget_s:
+        joint.misfit_and_grad(xs[(wid + k) % len(xs)])
+        k += 1
+    return kind, k, time.perf_counter() - t0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=8192, help="chains per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def _host_cpus():
+    """(logical CPUs this process may use, physical cores among them, model name)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model, cores = "unknown", set()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except Exception:
+        pass
+    try:
+        out = subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if line and not line.startswith("#"):
+                cpu, core, sock = (int(v) if v else 0 for v in line.split(",")[:3])
+                if cpu in allowed:
+                    cores.add((sock, core))
+    except Exception:
+        pass
+    return allowed, (len(cores) if cores else len(allowed)), model
 
+
+def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
+    """Reference CPU path on ALL host cores: one independent process per physical core (the reference's only
+    parallelism: one chain per MPI rank), same models as the GPU run; runs in the launching process, which never
+    initialised the GPU, after the GPU ranks have finished."""
+    import multiprocessing as mp
+    from oracle import oracle as O
+    O.build(ref=False)
+    allowed, ncores, model = _host_cpus()
+    ctx = mp.get_context("fork")
+    sample = xs[:max(64, ncores)]
+    with ctx.Pool(ncores) as pool:
+        res = pool.map(_cpu_worker, [(w, cfg["n"], cfg["nt"], cfg["dt"], dobs, sample, budget_s) for w in range(ncores)])
+    kind = res[0][0]
+    rates = [k / el for _, k, el in res]
+    total = float(sum(rates))
+    return {"value": total, "unit": "evals/s", "cores": ncores, "logical_cpus": len(allowed), "cpu_model": model,
+            "evals_per_s_per_core": total / ncores,
+            "kind": kind,
+            "kind_detail": ("reference (RF tail numpy): oracle/_ref = the reference's own sources compiled here -- libsurf "
+                            "complete, RF propagator/partials core of RFModule.f90; the 15-line RF tail (water level, "
+                            "Gaussian, irfft, e^{sigma t}) is numpy because FFTW3 is absent" if kind == "reference"
+                            else "port: the C restatement oracle/liboracle.so"),
+            "sample": f"{sum(k for _, k, _ in res)} joint misfit+grad evaluations of the bench's own {cfg['n']}-layer "
+                      f"models (nt = {cfg['nt']}, {NPER} Rc periods), {ncores} independent processes (one per physical "
+                      f"core) for {budget_s:.0f} s each"}
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def launch(args, argv):
+    """Parent process: spawn N rank processes, pass rank 0's JSON line through (adding the CPU baseline at N = 1)."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RFS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(rcs) or line is None:
+        print(out0 or "", file=sys.stderr)
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    res = json.loads(line)
+    assert res["n_gpus"] == n, (res["n_gpus"], n)
+    if n == 1 and not args.no_cpu_baseline and not args.dry_run:
+        cfg = CONFIGS[args.config]
+        side = res.pop("_cpu_inputs")
+        res["cpu_baseline"] = cpu_baseline(cfg, np.array(side["xs"]), np.array(side["dobs"]))
+        res["gpu_over_cpu_node"] = res["value"] / res["cpu_baseline"]["value"]
+    res.pop("_cpu_inputs", None)
+    print(json.dumps(res))
+
+
+# ------------------------------------------------------------------------------------------ one rank
+def dry_rank(args, rank, world):
+    """No GPU: the launcher / process-group / gather plumbing only (CPU test of `--gpus N`, gloo)."""
     import torch
+    import torch.distributed as dist
+    from rfsurfhmc_amd.chains import gather_misfits, shard_range
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == args.gpus
+        dist.barrier()
+    nchain = args.chains
+    first, last = shard_range(nchain * world, rank, world)
+    misfit = torch.arange(first, last, dtype=torch.float64)
+    el = torch.tensor([0.001 * (rank + 1) * args.steps], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        gathered = gather_misfits(misfit)
+    else:
+        gathered = misfit
+    if rank == 0:
+        assert gathered.shape[0] == nchain * world and bool((gathered == torch.arange(nchain * world)).all())
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": float(el) / args.steps * 1e3, "dry_run": True,
+                          "gathered_chains": int(gathered.shape[0])}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_run:
+        return dry_rank(args, rank, world)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP extension has no CPU fallback")
     torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")      # RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
 
     from rfsurfhmc_amd._lib import K_NAMES
     from rfsurfhmc_amd.model.model_rf import ReceiverFunc
     from rfsurfhmc_amd.model.model_surf import SurfWD
     from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
 
+    cfg = CONFIGS[args.config]
+    n, nt = cfg["n"], cfg["nt"]
     nchain = args.chains
     t = np.linspace(5, 44, NPER)
-    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(RAY_P, NT, DT, GAUSS, TSHIFT, WATER, "P", "freq", device=local_rank),
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(RAY_P, nt, cfg["dt"], GAUSS, TSHIFT, WATER, "P", "freq", device=local_rank),
                          SurfWD(tRc=t, device=local_rank))
-    drf, dswd, flag = joint.forward(true_model())
+    x_true = true_model(n)
+    drf, dswd, flag = joint.forward(x_true)
     assert flag
     joint.set_obsdata(drf, dswd)
-    xs = make_models(nchain, seed=991206 + rank)          # chain c of rank r ~ reference rank r*nchain + c
-    x = torch.from_numpy(xs).to(dev)
-    ctx = joint._ensure(N_LAYER)
-
-    # Warm-up (untimed steps).  From the second one on every kernel group is bracketed by HIP events: that gives the
-    # per-group table of the bench line and names the dominant group; inside the timed region only THAT group keeps
-    # its event pairs (each pair costs a few microseconds of the step: 0.1 ms with all seven groups).
+    bounds = bounds_of(x_true)
+    ctx = joint._ensure(n)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     nwarm = max(args.warmup, 2)
-    out = joint.misfit_and_grad_device(x)
-    ctx.check(ctx.L.rfs_synchronize(ctx.h))
-    ctx.check(ctx.L.rfs_enable_timing(ctx.h, 1))
-    for _ in range(nwarm - 1):
-        out = joint.misfit_and_grad_device(x)
-    torch.cuda.synchronize()
-    ms_w = np.zeros(len(K_NAMES)); cnt_w = np.zeros(len(K_NAMES), dtype=np.int32)
-    ctx.check(ctx.L.rfs_kernel_ms_sum(ctx.h, ms_w.ctypes.data_as(ctypes.c_void_p), cnt_w.ctypes.data_as(ctypes.c_void_p)))
-    warm_ms = {k: (ms_w[i] / cnt_w[i] if cnt_w[i] else 0.0) for i, k in enumerate(K_NAMES)}
-    dom_id = int(np.argmax([warm_ms[k] for k in K_NAMES]))
-    ctx.check(ctx.L.rfs_enable_timing(ctx.h, 2 * (1 << dom_id)))     # the dominant group only, measured live below
+    K = args.steps
+
+    def timing_all():
+        ctx.check(ctx.L.rfs_synchronize(ctx.h))
+        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 1))
+
+    def read_ms():
+        ms = np.zeros(len(K_NAMES)); cnt = np.zeros(len(K_NAMES), dtype=np.int32)
+        ctx.check(ctx.L.rfs_kernel_ms_sum(ctx.h, ms.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+        return ms, cnt
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    if cfg["sampler"] is None:
+        # ---- configs[1] / configs[4]: leapfrog steps of every chain on the flow entry (never-ending trajectories)
+        xs = make_models(nchain, seed=991206 + rank, n=n)      # chain c of rank r ~ reference rank r*nchain + c
+        rng = np.random.default_rng(7 + rank)
+        st = joint.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
+        st["p"].copy_(tt(0.5 * rng.standard_normal(xs.shape)))        # p ~ 0.5 N(0, I), hmc.py:146
+        st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
+        joint.flow_step(st)                                            # start evaluation + half kick (untimed)
+        timing_all()
+        for _ in range(nwarm - 1):
+            joint.flow_step(st)
+        torch.cuda.synchronize()
+        ms_w, cnt_w = read_ms()
+        warm_ms = {k: (ms_w[i] / cnt_w[i] if cnt_w[i] else 0.0) for i, k in enumerate(K_NAMES)}
+        dom_id = int(np.argmax([warm_ms[k] for k in K_NAMES]))
+        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 2 * (1 << dom_id)))  # the dominant group only, measured live below
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            joint.flow_step(st)
+        ctx.check(ctx.L.rfs_synchronize(ctx.h))
+        barrier()
+        el = time.perf_counter() - t0
+        ms, cnt = read_ms()
+        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 0))
+        nfail = int((st["ok"] == 0).sum().item())
+        evals_rank = nchain * K
+        misfit = st["Unew"]
+        # the bare evaluation on a fixed x (what round 1 reported as a step), for continuity
+        xfix = tt(xs)
+        joint.misfit_and_grad_device(xfix); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            joint.misfit_and_grad_device(xfix)
+        ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+        extra["eval_only_ms_per_step"] = (time.perf_counter() - t1) / 5 * 1e3
+    else:
+        # ---- configs[3]: a real HMCDualAveraging run on the continuous-flow schedule, K device steps timed
+        from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+        rs = np.random.default_rng(3 + rank)
+        xs = np.clip(x_true[None, :] * (1 + 0.02 * rs.standard_normal((nchain, 2 * n))), bounds[:, 0], bounds[:, 1])
+        xs[:, :n] = np.sort(xs[:, :n], axis=1)
+        # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
+        smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
+                               nchains=nchain, verbose=False, store_syn=False)
+        marks = {}
+        active = torch.zeros((), dtype=torch.int64, device=dev)
+
+        def hook(s, st):
+            if s == 1:
+                timing_all()
+            if s == nwarm:
+                ms_w, cnt_w = read_ms()
+                marks["warm"] = (ms_w, cnt_w)
+                dom = int(np.argmax(ms_w / np.maximum(cnt_w, 1)))
+                marks["dom"] = dom
+                ctx.check(ctx.L.rfs_enable_timing(ctx.h, 2 * (1 << dom)))
+                barrier()
+                marks["t0"] = time.perf_counter()
+            if nwarm <= s < nwarm + K:          # chains inside a trajectory in this step = leapfrog steps done
+                active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum())
+            if s == nwarm + K:
+                ctx.check(ctx.L.rfs_synchronize(ctx.h))
+                barrier()
+                marks["t1"] = time.perf_counter()
+
+        smp.sample_flow(x_init=xs, max_steps=nwarm + K + 1, step_hook=hook)
+        el = marks["t1"] - marks["t0"]
+        ms, cnt = read_ms()
+        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 0))
+        ms_w, cnt_w = marks["warm"]
+        warm_ms = {k: (ms_w[i] / cnt_w[i] if cnt_w[i] else 0.0) for i, k in enumerate(K_NAMES)}
+        dom_id = marks["dom"]
+        evals_rank = int(active.item())
+        nfail = 0
+        misfit = torch.zeros(nchain, dtype=torch.float64, device=dev)
+        extra["chains_in_a_trajectory_per_step"] = evals_rank / K
+
+    total_evals = evals_rank
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = joint.misfit_and_grad_device(x)
-    ctx.check(ctx.L.rfs_synchronize(ctx.h))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    ms = np.zeros(len(K_NAMES)); cnt = np.zeros(len(K_NAMES), dtype=np.int32)
-    ctx.check(ctx.L.rfs_kernel_ms_sum(ctx.h, ms.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
-    ctx.check(ctx.L.rfs_enable_timing(ctx.h, 0))
-    misfit, grad, dsyn, fl = out
-    nfail = int((fl == 0).sum().item())
-    if dist is not None:
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
+        red = torch.tensor([el, float(evals_rank)], dtype=torch.float64, device=dev)
+        tmax = red[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = red[1:].clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        el, total_evals = float(tmax.item()), float(tsum.item())
         # the path's only collective: gather the per-chain misfits on rank 0 (after the timed region)
         from rfsurfhmc_amd.chains import gather_misfits
         gathered = gather_misfits(misfit)
@@ -164,48 +398,82 @@ def main():
             dist.destroy_process_group()
         return
 
-    evals = nchain * world * args.steps
-    value = evals / el
+    value = total_evals / el
     dom = K_NAMES[dom_id]
-    dom_ms = ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0       # HIP events over the timed region
-    per_launch_ms = dict(warm_ms)                                   # the other groups: from the warm-up steps
+    dom_ms = ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0        # HIP events over the timed region
+    per_launch_ms = dict(warm_ms)                                    # the other groups: from the warm-up steps
     per_launch_ms[dom] = dom_ms
-    achieved = ALG_BYTES_PER_EVAL * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # HBM bytes per launch of that kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only
-    # valid for the configuration it was collected on
+    ab = alg_bytes_per_eval(n, nt)
+    achieved = ab * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM bytes per launch of that kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the
+    # configuration it was collected on
     traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj.get("chains") == nchain and dom in tj:
-            traffic = tj[dom]
-    except Exception:
-        traffic = None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if tj.get("chains") == nchain and tj.get("config", 1) == args.config and dom in tj:
+                traffic = tj[dom]
+                break
+        except Exception:
+            continue
+    fl = alg_flops_per_eval(n, nt)
+    flops_eval = sum(fl.values())
+    # per-kernel FP64 figures: hand-counted flops of the group / its measured time / the vector peak of the whole chip
+    per_kernel_fp64 = {}
+    for k, f in fl.items():
+        if per_launch_ms.get(k, 0) > 0:
+            tf = f * nchain / (per_launch_ms[k] * 1e-3) / 1e12
+            per_kernel_fp64[k] = {"tflops": tf, "frac_of_chip_peak": tf / FP64_VECTOR_PEAK_TFLOPS}
     res = {
-        "metric": "leapfrog steps/sec (= forward+grad evals/sec) per GPU and whole node, 30-layer model",
-        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": METRIC,
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[1]: 8192 chains x 30-layer Vs+thk, joint RF(512 samples)+SWD(40 Rc periods) per GPU",
-                   "chains_per_gpu": nchain, "nlayer": N_LAYER, "nt": NT, "nper": NPER,
+        "config": {"workload": cfg["name"], "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
+                   "step": ("one leapfrog step of every chain via rfs_flow_step (drift + mirror, misfit+gradient, kick)"
+                            if cfg["sampler"] is None else
+                            "one device step of HMCDualAveraging.sample_flow (host accept/reject + dual averaging "
+                            "overlapped); value counts only chains inside a trajectory"),
                    "parallelism": f"independent chains x{world}", "root_search_failures": nfail},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_EVAL * nchain,
-                     "avg_launch_ms": dom_ms,
+                     "algorithmic_bytes_per_launch": ab * nchain, "avg_launch_ms": dom_ms,
                      "note": "path is FP64-VALU/transcendental bound (SURVEY 8(d)); see fp64_vector"},
-        "fp64_vector": {"achieved_tflops": ALG_FLOPS_PER_EVAL * value / world / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                        "frac": ALG_FLOPS_PER_EVAL * value / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                        "alg_flops_per_eval": ALG_FLOPS_PER_EVAL},
+        "fp64_vector": {"achieved_tflops": flops_eval * value / world / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                        "frac": flops_eval * value / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                        "alg_flops_per_eval": flops_eval,
+                        "note": "whole-step figure from SURVEY 8(d)'s hand count of the minimal algorithm, not a counter",
+                        "per_kernel": per_kernel_fp64},
         "kernel_ms_per_launch": per_launch_ms,
         "kernel_ms_note": f"'{dom}' from HIP events over the timed region; the other groups from HIP events over the "
                           f"{nwarm - 1} warm-up step(s) before it (all groups bracketed there)",
     }
-    if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(xs, joint.dobs)
+    res.update(extra)
+    if world == 1 and not args.no_cpu_baseline and os.environ.get("RFS_BENCH_CHILD"):
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        res["_cpu_inputs"] = {"xs": xs[:max(64, ncpu)].tolist(), "dobs": joint.dobs.tolist()}
     print(json.dumps(res))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--chains", type=int, default=8192, help="chains per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU; gloo)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:                   # a rank: ours (RFS_BENCH_CHILD) or torch.distributed.run's
+        return run_rank(args)
+    launch(args, sys.argv[1:])                       # the launching process never initialises the GPU
 
 
 if __name__ == "__main__":

@@ -142,7 +142,9 @@ int rfs_joint_forward(rfs_ctx* ctx, int nchain, const double* x, int quirk_trc_e
  * drawn), per-chain dt and L, and bounds[2n][2], run the reference's leapfrog with mirror
  * reflection (hmc.py:121-137, 164-183; hmcda.py:246-271).  Outputs (DEVICE): xnew, Ucur, Unew,
  * Hcur, Hnew, dsyn_cur, dsyn_new [nchain][ndata], ok[nchain] (0 where the reference would return
- * early: flag False or NaN in x / grad / dsyn). */
+ * early: flag False or NaN in x / grad / dsyn).  Every output is written for every chain: a chain with ok = 0
+ * gets xnew = x0 and Hnew = +inf (the reference's (xcur, inf, dobs, False)).  1 <= L[chain] <= Lmax is required;
+ * a chain that violates it is reported with ok = 0. */
 int rfs_leapfrog_dev(rfs_ctx* ctx, int nchain, const double* x0, const double* p0, const double* dt,
                      const int32_t* L, int32_t Lmax /* max over chains of L, known to the host that drew L */,
                      const double* bounds, double* xnew, double* Ucur,

@@ -325,6 +325,33 @@ def gen_swd_wide(ref_surf, m_surf, M):
     print("swd_love_sphere_reference.npz:", len(g), "arrays")
 
 
+def gen_rf_full(M):
+    """Only where oracle/_ref holds the reference's COMPLETE librf (FFTW3 present, oracle/Makefile): the same cases
+    as gen_rf through the reference's own public entry points, frequency AND time method -- no numpy tail, so these
+    fixtures pin RFModule.f90:392-425 and deconit.f90:135-197 by reference runs.  Not reachable in this image."""
+    full = orc.ref_librf_full()
+    if full is None:
+        print("rf_trace_reference.npz: skipped (the reference's librf is unbuildable here: FFTW3 absent)")
+        return
+    g = {}
+    for name, (mname, nt, dt) in RF_CASES.items():
+        thk, vs, _ = M[mname]
+        vp, rho = emp(vs)
+        qa = np.full(len(vs), 9999.0)
+        for method in ("freq", "time"):
+            if method == "time" and nt > 512:
+                continue
+            rf, kl = full.kernel_all(thk, rho, vp, vs, qa, qa, RAY_P, nt, dt, GAUSS, TSHIFT, method, WATER, "P")
+            rf_fwd = full.forward(thk, rho, vp, vs, qa, qa, RAY_P, nt, dt, GAUSS, TSHIFT, method, WATER, "P")
+            tsel = np.arange(0, nt, max(1, nt // 64))
+            for k, v in (("thk", thk), ("vs", vs), ("nt", np.array(nt)), ("dt", np.array(dt)), ("rf", rf),
+                         ("rf_forward", rf_fwd), ("kl_t_index", tsel), ("kl_sub", kl[:, :, tsel])):
+                g[f"{name}/{method}/{k}"] = v
+    g["ray_p"], g["gauss"], g["time_shift"], g["water"] = (np.array(v) for v in (RAY_P, GAUSS, TSHIFT, WATER))
+    np.savez_compressed(os.path.join(OUT, "rf_trace_reference.npz"), **g)
+    print("rf_trace_reference.npz:", len(g), "arrays (complete reference librf)")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
@@ -332,6 +359,7 @@ def main():
     gen_swd(ref_surf, M)
     gen_swd_wide(ref_surf, m_surf, M)
     gen_rf(ref_rf, M)
+    gen_rf_full(M)
     gen_plugin(m_surf, m_rf, m_joint, M)
     gen_sampler(m_surf, m_rf, m_joint, M)
 

@@ -460,6 +460,22 @@ def ref_available() -> bool:
         and os.path.exists(os.path.join(d, "librf_core_ref.so"))
 
 
+def ref_librf_full():
+    """The reference's COMPLETE pybind11 module ``librf`` (oracle/Makefile builds it only where FFTW3 exists;
+    not in this image) or None.  With it the RF tail -- water level, Gaussian, irfft, e^{sigma t} scaling
+    (RFModule.f90:392-425) -- and ``deconit`` are pinned by reference runs instead of restated."""
+    d = os.path.join(_HERE, "_ref")
+    if not os.path.isdir(d):
+        return None
+    names = [f for f in os.listdir(d) if f.startswith("librf.") and f.endswith(".so")]
+    if not names:
+        return None
+    spec = importlib.util.spec_from_file_location("librf", os.path.join(d, names[0]))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def ref_libsurf():
     """The reference's own pybind11 module ``libsurf`` (complete build of src/SWD)."""
     d = os.path.join(_HERE, "_ref")

@@ -1,4 +1,5 @@
 """Build librfsurf_hip.so for gfx950 with hipcc (in-tree, so the .so travels with gpurun)."""
+import glob
 import os
 import subprocess
 
@@ -6,14 +7,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librfsurf_hip.so")
 SOURCES = ["rfsurf_hip.hip"]
-HEADERS = ["cplx.hpp", "rf_math.hpp", "swd_math.hpp", "rfsurf_kernels.hpp", "../../include/rfsurf.h"]
+
+
+def _inputs():
+    """Everything the library is compiled from: the translation unit, every header beside it, the public header."""
+    return ([os.path.join(CSRC, f) for f in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp")))
+            + [os.path.join(HERE, "..", "include", "rfsurf.h")])
 
 
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in _inputs())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

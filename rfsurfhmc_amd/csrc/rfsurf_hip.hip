@@ -1094,9 +1094,10 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
     int* fl = c->lflag.as<int>();
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
     TRY(joint_eval(c, nchain, x0, U, g, d, fl));
-    hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, x0, p0, dt, U, g, d, fl, x, p,
-                       Ucur, Hcur, Unew, dsyn_cur, dsyn_new, ok);
-    // failed chains keep xnew = x0, Hnew = +inf (reference returns (xcur, inf, dobs, False))
+    hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, x0, p0, dt, L, Lmax, U, g, d, fl,
+                       x, p, Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok);
+    // failed chains (ok = 0: failed evaluation, or L outside [1, Lmax]) keep xnew = x0, Hnew = +inf written by
+    // k_leap_begin (reference returns (xcur, inf, dobs, False))
     HIPCHK(c, hipMemcpyAsync(xnew, x0, (size_t)nchain * nx * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     for (int step = 0; step < Lmax; step++) {
         // chains sorted by decreasing L: only the first nactive[step] are still inside their trajectory

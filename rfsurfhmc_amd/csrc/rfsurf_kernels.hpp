@@ -1067,8 +1067,8 @@ __global__ void k_swd_forward_out(int nchain, int nt, SwdRows R, const double* _
 // minv (may be null = identity): diagonal inverse mass, x' = M^-1 p and K = p.M^-1 p / 2 (the reference carries an
 // identity `invert_Mass` that only enters its kinetic energy, pyhmc/hmc.py:48,102-108).
 __global__ void k_leap_begin(int nchain, int nx, int ndata, const double* minv, const double* x0, const double* p0, const double* dt,
-                             const double* U, const double* grad, const double* dsyn, const int* flag,
-                             double* x, double* p, double* Ucur, double* Hcur, double* Unew,
+                             const int* L, int Lmax, const double* U, const double* grad, const double* dsyn, const int* flag,
+                             double* x, double* p, double* Ucur, double* Hcur, double* Unew, double* Hnew,
                              double* dsyn_cur, double* dsyn_new, int* ok)
 {
     __shared__ double red[4];
@@ -1096,9 +1096,12 @@ __global__ void k_leap_begin(int nchain, int nx, int ndata, const double* minv, 
     if (tid == 0) {
         double s = 0.0;
         for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
-        int good = flag[chain] && !bad;                                   // hmc.py:155-156
+        // hmc.py:155-156; a trajectory length outside [1, Lmax] would never reach its last step: such a chain is
+        // reported failed instead of returning stale results
+        int good = flag[chain] && !bad && L[chain] >= 1 && L[chain] <= Lmax;
         Ucur[chain] = U[chain]; Unew[chain] = U[chain];
         Hcur[chain] = 0.5 * s + U[chain];                                 // hmc.py:153,157
+        Hnew[chain] = __longlong_as_double(0x7ff0000000000000LL);         // +inf until the trajectory completes
         ok[chain] = good;
     }
 }

@@ -114,6 +114,8 @@ class FusedPlugin:
                    Hnew=torch.full((nchain,), float("inf"), **f64), dsyn_cur=torch.empty(nchain, nd, **f64),
                    dsyn_new=torch.empty(nchain, nd, **f64), ok=torch.empty(nchain, dtype=torch.int32, device=dev))
         Lh = L.cpu().numpy()
+        if Lh.min() < 1:
+            raise ValueError("leapfrog_device: every chain needs L >= 1")
         Lmax = int(Lh.max())
         order = None
         nactive = None
@@ -123,7 +125,9 @@ class FusedPlugin:
             oh = np.argsort(-Lh, kind="stable")
             order = torch.from_numpy(oh).to(dev)
             x0, p0, dt, L = (t.index_select(0, order).contiguous() for t in (x0, p0, dt, L))
-            nactive = np.ascontiguousarray((Lh[None, :] > np.arange(Lmax)[:, None]).sum(axis=1).astype(np.int32))
+            # nactive[s] = #{chains with L > s}: a histogram of L and a suffix sum (not an [Lmax, nchain] matrix)
+            hist = np.bincount(Lh, minlength=Lmax + 1)
+            nactive = np.ascontiguousarray((nchain - np.cumsum(hist)[:Lmax]).astype(np.int32))
         ctx.check(ctx.L.rfs_leapfrog_dev2(ctx.h, nchain, x0.data_ptr(), p0.data_ptr(), dt.data_ptr(), L.data_ptr(),
                                           Lmax, hptr(nactive) if nactive is not None else None, bounds.data_ptr(),
                                           out["xnew"].data_ptr(), out["Ucur"].data_ptr(),

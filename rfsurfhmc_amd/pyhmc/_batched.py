@@ -154,7 +154,7 @@ def load_checkpoint(path, rng: ChainRNG):
     return {k: z[k] for k in z.files if not k.startswith("rng_")}
 
 
-def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True):
+def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max_steps=None, step_hook=None):
     """Drive model.flow_step (rfs_flow_step) until ``active()`` is False.
 
     After every step the chains that finished a trajectory are handed to ``process_done(idx, res)`` (host side:
@@ -163,7 +163,10 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True):
     pipeline=True: step s+1 is launched BEFORE the results of step s are processed, so the host work (one Python
     loop over the finished chains with per-chain RNG streams) overlaps the GPU step; the chains that finished at
     step s sit out step s+1 and restart with step s+2.  Each chain still sees exactly the same sequence of
-    trajectories and draws, so the samples do not depend on ``pipeline``.  Returns the number of device steps."""
+    trajectories and draws, so the samples do not depend on ``pipeline``.  Returns the number of device steps.
+    max_steps: stop after that many device steps (the run is then unfinished: benchmarks, smoke runs);
+    step_hook(s, st): called right before device step s is launched (s = 0, 1, ...; bench.py takes its time stamps
+    and counts the chains inside a trajectory there)."""
     import torch
     dev = st["x"].device
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -189,18 +192,26 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True):
             st["ok"].index_fill_(0, rs, 1)
 
     steps = 0
-    model.flow_step(st); steps += 1
+
+    def step():
+        nonlocal steps
+        if step_hook is not None:
+            step_hook(steps, st)
+        model.flow_step(st); steps += 1
+
+    capped = lambda: max_steps is not None and steps >= max_steps
+    step()
     while True:
         idx, res = fetch()                       # synchronises with the step just launched
-        more = active() or len(idx) > 0
+        more = (active() or len(idx) > 0) and not capped()
         if pipeline and more:
-            model.flow_step(st); steps += 1      # the finished chains idle in this step (rem = -1, fresh = 0)
+            step()                               # the finished chains idle in this step (rem = -1, fresh = 0)
         if len(idx):
             xkeep, restart = process_done(idx, res)
             apply(idx, xkeep, restart)           # stream-ordered after the step launched above
-        if not active():
+        if not active() or capped():
             break
         if not pipeline:
-            model.flow_step(st); steps += 1
+            step()
     return steps
 

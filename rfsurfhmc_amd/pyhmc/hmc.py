@@ -43,6 +43,10 @@ class HamitonianMC:
         # mass_adapt: trajectory counts (inside the burn-in) at which M^-1 is re-estimated from the cross-chain
         # variance of the current models (ensemble_inverse_mass); batch schedule only
         self.mass_adapt = None if mass_adapt is None else frozenset(int(k) for k in mass_adapt)
+        # every rank must reach every adaptation point (they are collective): no chain can finish before ndraws
+        # trajectories, so points below ndraws are safe on every rank whatever its acceptance rate
+        if self.mass_adapt and max(self.mass_adapt) >= ndraws:
+            raise ValueError(f"mass_adapt points must lie inside the burn-in (< ndraws = {ndraws}): {sorted(self.mass_adapt)}")
         self.rng = ChainRNG(seed, self.first_chain, self.nchains)
         self.ii = 0
         self.trace = None          # optional list collecting per-iteration records (tests)
@@ -52,7 +56,8 @@ class HamitonianMC:
         """pyhmc/hmc.py:63-72 (+ optional keys ``nchains``, ``mass_adapt``)."""
         return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["Lrange"], kargs["nbest"], kargs["seed"],
                    kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
-                   nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"))
+                   nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"),
+                   checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0))
 
     def _set_inverse_mass(self, minv):
         self.inverse_mass = np.asarray(minv, dtype=np.float64)
@@ -94,7 +99,7 @@ class HamitonianMC:
                                    Hnew=Hnew, u=u, ok=ok, accept=accept, xres=xres.copy(), Ures=Ures.copy()))
         return xres, Ures, dres, accept
 
-    def sample_flow(self, x_init=None, pipeline=True):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):
         """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
         chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
         chain at its own point of its own trajectory (rfs_flow_step), and a chain that finishes a trajectory is
@@ -105,6 +110,9 @@ class HamitonianMC:
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
         if self.mass_adapt:
             raise ValueError("mass_adapt needs the common trajectory boundaries of sample(); pass inverse_mass instead")
+        if self.checkpoint:
+            raise ValueError("checkpoint / resume is implemented for sample() only: the flow schedule has no common "
+                             "trajectory boundary to checkpoint at")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
@@ -161,8 +169,11 @@ class HamitonianMC:
             return x[idx], rs
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
-                                   fetch_syn=syndata is not None, pipeline=pipeline)
-        self.finished = True
+                                   fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
+                                   step_hook=step_hook)
+        self.finished = not bool(np.any(i < total))
+        if not self.finished:                    # stopped by max_steps: nothing is written
+            return misfit[0] if nc == 1 else misfit
         return self._finish(misfit, x_cache, syndata, i, ncount)
 
     def sample(self, x_init=None, resume=False, max_trajectories=None):

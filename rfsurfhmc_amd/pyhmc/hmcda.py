@@ -27,10 +27,17 @@ def _mirror(x, p, boundaries):
 class HMCDualAveraging:
     def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
-                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None):
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None,
+                 L_cap=None):
         self.model = UserDefinedModel
         self.boundaries = np.asarray(boundaries, dtype=np.float64)
         self.dt, self.L = dt, L0
+        # Longest trajectory a chain may ask for.  The reference's L = max(1, int(lambda / dt)) (hmcda.py:307) is
+        # unbounded: a chain whose dt collapses during burn-in only slows its own MPI rank there, but in a batch it
+        # would stall every chain of the rank (and overflow int32).  Such a chain is clamped to L_cap steps (and
+        # reported once); chains that stay below the cap are untouched.  Default: 100 L0.
+        self.L_cap = int(L_cap) if L_cap is not None else max(1, 100 * int(L0))
+        self._cap_warned = False
         self.nbest_model, self.nsamples, self.ndraws = nbest_model, nsamples, ndraws
         if ndraws < 0.1 * nsamples:                                           # hmcda.py:57-60
             raise ValueError(f"in dual averaging, ndraws should > nsamples * 0.1 (ndraws = {ndraws}, nsamples = {nsamples})")
@@ -47,6 +54,10 @@ class HMCDualAveraging:
         # mass_adapt: trajectory counts (inside the burn-in) at which M^-1 is re-estimated from the cross-chain
         # variance of the current models (ensemble_inverse_mass); batch schedule only
         self.mass_adapt = None if mass_adapt is None else frozenset(int(k) for k in mass_adapt)
+        # every rank must reach every adaptation point (they are collective): no chain can finish before ndraws
+        # trajectories, so points below ndraws are safe on every rank whatever its acceptance rate
+        if self.mass_adapt and max(self.mass_adapt) >= ndraws:
+            raise ValueError(f"mass_adapt points must lie inside the burn-in (< ndraws = {ndraws}): {sorted(self.mass_adapt)}")
         self.delta = target_ratio                                             # hmcda.py:70-76
         self._h0, self._gamma, self._t0, self._kappa = 0.0, 0.05, 10.0, 0.75
         self._lambda = L0 * self.dt
@@ -59,7 +70,20 @@ class HMCDualAveraging:
         """pyhmc/hmcda.py:84-97 (+ optional keys ``nchains``, ``mass_adapt``)."""
         return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["L0"], kargs["nbest"], kargs["target_ratio"],
                    kargs["seed"], kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
-                   nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"))
+                   nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"),
+                   checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0),
+                   L_cap=kargs.get("L_cap"))
+
+    def _traj_len(self, dt):
+        """L = max(1, int(lambda / dt)) per chain (hmcda.py:307), clamped to L_cap before the integer cast."""
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            lf = np.floor(self._lambda / np.asarray(dt, dtype=np.float64))
+        lf = np.where(np.isfinite(lf), lf, float(self.L_cap))
+        if not self._cap_warned and np.any(lf > self.L_cap):
+            self._cap_warned = True
+            print(f"HMCDualAveraging: {int(np.sum(lf > self.L_cap))} chain(s) ask for more than L_cap = {self.L_cap} "
+                  "leapfrog steps (collapsed dt); clamped", file=sys.stderr)
+        return np.clip(lf, 1.0, float(self.L_cap)).astype(np.int32)
 
     def _set_inverse_mass(self, minv):
         self.inverse_mass = np.asarray(minv, dtype=np.float64)
@@ -169,7 +193,7 @@ class HMCDualAveraging:
             if self.mass_adapt and ntraj in self.mass_adapt:        # dual averaging then re-tunes dt (burn-in)
                 self._set_inverse_mass(ensemble_inverse_mass(x))
             live = i < total
-            L = np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)     # hmcda.py:307
+            L = self._traj_len(dt)                                                  # hmcda.py:307
             x1, U, dsyn, alpha = self._leapfrog(x, dt, L)
             u = self.rng.rand(idx_all)
             acc = live & (u < alpha)
@@ -229,7 +253,7 @@ class HMCDualAveraging:
                                        None if syndata is None else syndata[c])
         return misfit[0] if nc == 1 else misfit
 
-    def sample_flow(self, x_init=None, pipeline=True):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):
         """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
         every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
         (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
@@ -238,6 +262,9 @@ class HMCDualAveraging:
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
         if self.mass_adapt:
             raise ValueError("mass_adapt needs the common trajectory boundaries of sample(); pass inverse_mass instead")
+        if self.checkpoint:
+            raise ValueError("checkpoint / resume is implemented for sample() only: the flow schedule has no common "
+                             "trajectory boundary to checkpoint at")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
@@ -257,7 +284,7 @@ class HMCDualAveraging:
         st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
         allc = list(range(nc))
         st["p"].copy_(t(self.rng.randn(allc, nx) * self._pscale))
-        st["rem"].copy_(t(np.maximum(1, (self._lambda / dt).astype(int)).astype(np.int32)))
+        st["rem"].copy_(t(self._traj_len(dt)))
         st["fresh"].fill_(1)
         def process_done(idx, res):
             ok = res["ok"].astype(bool)
@@ -298,12 +325,15 @@ class HMCDualAveraging:
             rs = None
             if restart:
                 rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, dt=dt[restart],
-                          rem=np.maximum(1, (self._lambda / dt[restart]).astype(int)))
+                          rem=self._traj_len(dt[restart]))
             return x[idx], rs
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
-                                   fetch_syn=syndata is not None, pipeline=pipeline)
-        self.finished = True
+                                   fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
+                                   step_hook=step_hook)
+        self.finished = not bool(np.any(i < total))
+        if not self.finished:                    # stopped by max_steps: nothing is written
+            return misfit[0] if nc == 1 else misfit
         return self._finish(misfit, x_cache, syndata, i, ncount, dt)
 
     def _save_checkpoint(self, x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0, ntraj):

@@ -1,0 +1,73 @@
+"""-m gpu: SURVEY section 8(f)3 on the device.  A real batched sampler run (64 chains, joint RF + SWD plugin,
+device-resident trajectories through the C ABI) is checkpointed mid-way, continued by fresh objects -- new model
+plugin, new rfs_ctx, new sampler, as a restarted job would have -- and must be bit-identical to the run that was
+never interrupted: samples, misfits, mean models, the batched result file, and the exported per-chain file with
+the reference's member names (pyhmc/hmc.py:203-226)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 8
+T = np.arange(5.0, 41.0, 5.0)
+THK = np.array([3.0, 3, 4, 5, 6, 8, 10, 0])
+VS = np.linspace(2.9, 4.5, N)
+
+
+def _fresh_joint():
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    j = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(0.045, 125, 0.4, 1.5, 5.0, 0.001, "P", "freq"), SurfWD(tRc=T))
+    drf, dswd, flag = j.forward(np.hstack((VS, THK)))
+    assert flag
+    j.set_obsdata(drf, dswd)
+    return j
+
+
+def _bounds():
+    import bench
+    return bench.bounds_of(np.hstack((VS, THK)))
+
+
+def _sampler(kind, outdir, **kw):
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    common = dict(myrank=0, name="dev", outdir=str(outdir), nchains=64, verbose=False, per_chain_files=False, **kw)
+    if kind == "hmc":
+        return HamitonianMC(_fresh_joint(), _bounds(), 0.02, [3, 8], 3, 991206, 6, 2, **common)
+    return HMCDualAveraging(_fresh_joint(), _bounds(), 0.02, 5, 3, 0.65, 991206, 6, 2, **common)
+
+
+@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
+def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, tmp_path):
+    from rfsurfhmc_amd.pyhmc._batched import export_chain
+    full = _sampler(kind, tmp_path / "a")
+    mis_full = full.sample()
+    assert full.finished and np.isfinite(mis_full).all()
+    ck = str(tmp_path / "state.npz")
+    part = _sampler(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2)
+    part.sample(max_trajectories=5)
+    assert not part.finished and os.path.exists(ck)
+    ctx_part = part.model._ctx
+    del part
+    rest = _sampler(kind, tmp_path / "b", checkpoint=ck)          # fresh plugin + rfs_ctx + sampler
+    assert rest.model._ctx is None or rest.model._ctx is not ctx_part
+    mis = rest.sample(resume=True)
+    assert rest.finished
+    assert np.array_equal(mis, mis_full)
+    assert np.array_equal(rest.x_cache, full.x_cache) and np.array_equal(rest.syndata, full.syndata)
+    assert np.array_equal(rest.xmean, full.xmean) and np.array_equal(rest.synmean, full.synmean)
+    a, b = np.load(full.result_file), np.load(rest.result_file)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    # one chain in the reference's per-rank layout
+    pa = export_chain(full.result_file, 17, outdir=str(tmp_path / "ea"))
+    pb = export_chain(rest.result_file, 17, outdir=str(tmp_path / "eb"))
+    za, zb = np.load(pa), np.load(pb)
+    assert {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"} <= set(za.files)
+    for k in za.files:
+        assert np.array_equal(za[k], zb[k]), k
