@@ -110,8 +110,11 @@ def _cpu_worker(args):
     plugins, one independent chain per process as the reference runs them (README.md:43-44).  Falls back to the C
     restatement where oracle/_ref is absent."""
     wid, n, nt, dt, dobs, xs, budget_s = args
-    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ[v] = "1"
+    try:                                   # numpy is already loaded (forked): pin its BLAS pool to this one core
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
     try:
         os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[wid % len(os.sched_getaffinity(0))]})
     except Exception:

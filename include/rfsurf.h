@@ -183,10 +183,19 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
 /* Tuning knobs (no effect on results beyond last-bit rounding):
  *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic, else a power
  *                          of two <= 64 (1 = the sequential lane-per-chain kernel).
+ *   "swd_coop_shape"       block shape of the cooperative root search, 10 * waves per block + layers per producer
+ *                          wave: 81 (512 threads, 64 chains; default), 42 (256 threads, 32 chains), 82, 44; 0 = default.
+ *   "swd_coop_blocks_per_cu"  how many such blocks may share a CU (default 2; 0 = whatever fits).
  *   "cu_split"             0 = RF kernels on the caller's stream, sharing CUs with the root search;
  *                          1 (default) / 2 = when the cooperative root search fits on half of the CUs, it and
  *                          the RF kernels run on disjoint halves of the CU mask (contiguous halves / even-odd
  *                          bits); the combine uses the whole chip.
+ *   "rf_scratch_budget_mb" the fused gradient keeps one row vector per (chain, layer, frequency) between its two RF
+ *                          sweeps (4.1 GB at 8192 chains x 30 layers x 512 samples); batches whose scratch would exceed
+ *                          this budget (default 4096 MB) go through the RF pipeline in chain tiles.  Results are
+ *                          bit-identical for every tile size.
+ *   "recalibrate"          forget the measured schedule (the partition / early-eigenfunction decisions are taken from
+ *                          HIP-event timings of the first evaluation of each shape and cached in the context).
  *   "early_eigen_periods"  in a partitioned step the RF half finishes before the root search; the eigenfunction
  *                          kernels of the first periods (whose roots are final by then) run there early and only
  *                          the rest waits for the search.  -1 (default) = automatic count, 0 = off, k > 0 = the

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(HERE, "librfsurf_hip.so")
+LIBPATH = os.environ.get("RFSURF_LIB") or os.path.join(HERE, "librfsurf_hip.so")     # RFSURF_LIB: A/B builds of the same ABI
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -29,8 +30,21 @@ struct FftPlan { rocfft_plan plan = nullptr; rocfft_execution_info info = nullpt
 
 }  // namespace
 
+// Schedule of a partitioned step, MEASURED once per shape (the first evaluation of a shape runs as a probe with HIP
+// events around the search, the RF pipeline and the eigenfunction pass; the second one reads them and decides).
+struct StepCalib {
+    int stage = -1;                      // -1 never seen (the first call allocates buffers and FFT plans: not timed),
+                                         // 0 ready to probe, 1 probe launched (events pending), 2 decided
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // search, RF, eigen: begin / end
+    float t_search = 0.f, t_rf = 0.f, t_eigen = 0.f;                             // ms
+    bool part = true;
+    int early_items = 0;
+};
+
 struct rfs_ctx {
     int device = 0, max_chains = 0, max_layers = 0;
+    std::map<std::tuple<int, int, int, int, int>, StepCalib> calib;   // key: chains, layers, nft, periods, sequences
+    size_t rf_scratch_budget = (size_t)4 << 30;   // bytes of pass-A row scratch (Rs) per chain tile of the fused gradient
     // user/main stream; SWD search stream; CU-partitioned pair (search on one half of the chip, RF on the other)
     hipStream_t stream = nullptr, stream2 = nullptr, stream2m = nullptr, stream3 = nullptr;
     bool own_stream = false;
@@ -51,6 +65,8 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    int coop_shape = 0;    // cooperative search: 10 * waves per block + layers per producer wave (0 = default 42)
+    int coop_per_cu = 2;   // ... and the number of such blocks allowed to share a CU (0 = whatever fits)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -218,23 +234,29 @@ int rf_block(const RfFreq& f) {
 int rf_chunks(const RfFreq& f) { int bs = rf_block(f); return (f.n2 - 1 + bs - 1) / bs; }
 int rf_nparts(const RfFreq& f) { return rf_chunks(f) * (rf_block(f) / 64) + 1; }
 
-// pass A (+ scratch) for nchain chains; lc must be ready
-int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch) {
+// pass A (+ scratch) for the nchain chains that start at chain c0 of the batch (RR, Rs are tile-local: offset 0); lc must
+// be ready
+int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, size_t c0 = 0) {
     ENSURE(c, c->RR, (size_t)nchain * 4 * f.n2p * sizeof(double));
     if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.n2p * sizeof(double));
     double* Rs = scratch ? c->Rs.as<double>() : nullptr;
+    const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
+#ifdef RFS_COOP_PROFILE
+    if (getenv("RFS_NO_RS")) Rs = nullptr;          // experiment: pass A without its scratch stores (results invalid)
+#endif
     dim3 grid(rf_chunks(f), nchain);
     hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f,
-                       c->lc.as<RfLayer>(), c->RR.as<double>(), Rs);
+                       lc, c->RR.as<double>(), Rs);
     hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
-                       c->lc.as<RfLayer>(), c->RR.as<double>(), Rs);
+                       lc, c->RR.as<double>(), Rs);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
 
 // spectrum -> rf(t): writes dsyn (stride ndata) and optionally misfit/weighted residual
+// (mrf: per-chain RF misfits of the whole batch, written at [c0, c0 + nchain); every other buffer is tile-local)
 int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dobs, int ndata, double* dsyn,
-               bool adjoint) {
+               bool adjoint, size_t c0 = 0, size_t nchain_total = 0) {
     // rocFFT plans are per batch size; varying chain counts (length-sorted trajectories) are rounded up to a
     // multiple of 256 so that a handful of cached plans serve them all (the padding transforms stale data)
     const size_t nb = nchain > 256 ? ((size_t)nchain + 255) / 256 * 256 : (size_t)nchain;
@@ -248,9 +270,9 @@ int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dob
     double* wres = nullptr; double* mrf = nullptr;
     if (adjoint) {
         ENSURE(c, c->wres, nb * f.nft * sizeof(double));
-        ENSURE(c, c->mrf, (size_t)nchain * sizeof(double));
+        ENSURE(c, c->mrf, std::max((size_t)nchain, nchain_total) * sizeof(double));
         ENSURE(c, c->W, nb * f.n2 * sizeof(cplx));
-        wres = c->wres.as<double>(); mrf = c->mrf.as<double>();
+        wres = c->wres.as<double>(); mrf = c->mrf.as<double>() + c0;
     }
     hipLaunchKernelGGL(k_rf_mid2, dim3(nchain), dim3(256), 0, c->stream, f, c->tser.as<double>(), dobs, ndata,
                        dsyn, mrf, wres);
@@ -259,15 +281,16 @@ int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dob
     return RFS_OK;
 }
 
-int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f) {
+int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0) {
     int npart = rf_nparts(f);
     ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
+    const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     dim3 grid(rf_chunks(f), nchain);
-    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, c->lc.as<RfLayer>(),
+    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, lc,
                        c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
                        c->PG.as<double>());
     hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
-                       c->lc.as<RfLayer>(), c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(),
+                       lc, c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(),
                        c->wmax2.as<double>(), npart, c->PG.as<double>());
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
@@ -418,6 +441,40 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
     return P;
 }
 
+// Shape of the cooperative root search (k_swd_roots_coop<NW, LPW, NCH>) for one launch
+struct CoopPlan { bool ok = false; int nw = 8, lpw = 1, nch = 0, blocks = 0, per_cu = 1; size_t lds = 0; };
+
+CoopPlan coop_plan(const rfs_ctx* c, const SwdSeqs& Q, int nchain, int n) {
+    CoopPlan P;
+    const int nitem = Q.nseq * nchain;
+    int npmax = 0;
+    for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
+    if (c->swd_lanes != 0 || nitem < 1024 || n < 3 || Q.nseq * npmax > 4096) return P;
+    int shape = c->coop_shape ? c->coop_shape : 81;
+    static const int shapes[4][3] = {{8, 1, 16}, {4, 2, 16}, {8, 2, 8}, {4, 4, 10}};     // NW, LPW, largest NCH
+    const int* sh = nullptr;
+    for (auto& t : shapes) if (t[0] * 10 + t[1] == shape) sh = t;
+    if (!sh) sh = shapes[0];
+    const int nprod = n - 1 - COOP_CL;
+    if (nprod > sh[2] * coop_chunk(sh[0], sh[1])) sh = shapes[0];          // too many layers for that shape
+    if (nprod > sh[2] * coop_chunk(sh[0], sh[1])) return P;
+    P.nw = sh[0]; P.lpw = sh[1];
+    const int cs = coop_chunk(P.nw, P.lpw), ipb = 64 / P.lpw;
+    P.nch = (nprod + cs - 1) / cs;
+    P.lds = coop_lds_bytes(P.nw, P.lpw, Q.nseq, npmax);
+    // blocks per CU: LDS (160 KB) and wave slots (32 per CU)
+    P.per_cu = (int)std::min<size_t>((size_t)160 * 1024 / P.lds, (size_t)32 / P.nw);
+    if (c->coop_per_cu > 0 && P.per_cu > c->coop_per_cu) {
+        // ask for more LDS than needed so that at most coop_per_cu blocks share a CU
+        P.lds = std::max(P.lds, (size_t)160 * 1024 / (c->coop_per_cu + 1) + 1024);
+        P.per_cu = c->coop_per_cu;
+    }
+    if (P.per_cu < 1) return P;
+    P.blocks = (nitem + ipb - 1) / ipb;
+    P.ok = true;
+    return P;
+}
+
 // per-family search models (earth flattening, Love); mdl must be ready on stream s
 int launch_family_prep(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, int sphere) {
     const bool wantR = P.QR.nseq > 0, wantL = P.QL.nseq > 0;
@@ -462,26 +519,32 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         while (G > 1 && G < 64 && (lds > 60 * 1024 || (n - 1 + G - 1) / G > 8)) {
             G *= 2; lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
         }
-        int npm = 0;
-        for (int q = 0; q < Q.nseq; q++) npm = Q.s[q].nper > npm ? Q.s[q].nper : npm;
-        if (c->swd_lanes == 0 && nitem >= 1024 && n - 2 <= 16 * COOP_NP && n >= 3 && Q.nseq * npm <= 4096) {
-            // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
-            int nch = (n - 1 - COOP_CL + COOP_NP - 1) / COOP_NP;
-            int npmax = 0;
-            for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
-            size_t lds2 = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + 24 * 64 + Q.nseq * npmax) * sizeof(double);
-            dim3 grid((nitem + 63) / 64);
-#define RFS_LAUNCH_COOP(NCH)                                                                                   \
+        CoopPlan cp = coop_plan(c, Q, nchain, n);
+        if (cp.ok) {
+            // cooperative producer/consumer blocks: least total work, shortest serial path
+            dim3 grid(cp.blocks);
+            size_t lds2 = cp.lds;
+#define RFS_LAUNCH_COOP(NW, LPW, NCH)                                                                          \
             do {                                                                                               \
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NCH>,                              \
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NW, LPW, NCH>,                     \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));          \
-                hipLaunchKernelGGL(k_swd_roots_coop<NCH>, grid, dim3(512), lds2, s, nchain, n, Q,               \
+                hipLaunchKernelGGL((k_swd_roots_coop<NW, LPW, NCH>), grid, dim3(NW * 64), lds2, s, nchain, n, Q, \
                                    mdlR, c->mdlc.as<double>(), c->croot.as<double>(),                           \
                                    c->sflag.as<int>());                                                         \
             } while (0)
-            if (nch <= 5) RFS_LAUNCH_COOP(5);
-            else if (nch <= 8) RFS_LAUNCH_COOP(8);
-            else RFS_LAUNCH_COOP(16);
+#define RFS_COOP_SHAPE(NW, LPW, A, B, C)                                                                       \
+            do {                                                                                               \
+                if (cp.nch <= A) RFS_LAUNCH_COOP(NW, LPW, A);                                                  \
+                else if (cp.nch <= B) RFS_LAUNCH_COOP(NW, LPW, B);                                             \
+                else RFS_LAUNCH_COOP(NW, LPW, C);                                                              \
+            } while (0)
+            switch (cp.nw * 10 + cp.lpw) {
+                case 42: RFS_COOP_SHAPE(4, 2, 5, 8, 16); break;
+                case 82: RFS_COOP_SHAPE(8, 2, 2, 4, 8); break;
+                case 44: RFS_COOP_SHAPE(4, 4, 3, 5, 10); break;
+                default: RFS_COOP_SHAPE(8, 1, 5, 8, 16); break;
+            }
+#undef RFS_COOP_SHAPE
 #undef RFS_LAUNCH_COOP
         } else if (G == 1) {
             hipLaunchKernelGGL(k_swd_roots<false>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
@@ -556,37 +619,76 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>());
     const SwdSeqs& Q = P.QR;
     hipStream_t user = c->stream;
-    // CU partition: the cooperative search occupies one CU per 64 sequences; when that fits on half of the
-    // chip it runs there undisturbed and the RF kernels take the other half (measured +11 % at config 2)
-    const int nblk = (Q.nseq * nchain + 63) / 64;
-    int npmax = 0;
-    for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
-    // ... but only while the RF kernels on half a chip stay shorter than the search (both scale with the layer
-    // count; RF with chains x frequencies, the search with the number of periods): calibrated at config 2
-    const double rf_half = c->has_rf ? (nchain / 8192.0) * ((c->f.n2 - 1) / 256.0) : 0.0;
+    // CU partition: the cooperative search occupies one CU per block (64 sequences); when that fits on half of the
+    // chip it runs there undisturbed and the RF kernels take the other half (measured +11 % at config 2) -- as long
+    // as the RF pipeline on half a chip does not take longer than the search.
     // (not on the context's own stream: there the extra masked streams were measured to share a hardware
     // queue with it and serialise -- the host-pointer entries keep the shared-CU schedule)
+    const CoopPlan cp = coop_plan(c, Q, nchain, n);
+    int npmax = 0;
+    for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
     const bool rf_time = c->has_rf && c->f.method != RFS_RF_FREQ;
-    const bool part = !rf_time && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m && c->stream3 &&
-                      c->swd_lanes == 0 && Q.nseq * nchain >= 1024 && nblk <= c->ncu / 2 &&
-                      rf_half <= 1.1 * (npmax / 40.0);
-    // Early eigenfunction pass: with the partition on, the RF half of the chip finishes before the search does (config
-    // 2: 6.6 vs 7.5 ms).  The eigenfunction kernels of the first periods -- whose roots have long been final by then --
-    // fill that gap on the RF half; only the rest waits for the search (k_swd_eigen launch modes).  What is left for
-    // the mop-up should be whole rounds of the chip's wave slots (an eigenfunction wavefront runs ~0.4 ms however few
-    // there are), and the early part should end about when the search does.  Times calibrated at config 2; a wrong
-    // guess costs time, never results: a wavefront whose roots are not final is left to the mop-up launch.
+    // chain tiles of the RF pipeline: the pass-A row scratch of one tile stays within rf_scratch_budget
+    int rf_tile = nchain;
+    if (c->has_rf && !rf_time) {
+        const size_t per_chain = (size_t)(n - 1) * 8 * c->f.n2p * sizeof(double);
+        size_t fit = per_chain ? c->rf_scratch_budget / per_chain : (size_t)nchain;
+        if (fit < (size_t)nchain) rf_tile = (int)std::max<size_t>(64, fit / 64 * 64);
+    }
+    const bool tiled = rf_tile < nchain;
+    const bool part_possible = !rf_time && !tiled && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m &&
+                               c->stream3 && cp.ok && cp.blocks <= (c->ncu / 2) * cp.per_cu;
+    // Early eigenfunction pass: with the partition on, the RF half of the chip finishes before the search does.  The
+    // eigenfunction kernels of the first periods -- whose roots have long been final by then -- fill that gap on the RF
+    // half; only the rest waits for the search (k_swd_eigen launch modes).  What is left for the mop-up should be
+    // whole rounds of the chip's wave slots (an eigenfunction wavefront runs ~0.4 ms however few there are), and the
+    // early part should end about when the search does.  A wrong choice costs time, never results: a wavefront whose
+    // roots are not final is left to the mop-up launch.
+    const bool early_possible = part_possible && P.QR.nseq == 1 && P.QL.nseq == 0 && nchain % 64 == 0;
+    bool part = part_possible;
     int early_items = 0;
-    bool rf_reduced = false;
-    if (part && P.QR.nseq == 1 && P.QL.nseq == 0 && nchain % 64 == 0 && c->early_eigen != 0) {
-        const double slack = 7.53 * (npmax / 40.0) - 6.59 * rf_half;             // ms, search end - RF end
-        const double cap = 1.3 * slack / (0.044 * (nchain / 8192.0));             // periods that fit (some overshoot pays)
-        const int ipr = std::max(1, c->ncu * 8 / (nchain / 64));                  // periods per full-chip round of slots
-        for (int r = 1; npmax - r * ipr > 0; r++)
-            if (npmax - r * ipr <= cap) { early_items = npmax - r * ipr; break; }
-        if (c->early_eigen > 0) early_items = c->early_eigen;
+    StepCalib* cal = nullptr;
+    bool probe = false;
+    if (part_possible) {
+        cal = &c->calib[std::make_tuple(nchain, n, c->f.nft, npmax, P.nseq)];
+        if (cal->stage == 1) {          // the probe of the previous call: read its three durations and decide
+            bool ok = true;
+            for (int i = 0; i < 3; i++) {
+                float* dst = i == 0 ? &cal->t_search : (i == 1 ? &cal->t_rf : &cal->t_eigen);
+                ok = ok && hipEventSynchronize(cal->ev[2 * i + 1]) == hipSuccess &&
+                     hipEventElapsedTime(dst, cal->ev[2 * i], cal->ev[2 * i + 1]) == hipSuccess;
+            }
+            if (ok && cal->t_search > 0.f) {
+                cal->part = cal->t_rf <= 1.1f * cal->t_search;
+                cal->early_items = 0;
+                if (cal->part && early_possible && cal->t_eigen > 0.f) {
+                    const double slack = cal->t_search - cal->t_rf;                 // ms, search end - RF end
+                    const double per_period = 2.0 * cal->t_eigen / npmax;           // one period's kernels on half of the chip
+                    const double cap = 1.3 * slack / per_period;                    // periods that fit (some overshoot pays)
+                    const int ipr = std::max(1, c->ncu * 8 / (nchain / 64));        // periods per full-chip round of wave slots
+                    for (int r = 1; npmax - r * ipr > 0; r++)
+                        if (npmax - r * ipr <= cap) { cal->early_items = npmax - r * ipr; break; }
+                }
+                cal->stage = 2;
+                if (getenv("RFS_DEBUG_CALIB"))
+                    fprintf(stderr, "[rfs] calibration chains %d layers %d nft %d: search %.3f ms, RF %.3f ms, eigen %.3f ms -> partition %d, early periods %d\n",
+                            nchain, n, c->f.nft, cal->t_search, cal->t_rf, cal->t_eigen, (int)cal->part, cal->early_items);
+            } else {
+                cal->stage = 0;
+            }
+        }
+        if (cal->stage == 0) {
+            probe = true;
+            for (auto& e : cal->ev) if (!e && hipEventCreate(&e) != hipSuccess) probe = false;
+        } else if (cal->stage < 0) {
+            cal->stage = 0;              // warm-up call of this shape: default schedule, no events
+        }
+        if (cal->stage == 2) { part = cal->part; early_items = cal->early_items; }
+        if (early_possible && !probe && c->early_eigen >= 0) early_items = c->early_eigen;       // explicit count (0 = off)
+        if (!part || !early_possible || probe) early_items = 0;
         early_items = std::max(0, std::min(early_items, npmax - 1));
     }
+    bool rf_reduced = false;
     if (early_items > 0) {
         const size_t ntot = (size_t)P.nitems * nchain;
         ENSURE(c, c->croot, ntot * sizeof(double));
@@ -612,7 +714,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         hipStream_t ss = part ? c->stream2m : c->stream2;
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
+        if (probe) HIPCHK(c, hipEventRecord(cal->ev[0], ss));
         TRY(launch_swd(c, ss, nchain, n, P, !part));
+        if (probe) HIPCHK(c, hipEventRecord(cal->ev[1], ss));
         HIPCHK(c, hipEventRecord(c->ev_join, ss));
     } else if (c->has_swd) {
         TRY(launch_swd(c, user, nchain, n, P, true));
@@ -620,8 +724,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     if (c->has_rf) {
         if (part) { HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); c->stream = c->stream3; }
         int rc = RFS_OK;
-        { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nchain, n, c->f, true); }
+        if (probe) HIPCHK(c, hipEventRecord(cal->ev[2], c->stream));
         if (rf_time) {
+            { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nchain, n, c->f, true); }
             // model_rf.py:162-196 with method "time": rf and kernels from cal_rf_par_time_all; the gradient
             // K.r is accumulated spike by spike (rf_time_kernels.hpp), no kernel trace is materialised
             double* ds = dsyn;
@@ -640,23 +745,37 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                 rc = ensure(c, c->PG, (size_t)nchain * 4 * n * sizeof(double));
                 if (!rc) rc = rft_partials(c, nchain, n, c->f, c->Cres.as<double>(), c->PG.as<double>(), nullptr); }
         } else {
-        if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
-          rc = launch_mid(c, nchain, n, c->f, c->d_dobs.as<double>(), c->ndata, dsyn, true); }
-        if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nchain, n, c->f);
-            if (!rc && part) {      // the RF part of the gradient does not wait for the search: reduce it on the RF half
-                hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
-                                   (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
-                                   c->cr.as<double>(), misfit, grad, flag);
-                rf_reduced = true;
-            } }
-        if (!rc && early_items > 0) rc = launch_swd(c, c->stream3, nchain, n, P, true, false, 1, early_items);
+            // Frequency-domain pipeline, one chain tile at a time (a single tile unless the row scratch of the whole
+            // batch would exceed rf_scratch_budget): pass A -> spectrum, IFFT, residual, FFT -> pass B -> RF part of
+            // the gradient.  The reduction does not wait for the search, so it runs here, on the RF stream.
+            for (int c0 = 0; c0 < nchain && !rc; c0 += rf_tile) {
+                const int nc = std::min(rf_tile, nchain - c0);
+                { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nc, n, c->f, true, (size_t)c0); }
+                if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
+                    rc = launch_mid(c, nc, n, c->f, c->d_dobs.as<double>(), c->ndata,
+                                    dsyn ? dsyn + (size_t)c0 * c->ndata : nullptr, true, (size_t)c0, (size_t)nchain); }
+                if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0);
+                    if (!rc) {
+                        hipLaunchKernelGGL(k_rf_reduce, dim3(nc), dim3(n <= 64 ? 64 : 128), 0, c->stream, nc, n,
+                                           (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>() + c0,
+                                           c->cr.as<double>() + (size_t)c0 * 2 * n, misfit + c0, grad + (size_t)c0 * 2 * n,
+                                           flag + c0);
+                    } }
+            }
+            rf_reduced = true;
+            if (probe) HIPCHK(c, hipEventRecord(cal->ev[3], c->stream));
+            if (!rc && early_items > 0) rc = launch_swd(c, c->stream3, nchain, n, P, true, false, 1, early_items);
         }
         c->stream = user;
         if (rc) return rc;
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
     if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
-    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, early_items > 0 ? 2 : 0));   // (rest of the) eigenfunction pass, whole chip
+    if (part) {                                    // (rest of the) eigenfunction pass, whole chip
+        if (probe) HIPCHK(c, hipEventRecord(cal->ev[4], user));
+        TRY(launch_swd(c, user, nchain, n, P, true, false, early_items > 0 ? 2 : 0));
+        if (probe) { HIPCHK(c, hipEventRecord(cal->ev[5], user)); cal->stage = 1; }
+    }
     {
         KTimer t(c, RFS_K_COMBINE, c->stream);
         const SwdRows& R = P.R;
@@ -725,6 +844,7 @@ void rfs_destroy(rfs_ctx* c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     for (auto& pool : c->tev) for (auto e : pool) hipEventDestroy(e);
+    for (auto& kv : c->calib) for (auto e : kv.second.ev) if (e) hipEventDestroy(e);
     delete c;
 }
 
@@ -771,17 +891,40 @@ int rfs_kernel_ms_sum(rfs_ctx* c, double* ms, int32_t* count) {
 
 int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
 
+#ifdef RFS_COOP_PROFILE
+// profiling builds only (scripts/coop_profile.py): cycle accumulators of the cooperative search's consumer waves
+int rfs_debug_coop_profile(rfs_ctx* c, long long* out, int nwords) {
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_prof), (size_t)nwords * sizeof(long long)));
+    return RFS_OK;
+}
+#endif
+
 int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!c || !name) return RFS_ERR_ARG;
     if (!strcmp(name, "swd_lanes_per_chain")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(c, RFS_ERR_ARG, "swd_lanes_per_chain must be 0 or a power of two <= 64");
         c->swd_lanes = value; return RFS_OK;
     }
+    if (!strcmp(name, "rf_scratch_budget_mb")) {
+        if (value < 1) return fail(c, RFS_ERR_ARG, "rf_scratch_budget_mb must be positive");
+        c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
+    }
+    if (!strcmp(name, "recalibrate")) { for (auto& kv : c->calib) kv.second.stage = 0; return RFS_OK; }
+    if (!strcmp(name, "swd_coop_shape")) {
+        if (value != 0 && value != 81 && value != 42 && value != 82 && value != 44) return fail(c, RFS_ERR_ARG, "swd_coop_shape must be 0, 81, 42, 82 or 44");
+        c->coop_shape = value; for (auto& kv : c->calib) kv.second.stage = 0; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_coop_blocks_per_cu")) {
+        if (value < 0 || value > 8) return fail(c, RFS_ERR_ARG, "swd_coop_blocks_per_cu must be within [0, 8]");
+        c->coop_per_cu = value; for (auto& kv : c->calib) kv.second.stage = 0; return RFS_OK;
+    }
     if (!strcmp(name, "cu_split")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "cu_split must be 0, 1 or 2");
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipDeviceSynchronize());
         c->cu_split = value;
+        for (auto& kv : c->calib) kv.second.stage = 0;
         return make_partition_streams(c);
     }
     if (!strcmp(name, "early_eigen_periods")) {

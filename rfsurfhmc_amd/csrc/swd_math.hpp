@@ -379,6 +379,12 @@ struct RootSearchT {
     int nev, m, nctrl;
     Tab tab;
     long nsec;
+#ifdef RFS_COOP_PROFILE
+    long long pf[6] = {0, 0, 0, 0, 0, 0};      // cycles: dispatch, looptop, a1 (Neville), finish + fail, half + scan, new period
+#define RS_STAMP(i) do { long long t_ = clock64(); pf[i] += t_ - tprev_; tprev_ = t_; } while (0)
+#else
+#define RS_STAMP(i)
+#endif
 
     template <class PeriodFn>
     RFS_HD void start_period(const PeriodFn& T) {
@@ -418,6 +424,9 @@ struct RootSearchT {
     template <class PeriodFn, class OutFn>
     RFS_HD void advance(double del, const PeriodFn& T, const OutFn& out) {
         nsec++;
+#ifdef RFS_COOP_PROFILE
+        long long tprev_ = clock64();
+#endif
         bool st_scan = false, st_looptop = false, st_a1 = false, st_finish = false, st_fail = false;
         bool st_half = false, st_newperiod = false;
         int half_phase = PH_HALF0;
@@ -439,12 +448,14 @@ struct RootSearchT {
         else if (phase == PH_HALF_B) { del3 = del; nev = 1; m = 1; st_looptop = true; }
         else { del3 = del; nev = 2; m = m + 1; if (m > 10) m = 10; st_looptop = true; }         // PH_NEV
 
+        RS_STAMP(0);
         if (st_looptop) {                                // nevill :595-607
             nctrl = nctrl + 1;
             if (nctrl >= 100) st_finish = true;
             else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) { nev = 0; st_half = true; half_phase = PH_HALF_OUT; }
             else st_a1 = true;
         }
+        RS_STAMP(1);
         if (st_a1) {                                     // nevill :608-681
             double s13 = del1 - del3, s32 = del3 - del2;
             if (sgn1(del3) * sgn1(del1) < 0.0) { c2 = c3; del2 = del3; }
@@ -495,6 +506,7 @@ struct RootSearchT {
                 }
             }
         }
+        RS_STAMP(2);
         if (st_finish) {                                 // getsol :483-487
             c1 = c3;
             if (c1 > (double)betmx) st_fail = true;
@@ -512,13 +524,16 @@ struct RootSearchT {
                 st_newperiod = true;
             } else { flag = 0; done = 1; }
         }
+        RS_STAMP(3);
         if (st_half) request_half(half_phase);
         if (st_scan) {                                   // getsol loop 1000, :457-469
             c2 = (idir > 0) ? c1 + dc : c1 - dc;
             if (c2 <= clow) { idir = +1; c1 = clow; c2 = c1 + dc; }   // del1 kept (quirk)
             creq = c2; phase = PH_SCAN;
         }
+        RS_STAMP(4);
         if (st_newperiod) start_period(T);
+        RS_STAMP(5);
     }
 };
 using RootSearch = RootSearchT<NevTabReg>;

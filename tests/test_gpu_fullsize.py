@@ -191,3 +191,50 @@ def test_every_root_of_the_bench_batch_against_the_restatement(full, orc):
     print(f"root soak: {ndiff} of {c_dev.size} roots differ, worst {worst:.2e}, flag mismatches {nflag}")
     assert nflag == 0
     assert ndiff <= 8 and worst <= 1.0e-6, (ndiff, worst)
+
+
+
+def test_rf_chain_tiles_are_bit_identical(full):
+    """The RF pipeline of the fused gradient in chain tiles (rf_scratch_budget_mb): whatever the tile size -- 64, 192 or
+    1024 chains here, against the untiled 2048 -- every chain's misfit, gradient, synthetics and flag are bit-identical."""
+    import torch
+    import bench
+    joint, xs, (mis, grad, dsyn, flag), t, _ = full
+    ctx = joint._ensure(bench.N_LAYER)
+    x = torch.from_numpy(np.ascontiguousarray(xs[:2048])).cuda()
+    per_chain_mb = 29 * 8 * 272 * 8 / 2 ** 20            # (n-1) rows x 8 doubles x n2p frequencies
+    try:
+        for tile in (64, 192, 1024):
+            ctx.check(ctx.L.rfs_set_option(ctx.h, b"rf_scratch_budget_mb", int(np.ceil(tile * per_chain_mb)) + 1))
+            out = [o.cpu().numpy() for o in joint.misfit_and_grad_device(x)]
+            assert np.array_equal(out[0], mis[:2048]) and np.array_equal(out[1], grad[:2048]), tile
+            assert np.array_equal(out[2], dsyn[:2048]) and np.array_equal(out[3], flag[:2048]), tile
+    finally:
+        ctx.check(ctx.L.rfs_set_option(ctx.h, b"rf_scratch_budget_mb", 4096))
+
+
+def test_65536_chains_on_one_device_within_the_scratch_budget():
+    """BASELINE configs[2]'s chain count on ONE device: 65 536 chains x 30 layers would need 33 GB of row scratch
+    untiled; with the default 4 GB budget the RF pipeline runs in eight tiles.  Spot chains equal the same models
+    evaluated in a small batch, bit for bit."""
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    t = np.linspace(5, 44, bench.NPER)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT, bench.WATER,
+                                                 "P", "freq"), SurfWD(tRc=t))
+    drf, dswd, flag = joint.forward(bench.true_model())
+    joint.set_obsdata(drf, dswd)
+    xs = bench.make_models(65536, 20260102)
+    torch.cuda.reset_peak_memory_stats()
+    free0 = torch.cuda.mem_get_info()[0]
+    out = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(xs).cuda())]
+    used_gb = (free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30
+    assert out[3].all() and np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
+    assert used_gb < 20.0, used_gb                       # untiled: 33 GB of Rs alone
+    sub = np.r_[0:64, 30000:30064, 65472:65536]
+    ref = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[sub])).cuda())]
+    for a, b in zip(out, ref):
+        assert np.array_equal(a[sub], b)

@@ -44,12 +44,17 @@ def _sampler(kind, outdir, **kw):
 @pytest.mark.parametrize("kind", ["hmc", "hmcda"])
 def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, tmp_path):
     from rfsurfhmc_amd.pyhmc._batched import export_chain
+    # start models: perturbations of the true model (a prior draw whose root search fails makes the reference -- and the
+    # mirror -- stop inside _find_initial_dt, hmcda.py:193-195)
+    b = _bounds()
+    x0 = np.hstack((VS, THK))[None, :] * (1 + 0.03 * np.random.default_rng(5).standard_normal((64, 2 * N)))
+    x0 = np.clip(x0, b[:, 0], b[:, 1]); x0[:, :N] = np.sort(x0[:, :N], axis=1)
     full = _sampler(kind, tmp_path / "a")
-    mis_full = full.sample()
+    mis_full = full.sample(x_init=x0)
     assert full.finished and np.isfinite(mis_full).all()
     ck = str(tmp_path / "state.npz")
     part = _sampler(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2)
-    part.sample(max_trajectories=5)
+    part.sample(x_init=x0, max_trajectories=5)
     assert not part.finished and os.path.exists(ck)
     ctx_part = part.model._ctx
     del part

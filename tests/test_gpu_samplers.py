@@ -230,6 +230,6 @@ def test_ensemble_mass_adaptation_on_the_device(golden):
     mb = b.sample(x_init=x)
     assert np.array_equal(ma, mb) and np.array_equal(a.x_cache, b.x_cache)
     assert np.all(np.isfinite(ma)) and a.accept_ratio.mean() > 0.3
-    d = HMCDualAveraging(_joint(g), bounds, 0.02, 4, 2, 0.65, 991206, 4, 2, mass_adapt=[0, 2], **kw)
+    d = HMCDualAveraging(_joint(g), bounds, 0.02, 4, 2, 0.65, 991206, 4, 3, mass_adapt=[0, 2], **kw)
     md = d.sample(x_init=x)
     assert np.all(np.isfinite(md)) and d.inverse_mass is not None and np.all(d.dt_final > 0)
