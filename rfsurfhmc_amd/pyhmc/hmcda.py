@@ -332,7 +332,9 @@ class HMCDualAveraging:
                                    fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
                                    step_hook=step_hook)
         self.finished = not bool(np.any(i < total))
+        self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written
+            self.x_cache, self.dt_final = x_cache, dt
             return misfit[0] if nc == 1 else misfit
         return self._finish(misfit, x_cache, syndata, i, ncount, dt)
 

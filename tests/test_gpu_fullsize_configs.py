@@ -1,0 +1,112 @@
+"""-m gpu: BASELINE.json configs[3] (50-layer models, the dual-averaging workload) and configs[4] (2048-point RF
+trace) at FULL size -- 8192 chains -- through size-independent properties: batch invariance / permutation
+equivariance (bit-identical), eight spot checks against the oracle within the north-star tolerance, and for configs[3]
+the sampler itself: a dual-averaging flow run with per-chain dt and L whose chains equal the same chains run alone."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def _setup(cfgid):
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    cfg = bench.CONFIGS[cfgid]
+    n, nt = cfg["n"], cfg["nt"]
+    t = np.linspace(5, 44, bench.NPER)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, nt, cfg["dt"], bench.GAUSS, bench.TSHIFT, bench.WATER,
+                                                 "P", "freq"), SurfWD(tRc=t))
+    drf, dswd, flag = joint.forward(bench.true_model(n))
+    assert flag
+    joint.set_obsdata(drf, dswd)
+    xs = bench.make_models(8192, 991206, n=n)
+    out = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(xs).cuda())]
+    return cfg, joint, xs, out, t, (drf, dswd)
+
+
+@pytest.fixture(scope="module", params=[3, 4], ids=["configs3_50layers", "configs4_nt2048"])
+def full(request):
+    return _setup(request.param)
+
+
+def test_full_batch_is_sane(full):
+    cfg, joint, xs, (mis, grad, dsyn, flag), t, _ = full
+    n, nt = cfg["n"], cfg["nt"]
+    assert mis.shape == (8192,) and grad.shape == (8192, 2 * n) and dsyn.shape == (8192, nt + 40)
+    assert flag.all() and np.isfinite(mis).all() and np.isfinite(grad).all() and np.isfinite(dsyn).all()
+    c = dsyn[:, nt:]
+    assert np.all(c > 1.0) and np.all(c < 5.0)
+    assert np.array_equal(c, c.astype(np.float32).astype(np.float64))      # float32-rounded roots (surfdisp96.f:302)
+    assert np.all(grad[:, 2 * n - 1] == 0.0)                               # the half-space thickness is a dummy
+
+
+def test_batch_invariance_and_permutation(full):
+    import torch
+    cfg, joint, xs, (mis, grad, dsyn, flag), t, _ = full
+    sub = np.r_[0:64, 4000:4064, 8128:8192]
+    o = [a.cpu().numpy() for a in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[sub])).cuda())]
+    assert np.array_equal(o[0], mis[sub]) and np.array_equal(o[1], grad[sub]) and np.array_equal(o[2], dsyn[sub])
+    perm = np.random.default_rng(0).permutation(8192)
+    o = [a.cpu().numpy() for a in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[perm])).cuda())]
+    assert np.array_equal(o[0], mis[perm]) and np.array_equal(o[1], grad[perm]) and np.array_equal(o[3], flag[perm])
+
+
+def test_spot_checks_against_the_oracle(full, orc):
+    import bench
+    cfg, joint, xs, (mis, grad, dsyn, flag), t, (drf, dswd) = full
+    jo = orc.Joint_RF_SWD(1.0, 1.0, orc.ReceiverFunc(bench.RAY_P, cfg["nt"], cfg["dt"], bench.GAUSS, bench.TSHIFT,
+                                                     bench.WATER, "P", "freq"), orc.SurfWD(tRc=t))
+    jo.set_obsdata(drf, dswd)
+    for i in (0, 1, 63, 64, 4095, 4096, 8000, 8191):
+        m0, g0, d0, f0 = jo.misfit_and_grad(xs[i])
+        assert f0
+        assert rel(dsyn[i], d0) < 1e-6                          # synthetics: float32 root rounding only
+        assert abs(mis[i] - m0) <= 1e-5 * m0                    # the north-star tolerance
+        assert rel(grad[i], g0) < 1e-5, (i, rel(grad[i], g0))
+
+
+def test_dual_averaging_flow_with_per_chain_trajectory_lengths():
+    """configs[3]'s sampler at 50 layers: HMCDualAveraging.sample_flow gives every chain its own dt and
+    L = max(1, int(lambda / dt)) (pyhmc/hmcda.py:307) and never makes a chain wait for another; chains are independent,
+    so a chain of a 256-chain run equals the same chain (same global number = same RNG stream) run in a 4-chain batch."""
+    import bench
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    n = 50
+    t = np.linspace(5, 44, bench.NPER)
+    x_true = bench.true_model(n)
+    bounds = bench.bounds_of(x_true)
+
+    def make():
+        j = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, 512, 0.1, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq"),
+                         SurfWD(tRc=t))
+        drf, dswd, flag = j.forward(x_true)
+        j.set_obsdata(drf, dswd)
+        return j
+
+    rs = np.random.default_rng(3)
+    xs = np.clip(x_true[None, :] * (1 + 0.01 * rs.standard_normal((256, 2 * n))), bounds[:, 0], bounds[:, 1])
+    xs[:, :n] = np.sort(xs[:, :n], axis=1)
+    # a bounded number of device steps (a chain whose dt collapsed in the burn-in would otherwise set the run time)
+    steps = 120
+    big = HMCDualAveraging(make(), bounds, 0.005, 6, 2, 0.65, 991206, 20, 10, myrank=0, name="b", outdir=None, nchains=256,
+                           verbose=False)
+    mb = big.sample_flow(x_init=xs, max_steps=steps)
+    assert big.flow_steps == steps and np.isfinite(mb).all()
+    assert big.ntrajectories.min() >= 3 and big.naccepted.sum() > 256          # trajectories ran and were accepted
+    assert len(np.unique(np.round(big.dt_final, 12))) > 16                     # per-chain step sizes -> per-chain L
+    # chains 8..11 alone: myrank = 2 with 4 chains per rank -> the same global chain numbers 8..11
+    small = HMCDualAveraging(make(), bounds, 0.005, 6, 2, 0.65, 991206, 20, 10, myrank=2, name="s", outdir=None, nchains=4,
+                             verbose=False)
+    ms = small.sample_flow(x_init=xs[8:12], max_steps=steps)
+    assert np.array_equal(ms, mb[8:12]) and np.array_equal(small.x_cache, big.x_cache[8:12])
+    assert np.array_equal(small.dt_final, big.dt_final[8:12]) and np.array_equal(small.naccepted, big.naccepted[8:12])

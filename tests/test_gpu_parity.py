@@ -69,7 +69,8 @@ def test_swd_b1_against_reference_fixtures(hip, orc, golden):
             for arr, key in ((ka, "dcda"), (kb, "dcdb"), (kr, "dcdr"), (kh, "dcdh")):
                 assert rel(arr, g[f"{name}/{wt}/{key}"]) < tol, (name, wt, key, rel(arr, g[f"{name}/{wt}/{key}"]))
     print(f"swd fixtures: {nexact} of {ntotal} Rc roots identical, {nfail} failing models")
-    assert nfail >= 3 and nexact >= 0.9 * ntotal, (nfail, nexact, ntotal)
+    # observed: 952 of 956 identical (the other four sit on the wild / inverted models, within their 1.2e-6 bound above)
+    assert nfail >= 3 and nexact >= ntotal - 4, (nfail, nexact, ntotal)
 
 
 def test_swd_b1_batched_equals_single(hip, orc):
