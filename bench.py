@@ -137,6 +137,21 @@ def _cpu_worker(args):
     return kind, k, time.perf_counter() - t0
 
 
+def _cpu_quota():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except Exception:
+        return None
+
+
 def _host_cpus():
     """(logical CPUs this process may use, physical cores among them, model name)."""
     allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
@@ -166,7 +181,11 @@ def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
     import multiprocessing as mp
     from oracle import oracle as O
     O.build(ref=False)
-    allowed, ncores, model = _host_cpus()
+    allowed, nphys, model = _host_cpus()
+    quota = _cpu_quota()
+    # one process per core the container can actually run: its physical cores, capped by the cgroup's CPU quota (more
+    # processes than that only time-share the same cores)
+    ncores = max(1, min(nphys, int(quota)) if quota else nphys)
     ctx = mp.get_context("fork")
     sample = xs[:max(64, ncores)]
     with ctx.Pool(ncores) as pool:
@@ -174,7 +193,8 @@ def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
     kind = res[0][0]
     rates = [k / el for _, k, el in res]
     total = float(sum(rates))
-    return {"value": total, "unit": "evals/s", "cores": ncores, "logical_cpus": len(allowed), "cpu_model": model,
+    return {"value": total, "unit": "evals/s", "cores": ncores, "physical_cores_visible": nphys,
+            "logical_cpus": len(allowed), "cpu_quota_cores": quota, "cpu_model": model,
             "evals_per_s_per_core": total / ncores,
             "kind": kind,
             "kind_detail": ("reference (RF tail numpy): oracle/_ref = the reference's own sources compiled here -- libsurf "
@@ -182,8 +202,8 @@ def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
                             "Gaussian, irfft, e^{sigma t}) is numpy because FFTW3 is absent" if kind == "reference"
                             else "port: the C restatement oracle/liboracle.so"),
             "sample": f"{sum(k for _, k, _ in res)} joint misfit+grad evaluations of the bench's own {cfg['n']}-layer "
-                      f"models (nt = {cfg['nt']}, {NPER} Rc periods), {ncores} independent processes (one per physical "
-                      f"core) for {budget_s:.0f} s each"}
+                      f"models (nt = {cfg['nt']}, {NPER} Rc periods), {ncores} independent processes (one per core the "
+                      f"container may use) for {budget_s:.0f} s each"}
 
 
 # ------------------------------------------------------------------------------------------ launcher

@@ -234,9 +234,13 @@ int rf_block(const RfFreq& f) {
 int rf_chunks(const RfFreq& f) { int bs = rf_block(f); return (f.n2 - 1 + bs - 1) / bs; }
 int rf_nparts(const RfFreq& f) { return rf_chunks(f) * (rf_block(f) / 64) + 1; }
 
+constexpr int RF_MAX_CHAINS_PER_LAUNCH = 32768;      // the RF sweeps use one grid row per chain (gridDim.y <= 65535)
+
 // pass A (+ scratch) for the nchain chains that start at chain c0 of the batch (RR, Rs are tile-local: offset 0); lc must
 // be ready
 int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, size_t c0 = 0) {
+    if (nchain > 2 * RF_MAX_CHAINS_PER_LAUNCH - 4096)
+        return fail(c, RFS_ERR_UNSUPPORTED, "more than 61440 chains in one receiver-function launch: split the batch");
     ENSURE(c, c->RR, (size_t)nchain * 4 * f.n2p * sizeof(double));
     if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.n2p * sizeof(double));
     double* Rs = scratch ? c->Rs.as<double>() : nullptr;
@@ -244,11 +248,9 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
 #ifdef RFS_COOP_PROFILE
     if (getenv("RFS_NO_RS")) Rs = nullptr;          // experiment: pass A without its scratch stores (results invalid)
 #endif
-    dim3 grid(rf_chunks(f), nchain);
-    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f,
-                       lc, c->RR.as<double>(), Rs);
-    hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
-                       lc, c->RR.as<double>(), Rs);
+    const int bs = rf_block(f);
+    dim3 grid(rf_chunks(f), nchain + (nchain + bs - 1) / bs);           // + the rows that sweep the Nyquist bin
+    hipLaunchKernelGGL(k_rf_passA, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -285,13 +287,11 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0) 
     int npart = rf_nparts(f);
     ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
-    dim3 grid(rf_chunks(f), nchain);
-    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, lc,
+    const int bs = rf_block(f);
+    dim3 grid(rf_chunks(f), nchain + (nchain + bs - 1) / bs);           // + the rows that sweep the Nyquist bin
+    hipLaunchKernelGGL(k_rf_passB, grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
                        c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
                        c->PG.as<double>());
-    hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f,
-                       lc, c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(),
-                       c->wmax2.as<double>(), npart, c->PG.as<double>());
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -634,6 +634,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         const size_t per_chain = (size_t)(n - 1) * 8 * c->f.n2p * sizeof(double);
         size_t fit = per_chain ? c->rf_scratch_budget / per_chain : (size_t)nchain;
         if (fit < (size_t)nchain) rf_tile = (int)std::max<size_t>(64, fit / 64 * 64);
+        rf_tile = std::min(rf_tile, RF_MAX_CHAINS_PER_LAUNCH);      // grid rows of the RF sweeps
     }
     const bool tiled = rf_tile < nchain;
     const bool part_possible = !rf_time && !tiled && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m &&

@@ -216,17 +216,21 @@ __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ m
 // constants are wave-uniform -> scalar loads) or lane = chain at the last frequency
 // (TAIL=true: n2 = nft/2 + 1 is odd, the Nyquist bin is swept "chain-wide" instead).
 // ---------------------------------------------------------------------------------------
+// One launch covers both: the first ntail = ceil(nchain / blockDim.x) grid rows sweep the Nyquist bin of blockDim.x
+// chains each (only their first column; dispatched first, so they run beside the bulk), the rows after them are the
+// frequency blocks of one chain each -- the small chain-wide part runs inside the big launch instead of as a
+// 0.12 ms kernel of 128 wavefronts behind it.
 template <bool TAIL>
-__global__ void __launch_bounds__(256)
-k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
-           double* __restrict__ Rs)
+__device__ __forceinline__ void
+rf_passA_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
+              double* __restrict__ Rs)
 {
     int chain, k;
     if (TAIL) {
-        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1;
+        chain = blockIdx.y * blockDim.x + threadIdx.x; k = f.n2 - 1;
         if (chain >= nchain) return;
     } else {
-        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
+        chain = blockIdx.y - (nchain + blockDim.x - 1) / blockDim.x; k = blockIdx.x * blockDim.x + threadIdx.x;
         if (k >= f.n2 - 1) return;
     }
     const RfLayer* L = lc + (size_t)chain * n;
@@ -252,6 +256,14 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
     if (r22.re != r22.re || r22.im != r22.im) r22 = C(0.0);
     double* o = RR + (size_t)chain * 4 * n2p + k;
     o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
+}
+__global__ void __launch_bounds__(256)
+k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
+           double* __restrict__ Rs)
+{
+    const int ntail = (nchain + blockDim.x - 1) / blockDim.x;
+    if ((int)blockIdx.y >= ntail) rf_passA_body<false>(nchain, n, f, lc, RR, Rs);
+    else if (blockIdx.x == 0) rf_passA_body<true>(nchain, n, f, lc, RR, Rs);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -351,18 +363,18 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
 }
 
 template <bool TAIL>
-__global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
-k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
-           const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
-           int npart, double* __restrict__ PG)
+__device__ __forceinline__ void
+rf_passB_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
+              const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
+              int npart, double* __restrict__ PG)
 {
     int chain, k, part;
     bool live = true;
     if (TAIL) {
-        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1; part = npart - 1;
+        chain = blockIdx.y * blockDim.x + threadIdx.x; k = f.n2 - 1; part = npart - 1;
         if (chain >= nchain) return;
     } else {
-        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
+        chain = blockIdx.y - (nchain + blockDim.x - 1) / blockDim.x; k = blockIdx.x * blockDim.x + threadIdx.x;
         part = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         if (k >= f.n2 - 1) { live = false; k = f.n2 - 2; }
     }
@@ -424,6 +436,16 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
             }
         }
     }
+}
+// the first ceil(nchain / blockDim.x) rows: the Nyquist bin of blockDim.x chains each; then the frequency blocks (see k_rf_passA)
+__global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
+k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
+           const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
+           int npart, double* __restrict__ PG)
+{
+    const int ntail = (nchain + blockDim.x - 1) / blockDim.x;
+    if ((int)blockIdx.y >= ntail) rf_passB_body<false>(nchain, n, f, lc, RR, Rs, W, wmax2, npart, PG);
+    else if (blockIdx.x == 0) rf_passB_body<true>(nchain, n, f, lc, RR, Rs, W, wmax2, npart, PG);
 }
 
 // B1 kernel_all: materialise the partial spectra S_{p,j,k} (RFModule.f90:416-419) with one column sweep
@@ -625,14 +647,44 @@ constexpr int COOP_CL = 1;                       // the consumer builds the deep
 constexpr int coop_chunk(int nw, int lpw) { return (nw - 1) * lpw; }
 inline size_t coop_lds_bytes(int nw, int lpw, int nseq, int npmax) {
     const int ipb = 64 / lpw;
-    return (size_t)(4 * ipb + 8 + 2 * coop_chunk(nw, lpw) * SWD_NENT * ipb + 24 * ipb + nseq * npmax) * sizeof(double);
+    return (size_t)(4 * ipb + 8 + 2 * coop_chunk(nw, lpw) * SWD_NENT * ipb + 24 * ipb + 2 * nseq * npmax) * sizeof(double);
 }
+// periods of a search sequence as tables in LDS: omega_k = 2 pi / T_k and 1 / max(omega_k, 1e-4), divided once per block
+// instead of once per (lane, period) inside the consumer's serial phase
+struct SwdOmegaTab {
+    const double* om;
+    __device__ __forceinline__ double operator()(int k) const { return (2.0 * 3.141592653589793) / om[k]; }   // period (unused)
+    __device__ __forceinline__ double omega(int k) const { return om[k]; }
+};
 #ifdef RFS_COOP_PROFILE
 __device__ long long g_coop_prof[16 * 1024];     // [block][16]: rounds, request, ..., state-machine stages
 #define COOP_STAMP(v) long long v = clock64()
 #else
 #define COOP_STAMP(v)
 #endif
+// The consumer's recurrence over the K layers of one chunk (entries of layer i at eb[(i * 15 + q) * IPB]).  Every chunk
+// is full (slots in front of the deepest layer are identity matrices), so this is straight-line code: three rotating
+// register buffers keep the LDS reads of layers i+1 and i+2 in flight while layer i's 25 FMAs issue.
+template <int K, int IPB>
+__device__ __forceinline__ void coop_apply_chunk(double e[5], const double* __restrict__ eb, double tt) {
+    double buf[3][SWD_NENT];
+#pragma unroll
+    for (int q = 0; q < SWD_NENT; q++) buf[0][q] = eb[(size_t)q * IPB];
+    if (K > 1) {
+#pragma unroll
+        for (int q = 0; q < SWD_NENT; q++) buf[1][q] = eb[(size_t)(SWD_NENT + q) * IPB];
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if (i + 2 < K) {
+#pragma unroll
+            for (int q = 0; q < SWD_NENT; q++) buf[(i + 2) % 3][q] = eb[(size_t)((i + 2) * SWD_NENT + q) * IPB];
+        }
+        swd_apply_layer_raw(e, buf[i % 3], tt);
+    }
+    swd_rescale_pow2(e);                             // once per chunk
+}
+
 template <int NW, int LPW, int NCH>              // chunks held in registers: (n-1-COOP_CL) <= NCH*CS
 __global__ void __launch_bounds__(NW * 64)
 k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
@@ -645,7 +697,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     int* go = (int*)(lds + 4 * IPB);             // go[0]: the consumer has another evaluation
     double* ent = lds + 4 * IPB + 8;             // [2][CS][15][IPB]
     double* nev = ent + 2 * CS * SWD_NENT * IPB; // [24][IPB] Neville tables of the state machines
-    double* tper = nev + 24 * IPB;               // [nseq][nper_max] scaled periods (no global loads in the loop)
+    double* tper = nev + 24 * IPB;               // [2][nseq][nper_max]: omega_k = 2 pi / T_k, then 1 / max(omega_k, 1e-4)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bl = lane % IPB, sub = lane / IPB; // block-lane = which of the block's items this thread works on
     int item = blockIdx.x * IPB + bl;
@@ -659,7 +711,9 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     for (int q = 0; q < Q.nseq; q++) npmax = max(npmax, Q.s[q].nper);
     for (int i = threadIdx.x; i < Q.nseq * npmax; i += blockDim.x) {
         int q = i / npmax, k = i - q * npmax;
-        tper[i] = (k < Q.s[q].nper) ? Q.s[q].t[k] * Q.s[q].scale : 1.0;
+        const double om = (2.0 * 3.141592653589793) / ((k < Q.s[q].nper) ? Q.s[q].t[k] * Q.s[q].scale : 1.0);
+        tper[i] = om;                                                      // RootSearchT::start_period's TWOPI / T(k)
+        tper[Q.nseq * npmax + i] = 1.0 / (om < 1.0e-4 ? 1.0e-4 : om);
     }
     if (threadIdx.x < 8) go[threadIdx.x] = 0;
     __syncthreads();
@@ -675,8 +729,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         const SwdSeq sq = Q.s[seq];
-        const double* tp = tper + seq * npmax;
-        auto T = [&](int k) { return tp[k]; };
+        const SwdOmegaTab T{tper + seq * npmax};
+        const double* iom = tper + (Q.nseq + seq) * npmax;
         double* cr = croot + (size_t)sq.croot_off * nchain + chain;
         // agent-scope stores: an eigenfunction launch that runs beside this kernel on the other half of the chip may
         // pick up finished periods (k_swd_eigen, early mode: a root is final once it is non-zero)
@@ -688,7 +742,6 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         rs.begin(M, T, sq.nper);
         if (!live) rs.done = 1;
         const SwdLayerC Lhalf = loadL(n - 1), Ldeep = loadL(n - 2);
-        int k_iom = -1; double iomega = 0.0;
 #ifdef RFS_COOP_PROFILE
         long long pr_rounds = 0, pr_prod = 0, pr_apply = 0, pr_sm = 0, pr_req = 0, pr_first = 0;
         long long tq = clock64();
@@ -696,7 +749,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         for (;;) {
             int more = __any(!rs.done);
             double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
-            if (rs.k != k_iom) { iomega = 1.0 / omega; k_iom = rs.k; }           // omega changes with the period only
+            const double iomega = iom[rs.k < sq.nper ? rs.k : 0];               // 1 / omega from the block's table
             double wvno = rs.omega / rs.creq, wvno2 = wvno * wvno;
             if (lane < IPB) { req[bl] = wvno; req[IPB + bl] = wvno2; req[2 * IPB + bl] = omega; req[3 * IPB + bl] = iomega; }
             if (lane == 0) go[0] = more;
@@ -720,26 +773,7 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 #ifdef RFS_COOP_PROFILE
                 if (c == nch - 1) tl = clock64();
 #endif
-                const double* eb = ent + (size_t)(c & 1) * CS * SWD_NENT * IPB + bl;
-                // Every chunk holds CS layers (slots in front of the deepest layer are identity matrices), so the
-                // recurrence is straight-line code: three rotating register buffers keep the LDS reads of layers
-                // i+1 and i+2 in flight while layer i's 25 FMAs issue.
-                double buf[3][SWD_NENT];
-#pragma unroll
-                for (int q = 0; q < SWD_NENT; q++) buf[0][q] = eb[(size_t)q * IPB];
-                if (CS > 1) {
-#pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) buf[1][q] = eb[(size_t)(SWD_NENT + q) * IPB];
-                }
-#pragma unroll
-                for (int i = 0; i < CS; i++) {
-                    if (i + 2 < CS) {
-#pragma unroll
-                        for (int q = 0; q < SWD_NENT; q++) buf[(i + 2) % 3][q] = eb[(size_t)((i + 2) * SWD_NENT + q) * IPB];
-                    }
-                    swd_apply_layer_raw(e, buf[i % 3], tt);
-                }
-                swd_rescale_pow2(e);                             // once per chunk
+                coop_apply_chunk<CS, IPB>(e, ent + (size_t)(c & 1) * CS * SWD_NENT * IPB + bl, tt);
             }
             COOP_STAMP(t2);
             if (!rs.done) rs.advance(swd_finish(e), T, out);

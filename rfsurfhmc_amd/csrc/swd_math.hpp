@@ -59,6 +59,8 @@ struct SwdModelD {
 };
 
 RFS_HD double sgn1(double x) { return copysign(1.0, x); }
+// sgn1(a) != sgn1(b), i.e. sgn1(a) * sgn1(b) < 0: the sign bits differ (NaN and -0 by their sign bit, like copysign)
+RFS_HD bool diffsign(double a, double b) { return (bool)signbit(a) != (bool)signbit(b); }
 
 // ---------------------------------------------------------------------------
 // Love secular function (surfdisp96.f:727-787 dltar1, all-solid model): 2-vector recurrence
@@ -364,6 +366,10 @@ struct NevTabMem {             // x(i) at base[i*stride], y(i) at base[(12+i)*st
     RFS_HD void sy(int i, double v) { base[(12 + i) * stride] = v; }
 };
 
+// omega of period k: a period functor may provide a precomputed table (omega(k)); otherwise 2 pi / T(k)
+template <class F> RFS_HD auto rs_omega_of(const F& T, int k, int) -> decltype(T.omega(k)) { return T.omega(k); }
+template <class F> RFS_HD double rs_omega_of(const F& T, int k, long) { return (2.0 * 3.141592653589793) / T(k); }
+
 template <class Tab = NevTabReg>
 struct RootSearchT {
     enum { PH_START, PH_SCAN, PH_HALF0, PH_HALF_OUT, PH_HALF_B, PH_NEV };
@@ -390,7 +396,7 @@ struct RootSearchT {
     RFS_HD void start_period(const PeriodFn& T) {
         if (retry || k == 0) { c1 = cc; clow = cc; ifirst = 1; }       // surfdisp96.f:257-260
         else { ifirst = 0; c1 = cprev - 1.5 * dc; clow = cm; }         // :272-275 (onea = 1.5)
-        omega = TWOPI / T(k);
+        omega = rs_omega_of(T, k, 0);
         creq = c1; phase = PH_START;
     }
 
@@ -415,8 +421,6 @@ struct RootSearchT {
         start_period(T);
     }
 
-    RFS_HD void request_half(int next_phase) { c3 = 0.5 * (c1 + c2); creq = c3; phase = next_phase; }
-
     // consume del = secular(creq) and run until the next request (or completion).
     // Forward-only staging (phase dispatch -> LOOPTOP -> A1 -> FINISH -> FAIL -> SCAN / new period): every
     // transition of getsol / nevill moves forward through these stages, so there is no loop over states and
@@ -427,42 +431,47 @@ struct RootSearchT {
 #ifdef RFS_COOP_PROFILE
         long long tprev_ = clock64();
 #endif
-        bool st_scan = false, st_looptop = false, st_a1 = false, st_finish = false, st_fail = false;
-        bool st_half = false, st_newperiod = false;
+        // Phase dispatch and the loop head of nevill as PREDICATED updates (selects, no branches): with 64 lanes in a
+        // mixture of phases every branch of an if / else chain would be executed anyway, and the structurised control
+        // flow cost several times the dozen selects below.  sgn1(a) * sgn1(b) < 0  <=>  the sign bits differ.
+        const int ph = phase;
+        const bool pS = ph == PH_START, pC = ph == PH_SCAN, pH0 = ph == PH_HALF0, pHO = ph == PH_HALF_OUT,
+                   pHB = ph == PH_HALF_B, pN = ph == PH_NEV;
+        // getsol head (surfdisp96.f:433-447) and one scan step (:470-479)
+        del1st = (pS && ifirst == 1) ? del : del1st;
+        idir = pS ? (diffsign(del1st, del) ? -1 : +1) : idir;              // ifirst == 1: del1st == del -> +1
+        const bool chg = pC && diffsign(del1, del);                         // bracket found
+        const bool cont = pC && !chg;
+        del2 = pC ? del : del2;
+        c1 = cont ? c2 : c1;
+        del1 = (pS || cont) ? del : del1;
+        const bool sfail = cont && (c1 < cm || c1 >= ((double)betmx + dc));
+        const bool st_scan = pS || (cont && !sfail);
+        bool st_fail = sfail, st_half = chg, st_newperiod = false;
         int half_phase = PH_HALF0;
-        if (phase == PH_START) {                         // getsol head, surfdisp96.f:433-447
-            del1 = del;
-            if (ifirst == 1) del1st = del1;
-            if (ifirst == 1) idir = +1;
-            else idir = (sgn1(del1st) * sgn1(del1) >= 0.0) ? +1 : -1;
-            st_scan = true;
-        } else if (phase == PH_SCAN) {                   // :470-479
-            del2 = del;
-            if (sgn1(del1) != sgn1(del2)) { st_half = true; half_phase = PH_HALF0; }
-            else {
-                c1 = c2; del1 = del2;
-                if (c1 < cm || c1 >= ((double)betmx + dc)) st_fail = true; else st_scan = true;
-            }
-        } else if (phase == PH_HALF0) { del3 = del; nev = 1; nctrl = 1; st_looptop = true; }   // nevill :590-594
-        else if (phase == PH_HALF_OUT) { del3 = del; st_a1 = true; }
-        else if (phase == PH_HALF_B) { del3 = del; nev = 1; m = 1; st_looptop = true; }
-        else { del3 = del; nev = 2; m = m + 1; if (m > 10) m = 10; st_looptop = true; }         // PH_NEV
-
+        // entries of nevill's loop (:590-594 and the three ways back to its top)
+        del3 = (pH0 || pHO || pHB || pN) ? del : del3;
+        nev = (pH0 || pHB) ? 1 : (pN ? 2 : nev);
+        m = pHB ? 1 : (pN ? (m >= 10 ? 10 : m + 1) : m);
+        const bool st_looptop = pH0 || pHB || pN;
+        nctrl = pH0 ? 2 : (st_looptop ? nctrl + 1 : nctrl);                 // :595 (HALF0 starts from nctrl = 1)
+        const bool lt_fin = st_looptop && nctrl >= 100;
+        const bool lt_out = st_looptop && !lt_fin && (c3 < fmin(c1, c2) || c3 > fmax(c1, c2));   // :597-607
+        nev = lt_out ? 0 : nev;
+        st_half = st_half || lt_out;
+        half_phase = lt_out ? (int)PH_HALF_OUT : half_phase;
+        bool st_finish = lt_fin;
+        const bool st_a1 = pHO || (st_looptop && !lt_fin && !lt_out);
         RS_STAMP(0);
-        if (st_looptop) {                                // nevill :595-607
-            nctrl = nctrl + 1;
-            if (nctrl >= 100) st_finish = true;
-            else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) { nev = 0; st_half = true; half_phase = PH_HALF_OUT; }
-            else st_a1 = true;
-        }
         RS_STAMP(1);
         if (st_a1) {                                     // nevill :608-681
-            double s13 = del1 - del3, s32 = del3 - del2;
-            if (sgn1(del3) * sgn1(del1) < 0.0) { c2 = c3; del2 = del3; }
-            else { c1 = c3; del1 = del3; }
+            const double s13 = del1 - del3, s32 = del3 - del2;
+            const bool opp = diffsign(del3, del1);
+            c2 = opp ? c3 : c2; del2 = opp ? del3 : del2;
+            c1 = opp ? c1 : c3; del1 = opp ? del1 : del3;
             if (fabs(c1 - c2) <= 1.0e-6 * c1) st_finish = true;
             else {
-                if (sgn1(s13) != sgn1(s32)) nev = 0;
+                if (diffsign(s13, s32)) nev = 0;
                 const double pct = (double)0.01f;        // default-real literal 0.01 (:637,639)
                 double ss1 = fabs(del1), s1 = pct * ss1, ss2 = fabs(del2), s2 = pct * ss2;
                 if (s1 > ss2 || s2 > ss1 || nev == 0) { st_half = true; half_phase = PH_HALF_B; }
@@ -525,11 +534,16 @@ struct RootSearchT {
             } else { flag = 0; done = 1; }
         }
         RS_STAMP(3);
-        if (st_half) request_half(half_phase);
-        if (st_scan) {                                   // getsol loop 1000, :457-469
-            c2 = (idir > 0) ? c1 + dc : c1 - dc;
-            if (c2 <= clow) { idir = +1; c1 = clow; c2 = c1 + dc; }   // del1 kept (quirk)
-            creq = c2; phase = PH_SCAN;
+        {   // next request of the lanes that stay inside the period: a bisection point or the next scan point
+            // (getsol loop 1000, :457-469); predicated, the two cases exclude each other
+            const double c2n = (idir > 0) ? c1 + dc : c1 - dc;
+            const bool clamp = st_scan && c2n <= clow;                      // del1 kept (quirk)
+            idir = clamp ? +1 : idir;
+            c1 = clamp ? clow : c1;
+            c2 = st_scan ? (clamp ? c1 + dc : c2n) : c2;
+            c3 = st_half ? 0.5 * (c1 + c2) : c3;
+            creq = st_half ? c3 : (st_scan ? c2 : creq);
+            phase = st_half ? half_phase : (st_scan ? (int)PH_SCAN : phase);
         }
         RS_STAMP(4);
         if (st_newperiod) start_period(T);
