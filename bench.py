@@ -373,6 +373,9 @@ def run_rank(args):
         # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
         smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
                                nchains=nchain, verbose=False, store_syn=False)
+        # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
+        # given the chains different step sizes) finish in bursts; time a window behind them
+        nwarm = max(nwarm, 40)
         marks = {}
         active = torch.zeros((), dtype=torch.int64, device=dev)
 

@@ -169,7 +169,28 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max
     and counts the chains inside a trajectory there)."""
     import torch
     dev = st["x"].device
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    nchain_all = st["x"].shape[0]
+    pinned = {}                                  # (trailing shape, dtype) -> [rotating pinned buffers, next]
+
+    def t(a):
+        """Host array (at most one row per chain) -> device tensor.  On a GPU the copy goes through preallocated pinned
+        staging buffers and is asynchronous: a plain .to(device) of pageable memory is stream-ordered behind the step that
+        was just launched AND blocks the host until it has run, which would serialise the host bookkeeping with the GPU
+        step it is meant to overlap.  Four buffers per shape rotate; fetch() synchronises with the device once per
+        step, so a buffer is idle again long before its turn comes round."""
+        a = np.ascontiguousarray(a)
+        if dev.type != "cuda":
+            return torch.from_numpy(a).to(dev)
+        src = torch.from_numpy(a)
+        key = (tuple(a.shape[1:]), src.dtype)
+        if key not in pinned:
+            pinned[key] = [[torch.empty((nchain_all,) + key[0], dtype=src.dtype, pin_memory=True) for _ in range(4)], 0]
+        bufs, nxt = pinned[key]
+        pinned[key][1] = (nxt + 1) % len(bufs)
+        h = bufs[nxt][: a.shape[0]]
+        h.copy_(src)
+        return h.to(dev, non_blocking=True)
 
     def fetch():
         idx = np.nonzero(st["done"].cpu().numpy())[0]

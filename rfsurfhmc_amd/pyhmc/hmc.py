@@ -139,20 +139,20 @@ class HamitonianMC:
             u[ok] = self.rng.rand([int(c) for c in idx[ok]])                    # hmc.py:193, skipped on failure
             with np.errstate(over="ignore", invalid="ignore"):
                 accept = ok & (u < np.exp(-(Hnew - Hcur)))
-            restart = []
-            for k, c in enumerate(idx):
-                if accept[k]:
-                    x[c] = xend[k]
-                    if i[c] >= nd_:
-                        misfit[c, i[c] - nd_] = Unew[k]
-                        x_cache[c, i[c] - nd_] = xend[k]
-                        if syndata is not None:
-                            syndata[c, i[c] - nd_] = dnew[k]
-                    i[c] += 1
-                    self.ii += 1
-                ncount[c] += 1
-                if i[c] < total:
-                    restart.append(int(c))
+            # accepted end points (vectorised over the finished chains; one sample slot per chain and trajectory)
+            ca = idx[accept]
+            if len(ca):
+                x[ca] = xend[accept]
+                keep = i[ca] >= nd_
+                if np.any(keep):
+                    ck, slot = ca[keep], i[ca][keep] - nd_
+                    misfit[ck, slot] = Unew[accept][keep]
+                    x_cache[ck, slot] = xend[accept][keep]
+                    if syndata is not None:
+                        syndata[ck, slot] = dnew[accept][keep]
+                i[ca] += 1; self.ii += len(ca)
+            ncount[idx] += 1
+            restart = [int(c) for c in idx[i[idx] < total]]
             if self.verbose:
                 for k, c in enumerate(idx):
                     if i[c] % 50 == 0 or i[c] == ns - 1:

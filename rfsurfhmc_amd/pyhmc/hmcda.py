@@ -295,14 +295,19 @@ class HMCDualAveraging:
                 alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
             u = self.rng.rand([int(c) for c in idx])
             acc = u < alpha
-            for k, c in enumerate(idx):
-                if acc[k]:
-                    x[c] = xend[k]
-                    if i[c] >= nd_:
-                        misfit[c, i[c] - nd_] = Unew[k]; x_cache[c, i[c] - nd_] = xend[k]
-                        if syndata is not None:
-                            syndata[c, i[c] - nd_] = dnew[k] if ok[k] else self.model.dobs
-                    i[c] += 1; self.ii += 1
+            # accepted end points (vectorised over the finished chains; one sample slot per chain and trajectory)
+            ca = idx[acc]
+            if len(ca):
+                x[ca] = xend[acc]
+                keep = i[ca] >= nd_
+                if np.any(keep):
+                    ck, slot = ca[keep], i[ca][keep] - nd_
+                    misfit[ck, slot] = Unew[acc][keep]
+                    x_cache[ck, slot] = xend[acc][keep]
+                    if syndata is not None:
+                        okk = ok[acc][keep]
+                        syndata[ck, slot] = np.where(okk[:, None], dnew[acc][keep], self.model.dobs[None, :])
+                i[ca] += 1; self.ii += len(ca)
             # dual averaging for the chains that just finished a trajectory (hmcda.py:329-345)
             adapt = ncount[idx] < nd_
             m = ncount[idx] + 1.0
