@@ -22,8 +22,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(f) > t for f in _inputs())
 
 
+RNGLIB = os.path.join(HERE, "librngbatch.so")
+RNGSRC = os.path.join(HERE, "csrc_host", "rngbatch.c")
+
+
+def build_host_helpers(force: bool = False) -> str:
+    """gcc -> rfsurfhmc_amd/librngbatch.so: the batched samplers' C loop over per-chain numpy legacy RNG streams."""
+    if force or not os.path.exists(RNGLIB) or os.path.getmtime(RNGSRC) > os.path.getmtime(RNGLIB):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", RNGSRC, "-o", RNGLIB, "-lm"], check=True)
+    return RNGLIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 ... -> rfsurfhmc_amd/librfsurf_hip.so"""
+    build_host_helpers(force)
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -7,18 +7,68 @@ import os
 import numpy as np
 
 
+def _load_rngbatch():
+    """librngbatch.so (csrc_host/rngbatch.c, built by rfsurfhmc_amd.build): C loop over the chains' streams.  It
+    advances the MT19937 states inside numpy in place, so it is only used when numpy's bit generator is the expected
+    one (struct of 624 key words + position; checked against rs.rand() / rs.randn() when the first ChainRNG is made)."""
+    import ctypes
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "librngbatch.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        L = ctypes.CDLL(path)
+    except OSError:
+        return None
+    vp, i64, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64
+    L.rngbatch_randn.argtypes = [vp, vp, vp, vp, i64, i64, vp]
+    L.rngbatch_randn.restype = None
+    L.rngbatch_rand.argtypes = [vp, vp, i64, vp]
+    L.rngbatch_rand.restype = None
+    return L
+
+
 class ChainRNG:
     """One legacy MT19937 stream per chain: RandomState(seed + first_chain + c) draws exactly what the
-    reference's global generator draws on rank (first_chain + c)."""
+    reference's global generator draws on rank (first_chain + c).
+
+    With librngbatch.so the uniform and normal deviates of many chains are drawn by one C call that drives each
+    stream's own bit generator (same values as rs.rand() / rs.randn(n), bit for bit); the cached second deviate of
+    numpy's legacy Gaussian then lives in this object (has_gauss / gauss) instead of inside the RandomState.  Without
+    the library the same draws are made chain by chain in Python."""
 
     def __init__(self, seed, first_chain, nchains):
+        import ctypes
         self.rs = [np.random.RandomState(seed + first_chain + c) for c in range(nchains)]
+        self._L = _load_rngbatch()
+        if self._L is not None:
+            bgs = [r._bit_generator for r in self.rs]
+            self._bgs = bgs                                   # keeps the ctypes interfaces (and their states) alive
+            self._states = np.array([b.ctypes.state_address for b in bgs], dtype=np.uint64)
+            self._has = np.zeros(nchains, dtype=np.int32)
+            self._gauss = np.zeros(nchains)
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data
 
     def rand(self, idx):
-        return np.array([self.rs[c].rand() for c in idx])
+        if self._L is None:
+            return np.array([self.rs[c].rand() for c in idx])
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty(len(idx))
+        if len(idx):
+            self._L.rngbatch_rand(self._p(self._states), self._p(idx), len(idx), self._p(out))
+        return out
 
     def randn(self, idx, n):
-        return np.stack([self.rs[c].randn(n) for c in idx]) if len(idx) else np.zeros((0, n))
+        if self._L is None:
+            return np.stack([self.rs[c].randn(n) for c in idx]) if len(idx) else np.zeros((0, n))
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty((len(idx), n))
+        if len(idx):
+            self._L.rngbatch_randn(self._p(self._states), self._p(self._has), self._p(self._gauss), self._p(idx),
+                                   len(idx), n, self._p(out))
+        return out
 
     def randint(self, idx, lo, hi):
         return np.array([self.rs[c].randint(lo, hi) for c in idx], dtype=np.int32)
@@ -26,13 +76,21 @@ class ChainRNG:
     def get_state(self):
         """Arrays that restore every stream exactly (MT19937 key, position, cached Gaussian)."""
         st = [r.get_state() for r in self.rs]
-        return {"rng_key": np.stack([t[1] for t in st]), "rng_pos": np.array([t[2] for t in st]),
-                "rng_has_gauss": np.array([t[3] for t in st]), "rng_gauss": np.array([t[4] for t in st])}
+        d = {"rng_key": np.stack([t[1] for t in st]), "rng_pos": np.array([t[2] for t in st])}
+        if self._L is None:
+            d["rng_has_gauss"] = np.array([t[3] for t in st]); d["rng_gauss"] = np.array([t[4] for t in st])
+        else:
+            d["rng_has_gauss"] = self._has.copy(); d["rng_gauss"] = self._gauss.copy()
+        return d
 
     def set_state(self, d):
         for c, r in enumerate(self.rs):
-            r.set_state(("MT19937", d["rng_key"][c], int(d["rng_pos"][c]), int(d["rng_has_gauss"][c]),
-                         float(d["rng_gauss"][c])))
+            keep = self._L is None
+            r.set_state(("MT19937", d["rng_key"][c], int(d["rng_pos"][c]), int(d["rng_has_gauss"][c]) if keep else 0,
+                         float(d["rng_gauss"][c]) if keep else 0.0))
+        if self._L is not None:
+            self._has[:] = np.asarray(d["rng_has_gauss"], dtype=np.int32)
+            self._gauss[:] = np.asarray(d["rng_gauss"], dtype=np.float64)
 
 
 def set_initial_model(rs, boundaries):

@@ -19,7 +19,7 @@ smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, 100, 20, myrank
 pr = cProfile.Profile()
 import time
 def hook(s, st):
-    if s == 5: pr.enable(); hook.t0 = time.perf_counter()
-    if s == 35: pr.disable(); print("ms/step", (time.perf_counter() - hook.t0) / 30 * 1e3)
-smp.sample_flow(x_init=xs, max_steps=37, step_hook=hook)
+    if s == 40: pr.enable(); hook.t0 = time.perf_counter()
+    if s == 70: pr.disable(); print("ms/step", (time.perf_counter() - hook.t0) / 30 * 1e3)
+smp.sample_flow(x_init=xs, max_steps=72, step_hook=hook)
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
