@@ -336,6 +336,10 @@ def run_rank(args):
         st["p"].copy_(tt(0.5 * rng.standard_normal(xs.shape)))        # p ~ 0.5 N(0, I), hmc.py:146
         st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
         joint.flow_step(st)                                            # start evaluation + half kick (untimed)
+        # set-up, not warm-up: the library times its candidate schedules (CU partition, early eigenfunction periods) on
+        # the first evaluations of a new shape -- twice each -- and keeps the fastest (include/rfsurf.h, "recalibrate")
+        for _ in range(32):
+            joint.flow_step(st)
         timing_all()
         for _ in range(nwarm - 1):
             joint.flow_step(st)

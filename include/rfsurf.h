@@ -183,9 +183,6 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
 /* Tuning knobs (no effect on results beyond last-bit rounding):
  *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic, else a power
  *                          of two <= 64 (1 = the sequential lane-per-chain kernel).
- *   "swd_coop_shape"       block shape of the cooperative root search, 10 * waves per block + layers per producer
- *                          wave: 81 (512 threads, 64 chains; default), 42 (256 threads, 32 chains), 82, 44; 0 = default.
- *   "swd_coop_blocks_per_cu"  how many such blocks may share a CU (default 2; 0 = whatever fits).
  *   "cu_split"             0 = RF kernels on the caller's stream, sharing CUs with the root search;
  *                          1 (default) / 2 = when the cooperative root search fits on half of the CUs, it and
  *                          the RF kernels run on disjoint halves of the CU mask (contiguous halves / even-odd

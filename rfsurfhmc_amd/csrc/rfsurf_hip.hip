@@ -30,16 +30,20 @@ struct FftPlan { rocfft_plan plan = nullptr; rocfft_execution_info info = nullpt
 
 }  // namespace
 
-// Schedule of a partitioned step, MEASURED once per shape (the first evaluation of a shape runs as a probe with HIP
-// events around the search, the RF pipeline and the eigenfunction pass; the second one reads them and decides).
+// Schedule of a step, MEASURED once per shape: the candidates -- everything on shared CUs, or the CU partition with
+// 0 / some / more of the first periods' eigenfunction kernels moved onto the RF half -- are each run (as ordinary
+// evaluations: every schedule returns bit-identical results) with one HIP-event pair around the whole step, twice; the
+// fastest one is kept for the shape.  The first call of a shape (buffer and FFT-plan allocation) is not timed.
+struct StepCand { bool part; int early; float ms; };
 struct StepCalib {
-    int stage = -1;                      // -1 never seen (the first call allocates buffers and FFT plans: not timed),
-                                         // 0 ready to probe, 1 probe launched (events pending), 2 decided
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // search, RF, eigen: begin / end
-    float t_search = 0.f, t_rf = 0.f, t_eigen = 0.f;                             // ms
+    int stage = -1;                      // -1 never seen; 0 .. 2 * ncand: timed calls launched so far; CALIB_DONE: decided
+    int harvested = 0;                   // timed calls whose event pair has been read (never waited for: hipEventQuery)
+    std::vector<hipEvent_t> ev;          // [2 * ncand][begin, end]
+    std::vector<StepCand> cand;
     bool part = true;
     int early_items = 0;
 };
+constexpr int CALIB_DONE = 1 << 20;
 
 struct rfs_ctx {
     int device = 0, max_chains = 0, max_layers = 0;
@@ -65,8 +69,6 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
-    int coop_shape = 0;    // cooperative search: 10 * waves per block + layers per producer wave (0 = default 42)
-    int coop_per_cu = 2;   // ... and the number of such blocks allowed to share a CU (0 = whatever fits)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -245,12 +247,10 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.n2p * sizeof(double));
     double* Rs = scratch ? c->Rs.as<double>() : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
-#ifdef RFS_COOP_PROFILE
-    if (getenv("RFS_NO_RS")) Rs = nullptr;          // experiment: pass A without its scratch stores (results invalid)
-#endif
-    const int bs = rf_block(f);
-    dim3 grid(rf_chunks(f), nchain + (nchain + bs - 1) / bs);           // + the rows that sweep the Nyquist bin
-    hipLaunchKernelGGL(k_rf_passA, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs);
+    dim3 grid(rf_chunks(f), nchain);
+    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs);
+    hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
+                       c->RR.as<double>(), Rs);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -287,9 +287,11 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0) 
     int npart = rf_nparts(f);
     ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
-    const int bs = rf_block(f);
-    dim3 grid(rf_chunks(f), nchain + (nchain + bs - 1) / bs);           // + the rows that sweep the Nyquist bin
-    hipLaunchKernelGGL(k_rf_passB, grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
+    dim3 grid(rf_chunks(f), nchain);
+    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, lc,
+                       c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
+                       c->PG.as<double>());
+    hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
                        c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
                        c->PG.as<double>());
     HIPCHK(c, hipGetLastError());
@@ -441,36 +443,19 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
     return P;
 }
 
-// Shape of the cooperative root search (k_swd_roots_coop<NW, LPW, NCH>) for one launch
-struct CoopPlan { bool ok = false; int nw = 8, lpw = 1, nch = 0, blocks = 0, per_cu = 1; size_t lds = 0; };
+// Launch shape of the cooperative root search (k_swd_roots_coop<NCH>): 512-thread blocks of 64 (sequence, chain) items,
+// one block per CU (107 KB of LDS)
+struct CoopPlan { bool ok = false; int nch = 0, blocks = 0, per_cu = 1; size_t lds = 0; };
 
 CoopPlan coop_plan(const rfs_ctx* c, const SwdSeqs& Q, int nchain, int n) {
     CoopPlan P;
     const int nitem = Q.nseq * nchain;
     int npmax = 0;
     for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
-    if (c->swd_lanes != 0 || nitem < 1024 || n < 3 || Q.nseq * npmax > 4096) return P;
-    int shape = c->coop_shape ? c->coop_shape : 81;
-    static const int shapes[4][3] = {{8, 1, 16}, {4, 2, 16}, {8, 2, 8}, {4, 4, 10}};     // NW, LPW, largest NCH
-    const int* sh = nullptr;
-    for (auto& t : shapes) if (t[0] * 10 + t[1] == shape) sh = t;
-    if (!sh) sh = shapes[0];
-    const int nprod = n - 1 - COOP_CL;
-    if (nprod > sh[2] * coop_chunk(sh[0], sh[1])) sh = shapes[0];          // too many layers for that shape
-    if (nprod > sh[2] * coop_chunk(sh[0], sh[1])) return P;
-    P.nw = sh[0]; P.lpw = sh[1];
-    const int cs = coop_chunk(P.nw, P.lpw), ipb = 64 / P.lpw;
-    P.nch = (nprod + cs - 1) / cs;
-    P.lds = coop_lds_bytes(P.nw, P.lpw, Q.nseq, npmax);
-    // blocks per CU: LDS (160 KB) and wave slots (32 per CU)
-    P.per_cu = (int)std::min<size_t>((size_t)160 * 1024 / P.lds, (size_t)32 / P.nw);
-    if (c->coop_per_cu > 0 && P.per_cu > c->coop_per_cu) {
-        // ask for more LDS than needed so that at most coop_per_cu blocks share a CU
-        P.lds = std::max(P.lds, (size_t)160 * 1024 / (c->coop_per_cu + 1) + 1024);
-        P.per_cu = c->coop_per_cu;
-    }
-    if (P.per_cu < 1) return P;
-    P.blocks = (nitem + ipb - 1) / ipb;
+    if (c->swd_lanes != 0 || nitem < 1024 || n < 3 || n - 2 > 16 * COOP_NP || Q.nseq * npmax > 4096) return P;
+    P.nch = (n - 1 - COOP_CL + COOP_NP - 1) / COOP_NP;
+    P.lds = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + 24 * 64 + 2 * Q.nseq * npmax) * sizeof(double);
+    P.blocks = (nitem + 63) / 64;
     P.ok = true;
     return P;
 }
@@ -521,30 +506,20 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         }
         CoopPlan cp = coop_plan(c, Q, nchain, n);
         if (cp.ok) {
-            // cooperative producer/consumer blocks: least total work, shortest serial path
+            // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
             dim3 grid(cp.blocks);
             size_t lds2 = cp.lds;
-#define RFS_LAUNCH_COOP(NW, LPW, NCH)                                                                          \
+#define RFS_LAUNCH_COOP(NCH)                                                                                   \
             do {                                                                                               \
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NW, LPW, NCH>,                     \
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NCH>,                              \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));          \
-                hipLaunchKernelGGL((k_swd_roots_coop<NW, LPW, NCH>), grid, dim3(NW * 64), lds2, s, nchain, n, Q, \
+                hipLaunchKernelGGL(k_swd_roots_coop<NCH>, grid, dim3(512), lds2, s, nchain, n, Q,               \
                                    mdlR, c->mdlc.as<double>(), c->croot.as<double>(),                           \
                                    c->sflag.as<int>());                                                         \
             } while (0)
-#define RFS_COOP_SHAPE(NW, LPW, A, B, C)                                                                       \
-            do {                                                                                               \
-                if (cp.nch <= A) RFS_LAUNCH_COOP(NW, LPW, A);                                                  \
-                else if (cp.nch <= B) RFS_LAUNCH_COOP(NW, LPW, B);                                             \
-                else RFS_LAUNCH_COOP(NW, LPW, C);                                                              \
-            } while (0)
-            switch (cp.nw * 10 + cp.lpw) {
-                case 42: RFS_COOP_SHAPE(4, 2, 5, 8, 16); break;
-                case 82: RFS_COOP_SHAPE(8, 2, 2, 4, 8); break;
-                case 44: RFS_COOP_SHAPE(4, 4, 3, 5, 10); break;
-                default: RFS_COOP_SHAPE(8, 1, 5, 8, 16); break;
-            }
-#undef RFS_COOP_SHAPE
+            if (cp.nch <= 5) RFS_LAUNCH_COOP(5);
+            else if (cp.nch <= 8) RFS_LAUNCH_COOP(8);
+            else RFS_LAUNCH_COOP(16);
 #undef RFS_LAUNCH_COOP
         } else if (G == 1) {
             hipLaunchKernelGGL(k_swd_roots<false>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
@@ -649,45 +624,58 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     bool part = part_possible;
     int early_items = 0;
     StepCalib* cal = nullptr;
-    bool probe = false;
+    bool timed = false;
     if (part_possible) {
         cal = &c->calib[std::make_tuple(nchain, n, c->f.nft, npmax, P.nseq)];
-        if (cal->stage == 1) {          // the probe of the previous call: read its three durations and decide
-            bool ok = true;
-            for (int i = 0; i < 3; i++) {
-                float* dst = i == 0 ? &cal->t_search : (i == 1 ? &cal->t_rf : &cal->t_eigen);
-                ok = ok && hipEventSynchronize(cal->ev[2 * i + 1]) == hipSuccess &&
-                     hipEventElapsedTime(dst, cal->ev[2 * i], cal->ev[2 * i + 1]) == hipSuccess;
+        // harvest the event pairs of earlier timed calls that have completed (never wait: a host that blocks here stops
+        // running ahead of the device, and the launch gaps that then open up would be timed as part of the schedule)
+        while (cal->stage >= 0 && cal->stage < CALIB_DONE && cal->harvested < cal->stage &&
+               hipEventQuery(cal->ev[2 * cal->harvested + 1]) == hipSuccess) {
+            float ms = 0.f;
+            StepCand& k = cal->cand[cal->harvested / 2];
+            if (hipEventElapsedTime(&ms, cal->ev[2 * cal->harvested], cal->ev[2 * cal->harvested + 1]) == hipSuccess &&
+                ms > 0.f && (k.ms == 0.f || ms < k.ms))
+                k.ms = ms;
+            cal->harvested++;
+        }
+        if (cal->stage < 0) {            // first call of the shape: default schedule, untimed; build the candidate list
+            cal->cand.clear();
+            cal->cand.push_back(StepCand{false, 0, 0.f});
+            cal->cand.push_back(StepCand{true, 0, 0.f});
+            if (early_possible) {
+                const int ipr = std::max(1, c->ncu * 8 / (nchain / 64));    // periods per full-chip round of wave slots
+                const int step = std::max(1, std::min(ipr, npmax) / 4);
+                for (int e = step; e < npmax; e += step) cal->cand.push_back(StepCand{true, e, 0.f});
             }
-            if (ok && cal->t_search > 0.f) {
-                cal->part = cal->t_rf <= 1.1f * cal->t_search;
-                cal->early_items = 0;
-                if (cal->part && early_possible && cal->t_eigen > 0.f) {
-                    const double slack = cal->t_search - cal->t_rf;                 // ms, search end - RF end
-                    const double per_period = 2.0 * cal->t_eigen / npmax;           // one period's kernels on half of the chip
-                    const double cap = 1.3 * slack / per_period;                    // periods that fit (some overshoot pays)
-                    const int ipr = std::max(1, c->ncu * 8 / (nchain / 64));        // periods per full-chip round of wave slots
-                    for (int r = 1; npmax - r * ipr > 0; r++)
-                        if (npmax - r * ipr <= cap) { cal->early_items = npmax - r * ipr; break; }
+            for (auto e : cal->ev) hipEventDestroy(e);
+            cal->ev.assign(4 * cal->cand.size(), nullptr);
+            for (auto& e : cal->ev) if (hipEventCreate(&e) != hipSuccess) { cal->cand.clear(); break; }
+            cal->harvested = 0;
+            cal->stage = cal->cand.empty() ? CALIB_DONE : 0;
+        } else if (cal->stage < CALIB_DONE) {
+            const int ntimed = 2 * (int)cal->cand.size();
+            if (cal->stage < ntimed) {                                   // next candidate (each one twice in a row)
+                const StepCand& k = cal->cand[cal->stage / 2];
+                part = k.part; early_items = k.early;
+                timed = true;
+            } else if (cal->harvested >= ntimed) {                       // everything measured: decide
+                int best = 0;
+                for (int i = 1; i < (int)cal->cand.size(); i++)
+                    if (cal->cand[i].ms > 0.f && (cal->cand[best].ms == 0.f || cal->cand[i].ms < cal->cand[best].ms)) best = i;
+                cal->part = cal->cand[best].part; cal->early_items = cal->cand[best].early;
+                cal->stage = CALIB_DONE;
+                if (getenv("RFS_DEBUG_CALIB")) {
+                    fprintf(stderr, "[rfs] schedule of %d chains x %d layers, nft %d:", nchain, n, c->f.nft);
+                    for (auto& k : cal->cand) fprintf(stderr, " (%s,%d) %.3f", k.part ? "split" : "shared", k.early, k.ms);
+                    fprintf(stderr, " ms -> %s, early %d\n", cal->part ? "split" : "shared", cal->early_items);
                 }
-                cal->stage = 2;
-                if (getenv("RFS_DEBUG_CALIB"))
-                    fprintf(stderr, "[rfs] calibration chains %d layers %d nft %d: search %.3f ms, RF %.3f ms, eigen %.3f ms -> partition %d, early periods %d\n",
-                            nchain, n, c->f.nft, cal->t_search, cal->t_rf, cal->t_eigen, (int)cal->part, cal->early_items);
-            } else {
-                cal->stage = 0;
             }
         }
-        if (cal->stage == 0) {
-            probe = true;
-            for (auto& e : cal->ev) if (!e && hipEventCreate(&e) != hipSuccess) probe = false;
-        } else if (cal->stage < 0) {
-            cal->stage = 0;              // warm-up call of this shape: default schedule, no events
-        }
-        if (cal->stage == 2) { part = cal->part; early_items = cal->early_items; }
-        if (early_possible && !probe && c->early_eigen >= 0) early_items = c->early_eigen;       // explicit count (0 = off)
-        if (!part || !early_possible || probe) early_items = 0;
+        if (cal->stage >= CALIB_DONE && !timed) { part = cal->part; early_items = cal->early_items; }
+        if (!timed && early_possible && c->early_eigen >= 0) early_items = c->early_eigen;       // explicit count (0 = off)
+        if (!part || !early_possible) early_items = 0;
         early_items = std::max(0, std::min(early_items, npmax - 1));
+        if (timed) HIPCHK(c, hipEventRecord(cal->ev[2 * cal->stage], user));
     }
     bool rf_reduced = false;
     if (early_items > 0) {
@@ -715,9 +703,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         hipStream_t ss = part ? c->stream2m : c->stream2;
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
-        if (probe) HIPCHK(c, hipEventRecord(cal->ev[0], ss));
         TRY(launch_swd(c, ss, nchain, n, P, !part));
-        if (probe) HIPCHK(c, hipEventRecord(cal->ev[1], ss));
         HIPCHK(c, hipEventRecord(c->ev_join, ss));
     } else if (c->has_swd) {
         TRY(launch_swd(c, user, nchain, n, P, true));
@@ -725,7 +711,6 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     if (c->has_rf) {
         if (part) { HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); c->stream = c->stream3; }
         int rc = RFS_OK;
-        if (probe) HIPCHK(c, hipEventRecord(cal->ev[2], c->stream));
         if (rf_time) {
             { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nchain, n, c->f, true); }
             // model_rf.py:162-196 with method "time": rf and kernels from cal_rf_par_time_all; the gradient
@@ -764,7 +749,6 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                     } }
             }
             rf_reduced = true;
-            if (probe) HIPCHK(c, hipEventRecord(cal->ev[3], c->stream));
             if (!rc && early_items > 0) rc = launch_swd(c, c->stream3, nchain, n, P, true, false, 1, early_items);
         }
         c->stream = user;
@@ -772,11 +756,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
     if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
-    if (part) {                                    // (rest of the) eigenfunction pass, whole chip
-        if (probe) HIPCHK(c, hipEventRecord(cal->ev[4], user));
-        TRY(launch_swd(c, user, nchain, n, P, true, false, early_items > 0 ? 2 : 0));
-        if (probe) { HIPCHK(c, hipEventRecord(cal->ev[5], user)); cal->stage = 1; }
-    }
+    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, early_items > 0 ? 2 : 0));   // (rest of the) eigenfunction pass, whole chip
     {
         KTimer t(c, RFS_K_COMBINE, c->stream);
         const SwdRows& R = P.R;
@@ -796,6 +776,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         }
         HIPCHK(c, hipGetLastError());
     }
+    if (timed) { HIPCHK(c, hipEventRecord(cal->ev[2 * cal->stage + 1], user)); cal->stage++; }
     return RFS_OK;
 }
 
@@ -892,14 +873,7 @@ int rfs_kernel_ms_sum(rfs_ctx* c, double* ms, int32_t* count) {
 
 int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
 
-#ifdef RFS_COOP_PROFILE
-// profiling builds only (scripts/coop_profile.py): cycle accumulators of the cooperative search's consumer waves
-int rfs_debug_coop_profile(rfs_ctx* c, long long* out, int nwords) {
-    HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_prof), (size_t)nwords * sizeof(long long)));
-    return RFS_OK;
-}
-#endif
+
 
 int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!c || !name) return RFS_ERR_ARG;
@@ -911,21 +885,13 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 1) return fail(c, RFS_ERR_ARG, "rf_scratch_budget_mb must be positive");
         c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
     }
-    if (!strcmp(name, "recalibrate")) { for (auto& kv : c->calib) kv.second.stage = 0; return RFS_OK; }
-    if (!strcmp(name, "swd_coop_shape")) {
-        if (value != 0 && value != 81 && value != 42 && value != 82 && value != 44) return fail(c, RFS_ERR_ARG, "swd_coop_shape must be 0, 81, 42, 82 or 44");
-        c->coop_shape = value; for (auto& kv : c->calib) kv.second.stage = 0; return RFS_OK;
-    }
-    if (!strcmp(name, "swd_coop_blocks_per_cu")) {
-        if (value < 0 || value > 8) return fail(c, RFS_ERR_ARG, "swd_coop_blocks_per_cu must be within [0, 8]");
-        c->coop_per_cu = value; for (auto& kv : c->calib) kv.second.stage = 0; return RFS_OK;
-    }
+    if (!strcmp(name, "recalibrate")) { for (auto& kv : c->calib) kv.second.stage = -1; return RFS_OK; }
     if (!strcmp(name, "cu_split")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "cu_split must be 0, 1 or 2");
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipDeviceSynchronize());
         c->cu_split = value;
-        for (auto& kv : c->calib) kv.second.stage = 0;
+        for (auto& kv : c->calib) kv.second.stage = -1;
         return make_partition_streams(c);
     }
     if (!strcmp(name, "early_eigen_periods")) {

@@ -216,21 +216,17 @@ __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ m
 // constants are wave-uniform -> scalar loads) or lane = chain at the last frequency
 // (TAIL=true: n2 = nft/2 + 1 is odd, the Nyquist bin is swept "chain-wide" instead).
 // ---------------------------------------------------------------------------------------
-// One launch covers both: the first ntail = ceil(nchain / blockDim.x) grid rows sweep the Nyquist bin of blockDim.x
-// chains each (only their first column; dispatched first, so they run beside the bulk), the rows after them are the
-// frequency blocks of one chain each -- the small chain-wide part runs inside the big launch instead of as a
-// 0.12 ms kernel of 128 wavefronts behind it.
 template <bool TAIL>
-__device__ __forceinline__ void
-rf_passA_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
-              double* __restrict__ Rs)
+__global__ void __launch_bounds__(256)
+k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
+           double* __restrict__ Rs)
 {
     int chain, k;
     if (TAIL) {
-        chain = blockIdx.y * blockDim.x + threadIdx.x; k = f.n2 - 1;
+        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1;
         if (chain >= nchain) return;
     } else {
-        chain = blockIdx.y - (nchain + blockDim.x - 1) / blockDim.x; k = blockIdx.x * blockDim.x + threadIdx.x;
+        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
         if (k >= f.n2 - 1) return;
     }
     const RfLayer* L = lc + (size_t)chain * n;
@@ -257,15 +253,6 @@ rf_passA_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc
     double* o = RR + (size_t)chain * 4 * n2p + k;
     o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
 }
-__global__ void __launch_bounds__(256)
-k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
-           double* __restrict__ Rs)
-{
-    const int ntail = (nchain + blockDim.x - 1) / blockDim.x;
-    if ((int)blockIdx.y >= ntail) rf_passA_body<false>(nchain, n, f, lc, RR, Rs);
-    else if (blockIdx.x == 0) rf_passA_body<true>(nchain, n, f, lc, RR, Rs);
-}
-
 // ---------------------------------------------------------------------------------------
 // K2 mid 1: per chain -- water level (max over all frequencies, RFModule.f90:396-398,
 // 411-413) and the RF spectrum S = conj(R21) R22 G e^{-i w t0} / fai (:401), with the
@@ -363,18 +350,18 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
 }
 
 template <bool TAIL>
-__device__ __forceinline__ void
-rf_passB_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
-              const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
-              int npart, double* __restrict__ PG)
+__global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
+k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
+           const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
+           int npart, double* __restrict__ PG)
 {
     int chain, k, part;
     bool live = true;
     if (TAIL) {
-        chain = blockIdx.y * blockDim.x + threadIdx.x; k = f.n2 - 1; part = npart - 1;
+        chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1; part = npart - 1;
         if (chain >= nchain) return;
     } else {
-        chain = blockIdx.y - (nchain + blockDim.x - 1) / blockDim.x; k = blockIdx.x * blockDim.x + threadIdx.x;
+        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
         part = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         if (k >= f.n2 - 1) { live = false; k = f.n2 - 2; }
     }
@@ -389,19 +376,13 @@ rf_passB_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc
     double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const int lane = threadIdx.x & 63;
     double* pg = PG + ((size_t)chain * npart + part) * 4 * n;
-    // the row r_{j+1} is fetched a whole layer ahead: at two waves per SIMD nothing else hides the HBM round trip
-    V4 rnext;
-#pragma unroll
-    for (int i = 0; i < 4; i++) rnext.v[i] = (n > 1) ? C(rs[(2 * i) * n2p], rs[(2 * i + 1) * n2p]) : C(0.0);
     for (int j = 0; j < n; j++) {
         cplx T[4];
         if (j < n - 1) {
-            V4 r = rnext;
-            if (j + 1 < n - 1) {
-                const double* o = rs + (size_t)(j + 1) * 8 * n2p;
+            const double* o = rs + (size_t)j * 8 * n2p;
+            V4 r;
 #pragma unroll
-                for (int i = 0; i < 4; i++) rnext.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
-            }
+            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
             RfHyp H; RfA A;
             rf_hyp(L[j], omega, H);
             rf_layer_partials(L[j], H, kk, r, y, T);
@@ -437,17 +418,6 @@ rf_passB_body(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc
         }
     }
 }
-// the first ceil(nchain / blockDim.x) rows: the Nyquist bin of blockDim.x chains each; then the frequency blocks (see k_rf_passA)
-__global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
-k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
-           const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
-           int npart, double* __restrict__ PG)
-{
-    const int ntail = (nchain + blockDim.x - 1) / blockDim.x;
-    if ((int)blockIdx.y >= ntail) rf_passB_body<false>(nchain, n, f, lc, RR, Rs, W, wmax2, npart, PG);
-    else if (blockIdx.x == 0) rf_passB_body<true>(nchain, n, f, lc, RR, Rs, W, wmax2, npart, PG);
-}
-
 // B1 kernel_all: materialise the partial spectra S_{p,j,k} (RFModule.f90:416-419) with one column sweep
 // (the two unit-seed columns for R21_m and R22_m combined up front).  specp: [chain][4][n][n2] complex.
 template <bool TAIL>
@@ -630,25 +600,7 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
     if (writer) sflag[(size_t)seq * nchain + chain] = rs.flag;
 }
 
-// K3 (cooperative): one block of NW waves owns IPB = 64 / LPW (sequence, chain) items.  Wave 0 is the CONSUMER:
-// lane = item, it owns the search state machines and runs the short sequential vector recurrence.
-// Waves 1..NW-1 are PRODUCERS: wave p builds, for all items at once (lane = item + IPB * sub: the wave's lanes
-// cover LPW layers of every item; with LPW = 1 every lane of a wave works on the same layer index), the
-// vector-independent entries of its layers into a double-buffered LDS ring, one chunk of CS = (NW-1)*LPW layers
-// ahead of the consumer.  Nothing is computed twice, and the serial path per secular evaluation shrinks to
-// (one layer's entries) + (the 25-FMA recurrence over all layers).
-//   <8, 1>: 512 threads, 64 items, chunk of 7 layers, 107 KB of LDS -> one block per CU.  A round costs the four
-//           chunk productions (VALU-issue bound) PLUS the consumer's serial phase (last chunk's recurrence + the
-//           state machine), during which the block's seven producer waves idle.
-//   <4, 2>: 256 threads, 32 items, chunk of 6 layers, 46 KB -> TWO blocks per CU: while one block sits in its
-//           serial phase the other block's producers have the SIMDs to themselves -- the hardware interleaves
-//           what an explicit ping-pong of two item groups would schedule by hand, without any cross-group barrier.
 constexpr int COOP_CL = 1;                       // the consumer builds the deepest finite layer itself
-constexpr int coop_chunk(int nw, int lpw) { return (nw - 1) * lpw; }
-inline size_t coop_lds_bytes(int nw, int lpw, int nseq, int npmax) {
-    const int ipb = 64 / lpw;
-    return (size_t)(4 * ipb + 8 + 2 * coop_chunk(nw, lpw) * SWD_NENT * ipb + 24 * ipb + 2 * nseq * npmax) * sizeof(double);
-}
 // periods of a search sequence as tables in LDS: omega_k = 2 pi / T_k and 1 / max(omega_k, 1e-4), divided once per block
 // instead of once per (lane, period) inside the consumer's serial phase
 struct SwdOmegaTab {
@@ -656,64 +608,47 @@ struct SwdOmegaTab {
     __device__ __forceinline__ double operator()(int k) const { return (2.0 * 3.141592653589793) / om[k]; }   // period (unused)
     __device__ __forceinline__ double omega(int k) const { return om[k]; }
 };
-#ifdef RFS_COOP_PROFILE
-__device__ long long g_coop_prof[16 * 1024];     // [block][16]: rounds, request, ..., state-machine stages
-#define COOP_STAMP(v) long long v = clock64()
-#else
-#define COOP_STAMP(v)
+// K3 (cooperative): one 512-thread block = 64 (sequence, chain) items.  Wave 0 is the CONSUMER:
+// lane = item, it owns the search state machines and runs the short sequential vector recurrence.
+// Waves 1..7 are PRODUCERS: wave p builds, for all 64 items at once (lane = item, so every lane of
+// a wave works on the same layer index -> little branch divergence, coalesced constants), the
+// vector-independent entries of one layer per chunk of 7 layers into a double-buffered LDS ring,
+// one chunk ahead of the consumer.  Nothing is computed twice, and the serial path per secular
+// evaluation shrinks to (one layer's entries) + (the 25-FMA recurrence over all layers).
+#ifndef RFS_COOP_NC
+#define RFS_COOP_NC 1
 #endif
-// The consumer's recurrence over the K layers of one chunk (entries of layer i at eb[(i * 15 + q) * IPB]).  Every chunk
-// is full (slots in front of the deepest layer are identity matrices), so this is straight-line code: three rotating
-// register buffers keep the LDS reads of layers i+1 and i+2 in flight while layer i's 25 FMAs issue.
-template <int K, int IPB>
-__device__ __forceinline__ void coop_apply_chunk(double e[5], const double* __restrict__ eb, double tt) {
-    double buf[3][SWD_NENT];
-#pragma unroll
-    for (int q = 0; q < SWD_NENT; q++) buf[0][q] = eb[(size_t)q * IPB];
-    if (K > 1) {
-#pragma unroll
-        for (int q = 0; q < SWD_NENT; q++) buf[1][q] = eb[(size_t)(SWD_NENT + q) * IPB];
-    }
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-        if (i + 2 < K) {
-#pragma unroll
-            for (int q = 0; q < SWD_NENT; q++) buf[(i + 2) % 3][q] = eb[(size_t)((i + 2) * SWD_NENT + q) * IPB];
-        }
-        swd_apply_layer_raw(e, buf[i % 3], tt);
-    }
-    swd_rescale_pow2(e);                             // once per chunk
-}
-
-template <int NW, int LPW, int NCH>              // chunks held in registers: (n-1-COOP_CL) <= NCH*CS
-__global__ void __launch_bounds__(NW * 64)
+constexpr int COOP_NC = RFS_COOP_NC;                // consumer waves (each owns 64/COOP_NC of the block's items)
+constexpr int COOP_NP = 8 - COOP_NC;             // producer waves = layers per chunk
+template <int NCH>                               // chunks held in registers: (n-1-COOP_CL) <= NCH*COOP_NP
+__global__ void __launch_bounds__(512)
 k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                  const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
 {
-    constexpr int IPB = 64 / LPW;                // items per block
-    constexpr int CS = coop_chunk(NW, LPW);      // layers per chunk
     extern __shared__ double lds[];
-    double* req = lds;                           // [4][IPB]: wvno, wvno2, omega, 1/omega
-    int* go = (int*)(lds + 4 * IPB);             // go[0]: the consumer has another evaluation
-    double* ent = lds + 4 * IPB + 8;             // [2][CS][15][IPB]
-    double* nev = ent + 2 * CS * SWD_NENT * IPB; // [24][IPB] Neville tables of the state machines
-    double* tper = nev + 24 * IPB;               // [2][nseq][nper_max]: omega_k = 2 pi / T_k, then 1 / max(omega_k, 1e-4)
+    double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
+    int* go = (int*)(lds + 4 * 64);              // go[w]: consumer w has another evaluation
+    double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][15][64]
+    double* nev = ent + 2 * COOP_NP * SWD_NENT * 64;    // [24][64] Neville tables of the 64 state machines
+    double* tper = nev + 24 * 64;                       // [2][nseq][nper_max]: omega_k = 2 pi / T_k, then 1 / max(omega_k, 1e-4)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bl = lane % IPB, sub = lane / IPB; // block-lane = which of the block's items this thread works on
-    int item = blockIdx.x * IPB + bl;
+    constexpr int IPC = 64 / COOP_NC;            // items per consumer wave
+    // block-lane = which of the block's 64 items this thread works on
+    const int bl = (wave < COOP_NC) ? wave * IPC + (lane % IPC) : lane;
+    int item = blockIdx.x * 64 + bl;
     int seq = item / nchain, chain = item - seq * nchain;
     bool live = seq < Q.nseq;
-    if (wave == 0 && lane >= IPB) live = false;  // upper lanes of the consumer wave idle (LPW > 1)
+    if (wave < COOP_NC && lane >= IPC) live = false;     // upper lanes of a consumer wave idle
     if (seq >= Q.nseq) { seq = 0; chain = 0; }
     const int nprod = n - 1 - COOP_CL;           // layers handled by the producers
-    const int nch = (nprod + CS - 1) / CS;
+    const int nch = (nprod + COOP_NP - 1) / COOP_NP;
     int npmax = 0;
     for (int q = 0; q < Q.nseq; q++) npmax = max(npmax, Q.s[q].nper);
     for (int i = threadIdx.x; i < Q.nseq * npmax; i += blockDim.x) {
         int q = i / npmax, k = i - q * npmax;
-        const double om = (2.0 * 3.141592653589793) / ((k < Q.s[q].nper) ? Q.s[q].t[k] * Q.s[q].scale : 1.0);
-        tper[i] = om;                                                      // RootSearchT::start_period's TWOPI / T(k)
-        tper[Q.nseq * npmax + i] = 1.0 / (om < 1.0e-4 ? 1.0e-4 : om);
+        const double per = (k < Q.s[q].nper) ? Q.s[q].t[k] * Q.s[q].scale : 1.0;
+        const double om = (2.0 * 3.141592653589793) / per;                  // RootSearchT::start_period's TWOPI / T(k)
+        tper[i] = om; tper[Q.nseq * npmax + i] = 1.0 / (om < 1.0e-4 ? 1.0e-4 : om);
     }
     if (threadIdx.x < 8) go[threadIdx.x] = 0;
     __syncthreads();
@@ -723,8 +658,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
-    if (wave == 0) {
-        // the consumer is the block's critical path: static priority lets its dependent chains issue first
+    if (wave < COOP_NC) {
+        // the consumers are the block's critical path: static priority lets their dependent chains issue first
         __builtin_amdgcn_s_setprio(3);
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
@@ -738,24 +673,22 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
             if (live) __hip_atomic_store(&cr[(size_t)k * nchain], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         RootSearchT<NevTabMem> rs;
-        rs.tab.base = nev + bl; rs.tab.stride = IPB;
+        rs.tab.base = nev + bl; rs.tab.stride = 64;
         rs.begin(M, T, sq.nper);
         if (!live) rs.done = 1;
         const SwdLayerC Lhalf = loadL(n - 1), Ldeep = loadL(n - 2);
-#ifdef RFS_COOP_PROFILE
-        long long pr_rounds = 0, pr_prod = 0, pr_apply = 0, pr_sm = 0, pr_req = 0, pr_first = 0;
-        long long tq = clock64();
-#endif
         for (;;) {
             int more = __any(!rs.done);
             double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
-            const double iomega = iom[rs.k < sq.nper ? rs.k : 0];               // 1 / omega from the block's table
             double wvno = rs.omega / rs.creq, wvno2 = wvno * wvno;
-            if (lane < IPB) { req[bl] = wvno; req[IPB + bl] = wvno2; req[2 * IPB + bl] = omega; req[3 * IPB + bl] = iomega; }
-            if (lane == 0) go[0] = more;
+            const double iomega = iom[rs.k < sq.nper ? rs.k : 0];               // 1 / omega from the block's table
+            if (lane < IPC) { req[bl] = wvno; req[64 + bl] = wvno2; req[128 + bl] = omega; req[192 + bl] = iomega; }
+            if (lane == 0) go[wave] = more;
             __syncthreads();                                     // B0
-            if (!go[0]) break;
-            COOP_STAMP(t0);
+            int any_more = 0;
+#pragma unroll
+            for (int w = 0; w < COOP_NC; w++) any_more |= go[w];
+            if (!any_more) break;
             double e[5];
             swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
             const double tt = -2.0 * wvno2;
@@ -764,65 +697,64 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                 swd_layer_entries(Ldeep, wvno, wvno2, omega, iomega, d15);
                 swd_apply_layer_raw(e, d15, tt);
             }
-            COOP_STAMP(t1);
-#ifdef RFS_COOP_PROFILE
-            long long tl = t1;
-#endif
             for (int c = 0; c < nch; c++) {
                 __syncthreads();                                 // chunk c is in buffer c&1
-#ifdef RFS_COOP_PROFILE
-                if (c == nch - 1) tl = clock64();
-#endif
-                coop_apply_chunk<CS, IPB>(e, ent + (size_t)(c & 1) * CS * SWD_NENT * IPB + bl, tt);
+                const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + bl;
+                const int nl = min(COOP_NP, nprod - c * COOP_NP);        // layers in this chunk
+                // software pipeline: the LDS reads of layer i+1 are in flight while layer i's 25 FMAs issue
+                double bufA[SWD_NENT], bufB[SWD_NENT];
+#pragma unroll
+                for (int q = 0; q < SWD_NENT; q++) bufA[q] = eb[(size_t)q * 64];
+#pragma unroll
+                for (int i = 0; i < COOP_NP; i += 2) {
+                    if (i + 1 < nl) {
+#pragma unroll
+                        for (int q = 0; q < SWD_NENT; q++) bufB[q] = eb[(size_t)((i + 1) * SWD_NENT + q) * 64];
+                    }
+                    if (i < nl) swd_apply_layer_raw(e, bufA, tt);
+                    if (i + 2 < nl) {
+#pragma unroll
+                        for (int q = 0; q < SWD_NENT; q++) bufA[q] = eb[(size_t)((i + 2) * SWD_NENT + q) * 64];
+                    }
+                    if (i + 1 < nl) swd_apply_layer_raw(e, bufB, tt);
+                }
+                swd_rescale_pow2(e);                             // once per chunk
             }
-            COOP_STAMP(t2);
             if (!rs.done) rs.advance(swd_finish(e), T, out);
-#ifdef RFS_COOP_PROFILE
-            long long t3 = clock64();
-            pr_rounds++; pr_req += t0 - tq; pr_first += t1 - t0; pr_prod += tl - t0; pr_apply += t2 - tl; pr_sm += t3 - t2;
-            tq = t3;
-#endif
+            if (COOP_NC > 1) __syncthreads();                    // B_end: go[] may be rewritten
         }
-#ifdef RFS_COOP_PROFILE
-        if (lane == 0 && blockIdx.x < 1024) {
-            long long* o = g_coop_prof + blockIdx.x * 16;
-            o[0] = pr_rounds; o[1] = pr_req; o[2] = pr_first; o[3] = pr_prod; o[4] = pr_apply; o[5] = pr_sm;
-            for (int i = 0; i < 6; i++) o[6 + i] = rs.pf[i];
-        }
-#endif
         if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
     } else {
         __builtin_amdgcn_s_setprio(2);           // the search is the step's critical path: outrank co-resident RF waves
-        const int slot = (wave - 1) * LPW + sub; // this lane's layer slot inside a chunk
-        // slot s = c * CS + slot of an evaluation holds layer (n-2-COOP_CL) - (s - pad); the first pad slots (in front of
-        // the deepest layer) are identity matrices so that every chunk is full
-        const int pad = nch * CS - nprod;
+        const int p = wave - COOP_NC;
         SwdLayerC Lmine[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            int m = (n - 2 - COOP_CL) - (c * CS + slot - pad);
-            Lmine[c] = loadL((m >= 0 && m <= n - 2 - COOP_CL) ? m : 0);
+            int m = (n - 2 - COOP_CL) - (c * COOP_NP + p);
+            Lmine[c] = loadL(m >= 0 ? m : 0);
         }
         for (;;) {
             __syncthreads();                                     // B0
-            if (!go[0]) break;
-            double wvno = req[bl], wvno2 = req[IPB + bl], omega = req[2 * IPB + bl], iomega = req[3 * IPB + bl];
+            int any_more = 0;
+#pragma unroll
+            for (int w = 0; w < COOP_NC; w++) any_more |= go[w];
+            if (!any_more) break;
+            double wvno = req[lane], wvno2 = req[64 + lane], omega = req[128 + lane], iomega = req[192 + lane];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 if (c < nch) {
-                    double e15[SWD_NENT];
-                    if (c * CS + slot >= pad) {
+                    int m = (n - 2 - COOP_CL) - (c * COOP_NP + p);
+                    if (m >= 0) {
+                        double e15[SWD_NENT];
                         swd_layer_entries(Lmine[c], wvno, wvno2, omega, iomega, e15);
-                    } else {                                     // identity: e . I = e exactly
+                        double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + (size_t)p * SWD_NENT * 64 + lane;
 #pragma unroll
-                        for (int q = 0; q < SWD_NENT; q++) e15[q] = (q == 0 || q == 6 || q == 14) ? 1.0 : 0.0;
+                        for (int q = 0; q < SWD_NENT; q++) eb[(size_t)q * 64] = e15[q];
                     }
-                    double* eb = ent + (size_t)(c & 1) * CS * SWD_NENT * IPB + (size_t)slot * SWD_NENT * IPB + bl;
-#pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) eb[(size_t)q * IPB] = e15[q];
                     __syncthreads();
                 }
             }
+            if (COOP_NC > 1) __syncthreads();                    // B_end
         }
     }
 }

@@ -385,12 +385,6 @@ struct RootSearchT {
     int nev, m, nctrl;
     Tab tab;
     long nsec;
-#ifdef RFS_COOP_PROFILE
-    long long pf[6] = {0, 0, 0, 0, 0, 0};      // cycles: dispatch, looptop, a1 (Neville), finish + fail, half + scan, new period
-#define RS_STAMP(i) do { long long t_ = clock64(); pf[i] += t_ - tprev_; tprev_ = t_; } while (0)
-#else
-#define RS_STAMP(i)
-#endif
 
     template <class PeriodFn>
     RFS_HD void start_period(const PeriodFn& T) {
@@ -428,9 +422,6 @@ struct RootSearchT {
     template <class PeriodFn, class OutFn>
     RFS_HD void advance(double del, const PeriodFn& T, const OutFn& out) {
         nsec++;
-#ifdef RFS_COOP_PROFILE
-        long long tprev_ = clock64();
-#endif
         // Phase dispatch and the loop head of nevill as PREDICATED updates (selects, no branches): with 64 lanes in a
         // mixture of phases every branch of an if / else chain would be executed anyway, and the structurised control
         // flow cost several times the dozen selects below.  sgn1(a) * sgn1(b) < 0  <=>  the sign bits differ.
@@ -462,8 +453,6 @@ struct RootSearchT {
         half_phase = lt_out ? (int)PH_HALF_OUT : half_phase;
         bool st_finish = lt_fin;
         const bool st_a1 = pHO || (st_looptop && !lt_fin && !lt_out);
-        RS_STAMP(0);
-        RS_STAMP(1);
         if (st_a1) {                                     // nevill :608-681
             const double s13 = del1 - del3, s32 = del3 - del2;
             const bool opp = diffsign(del3, del1);
@@ -515,7 +504,6 @@ struct RootSearchT {
                 }
             }
         }
-        RS_STAMP(2);
         if (st_finish) {                                 // getsol :483-487
             c1 = c3;
             if (c1 > (double)betmx) st_fail = true;
@@ -533,7 +521,6 @@ struct RootSearchT {
                 st_newperiod = true;
             } else { flag = 0; done = 1; }
         }
-        RS_STAMP(3);
         {   // next request of the lanes that stay inside the period: a bisection point or the next scan point
             // (getsol loop 1000, :457-469); predicated, the two cases exclude each other
             const double c2n = (idir > 0) ? c1 + dc : c1 - dc;
@@ -545,9 +532,7 @@ struct RootSearchT {
             creq = st_half ? c3 : (st_scan ? c2 : creq);
             phase = st_half ? half_phase : (st_scan ? (int)PH_SCAN : phase);
         }
-        RS_STAMP(4);
         if (st_newperiod) start_period(T);
-        RS_STAMP(5);
     }
 };
 using RootSearch = RootSearchT<NevTabReg>;
