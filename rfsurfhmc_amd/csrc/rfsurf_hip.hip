@@ -69,6 +69,7 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    int exp_variant = 0;   // A/B experiments (scripts/ab_variants.py)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -235,6 +236,13 @@ int rf_block(const RfFreq& f) {
 }
 int rf_chunks(const RfFreq& f) { int bs = rf_block(f); return (f.n2 - 1 + bs - 1) / bs; }
 int rf_nparts(const RfFreq& f) { return rf_chunks(f) * (rf_block(f) / 64) + 1; }
+// The two sweeps of the fused gradient run best on smaller blocks than the 256 threads of the other frequency-lane
+// kernels (same-box A/B at config 2: pass A 1.718 -> 1.705 ms at 128, pass B 4.28 -> 4.12 ms at 64): a block is one
+// chain's frequencies, and the fewer waves share a block the less a wave waits for its siblings' slots.  The
+// partial-sum layout of pass B (one slot per 64-frequency group + the Nyquist slot) does not depend on the block size.
+int rf_block_of(const RfFreq& f, int want) { int b = rf_block(f); return b > want ? want : b; }
+int rf_chunks_of(const RfFreq& f, int bs) { return (f.n2 - 1 + bs - 1) / bs; }
+int rf_nparts_b(const RfFreq& f) { int bs = rf_block_of(f, 64); return rf_chunks_of(f, bs) * (bs / 64) + 1; }
 
 constexpr int RF_MAX_CHAINS_PER_LAUNCH = 32768;      // the RF sweeps use one grid row per chain (gridDim.y <= 65535)
 
@@ -247,8 +255,9 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.n2p * sizeof(double));
     double* Rs = scratch ? c->Rs.as<double>() : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
-    dim3 grid(rf_chunks(f), nchain);
-    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs);
+    const int bs = rf_block_of(f, 128);
+    dim3 grid(rf_chunks_of(f, bs), nchain);
+    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs);
     hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
                        c->RR.as<double>(), Rs);
     HIPCHK(c, hipGetLastError());
@@ -284,11 +293,12 @@ int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dob
 }
 
 int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0) {
-    int npart = rf_nparts(f);
+    int npart = rf_nparts_b(f);
     ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
-    dim3 grid(rf_chunks(f), nchain);
-    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(rf_block(f)), 0, c->stream, nchain, n, f, lc,
+    const int bs = rf_block_of(f, 64);
+    dim3 grid(rf_chunks_of(f, bs), nchain);
+    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
                        c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
                        c->PG.as<double>());
     hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
@@ -743,7 +753,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                 if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0);
                     if (!rc) {
                         hipLaunchKernelGGL(k_rf_reduce, dim3(nc), dim3(n <= 64 ? 64 : 128), 0, c->stream, nc, n,
-                                           (int)!c->has_swd, rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>() + c0,
+                                           (int)!c->has_swd, rf_nparts_b(c->f), c->PG.as<double>(), c->mrf.as<double>() + c0,
                                            c->cr.as<double>() + (size_t)c0 * 2 * n, misfit + c0, grad + (size_t)c0 * 2 * n,
                                            flag + c0);
                     } }
@@ -886,6 +896,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
     }
     if (!strcmp(name, "recalibrate")) { for (auto& kv : c->calib) kv.second.stage = -1; return RFS_OK; }
+    if (!strcmp(name, "experiment")) { c->exp_variant = value; c->f.exp = value; return RFS_OK; }
     if (!strcmp(name, "cu_split")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "cu_split must be 0, 1 or 2");
         HIPCHK(c, hipSetDevice(c->device));
