@@ -69,7 +69,6 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
-    int exp_variant = 0;   // A/B experiments (scripts/ab_variants.py)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -896,7 +895,6 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
     }
     if (!strcmp(name, "recalibrate")) { for (auto& kv : c->calib) kv.second.stage = -1; return RFS_OK; }
-    if (!strcmp(name, "experiment")) { c->exp_variant = value; c->f.exp = value; return RFS_OK; }
     if (!strcmp(name, "cu_split")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "cu_split must be 0, 1 or 2");
         HIPCHK(c, hipSetDevice(c->device));

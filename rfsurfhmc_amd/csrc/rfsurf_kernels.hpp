@@ -29,7 +29,6 @@ struct RfFreq {             // frequency axis + RF scalars shared by the RF kern
     double dt, sigma, p, f0, t0, water;
     int nft, n2, n2p, nt, rf_type, fwd_order;
     int method, pi64;       // method: RFS_RF_* ; pi64: f64 pi on the frequency axis (cal_rf_par_time_all only)
-    int exp;                // A/B experiments (scripts/ab_variants.py)
 };
 
 __device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
