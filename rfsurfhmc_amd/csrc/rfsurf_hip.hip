@@ -635,7 +635,27 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     StepCalib* cal = nullptr;
     bool timed = false;
     if (part_possible) {
-        cal = &c->calib[std::make_tuple(nchain, n, c->f.nft, npmax, P.nseq)];
+        // One calibration per SHAPE BUCKET: chain counts within 1/8 of an octave share it (length-sorted trajectories
+        // evaluate a slightly different number of chains at every leapfrog step), and at most 32 buckets are ever
+        // calibrated -- a shape beyond that borrows the schedule of the nearest calibrated chain count (or runs the
+        // default: partition, nothing early).
+        int gran = 64;
+        while (gran * 16 <= nchain) gran *= 2;
+        const int bucket = (nchain + gran / 2) / gran * gran;
+        const auto key = std::make_tuple(bucket, n, c->f.nft, npmax, P.nseq);
+        auto it = c->calib.find(key);
+        if (it == c->calib.end() && c->calib.size() >= 32) {
+            const StepCalib* near = nullptr; int dist = 1 << 30;
+            for (auto& kv : c->calib)
+                if (std::get<1>(kv.first) == n && std::get<2>(kv.first) == c->f.nft && std::get<3>(kv.first) == npmax &&
+                    std::get<4>(kv.first) == P.nseq && kv.second.stage >= CALIB_DONE &&
+                    std::abs(std::get<0>(kv.first) - bucket) < dist) { near = &kv.second; dist = std::abs(std::get<0>(kv.first) - bucket); }
+            if (near) { part = near->part; early_items = near->early_items; }
+        } else {
+            cal = &c->calib[key];
+        }
+    }
+    if (cal) {
         // harvest the event pairs of earlier timed calls that have completed (never wait: a host that blocks here stops
         // running ahead of the device, and the launch gaps that then open up would be timed as part of the schedule)
         while (cal->stage >= 0 && cal->stage < CALIB_DONE && cal->harvested < cal->stage &&
@@ -681,6 +701,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
             }
         }
         if (cal->stage >= CALIB_DONE && !timed) { part = cal->part; early_items = cal->early_items; }
+    }
+    if (part_possible) {
         if (!timed && early_possible && c->early_eigen >= 0) early_items = c->early_eigen;       // explicit count (0 = off)
         if (!part || !early_possible) early_items = 0;
         early_items = std::max(0, std::min(early_items, npmax - 1));
