@@ -340,6 +340,7 @@ def run_rank(args):
         # the first evaluations of a new shape -- twice each -- and keeps the fastest (include/rfsurf.h, "recalibrate")
         for _ in range(32):
             joint.flow_step(st)
+        extra["setup_steps"] = 33      # start evaluation + 32 untimed steps during which the library settles on a schedule
         timing_all()
         for _ in range(nwarm - 1):
             joint.flow_step(st)
