@@ -238,3 +238,30 @@ def test_65536_chains_on_one_device_within_the_scratch_budget():
     ref = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[sub])).cuda())]
     for a, b in zip(out, ref):
         assert np.array_equal(a[sub], b)
+
+
+def test_schedule_calibration_never_changes_a_result():
+    """The first evaluations of a new shape run the candidate schedules (shared CUs, CU partition with different numbers
+    of early eigenfunction periods) as ordinary evaluations and the fastest is kept: every one of sixty consecutive
+    evaluations of the same batch -- through the whole calibration and beyond, and again after "recalibrate" -- returns
+    bit-identical misfit, gradient, synthetics and flags."""
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    t = np.linspace(5, 44, bench.NPER)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT, bench.WATER,
+                                                 "P", "freq"), SurfWD(tRc=t))
+    drf, dswd, flag = joint.forward(bench.true_model())
+    joint.set_obsdata(drf, dswd)
+    x = torch.from_numpy(bench.make_models(4096, 11)).cuda()
+    ctx = joint._ensure(bench.N_LAYER)
+    ref = [o.clone() for o in joint.misfit_and_grad_device(x)]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for i in range(60):
+            out = joint.misfit_and_grad_device(x)
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), (rep, i)
+        ctx.check(ctx.L.rfs_set_option(ctx.h, b"recalibrate", 1))
