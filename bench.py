@@ -463,7 +463,9 @@ def run_rank(args):
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": cfg["name"], "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
+        "config": {"workload": cfg["name"] if not (args.config == 1 and world * nchain == 65536) else
+                   "configs[2]: 65536 chains x 30-layer joint RF+SWD, 8xMI355X independent-chain shard, RCCL gather "
+                   "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
                    "step": ("one leapfrog step of every chain via rfs_flow_step (drift + mirror, misfit+gradient, kick)"
                             if cfg["sampler"] is None else
                             "one device step of HMCDualAveraging.sample_flow (host accept/reject + dual averaging "
