@@ -7,7 +7,8 @@
 One process per GPU; every process runs `hmc.nchains` chains (global chain c is what the reference runs as MPI rank
 c: seed + c, main_base.py:16-18,81).  Rank 0 makes the synthetic observed data from `true_model` and broadcasts it
 (main_base.py:49-60), every rank samples, rank 0 gathers the misfits over RCCL and writes `misfit.npy`
-[total_chains, nsamples] and `real_syn.npy` (main_base.py:56,86-93).  Per-rank results: `{name}.rank{r}.npz`."""
+[total_chains, nsamples] and `real_syn.npy` (main_base.py:56,86-93).  Per-rank results: `{name}.rank{r}.h5`
+(`.npz` where no HDF5 library exists); per-chain `{name}.{chain}.h5` as the reference writes them for <= 16 chains."""
 import argparse
 import os
 import sys

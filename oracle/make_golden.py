@@ -217,12 +217,12 @@ class _H5Stub:
             pass
 
 
-def gen_sampler(m_surf, m_rf, m_joint, M):
-    """Reference HamitonianMC / HMCDualAveraging (unmodified pyhmc/*.py) on the param.yaml joint problem,
-    a few iterations, with every random draw and every trajectory result recorded."""
+def _sampler_problem(m_surf, m_rf, m_joint, M, real_h5py=False):
+    """The param.yaml joint problem and the unmodified reference sampler modules (pyhmc/*.py)."""
     import importlib
-    mod = types.ModuleType("h5py"); mod.File = _H5Stub.File
-    sys.modules["h5py"] = mod
+    if not real_h5py:
+        mod = types.ModuleType("h5py"); mod.File = _H5Stub.File
+        sys.modules["h5py"] = mod
     pk = types.ModuleType("pyhmc"); pk.__path__ = [os.path.join(REF, "pyhmc")]
     sys.modules["pyhmc"] = pk
     hmc = importlib.import_module("pyhmc.hmc"); hmcda = importlib.import_module("pyhmc.hmcda")
@@ -239,6 +239,37 @@ def gen_sampler(m_surf, m_rf, m_joint, M):
         bounds[i, 0] = max(vs[i] - vs[i] * 0.8, 1.5); bounds[i, 1] = min(vs[i] + vs[i] * 0.8, 5.0)
         bounds[i + len(thk), 0] = thk[i] - thk[i] * 0.2; bounds[i + len(thk), 1] = thk[i] + thk[i] * 0.2
     bounds[-1, :] = 0.0, 2.0
+    return hmc, hmcda, joint, x0, bounds, t
+
+
+def gen_store_h5(m_surf, m_rf, m_joint, M):
+    """The files the reference samplers write through a REAL h5py (pyhmc/hmc.py:58,203-226,272-275): the same two
+    seeded runs as sampler_hybrid.npz's hmc_r0 / da_r0, under an interpreter that has h5py (here the image's conda
+    python3.9; oracle/_ref/py39/ holds libsurf built for it).  The .h5 files are committed as data fixtures."""
+    import contextlib, io, shutil, tempfile
+    import h5py                                   # the real one, or this function has no business running
+    assert hasattr(h5py, "version"), "gen_store_h5 needs the genuine h5py"
+    hmc, hmcda, joint, x0, bounds, t = _sampler_problem(m_surf, m_rf, m_joint, M, real_h5py=True)
+    out = os.path.join(OUT, "reference_store"); os.makedirs(out, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    ch = hmc.HamitonianMC(joint, bounds, 0.1, [5, 20], 2, 991206, 6, 3, 0, "hmc", tmp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mis = ch.sample()
+    ch.fio.close(); np.save(os.path.join(out, "hmc.misfit.npy"), mis)
+    ch = hmcda.HMCDualAveraging(joint, bounds, 0.1, 10, 2, 0.65, 991206, 6, 3, 0, "da", tmp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mis = ch.sample()
+    ch.fio.close(); np.save(os.path.join(out, "da.misfit.npy"), mis)
+    for f in ("hmc.0.h5", "da.0.h5"):
+        shutil.copy(os.path.join(tmp, f), os.path.join(out, f))
+        print("reference_store/" + f, os.path.getsize(os.path.join(out, f)), "bytes, h5py", h5py.__version__)
+    shutil.rmtree(tmp)
+
+
+def gen_sampler(m_surf, m_rf, m_joint, M):
+    """Reference HamitonianMC / HMCDualAveraging (unmodified pyhmc/*.py) on the param.yaml joint problem,
+    a few iterations, with every random draw and every trajectory result recorded."""
+    hmc, hmcda, joint, x0, bounds, t = _sampler_problem(m_surf, m_rf, m_joint, M)
     g = {"x0": x0, "dobs": joint.dobs, "bounds": bounds, "t": t}
     for tag, rank in (("hmc_r0", 0), ("hmc_r1", 1)):
         ch = hmc.HamitonianMC(joint, bounds, 0.1, [5, 20], 2, 991206, 6, 3, rank, "g", "/tmp")
@@ -362,7 +393,19 @@ def main():
     gen_rf_full(M)
     gen_plugin(m_surf, m_rf, m_joint, M)
     gen_sampler(m_surf, m_rf, m_joint, M)
+    # the result files themselves need a real h5py: run that leg under an interpreter that has one
+    py = os.environ.get("RFS_H5PY_PYTHON", "/opt/conda/bin/python3.9")
+    import subprocess
+    if os.path.exists(py) and subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode == 0:
+        subprocess.check_call([py, os.path.abspath(__file__), "--h5-store"])
+    else:
+        print("no interpreter with h5py: tests/golden/reference_store/ left as it is")
+
+
+def main_h5_store():
+    ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
+    gen_store_h5(m_surf, m_rf, m_joint, models())
 
 
 if __name__ == "__main__":
-    main()
+    main_h5_store() if "--h5-store" in sys.argv else main()

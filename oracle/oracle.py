@@ -478,9 +478,14 @@ def ref_librf_full():
 
 def ref_libsurf():
     """The reference's own pybind11 module ``libsurf`` (complete build of src/SWD)."""
-    d = os.path.join(_HERE, "_ref")
-    name = [f for f in os.listdir(d) if f.startswith("libsurf") and f.endswith(".so")][0]
-    spec = importlib.util.spec_from_file_location("libsurf", os.path.join(d, name))
+    import sysconfig
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")         # _ref/ holds this interpreter's build; _ref/py39/ the
+    d = os.path.join(_HERE, "_ref")                         # one for the conda python3.9 that has a real h5py
+    hits = [os.path.join(r, f) for r in (d, os.path.join(d, "py39")) if os.path.isdir(r)
+            for f in os.listdir(r) if f == "libsurf" + suffix]
+    if not hits:
+        raise ImportError(f"oracle/_ref holds no libsurf{suffix} (make -C oracle ref)")
+    spec = importlib.util.spec_from_file_location("libsurf", hits[0])
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod

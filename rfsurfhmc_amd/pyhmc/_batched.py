@@ -125,61 +125,147 @@ def initial_models(rng: ChainRNG, boundaries):
     return np.stack(xs)
 
 
-def save_chain_results(outdir, name, rank, initmodel, obs, xmean, synmean, x_cache, syndata):
-    """Result store with the reference's HDF5 member names (pyhmc/hmc.py:203-226, 272-275) as keys of
-    one .npz per chain ({name}.{rank}.npz): initmodel, obs, mean/model, mean/syn, model[i], syn[i]."""
+def store_format(fmt="auto"):
+    """"h5" or "npz".  ``auto`` is the reference's HDF5 wherever it can be written (h5py, or libhdf5 through
+    pyhmc/_h5.py) and .npz otherwise; asking for "h5" where it cannot be written raises ImportError."""
+    from . import _h5
+    if fmt in (None, "auto"):
+        return "h5" if _h5.backend() else "npz"
+    if fmt not in ("h5", "npz"):
+        raise ValueError("store format should be auto, h5 or npz")
+    if fmt == "h5" and _h5.backend() is None:
+        _h5.library()                       # raises the ImportError that says where it looked
+    return fmt
+
+
+def save_chain_results(outdir, name, rank, initmodel, obs, xmean, synmean, x_cache, syndata, fmt="npz"):
+    """One chain's results under the reference's member names (pyhmc/hmc.py:203-226, 272-275).
+    ``fmt="h5"``: {name}.{rank}.h5 exactly as the reference lays it out -- datasets initmodel, obs, groups
+    mean/{model,syn} and {i}/{model,syn} for every sample i -- the file src/plot_results.py:106-156 reads.
+    ``fmt="npz"``: {name}.{rank}.npz with keys initmodel, obs, mean/model, mean/syn, model[i], syn[i]."""
     os.makedirs(outdir, exist_ok=True)
+    if fmt == "h5":
+        from . import _h5
+        path = os.path.join(outdir, f"{name}.{rank}.h5")
+        with _h5.open_file(path, "w") as f:
+            f.create_dataset("initmodel", data=np.asarray(initmodel, dtype=np.float64))
+            f.create_dataset("obs", data=np.asarray(obs, dtype=np.float64))
+            groups = [("mean", xmean, synmean)] + [(str(i), x_cache[i], None if syndata is None else syndata[i])
+                                                   for i in range(len(x_cache))]
+            for g, x, syn in groups:
+                f.create_group(g)
+                f.create_dataset(f"{g}/model", data=np.asarray(x, dtype=np.float64))
+                if syn is not None:
+                    f.create_dataset(f"{g}/syn", data=np.asarray(syn, dtype=np.float64))
+        return path
     d = {"initmodel": initmodel, "obs": obs, "mean/model": xmean, "mean/syn": synmean, "model": x_cache}
     if syndata is not None:
         d["syn"] = syndata
-    np.savez(os.path.join(outdir, f"{name}.{rank}.npz"), **d)
+    path = os.path.join(outdir, f"{name}.{rank}.npz")
+    np.savez(path, **d)
+    return path
 
 
-def save_batched_results(outdir, name, rank, first_chain, initmodel, obs, xmean, synmean, x_cache, syndata, misfit):
-    """One file per rank, every chain inside ({name}.rank{rank}.npz): initmodel [nc, nx], obs [nd],
-    mean_model [nc, nx], mean_syn [nc, nd], model [nc, ns, nx], syn [nc, ns, nd] (optional), misfit [nc, ns].
-    The reference writes one HDF5 per MPI rank = per chain (pyhmc/hmc.py:203-226, 272-275); with thousands of
-    chains per GPU that is the wrong granularity -- export_chain() recreates a single chain's file on demand."""
+def load_chain_results(path):
+    """Either per-chain format back as one dict: initmodel, obs, mean/model, mean/syn, model [ns, nx], syn [ns, nd]
+    (syn missing when it was not stored)."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        return {k: z[k] for k in z.files}
+    from . import _h5
+    with _h5.open_file(path, "r") as f:
+        d = {k: f[k][:] for k in ("initmodel", "obs", "mean/model", "mean/syn")}
+        ns = 0
+        while str(ns) in f:
+            ns += 1
+        d["model"] = np.stack([f[f"{i}/model"][:] for i in range(ns)]) if ns else np.zeros((0, len(d["initmodel"])))
+        if ns and f"0/syn" in f:
+            d["syn"] = np.stack([f[f"{i}/syn"][:] for i in range(ns)])
+    return d
+
+
+_BATCHED_KEYS = ("first_chain", "initmodel", "obs", "mean_model", "mean_syn", "model", "syn", "misfit")
+
+
+def save_batched_results(outdir, name, rank, first_chain, initmodel, obs, xmean, synmean, x_cache, syndata, misfit,
+                         fmt="npz"):
+    """One file per rank, every chain inside ({name}.rank{rank}.npz or .h5): first_chain, initmodel [nc, nx],
+    obs [nd], mean_model [nc, nx], mean_syn [nc, nd], model [nc, ns, nx], syn [nc, ns, nd] (optional),
+    misfit [nc, ns].  The reference writes one HDF5 per MPI rank = per chain (pyhmc/hmc.py:203-226, 272-275);
+    with thousands of chains per GPU that is the wrong granularity -- export_chain() recreates a single chain's
+    file on demand.  In the HDF5 form the datasets are contiguous and chain-major, so one chain's samples are one
+    hyperslab (``f["model"][c]``)."""
     os.makedirs(outdir, exist_ok=True)
-    d = {"first_chain": np.array(first_chain), "initmodel": initmodel, "obs": obs, "mean_model": xmean,
+    d = {"first_chain": np.array(first_chain, dtype=np.int64), "initmodel": initmodel, "obs": obs, "mean_model": xmean,
          "mean_syn": synmean, "model": x_cache, "misfit": misfit}
     if syndata is not None:
         d["syn"] = syndata
+    if fmt == "h5":
+        from . import _h5
+        path = os.path.join(outdir, f"{name}.rank{rank}.h5")
+        with _h5.open_file(path, "w") as f:
+            for k, v in d.items():
+                f.create_dataset(k, data=np.asarray(v))
+        return path
     path = os.path.join(outdir, f"{name}.rank{rank}.npz")
     np.savez(path, **d)
     return path
 
 
-def export_chain(batched_path, chain, outdir=None, name=None, fmt="npz"):
-    """Write chain ``chain`` (global chain number = the reference's MPI rank) of a batched result file in the
-    reference's per-rank layout: ``fmt="npz"`` -> {name}.{chain}.npz as save_chain_results writes it;
-    ``fmt="h5"`` -> {name}.{chain}.h5 with initmodel, obs, mean/{model,syn}, {i}/{model,syn}
-    (pyhmc/hmc.py:203-226), which needs h5py (not part of this image: ImportError says so)."""
-    z = np.load(batched_path)
-    c = int(chain) - int(z["first_chain"])
-    if not 0 <= c < z["model"].shape[0]:
-        raise IndexError(f"chain {chain} is not in {batched_path}")
-    outdir = os.path.dirname(batched_path) if outdir is None else outdir
-    name = os.path.basename(batched_path).split(".rank")[0] if name is None else name
-    syn = z["syn"][c] if "syn" in z.files else None
-    if fmt == "npz":
-        save_chain_results(outdir, name, chain, z["initmodel"][c], z["obs"], z["mean_model"][c], z["mean_syn"][c],
-                           z["model"][c], syn)
-        return os.path.join(outdir, f"{name}.{chain}.npz")
-    if fmt != "h5":
-        raise ValueError("fmt should be npz or h5")
-    import h5py
-    path = os.path.join(outdir, f"{name}.{chain}.h5")
-    with h5py.File(path, "w") as f:
-        f.create_dataset("initmodel", data=z["initmodel"][c])
-        f.create_dataset("obs", data=z["obs"])
-        f.create_dataset("mean/model", data=z["mean_model"][c])
-        f.create_dataset("mean/syn", data=z["mean_syn"][c])
-        for i in range(z["model"].shape[1]):
-            f.create_dataset(f"{i}/model", data=z["model"][c, i])
-            if syn is not None:
-                f.create_dataset(f"{i}/syn", data=syn[i])
-    return path
+class _BatchedView:
+    """Read access to a batched result file of either format: ``v[key]`` whole arrays, ``v.chain(key, c)`` one
+    chain's block (a single hyperslab read in the HDF5 form)."""
+
+    def __init__(self, path):
+        self.path = path
+        if path.endswith(".npz"):
+            self._z, self._f = np.load(path), None
+            self.files = list(self._z.files)
+        else:
+            from . import _h5
+            self._z, self._f = None, _h5.open_file(path, "r")
+            self.files = [k for k in _BATCHED_KEYS if k in self._f]
+
+    def __getitem__(self, k):
+        return self._z[k] if self._f is None else self._f[k][()] if self._f[k].shape == () else self._f[k][:]
+
+    def chain(self, k, c):
+        return self._z[k][c] if self._f is None else self._f[k][c]
+
+    def nchain(self):
+        return (self._z["model"] if self._f is None else self._f["model"]).shape[0]
+
+    def close(self):
+        if self._f is not None:
+            self._f.close()
+
+
+def load_batched_results(path):
+    """A batched result file (.npz or .h5) as a dict of arrays."""
+    v = _BatchedView(path)
+    try:
+        return {k: np.asarray(v[k]) for k in v.files}
+    finally:
+        v.close()
+
+
+def export_chain(batched_path, chain, outdir=None, name=None, fmt="auto"):
+    """Write chain ``chain`` (global chain number = the reference's MPI rank) of a batched result file (.npz or
+    .h5) in the reference's per-rank layout, see save_chain_results: ``fmt="h5"`` -> {name}.{chain}.h5,
+    ``fmt="npz"`` -> {name}.{chain}.npz, ``"auto"`` -> HDF5 where it can be written."""
+    fmt = store_format(fmt)
+    z = _BatchedView(batched_path)
+    try:
+        c = int(chain) - int(z["first_chain"])
+        if not 0 <= c < z.nchain():
+            raise IndexError(f"chain {chain} is not in {batched_path}")
+        outdir = os.path.dirname(batched_path) if outdir is None else outdir
+        name = os.path.basename(batched_path).split(".rank")[0] if name is None else name
+        syn = z.chain("syn", c) if "syn" in z.files else None
+        return save_chain_results(outdir, name, chain, z.chain("initmodel", c), z["obs"], z.chain("mean_model", c),
+                                  z.chain("mean_syn", c), z.chain("model", c), syn, fmt=fmt)
+    finally:
+        z.close()
 
 
 def ensemble_inverse_mass(x, clip=(1e-3, 1e3)):

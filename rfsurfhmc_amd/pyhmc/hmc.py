@@ -13,12 +13,14 @@ import numpy as np
 
 from ._batched import (ChainRNG, ensemble_inverse_mass, initial_models, load_checkpoint, run_flow, save_batched_results,
                        save_chain_results, save_checkpoint)
+from ._batched import store_format as resolve_store_format
 
 
 class HamitonianMC:
     def __init__(self, UserDefinedModel, boundaries, dt, Lrange, nbest_model, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
-                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None):
+                 per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None,
+                 store_format="auto"):
         self.myrank = myrank
         self.nchains = int(nchains)
         self.first_chain = myrank * self.nchains
@@ -32,6 +34,9 @@ class HamitonianMC:
         self.ndraws = ndraws
         self.name, self.outdir = name, outdir
         self.store_syn, self.verbose = store_syn, verbose
+        # result files: "h5" = the reference's HDF5 (pyhmc/hmc.py:58,203-226), "npz", or "auto" = HDF5 where h5py or
+        # libhdf5 is present; resolved when the files are written so that a missing library cannot fail a finished run early
+        self.store_format = store_format
         # result files: one per chain with the reference's names (default for a few chains) and / or one
         # batched file per rank (always written when outdir is set); checkpoint: path of a resumable state file
         self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
@@ -57,7 +62,8 @@ class HamitonianMC:
         return cls(UserDefinedModel, boundaries, kargs["dt"], kargs["Lrange"], kargs["nbest"], kargs["seed"],
                    kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
                    nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"),
-                   checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0))
+                   checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0),
+                   store_format=kargs.get("store_format", "auto"))
 
     def _set_inverse_mass(self, minv):
         self.inverse_mass = np.asarray(minv, dtype=np.float64)
@@ -254,14 +260,15 @@ class HamitonianMC:
         synmean = res[2]
         self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
         if self.outdir is not None:
+            fmt = resolve_store_format(self.store_format)
             self.result_file = save_batched_results(self.outdir, self.name, self.myrank, self.first_chain,
                                                     self.initmodel, self.model.dobs, xmean, synmean, x_cache,
-                                                    syndata, misfit)
+                                                    syndata, misfit, fmt=fmt)
             if self.per_chain_files:
                 for c in range(nc):
                     save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c],
                                        self.model.dobs, xmean[c], synmean[c], x_cache[c],
-                                       None if syndata is None else syndata[c])
+                                       None if syndata is None else syndata[c], fmt=fmt)
         return misfit[0] if nc == 1 else misfit
 
     def _save_checkpoint(self, x, U, i, ncount, misfit, x_cache, syndata, ntraj):

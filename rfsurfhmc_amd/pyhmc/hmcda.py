@@ -9,6 +9,7 @@ import numpy as np
 
 from ._batched import (ChainRNG, ensemble_inverse_mass, initial_models, load_checkpoint, run_flow, save_batched_results,
                        save_chain_results, save_checkpoint)
+from ._batched import store_format as resolve_store_format
 
 
 def _mirror(x, p, boundaries):
@@ -28,7 +29,7 @@ class HMCDualAveraging:
     def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
                  per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None,
-                 L_cap=None):
+                 L_cap=None, store_format="auto"):
         self.model = UserDefinedModel
         self.boundaries = np.asarray(boundaries, dtype=np.float64)
         self.dt, self.L = dt, L0
@@ -45,6 +46,9 @@ class HMCDualAveraging:
         self.first_chain = myrank * self.nchains
         self.seed, self.name, self.outdir = seed, name, outdir
         self.store_syn, self.verbose = store_syn, verbose
+        # result files: "h5" = the reference's HDF5 (pyhmc/hmc.py:58,203-226), "npz", or "auto" = HDF5 where h5py or
+        # libhdf5 is present; resolved when the files are written so that a missing library cannot fail a finished run early
+        self.store_format = store_format
         self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
         self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
         # diagonal inverse mass M^-1 (None = the reference's identity): momenta are drawn as 0.5 z sqrt(M), the
@@ -72,7 +76,7 @@ class HMCDualAveraging:
                    kargs["seed"], kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
                    nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"),
                    checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0),
-                   L_cap=kargs.get("L_cap"))
+                   L_cap=kargs.get("L_cap"), store_format=kargs.get("store_format", "auto"))
 
     def _traj_len(self, dt):
         """L = max(1, int(lambda / dt)) per chain (hmcda.py:307), clamped to L_cap before the integer cast."""
@@ -243,14 +247,15 @@ class HMCDualAveraging:
         synmean = self.model.misfit_and_grad(xmean)[2]
         self.x_cache, self.syndata, self.xmean, self.synmean = x_cache, syndata, xmean, synmean
         if self.outdir is not None:
+            fmt = resolve_store_format(self.store_format)
             self.result_file = save_batched_results(self.outdir, self.name, self.myrank, self.first_chain,
                                                     self.initmodel, self.model.dobs, xmean, synmean, x_cache,
-                                                    syndata, misfit)
+                                                    syndata, misfit, fmt=fmt)
             if self.per_chain_files:
                 for c in range(nc):
                     save_chain_results(self.outdir, self.name, self.first_chain + c, self.initmodel[c],
                                        self.model.dobs, xmean[c], synmean[c], x_cache[c],
-                                       None if syndata is None else syndata[c])
+                                       None if syndata is None else syndata[c], fmt=fmt)
         return misfit[0] if nc == 1 else misfit
 
     def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):

@@ -43,7 +43,7 @@ def _sampler(kind, outdir, **kw):
 
 @pytest.mark.parametrize("kind", ["hmc", "hmcda"])
 def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, tmp_path):
-    from rfsurfhmc_amd.pyhmc._batched import export_chain
+    from rfsurfhmc_amd.pyhmc._batched import export_chain, load_batched_results, load_chain_results
     # start models: perturbations of the true model (a prior draw whose root search fails makes the reference -- and the
     # mirror -- stop inside _find_initial_dt, hmcda.py:193-195)
     b = _bounds()
@@ -65,14 +65,14 @@ def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, tmp_path):
     assert np.array_equal(mis, mis_full)
     assert np.array_equal(rest.x_cache, full.x_cache) and np.array_equal(rest.syndata, full.syndata)
     assert np.array_equal(rest.xmean, full.xmean) and np.array_equal(rest.synmean, full.synmean)
-    a, b = np.load(full.result_file), np.load(rest.result_file)
-    assert sorted(a.files) == sorted(b.files)
-    for k in a.files:
+    a, b = load_batched_results(full.result_file), load_batched_results(rest.result_file)   # .h5 where HDF5 exists
+    assert sorted(a) == sorted(b)
+    for k in a:
         assert np.array_equal(a[k], b[k]), k
     # one chain in the reference's per-rank layout
     pa = export_chain(full.result_file, 17, outdir=str(tmp_path / "ea"))
     pb = export_chain(rest.result_file, 17, outdir=str(tmp_path / "eb"))
-    za, zb = np.load(pa), np.load(pb)
-    assert {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"} <= set(za.files)
-    for k in za.files:
+    za, zb = load_chain_results(pa), load_chain_results(pb)
+    assert {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"} <= set(za)
+    for k in za:
         assert np.array_equal(za[k], zb[k]), k

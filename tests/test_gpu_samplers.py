@@ -50,6 +50,44 @@ def test_hmc_reproduces_reference_ranks_0_and_1(golden):
         assert rel(mis[c], g[f"{tag}/misfit"]) < 1e-5
 
 
+def _same_store(mine, ref_path, tol):
+    """Member for member: the product's {name}.{rank}.h5 against the file the reference sampler wrote through h5py
+    (tests/golden/reference_store, see test_h5_store.py)."""
+    from rfsurfhmc_amd.pyhmc import _h5
+    with _h5.open_file(mine, "r") as fm, _h5.open_file(ref_path, "r") as fr:
+        a = {n: np.asarray(d[...]) for n, d in _h5.walk(fm)}
+        b = {n: np.asarray(d[...]) for n, d in _h5.walk(fr)}
+    assert set(a) == set(b) and len(a) == 4 + 2 * 6
+    for n in b:
+        assert a[n].shape == b[n].shape and a[n].dtype == b[n].dtype == np.float64, n
+        assert rel(a[n], b[n]) < tol, (n, rel(a[n], b[n]))
+
+
+@pytest.mark.parametrize("kind", ["hmc", "da"])
+def test_sampler_run_lands_in_the_reference_h5_file(kind, golden, tmp_path):
+    """End to end on the device path: the same seeded run as the reference's rank 0, written in the reference's HDF5
+    layout, equals the file the reference itself wrote (pyhmc/hmc.py:203-226, 272-275): every sample, every synthetic,
+    the mean-of-nbest model and its synthetics."""
+    import os
+    from rfsurfhmc_amd.pyhmc import _h5
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    if _h5.backend() is None:
+        pytest.skip("neither h5py nor libhdf5 on this box")
+    g = golden["sampler_hybrid"]
+    joint = _joint(g)
+    if kind == "hmc":
+        s = HamitonianMC(joint, g["bounds"], 0.1, [5, 20], 2, 991206, 6, 3, myrank=0, name="hmc", outdir=str(tmp_path),
+                         nchains=1, verbose=False, store_format="h5")
+    else:
+        s = HMCDualAveraging(joint, g["bounds"], 0.1, 10, 2, 0.65, 991206, 6, 3, myrank=0, name="da",
+                             outdir=str(tmp_path), nchains=1, verbose=False, store_format="h5")
+    s.sample()
+    assert sorted(os.listdir(tmp_path)) == [f"{kind}.0.h5", f"{kind}.rank0.h5"]
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_store", f"{kind}.0.h5")
+    _same_store(str(tmp_path / f"{kind}.0.h5"), ref, 1e-6)
+
+
 def test_hmcda_reproduces_reference_rank_0(golden):
     from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
     g = golden["sampler_hybrid"]

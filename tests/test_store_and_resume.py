@@ -2,6 +2,7 @@
 reference's member names) and checkpoint / resume.  The model here is a TOY stand-in with the plugin interface
 (dobs, misfit_and_grad, leapfrog_device on CPU tensors) -- it exercises the samplers' bookkeeping, not the HIP path."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -113,38 +114,61 @@ def test_resume_reproduces_an_uninterrupted_run(kind, tmp_path):
     assert rest.finished
     assert np.array_equal(mis, mis_full)
     assert np.array_equal(rest.x_cache, full.x_cache) and np.array_equal(rest.xmean, full.xmean)
-    a = np.load(full.result_file); b = np.load(rest.result_file)
-    for k in a.files:
+    from rfsurfhmc_amd.pyhmc._batched import load_batched_results
+    a = load_batched_results(full.result_file); b = load_batched_results(rest.result_file)
+    assert set(a) == set(b)
+    for k in a:
         assert np.array_equal(a[k], b[k]), k
 
 
-def test_result_store_layouts(tmp_path):
-    from rfsurfhmc_amd.pyhmc._batched import export_chain
-    s = _make("hmc", tmp_path)
+def _formats():
+    from rfsurfhmc_amd.pyhmc import _h5
+    return ["npz", "h5"] if _h5.backend() else ["npz"]
+
+
+@pytest.mark.parametrize("fmt", ["npz", "h5"])
+def test_result_store_layouts(fmt, tmp_path):
+    from rfsurfhmc_amd.pyhmc._batched import export_chain, load_batched_results, load_chain_results
+    if fmt not in _formats():
+        pytest.skip("neither h5py nor libhdf5 here")
+    s = _make("hmc", tmp_path, store_format=fmt)
     mis = s.sample()
-    z = np.load(s.result_file)
-    assert os.path.basename(s.result_file) == "toy.rank1.npz" and int(z["first_chain"]) == 5
+    z = load_batched_results(s.result_file)
+    assert os.path.basename(s.result_file) == f"toy.rank1.{fmt}" and int(z["first_chain"]) == 5
     assert z["model"].shape == (5, 12, 6) and z["syn"].shape == (5, 12, 6) and np.array_equal(z["misfit"], mis)
-    # per-chain files (written by default for a few chains): the reference's HDF5 member names as npz keys
+    # per-chain files (written by default for a few chains): the reference's members
     for c in range(5, 10):
-        f = np.load(tmp_path / f"toy.{c}.npz")
-        assert set(f.files) == {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"}
+        f = load_chain_results(str(tmp_path / f"toy.{c}.{fmt}"))
+        assert set(f) == {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"}
         assert np.array_equal(f["model"], z["model"][c - 5]) and np.array_equal(f["mean/model"], z["mean_model"][c - 5])
-    # exporter recreates one chain's file from the batched one
-    os.remove(tmp_path / "toy.7.npz")
-    p = export_chain(s.result_file, 7)
-    assert np.array_equal(np.load(p)["syn"], z["syn"][2])
+        assert np.array_equal(f["initmodel"], z["initmodel"][c - 5]) and np.array_equal(f["obs"], z["obs"])
+    # exporter recreates one chain's file from the batched one, in either format
+    os.remove(tmp_path / f"toy.7.{fmt}")
+    p = export_chain(s.result_file, 7, fmt=fmt)
+    assert p.endswith(f"toy.7.{fmt}") and np.array_equal(load_chain_results(p)["syn"], z["syn"][2])
+    other = "npz" if fmt == "h5" else _formats()[-1]
+    q = export_chain(s.result_file, 8, outdir=str(tmp_path / "x"), fmt=other)
+    assert np.array_equal(load_chain_results(q)["model"], z["model"][3])
     with pytest.raises(IndexError):
         export_chain(s.result_file, 99)
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            export_chain(s.result_file, 7, fmt="h5")
     # many chains: batched file only
-    big = _make("hmc", tmp_path / "big", per_chain_files=False)
+    big = _make("hmc", tmp_path / "big", per_chain_files=False, store_format=fmt)
     big.sample()
-    assert sorted(os.listdir(tmp_path / "big")) == ["toy.rank1.npz"]
+    assert sorted(os.listdir(tmp_path / "big")) == [f"toy.rank1.{fmt}"]
+
+
+def test_store_format_auto_and_errors(tmp_path, monkeypatch):
+    from rfsurfhmc_amd.pyhmc import _batched, _h5
+    assert _batched.store_format("auto") == _formats()[-1] and _batched.store_format("npz") == "npz"
+    with pytest.raises(ValueError):
+        _batched.store_format("hdf")
+    # no HDF5 at all: auto falls back to npz, an explicit "h5" says what it looked for
+    monkeypatch.setattr(_h5, "_lib", None)
+    monkeypatch.setenv("RFSURF_HDF5_LIB", str(tmp_path / "nowhere.so"))
+    monkeypatch.setitem(sys.modules, "h5py", None)
+    assert _h5.backend() is None and _batched.store_format("auto") == "npz"
+    with pytest.raises(ImportError, match="RFSURF_HDF5_LIB"):
+        _batched.store_format("h5")
 
 
 @pytest.mark.parametrize("kind", ["hmc", "hmcda"])
@@ -161,39 +185,3 @@ def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
     if kind == "hmcda":
         assert np.array_equal(a.dt_final, b.dt_final)
     assert b.flow_steps > 0
-
-
-
-def test_h5_exporter_writes_the_reference_member_names(tmp_path, monkeypatch):
-    """fmt="h5" with a recording stand-in for h5py (not in this image): the members are the ones the reference writes
-    and its plotting script reads -- initmodel, obs, mean/{model,syn}, {i}/{model,syn} (pyhmc/hmc.py:203-226,
-    src/plot_results.py:106-156)."""
-    import sys
-    import types
-    from rfsurfhmc_amd.pyhmc._batched import export_chain
-    written = {}
-
-    class File:
-        def __init__(self, path, mode):
-            assert mode == "w"
-            written["path"] = path
-
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *a):
-            return False
-
-        def create_dataset(self, name, data=None):
-            written[name] = np.array(data)
-
-    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
-    s = _make("hmc", tmp_path)
-    s.sample()
-    z = np.load(s.result_file)
-    p = export_chain(s.result_file, 6, fmt="h5")
-    assert p == written.pop("path") and p.endswith("toy.6.h5")
-    want = {"initmodel", "obs", "mean/model", "mean/syn"} | {f"{i}/{k}" for i in range(12) for k in ("model", "syn")}
-    assert set(written) == want
-    assert np.array_equal(written["3/model"], z["model"][1, 3]) and np.array_equal(written["3/syn"], z["syn"][1, 3])
-    assert np.array_equal(written["mean/model"], z["mean_model"][1]) and np.array_equal(written["obs"], z["obs"])
