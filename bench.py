@@ -219,6 +219,10 @@ def launch(args, argv):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    RFS_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # as torchrun does for its workers: a rank is one GPU's host thread, not an OpenMP team.  With one OpenMP thread
+        # per visible CPU the idle spinners exhaust a cgroup CPU quota and the kernel freezes the rank for the rest of each
+        # 100 ms period (see rfsurfhmc_amd.pyhmc._batched.host_threads)
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else None, text=True if r == 0 else None))
     out0, _ = procs[0].communicate()
