@@ -338,6 +338,17 @@ def host_threads(limit=None):
         torch.set_num_threads(before)
 
 
+def with_host_threads(fn):
+    """Decorator form of host_threads() for the samplers' entry points."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with host_threads():
+            return fn(*a, **k)
+    return wrapped
+
+
 def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max_steps=None, step_hook=None):
     """Drive model.flow_step (rfs_flow_step) until ``active()`` is False.
 

@@ -13,7 +13,7 @@ import numpy as np
 
 from ._batched import (ChainRNG, ensemble_inverse_mass, initial_models, load_checkpoint, run_flow, save_batched_results,
                        save_chain_results, save_checkpoint)
-from ._batched import store_format as resolve_store_format
+from ._batched import store_format as resolve_store_format, with_host_threads
 
 
 class HamitonianMC:
@@ -105,6 +105,7 @@ class HamitonianMC:
                                    Hnew=Hnew, u=u, ok=ok, accept=accept, xres=xres.copy(), Ures=Ures.copy()))
         return xres, Ures, dres, accept
 
+    @with_host_threads
     def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):
         """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
         chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
@@ -184,6 +185,7 @@ class HamitonianMC:
             return misfit[0] if nc == 1 else misfit
         return self._finish(misfit, x_cache, syndata, i, ncount)
 
+    @with_host_threads
     def sample(self, x_init=None, resume=False, max_trajectories=None):
         """pyhmc/hmc.py:228-276.  Returns misfit[nsamples] (nchains == 1) or [nchains, nsamples].
         ``resume``: continue from ``self.checkpoint`` (same results as an uninterrupted run);

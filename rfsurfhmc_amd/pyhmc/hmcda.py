@@ -9,7 +9,7 @@ import numpy as np
 
 from ._batched import (ChainRNG, ensemble_inverse_mass, initial_models, load_checkpoint, run_flow, save_batched_results,
                        save_chain_results, save_checkpoint)
-from ._batched import store_format as resolve_store_format
+from ._batched import store_format as resolve_store_format, with_host_threads
 
 
 def _mirror(x, p, boundaries):
@@ -158,6 +158,7 @@ class HMCDualAveraging:
                                    Hnew=Hnew, alpha=alpha.copy(), ok=ok))
         return xnew, Unew, dnew, alpha
 
+    @with_host_threads
     def sample(self, x_init=None, resume=False, max_trajectories=None):
         """pyhmc/hmcda.py:280-369.  ``resume`` / ``max_trajectories``: see HamitonianMC.sample."""
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
@@ -258,6 +259,7 @@ class HMCDualAveraging:
                                        None if syndata is None else syndata[c], fmt=fmt)
         return misfit[0] if nc == 1 else misfit
 
+    @with_host_threads
     def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):
         """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
         every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))

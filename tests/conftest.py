@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# One OpenMP thread per visible CPU (256 on the GPU boxes) against a 16-CPU cgroup quota gets the whole test process frozen
+# by the CFS throttle for half of every 100 ms; the suite needs no CPU parallelism.
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

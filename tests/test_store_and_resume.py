@@ -185,3 +185,22 @@ def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
     if kind == "hmcda":
         assert np.array_equal(a.dt_final, b.dt_final)
     assert b.flow_steps > 0
+
+
+def test_host_threads_caps_and_restores():
+    """The samplers' host side runs with torch's intra-op pool capped (a cgroup CPU quota below the visible CPU count
+    otherwise throttles the process, see _batched.host_threads) and gives the setting back."""
+    import torch
+    from rfsurfhmc_amd.pyhmc._batched import cpu_quota, host_threads
+    before = torch.get_num_threads()
+    assert 1 <= cpu_quota() <= (os.cpu_count() or 1)
+    with host_threads() as cap:
+        assert cap == max(1, min(before, 4, cpu_quota())) and torch.get_num_threads() == cap
+        with host_threads(1) as inner:
+            assert inner == 1 and torch.get_num_threads() == 1
+        assert torch.get_num_threads() == cap
+    assert torch.get_num_threads() == before
+    s = _make("hmc", None)
+    s.outdir = None
+    s.sample()
+    assert torch.get_num_threads() == before
