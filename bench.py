@@ -375,6 +375,35 @@ def run_rank(args):
             joint.misfit_and_grad_device(xfix)
         ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
         extra["eval_only_ms_per_step"] = (time.perf_counter() - t1) / K * 1e3
+        if rank == 0 and not args.no_sampler_leg:
+            # beside the headline: a REAL HamitonianMC run on the same chains (continuous-flow schedule: momentum draws
+            # from every chain's MT19937 stream, L ~ U{5..20}, accept / reject and restarts on the host beside the
+            # device steps, hmc.py:228-276), K device steps timed behind 25; counts only chains inside a trajectory
+            from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+            smp = HamitonianMC(joint, bounds, 0.002, [5, 20], 10, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
+                               nchains=nchain, verbose=False, store_syn=False)
+            mk = {}
+            act = torch.zeros((), dtype=torch.int64, device=dev)
+            w2 = 25
+
+            def hook2(s, stt):
+                if s == 1:                                   # torch loads these kernels on first use (~30 ms): not in the window
+                    act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum()); act.zero_()
+                if s == w2:
+                    torch.cuda.synchronize(); mk["t0"] = time.perf_counter()
+                if w2 <= s < w2 + K:
+                    act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum())
+                if s == w2 + K:
+                    ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); mk["t1"] = time.perf_counter()
+
+            smp.sample_flow(x_init=xs, max_steps=w2 + K + 1, step_hook=hook2)
+            el2 = mk["t1"] - mk["t0"]
+            extra["sampler_flow"] = {
+                "value": int(act.item()) / el2, "unit": "evals/s", "ms_per_step": el2 / K * 1e3,
+                "chains_in_a_trajectory_per_step": int(act.item()) / K,
+                "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): momentum draws, accept / "
+                        "reject, restarts on the host beside the device steps; a chain that finished a trajectory sits out "
+                        "one device step"}
     else:
         # ---- configs[3]: a real HMCDualAveraging run on the continuous-flow schedule, K device steps timed
         from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
@@ -393,6 +422,7 @@ def run_rank(args):
         def hook(s, st):
             if s == 1:
                 timing_all()
+                active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum()); active.zero_()   # first use loads torch kernels
             if s == nwarm:
                 ms_w, cnt_w = read_ms()
                 marks["warm"] = (ms_w, cnt_w)
@@ -508,6 +538,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--chains", type=int, default=8192, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler-leg", action="store_true", help="skip the extra HamitonianMC.sample_flow figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU; gloo)")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -377,8 +377,8 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         """Host array (at most one row per chain) -> device tensor.  On a GPU the copy goes through preallocated pinned
         staging buffers and is asynchronous: a plain .to(device) of pageable memory is stream-ordered behind the step that
         was just launched AND blocks the host until it has run, which would serialise the host bookkeeping with the GPU
-        step it is meant to overlap.  Four buffers per shape rotate; fetch() synchronises with the device once per
-        step, so a buffer is idle again long before its turn comes round."""
+        step it is meant to overlap.  Four buffers per shape rotate; a buffer's turn comes round an iteration later, after
+        fetch() has waited for the device and apply() for the event behind its previous copies."""
         a = np.ascontiguousarray(a)
         if dev.type != "cuda":
             return torch.from_numpy(a).to(dev)
@@ -392,16 +392,32 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         h.copy_(src)
         return h.to(dev, non_blocking=True)
 
+    # On a GPU with pipeline=True the results of step s are fetched on a side stream WHILE step s+1 runs: step s+1 is
+    # launched first, the side stream waits for the event recorded behind step s and gathers the finished chains' rows
+    # (those chains idle in step s+1, so nothing writes them; the done flags alternate between two buffers because
+    # every step clears its own).  The device then never waits for the host between steps.
+    side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and pipeline) else None
+    dbuf = [st["done"], torch.zeros_like(st["done"])]
+    marks = []                                   # (done buffer, event) of the steps not fetched yet
+
     def fetch():
-        idx = np.nonzero(st["done"].cpu().numpy())[0]
-        if len(idx) == 0:
-            return idx, None
-        sel = t(idx)
-        keys = ["ok", "Hcur", "Hnew", "Unew", "Ucur", "x"] + (["dsyn_new"] if fetch_syn else [])
-        res = {k: st[k].index_select(0, sel).cpu().numpy() for k in keys}
+        done, ev = marks.pop(0)
+        if side is not None:
+            side.wait_event(ev)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            idx = np.nonzero(done.cpu().numpy())[0]
+            if len(idx) == 0:
+                return idx, None
+            sel = t(idx)
+            keys = ["ok", "Hcur", "Hnew", "Unew", "Ucur", "x"] + (["dsyn_new"] if fetch_syn else [])
+            res = {k: st[k].index_select(0, sel).cpu().numpy() for k in keys}
         return idx, res
 
+    applied = []                                 # event behind the previous apply()'s copies out of the pinned buffers
+
     def apply(idx, xkeep, restart):
+        if applied:
+            applied.pop().synchronize()          # long past in practice; makes the reuse of the staging buffers formal
         st["x"].index_copy_(0, t(idx), t(xkeep))
         if restart is not None and len(restart["idx"]):
             rs = t(np.asarray(restart["idx"]))
@@ -411,6 +427,8 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                 st["dt"].index_copy_(0, rs, t(np.asarray(restart["dt"], dtype=np.float64)))
             st["fresh"].index_fill_(0, rs, 1)
             st["ok"].index_fill_(0, rs, 1)
+        if dev.type == "cuda":
+            ev = torch.cuda.Event(); ev.record(); applied.append(ev)
 
     steps = 0
 
@@ -418,14 +436,22 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         nonlocal steps
         if step_hook is not None:
             step_hook(steps, st)
+        st["done"] = dbuf[steps % 2]
         model.flow_step(st); steps += 1
+        ev = None
+        if side is not None:
+            ev = torch.cuda.Event(); ev.record()
+        marks.append((st["done"], ev))
 
     capped = lambda: max_steps is not None and steps >= max_steps
     step()
     while True:
-        idx, res = fetch()                       # synchronises with the step just launched
+        early = side is not None and active() and not capped()
+        if early:
+            step()                               # before the fetch: see above
+        idx, res = fetch()                       # synchronises with the step whose results it takes
         more = (active() or len(idx) > 0) and not capped()
-        if pipeline and more:
+        if pipeline and more and not early:
             step()                               # the finished chains idle in this step (rem = -1, fresh = 0)
         if len(idx):
             xkeep, restart = process_done(idx, res)
