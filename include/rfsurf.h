@@ -181,8 +181,17 @@ int rfs_set_inverse_mass(rfs_ctx* ctx, const double* minv);
 /* -------- introspection ---------------------------------------------------------------- */
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):
- *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic, else a power
- *                          of two <= 64 (1 = the sequential lane-per-chain kernel).
+ *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic (<= 1792 (sequence, chain) items: the
+ *                          latency form of the lanes-per-item kernel -- 64 / 32 / 16 lanes per item, see the next two
+ *                          options; above: cooperative producer / consumer blocks), else a power of two <= 64
+ *                          (1 = the sequential lane-per-chain kernel).
+ *   "swd_segments"         lanes-per-item search only: the sequential vector recurrence of one secular evaluation is cut
+ *                          into 1, 2 or 4 segments that run side by side on the item's lanes (rows of the segments'
+ *                          products, folded afterwards); -1 (default) = 4 where latency is what counts (few items).
+ *                          Same product, different association: roots agree to rounding.
+ *   "swd_speculate"        lanes-per-item search only: 1, 2 or 4 wavefronts per block evaluate the next points of a
+ *                          scan ahead of time; the state machine still consumes them one by one and only where it asks
+ *                          for exactly that point, so results are bit-identical.  -1 (default) = automatic.
  *   "cu_split"             0 = RF kernels on the caller's stream, sharing CUs with the root search;
  *                          1 (default) / 2 = when the cooperative root search fits on half of the CUs, it and
  *                          the RF kernels run on disjoint halves of the CU mask (contiguous halves / even-odd

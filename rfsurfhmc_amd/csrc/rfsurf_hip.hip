@@ -69,6 +69,8 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    int swd_speculate = -1; // wavefronts per block that look ahead in the scan of the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
+    int swd_segments = -1; // segments of the vector recurrence in the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -454,6 +456,10 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
 
 // Launch shape of the cooperative root search (k_swd_roots_coop<NCH>): 512-thread blocks of 64 (sequence, chain) items,
 // one block per CU (107 KB of LDS)
+// Up to this many (sequence, chain) items the device is mostly idle and the root search is a pure latency problem: the
+// lanes-per-item kernel with segmented recurrence and scan look-ahead (k_swd_roots_split) beats the cooperative blocks
+// (measured at 30 layers: 1 item 8.0 -> 3.5 ms, 1024 items 6.8 -> 4.6 ms, level at ~2000 items).
+constexpr int SWD_LAT_MAX_ITEMS = 1792;
 struct CoopPlan { bool ok = false; int nch = 0, blocks = 0, per_cu = 1; size_t lds = 0; };
 
 CoopPlan coop_plan(const rfs_ctx* c, const SwdSeqs& Q, int nchain, int n) {
@@ -461,7 +467,7 @@ CoopPlan coop_plan(const rfs_ctx* c, const SwdSeqs& Q, int nchain, int n) {
     const int nitem = Q.nseq * nchain;
     int npmax = 0;
     for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
-    if (c->swd_lanes != 0 || nitem < 1024 || n < 3 || n - 2 > 16 * COOP_NP || Q.nseq * npmax > 4096) return P;
+    if (c->swd_lanes != 0 || nitem <= SWD_LAT_MAX_ITEMS || n < 3 || n - 2 > 16 * COOP_NP || Q.nseq * npmax > 4096) return P;
     P.nch = (n - 1 - COOP_CL + COOP_NP - 1) / COOP_NP;
     P.lds = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SWD_NENT * 64 + 24 * 64 + 2 * Q.nseq * npmax) * sizeof(double);
     P.blocks = (nitem + 63) / 64;
@@ -505,7 +511,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         int nitem = Q.nseq * nchain;
         int G = c->swd_lanes;
-        if (G <= 0) {           // about one wave per SIMD (1024 of them): G = 65536 / items, within [4, 32]
+        int spec_auto = 1;
+        if (G <= 0 && nitem <= SWD_LAT_MAX_ITEMS) {
+            // latency mode: one item per wavefront while the device has room for it (no two items' state machines diverging
+            // inside a wavefront), then two, then four; 4 / 2 wavefronts per block look ahead in the scan
+            if (nitem <= 256) { G = 64; spec_auto = 4; }
+            else if (nitem <= 1152) { G = 32; spec_auto = 4; }
+            else { G = 16; spec_auto = 2; }
+        } else if (G <= 0) {    // about one wave per SIMD (1024 of them): G = 65536 / items, within [4, 32]
             G = 4;
             while (G < 32 && (size_t)nitem * G * 2 <= 65536 && 2 * G <= n - 1) G *= 2;
         }
@@ -536,14 +549,37 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         } else {
             int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
             dim3 grid((nitem + NG - 1) / NG);
-#define RFS_LAUNCH_SPLIT(LPL)                                                                              \
-            hipLaunchKernelGGL(k_swd_roots_split<LPL>, grid, dim3(64), lds, s, nchain, n, G, Q,             \
+            // few items (the device is mostly idle): cut the vector recurrence into segments that run side by side on the
+            // group's lanes -- 4 segments need 16 lanes, 2 need 6
+            int nseg = c->swd_segments;
+            if (nseg < 0) nseg = (nitem <= SWD_LAT_MAX_ITEMS) ? (G >= 16 && n - 1 >= 8 ? 4 : (G >= 8 && n - 1 >= 4 ? 2 : 1)) : 1;
+            if ((nseg == 4 && G < 16) || (nseg == 2 && G < 8) || (nseg != 2 && nseg != 4)) nseg = 1;
+            // ... and let 4 wavefronts per block look ahead in the scan
+            int spec = c->swd_speculate;
+            if (spec < 0) spec = spec_auto;
+            if (spec != 2 && spec != 4) spec = 1;
+            auto lds_of = [&](int sp) {
+                return (size_t)sp * (lds + (nseg > 1 ? (size_t)(1 + 5 * (nseg - 1)) * 5 * NG * sizeof(double) : 0)) +
+                       (sp > 1 ? (size_t)2 * sp * NG * sizeof(double) : 0);
+            };
+            while (spec > 1 && lds_of(spec) > 60 * 1024) spec /= 2;
+            size_t lds_s = lds_of(spec);
+#define RFS_LAUNCH_SPLIT3(LPL, NSEG, SPEC)                                                                          \
+            hipLaunchKernelGGL((k_swd_roots_split<LPL, NSEG, SPEC>), grid, dim3(64 * SPEC), lds_s, s, nchain, n, G, Q,  \
                                mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>())
+#define RFS_LAUNCH_SPLIT2(LPL, NSEG)                                                                                \
+            do { if (spec == 4) RFS_LAUNCH_SPLIT3(LPL, NSEG, 4); else if (spec == 2) RFS_LAUNCH_SPLIT3(LPL, NSEG, 2);   \
+                 else RFS_LAUNCH_SPLIT3(LPL, NSEG, 1); } while (0)
+#define RFS_LAUNCH_SPLIT(LPL)                                                                                       \
+            do { if (nseg == 4) RFS_LAUNCH_SPLIT2(LPL, 4); else if (nseg == 2) RFS_LAUNCH_SPLIT2(LPL, 2);               \
+                 else RFS_LAUNCH_SPLIT2(LPL, 1); } while (0)
             if (lpl <= 1) RFS_LAUNCH_SPLIT(1);
             else if (lpl <= 2) RFS_LAUNCH_SPLIT(2);
             else if (lpl <= 4) RFS_LAUNCH_SPLIT(4);
             else RFS_LAUNCH_SPLIT(8);
 #undef RFS_LAUNCH_SPLIT
+#undef RFS_LAUNCH_SPLIT2
+#undef RFS_LAUNCH_SPLIT3
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -908,6 +944,14 @@ int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
 
 int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!c || !name) return RFS_ERR_ARG;
+    if (!strcmp(name, "swd_speculate")) {
+        if (value != -1 && value != 1 && value != 2 && value != 4) return fail(c, RFS_ERR_ARG, "swd_speculate must be -1, 1, 2 or 4");
+        c->swd_speculate = value; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_segments")) {
+        if (value != -1 && value != 1 && value != 2 && value != 4) return fail(c, RFS_ERR_ARG, "swd_segments must be -1, 1, 2 or 4");
+        c->swd_segments = value; return RFS_OK;
+    }
     if (!strcmp(name, "swd_lanes_per_chain")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(c, RFS_ERR_ARG, "swd_lanes_per_chain must be 0 or a power of two <= 64");
         c->swd_lanes = value; return RFS_OK;

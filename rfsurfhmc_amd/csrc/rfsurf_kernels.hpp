@@ -533,14 +533,28 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
 // vector recurrence reading the group's entries back (LDS broadcast).  This cuts the serial
 // instruction count per evaluation ~G-fold where it matters (sqrt/sincos/exp live in the
 // layer part) and turns 128 latency-bound waves into 128*G waves.
-template <int LPL>   // layers per lane held in registers: (n-1) <= G*LPL
-__global__ void __launch_bounds__(64)
+// SPEC > 1 (small batches again): the block has SPEC wavefronts that all carry the same items and the same states.
+// While an item steps through its scan (getsol's "move c by dc until the sign changes", surfdisp96.f:457-479) wavefront
+// w evaluates the point the search WOULD ask for w steps ahead (RootSearch::scan_peek), so one round settles up to SPEC
+// scan steps.  The results are then fed to the unchanged state machine in order, each only if the machine's next request
+// is bit for bit the point that was evaluated; anything else (sign change, clamp, limit) discards the rest.  The
+// sequence of (request, Delta) pairs the machine consumes is exactly that of the one-at-a-time search.
+template <int LPL, int NSEG, int SPEC>   // LPL layers per lane in registers: (n-1) <= G*LPL;  NSEG segments;  SPEC wavefronts
+__global__ void __launch_bounds__(64 * SPEC)
 k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__ mdl,
                   const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
 {
-    extern __shared__ double ent_lds[];          // [(m*15 + i)*NG + grp]
-    const int NG = 64 / G;
-    const int lane = threadIdx.x, grp = lane / G, lg = lane - grp * G;
+    extern __shared__ double split_lds[];        // per wavefront: [(m*15 + i)*NG + grp], NSEG > 1: [(chain*5 + j)*NG + grp];
+    const int NG = 64 / G;                       // then SPEC > 1: Delta [SPEC][NG], the points they belong to [SPEC][NG]
+    constexpr int NCHAINS = 1 + 5 * (NSEG - 1);
+    const int sw = SPEC > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const size_t per_wave = (size_t)(n - 1) * SWD_NENT * NG + (NSEG > 1 ? (size_t)NCHAINS * 5 * NG : 0);
+    double* ent_lds = split_lds + (size_t)sw * per_wave;
+    double* seg_lds = ent_lds + (size_t)(n - 1) * SWD_NENT * NG;
+    double* del_lds = split_lds + (size_t)SPEC * per_wave;
+    double* pt_lds = del_lds + SPEC * NG;
+    const int seglen = (n - 1 + NSEG - 1) / NSEG;      // layers per segment (the shallowest one may be shorter)
+    const int lane = threadIdx.x & 63, grp = lane / G, lg = lane - grp * G;
     int item = blockIdx.x * NG + grp;            // (sequence, chain) handled by this group
     int seq = item / nchain, chain = item - seq * nchain;
     bool live = seq < Q.nseq;
@@ -566,10 +580,14 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
     SwdLayerC Lmine[LPL];                        // this lane's layers lg, lg+G, ... stay in registers
 #pragma unroll
     for (int q = 0; q < LPL; q++) { int m = lg + q * G; Lmine[q] = loadL(m < n - 1 ? m : n - 2); }
-    while (__any(!rs.done)) {
+    while (__any(!rs.done)) {                    // (the wavefronts of a block hold identical states: same trip count)
         double omega = rs.omega < 1.0e-4 ? 1.0e-4 : rs.omega;
-        double wvno = rs.omega / rs.creq, wvno2 = wvno * wvno, iomega = 1.0 / omega;
-        if (!rs.done) {
+        double creq = rs.creq;
+        bool act = !rs.done;
+        if (SPEC > 1 && sw > 0) act = act && rs.scan_peek(sw, creq);
+        double wvno = rs.omega / creq, wvno2 = wvno * wvno, iomega = 1.0 / omega;
+        double delta = 0.0;
+        if (act) {
 #pragma unroll
             for (int q = 0; q < LPL; q++) {
                 int m = lg + q * G;
@@ -582,18 +600,80 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
             }
         }
         __syncthreads();
-        if (!rs.done) {
-            double e[5];
-            swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
-            const double tt = -2.0 * wvno2;
-            for (int m = n - 2; m >= 0; m--) {
-                double cur[SWD_NENT];
+        const double tt = -2.0 * wvno2;
+        if constexpr (NSEG == 1) {
+            if (act) {
+                double e[5];
+                swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+                for (int m = n - 2; m >= 0; m--) {
+                    double cur[SWD_NENT];
 #pragma unroll
-                for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp];
-                swd_apply_layer_raw(e, cur, tt);
-                if ((m & 7) == 0) swd_rescale_pow2(e);
+                    for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp];
+                    swd_apply_layer_raw(e, cur, tt);
+                    if ((m & 7) == 0) swd_rescale_pow2(e);
+                }
+                delta = swd_finish(e);
             }
-            rs.advance(swd_finish(e), T, out);
+        } else {
+            // lane lg < NCHAINS runs chain lg: chain 0 = half-space vector through the deepest segment, chain 1 + 5 (s - 1) + i
+            // = unit vector i through segment s (s = 1 .. NSEG - 1, counted from the deepest)
+            if (act && lg < NCHAINS) {
+                const int sg = lg == 0 ? 0 : 1 + (lg - 1) / 5, ui = lg == 0 ? -1 : (lg - 1) % 5;
+                double e[5];
+                if (lg == 0) swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 5; j++) e[j] = (j == ui) ? 1.0 : 0.0;
+                }
+                int mhi = n - 2 - sg * seglen, mlo = mhi - seglen + 1;
+                if (mlo < 0) mlo = 0;
+                for (int m = mhi; m >= mlo; m--) {
+                    double cur[SWD_NENT];
+#pragma unroll
+                    for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp];
+                    swd_apply_layer_raw(e, cur, tt);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; j++) seg_lds[(size_t)(lg * 5 + j) * NG + grp] = e[j];
+            }
+            __syncthreads();
+            if (act) {
+                double e[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) e[j] = seg_lds[(size_t)j * NG + grp];
+                swd_rescale_pow2(e);
+#pragma unroll
+                for (int sg = 1; sg < NSEG; sg++) {
+                    if (n - 2 - sg * seglen < 0) break;                  // fewer layers than segments
+                    double nw[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+#pragma unroll
+                        for (int j = 0; j < 5; j++)
+                            nw[j] += e[i] * seg_lds[(size_t)((1 + 5 * (sg - 1) + i) * 5 + j) * NG + grp];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; j++) e[j] = nw[j];
+                    swd_rescale_pow2(e);
+                }
+                delta = swd_finish(e);
+            }
+        }
+        if constexpr (SPEC == 1) {
+            if (act) rs.advance(delta, T, out);
+        } else {
+            if (lg == 0) { del_lds[sw * NG + grp] = delta; pt_lds[sw * NG + grp] = act ? creq : __longlong_as_double(0x7ff8000000000000LL); }
+            __syncthreads();
+            if (!rs.done) {
+                rs.advance(del_lds[grp], T, out);
+                bool on = true;
+#pragma unroll
+                for (int w = 1; w < SPEC; w++) {
+                    // the machine now asks for rs.creq: use wavefront w's result only if that is the very point it evaluated
+                    on = on && !rs.done && rs.phase == RootSearch::PH_SCAN && pt_lds[w * NG + grp] == rs.creq;
+                    if (on) rs.advance(del_lds[w * NG + grp], T, out);
+                }
+            }
         }
         __syncthreads();
     }

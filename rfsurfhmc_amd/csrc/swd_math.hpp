@@ -415,6 +415,25 @@ struct RootSearchT {
         start_period(T);
     }
 
+    // Where the scan would be j steps from now if no sign change came (the `cont` path of advance() and its next-request
+    // block, repeated): false when the pending request is not a scan point or a limit would end the scan first.  Only
+    // an efficiency device -- a caller evaluates the point ahead of time and offers the result to advance() once the
+    // machine really asks for that very point.
+    RFS_HD bool scan_peek(int j, double& c) const {
+        if (phase != PH_SCAN) return false;
+        double a1 = c1, a2 = c2; int id = idir;
+        for (int i = 0; i < j; i++) {
+            a1 = a2;
+            if (a1 < cm || a1 >= ((double)betmx + dc)) return false;
+            const double c2n = (id > 0) ? a1 + dc : a1 - dc;
+            const bool clamp = c2n <= clow;
+            if (clamp) { id = +1; a1 = clow; }
+            a2 = clamp ? a1 + dc : c2n;
+        }
+        c = a2;
+        return true;
+    }
+
     // consume del = secular(creq) and run until the next request (or completion).
     // Forward-only staging (phase dispatch -> LOOPTOP -> A1 -> FINISH -> FAIL -> SCAN / new period): every
     // transition of getsol / nevill moves forward through these stages, so there is no loop over states and

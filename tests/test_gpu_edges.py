@@ -60,27 +60,69 @@ def test_fft_length_extremes_b1(orc, nt, dt):
     assert rel(librf.forward(*args), orc.librf.forward(*args)) < 1e-9
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64, 0])
-def test_every_root_search_kernel_agrees(orc, lanes):
-    """lane-per-chain, G-lanes-per-chain (LDS) and cooperative kernels return the same roots and flags."""
-    from rfsurfhmc_amd._lib import Context, hptr
-    rng = np.random.default_rng(77)
-    nchain, n = 1100, 12                      # > 1024 sequences so that lanes=0 picks the cooperative kernel
+def _root_search_problem(orc, nchain, n=12, seed=77):
+    rng = np.random.default_rng(seed)
     vs = np.sort(2.0 + 2.6 * rng.random((nchain, n)), axis=1)
     vs[5] = vs[5, ::-1]                       # a velocity-inversion model
     thk = 1.0 + 3 * rng.random((nchain, n)); thk[:, -1] = 0
     vp, rho, _, _ = orc.empirical_relation(vs)
-    t = np.linspace(3, 35, 7)
+    return thk, vp, vs, rho, np.linspace(3, 35, 7)
+
+
+def _roots(nchain, n, model, t, **options):
+    from rfsurfhmc_amd._lib import Context, hptr
     ctx = Context(0, max_chains=4096)
-    ctx.check(ctx.L.rfs_set_option(ctx.h, b"swd_lanes_per_chain", lanes))
+    for k, v in options.items():
+        ctx.check(ctx.L.rfs_set_option(ctx.h, k.encode(), v))
     c = np.zeros((nchain, len(t))); flag = np.zeros(nchain, dtype=np.int32)
-    a = [np.ascontiguousarray(v) for v in (thk, vp, vs, rho)]
+    a = [np.ascontiguousarray(v) for v in model]
     ctx.check(ctx.L.rfs_swd_forward(ctx.h, nchain, n, hptr(a[0]), hptr(a[1]), hptr(a[2]), hptr(a[3]), len(t), hptr(t),
                                     0, 0, 0, hptr(c), hptr(flag)))
+    ctx.close()
+    return c, flag
+
+
+# lanes = 0 is the automatic choice: <= 1792 items the latency form of the lanes-per-item kernel (one / two / four items
+# per wavefront, recurrence in four segments, scan look-ahead), above it the cooperative producer / consumer blocks
+@pytest.mark.parametrize("lanes,nchain", [(1, 1100), (2, 1100), (4, 1100), (8, 1100), (16, 1100), (32, 1100), (64, 1100),
+                                          (0, 2000), (0, 1500), (0, 1100), (0, 200)])
+def test_every_root_search_kernel_agrees(orc, lanes, nchain):
+    """lane-per-chain, G-lanes-per-chain (LDS; plain and latency form) and cooperative kernels return the reference's
+    roots and flags."""
+    n = 12
+    thk, vp, vs, rho, t = _root_search_problem(orc, nchain, n)
+    c, flag = _roots(nchain, n, (thk, vp, vs, rho), t, swd_lanes_per_chain=lanes)
     for i in list(range(0, nchain, 97)) + [5]:
         co, fo = orc.libsurf.forward(thk[i], vp[i], vs[i], rho[i], t, "Rc")
         assert bool(flag[i]) == fo
         assert np.all(np.abs(c[i] - co) <= 1.2e-6 * np.abs(co) + 1e-300), (lanes, i)
+
+
+def test_scan_look_ahead_changes_nothing_and_segments_only_rounding(orc):
+    """Speculation feeds the state machine exactly the (request, Delta) pairs of the one-at-a-time search: bit-identical
+    roots for every chain.  The segmented recurrence is the same product associated differently: roots equal to rounding
+    (a float32-rounded root may land on the neighbouring value once in thousands)."""
+    n, nchain = 12, 900
+    thk, vp, vs, rho, t = _root_search_problem(orc, nchain, n, seed=78)
+    mdl = (thk, vp, vs, rho)
+    base, fb = _roots(nchain, n, mdl, t, swd_lanes_per_chain=32, swd_segments=1, swd_speculate=1)
+    seq, fs = _roots(nchain, n, mdl, t, swd_lanes_per_chain=1)
+    assert np.array_equal(base, seq) and np.array_equal(fb, fs)
+    for spec in (2, 4):
+        for lanes in (16, 64):
+            c, f = _roots(nchain, n, mdl, t, swd_lanes_per_chain=lanes, swd_segments=1, swd_speculate=spec)
+            assert np.array_equal(c, base) and np.array_equal(f, fb), (spec, lanes)
+    for seg, lanes in ((2, 8), (4, 16), (4, 64)):
+        c, f = _roots(nchain, n, mdl, t, swd_lanes_per_chain=lanes, swd_segments=seg, swd_speculate=4)
+        assert np.array_equal(f, fb)
+        ndiff = int((c != base).sum())
+        assert ndiff <= 3 and np.all(np.abs(c - base) <= 1.2e-6 * np.abs(base)), (seg, lanes, ndiff)
+    auto, fa = _roots(nchain, n, mdl, t)
+    assert np.array_equal(fa, fb) and int((auto != base).sum()) <= 3
+    # nothing fancy is accepted silently
+    from rfsurfhmc_amd._lib import Context
+    ctx = Context(0, max_chains=8)
+    assert ctx.L.rfs_set_option(ctx.h, b"swd_speculate", 3) == -1 and ctx.L.rfs_set_option(ctx.h, b"swd_segments", 8) == -1
     ctx.close()
 
 
