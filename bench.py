@@ -224,7 +224,7 @@ def launch(args, argv):
         # 100 ms period (see rfsurfhmc_amd.pyhmc._batched.host_threads)
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None, text=True if r == 0 else None))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
     out0, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
     line = None
@@ -287,12 +287,18 @@ def run_rank(args):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP extension has no CPU fallback")
+    # RFS_BENCH_SHARED_GPU=1: functional check of the N > 1 code path on a box with ONE GPU -- every rank on device 0,
+    # collectives over gloo (RCCL refuses two ranks on one device).  The number it prints is meaningless and says so.
+    shared = os.environ.get("RFS_BENCH_SHARED_GPU") == "1" and world > 1
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if shared else dev    # where the collectives' tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")      # RCCL on ROCm
+        dist.init_process_group(backend="gloo" if shared else "nccl")      # "nccl" is RCCL on ROCm
         assert dist.get_world_size() == args.gpus
 
     from rfsurfhmc_amd._lib import K_NAMES
@@ -452,13 +458,13 @@ def run_rank(args):
 
     total_evals = evals_rank
     if dist is not None:
-        red = torch.tensor([el, float(evals_rank)], dtype=torch.float64, device=dev)
+        red = torch.tensor([el, float(evals_rank)], dtype=torch.float64, device=cdev)
         tmax = red[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = red[1:].clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         el, total_evals = float(tmax.item()), float(tsum.item())
         # the path's only collective: gather the per-chain misfits on rank 0 (after the timed region)
         from rfsurfhmc_amd.chains import gather_misfits
-        gathered = gather_misfits(misfit)
+        gathered = gather_misfits(misfit.to(cdev))
         assert rank != 0 or gathered.shape[0] == nchain * world
     if rank != 0:
         if dist is not None:
@@ -506,7 +512,9 @@ def run_rank(args):
                             if cfg["sampler"] is None else
                             "one device step of HMCDualAveraging.sample_flow (host accept/reject + dual averaging "
                             "overlapped); value counts only chains inside a trajectory"),
-                   "parallelism": f"independent chains x{world}", "root_search_failures": nfail},
+                   "parallelism": f"independent chains x{world}" + (" -- FUNCTIONAL CHECK: all ranks share GPU 0, gloo "
+                                                                    "collectives; not a measurement" if shared else ""),
+                   "root_search_failures": nfail},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": ab * nchain, "avg_launch_ms": dom_ms,
