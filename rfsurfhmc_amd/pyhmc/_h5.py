@@ -164,7 +164,11 @@ class Dataset:
             self._lib.L.H5Dclose(self._id)
             self._id = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # interpreter shutdown: the library may already be gone
+            pass
 
     def _row(self, key):
         """(file space, mem space, shape) of row ``key`` of the first axis, or (0, 0, shape) for everything."""
@@ -299,12 +303,15 @@ class Group:
         return len(self.keys())
 
     def close(self):
-        if self._id is not None and not isinstance(self, File):
+        if self._id is not None:
             self._lib.L.H5Gclose(self._id)
             self._id = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:            # interpreter shutdown: the library may already be gone
+            pass
 
 
 class File(Group):
@@ -338,9 +345,6 @@ class File(Group):
         return self
 
     def __exit__(self, *exc):
-        self.close()
-
-    def __del__(self):
         self.close()
 
 

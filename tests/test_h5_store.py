@@ -140,3 +140,36 @@ def test_binding_surface_used_by_the_reference_writer(tmp_path):
         assert np.array_equal(f["7/model"][:], 2 * x)
     with pytest.raises(OSError):
         h5.File(str(tmp_path / "absent.h5"), "r")
+
+
+def test_the_references_plot_script_runs_on_the_products_files(tmp_path):
+    """plot.py + src/plot_results.py of the reference, unmodified, under the interpreter that has h5py and matplotlib,
+    on an output directory written by the product ({name}.{chain}.h5, misfit.npy, real_syn.npy -- main_base.py:56,93):
+    all six figures come out.  Runs only where /root/reference exists (this container)."""
+    _need_backend()
+    py = _real_h5py()
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "plot.py")):
+        pytest.skip("reference tree not present")
+    if subprocess.run([py, "-c", "import matplotlib, yaml"], capture_output=True).returncode != 0:
+        pytest.skip("no matplotlib / yaml beside h5py")
+    import yaml
+    from rfsurfhmc_amd.pyhmc._batched import load_chain_results, save_chain_results
+    d = load_chain_results(os.path.join(STORE, "hmc.0.h5"))
+    mis = np.load(os.path.join(STORE, "hmc.misfit.npy"))
+    par = yaml.safe_load(open(os.path.join(ref, "param.yaml")))
+    par["hmc"]["OUTPUT_DIR"], par["hmc"]["name"] = "./results/", "mine"
+    yaml.safe_dump(par, open(tmp_path / "param.yaml", "w"))
+    out = str(tmp_path / "results")
+    for c in range(2):                                    # two chains = two of the reference's MPI ranks
+        f = 1 + 0.01 * c
+        save_chain_results(out, "mine", c, d["initmodel"] * f, d["obs"], d["mean/model"] * f, d["mean/syn"],
+                           d["model"] * f, d["syn"], fmt="h5")
+    np.save(os.path.join(out, "misfit.npy"), np.stack([mis, 1.1 * mis]))
+    np.save(os.path.join(out, "real_syn.npy"), d["obs"])
+    r = subprocess.run([py, os.path.join(ref, "plot.py")], cwd=str(tmp_path), capture_output=True, text=True,
+                       env=dict(os.environ, MPLBACKEND="Agg"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    figs = {"best_model.png", "best_syn_fit.png", "best_model_hist.png", "misfit.png", "plot_best_fit_hist.png", "static.png"}
+    assert figs <= set(os.listdir(out)), sorted(os.listdir(out))
+    assert all(os.path.getsize(os.path.join(out, f)) > 10_000 for f in figs)
