@@ -559,7 +559,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             if (spec < 0) spec = spec_auto;
             if (spec != 2 && spec != 4) spec = 1;
             auto lds_of = [&](int sp) {
-                return (size_t)sp * (lds + (nseg > 1 ? (size_t)(1 + 5 * (nseg - 1)) * 5 * NG * sizeof(double) : 0)) +
+                return (size_t)sp * (lds + (size_t)(2 + 5 * (nseg - 1)) * 5 * NG * sizeof(double)) +
                        (sp > 1 ? (size_t)2 * sp * NG * sizeof(double) : 0);
             };
             while (spec > 1 && lds_of(spec) > 60 * 1024) spec /= 2;

@@ -544,17 +544,21 @@ __global__ void __launch_bounds__(64 * SPEC)
 k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__ mdl,
                   const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
 {
-    extern __shared__ double split_lds[];        // per wavefront: [(m*15 + i)*NG + grp], NSEG > 1: [(chain*5 + j)*NG + grp];
+    extern __shared__ double split_lds[];        // per wavefront: entries [grp][m][15], NSEG > 1: rows [grp][chain][5];
     const int NG = 64 / G;                       // then SPEC > 1: Delta [SPEC][NG], the points they belong to [SPEC][NG]
     constexpr int NCHAINS = 1 + 5 * (NSEG - 1);
     const int sw = SPEC > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const size_t per_wave = (size_t)(n - 1) * SWD_NENT * NG + (NSEG > 1 ? (size_t)NCHAINS * 5 * NG : 0);
+    const size_t per_wave = (size_t)(n - 1) * SWD_NENT * NG + (size_t)(NCHAINS + 1) * 5 * NG;   // (+1: the half-space vector)
     double* ent_lds = split_lds + (size_t)sw * per_wave;
     double* seg_lds = ent_lds + (size_t)(n - 1) * SWD_NENT * NG;
     double* del_lds = split_lds + (size_t)SPEC * per_wave;
     double* pt_lds = del_lds + SPEC * NG;
     const int seglen = (n - 1 + NSEG - 1) / NSEG;      // layers per segment (the shallowest one may be shorter)
     const int lane = threadIdx.x & 63, grp = lane / G, lg = lane - grp * G;
+    // a group's numbers are contiguous, so that every read below is one base register + an immediate offset
+    double* const ent_g = ent_lds + (size_t)grp * (n - 1) * SWD_NENT;
+    double* const seg_g = seg_lds + (size_t)grp * (NCHAINS + 1) * 5;
+    double* const hs_g = seg_g + NCHAINS * 5;   // half-space start vector, built beside the layer entries by the group's last lane
     int item = blockIdx.x * NG + grp;            // (sequence, chain) handled by this group
     int seq = item / nchain, chain = item - seq * nchain;
     bool live = seq < Q.nseq;
@@ -595,8 +599,14 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
                     double ent[SWD_NENT];
                     swd_layer_entries(Lmine[q], wvno, wvno2, omega, iomega, ent);
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp] = ent[i];
+                    for (int i = 0; i < SWD_NENT; i++) ent_g[m * SWD_NENT + i] = ent[i];
                 }
+            }
+            if (lg == G - 1) {               // the lane with the fewest layers (none when G > n - 1)
+                double e[5];
+                swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+#pragma unroll
+                for (int j = 0; j < 5; j++) hs_g[j] = e[j];
             }
         }
         __syncthreads();
@@ -604,11 +614,13 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
         if constexpr (NSEG == 1) {
             if (act) {
                 double e[5];
-                swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
-                for (int m = n - 2; m >= 0; m--) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) e[j] = hs_g[j];
+                const double* pe = ent_g + (size_t)(n - 2) * SWD_NENT;
+                for (int m = n - 2; m >= 0; m--, pe -= SWD_NENT) {
                     double cur[SWD_NENT];
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp];
+                    for (int i = 0; i < SWD_NENT; i++) cur[i] = pe[i];
                     swd_apply_layer_raw(e, cur, tt);
                     if ((m & 7) == 0) swd_rescale_pow2(e);
                 }
@@ -620,27 +632,34 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
             if (act && lg < NCHAINS) {
                 const int sg = lg == 0 ? 0 : 1 + (lg - 1) / 5, ui = lg == 0 ? -1 : (lg - 1) % 5;
                 double e[5];
-                if (lg == 0) swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
-                else {
 #pragma unroll
-                    for (int j = 0; j < 5; j++) e[j] = (j == ui) ? 1.0 : 0.0;
-                }
+                for (int j = 0; j < 5; j++) e[j] = lg == 0 ? hs_g[j] : ((j == ui) ? 1.0 : 0.0);
                 int mhi = n - 2 - sg * seglen, mlo = mhi - seglen + 1;
                 if (mlo < 0) mlo = 0;
-                for (int m = mhi; m >= mlo; m--) {
-                    double cur[SWD_NENT];
+                // two layers per trip, the next layer's entries on their way while this one is applied (the LDS round trip
+                // is as long as the 25 FMAs); reading one layer past the segment's end is harmless (clamped to layer 0)
+                const double* pe = ent_g + (size_t)mhi * SWD_NENT;
+                double ca[SWD_NENT], cb[SWD_NENT];
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) cur[i] = ent_lds[(size_t)(m * SWD_NENT + i) * NG + grp];
-                    swd_apply_layer_raw(e, cur, tt);
+                for (int i = 0; i < SWD_NENT; i++) ca[i] = pe[i];
+                for (int m = mhi; m >= mlo; m -= 2) {
+                    const double* pb = pe - (m - 1 >= 0 ? SWD_NENT : 0);
+#pragma unroll
+                    for (int i = 0; i < SWD_NENT; i++) cb[i] = pb[i];
+                    swd_apply_layer_raw(e, ca, tt);
+                    pe = pb - (m - 2 >= 0 ? SWD_NENT : 0);
+#pragma unroll
+                    for (int i = 0; i < SWD_NENT; i++) ca[i] = pe[i];
+                    if (m - 1 >= mlo) swd_apply_layer_raw(e, cb, tt);
                 }
 #pragma unroll
-                for (int j = 0; j < 5; j++) seg_lds[(size_t)(lg * 5 + j) * NG + grp] = e[j];
+                for (int j = 0; j < 5; j++) seg_g[lg * 5 + j] = e[j];
             }
             __syncthreads();
             if (act) {
                 double e[5];
 #pragma unroll
-                for (int j = 0; j < 5; j++) e[j] = seg_lds[(size_t)j * NG + grp];
+                for (int j = 0; j < 5; j++) e[j] = seg_g[j];
                 swd_rescale_pow2(e);
 #pragma unroll
                 for (int sg = 1; sg < NSEG; sg++) {
@@ -650,11 +669,11 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
                     for (int i = 0; i < 5; i++) {
 #pragma unroll
                         for (int j = 0; j < 5; j++)
-                            nw[j] += e[i] * seg_lds[(size_t)((1 + 5 * (sg - 1) + i) * 5 + j) * NG + grp];
+                            nw[j] += e[i] * seg_g[(1 + 5 * (sg - 1) + i) * 5 + j];
                     }
 #pragma unroll
                     for (int j = 0; j < 5; j++) e[j] = nw[j];
-                    swd_rescale_pow2(e);
+                    if (sg & 1) swd_rescale_pow2(e);         // the range is safe for two segments at a time
                 }
                 delta = swd_finish(e);
             }
