@@ -181,7 +181,7 @@ int rfs_set_inverse_mass(rfs_ctx* ctx, const double* minv);
 /* -------- introspection ---------------------------------------------------------------- */
 int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the current joint setup */
 /* Tuning knobs (no effect on results beyond last-bit rounding):
- *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic (<= 1792 (sequence, chain) items: the
+ *   "swd_lanes_per_chain"  lanes that share one chain's root search: 0 = automatic (<= 3072 (sequence, chain) items: the
  *                          latency form of the lanes-per-item kernel -- 64 / 32 / 16 lanes per item, see the next two
  *                          options; above: cooperative producer / consumer blocks), else a power of two <= 64
  *                          (1 = the sequential lane-per-chain kernel).

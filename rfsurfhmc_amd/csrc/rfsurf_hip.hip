@@ -458,8 +458,8 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
 // one block per CU (107 KB of LDS)
 // Up to this many (sequence, chain) items the device is mostly idle and the root search is a pure latency problem: the
 // lanes-per-item kernel with segmented recurrence and scan look-ahead (k_swd_roots_split) beats the cooperative blocks
-// (measured at 30 layers: 1 item 8.0 -> 3.5 ms, 1024 items 6.8 -> 4.6 ms, level at ~2000 items).
-constexpr int SWD_LAT_MAX_ITEMS = 1792;
+// (measured at 30 layers: 1 item 8.0 -> 3.0 ms, 1024 items 6.8 -> 4.3 ms, 3072 items 7.0 -> 6.2 ms, level at ~3500 items).
+constexpr int SWD_LAT_MAX_ITEMS = 3072;
 struct CoopPlan { bool ok = false; int nch = 0, blocks = 0, per_cu = 1; size_t lds = 0; };
 
 CoopPlan coop_plan(const rfs_ctx* c, const SwdSeqs& Q, int nchain, int n) {

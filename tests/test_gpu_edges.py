@@ -82,10 +82,10 @@ def _roots(nchain, n, model, t, **options):
     return c, flag
 
 
-# lanes = 0 is the automatic choice: <= 1792 items the latency form of the lanes-per-item kernel (one / two / four items
+# lanes = 0 is the automatic choice: <= 3072 items the latency form of the lanes-per-item kernel (one / two / four items
 # per wavefront, recurrence in four segments, scan look-ahead), above it the cooperative producer / consumer blocks
 @pytest.mark.parametrize("lanes,nchain", [(1, 1100), (2, 1100), (4, 1100), (8, 1100), (16, 1100), (32, 1100), (64, 1100),
-                                          (0, 2000), (0, 1500), (0, 1100), (0, 200)])
+                                          (0, 3500), (0, 1500), (0, 1100), (0, 200)])
 def test_every_root_search_kernel_agrees(orc, lanes, nchain):
     """lane-per-chain, G-lanes-per-chain (LDS; plain and latency form) and cooperative kernels return the reference's
     roots and flags."""
