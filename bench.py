@@ -382,9 +382,9 @@ def run_rank(args):
         ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
         extra["eval_only_ms_per_step"] = (time.perf_counter() - t1) / K * 1e3
         if rank == 0 and not args.no_sampler_leg:
-            # beside the headline: a REAL HamitonianMC run on the same chains (continuous-flow schedule: momentum draws
-            # from every chain's MT19937 stream, L ~ U{5..20}, accept / reject and restarts on the host beside the
-            # device steps, hmc.py:228-276), K device steps timed behind 25; counts only chains inside a trajectory
+            # beside the headline: a REAL HamitonianMC run on the same chains (continuous-flow schedule: draws from every
+            # chain's MT19937 stream, L ~ U{5..20}, accept / reject and restarts, hmc.py:228-276), K device steps timed
+            # behind 25; counts only chains inside a trajectory
             from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
             smp = HamitonianMC(joint, bounds, 0.002, [5, 20], 10, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
                                nchains=nchain, verbose=False, store_syn=False)
@@ -407,9 +407,10 @@ def run_rank(args):
             extra["sampler_flow"] = {
                 "value": int(act.item()) / el2, "unit": "evals/s", "ms_per_step": el2 / K * 1e3,
                 "chains_in_a_trajectory_per_step": int(act.item()) / K,
-                "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): momentum draws, accept / "
-                        "reject, restarts on the host beside the device steps; a chain that finished a trajectory sits out "
-                        "one device step"}
+                "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): every chain's acceptance draw, "
+                        "next L and momentum come from its own MT19937 stream on the host, ahead of time; the device accepts / "
+                        "rejects and starts the next trajectory itself (rfs_flow_step2); books and samples are kept on the "
+                        "host beside the device steps"}
     else:
         # ---- configs[3]: a real HMCDualAveraging run on the continuous-flow schedule, K device steps timed
         from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging

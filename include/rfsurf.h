@@ -173,6 +173,32 @@ int rfs_flow_step(rfs_ctx* ctx, int nchain, double* x, double* p, const double* 
                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                   double* dsyn_new, int32_t* ok, int32_t* done);
 
+/* rfs_flow_step with restarts on the device.  The reference's chain, after a trajectory (pyhmc/hmc.py:192-198, 246-258):
+ * draws u ~ U(0,1), accepts the end point if u < exp(-(Hnew - Hcur)), draws the next L and momentum, starts over.  None of
+ * those draws depends on the trajectory, so a caller can make them AHEAD of time and deposit them here (have[chain] = 1
+ * before the call in which the chain's rem reaches 0).  The device then does the accept / reject itself -- x[chain] stays at
+ * the end model or goes back to xstart[chain], the model the trajectory started from, which the calls maintain -- takes the
+ * next momentum and length, sets fresh = 1 and reports done[chain] = 2 (rejected) or 3 (accepted): the chain evaluates its
+ * new start model in the very next call instead of sitting one out while the host catches up.  What the host still needs
+ * for its books is parked where the next trajectory does not touch it: res_x (end model), res_val = {Ucur, Hcur, Hnew, Unew},
+ * res_dsyn (synthetics at the end model; may be NULL).  have[chain] is cleared when consumed.  A chain without a deposit,
+ * or one that fails (ok = 0), behaves exactly as in rfs_flow_step (done = 1, the host restarts it) -- and keeps its deposit,
+ * which the host has to withdraw (have = 0).  next == NULL: rfs_flow_step.  The struct lives on the HOST, every pointer in
+ * it is a DEVICE pointer. */
+typedef struct rfs_flow_next {
+    int32_t* have;        /* [nchain] */
+    const double* u;      /* [nchain] acceptance draw */
+    const double* p;      /* [nchain][2*nlayer] momentum of the next trajectory */
+    const int32_t* rem;   /* [nchain] its number of leapfrog steps */
+    double* xstart;       /* [nchain][2*nlayer] */
+    double* res_x;        /* [nchain][2*nlayer] */
+    double* res_val;      /* [nchain][4] */
+    double* res_dsyn;     /* [nchain][ndata] or NULL */
+} rfs_flow_next;
+int rfs_flow_step2(rfs_ctx* ctx, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                   double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next);
+
 /* Diagonal inverse mass matrix of the leapfrog entries above (rfs_leapfrog_dev / dev2, rfs_flow_step): drift
  * x += dt * minv * p, kinetic energy p.minv.p / 2; the caller draws p ~ N(0, M).  minv: HOST [2*nlayer], NULL =
  * identity (the reference's `invert_Mass`, pyhmc/hmc.py:48).  Reset by rfs_joint_setup. */

@@ -28,6 +28,10 @@ class SwdParams(ctypes.Structure):
                 ("sphere", ctypes.c_int32), ("mode", ctypes.c_int32)]
 
 
+class FlowNext(ctypes.Structure):      # rfs_flow_next (include/rfsurf.h): device pointers
+    _fields_ = [(k, ctypes.c_void_p) for k in ("have", "u", "p", "rem", "xstart", "res_x", "res_val", "res_dsyn")]
+
+
 class RfsError(RuntimeError):
     pass
 
@@ -54,6 +58,7 @@ SIGNATURES = {
     "rfs_leapfrog_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp] + [_vp] * 8),
     "rfs_leapfrog_dev2": (_i, [_vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp] + [_vp] * 8),
     "rfs_flow_step": (_i, [_vp, _i] + [_vp] * 14),
+    "rfs_flow_step2": (_i, [_vp, _i] + [_vp] * 14 + [ctypes.POINTER(FlowNext)]),
     "rfs_set_inverse_mass": (_i, [_vp, _vp]),
     "rfs_ndata": (_i, [_vp]),
     "rfs_set_option": (_i, [_vp, ctypes.c_char_p, _i]),

@@ -1310,14 +1310,20 @@ int rfs_set_inverse_mass(rfs_ctx* c, const double* minv) {
     return RFS_OK;
 }
 
-int rfs_flow_step(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
-                  const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
-                  double* dsyn_new, int32_t* ok, int32_t* done) {
+int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                   double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next) {
     if (!c) return RFS_ERR_ARG;
     if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
     TRY(check_batch(c, nchain, c->n));
     if (!x || !p || !dt || !rem || !fresh || !bounds || !Ucur || !Hcur || !Unew || !Hnew || !dsyn_cur || !dsyn_new || !ok || !done)
         return fail(c, RFS_ERR_ARG, "null argument");
+    FlowNext fn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (next) {
+        if (!next->have || !next->u || !next->p || !next->rem || !next->xstart || !next->res_x || !next->res_val)
+            return fail(c, RFS_ERR_ARG, "rfs_flow_next: only res_dsyn may be null");
+        fn = FlowNext{next->have, next->u, next->p, next->rem, next->xstart, next->res_x, next->res_val, next->res_dsyn};
+    }
     const int n = c->n, nx = 2 * n, nd = c->ndata;
     ENSURE(c, c->lU, (size_t)nchain * sizeof(double)); ENSURE(c, c->lgrad, (size_t)nchain * nx * sizeof(double));
     ENSURE(c, c->ldsyn, (size_t)nchain * nd * sizeof(double)); ENSURE(c, c->lflag, (size_t)nchain * sizeof(int));
@@ -1328,9 +1334,15 @@ int rfs_flow_step(rfs_ctx* c, int nchain, double* x, double* p, const double* dt
     hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p);
     TRY(joint_eval(c, nchain, x, U, g, d, fl));
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
-                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done);
+                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
+}
+
+int rfs_flow_step(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                  const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                  double* dsyn_new, int32_t* ok, int32_t* done) {
+    return rfs_flow_step2(c, nchain, x, p, dt, rem, fresh, bounds, Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, nullptr);
 }
 
 int rfs_leapfrog_dev(rfs_ctx* c, int nchain, const double* x0, const double* p0, const double* dt, const int32_t* L,

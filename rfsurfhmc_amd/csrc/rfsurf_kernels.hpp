@@ -1318,13 +1318,19 @@ __global__ void k_flow_pre(int nchain, int nx, const double* minv, const double*
     x[g] = xv; p[g] = pv;
 }
 
-__global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, const double* x, const double* U,
+// Device-side restart of a completed trajectory (rfs_flow_next, include/rfsurf.h): all pointers device, have == nullptr = off
+struct FlowNext {
+    int* have; const double* u; const double* p; const int* rem;
+    double* xstart; double* res_x; double* res_val; double* res_dsyn;
+};
+__global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, const double* U,
                             const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
                             double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
-                            double* dsyn_new, int* ok, int* done)
+                            double* dsyn_new, int* ok, int* done, FlowNext nx_)
 {
     __shared__ double red[4];
     __shared__ int bad;
+    __shared__ int acc_s;
     const int chain = blockIdx.x, tid = threadIdx.x;
     const int fr = fresh[chain], rm = rem[chain];
     if (tid == 0) done[chain] = 0;
@@ -1354,6 +1360,8 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
             double d = dsyn[(size_t)chain * ndata + i];
             dsyn_cur[(size_t)chain * ndata + i] = d; dsyn_new[(size_t)chain * ndata + i] = d;
         }
+        if (nx_.have)                                           // the model this trajectory starts from (kept for a rejection)
+            for (int i = tid; i < nx; i += blockDim.x) nx_.xstart[(size_t)chain * nx + i] = x[(size_t)chain * nx + i];
         k = wave_sum(k);
         if ((tid & 63) == 0) red[tid >> 6] = k;
         __syncthreads();
@@ -1382,16 +1390,40 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
     k = wave_sum(k);
     if ((tid & 63) == 0) red[tid >> 6] = k;
     __syncthreads();
+    const bool auto_next = last && nx_.have && nx_.have[chain];   // block-uniform
     if (tid == 0) {
         if (last) {
             double s = 0.0;
             for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+            const double hn = 0.5 * s + U[chain];
             Unew[chain] = U[chain];
-            Hnew[chain] = 0.5 * s + U[chain];
-            rem[chain] = -1; done[chain] = 1;
+            Hnew[chain] = hn;
+            if (auto_next) {                                    // hmc.py:192-198 on the device, with the caller's draw
+                const int acc = nx_.u[chain] < exp(-(hn - Hcur[chain]));
+                acc_s = acc;
+                double* rv = nx_.res_val + (size_t)chain * 4;
+                rv[0] = Ucur[chain]; rv[1] = Hcur[chain]; rv[2] = hn; rv[3] = U[chain];
+                rem[chain] = nx_.rem[chain]; fresh[chain] = 1; done[chain] = 2 + acc;
+            } else {
+                rem[chain] = -1; done[chain] = 1;
+            }
         } else {
             rem[chain] = rm - 1;
         }
+    }
+    if (auto_next) {
+        __syncthreads();
+        const int acc = acc_s;
+        for (int i = tid; i < nx; i += blockDim.x) {
+            const size_t o = (size_t)chain * nx + i;
+            nx_.res_x[o] = x[o];                                // end model of the trajectory, whatever its fate
+            if (!acc) x[o] = nx_.xstart[o];                     // rejected: back to the start model
+            p[o] = nx_.p[o];                                    // momentum of the next trajectory
+        }
+        if (nx_.res_dsyn)
+            for (int i = tid; i < ndata; i += blockDim.x) nx_.res_dsyn[(size_t)chain * ndata + i] = dsyn[(size_t)chain * ndata + i];
+        __syncthreads();
+        if (tid == 0) nx_.have[chain] = 0;
     }
 }
 

@@ -86,3 +86,23 @@ void rngbatch_randn(const uint64_t* states, int32_t* has_gauss, double* gauss, c
 void rngbatch_rand(const uint64_t* states, const int64_t* idx, int64_t nidx, double* out) {
     for (int64_t i = 0; i < nidx; i++) out[i] = mt_double((mt_state*)(uintptr_t)states[idx[i]]);
 }
+
+/* Snapshot / restore of whole streams (624 key words + position, then the caller-held Gaussian cache): a sampler that
+ * draws AHEAD of time for a trajectory still running takes a snapshot first and restores it should the trajectory fail
+ * (the reference skips the acceptance draw on its failure paths, pyhmc/hmc.py:156,173,177,179).  buf: nidx * 625 uint32. */
+void rngbatch_save(const uint64_t* states, const int64_t* idx, int64_t nidx, uint32_t* buf) {
+    for (int64_t k = 0; k < nidx; k++) {
+        const mt_state* st = (const mt_state*)(uintptr_t)states[idx[k]];
+        uint32_t* b = buf + k * (MT_N + 1);
+        for (int i = 0; i < MT_N; i++) b[i] = st->key[i];
+        b[MT_N] = (uint32_t)st->pos;
+    }
+}
+void rngbatch_load(const uint64_t* states, const int64_t* idx, int64_t nidx, const uint32_t* buf) {
+    for (int64_t k = 0; k < nidx; k++) {
+        mt_state* st = (mt_state*)(uintptr_t)states[idx[k]];
+        const uint32_t* b = buf + k * (MT_N + 1);
+        for (int i = 0; i < MT_N; i++) st->key[i] = b[i];
+        st->pos = (int)b[MT_N];
+    }
+}

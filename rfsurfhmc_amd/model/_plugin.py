@@ -162,9 +162,29 @@ class FusedPlugin:
         nchain, nx = x.shape
         ctx = self._ensure(nx // 2)
         ctx.check(ctx.L.rfs_set_stream(ctx.h, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        ctx.check(ctx.L.rfs_flow_step(ctx.h, nchain, *[st[k].data_ptr() for k in
-                                      ("x", "p", "dt", "rem", "fresh", "bounds", "Ucur", "Hcur", "Unew", "Hnew",
-                                       "dsyn_cur", "dsyn_new", "ok", "done")]))
+        args = [st[k].data_ptr() for k in ("x", "p", "dt", "rem", "fresh", "bounds", "Ucur", "Hcur", "Unew", "Hnew",
+                                           "dsyn_cur", "dsyn_new", "ok", "done")]
+        if "nxt_have" in st:        # restarts on the device (rfs_flow_step2), state from flow_restart_state()
+            from .._lib import FlowNext
+            nxt = FlowNext(*[st[k].data_ptr() if st.get(k) is not None else None for k in
+                             ("nxt_have", "nxt_u", "nxt_p", "nxt_rem", "xstart", "res_x", "res_val", "res_dsyn")])
+            ctx.check(ctx.L.rfs_flow_step2(ctx.h, nchain, *args, ctypes.byref(nxt)))
+        else:
+            ctx.check(ctx.L.rfs_flow_step(ctx.h, nchain, *args))
+
+    def flow_restart_state(self, st, want_dsyn=False):
+        """Adds to a flow state the arrays of rfs_flow_next: deposits for the next trajectory (nxt_have / nxt_u / nxt_p /
+        nxt_rem), the start model of the running one (xstart) and the parked results of the last completed one (res_x,
+        res_val = [Ucur, Hcur, Hnew, Unew], res_dsyn if wanted)."""
+        import torch
+        x = st["x"]
+        nchain, nx = x.shape
+        f64 = dict(dtype=torch.float64, device=x.device)
+        st.update(nxt_have=torch.zeros(nchain, dtype=torch.int32, device=x.device), nxt_u=torch.zeros(nchain, **f64),
+                  nxt_p=torch.zeros(nchain, nx, **f64), nxt_rem=torch.zeros(nchain, dtype=torch.int32, device=x.device),
+                  xstart=x.clone(), res_x=torch.zeros(nchain, nx, **f64), res_val=torch.zeros(nchain, 4, **f64),
+                  res_dsyn=torch.zeros_like(st["dsyn_new"]) if want_dsyn else None)
+        return st
 
     def flow_state(self, x0, dt, bounds):
         """Fresh state for flow_step: x0 float64 CUDA [nchain, 2n], dt float64 CUDA [nchain], bounds [2n, 2]."""

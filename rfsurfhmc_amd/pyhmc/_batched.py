@@ -25,6 +25,8 @@ def _load_rngbatch():
     L.rngbatch_randn.restype = None
     L.rngbatch_rand.argtypes = [vp, vp, i64, vp]
     L.rngbatch_rand.restype = None
+    for f in (L.rngbatch_save, L.rngbatch_load):
+        f.argtypes, f.restype = [vp, vp, i64, vp], None
     return L
 
 
@@ -70,6 +72,32 @@ class ChainRNG:
             self._L.rngbatch_randn(self._p(self._states), self._p(self._has), self._p(self._gauss), self._p(idx),
                                    len(idx), n, self._p(out))
         return out
+
+    def snapshot(self, idx):
+        """Everything needed to put the streams of chains ``idx`` back where they are now (see restore)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        if self._L is None:
+            return idx, [self.rs[c].get_state() for c in idx]
+        buf = np.empty((len(idx), 625), dtype=np.uint32)
+        if len(idx):
+            self._L.rngbatch_save(self._p(self._states), self._p(idx), len(idx), self._p(buf))
+        return idx, (buf, self._has[idx].copy(), self._gauss[idx].copy())
+
+    def restore(self, snap, which):
+        """Rewind the streams of the chains ``which`` (a subset of the snapshot's chains) to the snapshot."""
+        idx, data = snap
+        pos = {int(c): k for k, c in enumerate(idx)}
+        rows = np.array([pos[int(c)] for c in which], dtype=np.int64)
+        sel = np.ascontiguousarray(idx[rows])
+        if self._L is None:
+            for c, k in zip(sel, rows):
+                self.rs[int(c)].set_state(data[k])
+            return
+        buf, has, gauss = data
+        b = np.ascontiguousarray(buf[rows])
+        if len(sel):
+            self._L.rngbatch_load(self._p(self._states), self._p(sel), len(sel), self._p(b))
+            self._has[sel] = has[rows]; self._gauss[sel] = gauss[rows]
 
     def randint(self, idx, lo, hi):
         return np.array([self.rs[c].randint(lo, hi) for c in idx], dtype=np.int32)
@@ -349,7 +377,8 @@ def with_host_threads(fn):
     return wrapped
 
 
-def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max_steps=None, step_hook=None):
+def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max_steps=None, step_hook=None,
+             restart=None):
     """Drive model.flow_step (rfs_flow_step) until ``active()`` is False.
 
     After every step the chains that finished a trajectory are handed to ``process_done(idx, res)`` (host side:
@@ -361,12 +390,20 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max
     trajectories and draws, so the samples do not depend on ``pipeline``.  Returns the number of device steps.
     max_steps: stop after that many device steps (the run is then unfinished: benchmarks, smoke runs);
     step_hook(s, st): called right before device step s is launched (s = 0, 1, ...; bench.py takes its time stamps
-    and counts the chains inside a trajectory there)."""
+    and counts the chains inside a trajectory there).
+    restart: restarts on the device (rfs_flow_step2), for samplers whose draws do not depend on the trajectory.  An object
+    with ``rem0`` (lengths of the trajectories the state starts with), ``predraw(chains) -> (sel, u, p, rem)`` (for a
+    subset ``sel`` of ``chains`` -- the ones that complete their trajectory in the step launched next -- the acceptance
+    draw and the next trajectory's momentum and length, drawn now), ``done(idx, res, accepted)`` (books of chains the
+    device accepted / rejected and restarted; ``res`` holds Ucur, Hcur, Hnew, Unew, x [, dsyn_new] of the completed
+    trajectory) and ``withdraw(idx)`` (chains that failed with a deposit outstanding: rewind their streams, they come
+    through ``process_done`` next).  Such chains evaluate their new start model in the very next step instead of sitting
+    one out; the sequence of draws and decisions per chain is unchanged."""
     with host_threads():                         # see there: the host side must not spin up torch's whole thread pool
-        return _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook)
+        return _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook, restart)
 
 
-def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook):
+def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook, restart):
     import torch
     dev = st["x"].device
 
@@ -377,15 +414,15 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         """Host array (at most one row per chain) -> device tensor.  On a GPU the copy goes through preallocated pinned
         staging buffers and is asynchronous: a plain .to(device) of pageable memory is stream-ordered behind the step that
         was just launched AND blocks the host until it has run, which would serialise the host bookkeeping with the GPU
-        step it is meant to overlap.  Four buffers per shape rotate; a buffer's turn comes round an iteration later, after
-        fetch() has waited for the device and apply() for the event behind its previous copies."""
+        step it is meant to overlap.  Eight buffers per shape rotate (at most four uses per iteration); a buffer's turn comes round
+        two iterations later, and every iteration waits for the event behind the previous one's copies."""
         a = np.ascontiguousarray(a)
         if dev.type != "cuda":
             return torch.from_numpy(a).to(dev)
         src = torch.from_numpy(a)
         key = (tuple(a.shape[1:]), src.dtype)
         if key not in pinned:
-            pinned[key] = [[torch.empty((nchain_all,) + key[0], dtype=src.dtype, pin_memory=True) for _ in range(4)], 0]
+            pinned[key] = [[torch.empty((nchain_all,) + key[0], dtype=src.dtype, pin_memory=True) for _ in range(8)], 0]
         bufs, nxt = pinned[key]
         pinned[key][1] = (nxt + 1) % len(bufs)
         h = bufs[nxt][: a.shape[0]]
@@ -398,37 +435,50 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
     # every step clears its own).  The device then never waits for the host between steps.
     side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and pipeline) else None
     dbuf = [st["done"], torch.zeros_like(st["done"])]
-    marks = []                                   # (done buffer, event) of the steps not fetched yet
+    marks = []                                   # (done buffer, event, step index) of the steps not fetched yet
+    if restart is not None and not hasattr(model, "flow_restart_state"):
+        restart = None
+    if restart is not None:
+        model.flow_restart_state(st, want_dsyn=fetch_syn)
+        finish = np.asarray(restart.rem0, dtype=np.int64).copy()      # step in which each chain completes (fresh at step 0)
+        has_dep = np.zeros(nchain_all, dtype=bool)                    # deposit outstanding
+        dep_rem = np.zeros(nchain_all, dtype=np.int64)                # length of the deposited trajectory
 
     def fetch():
-        done, ev = marks.pop(0)
+        """-> (s, idx1, res1, idx2, res2, acc2): step index; chains that finished and wait for the host (done = 1) with
+        their rows; chains the device restarted (done = 2 / 3) with the parked results and the accept flags."""
+        done, ev, s = marks.pop(0)
         if side is not None:
             side.wait_event(ev)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            idx = np.nonzero(done.cpu().numpy())[0]
-            if len(idx) == 0:
-                return idx, None
-            sel = t(idx)
-            keys = ["ok", "Hcur", "Hnew", "Unew", "Ucur", "x"] + (["dsyn_new"] if fetch_syn else [])
-            res = {k: st[k].index_select(0, sel).cpu().numpy() for k in keys}
-        return idx, res
+            d = done.cpu().numpy()
+            idx1, idx2 = np.nonzero(d == 1)[0], np.nonzero(d >= 2)[0]
+            res1 = res2 = None
+            if len(idx1):
+                sel = t(idx1)
+                keys = ["ok", "Hcur", "Hnew", "Unew", "Ucur", "x"] + (["dsyn_new"] if fetch_syn else [])
+                res1 = {k: st[k].index_select(0, sel).cpu().numpy() for k in keys}
+            if len(idx2):
+                sel = t(idx2)
+                val = st["res_val"].index_select(0, sel).cpu().numpy()
+                res2 = dict(Ucur=val[:, 0], Hcur=val[:, 1], Hnew=val[:, 2], Unew=val[:, 3],
+                            x=st["res_x"].index_select(0, sel).cpu().numpy())
+                if fetch_syn:
+                    res2["dsyn_new"] = st["res_dsyn"].index_select(0, sel).cpu().numpy()
+        return s, idx1, res1, idx2, res2, d[idx2] == 3
 
-    applied = []                                 # event behind the previous apply()'s copies out of the pinned buffers
+    uploaded = []                                # event behind the previous iteration's copies out of the pinned buffers
 
-    def apply(idx, xkeep, restart):
-        if applied:
-            applied.pop().synchronize()          # long past in practice; makes the reuse of the staging buffers formal
+    def apply(idx, xkeep, rs_):
         st["x"].index_copy_(0, t(idx), t(xkeep))
-        if restart is not None and len(restart["idx"]):
-            rs = t(np.asarray(restart["idx"]))
-            st["p"].index_copy_(0, rs, t(restart["p"]))
-            st["rem"].index_copy_(0, rs, t(np.asarray(restart["rem"], dtype=np.int32)))
-            if restart.get("dt") is not None:
-                st["dt"].index_copy_(0, rs, t(np.asarray(restart["dt"], dtype=np.float64)))
+        if rs_ is not None and len(rs_["idx"]):
+            rs = t(np.asarray(rs_["idx"]))
+            st["p"].index_copy_(0, rs, t(rs_["p"]))
+            st["rem"].index_copy_(0, rs, t(np.asarray(rs_["rem"], dtype=np.int32)))
+            if rs_.get("dt") is not None:
+                st["dt"].index_copy_(0, rs, t(np.asarray(rs_["dt"], dtype=np.float64)))
             st["fresh"].index_fill_(0, rs, 1)
             st["ok"].index_fill_(0, rs, 1)
-        if dev.type == "cuda":
-            ev = torch.cuda.Event(); ev.record(); applied.append(ev)
 
     steps = 0
 
@@ -441,7 +491,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         ev = None
         if side is not None:
             ev = torch.cuda.Event(); ev.record()
-        marks.append((st["done"], ev))
+        marks.append((st["done"], ev, steps - 1))
 
     capped = lambda: max_steps is not None and steps >= max_steps
     step()
@@ -449,13 +499,42 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         early = side is not None and active() and not capped()
         if early:
             step()                               # before the fetch: see above
-        idx, res = fetch()                       # synchronises with the step whose results it takes
-        more = (active() or len(idx) > 0) and not capped()
+        s, idx1, res1, idx2, res2, acc2 = fetch()            # synchronises with the step whose results it takes
+        more = (active() or len(idx1) + len(idx2) > 0) and not capped()
         if pipeline and more and not early:
-            step()                               # the finished chains idle in this step (rem = -1, fresh = 0)
-        if len(idx):
-            xkeep, restart = process_done(idx, res)
-            apply(idx, xkeep, restart)           # stream-ordered after the step launched above
+            step()                               # the chains that wait for the host idle in this step (rem = -1, fresh = 0)
+        if uploaded:
+            uploaded.pop().synchronize()         # long past in practice; makes the reuse of the staging buffers formal
+        if len(idx1):
+            if restart is not None:
+                wd = idx1[has_dep[idx1]]
+                if len(wd):                      # failed with a deposit outstanding: take it back before anything is drawn
+                    restart.withdraw(wd)
+                    has_dep[wd] = False
+                    st["nxt_have"].index_fill_(0, t(wd), 0)
+            xkeep, rs_ = process_done(idx1, res1)
+            apply(idx1, xkeep, rs_)              # stream-ordered after the step launched above
+            if restart is not None:
+                finish[idx1] = -1
+                if rs_ is not None and len(rs_["idx"]):              # fresh in the step launched next
+                    finish[np.asarray(rs_["idx"])] = steps + np.asarray(rs_["rem"], dtype=np.int64)
+        if len(idx2):
+            restart.done(idx2, res2, acc2)
+            finish[idx2] = s + 1 + dep_rem[idx2]                     # fresh in step s + 1, already under way
+            has_dep[idx2] = False
+        if restart is not None and active() and not capped():
+            cand = np.nonzero((finish == steps) & ~has_dep)[0]       # they complete in the step launched next
+            if len(cand):
+                sel, u, pn, rem = restart.predraw(cand)
+                if len(sel):
+                    ts = t(np.asarray(sel, dtype=np.int64))
+                    st["nxt_u"].index_copy_(0, ts, t(np.asarray(u, dtype=np.float64)))
+                    st["nxt_p"].index_copy_(0, ts, t(pn))
+                    st["nxt_rem"].index_copy_(0, ts, t(np.asarray(rem, dtype=np.int32)))
+                    st["nxt_have"].index_fill_(0, ts, 1)
+                    has_dep[sel] = True; dep_rem[sel] = rem
+        if dev.type == "cuda":
+            ev = torch.cuda.Event(); ev.record(); uploaded.append(ev)
         if not active() or capped():
             break
         if not pipeline:

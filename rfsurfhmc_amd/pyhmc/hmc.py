@@ -106,7 +106,7 @@ class HamitonianMC:
         return xres, Ures, dres, accept
 
     @with_host_threads
-    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True):
         """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
         chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
         chain at its own point of its own trajectory (rfs_flow_step), and a chain that finishes a trajectory is
@@ -146,19 +146,7 @@ class HamitonianMC:
             u[ok] = self.rng.rand([int(c) for c in idx[ok]])                    # hmc.py:193, skipped on failure
             with np.errstate(over="ignore", invalid="ignore"):
                 accept = ok & (u < np.exp(-(Hnew - Hcur)))
-            # accepted end points (vectorised over the finished chains; one sample slot per chain and trajectory)
-            ca = idx[accept]
-            if len(ca):
-                x[ca] = xend[accept]
-                keep = i[ca] >= nd_
-                if np.any(keep):
-                    ck, slot = ca[keep], i[ca][keep] - nd_
-                    misfit[ck, slot] = Unew[accept][keep]
-                    x_cache[ck, slot] = xend[accept][keep]
-                    if syndata is not None:
-                        syndata[ck, slot] = dnew[accept][keep]
-                i[ca] += 1; self.ii += len(ca)
-            ncount[idx] += 1
+            book(idx, accept, Unew, xend, dnew)
             restart = [int(c) for c in idx[i[idx] < total]]
             if self.verbose:
                 for k, c in enumerate(idx):
@@ -175,9 +163,59 @@ class HamitonianMC:
                 rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, rem=Lr)
             return x[idx], rs
 
+        def book(idx, accept, Unew, xend, dnew):
+            """One completed trajectory per chain of idx: keep the accepted end points, fill the sample slots."""
+            ca = idx[accept]
+            if len(ca):
+                x[ca] = xend[accept]
+                keep = i[ca] >= nd_
+                if np.any(keep):
+                    ck, slot = ca[keep], i[ca][keep] - nd_
+                    misfit[ck, slot] = Unew[accept][keep]
+                    x_cache[ck, slot] = xend[accept][keep]
+                    if syndata is not None:
+                        syndata[ck, slot] = dnew[accept][keep]
+                i[ca] += 1; self.ii += len(ca)
+            ncount[idx] += 1
+
+        # Restarts on the device (rfs_flow_step2): neither the acceptance draw nor the next L and momentum depend on the
+        # trajectory (hmc.py:193, 248, 146), so they are drawn -- in that order, from the chain's own stream -- while the
+        # trajectory still runs, and the device accepts / rejects and starts over by itself.  The one exception is the
+        # reference's failure paths, which skip the acceptance draw (hmc.py:156,173,177,179): the streams are
+        # snapshotted before the early draws and rewound for a chain that fails.
+        sampler = self
+        pending = {}                                # chain -> snapshot its early draws can be undone with
+
+        class Restart:
+            rem0 = L
+
+            @staticmethod
+            def predraw(cands):
+                sel = cands[i[cands] + 1 < total]   # needs another trajectory whatever the decision
+                if len(sel) == 0:
+                    return sel, None, None, None
+                snap = sampler.rng.snapshot(sel)
+                for c in sel:
+                    pending[int(c)] = snap
+                cl = [int(c) for c in sel]
+                u = sampler.rng.rand(cl)
+                Ln = sampler.rng.randint(cl, sampler.Lrange[0], sampler.Lrange[1] + 1)
+                return sel, u, sampler.rng.randn(cl, nx) * sampler._pscale, Ln
+
+            @staticmethod
+            def done(idx, res, accepted):
+                book(idx, accepted, res["Unew"], res["x"], res.get("dsyn_new"))
+                for c in idx:
+                    pending.pop(int(c), None)
+
+            @staticmethod
+            def withdraw(idx):
+                for c in idx:
+                    sampler.rng.restore(pending.pop(int(c)), [int(c)])
+
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
                                    fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
-                                   step_hook=step_hook)
+                                   step_hook=step_hook, restart=Restart if device_restart else None)
         self.finished = not bool(np.any(i < total))
         self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written

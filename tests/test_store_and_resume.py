@@ -70,6 +70,8 @@ def _toy_flow_step(self, st):
         st["dsyn_cur"][fr] = x[fr]; st["dsyn_new"][fr] = x[fr]
         p[fr] = p[fr] - 0.5 * dt[fr, None] * g[fr]
         fresh[fr] = 0
+    if "nxt_have" in st and fr.any():
+        st["xstart"][fr] = x[fr]
     if run.any():
         last = run & (rem == 1)
         w = torch.where(last, 0.5, 1.0)
@@ -80,10 +82,32 @@ def _toy_flow_step(self, st):
         rem[run] = rem[run] - 1
         rem[last] = -1
         st["done"][last] = 1
+        if "nxt_have" in st:                     # rfs_flow_step2: accept / reject and restart where a deposit waits
+            au = last & (st["nxt_have"] == 1)
+            if au.any():
+                acc = au & (st["nxt_u"] < torch.exp(-(st["Hnew"] - st["Hcur"])))
+                st["res_val"][au] = torch.stack([st["Ucur"], st["Hcur"], st["Hnew"], st["Unew"]], dim=1)[au]
+                st["res_x"][au] = x[au]
+                if st.get("res_dsyn") is not None:
+                    st["res_dsyn"][au] = x[au]
+                rej = au & ~acc
+                x[rej] = st["xstart"][rej]
+                p[au] = st["nxt_p"][au]; rem[au] = st["nxt_rem"][au]; fresh[au] = 1
+                st["done"][au] = 2; st["done"][acc] = 3
+                st["nxt_have"][au] = 0
+
+
+def _toy_flow_restart_state(self, st, want_dsyn=False):
+    n, nx = st["x"].shape
+    z = lambda *sh: torch.zeros(*sh, dtype=torch.float64)
+    st.update(nxt_have=torch.zeros(n, dtype=torch.int32), nxt_u=z(n), nxt_p=z(n, nx), nxt_rem=torch.zeros(n, dtype=torch.int32),
+              xstart=st["x"].clone(), res_x=z(n, nx), res_val=z(n, 4), res_dsyn=z(n, nx) if want_dsyn else None)
+    return st
 
 
 ToyModel.flow_state = _toy_flow_state
 ToyModel.flow_step = _toy_flow_step
+ToyModel.flow_restart_state = _toy_flow_restart_state
 
 
 def _bounds(n):
@@ -180,6 +204,10 @@ def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
     b = _make(kind, tmp_path / "b"); mb = b.sample_flow(x_init=x0)
     c = _make(kind, tmp_path / "c"); mc = c.sample_flow(x_init=x0, pipeline=False)
     assert np.array_equal(ma, mb) and np.array_equal(ma, mc) and c.flow_steps <= b.flow_steps
+    if kind == "hmc":           # restarts on the device (early draws) against restarts by the host: same samples, fewer steps
+        d = _make(kind, tmp_path / "d"); md = d.sample_flow(x_init=x0, device_restart=False)
+        assert np.array_equal(ma, md) and np.array_equal(a.x_cache, d.x_cache) and b.flow_steps < d.flow_steps
+        assert np.array_equal(b.accept_ratio, d.accept_ratio)
     assert np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.syndata, b.syndata)
     assert np.array_equal(a.accept_ratio, b.accept_ratio)
     if kind == "hmcda":
