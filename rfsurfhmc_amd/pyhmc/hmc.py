@@ -184,6 +184,7 @@ class HamitonianMC:
         # reference's failure paths, which skip the acceptance draw (hmc.py:156,173,177,179): the streams are
         # snapshotted before the early draws and rewound for a chain that fails.
         sampler = self
+        self.flow_withdrawn = 0                     # early draws taken back because the trajectory failed after all
         pending = {}                                # chain -> snapshot its early draws can be undone with
 
         class Restart:
@@ -210,6 +211,7 @@ class HamitonianMC:
 
             @staticmethod
             def withdraw(idx):
+                sampler.flow_withdrawn += len(idx)
                 for c in idx:
                     sampler.rng.restore(pending.pop(int(c)), [int(c)])
 

@@ -13,9 +13,10 @@ class ToyModel:
     """U(x) = 0.5 |x - m|^2, synthetics = x; leapfrog with the reference's half-step scheme, no reflection."""
     torch_device = torch.device("cpu")
 
-    def __init__(self, n):
+    def __init__(self, n, fail_above=None):
         self.m = np.linspace(1.0, 2.0, n)
         self.dobs = self.m.copy()
+        self.fail_above = fail_above          # an evaluation with U above this "fails" (the reference's flag False)
 
     def misfit_and_grad(self, x):
         x = np.atleast_2d(x)
@@ -30,17 +31,21 @@ class ToyModel:
         Lmax = int(L.max())
         xn, Un, Hn = x.clone(), U0.clone(), H0.clone()
         p = p - 0.5 * dt[:, None] * (x - m)
+        bad = torch.zeros(len(x), dtype=torch.bool) if self.fail_above is None else U0 > self.fail_above
         for s in range(Lmax):
-            live = (L > s)[:, None]
+            live = (L > s)[:, None] & ~bad[:, None]
             x = torch.where(live, x + dt[:, None] * p, x)
             g = x - m
+            if self.fail_above is not None:
+                bad = bad | (live[:, 0] & (0.5 * (g * g).sum(1) > self.fail_above))
+                live = live & ~bad[:, None]
             last = (L == s + 1)[:, None]
             p = torch.where(live, p - torch.where(last, 0.5, 1.0) * dt[:, None] * g, p)
             done = (L == s + 1)
             U = 0.5 * (g * g).sum(1)
             xn = torch.where(done[:, None], x, xn); Un = torch.where(done, U, Un)
             Hn = torch.where(done, U + 0.5 * (p * p).sum(1), Hn)
-        return dict(ok=torch.ones(len(x), dtype=torch.int32), Hcur=H0, Hnew=Hn, xnew=xn, Unew=Un, Ucur=U0,
+        return dict(ok=(~bad).to(torch.int32), Hcur=H0, Hnew=Hn, xnew=xn, Unew=Un, Ucur=U0,
                     dsyn_new=xn.clone(), dsyn_cur=x0)
 
 
@@ -57,12 +62,13 @@ def _toy_flow_step(self, st):
     """rfs_flow_step semantics (include/rfsurf.h) for the toy potential, same arithmetic as leapfrog_device above."""
     m = torch.from_numpy(self.m)
     x, p, dt, rem, fresh = st["x"], st["p"], st["dt"], st["rem"], st["fresh"]
-    run = (fresh == 0) & (rem > 0)
+    run = (fresh == 0) & (rem > 0) & (st["ok"] == 1)
     x[run] = x[run] + dt[run, None] * p[run]
     g = x - m
     U = 0.5 * (g * g).sum(1)
     st["done"].zero_()
     fr = fresh == 1
+    fail = torch.zeros_like(run) if self.fail_above is None else (U > self.fail_above)
     if fr.any():
         st["Ucur"][fr] = U[fr]; st["Unew"][fr] = U[fr]
         st["Hcur"][fr] = U[fr] + 0.5 * (p[fr] * p[fr]).sum(1)
@@ -70,6 +76,13 @@ def _toy_flow_step(self, st):
         st["dsyn_cur"][fr] = x[fr]; st["dsyn_new"][fr] = x[fr]
         p[fr] = p[fr] - 0.5 * dt[fr, None] * g[fr]
         fresh[fr] = 0
+        st["ok"][fr] = (~fail[fr]).to(torch.int32)
+        ff = fr & fail
+        rem[ff] = -1; st["done"][ff] = 1
+    rf = run & fail                              # a running chain whose evaluation fails: no kick, the host restarts it
+    if rf.any():
+        st["ok"][rf] = 0; rem[rf] = -1; st["done"][rf] = 1
+        run = run & ~fail
     if "nxt_have" in st and fr.any():
         st["xstart"][fr] = x[fr]
     if run.any():
@@ -114,14 +127,14 @@ def _bounds(n):
     return np.stack([np.full(n, -5.0), np.full(n, 5.0)], axis=1)
 
 
-def _make(kind, tmp, **kw):
+def _make(kind, tmp, fail_above=None, **kw):
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
     n = 6
-    common = dict(myrank=1, name="toy", outdir=str(tmp), nchains=5, verbose=False, **kw)
+    common = dict(myrank=1, name="toy", outdir=None if tmp is None else str(tmp), nchains=kw.pop("nchains", 5), verbose=False, **kw)
     if kind == "hmc":
-        return HamitonianMC(ToyModel(n), _bounds(n), 0.3, [3, 8], 4, 991206, 12, 4, **common)
-    return HMCDualAveraging(ToyModel(n), _bounds(n), 0.3, 5, 4, 0.65, 991206, 12, 4, **common)
+        return HamitonianMC(ToyModel(n, fail_above), _bounds(n), 0.3, [3, 8], 4, 991206, 12, 4, **common)
+    return HMCDualAveraging(ToyModel(n, fail_above), _bounds(n), 0.3, 5, 4, 0.65, 991206, 12, 4, **common)
 
 
 @pytest.mark.parametrize("kind", ["hmc", "hmcda"])
@@ -232,3 +245,26 @@ def test_host_threads_caps_and_restores():
     s.outdir = None
     s.sample()
     assert torch.get_num_threads() == before
+
+
+def test_device_restarts_with_failing_trajectories_keep_the_reference_draw_order():
+    """Trajectories that fail skip the acceptance draw (hmc.py:156,173,177,179).  With restarts on the device that draw
+    and the next L and momentum are made one step before a trajectory completes -- so a chain that fails in its last
+    two steps has drawn too much, and its stream must be rewound.  40 chains of which a good part fail now and then:
+    batch schedule, flow with host restarts and flow with device restarts give the same samples and the same counts."""
+    # start models near the minimum (a chain whose START model fails can never leave it, in the reference either); the
+    # threshold is crossed by the excursions of the more energetic trajectories only
+    x0 = np.linspace(1.0, 2.0, 6)[None, :] + 0.2 * np.random.default_rng(11).standard_normal((40, 6))
+    runs = {}
+    for name, kw in (("batch", None), ("flow_host", dict(device_restart=False)), ("flow_dev", dict(device_restart=True)),
+                     ("flow_dev_sync", dict(device_restart=True, pipeline=False))):
+        smp = _make("hmc", None, fail_above=1.0, nchains=40)
+        mis = smp.sample(x_init=x0) if kw is None else smp.sample_flow(x_init=x0, **kw)
+        runs[name] = (mis, smp.x_cache.copy(), smp.accept_ratio.copy(), smp)
+    base = runs["batch"]
+    assert base[2].min() < 0.8 and base[2].max() <= 1.0           # rejections and failures did happen
+    for name in ("flow_host", "flow_dev", "flow_dev_sync"):
+        assert np.array_equal(runs[name][0], base[0]), name
+        assert np.array_equal(runs[name][1], base[1]) and np.array_equal(runs[name][2], base[2]), name
+    assert runs["flow_dev"][3].flow_steps < runs["flow_host"][3].flow_steps
+    assert runs["flow_dev"][3].flow_withdrawn > 0 and runs["flow_dev_sync"][3].flow_withdrawn > 0      # the rewind was exercised
