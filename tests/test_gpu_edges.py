@@ -174,6 +174,9 @@ def test_argument_errors_are_reported_not_fatal():
     assert L.rfs_leapfrog_dev2(ctx.h, 2, dummy, dummy, dummy, dummy, 2, hptr(bad), *([dummy] * 9)) == -1
     assert L.rfs_flow_step(ctx.h, 1, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy,
                            dummy, dummy, None) == -1                                                        # null output
+    from rfsurfhmc_amd._lib import FlowNext
+    nxt = FlowNext()                                                                                        # all null
+    assert L.rfs_flow_step2(ctx.h, 1, *([dummy] * 14), ctypes.byref(nxt)) == -1 and b"rfs_flow_next" in L.rfs_last_error(ctx.h)
     assert L.rfs_set_option(ctx.h, b"early_eigen_periods", -2) == -1 and L.rfs_set_option(ctx.h, b"no_such_option", 1) == -1
     assert L.rfs_set_option(ctx.h, b"early_eigen_periods", 0) == 0 and L.rfs_set_option(ctx.h, b"early_eigen_periods", -1) == 0
     with pytest.raises(RfsError):

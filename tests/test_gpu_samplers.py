@@ -271,3 +271,55 @@ def test_ensemble_mass_adaptation_on_the_device(golden):
     d = HMCDualAveraging(_joint(g), bounds, 0.02, 4, 2, 0.65, 991206, 4, 3, mass_adapt=[0, 2], **kw)
     md = d.sample(x_init=x)
     assert np.all(np.isfinite(md)) and d.inverse_mass is not None and np.all(d.dt_final > 0)
+
+
+def test_flow_step2_accepts_rejects_and_restarts_like_the_host(golden):
+    """rfs_flow_step2 at the boundary: two copies of 64 chains take the same trajectories; in one the host does what
+    pyhmc/hmc.py:192-198 does after the step that completes them, in the other the draws were deposited beforehand and
+    the device did it.  Same models, same momenta, same books, and the deposit is consumed."""
+    import torch
+    g = golden["sampler_hybrid"]
+    joint = _joint(g)
+    nc, nx = 64, len(g["x0"])
+    rng = np.random.default_rng(3)
+    x0 = np.clip(g["x0"][None, :] * (1 + 0.02 * rng.standard_normal((nc, nx))), g["bounds"][:, 0], g["bounds"][:, 1])
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    L = 3
+    p0 = 0.5 * rng.standard_normal((nc, nx)); pnext = 0.5 * rng.standard_normal((nc, nx))
+    u = rng.random(nc); u[:8] = 0.0; u[8:16] = 1e300                   # some certain accepts, some certain rejects
+    Lnext = rng.integers(2, 6, nc).astype(np.int32)
+
+    def start():
+        st = joint.flow_state(t(x0), torch.full((nc,), 0.05, dtype=torch.float64, device=dev), t(g["bounds"]))
+        st["p"].copy_(t(p0)); st["rem"].fill_(L); st["fresh"].fill_(1)
+        return st
+    a, b = start(), joint.flow_restart_state(start())
+    for s in range(L + 1):
+        if s == L:                                                     # deposits one step before completion
+            b["nxt_u"].copy_(t(u)); b["nxt_p"].copy_(t(pnext)); b["nxt_rem"].copy_(t(Lnext)); b["nxt_have"].fill_(1)
+            b["nxt_have"][5] = 0                                       # ... except for one chain: it must wait for the host
+        joint.flow_step(a); joint.flow_step(b)
+    torch.cuda.synchronize()
+    assert int(a["done"].sum()) == nc
+    Hc, Hn = a["Hcur"].cpu().numpy(), a["Hnew"].cpu().numpy()
+    acc = u < np.exp(-(Hn - Hc))
+    assert acc[:8].all() and not acc[8:16].any()
+    db = b["done"].cpu().numpy()
+    want = np.where(acc, 3, 2); want[5] = 1
+    assert np.array_equal(db, want)
+    dep = np.arange(nc) != 5
+    rv = b["res_val"].cpu().numpy()
+    assert np.array_equal(rv[dep, 1], Hc[dep]) and np.array_equal(rv[dep, 2], Hn[dep])
+    assert np.array_equal(rv[dep, 3], a["Unew"].cpu().numpy()[dep]) and np.array_equal(rv[dep, 0], a["Ucur"].cpu().numpy()[dep])
+    xa = a["x"].cpu().numpy()
+    assert np.array_equal(b["res_x"].cpu().numpy()[dep], xa[dep])
+    xb = b["x"].cpu().numpy()
+    assert np.array_equal(xb[dep & acc], xa[dep & acc]) and np.array_equal(xb[dep & ~acc], x0[dep & ~acc])
+    assert np.array_equal(b["p"].cpu().numpy()[dep], pnext[dep]) and np.array_equal(b["rem"].cpu().numpy()[dep], Lnext[dep])
+    assert np.array_equal(b["fresh"].cpu().numpy(), dep.astype(np.int32)) and int(b["nxt_have"].sum()) == 0
+    assert int(b["rem"][5]) == -1 and np.array_equal(xb[5], xa[5])      # the chain without a deposit: rfs_flow_step behaviour
+    # next call: the restarted chains evaluate their start model (fresh), the books of the finished trajectory stay parked
+    joint.flow_step(b); torch.cuda.synchronize()
+    assert np.array_equal(b["res_val"].cpu().numpy(), rv) and int(b["fresh"].sum()) == 0
+    assert np.array_equal(b["xstart"].cpu().numpy()[dep], xb[dep]) and np.isinf(b["Hnew"].cpu().numpy()[dep]).all()
