@@ -482,8 +482,12 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
 
     steps = 0
 
+    deposited = []                               # events behind deposits made on the side stream
+
     def step():
         nonlocal steps
+        while deposited:
+            torch.cuda.current_stream().wait_event(deposited.pop())
         if step_hook is not None:
             step_hook(steps, st)
         st["done"] = dbuf[steps % 2]
@@ -527,11 +531,16 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
             if len(cand):
                 sel, u, pn, rem = restart.predraw(cand)
                 if len(sel):
-                    ts = t(np.asarray(sel, dtype=np.int64))
-                    st["nxt_u"].index_copy_(0, ts, t(np.asarray(u, dtype=np.float64)))
-                    st["nxt_p"].index_copy_(0, ts, t(pn))
-                    st["nxt_rem"].index_copy_(0, ts, t(np.asarray(rem, dtype=np.int32)))
-                    st["nxt_have"].index_fill_(0, ts, 1)
+                    # on the side stream, beside the step that is running: these chains are in mid-trajectory there and the
+                    # device looks at a deposit only in the step that completes one; the next launch waits for the event
+                    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                        ts = t(np.asarray(sel, dtype=np.int64))
+                        st["nxt_u"].index_copy_(0, ts, t(np.asarray(u, dtype=np.float64)))
+                        st["nxt_p"].index_copy_(0, ts, t(pn))
+                        st["nxt_rem"].index_copy_(0, ts, t(np.asarray(rem, dtype=np.int32)))
+                        st["nxt_have"].index_fill_(0, ts, 1)
+                        if side is not None:
+                            ev = torch.cuda.Event(); ev.record(); deposited.append(ev)
                     has_dep[sel] = True; dep_rem[sel] = rem
         if dev.type == "cuda":
             ev = torch.cuda.Event(); ev.record(); uploaded.append(ev)
