@@ -184,7 +184,13 @@ int rfs_flow_step(rfs_ctx* ctx, int nchain, double* x, double* p, const double* 
  * res_dsyn (synthetics at the end model; may be NULL).  have[chain] is cleared when consumed.  A chain without a deposit,
  * or one that fails (ok = 0), behaves exactly as in rfs_flow_step (done = 1, the host restarts it) -- and keeps its deposit,
  * which the host has to withdraw (have = 0).  next == NULL: rfs_flow_step.  The struct lives on the HOST, every pointer in
- * it is a DEVICE pointer. */
+ * it is a DEVICE pointer.
+ * Deferred form (rem == NULL, gsave and kick given) for samplers whose next step size depends on the trajectory just
+ * completed (dual averaging, pyhmc/hmcda.py:329-345): the deposit holds only u and p; a restarted chain gets a placeholder
+ * length, and NO chain takes its first half kick p -= dt/2 grad in the call that evaluates its start model -- the
+ * gradient is kept in gsave, kick[chain] = 1, and the kick is applied (same arithmetic) at the start of the next call.
+ * The host therefore has one whole call to write the chain's new dt and rem.  gsave / kick may also be given together
+ * with rem; all start models are then treated that way. */
 typedef struct rfs_flow_next {
     int32_t* have;        /* [nchain] */
     const double* u;      /* [nchain] acceptance draw */
@@ -194,6 +200,8 @@ typedef struct rfs_flow_next {
     double* res_x;        /* [nchain][2*nlayer] */
     double* res_val;      /* [nchain][4] */
     double* res_dsyn;     /* [nchain][ndata] or NULL */
+    double* gsave;        /* [nchain][2*nlayer] or NULL, see below */
+    int32_t* kick;        /* [nchain] or NULL */
 } rfs_flow_next;
 int rfs_flow_step2(rfs_ctx* ctx, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
                    const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,

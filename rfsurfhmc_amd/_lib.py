@@ -29,7 +29,8 @@ class SwdParams(ctypes.Structure):
 
 
 class FlowNext(ctypes.Structure):      # rfs_flow_next (include/rfsurf.h): device pointers
-    _fields_ = [(k, ctypes.c_void_p) for k in ("have", "u", "p", "rem", "xstart", "res_x", "res_val", "res_dsyn")]
+    _fields_ = [(k, ctypes.c_void_p) for k in ("have", "u", "p", "rem", "xstart", "res_x", "res_val", "res_dsyn", "gsave",
+                                               "kick")]
 
 
 class RfsError(RuntimeError):

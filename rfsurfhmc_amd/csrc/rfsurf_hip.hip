@@ -1318,11 +1318,16 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     TRY(check_batch(c, nchain, c->n));
     if (!x || !p || !dt || !rem || !fresh || !bounds || !Ucur || !Hcur || !Unew || !Hnew || !dsyn_cur || !dsyn_new || !ok || !done)
         return fail(c, RFS_ERR_ARG, "null argument");
-    FlowNext fn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    FlowNext fn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (next) {
-        if (!next->have || !next->u || !next->p || !next->rem || !next->xstart || !next->res_x || !next->res_val)
-            return fail(c, RFS_ERR_ARG, "rfs_flow_next: only res_dsyn may be null");
-        fn = FlowNext{next->have, next->u, next->p, next->rem, next->xstart, next->res_x, next->res_val, next->res_dsyn};
+        if (!next->have || !next->u || !next->p || !next->xstart || !next->res_x || !next->res_val)
+            return fail(c, RFS_ERR_ARG, "rfs_flow_next: only rem (with gsave, kick given), res_dsyn, gsave and kick may be null");
+        if (!next->rem && (!next->gsave || !next->kick))
+            return fail(c, RFS_ERR_ARG, "rfs_flow_next: rem == NULL (length and step size follow later) needs gsave and kick");
+        if ((next->gsave == nullptr) != (next->kick == nullptr))
+            return fail(c, RFS_ERR_ARG, "rfs_flow_next: gsave and kick go together");
+        fn = FlowNext{next->have, next->u, next->p, next->rem, next->xstart, next->res_x, next->res_val, next->res_dsyn,
+                      next->gsave, next->kick};
     }
     const int n = c->n, nx = 2 * n, nd = c->ndata;
     ENSURE(c, c->lU, (size_t)nchain * sizeof(double)); ENSURE(c, c->lgrad, (size_t)nchain * nx * sizeof(double));
@@ -1331,7 +1336,8 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     int* fl = c->lflag.as<int>();
     const int nth = nchain * nx;
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
-    hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p);
+    hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p,
+                       fn.gsave, fn.kick);
     TRY(joint_eval(c, nchain, x, U, g, d, fl));
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn);

@@ -1303,13 +1303,16 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
 // with this call (x = start model, p = drawn momentum).  Same arithmetic as k_leap_begin / drift / kick.
 // ---------------------------------------------------------------------------------------
 __global__ void k_flow_pre(int nchain, int nx, const double* minv, const double* dt, const int* rem, const int* fresh, const int* ok,
-                           const double* bounds, double* x, double* p)
+                           const double* bounds, double* x, double* p, const double* gsave, const int* kick)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nx) return;
     int chain = g / nx, i = g - chain * nx;
     if (fresh[chain] || rem[chain] <= 0 || !ok[chain]) return;
-    double xv = x[g] + dt[chain] * (p[g] * (minv ? minv[i] : 1.0)), pv = p[g];
+    double pv = p[g];
+    if (kick && kick[chain]) pv = pv - dt[chain] * gsave[g] * 0.5;      // the half kick a deferred start left open (hmc.py:164)
+    // (same expression as in k_flow_post's start branch: the two forms give the same p bit for bit)
+    double xv = x[g] + dt[chain] * (pv * (minv ? minv[i] : 1.0));
     double lo = bounds[2 * i], hi = bounds[2 * i + 1];
     for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
         if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
@@ -1322,6 +1325,7 @@ __global__ void k_flow_pre(int nchain, int nx, const double* minv, const double*
 struct FlowNext {
     int* have; const double* u; const double* p; const int* rem;
     double* xstart; double* res_x; double* res_val; double* res_dsyn;
+    double* gsave; int* kick;        // deferred first half kick (rem == nullptr): gradient at the start model, flag
 };
 __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, const double* U,
                             const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
@@ -1351,10 +1355,12 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
     const int fail = bad || !flag[chain];
     if (fr) {                                                   // hmc.py:150-164
         double k = 0.0;
+        const bool defer = nx_.kick != nullptr;                 // the step size may still be on its way: kick in the next call
         for (int i = tid; i < nx; i += blockDim.x) {
             double pv = p[(size_t)chain * nx + i];
             k += pv * pv * (minv ? minv[i] : 1.0);
-            p[(size_t)chain * nx + i] = pv - dt[chain] * grad[(size_t)chain * nx + i] * 0.5;
+            if (defer) nx_.gsave[(size_t)chain * nx + i] = grad[(size_t)chain * nx + i];
+            else p[(size_t)chain * nx + i] = pv - dt[chain] * grad[(size_t)chain * nx + i] * 0.5;
         }
         for (int i = tid; i < ndata; i += blockDim.x) {
             double d = dsyn[(size_t)chain * ndata + i];
@@ -1373,10 +1379,12 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
             Hnew[chain] = __longlong_as_double(0x7ff0000000000000LL);          // +inf until the trajectory completes
             ok[chain] = !fail;
             fresh[chain] = 0;
+            if (defer) nx_.kick[chain] = !fail;
             if (fail) { rem[chain] = -1; done[chain] = 1; }
         }
         return;
     }
+    if (tid == 0 && nx_.kick) nx_.kick[chain] = 0;              // k_flow_pre has applied the deferred half kick (p holds it)
     if (fail) { if (tid == 0) { ok[chain] = 0; rem[chain] = -1; done[chain] = 1; } return; }
     const bool last = (rm == 1);                                // hmc.py:170-190
     double k = 0.0;
@@ -1403,7 +1411,8 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
                 acc_s = acc;
                 double* rv = nx_.res_val + (size_t)chain * 4;
                 rv[0] = Ucur[chain]; rv[1] = Hcur[chain]; rv[2] = hn; rv[3] = U[chain];
-                rem[chain] = nx_.rem[chain]; fresh[chain] = 1; done[chain] = 2 + acc;
+                rem[chain] = nx_.rem ? nx_.rem[chain] : (1 << 30);      // deferred: the caller sets the length before the first step
+                fresh[chain] = 1; done[chain] = 2 + acc;
             } else {
                 rem[chain] = -1; done[chain] = 1;
             }

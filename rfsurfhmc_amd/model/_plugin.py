@@ -167,15 +167,16 @@ class FusedPlugin:
         if "nxt_have" in st:        # restarts on the device (rfs_flow_step2), state from flow_restart_state()
             from .._lib import FlowNext
             nxt = FlowNext(*[st[k].data_ptr() if st.get(k) is not None else None for k in
-                             ("nxt_have", "nxt_u", "nxt_p", "nxt_rem", "xstart", "res_x", "res_val", "res_dsyn")])
+                             ("nxt_have", "nxt_u", "nxt_p", "nxt_rem", "xstart", "res_x", "res_val", "res_dsyn", "gsave", "kick")])
             ctx.check(ctx.L.rfs_flow_step2(ctx.h, nchain, *args, ctypes.byref(nxt)))
         else:
             ctx.check(ctx.L.rfs_flow_step(ctx.h, nchain, *args))
 
-    def flow_restart_state(self, st, want_dsyn=False):
+    def flow_restart_state(self, st, want_dsyn=False, deferred=False):
         """Adds to a flow state the arrays of rfs_flow_next: deposits for the next trajectory (nxt_have / nxt_u / nxt_p /
         nxt_rem), the start model of the running one (xstart) and the parked results of the last completed one (res_x,
-        res_val = [Ucur, Hcur, Hnew, Unew], res_dsyn if wanted)."""
+        res_val = [Ucur, Hcur, Hnew, Unew], res_dsyn if wanted).  deferred: the form for samplers whose next step size
+        depends on the finished trajectory (no nxt_rem; gsave / kick for the first half kick one call later)."""
         import torch
         x = st["x"]
         nchain, nx = x.shape
@@ -183,7 +184,10 @@ class FusedPlugin:
         st.update(nxt_have=torch.zeros(nchain, dtype=torch.int32, device=x.device), nxt_u=torch.zeros(nchain, **f64),
                   nxt_p=torch.zeros(nchain, nx, **f64), nxt_rem=torch.zeros(nchain, dtype=torch.int32, device=x.device),
                   xstart=x.clone(), res_x=torch.zeros(nchain, nx, **f64), res_val=torch.zeros(nchain, 4, **f64),
-                  res_dsyn=torch.zeros_like(st["dsyn_new"]) if want_dsyn else None)
+                  res_dsyn=torch.zeros_like(st["dsyn_new"]) if want_dsyn else None, gsave=None, kick=None)
+        if deferred:
+            st.update(nxt_rem=None, gsave=torch.zeros(nchain, nx, **f64),
+                      kick=torch.zeros(nchain, dtype=torch.int32, device=x.device))
         return st
 
     def flow_state(self, x0, dt, bounds):

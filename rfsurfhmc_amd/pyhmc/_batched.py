@@ -439,7 +439,8 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
     if restart is not None and not hasattr(model, "flow_restart_state"):
         restart = None
     if restart is not None:
-        model.flow_restart_state(st, want_dsyn=fetch_syn)
+        deferred = bool(getattr(restart, "deferred", False))          # lengths / step sizes follow a call later (done())
+        model.flow_restart_state(st, want_dsyn=fetch_syn, deferred=deferred)
         finish = np.asarray(restart.rem0, dtype=np.int64).copy()      # step in which each chain completes (fresh at step 0)
         has_dep = np.zeros(nchain_all, dtype=bool)                    # deposit outstanding
         dep_rem = np.zeros(nchain_all, dtype=np.int64)                # length of the deposited trajectory
@@ -523,7 +524,12 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                 if rs_ is not None and len(rs_["idx"]):              # fresh in the step launched next
                     finish[np.asarray(rs_["idx"])] = steps + np.asarray(rs_["rem"], dtype=np.int64)
         if len(idx2):
-            restart.done(idx2, res2, acc2)
+            late = restart.done(idx2, res2, acc2)
+            if late is not None:                 # deferred form: the new step sizes and lengths, needed from step s + 2 on
+                ts = t(idx2)
+                st["dt"].index_copy_(0, ts, t(np.asarray(late["dt"], dtype=np.float64)))
+                st["rem"].index_copy_(0, ts, t(np.asarray(late["rem"], dtype=np.int32)))
+                dep_rem[idx2] = late["rem"]
             finish[idx2] = s + 1 + dep_rem[idx2]                     # fresh in step s + 1, already under way
             has_dep[idx2] = False
         if restart is not None and active() and not capped():
@@ -537,11 +543,14 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                         ts = t(np.asarray(sel, dtype=np.int64))
                         st["nxt_u"].index_copy_(0, ts, t(np.asarray(u, dtype=np.float64)))
                         st["nxt_p"].index_copy_(0, ts, t(pn))
-                        st["nxt_rem"].index_copy_(0, ts, t(np.asarray(rem, dtype=np.int32)))
+                        if rem is not None:
+                            st["nxt_rem"].index_copy_(0, ts, t(np.asarray(rem, dtype=np.int32)))
                         st["nxt_have"].index_fill_(0, ts, 1)
                         if side is not None:
                             ev = torch.cuda.Event(); ev.record(); deposited.append(ev)
-                    has_dep[sel] = True; dep_rem[sel] = rem
+                    has_dep[sel] = True
+                    if rem is not None:
+                        dep_rem[sel] = rem
         if dev.type == "cuda":
             ev = torch.cuda.Event(); ev.record(); uploaded.append(ev)
         if not active() or capped():

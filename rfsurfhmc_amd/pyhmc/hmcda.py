@@ -260,7 +260,7 @@ class HMCDualAveraging:
         return misfit[0] if nc == 1 else misfit
 
     @with_host_threads
-    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True):
         """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
         every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
         (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
@@ -293,15 +293,16 @@ class HMCDualAveraging:
         st["p"].copy_(t(self.rng.randn(allc, nx) * self._pscale))
         st["rem"].copy_(t(self._traj_len(dt)))
         st["fresh"].fill_(1)
-        def process_done(idx, res):
-            ok = res["ok"].astype(bool)
-            Hcur, Hnew, xend = res["Hcur"], res["Hnew"], res["x"]
-            Unew = np.where(ok, res["Unew"], np.inf)
-            dnew = res.get("dsyn_new")
+        pending = {}                                # chain -> (u, p) drawn ahead of time for it (restarts on the device)
+
+        def books(idx, ok, Hcur, Hnew, Unew, xend, dnew, u, acc=None):
+            """One completed trajectory per chain of idx: accept / reject (acc given: the device's decision with the same
+            u), sample slots, dual averaging of the step size (hmcda.py:329-345)."""
+            Unew = np.where(ok, Unew, np.inf)
             with np.errstate(over="ignore", invalid="ignore"):
                 alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
-            u = self.rng.rand([int(c) for c in idx])
-            acc = u < alpha
+            if acc is None:
+                acc = u < alpha
             # accepted end points (vectorised over the finished chains; one sample slot per chain and trajectory)
             ca = idx[acc]
             if len(ca):
@@ -315,7 +316,6 @@ class HMCDualAveraging:
                         okk = ok[acc][keep]
                         syndata[ck, slot] = np.where(okk[:, None], dnew[acc][keep], self.model.dobs[None, :])
                 i[ca] += 1; self.ii += len(ca)
-            # dual averaging for the chains that just finished a trajectory (hmcda.py:329-345)
             adapt = ncount[idx] < nd_
             m = ncount[idx] + 1.0
             fac = 1.0 / (m + self._t0)
@@ -333,16 +333,66 @@ class HMCDualAveraging:
                         print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
                             self.first_chain + c, i[c] / total, dt[c], Unew[k], i[c] / ncount[c]))
                 sys.stdout.flush()
+
+        def process_done(idx, res):
+            ok = res["ok"].astype(bool)
+            # acceptance draws (every iteration, hmcda.py:311): a chain that had its draws made early but failed -- the
+            # device leaves those to the host -- uses exactly those, the others draw now
+            early = np.array([int(c) in pending for c in idx], dtype=bool)
+            u = np.empty(len(idx))
+            if early.any():
+                u[early] = [pending[int(c)][0] for c in idx[early]]
+            if (~early).any():
+                u[~early] = self.rng.rand([int(c) for c in idx[~early]])
+            books(idx, ok, res["Hcur"], res["Hnew"], res["Unew"], res["x"], res.get("dsyn_new"), u)
             restart = [int(c) for c in idx if i[c] < total]
             rs = None
             if restart:
-                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, dt=dt[restart],
-                          rem=self._traj_len(dt[restart]))
+                fresh_p = [c for c in restart if c not in pending]
+                drawn = dict(zip(fresh_p, self.rng.randn(fresh_p, nx) * self._pscale)) if fresh_p else {}
+                pr = np.stack([pending[c][1] if c in pending else drawn[c] for c in restart])
+                rs = dict(idx=restart, p=pr, dt=dt[restart], rem=self._traj_len(dt[restart]))
+            for c in idx:
+                pending.pop(int(c), None)
             return x[idx], rs
+
+        # Restarts on the device, deferred form (rfs_flow_step2 with gsave / kick): the acceptance draw and the next
+        # momentum never depend on the trajectory (hmcda.py:311, :236) and are drawn one step ahead; the next step size
+        # does (dual averaging), so the device accepts / rejects, starts the chain on its new momentum and evaluates the
+        # start model at once, while the first half kick waits one call for dt and L from the host.
+        sampler = self
+
+        class Restart:
+            rem0 = self._traj_len(dt)
+            deferred = True
+
+            @staticmethod
+            def predraw(cands):
+                sel = cands[i[cands] + 1 < total]
+                if len(sel) == 0:
+                    return sel, None, None, None
+                cl = [int(c) for c in sel]
+                u = sampler.rng.rand(cl)
+                pn = sampler.rng.randn(cl, nx) * sampler._pscale
+                for k, c in enumerate(cl):
+                    pending[c] = (u[k], pn[k])
+                return sel, u, pn, None
+
+            @staticmethod
+            def done(idx, res, accepted):
+                ok = np.ones(len(idx), dtype=bool)
+                books(idx, ok, res["Hcur"], res["Hnew"], res["Unew"], res["x"], res.get("dsyn_new"), None, acc=accepted)
+                for c in idx:
+                    pending.pop(int(c), None)
+                return dict(dt=dt[idx], rem=sampler._traj_len(dt[idx]))
+
+            @staticmethod
+            def withdraw(idx):                      # nothing to rewind: process_done uses the early draws
+                pass
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
                                    fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
-                                   step_hook=step_hook)
+                                   step_hook=step_hook, restart=Restart if device_restart else None)
         self.finished = not bool(np.any(i < total))
         self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written

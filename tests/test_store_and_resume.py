@@ -63,6 +63,11 @@ def _toy_flow_step(self, st):
     m = torch.from_numpy(self.m)
     x, p, dt, rem, fresh = st["x"], st["p"], st["dt"], st["rem"], st["fresh"]
     run = (fresh == 0) & (rem > 0) & (st["ok"] == 1)
+    defer = st.get("kick") is not None
+    if defer:                                    # the half kick a deferred start left open
+        kk = run & (st["kick"] == 1)
+        p[kk] = p[kk] - 0.5 * dt[kk, None] * st["gsave"][kk]
+        st["kick"][run] = 0
     x[run] = x[run] + dt[run, None] * p[run]
     g = x - m
     U = 0.5 * (g * g).sum(1)
@@ -74,7 +79,10 @@ def _toy_flow_step(self, st):
         st["Hcur"][fr] = U[fr] + 0.5 * (p[fr] * p[fr]).sum(1)
         st["Hnew"][fr] = float("inf")
         st["dsyn_cur"][fr] = x[fr]; st["dsyn_new"][fr] = x[fr]
-        p[fr] = p[fr] - 0.5 * dt[fr, None] * g[fr]
+        if defer:
+            st["gsave"][fr] = g[fr]; st["kick"][fr] = (~fail[fr]).to(torch.int32)
+        else:
+            p[fr] = p[fr] - 0.5 * dt[fr, None] * g[fr]
         fresh[fr] = 0
         st["ok"][fr] = (~fail[fr]).to(torch.int32)
         ff = fr & fail
@@ -105,16 +113,20 @@ def _toy_flow_step(self, st):
                     st["res_dsyn"][au] = x[au]
                 rej = au & ~acc
                 x[rej] = st["xstart"][rej]
-                p[au] = st["nxt_p"][au]; rem[au] = st["nxt_rem"][au]; fresh[au] = 1
+                p[au] = st["nxt_p"][au]; fresh[au] = 1
+                rem[au] = st["nxt_rem"][au] if st.get("nxt_rem") is not None else (1 << 30)
                 st["done"][au] = 2; st["done"][acc] = 3
                 st["nxt_have"][au] = 0
 
 
-def _toy_flow_restart_state(self, st, want_dsyn=False):
+def _toy_flow_restart_state(self, st, want_dsyn=False, deferred=False):
     n, nx = st["x"].shape
     z = lambda *sh: torch.zeros(*sh, dtype=torch.float64)
     st.update(nxt_have=torch.zeros(n, dtype=torch.int32), nxt_u=z(n), nxt_p=z(n, nx), nxt_rem=torch.zeros(n, dtype=torch.int32),
-              xstart=st["x"].clone(), res_x=z(n, nx), res_val=z(n, 4), res_dsyn=z(n, nx) if want_dsyn else None)
+              xstart=st["x"].clone(), res_x=z(n, nx), res_val=z(n, 4), res_dsyn=z(n, nx) if want_dsyn else None,
+              gsave=None, kick=None)
+    if deferred:
+        st.update(nxt_rem=None, gsave=z(n, nx), kick=torch.zeros(n, dtype=torch.int32))
     return st
 
 
@@ -217,10 +229,10 @@ def test_flow_schedule_bookkeeping_equals_batch(kind, tmp_path):
     b = _make(kind, tmp_path / "b"); mb = b.sample_flow(x_init=x0)
     c = _make(kind, tmp_path / "c"); mc = c.sample_flow(x_init=x0, pipeline=False)
     assert np.array_equal(ma, mb) and np.array_equal(ma, mc) and c.flow_steps <= b.flow_steps
-    if kind == "hmc":           # restarts on the device (early draws) against restarts by the host: same samples, fewer steps
-        d = _make(kind, tmp_path / "d"); md = d.sample_flow(x_init=x0, device_restart=False)
-        assert np.array_equal(ma, md) and np.array_equal(a.x_cache, d.x_cache) and b.flow_steps < d.flow_steps
-        assert np.array_equal(b.accept_ratio, d.accept_ratio)
+    # restarts on the device (early draws) against restarts by the host: same samples, fewer steps
+    d = _make(kind, tmp_path / "d"); md = d.sample_flow(x_init=x0, device_restart=False)
+    assert np.array_equal(ma, md) and np.array_equal(a.x_cache, d.x_cache) and b.flow_steps < d.flow_steps
+    assert np.array_equal(b.accept_ratio, d.accept_ratio)
     assert np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.syndata, b.syndata)
     assert np.array_equal(a.accept_ratio, b.accept_ratio)
     if kind == "hmcda":
@@ -247,7 +259,8 @@ def test_host_threads_caps_and_restores():
     assert torch.get_num_threads() == before
 
 
-def test_device_restarts_with_failing_trajectories_keep_the_reference_draw_order():
+@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
+def test_device_restarts_with_failing_trajectories_keep_the_reference_draw_order(kind):
     """Trajectories that fail skip the acceptance draw (hmc.py:156,173,177,179).  With restarts on the device that draw
     and the next L and momentum are made one step before a trajectory completes -- so a chain that fails in its last
     two steps has drawn too much, and its stream must be rewound.  40 chains of which a good part fail now and then:
@@ -258,7 +271,7 @@ def test_device_restarts_with_failing_trajectories_keep_the_reference_draw_order
     runs = {}
     for name, kw in (("batch", None), ("flow_host", dict(device_restart=False)), ("flow_dev", dict(device_restart=True)),
                      ("flow_dev_sync", dict(device_restart=True, pipeline=False))):
-        smp = _make("hmc", None, fail_above=1.0, nchains=40)
+        smp = _make(kind, None, fail_above=1.0, nchains=40)
         mis = smp.sample(x_init=x0) if kw is None else smp.sample_flow(x_init=x0, **kw)
         runs[name] = (mis, smp.x_cache.copy(), smp.accept_ratio.copy(), smp)
     base = runs["batch"]
@@ -267,4 +280,5 @@ def test_device_restarts_with_failing_trajectories_keep_the_reference_draw_order
         assert np.array_equal(runs[name][0], base[0]), name
         assert np.array_equal(runs[name][1], base[1]) and np.array_equal(runs[name][2], base[2]), name
     assert runs["flow_dev"][3].flow_steps < runs["flow_host"][3].flow_steps
-    assert runs["flow_dev"][3].flow_withdrawn > 0 and runs["flow_dev_sync"][3].flow_withdrawn > 0      # the rewind was exercised
+    if kind == "hmc":
+        assert runs["flow_dev"][3].flow_withdrawn > 0 and runs["flow_dev_sync"][3].flow_withdrawn > 0  # the rewind was exercised
