@@ -511,8 +511,9 @@ def run_rank(args):
                    "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
                    "step": ("one leapfrog step of every chain via rfs_flow_step (drift + mirror, misfit+gradient, kick)"
                             if cfg["sampler"] is None else
-                            "one device step of HMCDualAveraging.sample_flow (host accept/reject + dual averaging "
-                            "overlapped); value counts only chains inside a trajectory"),
+                            "one device step of HMCDualAveraging.sample_flow (accept / reject and restart on the device from "
+                            "draws made ahead, dual averaging on the host beside the steps); value counts only chains "
+                            "inside a trajectory"),
                    "parallelism": f"independent chains x{world}" + (" -- FUNCTIONAL CHECK: all ranks share GPU 0, gloo "
                                                                     "collectives; not a measurement" if shared else ""),
                    "root_search_failures": nfail},
