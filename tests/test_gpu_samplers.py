@@ -323,3 +323,31 @@ def test_flow_step2_accepts_rejects_and_restarts_like_the_host(golden):
     joint.flow_step(b); torch.cuda.synchronize()
     assert np.array_equal(b["res_val"].cpu().numpy(), rv) and int(b["fresh"].sum()) == 0
     assert np.array_equal(b["xstart"].cpu().numpy()[dep], xb[dep]) and np.isinf(b["Hnew"].cpu().numpy()[dep]).all()
+
+
+@pytest.mark.parametrize("kind", ["hmc", "da"])
+def test_flow_with_device_restarts_at_scale_equals_the_synchronous_host_path(kind, golden):
+    """2048 chains: restarts on the device, results fetched and deposits made on a side stream beside the running step --
+    against the same run with every step followed by a blocking fetch and the host doing the accept / reject
+    (pipeline=False, device_restart=False).  Any race between the streams would show as a differing sample."""
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    g = golden["sampler_hybrid"]
+    nc = 2048 if kind == "hmc" else 256
+    rng = np.random.default_rng(21)
+    x0 = np.clip(g["x0"][None, :] * (1 + 0.02 * rng.standard_normal((nc, len(g["x0"])))), g["bounds"][:, 0], g["bounds"][:, 1])
+
+    def mk():
+        if kind == "hmc":
+            return HamitonianMC(_joint(g), g["bounds"], 0.05, [5, 20], 2, 991206, 4, 2, myrank=0, name="t", outdir=None,
+                                nchains=nc, verbose=False)
+        # (dual averaging lets a chain whose first trajectories are rejected shrink dt, hence lengthen L = lambda / dt: capped)
+        return HMCDualAveraging(_joint(g), g["bounds"], 0.05, 10, 2, 0.65, 991206, 3, 12, myrank=0, name="t", outdir=None,
+                                nchains=nc, verbose=False, L_cap=30)
+    a = mk(); ma = a.sample_flow(x_init=x0, pipeline=False, device_restart=False, max_steps=6000)   # (bounded: never hangs)
+    b = mk(); mb = b.sample_flow(x_init=x0, max_steps=6000)
+    assert a.finished and b.finished, (a.flow_steps, b.flow_steps)
+    assert np.array_equal(ma, mb) and np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.syndata, b.syndata)
+    assert np.array_equal(a.naccepted, b.naccepted) and np.array_equal(a.ntrajectories, b.ntrajectories)
+    if kind == "da":
+        assert np.array_equal(a.dt_final, b.dt_final)
