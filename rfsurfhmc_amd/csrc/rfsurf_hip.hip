@@ -51,6 +51,8 @@ struct rfs_ctx {
     size_t rf_scratch_budget = (size_t)4 << 30;   // bytes of pass-A row scratch (Rs) per chain tile of the fused gradient
     // user/main stream; SWD search stream; CU-partitioned pair (search on one half of the chip, RF on the other)
     hipStream_t stream = nullptr, stream2 = nullptr, stream2m = nullptr, stream3 = nullptr;
+    hipStream_t stream_l = nullptr;     // Love root search beside the Rayleigh one (unpartitioned steps)
+    hipEvent_t ev_lf = nullptr, ev_lj = nullptr;
     bool own_stream = false;
     int early_eigen = -1;      // periods whose eigenfunction kernels run early on the RF half: -1 automatic, 0 off
     int cu_split = 1;          // 0: never partition; 1/2: partition (contiguous / even-odd mask bits) when the
@@ -74,7 +76,7 @@ struct rfs_ctx {
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
-    Buf mdlc, mdlSR, mdlL, sphR, sphL;   // per-family search models / bldsph arrays (sphere, Love)
+    Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
     // leapfrog state
@@ -481,12 +483,70 @@ int launch_family_prep(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPl
     if (!(sphere && wantR) && !wantL) return RFS_OK;
     size_t nn = (size_t)n * nchain;
     if (sphere && wantR) { ENSURE(c, c->mdlSR, 4 * nn * sizeof(float)); ENSURE(c, c->sphR, 7 * nn * sizeof(double)); }
-    if (wantL) { ENSURE(c, c->mdlL, 5 * nn * sizeof(float)); if (sphere) ENSURE(c, c->sphL, 7 * nn * sizeof(double)); }
+    if (wantL) { ENSURE(c, c->mdlL, 5 * nn * sizeof(float)); ENSURE(c, c->mdlcL, 6 * nn * sizeof(double)); if (sphere) ENSURE(c, c->sphL, 7 * nn * sizeof(double)); }
     hipLaunchKernelGGL(k_prep_swd_family, dim3((nchain + 63) / 64), dim3(64), 0, s, nchain, n, c->mdl.as<float>(), sphere,
                        (int)wantR, (int)wantL, c->mdlSR.as<float>(), c->mdlc.as<double>(), c->sphR.as<double>(),
-                       c->mdlL.as<float>(), c->sphL.as<double>());
+                       c->mdlL.as<float>(), c->sphL.as<double>(), c->mdlcL.as<double>());
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
+}
+
+// The lanes-per-item root search (k_swd_roots_split) for one wave family.  coop_ok: the cooperative blocks take the big
+// Rayleigh batches, so G is only needed up to SWD_LAT_MAX_ITEMS there.
+template <class F>
+int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, const float* mdl, const double* mdlc,
+                       int* sflag, int G) {
+    const int nitem = Q.nseq * nchain;
+    int spec_auto = 1;
+    if (G <= 0 && nitem <= SWD_LAT_MAX_ITEMS) {
+        // latency mode: one item per wavefront while the device has room for it (no two items' state machines diverging
+        // inside a wavefront), then two, then four; 4 / 2 wavefronts per block look ahead in the scan
+        if (nitem <= 256) { G = 64; spec_auto = 4; }
+        else if (nitem <= 1152) { G = 32; spec_auto = 4; }
+        else { G = 16; spec_auto = 2; }
+    } else if (G <= 0) {    // about one wave per SIMD (1024 of them): G = 65536 / items, within [4, 32]
+        G = 4;
+        while (G < 32 && (size_t)nitem * G * 2 <= 65536 && 2 * G <= n - 1) G *= 2;
+    }
+    size_t lds = (size_t)(n - 1) * F::NENT * (64 / G) * sizeof(double);
+    while (G > 1 && G < 64 && (lds > 60 * 1024 || (n - 1 + G - 1) / G > 8)) {
+        G *= 2; lds = (size_t)(n - 1) * F::NENT * (64 / G) * sizeof(double);
+    }
+    if (G == 1) return 1;                    // caller falls back to the lane-per-item kernel
+    int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
+    dim3 grid((nitem + NG - 1) / NG);
+    // few items (the device is mostly idle): cut the vector recurrence into segments that run side by side on the
+    // group's lanes -- 4 segments need 1 + 3 NV lanes, 2 need 1 + NV
+    int nseg = c->swd_segments;
+    if (nseg < 0) nseg = (nitem <= SWD_LAT_MAX_ITEMS) ? (G >= 16 && n - 1 >= 8 ? 4 : (G >= 8 && n - 1 >= 4 ? 2 : 1)) : 1;
+    if ((nseg == 4 && G < 16) || (nseg == 2 && G < 8) || (nseg != 2 && nseg != 4)) nseg = 1;
+    // ... and let 4 wavefronts per block look ahead in the scan
+    int spec = c->swd_speculate;
+    if (spec < 0) spec = spec_auto;
+    if (spec != 2 && spec != 4) spec = 1;
+    auto lds_of = [&](int sp) {
+        return (size_t)sp * (lds + (size_t)(2 + F::NV * (nseg - 1)) * F::NV * NG * sizeof(double)) +
+               (sp > 1 ? (size_t)2 * sp * NG * sizeof(double) : 0);
+    };
+    while (spec > 1 && lds_of(spec) > 60 * 1024) spec /= 2;
+    size_t lds_s = lds_of(spec);
+#define RFS_LAUNCH_SPLIT3(LPL, NSEG, SPEC)                                                                          \
+    hipLaunchKernelGGL((k_swd_roots_split<F, LPL, NSEG, SPEC>), grid, dim3(64 * SPEC), lds_s, s, nchain, n, G, Q,   \
+                       mdl, mdlc, c->croot.as<double>(), sflag)
+#define RFS_LAUNCH_SPLIT2(LPL, NSEG)                                                                                \
+    do { if (spec == 4) RFS_LAUNCH_SPLIT3(LPL, NSEG, 4); else if (spec == 2) RFS_LAUNCH_SPLIT3(LPL, NSEG, 2);       \
+         else RFS_LAUNCH_SPLIT3(LPL, NSEG, 1); } while (0)
+#define RFS_LAUNCH_SPLIT(LPL)                                                                                       \
+    do { if (nseg == 4) RFS_LAUNCH_SPLIT2(LPL, 4); else if (nseg == 2) RFS_LAUNCH_SPLIT2(LPL, 2);                   \
+         else RFS_LAUNCH_SPLIT2(LPL, 1); } while (0)
+    if (lpl <= 1) RFS_LAUNCH_SPLIT(1);
+    else if (lpl <= 2) RFS_LAUNCH_SPLIT(2);
+    else if (lpl <= 4) RFS_LAUNCH_SPLIT(4);
+    else RFS_LAUNCH_SPLIT(8);
+#undef RFS_LAUNCH_SPLIT
+#undef RFS_LAUNCH_SPLIT2
+#undef RFS_LAUNCH_SPLIT3
+    return 0;
 }
 
 // root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
@@ -500,32 +560,26 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     ENSURE(c, c->sflag, (size_t)8 * nchain * sizeof(int));
     const float* mdlR = sphere ? c->mdlSR.as<float>() : c->mdl.as<float>();
     int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
-    if (roots && P.QL.nseq > 0) {       // Love: cheap 2-vector recurrence, lane = (sequence, chain)
-        KTimer t(c, RFS_K_SWD_ROOTS, s);
-        int nitem = P.QL.nseq * nchain;
-        hipLaunchKernelGGL(k_swd_roots<true>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, P.QL,
-                           c->mdlL.as<float>(), c->croot.as<double>(), sflagL);
-        HIPCHK(c, hipGetLastError());
+    // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
+    // the Rayleigh one (a fifth active stream inside the partitioned step would share a hardware queue)
+    const bool love_aside = roots && P.QL.nseq > 0 && Q.nseq > 0 && c->stream_l && s != c->stream2m && s != c->stream3;
+    if (roots && P.QL.nseq > 0) {       // Love: 2-vector recurrence, same lanes-per-item search as the small Rayleigh batches
+        hipStream_t sl = love_aside ? c->stream_l : s;
+        if (love_aside) { HIPCHK(c, hipEventRecord(c->ev_lf, s)); HIPCHK(c, hipStreamWaitEvent(sl, c->ev_lf, 0)); }
+        {
+            KTimer t(c, RFS_K_SWD_ROOTS, sl);
+            int nitem = P.QL.nseq * nchain;
+            if (n < 3 || launch_roots_split<SwdLoveFamily>(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(),
+                                                            sflagL, c->swd_lanes))
+                hipLaunchKernelGGL(k_swd_roots<true>, dim3((nitem + 63) / 64), dim3(64), 0, sl, nchain, n, P.QL,
+                                   c->mdlL.as<float>(), c->croot.as<double>(), sflagL);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (love_aside) HIPCHK(c, hipEventRecord(c->ev_lj, sl));
     }
     if (roots && Q.nseq > 0) {
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         int nitem = Q.nseq * nchain;
-        int G = c->swd_lanes;
-        int spec_auto = 1;
-        if (G <= 0 && nitem <= SWD_LAT_MAX_ITEMS) {
-            // latency mode: one item per wavefront while the device has room for it (no two items' state machines diverging
-            // inside a wavefront), then two, then four; 4 / 2 wavefronts per block look ahead in the scan
-            if (nitem <= 256) { G = 64; spec_auto = 4; }
-            else if (nitem <= 1152) { G = 32; spec_auto = 4; }
-            else { G = 16; spec_auto = 2; }
-        } else if (G <= 0) {    // about one wave per SIMD (1024 of them): G = 65536 / items, within [4, 32]
-            G = 4;
-            while (G < 32 && (size_t)nitem * G * 2 <= 65536 && 2 * G <= n - 1) G *= 2;
-        }
-        size_t lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
-        while (G > 1 && G < 64 && (lds > 60 * 1024 || (n - 1 + G - 1) / G > 8)) {
-            G *= 2; lds = (size_t)(n - 1) * SWD_NENT * (64 / G) * sizeof(double);
-        }
         CoopPlan cp = coop_plan(c, Q, nchain, n);
         if (cp.ok) {
             // cooperative producer/consumer blocks (64 items each): least total work, shortest serial path
@@ -543,46 +597,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             else if (cp.nch <= 8) RFS_LAUNCH_COOP(8);
             else RFS_LAUNCH_COOP(16);
 #undef RFS_LAUNCH_COOP
-        } else if (G == 1) {
+        } else if (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(), c->sflag.as<int>(),
+                                                             c->swd_lanes)) {
             hipLaunchKernelGGL(k_swd_roots<false>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
                                mdlR, c->croot.as<double>(), c->sflag.as<int>());
-        } else {
-            int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
-            dim3 grid((nitem + NG - 1) / NG);
-            // few items (the device is mostly idle): cut the vector recurrence into segments that run side by side on the
-            // group's lanes -- 4 segments need 16 lanes, 2 need 6
-            int nseg = c->swd_segments;
-            if (nseg < 0) nseg = (nitem <= SWD_LAT_MAX_ITEMS) ? (G >= 16 && n - 1 >= 8 ? 4 : (G >= 8 && n - 1 >= 4 ? 2 : 1)) : 1;
-            if ((nseg == 4 && G < 16) || (nseg == 2 && G < 8) || (nseg != 2 && nseg != 4)) nseg = 1;
-            // ... and let 4 wavefronts per block look ahead in the scan
-            int spec = c->swd_speculate;
-            if (spec < 0) spec = spec_auto;
-            if (spec != 2 && spec != 4) spec = 1;
-            auto lds_of = [&](int sp) {
-                return (size_t)sp * (lds + (size_t)(2 + 5 * (nseg - 1)) * 5 * NG * sizeof(double)) +
-                       (sp > 1 ? (size_t)2 * sp * NG * sizeof(double) : 0);
-            };
-            while (spec > 1 && lds_of(spec) > 60 * 1024) spec /= 2;
-            size_t lds_s = lds_of(spec);
-#define RFS_LAUNCH_SPLIT3(LPL, NSEG, SPEC)                                                                          \
-            hipLaunchKernelGGL((k_swd_roots_split<LPL, NSEG, SPEC>), grid, dim3(64 * SPEC), lds_s, s, nchain, n, G, Q,  \
-                               mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>())
-#define RFS_LAUNCH_SPLIT2(LPL, NSEG)                                                                                \
-            do { if (spec == 4) RFS_LAUNCH_SPLIT3(LPL, NSEG, 4); else if (spec == 2) RFS_LAUNCH_SPLIT3(LPL, NSEG, 2);   \
-                 else RFS_LAUNCH_SPLIT3(LPL, NSEG, 1); } while (0)
-#define RFS_LAUNCH_SPLIT(LPL)                                                                                       \
-            do { if (nseg == 4) RFS_LAUNCH_SPLIT2(LPL, 4); else if (nseg == 2) RFS_LAUNCH_SPLIT2(LPL, 2);               \
-                 else RFS_LAUNCH_SPLIT2(LPL, 1); } while (0)
-            if (lpl <= 1) RFS_LAUNCH_SPLIT(1);
-            else if (lpl <= 2) RFS_LAUNCH_SPLIT(2);
-            else if (lpl <= 4) RFS_LAUNCH_SPLIT(4);
-            else RFS_LAUNCH_SPLIT(8);
-#undef RFS_LAUNCH_SPLIT
-#undef RFS_LAUNCH_SPLIT2
-#undef RFS_LAUNCH_SPLIT3
         }
         HIPCHK(c, hipGetLastError());
     }
+    if (love_aside) HIPCHK(c, hipStreamWaitEvent(s, c->ev_lj, 0));
     if (kernels) {
         size_t ntot = (size_t)P.nitems * nchain;
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
@@ -860,6 +882,9 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     c->device = device; c->max_chains = max_chains; c->max_layers = max_layers;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream_l, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_lj, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) == hipSuccess;
@@ -877,7 +902,7 @@ void rfs_destroy(rfs_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    Buf* bufs[] = {&c->d_tw[0], &c->d_tw[1], &c->d_tw[2], &c->d_tw[3], &c->mdlSR, &c->mdlL, &c->sphR, &c->sphL, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
+    Buf* bufs[] = {&c->d_tw[0], &c->d_tw[1], &c->d_tw[2], &c->d_tw[3], &c->mdlSR, &c->mdlL, &c->mdlcL, &c->sphR, &c->sphL, &c->d_dobs, &c->x, &c->misfit, &c->grad, &c->dsyn, &c->flag, &c->lc, &c->cr,
                    &c->d_minv, &c->spec3, &c->ts3, &c->S0f, &c->S0p, &c->pulse_spec, &c->pulse_ts, &c->Pbuf, &c->Cres,
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
@@ -887,6 +912,9 @@ void rfs_destroy(rfs_ctx* c) {
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->stream_l) hipStreamDestroy(c->stream_l);
+    if (c->ev_lf) hipEventDestroy(c->ev_lf);
+    if (c->ev_lj) hipEventDestroy(c->ev_lj);
     if (c->stream2m) hipStreamDestroy(c->stream2m);
     if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->ev_join3) hipEventDestroy(c->ev_join3);
@@ -909,6 +937,7 @@ int rfs_set_stream(rfs_ctx* c, void* s) {
 int rfs_synchronize(rfs_ctx* c) {
     if (!c) return RFS_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream_l) HIPCHK(c, hipStreamSynchronize(c->stream_l));
     if (c->stream2m) HIPCHK(c, hipStreamSynchronize(c->stream2m));
     if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     HIPCHK(c, hipStreamSynchronize(c->stream));

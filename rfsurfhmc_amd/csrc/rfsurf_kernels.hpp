@@ -171,11 +171,12 @@ __global__ void k_prep_swd_b1(int nchain, int n, const double* thk, const double
 // Per-family SWD models, one thread per chain (sequential over the layers: the flattening accumulates depth).
 //   sphere && wantR : mdlSR = float32 flattened Rayleigh model for the root search (+ its f64 layer constants in
 //                     mdlc, replacing the flat ones), sphR = [7][n][chain] f64 bldsph arrays zd,za,zb,zrho,vtp,dtp,rtp
-//   wantL           : mdlL = [5][n][chain] float32 Love search model d,a,b,rho,a' (flat copy or flattened);
+//   wantL           : mdlL = [5][n][chain] float32 Love search model d,a,b,rho,a' (flat copy or flattened), mdlcL its
+//                     f64 layer constants;
 //                     a' = P velocity 1.732 vs of _LoveGroup (surfdisp.cpp:132); sphere: sphL like sphR
 __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ mdl, int sphere, int wantR, int wantL,
                                   float* __restrict__ mdlSR, double* __restrict__ mdlc, double* __restrict__ sphR,
-                                  float* __restrict__ mdlL, double* __restrict__ sphL)
+                                  float* __restrict__ mdlL, double* __restrict__ sphL, double* __restrict__ mdlcL)
 {
     int chain = blockIdx.x * blockDim.x + threadIdx.x;
     if (chain >= nchain) return;
@@ -208,6 +209,8 @@ __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ m
         } else {
             for (int m = 0; m < n; m++) { od[m * st] = d[m * st]; oa[m * st] = a[m * st]; ob[m * st] = b[m * st]; orr[m * st] = r[m * st]; }
         }
+        // f64 layer constants of the Love search model (the lanes-per-item search reads thickness, 1/beta, beta, rho, 1/rho)
+        for (int m = 0; m < n; m++) swd_store_layerc(mdlcL, m, chain, nchain, od[m * st], oa[m * st], ob[m * st], orr[m * st]);
     }
 }
 
@@ -539,33 +542,36 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
 // scan steps.  The results are then fed to the unchanged state machine in order, each only if the machine's next request
 // is bit for bit the point that was evaluated; anything else (sign change, clamp, limit) discards the rest.  The
 // sequence of (request, Delta) pairs the machine consumes is exactly that of the one-at-a-time search.
-template <int LPL, int NSEG, int SPEC>   // LPL layers per lane in registers: (n-1) <= G*LPL;  NSEG segments;  SPEC wavefronts
+// F: the secular function (SwdRayFamily / SwdLoveFamily, swd_math.hpp)
+template <class F, int LPL, int NSEG, int SPEC>   // LPL layers per lane in registers: (n-1) <= G*LPL;  NSEG segments;  SPEC wavefronts
 __global__ void __launch_bounds__(64 * SPEC)
 k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__ mdl,
                   const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
 {
     extern __shared__ double split_lds[];        // per wavefront: entries [grp][m][15], NSEG > 1: rows [grp][chain][5];
     const int NG = 64 / G;                       // then SPEC > 1: Delta [SPEC][NG], the points they belong to [SPEC][NG]
-    constexpr int NCHAINS = 1 + 5 * (NSEG - 1);
+    constexpr int NENT = F::NENT, NV = F::NV;
+    constexpr int NCHAINS = 1 + NV * (NSEG - 1);
     const int sw = SPEC > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const size_t per_wave = (size_t)(n - 1) * SWD_NENT * NG + (size_t)(NCHAINS + 1) * 5 * NG;   // (+1: the half-space vector)
+    const size_t per_wave = (size_t)(n - 1) * NENT * NG + (size_t)(NCHAINS + 1) * NV * NG;   // (+1: the half-space vector)
     double* ent_lds = split_lds + (size_t)sw * per_wave;
-    double* seg_lds = ent_lds + (size_t)(n - 1) * SWD_NENT * NG;
+    double* seg_lds = ent_lds + (size_t)(n - 1) * NENT * NG;
     double* del_lds = split_lds + (size_t)SPEC * per_wave;
     double* pt_lds = del_lds + SPEC * NG;
     const int seglen = (n - 1 + NSEG - 1) / NSEG;      // layers per segment (the shallowest one may be shorter)
     const int lane = threadIdx.x & 63, grp = lane / G, lg = lane - grp * G;
     // a group's numbers are contiguous, so that every read below is one base register + an immediate offset
-    double* const ent_g = ent_lds + (size_t)grp * (n - 1) * SWD_NENT;
-    double* const seg_g = seg_lds + (size_t)grp * (NCHAINS + 1) * 5;
-    double* const hs_g = seg_g + NCHAINS * 5;   // half-space start vector, built beside the layer entries by the group's last lane
+    double* const ent_g = ent_lds + (size_t)grp * (n - 1) * NENT;
+    double* const seg_g = seg_lds + (size_t)grp * (NCHAINS + 1) * NV;
+    double* const hs_g = seg_g + NCHAINS * NV;   // half-space start vector, built beside the layer entries by the group's last lane
     int item = blockIdx.x * NG + grp;            // (sequence, chain) handled by this group
     int seq = item / nchain, chain = item - seq * nchain;
     bool live = seq < Q.nseq;
     if (!live) { seq = 0; chain = 0; }
     const size_t s = (size_t)n * nchain;
-    SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
     const SwdSeq sq = Q.s[seq];
+    // Love group forward (_LoveGroup) searches with vp = 1.732 vs: array 4 of the Love model
+    SwdModel M{mdl + chain, mdl + (F::LOVE && sq.alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
     const double* tp = sq.t; const double sc = sq.scale;
     auto T = [&](int k) { return tp[k] * sc; };
     double* cr = croot + (size_t)sq.croot_off * nchain + chain;
@@ -596,86 +602,88 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
             for (int q = 0; q < LPL; q++) {
                 int m = lg + q * G;
                 if (m < n - 1) {
-                    double ent[SWD_NENT];
-                    swd_layer_entries(Lmine[q], wvno, wvno2, omega, iomega, ent);
+                    double ent[NENT];
+                    F::entries(Lmine[q], wvno, wvno2, omega, iomega, ent);
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) ent_g[m * SWD_NENT + i] = ent[i];
+                    for (int i = 0; i < NENT; i++) ent_g[m * NENT + i] = ent[i];
                 }
             }
             if (lg == G - 1) {               // the lane with the fewest layers (none when G > n - 1)
-                double e[5];
-                swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+                double e[NV];
+                F::halfspace(Lhalf, wvno, wvno2, omega, iomega, e);
 #pragma unroll
-                for (int j = 0; j < 5; j++) hs_g[j] = e[j];
+                for (int j = 0; j < NV; j++) hs_g[j] = e[j];
             }
         }
         __syncthreads();
         const double tt = -2.0 * wvno2;
         if constexpr (NSEG == 1) {
             if (act) {
-                double e[5];
+                double e[NV];
 #pragma unroll
-                for (int j = 0; j < 5; j++) e[j] = hs_g[j];
-                const double* pe = ent_g + (size_t)(n - 2) * SWD_NENT;
-                for (int m = n - 2; m >= 0; m--, pe -= SWD_NENT) {
-                    double cur[SWD_NENT];
+                for (int j = 0; j < NV; j++) e[j] = hs_g[j];
+                const double* pe = ent_g + (size_t)(n - 2) * NENT;
+                for (int m = n - 2; m >= 0; m--, pe -= NENT) {
+                    double cur[NENT];
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) cur[i] = pe[i];
-                    swd_apply_layer_raw(e, cur, tt);
-                    if ((m & 7) == 0) swd_rescale_pow2(e);
+                    for (int i = 0; i < NENT; i++) cur[i] = pe[i];
+                    F::apply(e, cur, tt);
+                    if ((m & 7) == 0) swd_rescale_pow2_n<NV>(e);
                 }
-                delta = swd_finish(e);
+                delta = swd_finish_n<NV>(e);
             }
         } else {
-            // lane lg < NCHAINS runs chain lg: chain 0 = half-space vector through the deepest segment, chain 1 + 5 (s - 1) + i
+            // lane lg < NCHAINS runs chain lg: chain 0 = half-space vector through the deepest segment, chain 1 + NV (s - 1) + i
             // = unit vector i through segment s (s = 1 .. NSEG - 1, counted from the deepest)
             if (act && lg < NCHAINS) {
-                const int sg = lg == 0 ? 0 : 1 + (lg - 1) / 5, ui = lg == 0 ? -1 : (lg - 1) % 5;
-                double e[5];
+                const int sg = lg == 0 ? 0 : 1 + (lg - 1) / NV, ui = lg == 0 ? -1 : (lg - 1) % NV;
+                double e[NV];
 #pragma unroll
-                for (int j = 0; j < 5; j++) e[j] = lg == 0 ? hs_g[j] : ((j == ui) ? 1.0 : 0.0);
+                for (int j = 0; j < NV; j++) e[j] = lg == 0 ? hs_g[j] : ((j == ui) ? 1.0 : 0.0);
                 int mhi = n - 2 - sg * seglen, mlo = mhi - seglen + 1;
                 if (mlo < 0) mlo = 0;
                 // two layers per trip, the next layer's entries on their way while this one is applied (the LDS round trip
                 // is as long as the 25 FMAs); reading one layer past the segment's end is harmless (clamped to layer 0)
-                const double* pe = ent_g + (size_t)mhi * SWD_NENT;
-                double ca[SWD_NENT], cb[SWD_NENT];
+                const double* pe = ent_g + (size_t)mhi * NENT;
+                double ca[NENT], cb[NENT];
 #pragma unroll
-                for (int i = 0; i < SWD_NENT; i++) ca[i] = pe[i];
+                for (int i = 0; i < NENT; i++) ca[i] = pe[i];
                 for (int m = mhi; m >= mlo; m -= 2) {
-                    const double* pb = pe - (m - 1 >= 0 ? SWD_NENT : 0);
+                    const double* pb = pe - (m - 1 >= 0 ? NENT : 0);
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) cb[i] = pb[i];
-                    swd_apply_layer_raw(e, ca, tt);
-                    pe = pb - (m - 2 >= 0 ? SWD_NENT : 0);
+                    for (int i = 0; i < NENT; i++) cb[i] = pb[i];
+                    F::apply(e, ca, tt);
+                    pe = pb - (m - 2 >= 0 ? NENT : 0);
 #pragma unroll
-                    for (int i = 0; i < SWD_NENT; i++) ca[i] = pe[i];
-                    if (m - 1 >= mlo) swd_apply_layer_raw(e, cb, tt);
+                    for (int i = 0; i < NENT; i++) ca[i] = pe[i];
+                    if (m - 1 >= mlo) F::apply(e, cb, tt);
                 }
 #pragma unroll
-                for (int j = 0; j < 5; j++) seg_g[lg * 5 + j] = e[j];
+                for (int j = 0; j < NV; j++) seg_g[lg * NV + j] = e[j];
             }
             __syncthreads();
             if (act) {
-                double e[5];
+                double e[NV];
 #pragma unroll
-                for (int j = 0; j < 5; j++) e[j] = seg_g[j];
-                swd_rescale_pow2(e);
+                for (int j = 0; j < NV; j++) e[j] = seg_g[j];
+                swd_rescale_pow2_n<NV>(e);
 #pragma unroll
                 for (int sg = 1; sg < NSEG; sg++) {
                     if (n - 2 - sg * seglen < 0) break;                  // fewer layers than segments
-                    double nw[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                    double nw[NV];
 #pragma unroll
-                    for (int i = 0; i < 5; i++) {
+                    for (int j = 0; j < NV; j++) nw[j] = 0.0;
 #pragma unroll
-                        for (int j = 0; j < 5; j++)
-                            nw[j] += e[i] * seg_g[(1 + 5 * (sg - 1) + i) * 5 + j];
+                    for (int i = 0; i < NV; i++) {
+#pragma unroll
+                        for (int j = 0; j < NV; j++)
+                            nw[j] += e[i] * seg_g[(1 + NV * (sg - 1) + i) * NV + j];
                     }
 #pragma unroll
-                    for (int j = 0; j < 5; j++) e[j] = nw[j];
-                    if (sg & 1) swd_rescale_pow2(e);         // the range is safe for two segments at a time
+                    for (int j = 0; j < NV; j++) e[j] = nw[j];
+                    if (sg & 1) swd_rescale_pow2_n<NV>(e);   // the range is safe for two segments at a time
                 }
-                delta = swd_finish(e);
+                delta = swd_finish_n<NV>(e);
             }
         }
         if constexpr (SPEC == 1) {

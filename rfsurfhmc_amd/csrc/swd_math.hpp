@@ -323,6 +323,60 @@ RFS_HD double swd_finish(const double e[5]) {
     return e[0] / t1;
 }
 
+// The two secular functions behind one interface for the lanes-per-item search (k_swd_roots_split): NENT numbers per
+// layer that do not depend on the propagated vector, an NV-vector carried through the layers, the start vector of the
+// half-space.  Rayleigh: the Dunkin form above.  Love (dltar1, surfdisp96.f:727-787): e <- e . [[cosq, y/mu], [mu z, cosq]]
+// with the same var-style scaling of the evanescent branch; as for Rayleigh the per-layer normalisation only rescales by a
+// positive number, so the raw recurrence with exact power-of-two rescales and one final e1 / max|e| gives the same
+// Delta up to rounding.
+struct SwdRayFamily {
+    static constexpr int NENT = SWD_NENT, NV = 5;
+    static constexpr bool LOVE = false;
+    static RFS_HD void entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent) {
+        swd_layer_entries(L, wvno, wvno2, omega, iomega, ent);
+    }
+    static RFS_HD void halfspace(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* e) {
+        swd_halfspace_e(L, wvno, wvno2, omega, iomega, e);
+    }
+    static RFS_HD void apply(double* e, const double* c, double tt) { swd_apply_layer_raw(e, c, tt); }
+};
+struct SwdLoveFamily {
+    static constexpr int NENT = 3, NV = 2;
+    static constexpr bool LOVE = true;
+    static RFS_HD void entries(const SwdLayerC& L, double wvno, double, double omega, double, double* ent) {
+        double ex, cosq, y, z, eh;
+        swd_trig_split(wvno, omega * L.ib, L.d, ex, cosq, y, z, eh);
+        ent[0] = cosq;
+        ent[1] = (L.rho * L.b * L.b) * z;                     // mu z
+        ent[2] = y * (L.irho * L.ib * L.ib);                  // y / mu
+    }
+    static RFS_HD void halfspace(const SwdLayerC& L, double wvno, double, double omega, double, double* e) {
+        const double xkb = omega * L.ib;
+        e[0] = L.rho * sqrt((wvno + xkb) * fabs(wvno - xkb));
+        e[1] = L.ib * L.ib;
+    }
+    static RFS_HD void apply(double* e, const double* c, double) {
+        const double n0 = e[0] * c[0] + e[1] * c[1], n1 = e[0] * c[2] + e[1] * c[0];
+        e[0] = n0; e[1] = n1;
+    }
+};
+template <int NV> RFS_HD void swd_rescale_pow2_n(double* e) {
+    double t1 = fabs(e[0]);
+#pragma unroll
+    for (int j = 1; j < NV; j++) t1 = fmax(t1, fabs(e[j]));
+    int ex = 0;
+    if (t1 > 0.0 && t1 < 1.0e300) frexp(t1, &ex);
+#pragma unroll
+    for (int j = 0; j < NV; j++) e[j] = ldexp(e[j], -ex);
+}
+template <int NV> RFS_HD double swd_finish_n(const double* e) {
+    double t1 = fabs(e[0]);
+#pragma unroll
+    for (int j = 1; j < NV; j++) t1 = fmax(t1, fabs(e[j]));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    return e[0] / t1;
+}
+
 // surfdisp96.f:375-396  gtsolh (single precision throughout)
 RFS_HD float swd_gtsolh(float a, float b) {
     float c = 0.95f * b;
