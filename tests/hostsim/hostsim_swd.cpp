@@ -5,6 +5,50 @@
 
 using namespace rfs;
 
+// The lanes-per-item kernel's arithmetic (k_swd_roots_split) on the host: per-layer entries through the family
+// interface, the recurrence either sequential or cut into nseg segments -- deepest segment from the half-space vector,
+// the others from the unit vectors -- folded afterwards.  love: SwdLoveFamily instead of SwdRayFamily.
+template <class F>
+static double family_delta(const std::vector<SwdLayerC>& LC, int n, double omega_in, double creq, int nseg)
+{
+    constexpr int NENT = F::NENT, NV = F::NV;
+    const double omega = omega_in < 1.0e-4 ? 1.0e-4 : omega_in, wvno = omega_in / creq, wvno2 = wvno * wvno;
+    const double iomega = 1.0 / omega, tt = -2.0 * wvno2;
+    std::vector<double> ent((size_t)(n - 1) * NENT);
+    for (int m = 0; m < n - 1; m++) F::entries(LC[m], wvno, wvno2, omega, iomega, &ent[(size_t)m * NENT]);
+    double e[NV];
+    F::halfspace(LC[n - 1], wvno, wvno2, omega, iomega, e);
+    if (nseg <= 1) {
+        for (int m = n - 2; m >= 0; m--) {
+            F::apply(e, &ent[(size_t)m * NENT], tt);
+            if ((m & 7) == 0) swd_rescale_pow2_n<NV>(e);
+        }
+        return swd_finish_n<NV>(e);
+    }
+    const int seglen = (n - 1 + nseg - 1) / nseg;
+    auto chain = [&](int sg, double* v) {
+        int mhi = n - 2 - sg * seglen, mlo = mhi - seglen + 1;
+        if (mlo < 0) mlo = 0;
+        for (int m = mhi; m >= mlo; m--) F::apply(v, &ent[(size_t)m * NENT], tt);
+    };
+    chain(0, e);
+    swd_rescale_pow2_n<NV>(e);
+    for (int sg = 1; sg < nseg; sg++) {
+        if (n - 2 - sg * seglen < 0) break;
+        double rows[NV][NV], nw[NV];
+        for (int i = 0; i < NV; i++) {
+            for (int j = 0; j < NV; j++) rows[i][j] = (i == j) ? 1.0 : 0.0;
+            chain(sg, rows[i]);
+        }
+        for (int j = 0; j < NV; j++) nw[j] = 0.0;
+        for (int i = 0; i < NV; i++)
+            for (int j = 0; j < NV; j++) nw[j] += e[i] * rows[i][j];
+        for (int j = 0; j < NV; j++) e[j] = nw[j];
+        if (sg & 1) swd_rescale_pow2_n<NV>(e);
+    }
+    return swd_finish_n<NV>(e);
+}
+
 extern "C" {
 
 int hs_swd_rootsearch(int n, const float* thk, const float* vp, const float* vs, const float* rho,
@@ -73,6 +117,31 @@ double hs_sregn96(int n, const float* thk, const float* vp, const float* vs, con
     for (int i = 0; i < n - 1; i++) { double sum = 0.0; for (int j = i + 1; j < n; j++) sum += dcdh[j]; dcdh[i] = sum; }
     dcdh[n - 1] = 0.0;
     return T.ugr;
+}
+
+int hs_rootsearch_family(int n, const float* thk, const float* vp, const float* vs, const float* rho,
+                         int kmax, const double* t, double* cg, int love, int sphere, int nseg)
+{
+    std::vector<float> w(4 * n);
+    const float *d = thk, *a = vp, *b = vs, *r = rho;
+    if (sphere) {
+        swd_flatten_f32(love != 0, n, thk, vp, vs, rho, 1, &w[0], &w[n], &w[2 * n], &w[3 * n], 1);
+        d = &w[0]; a = &w[n]; b = &w[2 * n]; r = &w[3 * n];
+    }
+    SwdModel M{d, a, b, r, 1, n};
+    std::vector<SwdLayerC> LC(n);
+    for (int m = 0; m < n; m++)
+        LC[m] = SwdLayerC{(double)d[m], 1.0 / (double)a[m], 1.0 / (double)b[m], (double)b[m], (double)r[m], 1.0 / (double)r[m]};
+    RootSearch rs;
+    auto T = [&](int k) { return t[k]; };
+    auto out = [&](int k, double v) { cg[k] = v; };
+    rs.begin(M, T, kmax);
+    while (!rs.done) {
+        double del = love ? family_delta<SwdLoveFamily>(LC, n, rs.omega, rs.creq, nseg)
+                          : family_delta<SwdRayFamily>(LC, n, rs.omega, rs.creq, nseg);
+        rs.advance(del, T, out);
+    }
+    return rs.flag;
 }
 
 // Love / spherical-earth variants --------------------------------------------------------------

@@ -132,6 +132,37 @@ def test_love_and_sphere_device_math(hs, golden):
     assert nroot > 100 and nexact >= 0.97 * nroot
 
 
+@pytest.mark.parametrize("nseg", [1, 2, 4])
+def test_family_form_of_the_search_rayleigh_and_love(hs, golden, nseg):
+    """The arithmetic of the lanes-per-item kernel (k_swd_roots_split) for both wave families on the host: per-layer
+    entries through SwdRayFamily / SwdLoveFamily, raw recurrence with power-of-two rescales, sequential or in nseg
+    segments started from unit vectors and folded.  Same flags as the compiled reference, flat roots within nevill's own
+    tolerance, almost all of them the very same float32 value as the plain form finds."""
+    g = golden["swd_love_sphere_reference"]
+    from oracle import oracle as O
+    H = hs["swd"]
+    nroot = nsame = 0
+    for name in sorted({k.split("/")[0] for k in g.files if k.endswith("/thk")}):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], np.ascontiguousarray(g[f"{name}/t"])
+        vp, rho, _, _ = O.empirical_relation(vs)
+        h, a, b, r = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)) for x in (thk, vp, vs, rho)]
+        n, nt = len(h), len(t)
+        for love, wt in ((0, "Rc"), (1, "Lc")):
+            for sph in (0, 1):
+                key = f"{name}/{wt}/{sph}"
+                if f"{key}/flag" not in g.files:
+                    continue
+                c0, c1 = np.zeros(nt), np.zeros(nt)
+                f0 = H.hs_rootsearch_general(n, F(h), F(a), F(b), F(r), nt, P(t), P(c0), love, sph)
+                f1 = H.hs_rootsearch_family(n, F(h), F(a), F(b), F(r), nt, P(t), P(c1), love, sph, nseg)
+                assert bool(f1) == bool(f0) == bool(g[f"{key}/flag"]), key
+                if not f1:
+                    continue
+                assert np.all(np.abs(c1 - c0) <= 1.2e-6 * np.abs(c0)), (key, nseg)
+                nroot += nt; nsame += int((c1 == c0).sum())
+    assert nroot > 500 and nsame >= 0.99 * nroot, (nroot, nsame)
+
+
 def test_fast_exp_and_sincos_accuracy(tmp_path):
     """fm_exp / fm_sincos (cplx.hpp: the transcendental functions of every layer sweep) against long double libm
     on the ranges they are used on: < 1 ulp (exp) and < 1.5 ulp (sin, cos); absolute error at multiples of pi/2."""
