@@ -514,6 +514,7 @@ int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSe
     }
     if (G == 1) return 1;                    // caller falls back to the lane-per-item kernel
     int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
+    if (lpl > 8 || lds > 60 * 1024) return 1;   // more than 8 layers per lane even with 64 lanes (> 513 layers): same fallback
     dim3 grid((nitem + NG - 1) / NG);
     // few items (the device is mostly idle): cut the vector recurrence into segments that run side by side on the
     // group's lanes -- 4 segments need 1 + 3 NV lanes, 2 need 1 + NV
