@@ -64,6 +64,7 @@ struct rfs_ctx {
     bool configured = false;
     int n = 0, mode = 0, ndata = 0;
     int ntw[4] = {0, 0, 0, 0};   // rows of the Rc, Rg, Lc, Lg blocks
+    bool rg_alias = false;       // tRg == tRc: the Rg block's pass at T reads the Rc block's items (make_plan)
     int sphere = 0;
     bool has_rf = false, has_swd = false;
     RfFreq f{};
@@ -71,6 +72,7 @@ struct rfs_ctx {
     Buf d_tw[4], d_dobs;
     // workspaces
     int swd_lanes = 0;     // lanes per chain in the root search (0 = pick from nchain / nlayer)
+    int share_rc_rg = 1;   // option "share_rc_rg": 0 = never alias the Rg block's central pass to the Rc block (tests)
     int swd_speculate = -1; // wavefronts per block that look ahead in the scan of the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     int swd_segments = -1; // segments of the vector recurrence in the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
@@ -428,19 +430,28 @@ struct SwdPlan {
 };
 
 SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, int sphere, int fwd,
-                  bool love_group_vp, const double* sphR, const double* sphL) {
+                  bool love_group_vp, const double* sphR, const double* sphL, bool alias_rg = false) {
     SwdPlan P;
     int off = 0;
-    int boff[4] = {0, 0, 0, 0};
+    int boff[4] = {0, 0, 0, 0}, boff1[4] = {0, 0, 0, 0}, boff2[4] = {0, 0, 0, 0};
     for (int type = 0; type < 4; type++) {
         if (nt[type] <= 0) continue;
         SwdSeqs& Q = (type < 2) ? P.QR : P.QL;
-        boff[type] = off;
         int alt = (type == 3 && love_group_vp) ? 1 : 0;
-        Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0, off, alt}; off += nt[type];
-        Q.nper_total += nt[type];
+        // alias_rg: the Rg block has the Rc block's periods.  Its pass at T (sregnpu's central pass, surfdisp.cpp:235-241)
+        // is then the very search and the very eigenfunction pass of the Rc block: it reads those items instead of
+        // repeating them (param.yaml's own set-up, tRc = tRg, saves a quarter of the Rayleigh work that way)
+        if (type == 1 && alias_rg && nt[0] == nt[1] && nt[0] > 0) {
+            boff[type] = boff[0];
+        } else {
+            boff[type] = off;
+            Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0, off, alt}; off += nt[type];
+            Q.nper_total += nt[type];
+        }
         if ((type & 1) && group_passes) {
+            boff1[type] = off;
             Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0 + 0.05, off, alt}; off += nt[type];
+            boff2[type] = off;
             Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0 - 0.05, off, alt}; off += nt[type];
             Q.nper_total += 2 * nt[type];
         }
@@ -448,7 +459,7 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
     P.nseq = P.QR.nseq + P.QL.nseq; P.nitems = off;
     for (int type = 0; type < 4; type++) {
         if (nt[type] <= 0) continue;
-        SwdBlk B{type, nt[type], boff[type], boff[type] + nt[type], boff[type] + 2 * nt[type], t[type]};
+        SwdBlk B{type, nt[type], boff[type], boff1[type], boff2[type], t[type]};
         P.R.b[P.R.nblk++] = B;
         P.R.nswd += nt[type];
     }
@@ -659,7 +670,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (c->sphere && c->ntw[0] + c->ntw[1] > 0) ENSURE(c, c->sphR, 7 * nn * sizeof(double));
         if (c->sphere && c->ntw[2] + c->ntw[3] > 0) ENSURE(c, c->sphL, 7 * nn * sizeof(double));
     }
-    SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>());
+    SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>(), c->rg_alias);
     const SwdSeqs& Q = P.QR;
     hipStream_t user = c->stream;
     // CU partition: the cooperative search occupies one CU per block (64 sequences); when that fits on half of the
@@ -974,6 +985,9 @@ int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
 
 int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!c || !name) return RFS_ERR_ARG;
+    if (!strcmp(name, "share_rc_rg")) {      // takes effect at the next rfs_joint_setup
+        c->share_rc_rg = value != 0; if (!c->share_rc_rg) c->rg_alias = false; return RFS_OK;
+    }
     if (!strcmp(name, "swd_speculate")) {
         if (value != -1 && value != 1 && value != 2 && value != 4) return fail(c, RFS_ERR_ARG, "swd_speculate must be -1, 1, 2 or 4");
         c->swd_speculate = value; return RFS_OK;
@@ -1183,6 +1197,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
         c->ntw[i] = ntw[i];
         if (ntw[i]) TRY(upload(c, c->d_tw[i], tw[i], (size_t)ntw[i] * sizeof(double)));
     }
+    c->rg_alias = c->share_rc_rg && ntw[0] > 0 && ntw[0] == ntw[1] && memcmp(tw[0], tw[1], (size_t)ntw[0] * sizeof(double)) == 0;
     ENSURE(c, c->d_dobs, (size_t)c->ndata * sizeof(double));
     if (dobs) HIPCHK(c, hipMemcpyAsync(c->d_dobs.p, dobs, (size_t)c->ndata * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else HIPCHK(c, hipMemsetAsync(c->d_dobs.p, 0, (size_t)c->ndata * sizeof(double), c->stream));
@@ -1269,7 +1284,8 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
         size_t nn = (size_t)n * nchain;
         if (c->sphere && ntw[0] + ntw[1] > 0) ENSURE(c, c->sphR, 7 * nn * sizeof(double));
         if (c->sphere && ntw[2] + ntw[3] > 0) ENSURE(c, c->sphL, 7 * nn * sizeof(double));
-        SwdPlan P = make_plan(ntw, tw, false, c->sphere, 1, true, c->sphR.as<double>(), c->sphL.as<double>());
+        SwdPlan P = make_plan(ntw, tw, false, c->sphere, 1, true, c->sphR.as<double>(), c->sphL.as<double>(),
+                              c->share_rc_rg && (c->rg_alias || (quirk && c->ntw[0] > 0)));
         TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
         TRY(launch_swd(c, c->stream, nchain, n, P, ntw[1] + ntw[3] > 0));
         ENSURE(c, c->ugr, 8);

@@ -240,3 +240,41 @@ def test_plain_c_client_of_the_abi(tmp_path):
     rf = np.array(out[3].split()[1:], dtype=float)
     np.testing.assert_allclose(rf, [1.750384485169e-04, 2.704993610476e-03, 2.454749574455e-02, 1.064170021474e-01,
                                     2.228427016323e-01, 2.188586786966e-01, 9.057466370315e-02, 1.807677009266e-02], rtol=1e-9)
+
+
+def test_rg_block_shares_the_rc_blocks_pass_when_periods_coincide(orc):
+    """tRg == tRc (param.yaml's own set-up): sregnpu's pass at T is the Rc block's search and eigenfunction pass, so the Rg
+    block reads those items (option share_rc_rg, default on).  Same numbers bit for bit as computing it again, and as
+    close to the oracle as before; different period lists are not shared."""
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    rng = np.random.default_rng(12)
+    vs, thk = _model(9, rng)
+    x0 = np.hstack((vs, thk))
+    xs = np.tile(x0, (6, 1)); xs[:, :9] = np.sort(xs[:, :9] * (0.98 + 0.04 * rng.random((6, 9))), axis=1)
+    t = np.linspace(6.0, 30.0, 7)
+
+    def run(share, tRg):
+        m = SurfWD(tRc=t, tRg=tRg)
+        d0, fl = m.forward(x0)
+        m.set_obsdata(d0 * 1.01)
+        ctx = m._ensure(9)
+        ctx.check(ctx.L.rfs_set_option(ctx.h, b"share_rc_rg", share))
+        m.set_obsdata(d0 * 1.01)                       # reconfigures the context with the option in force
+        out = m.misfit_and_grad(xs)
+        fwd = m.forward(xs[0])
+        return d0, out, fwd
+    d_on, on, f_on = run(1, t)
+    d_off, off, f_off = run(0, t)
+    assert np.array_equal(d_on, d_off) and np.array_equal(f_on[0], f_off[0])
+    for a, b in zip(on, off):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    o = orc.SurfWD(tRc=t, tRg=t); o.set_obsdata(d_on * 1.01)
+    for i in range(6):
+        mo, go, do, fo = o.misfit_and_grad(xs[i])
+        assert fo and rel(on[2][i], do) < 2e-6 and abs(on[0][i] - mo) <= 1e-5 * mo and rel(on[1][i], go) < 1e-4
+    # periods that differ in one entry: nothing to share, results still agree with the oracle
+    t2 = t.copy(); t2[3] += 0.25
+    d2, o2, _ = run(1, t2)
+    oo = orc.SurfWD(tRc=t, tRg=t2); oo.set_obsdata(d2 * 1.01)
+    mo, go, do, fo = oo.misfit_and_grad(xs[0])
+    assert fo and rel(o2[2][0], do) < 2e-6 and rel(o2[1][0], go) < 1e-4
