@@ -227,7 +227,8 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          scan ahead of time; the state machine still consumes them one by one and only where it asks
  *                          for exactly that point, so results are bit-identical.  -1 (default) = automatic.
  *   "share_rc_rg"          1 (default): when the Rg block has exactly the Rc block's periods, its pass at T (sregnpu's
- *                          central pass) reads the Rc block's roots and eigenfunctions instead of computing them again;
+ *                          central pass) reads the Rc block's roots and eigenfunctions instead of computing them again
+ *                          (Lg / Lc likewise);
  *                          0 = always compute it (set before rfs_joint_setup; results are bit-identical).
  *   "cu_split"             0 = RF kernels on the caller's stream, sharing CUs with the root search;
  *                          1 (default) / 2 = when the cooperative root search fits on half of the CUs, it and

@@ -65,6 +65,7 @@ struct rfs_ctx {
     int n = 0, mode = 0, ndata = 0;
     int ntw[4] = {0, 0, 0, 0};   // rows of the Rc, Rg, Lc, Lg blocks
     bool rg_alias = false;       // tRg == tRc: the Rg block's pass at T reads the Rc block's items (make_plan)
+    bool lg_alias = false;       // tLg == tLc likewise
     int sphere = 0;
     bool has_rf = false, has_swd = false;
     RfFreq f{};
@@ -430,7 +431,7 @@ struct SwdPlan {
 };
 
 SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, int sphere, int fwd,
-                  bool love_group_vp, const double* sphR, const double* sphL, bool alias_rg = false) {
+                  bool love_group_vp, const double* sphR, const double* sphL, bool alias_rg = false, bool alias_lg = false) {
     SwdPlan P;
     int off = 0;
     int boff[4] = {0, 0, 0, 0}, boff1[4] = {0, 0, 0, 0}, boff2[4] = {0, 0, 0, 0};
@@ -441,8 +442,11 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
         // alias_rg: the Rg block has the Rc block's periods.  Its pass at T (sregnpu's central pass, surfdisp.cpp:235-241)
         // is then the very search and the very eigenfunction pass of the Rc block: it reads those items instead of
         // repeating them (param.yaml's own set-up, tRc = tRg, saves a quarter of the Rayleigh work that way)
+        // (the same for Lg / Lc, except in libsurf.forward's form, where _LoveGroup searches with its own P velocity)
         if (type == 1 && alias_rg && nt[0] == nt[1] && nt[0] > 0) {
             boff[type] = boff[0];
+        } else if (type == 3 && alias_lg && !love_group_vp && nt[2] == nt[3] && nt[2] > 0) {
+            boff[type] = boff[2];
         } else {
             boff[type] = off;
             Q.s[Q.nseq++] = SwdSeq{t[type], nt[type], 1.0, off, alt}; off += nt[type];
@@ -670,7 +674,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (c->sphere && c->ntw[0] + c->ntw[1] > 0) ENSURE(c, c->sphR, 7 * nn * sizeof(double));
         if (c->sphere && c->ntw[2] + c->ntw[3] > 0) ENSURE(c, c->sphL, 7 * nn * sizeof(double));
     }
-    SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>(), c->rg_alias);
+    SwdPlan P = make_plan(c->ntw, tw, true, c->sphere, 0, false, c->sphR.as<double>(), c->sphL.as<double>(), c->rg_alias,
+                          c->lg_alias);
     const SwdSeqs& Q = P.QR;
     hipStream_t user = c->stream;
     // CU partition: the cooperative search occupies one CU per block (64 sequences); when that fits on half of the
@@ -986,7 +991,7 @@ int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
 int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!c || !name) return RFS_ERR_ARG;
     if (!strcmp(name, "share_rc_rg")) {      // takes effect at the next rfs_joint_setup
-        c->share_rc_rg = value != 0; if (!c->share_rc_rg) c->rg_alias = false; return RFS_OK;
+        c->share_rc_rg = value != 0; if (!c->share_rc_rg) c->rg_alias = c->lg_alias = false; return RFS_OK;
     }
     if (!strcmp(name, "swd_speculate")) {
         if (value != -1 && value != 1 && value != 2 && value != 4) return fail(c, RFS_ERR_ARG, "swd_speculate must be -1, 1, 2 or 4");
@@ -1198,6 +1203,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
         if (ntw[i]) TRY(upload(c, c->d_tw[i], tw[i], (size_t)ntw[i] * sizeof(double)));
     }
     c->rg_alias = c->share_rc_rg && ntw[0] > 0 && ntw[0] == ntw[1] && memcmp(tw[0], tw[1], (size_t)ntw[0] * sizeof(double)) == 0;
+    c->lg_alias = c->share_rc_rg && ntw[2] > 0 && ntw[2] == ntw[3] && memcmp(tw[2], tw[3], (size_t)ntw[2] * sizeof(double)) == 0;
     ENSURE(c, c->d_dobs, (size_t)c->ndata * sizeof(double));
     if (dobs) HIPCHK(c, hipMemcpyAsync(c->d_dobs.p, dobs, (size_t)c->ndata * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else HIPCHK(c, hipMemsetAsync(c->d_dobs.p, 0, (size_t)c->ndata * sizeof(double), c->stream));

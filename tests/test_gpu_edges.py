@@ -253,8 +253,8 @@ def test_rg_block_shares_the_rc_blocks_pass_when_periods_coincide(orc):
     xs = np.tile(x0, (6, 1)); xs[:, :9] = np.sort(xs[:, :9] * (0.98 + 0.04 * rng.random((6, 9))), axis=1)
     t = np.linspace(6.0, 30.0, 7)
 
-    def run(share, tRg):
-        m = SurfWD(tRc=t, tRg=tRg)
+    def run(share, tRg, love=False):
+        m = SurfWD(tRc=t, tRg=tRg, tLc=t, tLg=t) if love else SurfWD(tRc=t, tRg=tRg)
         d0, fl = m.forward(x0)
         m.set_obsdata(d0 * 1.01)
         ctx = m._ensure(9)
@@ -272,6 +272,12 @@ def test_rg_block_shares_the_rc_blocks_pass_when_periods_coincide(orc):
     for i in range(6):
         mo, go, do, fo = o.misfit_and_grad(xs[i])
         assert fo and rel(on[2][i], do) < 2e-6 and abs(on[0][i] - mo) <= 1e-5 * mo and rel(on[1][i], go) < 1e-4
+    # all four blocks on the same periods: both group blocks share
+    d4, o4, f4 = run(1, t, love=True)
+    d4n, o4n, f4n = run(0, t, love=True)
+    assert np.array_equal(d4, d4n) and np.array_equal(f4[0], f4n[0])
+    for a, b in zip(o4, o4n):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
     # periods that differ in one entry: nothing to share, results still agree with the oracle
     t2 = t.copy(); t2[3] += 0.25
     d2, o2, _ = run(1, t2)
