@@ -566,7 +566,7 @@ int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSe
 }
 
 // root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
-// eigen_mode 0: every item; 1: EARLY launch of the Rayleigh items [0, early_items) beside a running search;
+// eigen_mode 0: every item; 3 / 4: the Rayleigh / the Love items only; 1: EARLY launch of the Rayleigh items [0, early_items) beside a running search;
 // 2: MOP-UP of what the early launch left (k_swd_eigen)
 int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, bool kernels, bool roots = true,
                int eigen_mode = 0, int early_items = 0) {
@@ -578,9 +578,10 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
     // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
     // the Rayleigh one (a fifth active stream inside the partitioned step would share a hardware queue)
-    const bool love_aside = roots && P.QL.nseq > 0 && Q.nseq > 0 && c->stream_l && s != c->stream2m && s != c->stream3;
+    // -- inside it the Love search goes to the RF half's stream, ahead of the RF sweeps: the Rayleigh search keeps its half
+    const bool love_aside = roots && P.QL.nseq > 0 && Q.nseq > 0 && c->stream_l && s != c->stream3;
     if (roots && P.QL.nseq > 0) {       // Love: 2-vector recurrence, same lanes-per-item search as the small Rayleigh batches
-        hipStream_t sl = love_aside ? c->stream_l : s;
+        hipStream_t sl = !love_aside ? s : (s == c->stream2m ? c->stream3 : c->stream_l);
         if (love_aside) { HIPCHK(c, hipEventRecord(c->ev_lf, s)); HIPCHK(c, hipStreamWaitEvent(sl, c->ev_lf, 0)); }
         {
             KTimer t(c, RFS_K_SWD_ROOTS, sl);
@@ -620,7 +621,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         }
         HIPCHK(c, hipGetLastError());
     }
-    if (love_aside) HIPCHK(c, hipStreamWaitEvent(s, c->ev_lj, 0));
+    // (in the partitioned step the caller's stream joins the RF half's stream, which carries the Love search, anyway)
+    if (love_aside && s != c->stream2m) HIPCHK(c, hipStreamWaitEvent(s, c->ev_lj, 0));
     if (kernels) {
         size_t ntot = (size_t)P.nitems * nchain;
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
@@ -631,14 +633,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)),            \
                            dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(),     \
                            SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (int)(EL1), EARLY, EDONE)
-        int* ed = eigen_mode ? c->edone.as<int>() : nullptr;
-        if (P.QR.nper_total > 0) {
+        int* ed = (eigen_mode == 1 || eigen_mode == 2) ? c->edone.as<int>() : nullptr;
+        if (P.QR.nper_total > 0 && eigen_mode != 4) {
             const int el1 = eigen_mode == 1 ? early_items : P.QR.nper_total;
             const int early = eigen_mode == 1;
             if (sphere) RFS_LAUNCH_EIGEN(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>(), el1, early, ed);
             else RFS_LAUNCH_EIGEN(false, false, P.QR, nullptr, c->sflag.as<int>(), el1, early, ed);
         }
-        if (P.QL.nper_total > 0 && eigen_mode != 1) {
+        if (P.QL.nper_total > 0 && eigen_mode != 1 && eigen_mode != 3) {
             if (sphere) RFS_LAUNCH_EIGEN(true, true, P.QL, c->sphL.as<double>(), sflagL, P.QL.nper_total, 0, (int*)nullptr);
             else RFS_LAUNCH_EIGEN(true, false, P.QL, nullptr, sflagL, P.QL.nper_total, 0, (int*)nullptr);
         }
@@ -783,6 +785,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         early_items = std::max(0, std::min(early_items, npmax - 1));
         if (timed) HIPCHK(c, hipEventRecord(cal->ev[2 * cal->stage], user));
     }
+    const bool a_eigen = part && P.QL.nseq > 0 && P.QR.nseq > 0;
     bool rf_reduced = false;
     if (early_items > 0) {
         const size_t ntot = (size_t)P.nitems * nchain;
@@ -810,6 +813,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
         TRY(launch_swd(c, ss, nchain, n, P, !part));
+        // partitioned step with a Love block: the RF half carries the Love search ahead of its sweeps and ends last, so the
+        // Rayleigh eigenfunction pass runs on the search half right behind the search instead of waiting for the join
+        if (a_eigen) TRY(launch_swd(c, ss, nchain, n, P, true, false, 3));
         HIPCHK(c, hipEventRecord(c->ev_join, ss));
     } else if (c->has_swd) {
         TRY(launch_swd(c, user, nchain, n, P, true));
@@ -862,7 +868,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
     if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
-    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, early_items > 0 ? 2 : 0));   // (rest of the) eigenfunction pass, whole chip
+    if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, a_eigen ? 4 : (early_items > 0 ? 2 : 0)));   // (rest of the) eigenfunction pass, whole chip
     {
         KTimer t(c, RFS_K_COMBINE, c->stream);
         const SwdRows& R = P.R;
