@@ -390,23 +390,23 @@ def run_rank(args):
                                nchains=nchain, verbose=False, store_syn=False)
             mk = {}
             act = torch.zeros((), dtype=torch.int64, device=dev)
-            w2 = 25
+            w2, K2 = 25, max(K, 40)                  # (a window of at least 40 device steps: one host hiccup weighs less)
 
             def hook2(s, stt):
                 if s == 1:                                   # torch loads these kernels on first use (~30 ms): not in the window
                     act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum()); act.zero_()
                 if s == w2:
                     torch.cuda.synchronize(); mk["t0"] = time.perf_counter()
-                if w2 <= s < w2 + K:
+                if w2 <= s < w2 + K2:
                     act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum())
-                if s == w2 + K:
+                if s == w2 + K2:
                     ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); mk["t1"] = time.perf_counter()
 
-            smp.sample_flow(x_init=xs, max_steps=w2 + K + 1, step_hook=hook2)
+            smp.sample_flow(x_init=xs, max_steps=w2 + K2 + 1, step_hook=hook2)
             el2 = mk["t1"] - mk["t0"]
             extra["sampler_flow"] = {
-                "value": int(act.item()) / el2, "unit": "evals/s", "ms_per_step": el2 / K * 1e3,
-                "chains_in_a_trajectory_per_step": int(act.item()) / K,
+                "value": int(act.item()) / el2, "unit": "evals/s", "steps": K2, "ms_per_step": el2 / K2 * 1e3,
+                "chains_in_a_trajectory_per_step": int(act.item()) / K2,
                 "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): every chain's acceptance draw, "
                         "next L and momentum come from its own MT19937 stream on the host, ahead of time; the device accepts / "
                         "rejects and starts the next trajectory itself (rfs_flow_step2); books and samples are kept on the "
