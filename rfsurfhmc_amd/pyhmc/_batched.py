@@ -399,7 +399,10 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max
     trajectory) and ``withdraw(idx)`` (chains that failed with a deposit outstanding: rewind their streams, they come
     through ``process_done`` next).  Such chains evaluate their new start model in the very next step instead of sitting
     one out; the sequence of draws and decisions per chain is unchanged."""
-    with host_threads():                         # see there: the host side must not spin up torch's whole thread pool
+    import torch
+    dev = st["x"].device
+    # (events and side streams below belong to the state's device, whichever device is current in the caller)
+    with host_threads(), (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
         return _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook, restart)
 
 
