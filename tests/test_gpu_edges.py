@@ -284,3 +284,76 @@ def test_rg_block_shares_the_rc_blocks_pass_when_periods_coincide(orc):
     oo = orc.SurfWD(tRc=t, tRg=t2); oo.set_obsdata(d2 * 1.01)
     mo, go, do, fo = oo.misfit_and_grad(xs[0])
     assert fo and rel(o2[2][0], do) < 2e-6 and rel(o2[1][0], go) < 1e-4
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 9, 17, 33, 65, 128])
+def test_layer_count_extremes_love_search(orc, n):
+    """The Love root search through the lanes-per-item kernel at layer counts around its lane / segment boundaries
+    (1 layer over a half-space, fewer layers than segments, exactly one more than a power of two, the maximum):
+    SurfWD with all four blocks, flat and spherical, against the oracle."""
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    rng = np.random.default_rng(100 + n)
+    vs, thk = _model(n, rng)
+    if n > 40:
+        thk[:-1] *= 40.0 / n
+    t = np.array([6.0, 11.0, 23.0])
+    x0 = np.hstack((vs, thk))
+    for sph in (False, True):
+        kw = dict(tRc=t, tRg=t, tLc=t, tLg=t, sphere=sph)
+        s, o = SurfWD(**kw), orc.SurfWD(**kw)
+        d0, fl = o.forward(x0)
+        assert fl
+        s.set_obsdata(d0 * 1.01); o.set_obsdata(d0 * 1.01)
+        x = x0 * (1 + 0.02 * (rng.random(2 * n) - 0.5))
+        m, g, d, f = s.misfit_and_grad(x)
+        mo, go, do, fo = o.misfit_and_grad(x)
+        assert f == fo and f
+        assert rel(d, do) < 2e-6 and abs(m - mo) <= 1e-5 * abs(mo) and rel(g, go) < 1e-4, (n, sph, rel(d, do), rel(g, go))
+
+
+def test_flow_step2_deferred_form_equals_the_plain_step(orc):
+    """rfs_flow_step2 with gsave / kick (the dual-averaging form): every chain's first half kick is applied one call
+    later, from the saved gradient -- positions, momenta, energies and synthetics after a few calls equal those of
+    rfs_flow_step bit for bit, also across a restart made by the device with the step size written one call late."""
+    import torch
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    rng = np.random.default_rng(8)
+    vs, thk = _model(8, rng)
+    x0 = np.hstack((vs, thk))
+    t = np.linspace(6.0, 30.0, 6)
+    m = SurfWD(tRc=t)
+    d0, fl = m.forward(x0); m.set_obsdata(d0 * 1.01)
+    nc, nx = 48, 16
+    xs = np.tile(x0, (nc, 1)) * (1 + 0.01 * rng.standard_normal((nc, nx)))
+    xs[:, :8] = np.sort(xs[:, :8], axis=1)
+    lo, hi = xs.min(0) * 0.8, xs.max(0) * 1.2
+    bounds = np.stack([lo, hi], axis=1)
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p0 = 0.5 * rng.standard_normal((nc, nx)); p1 = 0.5 * rng.standard_normal((nc, nx))
+    dt0 = np.full(nc, 0.01); dt1 = 0.01 * (1 + 0.3 * rng.random(nc)); L0, L1 = 2, 3
+
+    def start(deferred):
+        st = m.flow_state(tt(xs), tt(dt0), tt(bounds))
+        st["p"].copy_(tt(p0)); st["rem"].fill_(L0); st["fresh"].fill_(1)
+        return m.flow_restart_state(st, deferred=True) if deferred else st
+    a, b = start(False), start(True)
+    for s in range(L0 + 1):                     # first trajectory: start evaluation + L0 steps
+        if s == L0:
+            b["nxt_u"].fill_(0.0); b["nxt_p"].copy_(tt(p1)); b["nxt_have"].fill_(1)      # u = 0: certain accept
+        m.flow_step(a); m.flow_step(b)
+    torch.cuda.synchronize()
+    assert int((a["done"] == 1).sum()) == nc and int((b["done"] == 3).sum()) == nc
+    for k in ("Hcur", "Hnew", "Unew"):
+        assert np.array_equal(a[k].cpu().numpy(), b["res_val"][:, {"Hcur": 1, "Hnew": 2, "Unew": 3}[k]].cpu().numpy()), k
+    assert np.array_equal(a["x"].cpu().numpy(), b["x"].cpu().numpy())
+    # the host restarts a by hand exactly as the device restarted b; b's step size and length arrive one call late
+    a["p"].copy_(tt(p1)); a["rem"].fill_(L1); a["dt"].copy_(tt(dt1)); a["fresh"].fill_(1)
+    m.flow_step(a); m.flow_step(b)              # start evaluation of the second trajectory (b: kick deferred)
+    b["dt"].copy_(tt(dt1)); b["rem"].fill_(L1)
+    for s in range(L1):
+        m.flow_step(a); m.flow_step(b)
+    torch.cuda.synchronize()
+    for k in ("x", "p", "Hcur", "Hnew", "Unew", "Ucur", "dsyn_new", "ok", "rem"):
+        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy()), k
+    assert int(b["kick"].sum()) == 0 and int((b["done"] == 1).sum()) == nc
