@@ -194,6 +194,32 @@ def test_every_root_of_the_bench_batch_against_the_restatement(full, orc):
 
 
 
+@pytest.mark.parametrize("nchain", [200, 1000, 3000])
+def test_roots_of_the_latency_form_against_the_restatement(orc, nchain):
+    """The same soak at the batch sizes of the lanes-per-item search in its latency form (one / two / four items per
+    wavefront, segmented recurrence, scan look-ahead): bench models of another seed x 40 periods against the C
+    restatement; same flags, at most 4 float32 roots on a neighbouring value (observed 0, 0, 2), none beyond 1e-6 c."""
+    import bench
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    t = np.linspace(5, 44, bench.NPER)
+    xs = bench.make_models(nchain, 7)
+    c_dev, flag = SurfWD(tRc=t).forward(xs)
+    n = bench.N_LAYER
+    ndiff, worst = 0, 0.0
+    for i in range(nchain):
+        vs, thk = xs[i, :n], xs[i, n:]
+        vp, rho, _, _ = orc.empirical_relation(vs)
+        cg, ok = orc.libsurf.forward(thk, vp, vs, rho, t, "Rc")
+        assert ok == bool(flag[i]), i
+        if ok:
+            bad = c_dev[i] != cg
+            if bad.any():
+                ndiff += int(bad.sum())
+                worst = max(worst, float((np.abs(c_dev[i] - cg)[bad] / cg[bad]).max()))
+    print(f"latency-form root soak, {nchain} chains: {ndiff} of {c_dev.size} roots differ, worst {worst:.2e}")
+    assert ndiff <= 4 and worst <= 1.0e-6, (ndiff, worst)
+
+
 def test_rf_chain_tiles_are_bit_identical(full):
     """The RF pipeline of the fused gradient in chain tiles (rf_scratch_budget_mb): whatever the tile size -- 64, 192 or
     1024 chains here, against the untiled 2048 -- every chain's misfit, gradient, synthetics and flag are bit-identical."""
