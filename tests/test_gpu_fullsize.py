@@ -220,6 +220,40 @@ def test_roots_of_the_latency_form_against_the_restatement(orc, nchain):
     assert ndiff <= 4 and worst <= 1.0e-6, (ndiff, worst)
 
 
+@pytest.mark.parametrize("nchain", [300, 2000, 5000])
+def test_love_roots_of_a_batch_against_the_restatement(orc, nchain):
+    """Love phase velocities (lanes-per-item search over SwdLoveFamily, in and beyond its latency form) of bench models x
+    40 periods against the C restatement of dltar1 / surfdisp96: same flags; float32 roots identical up to a handful on a
+    neighbouring value, none beyond 1e-6 c."""
+    import bench
+    from rfsurfhmc_amd.model.lib import libsurf
+    t = np.linspace(5, 44, bench.NPER)
+    xs = bench.make_models(nchain, 11)
+    n = bench.N_LAYER
+    vs, thk = xs[:, :n], xs[:, n:]
+    vp, rho = np.empty_like(vs), np.empty_like(vs)
+    for i in range(nchain):
+        vp[i], rho[i], _, _ = orc.empirical_relation(vs[i])
+    from rfsurfhmc_amd._lib import Context, hptr
+    ctx = Context(0, max_chains=nchain, max_layers=n)
+    c_dev = np.zeros((nchain, len(t))); flag = np.zeros(nchain, dtype=np.int32)
+    a = [np.ascontiguousarray(v) for v in (thk, vp, vs, rho)]
+    ctx.check(ctx.L.rfs_swd_forward(ctx.h, nchain, n, hptr(a[0]), hptr(a[1]), hptr(a[2]), hptr(a[3]), len(t), hptr(t),
+                                    2, 0, 0, hptr(c_dev), hptr(flag)))
+    ctx.close()
+    ndiff, worst = 0, 0.0
+    for i in range(0, nchain, max(1, nchain // 400)):            # (the oracle's Python wrapper costs 1 ms a model: a sample)
+        cg, ok = orc.libsurf.forward(thk[i], vp[i], vs[i], rho[i], t, "Lc")
+        assert ok == bool(flag[i]), i
+        if ok:
+            bad = c_dev[i] != cg
+            if bad.any():
+                ndiff += int(bad.sum())
+                worst = max(worst, float((np.abs(c_dev[i] - cg)[bad] / cg[bad]).max()))
+    print(f"Love root soak, {nchain} chains: {ndiff} roots differ, worst {worst:.2e}")
+    assert ndiff <= 4 and worst <= 1.0e-6, (ndiff, worst)
+
+
 def test_rf_chain_tiles_are_bit_identical(full):
     """The RF pipeline of the fused gradient in chain tiles (rf_scratch_budget_mb): whatever the tile size -- 64, 192 or
     1024 chains here, against the untiled 2048 -- every chain's misfit, gradient, synthetics and flag are bit-identical."""
