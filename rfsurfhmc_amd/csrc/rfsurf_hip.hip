@@ -565,6 +565,28 @@ int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSe
     return 0;
 }
 
+// Cooperative producer / consumer blocks for the Love family (big batches; the Rayleigh launch below has its own plan,
+// which the step's CU partition is built around).  Returns 1 when the shape does not fit (caller falls back).
+int launch_love_coop(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, const float* mdl, const double* mdlc,
+                     int* sflag) {
+    const int nitem = Q.nseq * nchain;
+    int npmax = 0;
+    for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
+    if (c->swd_lanes != 0 || nitem <= SWD_LAT_MAX_ITEMS || n < 3 || n - 2 > 16 * COOP_NP || Q.nseq * npmax > 4096) return 1;
+    const int nch = (n - 1 - COOP_CL + COOP_NP - 1) / COOP_NP;
+    const size_t lds = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SwdLoveFamily::NENT * 64 + 24 * 64 + 2 * Q.nseq * npmax) * sizeof(double);
+    if (lds > 60 * 1024) return 1;
+    dim3 grid((nitem + 63) / 64);
+#define RFS_LAUNCH_LCOOP(NCH)                                                                                  \
+    hipLaunchKernelGGL((k_swd_roots_coop<SwdLoveFamily, NCH>), grid, dim3(512), lds, s, nchain, n, Q, mdl, mdlc, \
+                       c->croot.as<double>(), sflag)
+    if (nch <= 5) RFS_LAUNCH_LCOOP(5);
+    else if (nch <= 8) RFS_LAUNCH_LCOOP(8);
+    else RFS_LAUNCH_LCOOP(16);
+#undef RFS_LAUNCH_LCOOP
+    return 0;
+}
+
 // root search (+ eigenfunction kernels) on stream `s`; mdl must be ready
 // eigen_mode 0: every item; 3 / 4: the Rayleigh / the Love items only; 1: EARLY launch of the Rayleigh items [0, early_items) beside a running search;
 // 2: MOP-UP of what the early launch left (k_swd_eigen)
@@ -586,8 +608,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         {
             KTimer t(c, RFS_K_SWD_ROOTS, sl);
             int nitem = P.QL.nseq * nchain;
-            if (n < 3 || launch_roots_split<SwdLoveFamily>(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(),
-                                                            sflagL, c->swd_lanes))
+            if (launch_love_coop(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL) &&
+                (n < 3 || launch_roots_split<SwdLoveFamily>(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(),
+                                                            sflagL, c->swd_lanes)))
                 hipLaunchKernelGGL(k_swd_roots<true>, dim3((nitem + 63) / 64), dim3(64), 0, sl, nchain, n, P.QL,
                                    c->mdlL.as<float>(), c->croot.as<double>(), sflagL);
             HIPCHK(c, hipGetLastError());
@@ -604,9 +627,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             size_t lds2 = cp.lds;
 #define RFS_LAUNCH_COOP(NCH)                                                                                   \
             do {                                                                                               \
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<NCH>,                              \
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<SwdRayFamily, NCH>,                              \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));          \
-                hipLaunchKernelGGL(k_swd_roots_coop<NCH>, grid, dim3(512), lds2, s, nchain, n, Q,               \
+                hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, s, nchain, n, Q,               \
                                    mdlR, c->mdlc.as<double>(), c->croot.as<double>(),                           \
                                    c->sflag.as<int>());                                                         \
             } while (0)

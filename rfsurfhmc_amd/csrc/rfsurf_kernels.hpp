@@ -727,7 +727,8 @@ struct SwdOmegaTab {
 #endif
 constexpr int COOP_NC = RFS_COOP_NC;                // consumer waves (each owns 64/COOP_NC of the block's items)
 constexpr int COOP_NP = 8 - COOP_NC;             // producer waves = layers per chunk
-template <int NCH>                               // chunks held in registers: (n-1-COOP_CL) <= NCH*COOP_NP
+// F: the secular function (SwdRayFamily; SwdLoveFamily: 3 entries per layer and a 2-vector, a fifth of the LDS)
+template <class F, int NCH>                      // chunks held in registers: (n-1-COOP_CL) <= NCH*COOP_NP
 __global__ void __launch_bounds__(512)
 k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                  const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
@@ -735,8 +736,9 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     extern __shared__ double lds[];
     double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
     int* go = (int*)(lds + 4 * 64);              // go[w]: consumer w has another evaluation
-    double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][15][64]
-    double* nev = ent + 2 * COOP_NP * SWD_NENT * 64;    // [24][64] Neville tables of the 64 state machines
+    constexpr int NENT = F::NENT, NV = F::NV;
+    double* ent = lds + 4 * 64 + 8;              // [2][COOP_NP][NENT][64]
+    double* nev = ent + 2 * COOP_NP * NENT * 64;    // [24][64] Neville tables of the 64 state machines
     double* tper = nev + 24 * 64;                       // [2][nseq][nper_max]: omega_k = 2 pi / T_k, then 1 / max(omega_k, 1e-4)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int IPC = 64 / COOP_NC;            // items per consumer wave
@@ -769,8 +771,8 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
         // the consumers are the block's critical path: static priority lets their dependent chains issue first
         __builtin_amdgcn_s_setprio(3);
         const size_t s = (size_t)n * nchain;
-        SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         const SwdSeq sq = Q.s[seq];
+        SwdModel M{mdl + chain, mdl + (F::LOVE && sq.alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         const SwdOmegaTab T{tper + seq * npmax};
         const double* iom = tper + (Q.nseq + seq) * npmax;
         double* cr = croot + (size_t)sq.croot_off * nchain + chain;
@@ -796,58 +798,58 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 #pragma unroll
             for (int w = 0; w < COOP_NC; w++) any_more |= go[w];
             if (!any_more) break;
-            double e[5];
-            swd_halfspace_e(Lhalf, wvno, wvno2, omega, iomega, e);
+            double e[NV];
+            F::halfspace(Lhalf, wvno, wvno2, omega, iomega, e);
             const double tt = -2.0 * wvno2;
             if (COOP_CL) {                                       // deepest layer: built here, beside chunk 0
-                double d15[SWD_NENT];
-                swd_layer_entries(Ldeep, wvno, wvno2, omega, iomega, d15);
-                swd_apply_layer_raw(e, d15, tt);
+                double d15[NENT];
+                F::entries(Ldeep, wvno, wvno2, omega, iomega, d15);
+                F::apply(e, d15, tt);
             }
             for (int c = 0; c < nch; c++) {
                 __syncthreads();                                 // chunk c is in buffer c&1
-                const double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + bl;
+                const double* eb = ent + (size_t)(c & 1) * COOP_NP * NENT * 64 + bl;
                 const int nl = min(COOP_NP, nprod - c * COOP_NP);        // layers in this chunk
                 if (nl == COOP_NP) {                             // a full chunk: branch-free code (same-box A/B: search 7.12 -> 6.98 ms)
-                    double bA[SWD_NENT], bB[SWD_NENT];
+                    double bA[NENT], bB[NENT];
 #pragma unroll
-                    for (int q = 0; q < SWD_NENT; q++) bA[q] = eb[(size_t)q * 64];
+                    for (int q = 0; q < NENT; q++) bA[q] = eb[(size_t)q * 64];
 #pragma unroll
                     for (int i = 0; i < COOP_NP; i += 2) {
                         if (i + 1 < COOP_NP) {
 #pragma unroll
-                            for (int q = 0; q < SWD_NENT; q++) bB[q] = eb[(size_t)((i + 1) * SWD_NENT + q) * 64];
+                            for (int q = 0; q < NENT; q++) bB[q] = eb[(size_t)((i + 1) * NENT + q) * 64];
                         }
-                        swd_apply_layer_raw(e, bA, tt);
+                        F::apply(e, bA, tt);
                         if (i + 2 < COOP_NP) {
 #pragma unroll
-                            for (int q = 0; q < SWD_NENT; q++) bA[q] = eb[(size_t)((i + 2) * SWD_NENT + q) * 64];
+                            for (int q = 0; q < NENT; q++) bA[q] = eb[(size_t)((i + 2) * NENT + q) * 64];
                         }
-                        if (i + 1 < COOP_NP) swd_apply_layer_raw(e, bB, tt);
+                        if (i + 1 < COOP_NP) F::apply(e, bB, tt);
                     }
-                    swd_rescale_pow2(e);
+                    F::rescale(e);
                     continue;
                 }
                 // software pipeline: the LDS reads of layer i+1 are in flight while layer i's 25 FMAs issue
-                double bufA[SWD_NENT], bufB[SWD_NENT];
+                double bufA[NENT], bufB[NENT];
 #pragma unroll
-                for (int q = 0; q < SWD_NENT; q++) bufA[q] = eb[(size_t)q * 64];
+                for (int q = 0; q < NENT; q++) bufA[q] = eb[(size_t)q * 64];
 #pragma unroll
                 for (int i = 0; i < COOP_NP; i += 2) {
                     if (i + 1 < nl) {
 #pragma unroll
-                        for (int q = 0; q < SWD_NENT; q++) bufB[q] = eb[(size_t)((i + 1) * SWD_NENT + q) * 64];
+                        for (int q = 0; q < NENT; q++) bufB[q] = eb[(size_t)((i + 1) * NENT + q) * 64];
                     }
-                    if (i < nl) swd_apply_layer_raw(e, bufA, tt);
+                    if (i < nl) F::apply(e, bufA, tt);
                     if (i + 2 < nl) {
 #pragma unroll
-                        for (int q = 0; q < SWD_NENT; q++) bufA[q] = eb[(size_t)((i + 2) * SWD_NENT + q) * 64];
+                        for (int q = 0; q < NENT; q++) bufA[q] = eb[(size_t)((i + 2) * NENT + q) * 64];
                     }
-                    if (i + 1 < nl) swd_apply_layer_raw(e, bufB, tt);
+                    if (i + 1 < nl) F::apply(e, bufB, tt);
                 }
-                swd_rescale_pow2(e);                             // once per chunk
+                F::rescale(e);                             // once per chunk
             }
-            if (!rs.done) rs.advance(swd_finish(e), T, out);
+            if (!rs.done) rs.advance(F::finish(e), T, out);
             if (COOP_NC > 1) __syncthreads();                    // B_end: go[] may be rewritten
         }
         if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
@@ -872,11 +874,11 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
                 if (c < nch) {
                     int m = (n - 2 - COOP_CL) - (c * COOP_NP + p);
                     if (m >= 0) {
-                        double e15[SWD_NENT];
-                        swd_layer_entries(Lmine[c], wvno, wvno2, omega, iomega, e15);
-                        double* eb = ent + (size_t)(c & 1) * COOP_NP * SWD_NENT * 64 + (size_t)p * SWD_NENT * 64 + lane;
+                        double e15[NENT];
+                        F::entries(Lmine[c], wvno, wvno2, omega, iomega, e15);
+                        double* eb = ent + (size_t)(c & 1) * COOP_NP * NENT * 64 + (size_t)p * NENT * 64 + lane;
 #pragma unroll
-                        for (int q = 0; q < SWD_NENT; q++) eb[(size_t)q * 64] = e15[q];
+                        for (int q = 0; q < NENT; q++) eb[(size_t)q * 64] = e15[q];
                     }
                     __syncthreads();
                 }

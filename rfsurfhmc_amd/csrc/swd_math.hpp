@@ -339,6 +339,8 @@ struct SwdRayFamily {
         swd_halfspace_e(L, wvno, wvno2, omega, iomega, e);
     }
     static RFS_HD void apply(double* e, const double* c, double tt) { swd_apply_layer_raw(e, c, tt); }
+    static RFS_HD void rescale(double* e) { swd_rescale_pow2(e); }
+    static RFS_HD double finish(const double* e) { return swd_finish(e); }
 };
 struct SwdLoveFamily {
     static constexpr int NENT = 3, NV = 2;
@@ -358,6 +360,17 @@ struct SwdLoveFamily {
     static RFS_HD void apply(double* e, const double* c, double) {
         const double n0 = e[0] * c[0] + e[1] * c[1], n1 = e[0] * c[2] + e[1] * c[0];
         e[0] = n0; e[1] = n1;
+    }
+    static RFS_HD void rescale(double* e) {
+        const double t1 = fmax(fabs(e[0]), fabs(e[1]));
+        int ex = 0;
+        if (t1 > 0.0 && t1 < 1.0e300) frexp(t1, &ex);
+        e[0] = ldexp(e[0], -ex); e[1] = ldexp(e[1], -ex);
+    }
+    static RFS_HD double finish(const double* e) {
+        double t1 = fmax(fabs(e[0]), fabs(e[1]));
+        if (t1 < 1.0e-40) t1 = 1.0;
+        return e[0] / t1;
     }
 };
 template <int NV> RFS_HD void swd_rescale_pow2_n(double* e) {
