@@ -240,11 +240,38 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          bit-identical for every tile size.
  *   "recalibrate"          forget the measured schedule (the partition / early-eigenfunction decisions are taken from
  *                          HIP-event timings of the first evaluation of each shape and cached in the context).
+ *   "swd_warm_start"       the root search inside a trajectory.  The reference searches every model from scratch, period
+ *                          after period (surfdisp96.f:257-316: ~23 secular evaluations per period, each period starting
+ *                          from the root before it).  Inside a leapfrog trajectory the model of step s is the model of
+ *                          step s-1 moved by dt M^-1 p, and step s-1 left its roots AND their Frechet kernels on the device:
+ *                          every (period, chain) item predicts its root to first order, brackets it inside a trust radius
+ *                          and refines it by false position (~3 secular evaluations, all periods in parallel).  Chains
+ *                          that cannot be continued -- first evaluation, a failed previous evaluation, no sign change
+ *                          where the first-order model says, root above the fastest layer -- go through the
+ *                          reference-semantics search, which alone decides flags.  Accepted roots are sign changes of the
+ *                          very secular function the reference brackets, located to 1e-7 c and rounded to float32 like
+ *                          the reference's: within the reference's own refinement tolerance 1e-6 c (surfdisp96.f:627) of
+ *                          its values, not bit-identical to them (its nevill ends in bisection steps and stops up to
+ *                          1e-6 c short of the root).
+ *                          0 = off: every evaluation by the reference-semantics search (bit-exact roots);
+ *                          1 (default) = on for the trajectory entries (rfs_leapfrog_dev / _dev2 without nactive,
+ *                          rfs_flow_step / _step2), whose consecutive evaluations are one set of chains moving;
+ *                          2 = also for rfs_joint_misfit_grad[_dev]: the CALLER promises that consecutive calls with the
+ *                          same nchain evaluate the same chains a small step apart (a host-side leapfrog loop).
+ *                          rfs_swd_forward / rfs_swd_kernel / rfs_joint_forward never warm-start.
+ *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
+ *                          evaluations the accept / reject decision and the stored sample come from) still go through the
+ *                          reference-semantics search.  0 (default) = off.
  *   "early_eigen_periods"  in a partitioned step the RF half finishes before the root search; the eigenfunction
  *                          kernels of the first periods (whose roots are final by then) run there early and only
  *                          the rest waits for the search.  -1 (default) = automatic count, 0 = off, k > 0 = the
  *                          first k periods.  Results are bit-identical for every value. */
 int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
+/* Counters (cumulative since the context's warm-start buffers were made; the call synchronises):
+ *   "swd_warm_declined_chains"  chain evaluations the warm start handed back to the reference-semantics search
+ *   "swd_warm_items"            (period, chain) items the warm start refined
+ *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items */
+int rfs_get_stat(rfs_ctx* ctx, const char* name, int64_t* value);
 /* Kernel groups of one rfs_joint_misfit_grad_dev call.  With timing enabled every group of every
  * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on
  * (the root search / eigenfunction groups run on the context's second stream); nothing

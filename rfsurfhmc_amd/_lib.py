@@ -63,6 +63,7 @@ SIGNATURES = {
     "rfs_set_inverse_mass": (_i, [_vp, _vp]),
     "rfs_ndata": (_i, [_vp]),
     "rfs_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
+    "rfs_get_stat": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "rfs_enable_timing": (_i, [_vp, _i]),
     "rfs_kernel_ms_sum": (_i, [_vp, _vp, _vp]),
 }
@@ -113,6 +114,14 @@ class Context:
     def check(self, rc: int):
         if rc != 0:
             raise RfsError(f"librfsurf_hip error {rc}: {self.L.rfs_last_error(self.h).decode()}")
+
+    def set_option(self, name: str, value: int):
+        self.check(self.L.rfs_set_option(self.h, name.encode(), int(value)))
+
+    def stat(self, name: str) -> int:
+        v = ctypes.c_int64(0)
+        self.check(self.L.rfs_get_stat(self.h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def close(self):
         if getattr(self, "h", None):

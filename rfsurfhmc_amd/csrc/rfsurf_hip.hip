@@ -77,6 +77,14 @@ struct rfs_ctx {
     int swd_speculate = -1; // wavefronts per block that look ahead in the scan of the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     int swd_segments = -1; // segments of the vector recurrence in the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
+    // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
+    int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
+    int exact_final = 0;       // option "swd_exact_final": first and last evaluation of a trajectory by the full search
+    bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
+    int warm_nchain = 0;
+    int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
+    int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats;
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
@@ -510,8 +518,10 @@ int launch_family_prep(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPl
 // Rayleigh batches, so G is only needed up to SWD_LAT_MAX_ITEMS there.
 template <class F>
 int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, const float* mdl, const double* mdlc,
-                       int* sflag, int G) {
-    const int nitem = Q.nseq * nchain;
+                       int* sflag, int G, const int* list = nullptr, const int* count = nullptr, int est_chains = 0) {
+    // list: the search of the chains a warm start handed back -- their number is only known on the device, the launch
+    // shape follows the host's estimate and the blocks stride over whatever the list holds
+    const int nitem = list ? Q.nseq * std::max(1, std::min(est_chains, nchain)) : Q.nseq * nchain;
     int spec_auto = 1;
     if (G <= 0 && nitem <= SWD_LAT_MAX_ITEMS) {
         // latency mode: one item per wavefront while the device has room for it (no two items' state machines diverging
@@ -530,7 +540,7 @@ int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSe
     if (G == 1) return 1;                    // caller falls back to the lane-per-item kernel
     int NG = 64 / G, lpl = (n - 1 + G - 1) / G;
     if (lpl > 8 || lds > 60 * 1024) return 1;   // more than 8 layers per lane even with 64 lanes (> 513 layers): same fallback
-    dim3 grid((nitem + NG - 1) / NG);
+    dim3 grid(list ? std::min((Q.nseq * nchain + NG - 1) / NG, std::max(64, 2 * (nitem + NG - 1) / NG)) : (nitem + NG - 1) / NG);
     // few items (the device is mostly idle): cut the vector recurrence into segments that run side by side on the
     // group's lanes -- 4 segments need 1 + 3 NV lanes, 2 need 1 + NV
     int nseg = c->swd_segments;
@@ -548,7 +558,7 @@ int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSe
     size_t lds_s = lds_of(spec);
 #define RFS_LAUNCH_SPLIT3(LPL, NSEG, SPEC)                                                                          \
     hipLaunchKernelGGL((k_swd_roots_split<F, LPL, NSEG, SPEC>), grid, dim3(64 * SPEC), lds_s, s, nchain, n, G, Q,   \
-                       mdl, mdlc, c->croot.as<double>(), sflag)
+                       mdl, mdlc, c->croot.as<double>(), sflag, list, count)
 #define RFS_LAUNCH_SPLIT2(LPL, NSEG)                                                                                \
     do { if (spec == 4) RFS_LAUNCH_SPLIT3(LPL, NSEG, 4); else if (spec == 2) RFS_LAUNCH_SPLIT3(LPL, NSEG, 2);       \
          else RFS_LAUNCH_SPLIT3(LPL, NSEG, 1); } while (0)
@@ -591,13 +601,51 @@ int launch_love_coop(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs
 // eigen_mode 0: every item; 3 / 4: the Rayleigh / the Love items only; 1: EARLY launch of the Rayleigh items [0, early_items) beside a running search;
 // 2: MOP-UP of what the early launch left (k_swd_eigen)
 int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, bool kernels, bool roots = true,
-               int eigen_mode = 0, int early_items = 0) {
+               int eigen_mode = 0, int early_items = 0, bool warm = false) {
     const SwdSeqs& Q = P.QR;
     const int sphere = P.R.sphere;
     ENSURE(c, c->croot, (size_t)P.nitems * nchain * sizeof(double));
     ENSURE(c, c->sflag, (size_t)8 * nchain * sizeof(int));
     const float* mdlR = sphere ? c->mdlSR.as<float>() : c->mdl.as<float>();
     int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
+    if (warm && roots) {
+        // Inside a trajectory: every (period, chain) item refines the previous evaluation's root on its own (k_swd_warm);
+        // the chains that cannot be continued go through the reference-semantics search right behind, on a list.
+        KTimer t(c, RFS_K_SWD_ROOTS, s);
+        SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
+                  c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>()};
+#define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
+        do {                                                                                                          \
+            dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
+            if (sphere) hipLaunchKernelGGL((k_swd_warm<FAM, true>), grid, dim3(64), 0, s, nchain, n, QQ, MDLC, SPHP,   \
+                                           c->krn.as<double>(), c->croot.as<double>(), W);                            \
+            else hipLaunchKernelGGL((k_swd_warm<FAM, false>), grid, dim3(64), 0, s, nchain, n, QQ, MDLC,              \
+                                    (const double*)nullptr, c->krn.as<double>(), c->croot.as<double>(), W);           \
+        } while (0)
+        if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
+        if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
+#undef RFS_LAUNCH_WARM
+        HIPCHK(c, hipGetLastError());
+        const int* list = c->wlist.as<int>();
+        const int* count = c->wneed.as<int>() + nchain;
+        // the list's length of an earlier step, whenever its copy has arrived (never waited for)
+        const int est = std::max(c->warm_est, 64);
+        const int gl = std::min((nchain + 63) / 64, std::max(8, (est + 63) / 64));
+        if (Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                                                                      c->sflag.as<int>(), 0, list, count, est)))
+            hipLaunchKernelGGL(k_swd_roots<false>, dim3(gl * Q.nseq), dim3(64), 0, s, nchain, n, Q, mdlR, c->croot.as<double>(),
+                               c->sflag.as<int>(), list, count);
+        if (P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                                                                         c->mdlcL.as<double>(), sflagL, 0, list, count, est)))
+            hipLaunchKernelGGL(k_swd_roots<true>, dim3(gl * P.QL.nseq), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                               c->croot.as<double>(), sflagL, list, count);
+        HIPCHK(c, hipGetLastError());
+        if (c->h_wcount) {
+            if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
+            HIPCHK(c, hipMemcpyAsync(c->h_wcount, count, sizeof(int), hipMemcpyDeviceToHost, s));
+        }
+        roots = false;
+    }
     // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
     // the Rayleigh one (a fifth active stream inside the partitioned step would share a hardware queue)
     // -- inside it the Love search goes to the RF half's stream, ahead of the RF sweeps: the Rayleigh search keeps its half
@@ -612,7 +660,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                 (n < 3 || launch_roots_split<SwdLoveFamily>(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(),
                                                             sflagL, c->swd_lanes)))
                 hipLaunchKernelGGL(k_swd_roots<true>, dim3((nitem + 63) / 64), dim3(64), 0, sl, nchain, n, P.QL,
-                                   c->mdlL.as<float>(), c->croot.as<double>(), sflagL);
+                                   c->mdlL.as<float>(), c->croot.as<double>(), sflagL, (const int*)nullptr, (const int*)nullptr);
             HIPCHK(c, hipGetLastError());
         }
         if (love_aside) HIPCHK(c, hipEventRecord(c->ev_lj, sl));
@@ -640,7 +688,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         } else if (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(), c->sflag.as<int>(),
                                                              c->swd_lanes)) {
             hipLaunchKernelGGL(k_swd_roots<false>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
-                               mdlR, c->croot.as<double>(), c->sflag.as<int>());
+                               mdlR, c->croot.as<double>(), c->sflag.as<int>(), (const int*)nullptr, (const int*)nullptr);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -687,9 +735,35 @@ int upload(rfs_ctx* c, Buf& b, const void* host, size_t bytes) {
 }
 
 // the whole misfit+gradient evaluation on device pointers
-int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn, int32_t* flag) {
+// traj: the call continues a trajectory of the SAME nchain chains (leapfrog / flow entries): the root search may start
+// from the previous evaluation (option "swd_warm_start")
+int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn, int32_t* flag,
+               bool traj = false) {
     const int n = c->n;
     HIPCHK(c, hipSetDevice(c->device));
+    // track: keep the model / roots / kernels of this evaluation for the next one; warm: use those of the previous one
+    const bool track = c->has_swd && (c->warm_opt == 2 || (c->warm_opt == 1 && traj));
+    const bool warm = track && c->warm_primed && c->warm_nchain == nchain;
+    if (track) {
+        const size_t nn = (size_t)n * nchain;
+        if (c->warm_nchain != nchain) c->warm_primed = false;
+        ENSURE(c, c->xw, 2 * nn * sizeof(double)); ENSURE(c, c->dxT, 2 * nn * sizeof(double));
+        ENSURE(c, c->crT, 2 * nn * sizeof(double));
+        const size_t before = c->wvalid.cap;
+        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, ((size_t)nchain + 1) * sizeof(int));
+        ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
+        ENSURE(c, c->wstats, 4 * sizeof(unsigned long long));
+        if (c->wvalid.cap != before) {
+            HIPCHK(c, hipMemsetAsync(c->wforce.p, 0, c->wforce.cap, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->wstats.p, 0, c->wstats.cap, c->stream));
+        }
+        if (!c->h_wcount) {
+            HIPCHK(c, hipHostMalloc((void**)&c->h_wcount, sizeof(int), hipHostMallocDefault));
+            *c->h_wcount = -1;
+        }
+    } else {
+        c->warm_primed = false;            // an unrelated evaluation overwrites croot / krn
+    }
     ENSURE(c, c->cr, (size_t)nchain * 2 * n * sizeof(double));
     if (c->has_rf) ENSURE(c, c->lc, (size_t)nchain * n * sizeof(RfLayer));
     if (c->has_swd) { ENSURE(c, c->mdl, (size_t)4 * n * nchain * sizeof(float)); ENSURE(c, c->mdlc, (size_t)6 * n * nchain * sizeof(double)); }
@@ -721,7 +795,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         rf_tile = std::min(rf_tile, RF_MAX_CHAINS_PER_LAUNCH);      // grid rows of the RF sweeps
     }
     const bool tiled = rf_tile < nchain;
-    const bool part_possible = !rf_time && !tiled && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m &&
+    // (a warm-started search is throughput work like the RF sweeps: no partition, everything shares the chip)
+    const bool part_possible = !warm && !rf_time && !tiled && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m &&
                                c->stream3 && cp.ok && cp.blocks <= (c->ncu / 2) * cp.per_cu;
     // Early eigenfunction pass: with the partition on, the RF half of the chip finishes before the search does.  The
     // eigenfunction kernels of the first periods -- whose roots have long been final by then -- fill that gap on the RF
@@ -827,7 +902,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd,
                            c->mdl.as<float>(), c->mdlc.as<double>(),
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
-                           early_items > 0 ? c->edone.as<int>() : (int*)nullptr, early_items > 0 ? ntot / 64 + 1 : (size_t)0);
+                           early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
+                           early_items > 0 ? ntot / 64 + 1 : (warm ? (size_t)nchain + 1 : (size_t)0),
+                           track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>());
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
     }
@@ -835,13 +912,13 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         hipStream_t ss = part ? c->stream2m : c->stream2;
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
-        TRY(launch_swd(c, ss, nchain, n, P, !part));
+        TRY(launch_swd(c, ss, nchain, n, P, !part, true, 0, 0, warm));
         // partitioned step with a Love block: the RF half carries the Love search ahead of its sweeps and ends last, so the
         // Rayleigh eigenfunction pass runs on the search half right behind the search instead of waiting for the join
         if (a_eigen) TRY(launch_swd(c, ss, nchain, n, P, true, false, 3));
         HIPCHK(c, hipEventRecord(c->ev_join, ss));
     } else if (c->has_swd) {
-        TRY(launch_swd(c, user, nchain, n, P, true));
+        TRY(launch_swd(c, user, nchain, n, P, true, true, 0, 0, warm));
     }
     if (c->has_rf) {
         if (part) { HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); c->stream = c->stream3; }
@@ -905,13 +982,15 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
             hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 16), (size_t)n * 32 * sizeof(double), \
                                c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),     \
                                c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),      \
-                               P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag)
+                               P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                  \
+                               track ? c->wvalid.as<int>() : (int*)nullptr)
             if (c->sphere) RFS_LAUNCH_COMBINE(true); else RFS_LAUNCH_COMBINE(false);
 #undef RFS_LAUNCH_COMBINE
         }
         HIPCHK(c, hipGetLastError());
     }
     if (timed) { HIPCHK(c, hipEventRecord(cal->ev[2 * cal->stage + 1], user)); cal->stage++; }
+    if (track) { c->warm_primed = true; c->warm_nchain = nchain; }
     return RFS_OK;
 }
 
@@ -953,8 +1032,10 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->mdl, &c->RR, &c->Rs, &c->spec, &c->tser, &c->wres, &c->W, &c->wmax2, &c->PG, &c->mrf,
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
-                   &c->ldsyn, &c->lflag, &c->mdlc};
+                   &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
+                   &c->wstats};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
+    if (c->h_wcount) hipHostFree(c->h_wcount);
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -1038,6 +1119,15 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 1) return fail(c, RFS_ERR_ARG, "rf_scratch_budget_mb must be positive");
         c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
     }
+    if (!strcmp(name, "swd_warm_start")) {
+        if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_warm_start must be 0, 1 or 2");
+        c->warm_opt = value; c->warm_primed = false; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_exact_final")) {
+        c->exact_final = value != 0;
+        if (c->wforce.p) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->wforce.p, 0, c->wforce.cap, c->stream)); }
+        return RFS_OK;
+    }
     if (!strcmp(name, "recalibrate")) { for (auto& kv : c->calib) kv.second.stage = -1; return RFS_OK; }
     if (!strcmp(name, "cu_split")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "cu_split must be 0, 1 or 2");
@@ -1052,6 +1142,23 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         c->early_eigen = value; return RFS_OK;
     }
     return fail(c, RFS_ERR_ARG, std::string("unknown option ") + name);
+}
+
+int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
+    if (!c || !name || !value) return RFS_ERR_ARG;
+    *value = 0;
+    int idx = -1;
+    if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
+    else if (!strcmp(name, "swd_warm_secular_evals")) idx = 1;
+    else if (!strcmp(name, "swd_warm_items")) idx = 2;
+    if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
+    if (!c->wstats.p) return RFS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(rfs_synchronize(c));
+    unsigned long long v[4];
+    HIPCHK(c, hipMemcpy(v, c->wstats.p, sizeof(v), hipMemcpyDeviceToHost));
+    *value = (int64_t)v[idx];
+    return RFS_OK;
 }
 
 // ---------------------------------------------------------------- B1 / libsurf
@@ -1200,6 +1307,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
                      double sigma2, const double* dobs) {
     if (!c) return RFS_ERR_ARG;
     c->configured = false;
+    c->warm_primed = false;
     if (nlayer < 2 || nlayer > c->max_layers || nlayer > MAXL) return fail(c, RFS_ERR_ARG, "nlayer outside [2, min(max_layers,128)]");
     int ntw[4] = {0, 0, 0, 0};
     const double* tw[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1295,7 +1403,9 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
     int nth = nchain * n;
     hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->x.as<double>(),
                        (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd, c->mdl.as<float>(),
-                       c->mdlc.as<double>(), (double*)nullptr, (size_t)0, (int*)nullptr, (size_t)0);
+                       c->mdlc.as<double>(), (double*)nullptr, (size_t)0, (int*)nullptr, (size_t)0,
+                       (double*)nullptr, (double*)nullptr, (double*)nullptr);
+    c->warm_primed = false;                    // croot / krn are about to be overwritten by an unrelated evaluation
     int nt = c->has_rf ? c->f.nt : 0;
     if (c->has_rf) {
         RfFreq f = c->f; f.fwd_order = 1; f.pi64 = 0;      // cal_rf_freq / cal_rf_time frequency axis
@@ -1359,7 +1469,14 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
            *d = c->ldsyn.as<double>();
     int* fl = c->lflag.as<int>();
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
-    TRY(joint_eval(c, nchain, x0, U, g, d, fl));
+    const bool traj = nactive == nullptr;      // (a shrinking chain count changes the layout of the kept roots / kernels)
+    int* wforce = nullptr;
+    if (traj && c->exact_final && c->has_swd && c->warm_opt) {
+        ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
+        HIPCHK(c, hipMemsetAsync(c->wforce.p, 0xff, (size_t)nchain * sizeof(int), c->stream));    // start models: full search
+        wforce = c->wforce.as<int>();
+    }
+    TRY(joint_eval(c, nchain, x0, U, g, d, fl, traj));
     hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, x0, p0, dt, L, Lmax, U, g, d, fl,
                        x, p, Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok);
     // failed chains (ok = 0: failed evaluation, or L outside [1, Lmax]) keep xnew = x0, Hnew = +inf written by
@@ -1369,8 +1486,9 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
         // chains sorted by decreasing L: only the first nactive[step] are still inside their trajectory
         const int na = nactive ? nactive[step] : nchain;
         const int nth = na * nx;
-        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, na, nx, step, minv, dt, L, bounds, x, p, ok);
-        TRY(joint_eval(c, na, x, U, g, d, fl));
+        hipLaunchKernelGGL(k_leap_drift, dim3((nth + 255) / 256), dim3(256), 0, c->stream, na, nx, step, minv, dt, L, bounds, x, p, ok,
+                           wforce);
+        TRY(joint_eval(c, na, x, U, g, d, fl, traj));
         hipLaunchKernelGGL(k_leap_kick, dim3(na), dim3(64), 0, c->stream, na, nx, nd, step, minv, dt, L, x, U, g, d, fl, p,
                            Unew, Hnew, dsyn_new, xnew, ok);
     }
@@ -1417,9 +1535,11 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     int* fl = c->lflag.as<int>();
     const int nth = nchain * nx;
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
+    int* wforce = nullptr;
+    if (c->exact_final && c->has_swd && c->warm_opt) { ENSURE(c, c->wforce, (size_t)nchain * sizeof(int)); wforce = c->wforce.as<int>(); }
     hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p,
-                       fn.gsave, fn.kick);
-    TRY(joint_eval(c, nchain, x, U, g, d, fl));
+                       fn.gsave, fn.kick, wforce);
+    TRY(joint_eval(c, nchain, x, U, g, d, fl, true));
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn);
     HIPCHK(c, hipGetLastError());

@@ -118,7 +118,8 @@ __device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int 
 __global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, int has_rf, double ray_p,
                              RfLayer* __restrict__ lc, double* __restrict__ cr, int has_swd,
                              float* __restrict__ mdl, double* __restrict__ mdlc,
-                             double* __restrict__ zero_d, size_t nzero_d, int* __restrict__ zero_i, size_t nzero_i)
+                             double* __restrict__ zero_d, size_t nzero_d, int* __restrict__ zero_i, size_t nzero_i,
+                             double* __restrict__ xw, double* __restrict__ dxT, double* __restrict__ crT)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     // per-step clearing for the early eigenfunction launch (roots: zero = not final; done map), folded in here
@@ -135,6 +136,16 @@ __global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, in
     double dadb = 2.0947 - 0.8206 * 2 * vs + 0.2683 * 3 * (vs * vs) - 0.0251 * 4 * (vs * vs * vs);
     cr[((size_t)chain * 2 + 0) * n + j] = dadb;
     cr[((size_t)chain * 2 + 1) * n + j] = drda * dadb;
+    if (xw) {
+        // warm start of the root search (k_swd_warm): the model's change since the evaluation before this one and the
+        // chain-rule factors, chain-minor; xw then becomes this model
+        double* w = xw + (size_t)chain * 2 * n;
+        dxT[(size_t)j * nchain + chain] = vs - w[j];
+        dxT[(size_t)(n + j) * nchain + chain] = thk - w[n + j];
+        w[j] = vs; w[n + j] = thk;
+        crT[(size_t)j * nchain + chain] = dadb;
+        crT[(size_t)(n + j) * nchain + chain] = drda * dadb;
+    }
     if (has_rf) rf_make_layer(lc[(size_t)chain * n + j], thk, rho, vp, vs, 9999.0, 9999.0, ray_p);
     if (has_swd) {
         size_t s = (size_t)n * nchain;
@@ -502,11 +513,14 @@ struct SwdSeqs { SwdSeq s[4]; int nseq; int nper_total; };   // one wave family 
 template <bool LOVE>
 __global__ void __launch_bounds__(64)
 k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double* __restrict__ croot,
-            int* __restrict__ sflag)
+            int* __restrict__ sflag, const int* __restrict__ list, const int* __restrict__ count)
 {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    int seq = g / nchain, chain = g - seq * nchain;
+    // list != nullptr: only the *count chains named there (the chains the warm start handed back, k_swd_warm)
+    const int nsel = list ? *count : nchain;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; (g & ~63) < Q.nseq * nsel; g += gridDim.x * blockDim.x) {
+    int seq = g / (nsel > 0 ? nsel : 1), chain = g - seq * nsel;
     bool live = seq < Q.nseq;
+    if (live && list) chain = list[chain];
     if (!live) { seq = 0; chain = 0; }
     const size_t s = (size_t)n * nchain;
     const SwdSeq sq = Q.s[seq];
@@ -527,6 +541,7 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
         }
     }
     if (live) sflag[(size_t)seq * nchain + chain] = rs.flag;
+    }
 }
 
 // K3 (split): G lanes per (sequence, chain).  Every lane of a group runs the same search state
@@ -546,7 +561,8 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
 template <class F, int LPL, int NSEG, int SPEC>   // LPL layers per lane in registers: (n-1) <= G*LPL;  NSEG segments;  SPEC wavefronts
 __global__ void __launch_bounds__(64 * SPEC)
 k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__ mdl,
-                  const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
+                  const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag,
+                  const int* __restrict__ list, const int* __restrict__ count)
 {
     extern __shared__ double split_lds[];        // per wavefront: entries [grp][m][15], NSEG > 1: rows [grp][chain][5];
     const int NG = 64 / G;                       // then SPEC > 1: Delta [SPEC][NG], the points they belong to [SPEC][NG]
@@ -564,9 +580,14 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
     double* const ent_g = ent_lds + (size_t)grp * (n - 1) * NENT;
     double* const seg_g = seg_lds + (size_t)grp * (NCHAINS + 1) * NV;
     double* const hs_g = seg_g + NCHAINS * NV;   // half-space start vector, built beside the layer entries by the group's last lane
-    int item = blockIdx.x * NG + grp;            // (sequence, chain) handled by this group
-    int seq = item / nchain, chain = item - seq * nchain;
+    // list != nullptr: only the *count chains named there (the chains the warm start handed back, k_swd_warm); the
+    // blocks then stride over the items, whose number the host does not know
+    const int nsel = list ? *count : nchain;
+    for (int blk = blockIdx.x; blk * NG < Q.nseq * nsel; blk += gridDim.x) {
+    int item = blk * NG + grp;                   // (sequence, chain) handled by this group
+    int seq = item / (nsel > 0 ? nsel : 1), chain = item - seq * nsel;
     bool live = seq < Q.nseq;
+    if (live && list) chain = list[chain];
     if (!live) { seq = 0; chain = 0; }
     const size_t s = (size_t)n * nchain;
     const SwdSeq sq = Q.s[seq];
@@ -705,6 +726,89 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
         __syncthreads();
     }
     if (writer) sflag[(size_t)seq * nchain + chain] = rs.flag;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3w warm-started root refinement inside a trajectory: lane = (item, chain), item = (sequence, period) of one wave
+// family -- every period on its own, no hand-over between periods (WarmSearch, swd_math.hpp).  The previous evaluation
+// of the SAME chains left its roots (croot), kernels (krn) and model behind; k_prep_joint wrote the model change dxT.
+// A lane predicts its root to first order, brackets it inside the trust radius, refines it by false position and
+// overwrites croot in place.  A lane that cannot (no usable previous evaluation, no sign change where the first-order
+// model says, root above the fastest layer) puts its CHAIN on the list for the reference-semantics search that
+// follows on the same stream (k_swd_roots_split / k_swd_roots with list), which rewrites all of that chain's roots
+// and alone decides its flag.
+// ---------------------------------------------------------------------------------------
+struct SwdWarm {
+    const double* dxT;      // [2n][chain] model change since the previous evaluation (vs, thk)
+    const double* crT;      // [2][n][chain] chain-rule factors dadb, drda * dadb
+    const int* valid;       // [chain] the previous evaluation of this chain succeeded
+    const int* force;       // [chain] the caller wants the reference-semantics search this time (or nullptr)
+    int* need;              // [chain] out: 1 = goes to the reference-semantics search
+    int* count; int* list;  // ... and the compacted list of those chains
+    unsigned long long* stats;   // [0] chains handed back, [1] secular evaluations, [2] items refined
+};
+
+template <class F, bool SPH>
+__global__ void __launch_bounds__(64)
+k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const double* __restrict__ sph,
+           const double* __restrict__ krn, double* __restrict__ croot, SwdWarm W)
+{
+    const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (size_t)Q.nper_total * nchain) return;
+    const int el = (int)(g / nchain), chain = (int)(g - (size_t)el * nchain);
+    const int e = Q.s[0].croot_off + el;
+    int seq = 0;
+    while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
+    const int k = e - Q.s[seq].croot_off;
+    const size_t s = (size_t)n * nchain;
+    auto decline = [&]() {
+        if (atomicExch(&W.need[chain], 1) == 0) {
+            W.list[atomicAdd(W.count, 1)] = chain;
+            atomicAdd(&W.stats[0], 1ull);
+        }
+    };
+    if (!W.valid[chain] || (W.force && W.force[chain])) { decline(); return; }
+    // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
+    // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
+    // vtp / dtp / rtp as swd_kernel_value does
+    const double* kr0 = krn + (size_t)e * 4 * s + chain;
+    double dc = 0.0, l1 = 0.0, suf = 0.0;
+    float betmx = -1.e20f;
+    for (int m = n - 1; m >= 0; m--) {
+        const size_t lm = (size_t)m * nchain;
+        double ka = kr0[lm], kb = kr0[s + lm], kr = kr0[2 * s + lm], kh = kr0[3 * s + lm];
+        if (SPH) {
+            const double vtp = sph[4 * s + lm + chain], dtp = sph[5 * s + lm + chain], rtp = sph[6 * s + lm + chain];
+            ka *= vtp; kb *= vtp; kr *= rtp; kh *= dtp;
+        }
+        const double gv = kb + ka * W.crT[lm + chain] + kr * W.crT[s + lm + chain];
+        const double t1 = gv * W.dxT[lm + chain], t2 = suf * W.dxT[s + lm + chain];
+        dc += t1 + t2; l1 += fabs(t1) + fabs(t2);
+        suf += kh;
+        betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);
+    }
+    const double cprev = croot[(size_t)e * nchain + chain];
+    const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
+    const double* lc0 = mdlc + chain;
+    auto loadL = [&](int m) {
+        const double* o = lc0 + (size_t)m * 6 * nchain;
+        return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                         o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+    };
+    WarmSearch ws;
+    ws.begin(cprev, dc, l1);
+    if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
+    while (__any(ws.active())) {
+        if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
+    }
+    const bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
+    if (ok) croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                // surfdisp96.f:302
+    else decline();
+    int nev = ws.nev, nok = ok ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&W.stats[1], (unsigned long long)nev); atomicAdd(&W.stats[2], (unsigned long long)nok); }
 }
 
 constexpr int COOP_CL = 1;                       // the consumer builds the deepest finite layer itself
@@ -1109,7 +1213,7 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
               const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
               const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
               const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
-              double* __restrict__ dsyn, int* __restrict__ flag)
+              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid)
 {
     extern __shared__ double hs[];               // [n][32] interface partial sums
     // 32 chains x 32 layer slots per block: a wavefront = 32 consecutive chains (256 B segments of the chain-minor
@@ -1167,13 +1271,14 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
     if (!ok) {
         // failure returns: joint -> (0, zeros, dobs, False); SWD only -> (0, zeros, zeros, False)
         if (dsyn) for (int i = slot; i < ndata; i += NS) dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
-        if (slot == 0) { misfit[chain] = 0.0; flag[chain] = 0; }
+        if (slot == 0) { misfit[chain] = 0.0; flag[chain] = 0; if (wvalid) wvalid[chain] = 0; }
         return;
     }
     if (slot == 0) {
         double mr = (mode == 0) ? misfit_rf[chain] : 0.0;
         misfit[chain] = mr + w * (0.5 * m_swd);
         flag[chain] = 1;
+        if (wvalid) wvalid[chain] = 1;          // roots + kernels of this chain can seed the next evaluation (k_swd_warm)
     }
 }
 
@@ -1246,11 +1351,12 @@ __global__ void k_leap_begin(int nchain, int nx, int ndata, const double* minv, 
 // x += dt p ; mirror reflection at the bounds (hmc.py:121-137, 166-169); only chains still
 // inside their trajectory (step < L) and not failed move.
 __global__ void k_leap_drift(int nchain, int nx, int step, const double* minv, const double* dt, const int* L,
-                             const double* bounds, double* x, double* p, int* ok)
+                             const double* bounds, double* x, double* p, int* ok, int* wforce)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nx) return;
     int chain = g / nx, i = g - chain * nx;
+    if (wforce && i == 0) wforce[chain] = step == L[chain] - 1;      // option swd_exact_final: the end model by the full search
     if (!ok[chain] || step >= L[chain]) return;
     double xv = x[g] + dt[chain] * (p[g] * (minv ? minv[i] : 1.0)), pv = p[g];
     double lo = bounds[2 * i], hi = bounds[2 * i + 1];
@@ -1313,11 +1419,13 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
 // with this call (x = start model, p = drawn momentum).  Same arithmetic as k_leap_begin / drift / kick.
 // ---------------------------------------------------------------------------------------
 __global__ void k_flow_pre(int nchain, int nx, const double* minv, const double* dt, const int* rem, const int* fresh, const int* ok,
-                           const double* bounds, double* x, double* p, const double* gsave, const int* kick)
+                           const double* bounds, double* x, double* p, const double* gsave, const int* kick, int* wforce)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nx) return;
     int chain = g / nx, i = g - chain * nx;
+    // option swd_exact_final: start and end models of a trajectory by the reference-semantics search (k_swd_warm's force)
+    if (wforce && i == 0) wforce[chain] = fresh[chain] || rem[chain] == 1;
     if (fresh[chain] || rem[chain] <= 0 || !ok[chain]) return;
     double pv = p[g];
     if (kick && kick[chain]) pv = pv - dt[chain] * gsave[g] * 0.5;      // the half kick a deferred start left open (hmc.py:164)

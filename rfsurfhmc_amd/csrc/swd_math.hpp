@@ -623,6 +623,120 @@ struct RootSearchT {
 };
 using RootSearch = RootSearchT<NevTabReg>;
 
+// ---------------------------------------------------------------------------
+// Warm-started root refinement for the leapfrog loop (no counterpart in the reference, which searches every model
+// from scratch: surfdisp96.f:257-316).  Inside a trajectory the model of step s differs from that of step s-1 by
+// dx = dt M^-1 p, and step s-1 left both its roots c_k and their Frechet kernels dc_k/dm behind.  Every (period,
+// chain) item is therefore independent of the other periods:
+//     predict   c_pred = c_prev + sum_j G_j dx_j          (first order; G = the kernels through the chain rule)
+//     bracket   [c_pred - eps, c_pred + eps], widened x4 (likelier side first) while the secular function keeps its
+//               sign, never beyond the trust radius R = R0 c + R1 sum_j |G_j dx_j|
+//     refine    false position with the Illinois rule until two successive estimates agree to WARM_TOL c
+// about 3 secular evaluations instead of the ~23 of the sequential scan + nevill, and lane = (period, chain).
+// The machine only REQUESTS evaluations, like RootSearchT.  It declines (status W_FAIL) whenever anything is off --
+// no sign change inside the trust radius, no convergence, a root above the fastest layer -- and the caller then runs
+// the reference-semantics search for that chain, which alone decides flags.  Accepted roots lie within WARM_TOL c of
+// a sign change of the very function the reference search brackets, i.e. inside the reference's own refinement
+// tolerance 1e-6 c (surfdisp96.f:627); they are rounded to float32 like the reference's (surfdisp96.f:302).
+// ---------------------------------------------------------------------------
+constexpr double WARM_TOL = 1.0e-7;          // relative agreement of two successive estimates
+constexpr double WARM_EPS0 = 1.0e-5;         // first bracket half-width, relative to c (+ WARM_EPS1 * l1)
+constexpr double WARM_EPS1 = 0.03;
+constexpr double WARM_R0 = 2.0e-4;           // trust radius: R0 c + R1 l1
+constexpr double WARM_R1 = 0.5;              // (a first-order model that misses by more than half its own size is no guide)
+constexpr double WARM_L1MAX = 0.1;           // km/s: beyond this first-order change the model is not "the previous one, moved"
+constexpr int WARM_MAXIT = 12;
+
+struct WarmSearch {
+    enum { W_A, W_B, W_X, W_REF, W_DONE, W_FAIL };
+    double cpred, eps, R, a, fa, b, fb, creq, root;
+    int phase, it, side, second, lastside, nev;
+
+    RFS_HD bool active() const { return phase < W_DONE; }
+
+    // cprev: root of the previous model; dc: first-order change; l1: sum of |first-order terms|
+    RFS_HD void begin(double cprev, double dc, double l1) {
+        cpred = cprev + dc;
+        R = WARM_R0 * cpred + WARM_R1 * l1;
+        nev = 0; it = 0; side = 0; second = 0; lastside = -1; root = 0.0;
+        fa = fb = 0.0;
+        eps = WARM_EPS0 * cpred + WARM_EPS1 * l1;
+        a = cpred - eps; b = cpred + eps; creq = a;
+        phase = W_A;
+        // not a continuation of the previous model (or no previous root at all): leave it to the full search
+        if (!(cprev > 0.0) || !(l1 <= WARM_L1MAX) || !(a > 0.0)) phase = W_FAIL;
+    }
+
+    RFS_HD void refine_from_bracket() {          // (a, fa), (b, fb) hold a sign change
+        const double c3 = a - fa * (b - a) / (fb - fa);
+        creq = c3; phase = W_REF; lastside = -1;
+    }
+
+    RFS_HD void advance(double f) {
+        nev++;
+        if (f != f) { phase = W_FAIL; return; }
+        bool widen = false;
+        if (phase == W_A) { fa = f; creq = b; phase = W_B; }
+        else if (phase == W_B) {
+            fb = f;
+            if (diffsign(fa, fb)) refine_from_bracket();
+            else { second = 0; widen = true; }
+        } else if (phase == W_X) {                 // a point further out on `side` was evaluated
+            bool found = false;
+            if (side == 0) {
+                if (diffsign(f, fa)) { b = a; fb = fa; a = creq; fa = f; found = true; }
+                else { a = creq; fa = f; }
+            } else {
+                if (diffsign(f, fb)) { a = b; fa = fb; b = creq; fb = f; found = true; }
+                else { b = creq; fb = f; }
+            }
+            if (found) refine_from_bracket();
+            else if (!second) {                    // the other side at the same distance
+                second = 1; side = 1 - side;
+                creq = side == 0 ? cpred - eps : cpred + eps;
+                if (!(creq > 0.0)) phase = W_FAIL;
+            } else { second = 0; widen = true; }
+        } else if (phase == W_REF) {
+            const double c3 = creq;
+            if (f == 0.0) { root = c3; phase = W_DONE; return; }
+            if (!diffsign(f, fa)) { a = c3; fa = f; if (lastside == 0) fb *= 0.5; lastside = 0; }    // Illinois rule
+            else { b = c3; fb = f; if (lastside == 1) fa *= 0.5; lastside = 1; }
+            const double c4 = a - fa * (b - a) / (fb - fa);
+            if (fabs(c4 - c3) <= WARM_TOL * fabs(c4)) { root = c4; phase = W_DONE; }
+            else if (++it >= WARM_MAXIT || !(c4 >= a && c4 <= b)) phase = W_FAIL;
+            else creq = c4;
+        }
+        if (widen) {
+            if (eps >= R) { phase = W_FAIL; return; }
+            eps = fmin(4.0 * eps, R);
+            side = (fabs(fa) <= fabs(fb)) ? 0 : 1;           // the side the function is closer to zero on goes first
+            creq = side == 0 ? cpred - eps : cpred + eps;
+            phase = (creq > 0.0) ? (int)W_X : (int)W_FAIL;
+        }
+    }
+};
+
+// The secular function of wave family F at phase velocity c, layer constants through a loader (m -> SwdLayerC):
+// the arithmetic of the lanes-per-item search (raw recurrence, power-of-two rescale every eighth layer, one final
+// normalisation), evaluated by ONE lane.
+template <class F, class LoadL>
+RFS_HD double swd_secular_family(int n, const LoadL& loadL, double omega_raw, double c) {
+    const double omega = omega_raw < 1.0e-4 ? 1.0e-4 : omega_raw, iomega = 1.0 / omega;
+    const double wvno = omega_raw / c, wvno2 = wvno * wvno, tt = -2.0 * wvno2;
+    double e[F::NV];
+    F::halfspace(loadL(n - 1), wvno, wvno2, omega, iomega, e);
+    SwdLayerC L = loadL(n - 2 >= 0 ? n - 2 : 0);
+    for (int m = n - 2; m >= 0; m--) {
+        const SwdLayerC Ln = loadL(m > 0 ? m - 1 : 0);      // next layer's constants on their way during this layer's math
+        double ent[F::NENT];
+        F::entries(L, wvno, wvno2, omega, iomega, ent);
+        F::apply(e, ent, tt);
+        if ((m & 7) == 0) swd_rescale_pow2_n<F::NV>(e);
+        L = Ln;
+    }
+    return swd_finish_n<F::NV>(e);
+}
+
 
 // ---------------------------------------------------------------------------
 // Eigenfunction pass.  float32 pi as in sregn96.f90:1654.

@@ -237,3 +237,41 @@ double hs_eigen_general(int n, const float* thk, const float* vp, const float* v
     return u;
 }
 }
+
+// Warm-started refinement (WarmSearch + swd_secular_family: the lane code of k_swd_warm) for the nt periods of one
+// model: cprev / dc / l1 per period as the kernel's predictor hands them over.  status[k] = 1 accepted, 0 declined;
+// nev[k] = secular evaluations spent.  Returns the number of declined periods.
+extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                             const double* t, const double* cprev, const double* dc, const double* l1, int love,
+                             int sphere, double* cout, int* nev, int* status)
+{
+    std::vector<float> w(4 * n);
+    const float *d = thk, *a = vp, *b = vs, *r = rho;
+    if (sphere) {
+        swd_flatten_f32(love != 0, n, thk, vp, vs, rho, 1, &w[0], &w[n], &w[2 * n], &w[3 * n], 1);
+        d = &w[0]; a = &w[n]; b = &w[2 * n]; r = &w[3 * n];
+    }
+    std::vector<SwdLayerC> LC(n);
+    float betmx = -1.e20f;
+    for (int m = 0; m < n; m++) {
+        LC[m] = SwdLayerC{(double)d[m], 1.0 / (double)a[m], 1.0 / (double)b[m], (double)b[m], (double)r[m], 1.0 / (double)r[m]};
+        if (b[m] > betmx) betmx = b[m];
+    }
+    auto loadL = [&](int m) { return LC[m]; };
+    int nfail = 0;
+    for (int k = 0; k < nt; k++) {
+        const double omega = (2.0 * 3.141592653589793) / t[k];
+        WarmSearch ws;
+        ws.begin(cprev[k], dc[k], l1[k]);
+        while (ws.active()) {
+            double f = love ? swd_secular_family<SwdLoveFamily>(n, loadL, omega, ws.creq)
+                            : swd_secular_family<SwdRayFamily>(n, loadL, omega, ws.creq);
+            ws.advance(f);
+        }
+        bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);
+        cout[k] = ok ? (double)(float)ws.root : 0.0;
+        nev[k] = ws.nev; status[k] = ok ? 1 : 0;
+        nfail += !ok;
+    }
+    return nfail;
+}
