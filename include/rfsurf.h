@@ -259,6 +259,9 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          2 = also for rfs_joint_misfit_grad[_dev]: the CALLER promises that consecutive calls with the
  *                          same nchain evaluate the same chains a small step apart (a host-side leapfrog loop).
  *                          rfs_swd_forward / rfs_swd_kernel / rfs_joint_forward never warm-start.
+ *   "swd_warm_reset"       (any value) forget the previous evaluation: the next one goes through the reference-semantics
+ *                          search for every chain.  A sampler calls it where a run may be cut and resumed (a checkpoint),
+ *                          so that the resumed run and the uninterrupted one evaluate the same way from there on.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.

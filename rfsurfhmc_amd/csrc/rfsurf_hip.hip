@@ -84,7 +84,7 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn;
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
@@ -613,7 +613,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // the chains that cannot be continued go through the reference-semantics search right behind, on a list.
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
-                  c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>()};
+                  c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
+                  c->wsgn.as<unsigned char>()};
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -625,6 +626,13 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
         if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
 #undef RFS_LAUNCH_WARM
+        // ... and is the continued root still the one the reference's scan would stop at?  (one evaluation per item)
+        if (Q.nper_total > 0)
+            hipLaunchKernelGGL((k_swd_warm_check<SwdRayFamily>), dim3((unsigned)(((size_t)Q.nper_total * nchain + 63) / 64)), dim3(64), 0, s,
+                               nchain, n, Q, mdlR, c->mdlc.as<double>(), c->croot.as<double>(), W);
+        if (P.QL.nper_total > 0)
+            hipLaunchKernelGGL((k_swd_warm_check<SwdLoveFamily>), dim3((unsigned)(((size_t)P.QL.nper_total * nchain + 63) / 64)), dim3(64), 0, s,
+                               nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
         HIPCHK(c, hipGetLastError());
         const int* list = c->wlist.as<int>();
         const int* count = c->wneed.as<int>() + nchain;
@@ -735,15 +743,17 @@ int upload(rfs_ctx* c, Buf& b, const void* host, size_t bytes) {
 }
 
 // the whole misfit+gradient evaluation on device pointers
-// traj: the call continues a trajectory of the SAME nchain chains (leapfrog / flow entries): the root search may start
-// from the previous evaluation (option "swd_warm_start")
+// traj: 1 = the call continues a trajectory of the SAME nchain chains (leapfrog / flow entries): the root search may
+// start from the previous evaluation (option "swd_warm_start"); 2 = the start models of a batch of trajectories
+// (rfs_leapfrog_dev): always the reference-semantics search, whose roots and kernels then seed the steps; 0 = a
+// plugin evaluation
 int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn, int32_t* flag,
-               bool traj = false) {
+               int traj = 0) {
     const int n = c->n;
     HIPCHK(c, hipSetDevice(c->device));
     // track: keep the model / roots / kernels of this evaluation for the next one; warm: use those of the previous one
     const bool track = c->has_swd && (c->warm_opt == 2 || (c->warm_opt == 1 && traj));
-    const bool warm = track && c->warm_primed && c->warm_nchain == nchain;
+    const bool warm = track && c->warm_primed && c->warm_nchain == nchain && traj != 2;
     if (track) {
         const size_t nn = (size_t)n * nchain;
         if (c->warm_nchain != nchain) c->warm_primed = false;
@@ -753,6 +763,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, ((size_t)nchain + 1) * sizeof(int));
         ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
         ENSURE(c, c->wstats, 4 * sizeof(unsigned long long));
+        ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         if (c->wvalid.cap != before) {
             HIPCHK(c, hipMemsetAsync(c->wforce.p, 0, c->wforce.cap, c->stream));
             HIPCHK(c, hipMemsetAsync(c->wstats.p, 0, c->wstats.cap, c->stream));
@@ -1033,7 +1044,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats};
+                   &c->wstats, &c->wsgn};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     drop_plans(c);
@@ -1123,6 +1134,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_warm_start must be 0, 1 or 2");
         c->warm_opt = value; c->warm_primed = false; return RFS_OK;
     }
+    if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
     if (!strcmp(name, "swd_exact_final")) {
         c->exact_final = value != 0;
         if (c->wforce.p) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->wforce.p, 0, c->wforce.cap, c->stream)); }
@@ -1469,14 +1481,17 @@ int rfs_leapfrog_dev2(rfs_ctx* c, int nchain, const double* x0, const double* p0
            *d = c->ldsyn.as<double>();
     int* fl = c->lflag.as<int>();
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
-    const bool traj = nactive == nullptr;      // (a shrinking chain count changes the layout of the kept roots / kernels)
+    // The start models go through the reference-semantics search whatever the options say: a batch of trajectories is
+    // then a function of its arguments alone (a resumed run repeats an uninterrupted one bit for bit), and Ucur / Hcur
+    // are the reference's numbers.  The steps continue from there.  (nactive: a shrinking chain count changes the layout
+    // of the kept roots / kernels -- no warm start.)
+    const int traj = nactive == nullptr ? 1 : 0;
     int* wforce = nullptr;
     if (traj && c->exact_final && c->has_swd && c->warm_opt) {
         ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
-        HIPCHK(c, hipMemsetAsync(c->wforce.p, 0xff, (size_t)nchain * sizeof(int), c->stream));    // start models: full search
         wforce = c->wforce.as<int>();
     }
-    TRY(joint_eval(c, nchain, x0, U, g, d, fl, traj));
+    TRY(joint_eval(c, nchain, x0, U, g, d, fl, traj ? 2 : 0));
     hipLaunchKernelGGL(k_leap_begin, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, x0, p0, dt, L, Lmax, U, g, d, fl,
                        x, p, Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok);
     // failed chains (ok = 0: failed evaluation, or L outside [1, Lmax]) keep xnew = x0, Hnew = +inf written by
@@ -1539,7 +1554,7 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     if (c->exact_final && c->has_swd && c->warm_opt) { ENSURE(c, c->wforce, (size_t)nchain * sizeof(int)); wforce = c->wforce.as<int>(); }
     hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p,
                        fn.gsave, fn.kick, wforce);
-    TRY(joint_eval(c, nchain, x, U, g, d, fl, true));
+    TRY(joint_eval(c, nchain, x, U, g, d, fl, 1));
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn);
     HIPCHK(c, hipGetLastError());

@@ -747,6 +747,7 @@ struct SwdWarm {
     int* need;              // [chain] out: 1 = goes to the reference-semantics search
     int* count; int* list;  // ... and the compacted list of those chains
     unsigned long long* stats;   // [0] chains handed back, [1] secular evaluations, [2] items refined
+    unsigned char* sgn;     // [item][chain] sign bit of the secular function just below the refined root (2: no root)
 };
 
 template <class F, bool SPH>
@@ -768,6 +769,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
             atomicAdd(&W.stats[0], 1ull);
         }
     };
+    W.sgn[(size_t)e * nchain + chain] = 2;
     if (!W.valid[chain] || (W.force && W.force[chain])) { decline(); return; }
     // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
     // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
@@ -803,12 +805,58 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
     }
     const bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
-    if (ok) croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                // surfdisp96.f:302
-    else decline();
+    if (ok) {
+        croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
+        W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
+    } else decline();
     int nev = ws.nev, nok = ok ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&W.stats[1], (unsigned long long)nev); atomicAdd(&W.stats[2], (unsigned long long)nok); }
+}
+
+// The branch test of the warm start (WarmSearch, swd_math.hpp): one secular evaluation per item at the point the
+// reference's scan of this period would start from -- the continued root of the period before minus 1.5 dc, or the
+// model's start value for a sequence's first period (surfdisp96.f:257-276).  mdl: the float32 search model (start value).
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc,
+                 const double* __restrict__ croot, SwdWarm W)
+{
+    const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (size_t)Q.nper_total * nchain) return;
+    const int el = (int)(g / nchain), chain = (int)(g - (size_t)el * nchain);
+    const int e = Q.s[0].croot_off + el;
+    int seq = 0;
+    while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
+    const int k = e - Q.s[seq].croot_off;
+    if (W.need[chain]) return;                                       // already on its way to the full search
+    const int sg = W.sgn[(size_t)e * nchain + chain];
+    const double ck = croot[(size_t)e * nchain + chain];
+    double sk;
+    if (k == 0) {
+        const size_t s = (size_t)n * nchain;
+        SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        float bmx;
+        sk = (double)swd_start_value(M, bmx);
+    } else {
+        sk = croot[(size_t)(e - 1) * nchain + chain] - 1.5 * (double)0.005f;
+    }
+    const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
+    const double* lc0 = mdlc + chain;
+    auto loadL = [&](int m) {
+        const double* o = lc0 + (size_t)m * 6 * nchain;
+        return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                         o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+    };
+    bool bad = sg > 1 || !(sk < ck) || !(sk > 0.0);
+    const double f = swd_secular_family<F>(n, loadL, omega, bad ? ck : sk);
+    bad = bad || ((signbit(f) ? 1 : 0) != sg);
+    if (bad && atomicExch(&W.need[chain], 1) == 0) {
+        W.list[atomicAdd(W.count, 1)] = chain;
+        atomicAdd(&W.stats[0], 1ull);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[1], 64ull);
 }
 
 constexpr int COOP_CL = 1;                       // the consumer builds the deepest finite layer itself

@@ -407,6 +407,23 @@ RFS_HD float swd_gtsolh(float a, float b) {
     return c;
 }
 
+// surfdisp96.f:149-160 extremal velocities, :203-222 start value of the search: 0.95 * 0.90 * (Rayleigh velocity of the
+// half-space made of the slowest layer), all in single precision; betmx = fastest S velocity
+template <class Mdl>
+RFS_HD float swd_start_value(const Mdl& M, float& betmx) {
+    float bmx = -1.e20f, bmn = 1.e20f; int jmn = 0, jsol = 1;
+    for (int i = 0; i < M.n; i++) {
+        float b = M.Bf(i), a = M.Af(i);
+        if (b > 0.01f && b < bmn) { bmn = b; jmn = i; jsol = 1; }
+        else if (b <= 0.01f && a < bmn) { bmn = a; jmn = i; jsol = 0; }
+        if (b > bmx) bmx = b;
+    }
+    float cc1 = (jsol == 0) ? bmn : swd_gtsolh(M.Af(jmn), M.Bf(jmn));
+    cc1 = 0.95f * cc1; cc1 = 0.90f * cc1;
+    betmx = bmx;
+    return cc1;
+}
+
 // ---------------------------------------------------------------------------
 // Root search state machine.  Usage:
 //     rs.begin(model, periods, kmax);
@@ -465,15 +482,7 @@ struct RootSearchT {
     RFS_HD void begin(const SwdModel& M, const PeriodFn& T, int kmax_) {
         // (the P velocity only enters through the water-layer test and the half-space start value gtsolh)
         // surfdisp96.f:149-160 extremal velocities, :203-222 start value
-        float bmx = -1.e20f, bmn = 1.e20f; int jmn = 0, jsol = 1;
-        for (int i = 0; i < M.n; i++) {
-            float b = M.Bf(i), a = M.Af(i);
-            if (b > 0.01f && b < bmn) { bmn = b; jmn = i; jsol = 1; }
-            else if (b <= 0.01f && a < bmn) { bmn = a; jmn = i; jsol = 0; }
-            if (b > bmx) bmx = b;
-        }
-        float cc1 = (jsol == 0) ? bmn : swd_gtsolh(M.Af(jmn), M.Bf(jmn));
-        cc1 = 0.95f * cc1; cc1 = 0.90f * cc1;
+        float bmx; float cc1 = swd_start_value(M, bmx);
         cc = (double)cc1; dc = (double)0.005f; cm = cc; betmx = bmx;
         kmax = kmax_; k = 0; retry = 0; done = 0; flag = 1; nsec = 0;
         del1st = 0.0; cprev = 0.0; m = 1; nev = 1; nctrl = 1;
@@ -633,6 +642,11 @@ using RootSearch = RootSearchT<NevTabReg>;
 //               sign, never beyond the trust radius R = R0 c + R1 sum_j |G_j dx_j|
 //     refine    false position with the Illinois rule until two successive estimates agree to WARM_TOL c
 // about 3 secular evaluations instead of the ~23 of the sequential scan + nevill, and lane = (period, chain).
+// A second, one-evaluation test keeps the continued root on the branch the reference's scan would pick: the scan of
+// period k starts at c(k-1) - 1.5 dc (the first period at the start value of the model, surfdisp96.f:257-276) and takes
+// the first sign change it meets, so the secular function at that start point must still have the sign it has just
+// below the continued root (k_swd_warm_check); otherwise another root has moved in between, or the dispersion has turned
+// anomalous and the scan would run downwards, and the chain is handed back.
 // The machine only REQUESTS evaluations, like RootSearchT.  It declines (status W_FAIL) whenever anything is off --
 // no sign change inside the trust radius, no convergence, a root above the fastest layer -- and the caller then runs
 // the reference-semantics search for that chain, which alone decides flags.  Accepted roots lie within WARM_TOL c of

@@ -12,6 +12,7 @@ class FusedPlugin:
 
     _ctx = None
     device = 0
+    _warm_start = None       # None = the library's default (rfs_set_option "swd_warm_start": 1)
 
     def _rf_params(self):
         return None
@@ -26,6 +27,8 @@ class FusedPlugin:
     def _configure(self, nlayer, dobs):
         if self._ctx is None:
             self._ctx = Context(device=self.device, max_chains=1 << 20, max_layers=128)
+            if self._warm_start is not None:
+                self._ctx.set_option("swd_warm_start", self._warm_start)
         ctx = self._ctx
         rf = self._rf_params()
         *tw, sphere = self._swd_config()
@@ -42,6 +45,21 @@ class FusedPlugin:
         tRc, tRg = tw[0], tw[1]
         self._cfg = (int(nlayer), None if d is None else d.tobytes())
         self._keep = (tw, d)
+
+    def set_warm_start(self, mode):
+        """Root search inside trajectories (include/rfsurf.h, option "swd_warm_start"): 0 = every evaluation by the
+        reference-semantics search (bit-exact float32 roots, bit-reproducible whatever the schedule); 1 = the
+        trajectory entries continue the previous step's roots (default: ~1.5x the leapfrog rate, roots within the
+        reference's own 1e-6 c refinement tolerance); 2 = also misfit_and_grad / misfit_and_grad_device (the caller
+        promises consecutive calls are consecutive models of the same chains)."""
+        self._warm_start = int(mode)
+        if self._ctx is not None:
+            self._ctx.set_option("swd_warm_start", self._warm_start)
+
+    def reset_warm_start(self):
+        """The next evaluation goes through the full search for every chain (samplers call this at checkpoints)."""
+        if self._ctx is not None:
+            self._ctx.set_option("swd_warm_reset", 1)
 
     def _ensure(self, nlayer):
         dobs = getattr(self, "dobs", None)

@@ -20,7 +20,7 @@ class HamitonianMC:
     def __init__(self, UserDefinedModel, boundaries, dt, Lrange, nbest_model, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
                  per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None,
-                 store_format="auto"):
+                 store_format="auto", warm_start=None):
         self.myrank = myrank
         self.nchains = int(nchains)
         self.first_chain = myrank * self.nchains
@@ -41,6 +41,10 @@ class HamitonianMC:
         # batched file per rank (always written when outdir is set); checkpoint: path of a resumable state file
         self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
         self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
+        # warm_start: None = the plugin's setting (library default: on); 0 / False = every evaluation by the
+        # reference-semantics root search (rfs_set_option "swd_warm_start")
+        if warm_start is not None and hasattr(self.model, "set_warm_start"):
+            self.model.set_warm_start(int(warm_start))
         # diagonal inverse mass M^-1 (None = the reference's identity): momenta are drawn as 0.5 z sqrt(M), the
         # device drifts with M^-1 p and uses K = p.M^-1 p / 2 (rfs_set_inverse_mass)
         self.inverse_mass = None if inverse_mass is None else np.asarray(inverse_mass, dtype=np.float64)
@@ -63,7 +67,7 @@ class HamitonianMC:
                    kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
                    nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"),
                    checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0),
-                   store_format=kargs.get("store_format", "auto"))
+                   store_format=kargs.get("store_format", "auto"), warm_start=kargs.get("warm_start"))
 
     def _set_inverse_mass(self, minv):
         self.inverse_mass = np.asarray(minv, dtype=np.float64)

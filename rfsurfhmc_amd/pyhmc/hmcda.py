@@ -29,7 +29,7 @@ class HMCDualAveraging:
     def __init__(self, UserDefinedModel, boundaries, dt, L0, nbest_model, target_ratio, seed, nsamples, ndraws,
                  myrank=0, name="mychain", outdir="./", nchains=1, store_syn=True, verbose=True,
                  per_chain_files=None, checkpoint=None, checkpoint_every=0, inverse_mass=None, mass_adapt=None,
-                 L_cap=None, store_format="auto"):
+                 L_cap=None, store_format="auto", warm_start=None):
         self.model = UserDefinedModel
         self.boundaries = np.asarray(boundaries, dtype=np.float64)
         self.dt, self.L = dt, L0
@@ -51,6 +51,10 @@ class HMCDualAveraging:
         self.store_format = store_format
         self.per_chain_files = (self.nchains <= 16) if per_chain_files is None else per_chain_files
         self.checkpoint, self.checkpoint_every = checkpoint, int(checkpoint_every)
+        # warm_start: None = the plugin's setting (library default: on); 0 / False = every evaluation by the
+        # reference-semantics root search (rfs_set_option "swd_warm_start")
+        if warm_start is not None and hasattr(self.model, "set_warm_start"):
+            self.model.set_warm_start(int(warm_start))
         # diagonal inverse mass M^-1 (None = the reference's identity): momenta are drawn as 0.5 z sqrt(M), the
         # device drifts with M^-1 p and uses K = p.M^-1 p / 2 (rfs_set_inverse_mass)
         self.inverse_mass = None if inverse_mass is None else np.asarray(inverse_mass, dtype=np.float64)
@@ -76,7 +80,7 @@ class HMCDualAveraging:
                    kargs["seed"], kargs["nsamples"], kargs["ndraws"], rank, kargs["name"], kargs["OUTPUT_DIR"],
                    nchains=kargs.get("nchains", 1), mass_adapt=kargs.get("mass_adapt"),
                    checkpoint=kargs.get("checkpoint"), checkpoint_every=kargs.get("checkpoint_every", 0),
-                   L_cap=kargs.get("L_cap"), store_format=kargs.get("store_format", "auto"))
+                   L_cap=kargs.get("L_cap"), store_format=kargs.get("store_format", "auto"), warm_start=kargs.get("warm_start"))
 
     def _traj_len(self, dt):
         """L = max(1, int(lambda / dt)) per chain (hmcda.py:307), clamped to L_cap before the integer cast."""

@@ -259,6 +259,7 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
     }
     auto loadL = [&](int m) { return LC[m]; };
     int nfail = 0;
+    std::vector<int> sgn_lo(nt, 0);
     for (int k = 0; k < nt; k++) {
         const double omega = (2.0 * 3.141592653589793) / t[k];
         WarmSearch ws;
@@ -271,7 +272,23 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
         bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);
         cout[k] = ok ? (double)(float)ws.root : 0.0;
         nev[k] = ws.nev; status[k] = ok ? 1 : 0;
-        nfail += !ok;
+        sgn_lo[k] = signbit(ws.fa) ? 1 : 0;
     }
+    // the check of k_swd_warm_check: the secular function at the point the reference's scan of period k starts from
+    // must have the sign it has just below the root
+    SwdModel M{d, a, b, r, 1, n};
+    RootSearch rs;
+    auto T = [&](int k) { return t[k]; };
+    rs.begin(M, T, nt);
+    for (int k = 0; k < nt; k++) {
+        if (!status[k] || (k > 0 && !status[k - 1])) continue;
+        const double omega = (2.0 * 3.141592653589793) / t[k];
+        const double sk = k == 0 ? rs.cc : cout[k - 1] - 1.5 * rs.dc;
+        double f = love ? swd_secular_family<SwdLoveFamily>(n, loadL, omega, sk)
+                        : swd_secular_family<SwdRayFamily>(n, loadL, omega, sk);
+        nev[k]++;
+        if ((signbit(f) ? 1 : 0) != sgn_lo[k] || !(sk < cout[k])) status[k] = 2;
+    }
+    for (int k = 0; k < nt; k++) nfail += status[k] != 1;
     return nfail;
 }

@@ -322,6 +322,7 @@ def test_flow_step2_deferred_form_equals_the_plain_step(orc):
     x0 = np.hstack((vs, thk))
     t = np.linspace(6.0, 30.0, 6)
     m = SurfWD(tRc=t)
+    m.set_warm_start(0)          # two flow states share this context call by call: each call must stand on its own
     d0, fl = m.forward(x0); m.set_obsdata(d0 * 1.01)
     nc, nx = 48, 16
     xs = np.tile(x0, (nc, 1)) * (1 + 0.01 * rng.standard_normal((nc, nx)))

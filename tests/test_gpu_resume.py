@@ -35,30 +35,33 @@ def _bounds():
 def _sampler(kind, outdir, **kw):
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    # (warm_start = 1: the steps of a trajectory continue the roots of the step before; its start models always go through
+    # the full search, so a batch of trajectories depends on nothing but its arguments and a resumed run repeats exactly)
     common = dict(myrank=0, name="dev", outdir=str(outdir), nchains=64, verbose=False, per_chain_files=False, **kw)
     if kind == "hmc":
         return HamitonianMC(_fresh_joint(), _bounds(), 0.02, [3, 8], 3, 991206, 6, 2, **common)
     return HMCDualAveraging(_fresh_joint(), _bounds(), 0.02, 5, 3, 0.65, 991206, 6, 2, **common)
 
 
+@pytest.mark.parametrize("warm", [0, 1])
 @pytest.mark.parametrize("kind", ["hmc", "hmcda"])
-def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, tmp_path):
+def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, warm, tmp_path):
     from rfsurfhmc_amd.pyhmc._batched import export_chain, load_batched_results, load_chain_results
     # start models: perturbations of the true model (a prior draw whose root search fails makes the reference -- and the
     # mirror -- stop inside _find_initial_dt, hmcda.py:193-195)
     b = _bounds()
     x0 = np.hstack((VS, THK))[None, :] * (1 + 0.03 * np.random.default_rng(5).standard_normal((64, 2 * N)))
     x0 = np.clip(x0, b[:, 0], b[:, 1]); x0[:, :N] = np.sort(x0[:, :N], axis=1)
-    full = _sampler(kind, tmp_path / "a")
+    full = _sampler(kind, tmp_path / "a", warm_start=warm)
     mis_full = full.sample(x_init=x0)
     assert full.finished and np.isfinite(mis_full).all()
     ck = str(tmp_path / "state.npz")
-    part = _sampler(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2)
+    part = _sampler(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2, warm_start=warm)
     part.sample(x_init=x0, max_trajectories=5)
     assert not part.finished and os.path.exists(ck)
     ctx_part = part.model._ctx
     del part
-    rest = _sampler(kind, tmp_path / "b", checkpoint=ck)          # fresh plugin + rfs_ctx + sampler
+    rest = _sampler(kind, tmp_path / "b", checkpoint=ck, warm_start=warm)          # fresh plugin + rfs_ctx + sampler
     assert rest.model._ctx is None or rest.model._ctx is not ctx_part
     mis = rest.sample(resume=True)
     assert rest.finished

@@ -12,13 +12,17 @@ def rel(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
 
 
-def _joint(g, hip=True, orc=None):
+def _joint(g, hip=True, orc=None, warm=0):
+    """warm = 0: every evaluation by the reference-semantics root search -- the mode in which a chain's numbers do not
+    depend on its history, so schedules can be compared bit for bit and the reference's traces are met to 1e-6;
+    warm = 1: the library's default inside trajectories (tests/test_gpu_warm.py)."""
     t = g["t"]
     if hip:
         from rfsurfhmc_amd.model.model_rf import ReceiverFunc
         from rfsurfhmc_amd.model.model_surf import SurfWD
         from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
         j = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(0.045, 125, 0.4, 1.5, 5.0, 0.001, "P", "freq"), SurfWD(tRc=t, tRg=t))
+        j.set_warm_start(warm)
     else:
         j = orc.Joint_RF_SWD(1.0, 1.0, orc.ReceiverFunc(0.045, 125, 0.4, 1.5, 5.0, 0.001, "P", "freq"), orc.SurfWD(tRc=t, tRg=t))
     j.set_obsdata(g["dobs"][:125], g["dobs"][125:])

@@ -1,0 +1,285 @@
+"""-m gpu: the warm-started root search of the leapfrog loop (k_swd_warm; include/rfsurf.h option "swd_warm_start").
+
+Inside a trajectory every (period, chain) item continues the previous step's root with the previous step's Frechet kernels
+as predictor, instead of repeating the reference's sequential scan (surfdisp96.f:257-316).  What is checked here:
+  * every root of every step of 20-step trajectories of the 8192 bench chains against the C restatement of surfdisp96
+    (bit-exact against the compiled reference): same flags, every root within 1.2e-6 c -- the reference's own refinement
+    tolerance (surfdisp96.f:627) plus the float32 rounding of both values;
+  * option 0 restores the history-free search bit for bit; models the search fails on get the reference's flags;
+  * Love / group-velocity / spherical blocks; the sampler traces of the reference at the tolerance the warm start keeps;
+  * "swd_exact_final": the end model of a trajectory carries reference-exact roots.
+"""
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def _bench_joint(warm, n=30, nt=512, dt=0.1, **swd):
+    import bench
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    t = np.linspace(5, 44, bench.NPER)
+    j = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, nt, dt, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq"),
+                     SurfWD(tRc=t, **swd))
+    j.set_warm_start(warm)
+    drf, dswd, flag = j.forward(bench.true_model(n))
+    assert flag
+    j.set_obsdata(drf, dswd)
+    return j, t
+
+
+def _leapfrog_move(x, p, g, dt, lo, hi):
+    """One leapfrog step with unit mass and mirror reflection (pyhmc/hmc.py:121-137,166-183), on torch tensors."""
+    import torch
+    p = p - dt * g
+    x = x + dt * p
+    for _ in range(4):
+        over, under = x > hi, x < lo
+        x = torch.where(over, 2 * hi - x, x); x = torch.where(under, 2 * lo - x, x)
+        p = torch.where(over | under, -p, p)
+    return x, p
+
+
+_ORC = {}
+
+
+def _oracle_roots(args):
+    xs, t, n = args
+    if "o" not in _ORC:
+        from oracle import oracle
+        _ORC["o"] = oracle
+    O = _ORC["o"]
+    out = np.zeros((len(xs), len(t))); ok = np.zeros(len(xs), dtype=bool)
+    for i, x in enumerate(xs):
+        vs, thk = x[:n], x[n:]
+        vp, rho, _, _ = O.empirical_relation(vs)
+        out[i], ok[i] = O.libsurf.forward(thk, vp, vs, rho, t, "Rc")
+    return out, ok
+
+
+def _oracle_batch(pool, xs, t, n, nproc):
+    parts = np.array_split(np.arange(len(xs)), nproc * 4)
+    res = pool.map(_oracle_roots, [(xs[p], t, n) for p in parts if len(p)])
+    return np.vstack([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+
+def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc):
+    """8192 bench chains x 20 leapfrog steps x 40 periods: the evaluation of every step continues the one before
+    (swd_warm_start = 2: the plugin entry, so that every step's synthetics come back), and every root of every step is
+    compared with the C restatement of the reference's search at that step's model."""
+    import os
+    import torch
+    import bench
+    n, nt, nchain, nsteps, dt = 30, 512, 8192, 20, 0.002
+    joint, t = _bench_joint(2)
+    ctx = joint._ensure(n)
+    dev = torch.device("cuda")
+    bounds = bench.bounds_of(bench.true_model(n))
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lo, hi = tt(bounds[:, 0]), tt(bounds[:, 1])
+    x = tt(bench.make_models(nchain, 991206, n))
+    p = tt(0.5 * np.random.default_rng(7).standard_normal((nchain, 2 * n)))
+    xs_steps, c_steps, f_steps = [], [], []
+    for s in range(nsteps + 1):
+        m, g, d, f = joint.misfit_and_grad_device(x)
+        xs_steps.append(x.cpu().numpy()); c_steps.append(d[:, nt:].cpu().numpy()); f_steps.append(f.cpu().numpy() != 0)
+        x, p = _leapfrog_move(x, p, g, dt, lo, hi)
+    items, evals = ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals")
+    declined = ctx.stat("swd_warm_declined_chains")
+    # the start models are evaluated by the full search; step 1 mirrors the out-of-range start thicknesses of the bench's
+    # models back into the bounds (a move of order 1 km that no first-order model covers: those chains are handed back);
+    # from then on nearly every chain is continued
+    assert items >= 0.95 * (nsteps - 1) * nchain * 40, (items, declined)
+    assert evals <= 4.6 * items, (evals, items)        # ~3 to refine + 1 for the branch test
+    nproc = max(1, min(16, len(os.sched_getaffinity(0))))
+    worst, nident, ntot = 0.0, 0, 0
+    with mp.get_context("fork").Pool(nproc) as pool:
+        for s in range(nsteps + 1):
+            co, oko = _oracle_batch(pool, xs_steps[s], t, n, nproc)
+            assert np.array_equal(oko, f_steps[s]), (s, int((oko != f_steps[s]).sum()))
+            ok = oko
+            r = np.abs(c_steps[s][ok] - co[ok]) / co[ok]
+            worst = max(worst, float(r.max()))
+            nident += int((c_steps[s][ok] == co[ok]).sum()); ntot += int(ok.sum()) * 40
+            assert r.max() <= 1.2e-6, (s, float(r.max()))
+    print(f"warm roots: {ntot} roots over {nsteps + 1} steps, worst {worst:.3e} c, bit-identical {nident}; "
+          f"{evals / max(items, 1):.2f} secular evaluations per item, {declined} chain evaluations handed back")
+
+
+def test_option_zero_is_the_history_free_search_and_failing_models_keep_their_flags(golden):
+    """swd_warm_start = 0 inside the flow entry == the plugin evaluation of the same models, bit for bit; with the warm
+    start on, models the reference search fails on (unsorted velocities with strong inversions) get the same flags and the
+    same failure returns, step after step."""
+    import torch
+    import bench
+    n, nt, nchain = 30, 512, 1024
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(11)
+    xs = bench.make_models(nchain, 5, n)
+    wild = rng.random(nchain) < 0.3                         # a third of the chains: unsorted layers
+    for i in np.nonzero(wild)[0]:
+        xs[i, :n] = rng.permutation(xs[i, :n])
+    bounds = np.stack([np.r_[np.full(n, 1.5), np.full(n, 0.0)], np.r_[np.full(n, 5.0), np.full(n, 3.0)]], axis=1)
+    lo, hi = tt(bounds[:, 0]), tt(bounds[:, 1])
+    jw, _ = _bench_joint(2); je, _ = _bench_joint(0)
+    x = tt(xs); p = tt(0.5 * rng.standard_normal(xs.shape))
+    nfail = 0
+    for s in range(8):
+        mw, gw, dw, fw = jw.misfit_and_grad_device(x)
+        me, ge, de, fe = je.misfit_and_grad_device(x)
+        assert torch.equal(fw, fe), s
+        bad = fe == 0
+        nfail += int(bad.sum())
+        assert torch.equal(mw[bad], me[bad]) and torch.equal(gw[bad], ge[bad]) and torch.equal(dw[bad], de[bad])
+        ok = ~bad
+        r = ((dw[ok][:, nt:] - de[ok][:, nt:]).abs() / de[ok][:, nt:]).max().item()
+        assert r <= 1.2e-6, (s, r)
+        x, p = _leapfrog_move(x, p, torch.where(bad[:, None], torch.zeros_like(gw), gw), 0.002, lo, hi)
+    # models the reference's search FAILS on (tests/golden/swd_reference.npz "inverted_20": ierr = 1 in the compiled
+    # reference) beside models it solves, moving together: same flags and failure returns at every step, and the failing
+    # chains never poison their neighbours
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    gs = golden["swd_reference"]
+    thk, vs, tp = gs["inverted_20/thk"], gs["inverted_20/vs"], gs["inverted_20/t"]
+    nl = len(vs)
+    x_bad = np.hstack((vs, thk)); x_ok = np.hstack((np.linspace(2.5, 4.2, nl), np.full(nl, 3.0)))
+    xs2 = np.vstack([x_bad if i % 3 == 0 else x_ok for i in range(192)]) * (1 + 0.002 * rng.standard_normal((192, 2 * nl)))
+    sw, se = SurfWD(tRc=tp), SurfWD(tRc=tp)
+    sw.set_warm_start(2); se.set_warm_start(0)
+    dobs = np.full(len(tp), 3.0)
+    sw.set_obsdata(dobs); se.set_obsdata(dobs)
+    x2 = tt(xs2); p2 = tt(0.5 * rng.standard_normal(xs2.shape))
+    lo2, hi2 = tt(0.5 * xs2.min(0)), tt(1.5 * xs2.max(0))
+    for s in range(6):
+        mw, gw, dw, fw = sw.misfit_and_grad_device(x2)
+        me, ge, de, fe = se.misfit_and_grad_device(x2)
+        assert torch.equal(fw, fe), s
+        bad = fe == 0
+        nfail += int(bad.sum())
+        assert torch.equal(mw[bad], me[bad]) and torch.equal(gw[bad], ge[bad]) and torch.equal(dw[bad], de[bad])
+        assert ((dw[~bad] - de[~bad]).abs() / de[~bad]).max().item() <= 1.2e-6
+        x2, p2 = _leapfrog_move(x2, p2, gw, 0.002, lo2, hi2)
+    assert nfail >= 6 * 60                                    # the inverted models do fail, at every step
+    # flow entry with the option off: every step's numbers are those of the plain evaluation
+    j0, _ = _bench_joint(0)
+    st = j0.flow_state(tt(xs[:256]), torch.full((256,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
+    st["p"].copy_(tt(0.5 * rng.standard_normal((256, 2 * n)))); st["rem"].fill_(3); st["fresh"].fill_(1)
+    for _ in range(4):
+        j0.flow_step(st)
+    torch.cuda.synchronize()
+    done = st["done"].cpu().numpy() == 1
+    m, g, d, f = je.misfit_and_grad_device(st["x"].clone())
+    okc = torch.from_numpy(done).to(dev) & (f != 0) & (st["ok"] != 0)
+    assert int(okc.sum()) > 100
+    assert torch.equal(st["Unew"][okc], m[okc]) and torch.equal(st["dsyn_new"][okc], d[okc])
+
+
+def test_exact_final_gives_reference_roots_at_the_end_model():
+    """swd_exact_final = 1: the steps inside a trajectory are warm-started, the evaluation of its END model goes through
+    the reference-semantics search: the synthetics stored for that model are bit for bit those of a plain evaluation."""
+    import torch
+    import bench
+    n, nt, nchain, L = 30, 512, 512, 6
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    jw, _ = _bench_joint(1); je, _ = _bench_joint(0)
+    ctx = jw._ensure(n)
+    ctx.set_option("swd_exact_final", 1)
+    bounds = bench.bounds_of(bench.true_model(n))
+    xs = np.clip(bench.make_models(nchain, 3, n), bounds[:, 0], bounds[:, 1])
+    st = jw.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
+    st["p"].copy_(tt(0.5 * np.random.default_rng(2).standard_normal(xs.shape))); st["rem"].fill_(L); st["fresh"].fill_(1)
+    for _ in range(L + 1):
+        jw.flow_step(st)
+    torch.cuda.synchronize()
+    assert int((st["done"] == 1).sum()) == nchain
+    items = ctx.stat("swd_warm_items")
+    assert items >= 0.9 * (L - 1) * nchain * 40                     # the inner steps were warm-started
+    m, g, d, f = je.misfit_and_grad_device(st["x"].clone())
+    assert torch.equal(st["dsyn_new"], d) and torch.equal(st["Unew"], m)
+
+
+def test_love_group_and_sphere_blocks_are_continued_too(orc):
+    """All four blocks (Rc, Rg, Lc, Lg: six search sequences -- the phase periods, shared by the group blocks' central pass,
+    and the +-5 % passes of the two group kernels) on a flat and
+    on a flattened earth: the warm-started sequence of evaluations against the history-free one."""
+    import torch
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    rng = np.random.default_rng(4)
+    n, nchain = 12, 256
+    thk = np.r_[np.full(n - 1, 3.0), 0.0]; vs = np.linspace(2.8, 4.5, n)
+    x0 = np.hstack((vs, thk))
+    t = np.linspace(6.0, 36.0, 7)
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for sph in (False, True):
+        kw = dict(tRc=t, tRg=t, tLc=t, tLg=t, sphere=sph, reference_periods=False)
+        sw, se = SurfWD(**kw), SurfWD(**kw)
+        sw.set_warm_start(2); se.set_warm_start(0)
+        d0, fl = se.forward(x0)
+        assert fl
+        sw.set_obsdata(d0 * 1.01); se.set_obsdata(d0 * 1.01)
+        xs = np.tile(x0, (nchain, 1)) * (1 + 0.02 * rng.standard_normal((nchain, 2 * n)))
+        xs[:, :n] = np.sort(xs[:, :n], axis=1); xs[:, -1] = 0.0
+        x = tt(xs); p = tt(0.5 * rng.standard_normal(xs.shape))
+        lo, hi = tt(0.7 * xs.min(0)), tt(1.3 * xs.max(0) + 1e-9)
+        for s in range(6):
+            mw, gw, dw, fw = sw.misfit_and_grad_device(x)
+            me, ge, de, fe = se.misfit_and_grad_device(x)
+            assert torch.equal(fw, fe) and bool((fe != 0).all())
+            nt4 = len(t)
+            # phase blocks: the roots themselves; group blocks: U = (k I1 + I2) / (omega I0) is evaluated AT the root and
+            # moves by ~1e2 times the root's relative change (the reference's own U carries its 1e-6 c root tolerance
+            # the same way): 2e-4
+            for b, tol in ((0, 1.2e-6), (2, 1.2e-6), (1, 2e-4), (3, 2e-4)):
+                a_, b_ = dw[:, b * nt4:(b + 1) * nt4], de[:, b * nt4:(b + 1) * nt4]
+                assert ((a_ - b_).abs() / b_.abs()).max().item() <= tol, (sph, s, b)
+            x, p = _leapfrog_move(x, p, gw, 0.003, lo, hi)
+        ctx = sw._ensure(n)
+        items = ctx.stat("swd_warm_items")
+        assert items >= 0.9 * 5 * nchain * 6 * len(t), (sph, items)
+
+
+@pytest.mark.parametrize("kind", ["hmc", "da"])
+def test_reference_sampler_traces_with_the_warm_start_on(kind, golden):
+    """The reference's own sampler traces (tests/golden/sampler_hybrid.npz) with the warm start on: same initial models, L
+    draws and accept decisions; states, step sizes and misfits at the tolerance the warm start keeps -- the reference's
+    roots stop up to 1e-6 c short of the sign change (surfdisp96.f:627), a residual of order 1e-2 turns that into ~1e-5
+    of a misfit, and the traces were made with dt = 0.1 (tests/test_gpu_samplers.py holds them to 1e-6 / 1e-5 with the
+    history-free search)."""
+    from test_gpu_samplers import _joint
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    g = golden["sampler_hybrid"]
+    joint = _joint(g, warm=1)
+    if kind == "hmc":
+        s = HamitonianMC(joint, g["bounds"], 0.1, [5, 20], 2, 991206, 6, 3, myrank=0, name="t", outdir=None,
+                         nchains=2, verbose=False)
+        s.trace = []
+        mis = s.sample()
+        for c, tag in ((0, "hmc_r0"), (1, "hmc_r1")):
+            seq = [(tr, tr["active"].index(c)) for tr in s.trace if c in tr["active"]]
+            assert np.array_equal(np.array([tr["L"][k] for tr, k in seq]), g[f"{tag}/L"])
+            assert np.array_equal(np.array([tr["accept"][k] for tr, k in seq]), g[f"{tag}/accept"])
+            assert rel(np.array([tr["xres"][k] for tr, k in seq]), g[f"{tag}/x"]) < 2e-5
+            assert rel(np.array([tr["Ures"][k] for tr, k in seq]), g[f"{tag}/U"]) < 1e-4
+            assert rel(mis[c], g[f"{tag}/misfit"]) < 1e-4
+    else:
+        s = HMCDualAveraging(joint, g["bounds"], 0.1, 10, 2, 0.65, 991206, 6, 3, myrank=0, name="t", outdir=None,
+                             nchains=1, verbose=False)
+        s.trace = []
+        mis = s.sample()
+        assert np.array_equal(np.array([tr["L"][0] for tr in s.trace]), g["da_r0/L"])
+        # (dual averaging feeds every acceptance ratio back into the next step size: differences compound)
+        assert rel(np.array([tr["dt"][0] for tr in s.trace]), g["da_r0/dt"]) < 1e-4
+        assert rel(np.array([tr["xend"][0] for tr in s.trace]), g["da_r0/x"]) < 1e-4
+        assert rel(mis, g["da_r0/misfit"]) < 1e-3
