@@ -111,7 +111,8 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
     if (edge) sq.im = 0.0;
     const double g = rft_gauss(f, k), g2 = g * g, ck = edge ? 1.0 : 2.0;
     const cplx Q = g2 * conj(sq);
-    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
+    const size_t nkp = f.nkp;                                   // (= n2p: the time-domain method runs without the band limit)
+    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k;
     const int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
     cplx* out = specp + (size_t)chain * 4 * n * f.n2 + k;
     // num is linear in the two unit-seed columns and both see the same layer matrices: carry their combination
@@ -126,10 +127,10 @@ k_rft_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ l
     for (int j = 0; j < n; j++) {
         cplx T[4];
         if (j < n - 1) {
-            const double* o = rs + (size_t)j * 8 * n2p;
+            const double* o = rs + (size_t)j * 8 * nkp;
             V4 r;
 #pragma unroll
-            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
+            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * nkp], o[(2 * i + 1) * nkp]);
             RfHyp H; RfA A;
             rf_hyp(L[j], omega, H);
             rf_layer_partials(L[j], H, kk, r, y, T);

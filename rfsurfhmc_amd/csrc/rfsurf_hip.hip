@@ -4,6 +4,7 @@
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +79,7 @@ struct rfs_ctx {
     int swd_segments = -1; // segments of the vector recurrence in the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
+    int rf_band_digits = 13;   // option "rf_band_limit_digits": adjoint band limit at 1e-digits * water (0 = off)
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
     int exact_final = 0;       // option "swd_exact_final": first and last evaluation of a trajectory by the full search
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
@@ -230,6 +232,7 @@ int check_rf(rfs_ctx* c, const rfs_rf_params* p) {
 RfFreq make_freq(const rfs_rf_params& p, int fwd_order) {
     RfFreq f{};
     f.nft = rf_nextpow2(p.nt); f.n2 = f.nft / 2 + 1; f.n2p = (f.n2 + 15) / 16 * 16;
+    f.nk = f.n2; f.nkp = f.n2p;
     f.nt = p.nt; f.dt = p.dt; f.p = p.ray_p; f.f0 = p.gauss; f.water = p.water;
     f.rf_type = p.rf_type;
     f.t0 = (p.rf_type == RFS_RF_S) ? -p.time_shift : p.time_shift;     // src/RF/main.cpp:35
@@ -256,7 +259,24 @@ int rf_nparts(const RfFreq& f) { return rf_chunks(f) * (rf_block(f) / 64) + 1; }
 // partial-sum layout of pass B (one slot per 64-frequency group + the Nyquist slot) does not depend on the block size.
 int rf_block_of(const RfFreq& f, int want) { int b = rf_block(f); return b > want ? want : b; }
 int rf_chunks_of(const RfFreq& f, int bs) { return (f.n2 - 1 + bs - 1) / bs; }
-int rf_nparts_b(const RfFreq& f) { int bs = rf_block_of(f, 64); return rf_chunks_of(f, bs) * (bs / 64) + 1; }
+// pass B's launch covers the frequencies below the band limit (and below the Nyquist bin, which has its own launch and
+// its own slot -- only where there is no band limit, it is the first bin to go)
+int rf_kmax_b(const RfFreq& f) { return std::min(f.nk, f.n2 - 1); }
+int rf_chunks_b(const RfFreq& f) { int bs = rf_block_of(f, 64); return (rf_kmax_b(f) + bs - 1) / bs; }
+int rf_nparts_b(const RfFreq& f) { int bs = rf_block_of(f, 64); return rf_chunks_b(f) * (bs / 64) + (f.nk >= f.n2 ? 1 : 0); }
+
+// The band limit of the fused gradient (RfFreq::nk): the adjoint weight of frequency k carries G_k = exp(-(w_k / 2 f0)^2)
+// over a denominator >= water * max (RFModule.f90:393,413-419); below eps * water it is lost in the double-precision sum
+// over frequencies.  digits = -log10(eps), 0 = no limit.
+void set_band_limit(RfFreq& f, int digits) {
+    f.nk = f.n2; f.nkp = f.n2p;
+    if (digits <= 0 || f.method != RFS_RF_FREQ || !(f.water > 0.0) || !(f.f0 > 0.0)) return;
+    const double thr = std::pow(10.0, -(double)digits) * std::min(1.0, f.water);
+    const double wcut = 2.0 * f.f0 * std::sqrt(-std::log(thr));           // G(w) >= thr  <=>  w <= wcut
+    const double dw = 2.0 * 3.14159265358979323846 / (f.nft * f.dt);
+    const int nk = (int)std::floor(wcut / dw) + 2;                        // one spare bin: the axis uses a float32 pi
+    if (nk < f.n2) { f.nk = std::max(nk, 1); f.nkp = (f.nk + 15) / 16 * 16; }
+}
 
 constexpr int RF_MAX_CHAINS_PER_LAUNCH = 32768;      // the RF sweeps use one grid row per chain (gridDim.y <= 65535)
 
@@ -266,7 +286,7 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     if (nchain > 2 * RF_MAX_CHAINS_PER_LAUNCH - 4096)
         return fail(c, RFS_ERR_UNSUPPORTED, "more than 61440 chains in one receiver-function launch: split the batch");
     ENSURE(c, c->RR, (size_t)nchain * 4 * f.n2p * sizeof(double));
-    if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.n2p * sizeof(double));
+    if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.nkp * sizeof(double));
     double* Rs = scratch ? c->Rs.as<double>() : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 128);
@@ -311,13 +331,14 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0) 
     ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 64);
-    dim3 grid(rf_chunks_of(f, bs), nchain);
+    dim3 grid(rf_chunks_b(f), nchain);
     hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
                        c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
                        c->PG.as<double>());
-    hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                       c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
-                       c->PG.as<double>());
+    if (f.nk >= f.n2)       // the Nyquist bin, lane = chain (no band limit: it is the first bin to go)
+        hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
+                           c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
+                           c->PG.as<double>());
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -405,11 +426,11 @@ int rft_partials(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* C
         dim3 grid(rf_chunks(f), nc);
         hipLaunchKernelGGL(k_rft_partial_spectra<false>, grid, dim3(rf_block(f)), 0, c->stream, nc, n, f,
                            c->lc.as<RfLayer>() + (size_t)c0 * n, c->RR.as<double>() + (size_t)c0 * 4 * f.n2p,
-                           c->Rs.as<double>() + (size_t)c0 * (n - 1) * 8 * f.n2p, npart, c->specp.as<cplx>(),
+                           c->Rs.as<double>() + (size_t)c0 * (n - 1) * 8 * f.nkp, npart, c->specp.as<cplx>(),
                            c->S0p.as<double>());
         hipLaunchKernelGGL(k_rft_partial_spectra<true>, dim3((nc + 63) / 64), dim3(64), 0, c->stream, nc, n, f,
                            c->lc.as<RfLayer>() + (size_t)c0 * n, c->RR.as<double>() + (size_t)c0 * 4 * f.n2p,
-                           c->Rs.as<double>() + (size_t)c0 * (n - 1) * 8 * f.n2p, npart, c->specp.as<cplx>(),
+                           c->Rs.as<double>() + (size_t)c0 * (n - 1) * 8 * f.nkp, npart, c->specp.as<cplx>(),
                            c->S0p.as<double>());
         HIPCHK(c, hipGetLastError());
         TRY(run_fft(c, f.nft, (size_t)nc * ntr, 1, c->specp.p, c->tserp.p));
@@ -800,7 +821,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     // chain tiles of the RF pipeline: the pass-A row scratch of one tile stays within rf_scratch_budget
     int rf_tile = nchain;
     if (c->has_rf && !rf_time) {
-        const size_t per_chain = (size_t)(n - 1) * 8 * c->f.n2p * sizeof(double);
+        const size_t per_chain = (size_t)(n - 1) * 8 * c->f.nkp * sizeof(double);
         size_t fit = per_chain ? c->rf_scratch_budget / per_chain : (size_t)nchain;
         if (fit < (size_t)nchain) rf_tile = (int)std::max<size_t>(64, fit / 64 * 64);
         rf_tile = std::min(rf_tile, RF_MAX_CHAINS_PER_LAUNCH);      // grid rows of the RF sweeps
@@ -1130,6 +1151,13 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 1) return fail(c, RFS_ERR_ARG, "rf_scratch_budget_mb must be positive");
         c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
     }
+    if (!strcmp(name, "rf_band_limit_digits")) {
+        if (value < 0 || value > 300) return fail(c, RFS_ERR_ARG, "rf_band_limit_digits must be within [0, 300]");
+        c->rf_band_digits = value;
+        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value); }
+        for (auto& kv : c->calib) kv.second.stage = -1;
+        return RFS_OK;
+    }
     if (!strcmp(name, "swd_warm_start")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_warm_start must be 0, 1 or 2");
         c->warm_opt = value; c->warm_primed = false; return RFS_OK;
@@ -1343,7 +1371,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
     c->sphere = sphere;
     c->has_minv = false;
     int nt = 0;
-    if (rf) { c->f = make_freq(*rf, 0); nt = rf->nt; }
+    if (rf) { c->f = make_freq(*rf, 0); set_band_limit(c->f, c->rf_band_digits); nt = rf->nt; }
     c->ndata = nt + nswd;
     // wt = (sigma1/sigma2)^2 n1/n2, model_rf_swd_vs_thk.py:79
     c->wt = c->has_swd && c->has_rf ? (sigma1 / sigma2) * (sigma1 / sigma2) * nt / (double)nswd : 1.0;

@@ -29,6 +29,11 @@ struct RfFreq {             // frequency axis + RF scalars shared by the RF kern
     double dt, sigma, p, f0, t0, water;
     int nft, n2, n2p, nt, rf_type, fwd_order;
     int method, pi64;       // method: RFS_RF_* ; pi64: f64 pi on the frequency axis (cal_rf_par_time_all only)
+    // Band limit of the adjoint (fused gradient only): frequencies k >= nk carry a Gaussian weight exp(-(w/2f0)^2) below
+    // eps * water and cannot reach the gradient in double precision; pass A still sweeps them (the water level is a
+    // maximum over ALL frequencies, RFModule.f90:396-398) but keeps no rows for them, pass B does not run them.
+    // nk = n2, nkp = n2p: no limit (B1 kernel_all, time-domain method).  nkp = row-scratch stride (nk padded to 16).
+    int nk, nkp;
 };
 
 __device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
@@ -246,13 +251,13 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
     const RfLayer* L = lc + (size_t)chain * n;
     cplx omega = C(rf_wk(f, k), -f.sigma);
     V4 r = rf_einv_row(L[n - 1], f.rf_type);
-    const size_t n2p = f.n2p;
-    double* rs = Rs ? Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k : nullptr;
+    const size_t n2p = f.n2p, nkp = f.nkp;
+    double* rs = (Rs && k < f.nk) ? Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k : nullptr;
     for (int j = n - 2; j >= 0; j--) {
         if (rs) {
-            double* o = rs + (size_t)j * 8 * n2p;
+            double* o = rs + (size_t)j * 8 * nkp;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { o[(2 * i) * n2p] = r.v[i].re; o[(2 * i + 1) * n2p] = r.v[i].im; }
+            for (int i = 0; i < 4; i++) { o[(2 * i) * nkp] = r.v[i].re; o[(2 * i + 1) * nkp] = r.v[i].im; }
         }
         RfHyp H; RfA A;
         rf_hyp(L[j], omega, H);
@@ -377,26 +382,27 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
     } else {
         chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
         part = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-        if (k >= f.n2 - 1) { live = false; k = f.n2 - 2; }
+        const int kmax = f.nk < f.n2 - 1 ? f.nk : f.n2 - 1;       // (the Nyquist bin has its own launch, TAIL)
+        if (k >= kmax) { live = false; k = kmax - 1; }
     }
     const RfLayer* L = lc + (size_t)chain * n;
-    const size_t n2p = f.n2p;
+    const size_t n2p = f.n2p, nkp = f.nkp;
     const double* rr = RR + (size_t)chain * 4 * n2p + k;
     cplx r21 = C(rr[0], rr[n2p]), r22 = C(rr[2 * n2p], rr[3 * n2p]);
     cplx omega = C(rf_wk(f, k), -f.sigma), kk = f.p * omega;
     V4 y = rf_adjoint_seed(f, k, r21, r22, W[(size_t)chain * f.n2 + k], wmax2[chain]);
     if (!live) { y.v[0] = C(0.0); y.v[1] = C(0.0); }
-    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
+    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k;
     double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const int lane = threadIdx.x & 63;
     double* pg = PG + ((size_t)chain * npart + part) * 4 * n;
     for (int j = 0; j < n; j++) {
         cplx T[4];
         if (j < n - 1) {
-            const double* o = rs + (size_t)j * 8 * n2p;
+            const double* o = rs + (size_t)j * 8 * nkp;
             V4 r;
 #pragma unroll
-            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
+            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * nkp], o[(2 * i + 1) * nkp]);
             RfHyp H; RfA A;
             rf_hyp(L[j], omega, H);
             rf_layer_partials(L[j], H, kk, r, y, T);
@@ -458,7 +464,8 @@ k_rf_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc
     double g = exp(-((w / 2 / f.f0) * (w / 2 / f.f0)));
     double s, c; sincos(w * f.t0, &s, &c);
     cplx Q = (conj(sq) * C(c, -s)) * (g / fai2);
-    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * n2p + k;
+    const size_t nkp = f.nkp;                                   // (= n2p: this entry runs without the band limit)
+    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k;
     const int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
     cplx* out = specp + (size_t)chain * 4 * n * f.n2 + k;
     // num = R22_m R21 - R21_m R22 is linear in the two unit-seed columns, and both are carried through the stack by
@@ -470,10 +477,10 @@ k_rf_partial_spectra(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc
     for (int j = 0; j < n; j++) {
         cplx T[4];
         if (j < n - 1) {
-            const double* o = rs + (size_t)j * 8 * n2p;
+            const double* o = rs + (size_t)j * 8 * nkp;
             V4 r;
 #pragma unroll
-            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * n2p], o[(2 * i + 1) * n2p]);
+            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * nkp], o[(2 * i + 1) * nkp]);
             RfHyp H; RfA A;
             rf_hyp(L[j], omega, H);
             rf_layer_partials(L[j], H, kk, r, y, T);
