@@ -197,9 +197,10 @@ def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
             "logical_cpus": len(allowed), "cpu_quota_cores": quota, "cpu_model": model,
             "evals_per_s_per_core": total / ncores,
             "kind": kind,
-            "kind_detail": ("reference (RF tail numpy): oracle/_ref = the reference's own sources compiled here -- libsurf "
-                            "complete, RF propagator/partials core of RFModule.f90; the 15-line RF tail (water level, "
-                            "Gaussian, irfft, e^{sigma t}) is numpy because FFTW3 is absent" if kind == "reference"
+            "kind_detail": ("reference (RF tail numpy): oracle/_ref = the reference's own sources, compiled in the BUILD "
+                            "container by oracle/Makefile and shipped to this box as binaries -- libsurf complete, RF "
+                            "propagator/partials core of RFModule.f90; the 15-line RF tail (water level, Gaussian, irfft, "
+                            "e^{sigma t}) is numpy because FFTW3 is absent from the image" if kind == "reference"
                             else "port: the C restatement oracle/liboracle.so"),
             "sample": f"{sum(k for _, k, _ in res)} joint misfit+grad evaluations of the bench's own {cfg['n']}-layer "
                       f"models (nt = {cfg['nt']}, {NPER} Rc periods), {ncores} independent processes (one per core the "
@@ -225,8 +226,34 @@ def launch(args, argv):
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+    # rank 0's stdout is drained by a thread; the children are polled: the first rank that dies takes the others with it
+    # (a rank missing from the rendezvous would leave them waiting for ever) and its exit code is reported
+    import threading
+    buf = []
+    th = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    deadline = time.time() + args.timeout
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed or time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                try:
+                    rcs[i] = p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill(); rcs[i] = p.wait()
+            th.join(timeout=5)
+            print("".join(buf), file=sys.stderr)
+            raise SystemExit(f"bench.py: {'timeout' if not failed else 'rank(s) ' + str(failed) + ' failed'}; rank exit codes {rcs}")
+        time.sleep(0.05)
+    th.join()
+    out0 = "".join(buf)
     line = None
     for ln in (out0 or "").splitlines():
         if ln.startswith("{"):
@@ -275,6 +302,220 @@ def dry_rank(args, rank, world):
         dist.destroy_process_group()
 
 
+CLOCK_HZ = 2.4e9        # MI355X peak engine clock (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs; one f64 (or any VALU) wave-instruction occupies a SIMD for 4 clocks
+
+
+def _counters(config):
+    """Per-step PMC figures of a configuration (profiles/r*_counters.json, written by scripts/pmc_summary.py from
+    separate rocprofv3 --pmc passes); None where no pass was committed."""
+    for name in ("r03_counters.json",):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if tj.get("chains") == 8192 and f"config{config}" in tj:
+                return tj[f"config{config}"]
+        except Exception:
+            continue
+    return None
+
+
+def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, dom_live_ms_launch):
+    """The figures of one timed leg: rate, per-step kernel-group times, roofline of the group with the largest per-STEP
+    sum, VALU issue per group from the committed counter passes."""
+    n, nt = cfg["n"], cfg["nt"]
+    ab = alg_bytes_per_eval(n, nt)
+    dom_ms = ms_step[dom]
+    achieved = ab * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    cnt = _counters(config) if nchain == 8192 else None
+    traffic = cnt[dom]["hbm_bytes"] if cnt and dom in cnt and cnt[dom]["hbm_bytes"] > 0 else None
+    rep = {
+        "ms_per_step": el / K * 1e3, "value": evals / el, "unit": "evals/s", "steps": K,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_step": ab * nchain, "group_ms_per_step": dom_ms,
+                     "launches_per_step": launches_step[dom], "avg_launch_ms": dom_live_ms_launch,
+                     "note": "group with the largest per-step sum of HIP-event durations; the path is FP64-VALU / "
+                             "transcendental bound (SURVEY 8(d)): see valu_issue"},
+        "kernel_ms_per_step": ms_step, "kernel_launches_per_step": launches_step,
+    }
+    if cnt:
+        vi, tot = {}, 0.0
+        for k, v in cnt.items():
+            if k in ms_step and v.get("valu_insts", 0) > 0:
+                full = v["valu_insts"] * 4.0 / N_SIMD / CLOCK_HZ * 1e3
+                tot += full
+                vi[k] = {"valu_wave_insts_per_step": v["valu_insts"], "ms_at_full_issue": full,
+                         "measured_ms_per_step": ms_step[k], "frac": full / ms_step[k] if ms_step[k] > 0 else None}
+        rep["valu_issue"] = {"per_group": vi, "step": {"ms_at_full_issue": tot, "measured_ms_per_step": el / K * 1e3,
+                                                       "frac": tot / (el / K * 1e3)},
+                             "note": "SQ_INSTS_VALU per leapfrog step (committed rocprofv3 --pmc pass, profiles/r03_pmc_config*.csv) "
+                                     "x 4 clocks / 1024 SIMDs / 2.4 GHz against the measured time; group times are HIP-event "
+                                     "durations on two concurrent streams (they overlap, their sum exceeds the step)"}
+    return rep
+
+
+def make_joint(cfg, local_rank):
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    n, nt = cfg["n"], cfg["nt"]
+    t = np.linspace(5, 44, NPER)
+    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(RAY_P, nt, cfg["dt"], GAUSS, TSHIFT, WATER, "P", "freq", device=local_rank),
+                         SurfWD(tRc=t, device=local_rank))
+    x_true = true_model(n)
+    drf, dswd, flag = joint.forward(x_true)
+    assert flag
+    joint.set_obsdata(drf, dswd)
+    return joint, x_true, bounds_of(x_true)
+
+
+class GroupTimer:
+    """Per-kernel-group HIP-event times of the library (rfs_enable_timing / rfs_kernel_ms_sum)."""
+
+    def __init__(self, ctx):
+        from rfsurfhmc_amd._lib import K_NAMES
+        self.ctx, self.names = ctx, K_NAMES
+
+    def on(self, mask=None):
+        self.ctx.check(self.ctx.L.rfs_synchronize(self.ctx.h))
+        self.ctx.check(self.ctx.L.rfs_enable_timing(self.ctx.h, 1 if mask is None else 2 * mask))
+
+    def off(self):
+        self.ctx.check(self.ctx.L.rfs_enable_timing(self.ctx.h, 0))
+
+    def read(self):
+        ms = np.zeros(len(self.names)); cnt = np.zeros(len(self.names), dtype=np.int32)
+        self.ctx.check(self.ctx.L.rfs_kernel_ms_sum(self.ctx.h, ms.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+        return ms, cnt
+
+
+def flow_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier, setup_steps=32):
+    """configs[1] / configs[4]: K leapfrog steps of every chain on the flow entry (never-ending trajectories)."""
+    import torch
+    n = cfg["n"]
+    ctx = joint._ensure(n)
+    gt = GroupTimer(ctx)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xs = make_models(nchain, seed=991206 + rank, n=n)      # chain c of rank r ~ reference rank r*nchain + c
+    rng = np.random.default_rng(7 + rank)
+    st = joint.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
+    st["p"].copy_(tt(0.5 * rng.standard_normal(xs.shape)))        # p ~ 0.5 N(0, I), hmc.py:146
+    st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
+    joint.flow_step(st)                                            # start evaluation + half kick (untimed): full root search
+    # set-up, not warm-up: the first steps hand the chains whose start thickness lay outside the bounds (mirrored back by
+    # the first drift: a move no first-order model covers) to the full search once more; from then on every chain is continued
+    for _ in range(setup_steps):
+        joint.flow_step(st)
+    gt.on()
+    for _ in range(max(nwarm - 1, 1)):
+        joint.flow_step(st)
+    torch.cuda.synchronize()
+    ms_w, cnt_w = gt.read()
+    nw = max(nwarm - 1, 1)
+    ms_step = {k: ms_w[i] / nw for i, k in enumerate(gt.names)}
+    launches = {k: cnt_w[i] / nw for i, k in enumerate(gt.names)}
+    dom_id = int(np.argmax([ms_step[k] for k in gt.names]))
+    gt.on(1 << dom_id)                                             # the dominant group only, measured live below
+    d0 = ctx.stat("swd_warm_declined_chains"); i0 = ctx.stat("swd_warm_items"); e0 = ctx.stat("swd_warm_secular_evals")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        joint.flow_step(st)
+    ctx.check(ctx.L.rfs_synchronize(ctx.h))
+    barrier()
+    el = time.perf_counter() - t0
+    ms, cnt = gt.read()
+    gt.off()
+    dom = gt.names[dom_id]
+    ms_step[dom] = ms[dom_id] / K                                  # HIP events over the timed region
+    launches[dom] = cnt[dom_id] / K
+    dom_launch = ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0
+    rep = leg_report(cfg, config, nchain, K, el, nchain * K, ms_step, launches, dom, dom_launch)
+    items = ctx.stat("swd_warm_items") - i0
+    rep["root_search"] = {
+        "warm_started_items_per_step": items / K, "items_per_step": nchain * NPER,
+        "secular_evals_per_item": (ctx.stat("swd_warm_secular_evals") - e0) / max(items, 1),
+        "chains_handed_back_to_the_full_search_per_step": (ctx.stat("swd_warm_declined_chains") - d0) / K,
+        "note": "inside a trajectory the roots of step s continue those of step s-1 (predictor from its Frechet kernels, "
+                "bracket, false position, branch test: rfs_set_option swd_warm_start, default 1); the reference-semantics "
+                "search runs for the start models and for every chain the continuation declines"}
+    rep["root_search_failures"] = int((st["ok"] == 0).sum().item())
+    rep["kernel_ms_note"] = (f"'{dom}' from HIP events over the timed region; the other groups from HIP events over the "
+                             f"{nw} warm-up step(s) before it (all groups bracketed there)")
+    return rep, st, xs, el
+
+
+def da_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier):
+    """configs[3]: a real HMCDualAveraging run on the continuous-flow schedule, K device steps timed."""
+    import torch
+    from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
+    n = cfg["n"]
+    ctx = joint._ensure(n)
+    gt = GroupTimer(ctx)
+    rs = np.random.default_rng(3 + rank)
+    xs = np.clip(x_true[None, :] * (1 + 0.02 * rs.standard_normal((nchain, 2 * n))), bounds[:, 0], bounds[:, 1])
+    xs[:, :n] = np.sort(xs[:, :n], axis=1)
+    # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
+    smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
+                           nchains=nchain, verbose=False, store_syn=False)
+    # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
+    # given the chains different step sizes) finish in bursts; time a window behind them
+    nwarm = max(nwarm, 40)
+    marks = {}
+    active = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def hook(s, st):
+        if s == 1:
+            gt.on()
+            active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum()); active.zero_()   # first use loads torch kernels
+        if s == nwarm:
+            marks["warm"] = gt.read()
+            marks["dom"] = int(np.argmax(marks["warm"][0]))
+            gt.on(1 << marks["dom"])
+            marks["stat0"] = (ctx.stat("swd_warm_declined_chains"), ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals"))
+            barrier()
+            marks["t0"] = time.perf_counter()
+        if nwarm <= s < nwarm + K:          # chains inside a trajectory in this step = leapfrog steps done
+            active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum())
+        if s == nwarm + K:
+            ctx.check(ctx.L.rfs_synchronize(ctx.h))
+            barrier()
+            marks["t1"] = time.perf_counter()
+            marks["dt"] = st["dt"].clone()
+            marks["stat1"] = (ctx.stat("swd_warm_declined_chains"), ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals"))
+
+    smp.sample_flow(x_init=xs, max_steps=nwarm + K + 1, step_hook=hook)
+    el = marks["t1"] - marks["t0"]
+    ms, cnt = gt.read()
+    gt.off()
+    ms_w, cnt_w = marks["warm"]
+    nw = nwarm - 1
+    ms_step = {k: ms_w[i] / nw for i, k in enumerate(gt.names)}
+    launches = {k: cnt_w[i] / nw for i, k in enumerate(gt.names)}
+    dom_id = marks["dom"]; dom = gt.names[dom_id]
+    ms_step[dom] = ms[dom_id] / K; launches[dom] = cnt[dom_id] / K
+    evals = int(active.item())
+    rep = leg_report(cfg, config, nchain, K, el, evals, ms_step, launches, dom, ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0)
+    d0, i0, e0 = marks["stat0"]
+    d1, i1, e1 = marks["stat1"]
+    items = i1 - i0
+    dtv = marks["dt"].cpu().numpy()
+    rep["chains_in_a_trajectory_per_step"] = evals / K
+    rep["root_search"] = {"warm_started_items_per_step": items / K, "items_per_step": nchain * NPER,
+                          "secular_evals_per_item": (e1 - e0) / max(items, 1),
+                          "chains_handed_back_to_the_full_search_per_step": (d1 - d0) / K,
+                          "handed_back_by_cause_total": {k: ctx.stat(f"swd_warm_cause_{k}") for k in range(4, 12)},
+                          "adapted_dt_median": float(np.median(dtv)), "adapted_dt_max": float(dtv.max())}
+    return rep, xs, el, evals
+
+
+STEP_TEXT = {
+    None: "one leapfrog step of every chain via rfs_flow_step (drift + mirror, misfit+gradient, kick)",
+    "da": "one device step of HMCDualAveraging.sample_flow (accept / reject and restart on the device from draws made "
+          "ahead, dual averaging on the host beside the steps); value counts only chains inside a trajectory",
+}
+
+
 def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -292,6 +533,8 @@ def run_rank(args):
     shared = os.environ.get("RFS_BENCH_SHARED_GPU") == "1" and world > 1
     if shared:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, the box has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if shared else dev    # where the collectives' tensors live
@@ -301,87 +544,53 @@ def run_rank(args):
         dist.init_process_group(backend="gloo" if shared else "nccl")      # "nccl" is RCCL on ROCm
         assert dist.get_world_size() == args.gpus
 
-    from rfsurfhmc_amd._lib import K_NAMES
-    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
-    from rfsurfhmc_amd.model.model_surf import SurfWD
-    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
-
-    cfg = CONFIGS[args.config]
-    n, nt = cfg["n"], cfg["nt"]
-    nchain = args.chains
-    t = np.linspace(5, 44, NPER)
-    joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(RAY_P, nt, cfg["dt"], GAUSS, TSHIFT, WATER, "P", "freq", device=local_rank),
-                         SurfWD(tRc=t, device=local_rank))
-    x_true = true_model(n)
-    drf, dswd, flag = joint.forward(x_true)
-    assert flag
-    joint.set_obsdata(drf, dswd)
-    bounds = bounds_of(x_true)
-    ctx = joint._ensure(n)
-    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    nwarm = max(args.warmup, 2)
-    K = args.steps
-
-    def timing_all():
-        ctx.check(ctx.L.rfs_synchronize(ctx.h))
-        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 1))
-
-    def read_ms():
-        ms = np.zeros(len(K_NAMES)); cnt = np.zeros(len(K_NAMES), dtype=np.int32)
-        ctx.check(ctx.L.rfs_kernel_ms_sum(ctx.h, ms.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
-        return ms, cnt
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    cfg = CONFIGS[args.config]
+    n, nt = cfg["n"], cfg["nt"]
+    nchain = args.chains
+    nwarm = max(args.warmup, 2)
+    K = args.steps
+    joint, x_true, bounds = make_joint(cfg, local_rank)
+    if args.warm_start is not None:
+        joint.set_warm_start(args.warm_start)
+    ctx = joint._ensure(n)
     extra = {}
     if cfg["sampler"] is None:
-        # ---- configs[1] / configs[4]: leapfrog steps of every chain on the flow entry (never-ending trajectories)
-        xs = make_models(nchain, seed=991206 + rank, n=n)      # chain c of rank r ~ reference rank r*nchain + c
-        rng = np.random.default_rng(7 + rank)
-        st = joint.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
-        st["p"].copy_(tt(0.5 * rng.standard_normal(xs.shape)))        # p ~ 0.5 N(0, I), hmc.py:146
-        st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
-        joint.flow_step(st)                                            # start evaluation + half kick (untimed)
-        # set-up, not warm-up: the library times its candidate schedules (CU partition, early eigenfunction periods) on
-        # the first evaluations of a new shape -- twice each -- and keeps the fastest (include/rfsurf.h, "recalibrate")
-        for _ in range(32):
-            joint.flow_step(st)
-        extra["setup_steps"] = 33      # start evaluation + 32 untimed steps during which the library settles on a schedule
-        timing_all()
-        for _ in range(nwarm - 1):
-            joint.flow_step(st)
-        torch.cuda.synchronize()
-        ms_w, cnt_w = read_ms()
-        warm_ms = {k: (ms_w[i] / cnt_w[i] if cnt_w[i] else 0.0) for i, k in enumerate(K_NAMES)}
-        dom_id = int(np.argmax([warm_ms[k] for k in K_NAMES]))
-        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 2 * (1 << dom_id)))  # the dominant group only, measured live below
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            joint.flow_step(st)
-        ctx.check(ctx.L.rfs_synchronize(ctx.h))
-        barrier()
-        el = time.perf_counter() - t0
-        ms, cnt = read_ms()
-        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 0))
-        nfail = int((st["ok"] == 0).sum().item())
+        rep, st, xs, el = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier)
         evals_rank = nchain * K
         misfit = st["Unew"]
-        # the bare evaluation on a fixed x (what round 1 reported as a step), for continuity
-        xfix = tt(xs)
-        for _ in range(3):
-            joint.misfit_and_grad_device(xfix)
-        ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(K):
-            joint.misfit_and_grad_device(xfix)
-        ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
-        extra["eval_only_ms_per_step"] = (time.perf_counter() - t1) / K * 1e3
-        if rank == 0 and not args.no_sampler_leg:
+        extra["setup_steps"] = 33      # start evaluation + 32 untimed steps
+        if rank == 0 and world == 1 and not args.headline_only:
+            # ---- the reference-semantics search on every evaluation (what rounds 1 and 2 measured): the same steps with
+            # the warm start off, and the bare evaluation on a fixed x
+            joint.set_warm_start(0)
+            for _ in range(34):
+                joint.flow_step(st)                  # (the library times its CU-partition schedules on these)
+            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(K):
+                joint.flow_step(st)
+            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            extra["full_search_every_step"] = {"ms_per_step": e1 / K * 1e3, "value": nchain * K / e1, "unit": "evals/s",
+                                               "note": "rfs_set_option swd_warm_start = 0: bit-exact float32 roots of the "
+                                                       "reference's sequential search at every step"}
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            xfix = tt(xs)
+            for _ in range(3):
+                joint.misfit_and_grad_device(xfix)
+            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(K):
+                joint.misfit_and_grad_device(xfix)
+            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+            extra["eval_only_ms_per_step"] = (time.perf_counter() - t1) / K * 1e3
+            joint.set_warm_start(1 if args.warm_start is None else args.warm_start)
+        if rank == 0 and not args.no_sampler_leg and not args.headline_only:
             # beside the headline: a REAL HamitonianMC run on the same chains (continuous-flow schedule: draws from every
             # chain's MT19937 stream, L ~ U{5..20}, accept / reject and restarts, hmc.py:228-276), K device steps timed
             # behind 25; counts only chains inside a trajectory
@@ -390,72 +599,34 @@ def run_rank(args):
                                nchains=nchain, verbose=False, store_syn=False)
             mk = {}
             act = torch.zeros((), dtype=torch.int64, device=dev)
-            w2, K2 = 25, max(K, 40)                  # (a window of at least 40 device steps: one host hiccup weighs less)
+            # (a window of >= 2 s: this is also the leg a coarse utilisation sampler can see the device busy in)
+            w2, K2 = 25, max(K, args.sustain)
 
             def hook2(s, stt):
                 if s == 1:                                   # torch loads these kernels on first use (~30 ms): not in the window
                     act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum()); act.zero_()
                 if s == w2:
                     torch.cuda.synchronize(); mk["t0"] = time.perf_counter()
+                    mk["d0"] = ctx.stat("swd_warm_declined_chains")
                 if w2 <= s < w2 + K2:
                     act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum())
                 if s == w2 + K2:
                     ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); mk["t1"] = time.perf_counter()
+                    mk["d1"] = ctx.stat("swd_warm_declined_chains")
 
             smp.sample_flow(x_init=xs, max_steps=w2 + K2 + 1, step_hook=hook2)
             el2 = mk["t1"] - mk["t0"]
             extra["sampler_flow"] = {
                 "value": int(act.item()) / el2, "unit": "evals/s", "steps": K2, "ms_per_step": el2 / K2 * 1e3,
                 "chains_in_a_trajectory_per_step": int(act.item()) / K2,
+                "chains_handed_back_to_the_full_search_per_step": (mk["d1"] - mk["d0"]) / K2,
                 "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): every chain's acceptance draw, "
                         "next L and momentum come from its own MT19937 stream on the host, ahead of time; the device accepts / "
                         "rejects and starts the next trajectory itself (rfs_flow_step2); books and samples are kept on the "
                         "host beside the device steps"}
     else:
-        # ---- configs[3]: a real HMCDualAveraging run on the continuous-flow schedule, K device steps timed
-        from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
-        rs = np.random.default_rng(3 + rank)
-        xs = np.clip(x_true[None, :] * (1 + 0.02 * rs.standard_normal((nchain, 2 * n))), bounds[:, 0], bounds[:, 1])
-        xs[:, :n] = np.sort(xs[:, :n], axis=1)
-        # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
-        smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
-                               nchains=nchain, verbose=False, store_syn=False)
-        # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
-        # given the chains different step sizes) finish in bursts; time a window behind them
-        nwarm = max(nwarm, 40)
-        marks = {}
-        active = torch.zeros((), dtype=torch.int64, device=dev)
-
-        def hook(s, st):
-            if s == 1:
-                timing_all()
-                active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum()); active.zero_()   # first use loads torch kernels
-            if s == nwarm:
-                ms_w, cnt_w = read_ms()
-                marks["warm"] = (ms_w, cnt_w)
-                dom = int(np.argmax(ms_w / np.maximum(cnt_w, 1)))
-                marks["dom"] = dom
-                ctx.check(ctx.L.rfs_enable_timing(ctx.h, 2 * (1 << dom)))
-                barrier()
-                marks["t0"] = time.perf_counter()
-            if nwarm <= s < nwarm + K:          # chains inside a trajectory in this step = leapfrog steps done
-                active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum())
-            if s == nwarm + K:
-                ctx.check(ctx.L.rfs_synchronize(ctx.h))
-                barrier()
-                marks["t1"] = time.perf_counter()
-
-        smp.sample_flow(x_init=xs, max_steps=nwarm + K + 1, step_hook=hook)
-        el = marks["t1"] - marks["t0"]
-        ms, cnt = read_ms()
-        ctx.check(ctx.L.rfs_enable_timing(ctx.h, 0))
-        ms_w, cnt_w = marks["warm"]
-        warm_ms = {k: (ms_w[i] / cnt_w[i] if cnt_w[i] else 0.0) for i, k in enumerate(K_NAMES)}
-        dom_id = marks["dom"]
-        evals_rank = int(active.item())
-        nfail = 0
+        rep, xs, el, evals_rank = da_leg(cfg, args.config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier)
         misfit = torch.zeros(nchain, dtype=torch.float64, device=dev)
-        extra["chains_in_a_trajectory_per_step"] = evals_rank / K
 
     total_evals = evals_rank
     if dist is not None:
@@ -467,40 +638,33 @@ def run_rank(args):
         from rfsurfhmc_amd.chains import gather_misfits
         gathered = gather_misfits(misfit.to(cdev))
         assert rank != 0 or gathered.shape[0] == nchain * world
+        if rank == 0 and shared:
+            extra["gathered"] = {"n": int(gathered.shape[0]), "sha": float(gathered.sum().item()),
+                                 "first_of_each_rank": [float(gathered[r * nchain].item()) for r in range(world)]}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    # ---- the other single-GPU configurations of BASELINE.json, as short legs of the default run
+    if world == 1 and args.config == 1 and nchain == 8192 and not args.headline_only and not args.no_other_configs:
+        joint._ctx.close(); joint._ctx = None; joint._cfg = None
+        torch.cuda.empty_cache()
+        for ci in (4, 3):
+            c2 = CONFIGS[ci]
+            j2, xt2, b2 = make_joint(c2, local_rank)
+            if c2["sampler"] is None:
+                r2, _, _, _ = flow_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, max(K, 20), nwarm, barrier, setup_steps=12)
+            else:
+                r2, _, _, _ = da_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, max(K, 20), nwarm, barrier)
+            r2["workload"] = c2["name"]; r2["step"] = STEP_TEXT[c2["sampler"]]
+            extra[f"config{ci}"] = r2
+            j2._ctx.close(); j2._ctx = None
+            torch.cuda.empty_cache()
+
     value = total_evals / el
-    dom = K_NAMES[dom_id]
-    dom_ms = ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0        # HIP events over the timed region
-    per_launch_ms = dict(warm_ms)                                    # the other groups: from the warm-up steps
-    per_launch_ms[dom] = dom_ms
-    ab = alg_bytes_per_eval(n, nt)
-    achieved = ab * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # HBM bytes per launch of that kernel group from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the
-    # configuration it was collected on
-    traffic = None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if tj.get("chains") == nchain and tj.get("config", 1) == args.config and dom in tj:
-                traffic = tj[dom]
-                break
-        except Exception:
-            continue
     fl = alg_flops_per_eval(n, nt)
     flops_eval = sum(fl.values())
-    # per-kernel FP64 figures: hand-counted flops of the group / its measured time / the vector peak of the whole chip
-    per_kernel_fp64 = {}
-    for k, f in fl.items():
-        if k == "swd_eigen":        # its timed group is the mop-up launch only (the other periods run early, beside the search)
-            continue
-        if per_launch_ms.get(k, 0) > 0:
-            tf = f * nchain / (per_launch_ms[k] * 1e-3) / 1e12
-            per_kernel_fp64[k] = {"tflops": tf, "frac_of_chip_peak": tf / FP64_VECTOR_PEAK_TFLOPS}
     res = {
         "metric": METRIC,
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -509,27 +673,22 @@ def run_rank(args):
         "config": {"workload": cfg["name"] if not (args.config == 1 and world * nchain == 65536) else
                    "configs[2]: 65536 chains x 30-layer joint RF+SWD, 8xMI355X independent-chain shard, RCCL gather "
                    "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
-                   "step": ("one leapfrog step of every chain via rfs_flow_step (drift + mirror, misfit+gradient, kick)"
-                            if cfg["sampler"] is None else
-                            "one device step of HMCDualAveraging.sample_flow (accept / reject and restart on the device from "
-                            "draws made ahead, dual averaging on the host beside the steps); value counts only chains "
-                            "inside a trajectory"),
+                   "step": STEP_TEXT[cfg["sampler"]],
                    "parallelism": f"independent chains x{world}" + (" -- FUNCTIONAL CHECK: all ranks share GPU 0, gloo "
                                                                     "collectives; not a measurement" if shared else ""),
-                   "root_search_failures": nfail},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": ab * nchain, "avg_launch_ms": dom_ms,
-                     "note": "path is FP64-VALU/transcendental bound (SURVEY 8(d)); see fp64_vector"},
+                   "root_search_failures": rep.get("root_search_failures", 0)},
+        "roofline": rep["roofline"],
         "fp64_vector": {"achieved_tflops": flops_eval * value / world / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                         "frac": flops_eval * value / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                         "alg_flops_per_eval": flops_eval,
-                        "note": "whole-step figure from SURVEY 8(d)'s hand count of the minimal algorithm, not a counter",
-                        "per_kernel": per_kernel_fp64},
-        "kernel_ms_per_launch": per_launch_ms,
-        "kernel_ms_note": f"'{dom}' from HIP events over the timed region; the other groups from HIP events over the "
-                          f"{nwarm - 1} warm-up step(s) before it (all groups bracketed there)",
+                        "note": "SURVEY 8(d)'s hand count of the reference's minimal algorithm (~23 secular evaluations per period "
+                                "in the root search), not a counter -- the warm-started search does ~4: see valu_issue for the "
+                                "counter view"},
+        "kernel_ms_per_step": rep["kernel_ms_per_step"], "kernel_launches_per_step": rep["kernel_launches_per_step"],
     }
+    for k in ("valu_issue", "root_search", "kernel_ms_note", "chains_in_a_trajectory_per_step"):
+        if k in rep:
+            res[k] = rep[k]
     res.update(extra)
     if world == 1 and not args.no_cpu_baseline and os.environ.get("RFS_BENCH_CHILD"):
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -550,6 +709,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler-leg", action="store_true", help="skip the extra HamitonianMC.sample_flow figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU; gloo)")
+    ap.add_argument("--timeout", type=float, default=1500.0, help="seconds before the launcher gives up on its ranks")
+    ap.add_argument("--sustain", type=int, default=400, help="device steps of the sampler_flow leg (a real HamitonianMC run, >= 2 s)")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline leg (profiling runs)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] legs of the default run")
+    ap.add_argument("--warm-start", type=int, default=None, choices=[0, 1], help="rfs_set_option swd_warm_start (default: library's, 1)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -282,7 +282,12 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
 /* Counters (cumulative since the context's warm-start buffers were made; the call synchronises):
  *   "swd_warm_declined_chains"  chain evaluations the warm start handed back to the reference-semantics search
  *   "swd_warm_items"            (period, chain) items the warm start refined
- *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items */
+ *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items
+ *   "swd_warm_cause_<k>"        chains handed back, by (first) cause: 4 no usable previous evaluation / forced, 5 step too
+ *                               large for a first-order model, 6 no sign change inside the trust radius, 7 root above the
+ *                               fastest layer, 9 / 11 another root lies between the point the reference's scan of that
+ *                               period (/ of a sequence's first period) starts from and the continued root, 8 / 10
+ *                               degenerate start point */
 int rfs_get_stat(rfs_ctx* ctx, const char* name, int64_t* value);
 /* Kernel groups of one rfs_joint_misfit_grad_dev call.  With timing enabled every group of every
  * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on

@@ -81,12 +81,14 @@ struct rfs_ctx {
     // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
     int rf_band_digits = 13;   // option "rf_band_limit_digits": adjoint band limit at 1e-digits * water (0 = off)
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
+    int warm_serial = 0;       // option "swd_warm_serial": warm-started steps on ONE stream (1) or SWD beside RF (0)
     int exact_final = 0;       // option "swd_exact_final": first and last evaluation of a trajectory by the full search
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs;
+    int warm_nitems = 0;       // (sequence, period) items of the joint configuration's evaluation
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
@@ -599,18 +601,19 @@ int launch_roots_split(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSe
 // Cooperative producer / consumer blocks for the Love family (big batches; the Rayleigh launch below has its own plan,
 // which the step's CU partition is built around).  Returns 1 when the shape does not fit (caller falls back).
 int launch_love_coop(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdSeqs& Q, const float* mdl, const double* mdlc,
-                     int* sflag) {
-    const int nitem = Q.nseq * nchain;
+                     int* sflag, const int* list = nullptr, const int* count = nullptr, int est_chains = 0) {
+    const int nitem = list ? Q.nseq * std::max(1, std::min(est_chains, nchain)) : Q.nseq * nchain;
     int npmax = 0;
     for (int q = 0; q < Q.nseq; q++) npmax = Q.s[q].nper > npmax ? Q.s[q].nper : npmax;
     if (c->swd_lanes != 0 || nitem <= SWD_LAT_MAX_ITEMS || n < 3 || n - 2 > 16 * COOP_NP || Q.nseq * npmax > 4096) return 1;
     const int nch = (n - 1 - COOP_CL + COOP_NP - 1) / COOP_NP;
     const size_t lds = (size_t)(4 * 64 + 8 + 2 * COOP_NP * SwdLoveFamily::NENT * 64 + 24 * 64 + 2 * Q.nseq * npmax) * sizeof(double);
     if (lds > 60 * 1024) return 1;
-    dim3 grid((nitem + 63) / 64);
+    dim3 grid((Q.nseq * nchain + 63) / 64);      // (with a list: sized for every chain, blocks beyond the list leave at once)
+    if (!list) grid = dim3((nitem + 63) / 64);
 #define RFS_LAUNCH_LCOOP(NCH)                                                                                  \
     hipLaunchKernelGGL((k_swd_roots_coop<SwdLoveFamily, NCH>), grid, dim3(512), lds, s, nchain, n, Q, mdl, mdlc, \
-                       c->croot.as<double>(), sflag)
+                       c->croot.as<double>(), sflag, list, count)
     if (nch <= 5) RFS_LAUNCH_LCOOP(5);
     else if (nch <= 8) RFS_LAUNCH_LCOOP(8);
     else RFS_LAUNCH_LCOOP(16);
@@ -660,12 +663,35 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // the list's length of an earlier step, whenever its copy has arrived (never waited for)
         const int est = std::max(c->warm_est, 64);
         const int gl = std::min((nchain + 63) / 64, std::max(8, (est + 63) / 64));
-        if (Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
-                                                                      c->sflag.as<int>(), 0, list, count, est)))
+        bool rdone = false;
+        if (Q.nseq > 0 && est * Q.nseq > SWD_LAT_MAX_ITEMS) {
+            // many chains handed back (large steps): the cooperative blocks of the full search, over the list
+            const CoopPlan cp = coop_plan(c, Q, nchain, n);
+            if (cp.ok) {
+                dim3 grid(cp.blocks);
+                size_t lds2 = cp.lds;
+#define RFS_LAUNCH_COOPL(NCH)                                                                                  \
+                do {                                                                                           \
+                    HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<SwdRayFamily, NCH>,            \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));      \
+                    hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, s, nchain, n, Q, \
+                                       mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>(), list, count); \
+                } while (0)
+                if (cp.nch <= 5) RFS_LAUNCH_COOPL(5);
+                else if (cp.nch <= 8) RFS_LAUNCH_COOPL(8);
+                else RFS_LAUNCH_COOPL(16);
+#undef RFS_LAUNCH_COOPL
+                rdone = true;
+            }
+        }
+        if (!rdone && Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                                                                               c->sflag.as<int>(), 0, list, count, est)))
             hipLaunchKernelGGL(k_swd_roots<false>, dim3(gl * Q.nseq), dim3(64), 0, s, nchain, n, Q, mdlR, c->croot.as<double>(),
                                c->sflag.as<int>(), list, count);
-        if (P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, s, nchain, n, P.QL, c->mdlL.as<float>(),
-                                                                         c->mdlcL.as<double>(), sflagL, 0, list, count, est)))
+        const bool ldone = P.QL.nseq > 0 && est * P.QL.nseq > SWD_LAT_MAX_ITEMS &&
+                           !launch_love_coop(c, s, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL, list, count, est);
+        if (!ldone && P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                                                                                   c->mdlcL.as<double>(), sflagL, 0, list, count, est)))
             hipLaunchKernelGGL(k_swd_roots<true>, dim3(gl * P.QL.nseq), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
                                c->croot.as<double>(), sflagL, list, count);
         HIPCHK(c, hipGetLastError());
@@ -708,7 +734,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));          \
                 hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, s, nchain, n, Q,               \
                                    mdlR, c->mdlc.as<double>(), c->croot.as<double>(),                           \
-                                   c->sflag.as<int>());                                                         \
+                                   c->sflag.as<int>(), (const int*)nullptr, (const int*)nullptr);               \
             } while (0)
             if (cp.nch <= 5) RFS_LAUNCH_COOP(5);
             else if (cp.nch <= 8) RFS_LAUNCH_COOP(8);
@@ -783,7 +809,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         const size_t before = c->wvalid.cap;
         ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, ((size_t)nchain + 1) * sizeof(int));
         ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
-        ENSURE(c, c->wstats, 4 * sizeof(unsigned long long));
+        ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         if (c->wvalid.cap != before) {
             HIPCHK(c, hipMemsetAsync(c->wforce.p, 0, c->wforce.cap, c->stream));
@@ -941,7 +967,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
     }
     if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
-        hipStream_t ss = part ? c->stream2m : c->stream2;
+        hipStream_t ss = part ? c->stream2m : ((warm && c->warm_serial) ? user : c->stream2);
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));
         TRY(launch_swd(c, ss, nchain, n, P, !part, true, 0, 0, warm));
@@ -1022,7 +1048,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         HIPCHK(c, hipGetLastError());
     }
     if (timed) { HIPCHK(c, hipEventRecord(cal->ev[2 * cal->stage + 1], user)); cal->stage++; }
-    if (track) { c->warm_primed = true; c->warm_nchain = nchain; }
+    if (track) { c->warm_primed = true; c->warm_nchain = nchain; c->warm_nitems = P.nitems; }
     return RFS_OK;
 }
 
@@ -1065,7 +1091,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn};
+                   &c->wstats, &c->wsgn, &c->crs};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     drop_plans(c);
@@ -1162,6 +1188,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_warm_start must be 0, 1 or 2");
         c->warm_opt = value; c->warm_primed = false; return RFS_OK;
     }
+    if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
     if (!strcmp(name, "swd_exact_final")) {
         c->exact_final = value != 0;
@@ -1191,11 +1218,12 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
     else if (!strcmp(name, "swd_warm_secular_evals")) idx = 1;
     else if (!strcmp(name, "swd_warm_items")) idx = 2;
+    else if (!strncmp(name, "swd_warm_cause_", 15)) { idx = atoi(name + 15); if (idx < 4 || idx > 11) idx = -1; }
     if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
     if (!c->wstats.p) return RFS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     TRY(rfs_synchronize(c));
-    unsigned long long v[4];
+    unsigned long long v[16];
     HIPCHK(c, hipMemcpy(v, c->wstats.p, sizeof(v), hipMemcpyDeviceToHost));
     *value = (int64_t)v[idx];
     return RFS_OK;
@@ -1560,7 +1588,7 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     TRY(check_batch(c, nchain, c->n));
     if (!x || !p || !dt || !rem || !fresh || !bounds || !Ucur || !Hcur || !Unew || !Hnew || !dsyn_cur || !dsyn_new || !ok || !done)
         return fail(c, RFS_ERR_ARG, "null argument");
-    FlowNext fn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    FlowNext fn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (next) {
         if (!next->have || !next->u || !next->p || !next->xstart || !next->res_x || !next->res_val)
             return fail(c, RFS_ERR_ARG, "rfs_flow_next: only rem (with gsave, kick given), res_dsyn, gsave and kick may be null");
@@ -1569,7 +1597,7 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
         if ((next->gsave == nullptr) != (next->kick == nullptr))
             return fail(c, RFS_ERR_ARG, "rfs_flow_next: gsave and kick go together");
         fn = FlowNext{next->have, next->u, next->p, next->rem, next->xstart, next->res_x, next->res_val, next->res_dsyn,
-                      next->gsave, next->kick};
+                      next->gsave, next->kick, nullptr, nullptr, nullptr, 0};
     }
     const int n = c->n, nx = 2 * n, nd = c->ndata;
     ENSURE(c, c->lU, (size_t)nchain * sizeof(double)); ENSURE(c, c->lgrad, (size_t)nchain * nx * sizeof(double));
@@ -1583,6 +1611,15 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p,
                        fn.gsave, fn.kick, wforce);
     TRY(joint_eval(c, nchain, x, U, g, d, fl, 1));
+    if (next && c->has_swd && c->warm_opt && c->warm_primed && c->warm_nchain == nchain && c->xw.p) {
+        // the start roots of every running trajectory, restored with the start model when it is rejected (k_flow_post)
+        const int nitems = (int)(c->croot.cap / sizeof(double) / (size_t)nchain);
+        const int nit = c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3] > 0 ? c->warm_nitems : 0;
+        if (nit > 0 && nit <= nitems) {
+            ENSURE(c, c->crs, (size_t)nit * nchain * sizeof(double));
+            fn.croot = c->croot.as<double>(); fn.crs = c->crs.as<double>(); fn.xw = c->xw.as<double>(); fn.nitems = nit;
+        }
+    }
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn);
     HIPCHK(c, hipGetLastError());

@@ -770,14 +770,17 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
     const int k = e - Q.s[seq].croot_off;
     const size_t s = (size_t)n * nchain;
-    auto decline = [&]() {
+    // cause: 4 no usable previous evaluation / forced, 5 step too large for a first-order model, 6 no sign change inside
+    // the trust radius or no convergence, 7 root above the fastest layer  (statistics only)
+    auto decline = [&](int cause) {
         if (atomicExch(&W.need[chain], 1) == 0) {
             W.list[atomicAdd(W.count, 1)] = chain;
             atomicAdd(&W.stats[0], 1ull);
+            atomicAdd(&W.stats[cause], 1ull);
         }
     };
     W.sgn[(size_t)e * nchain + chain] = 2;
-    if (!W.valid[chain] || (W.force && W.force[chain])) { decline(); return; }
+    if (!W.valid[chain] || (W.force && W.force[chain])) { decline(4); return; }
     // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
     // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
     // vtp / dtp / rtp as swd_kernel_value does
@@ -808,6 +811,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     WarmSearch ws;
     ws.begin(cprev, dc, l1);
     if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
+    const bool refused = !ws.active();
     while (__any(ws.active())) {
         if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
     }
@@ -815,7 +819,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     if (ok) {
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
         W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
-    } else decline();
+    } else decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
     int nev = ws.nev, nok = ok ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }
@@ -856,12 +860,21 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
-    bool bad = sg > 1 || !(sk < ck) || !(sk > 0.0);
-    const double f = swd_secular_family<F>(n, loadL, omega, bad ? ck : sk);
-    bad = bad || ((signbit(f) ? 1 : 0) != sg);
+    // The scan runs from sk towards the first sign change it meets: upwards when the function at sk has the sign it has
+    // below the lowest root, downwards otherwise (getsol :439-447).  No root may lie between sk and the continued root:
+    // below it the function must have the sign it has just below the root, above it (anomalous dispersion: the root has
+    // dropped more than 1.5 dc under the previous period's) the opposite one.
+    // (downwards only over a short stretch: a long one may hide a PAIR of roots of other modes between two scan points,
+    // which the sign alone cannot show -- the reference itself sees or misses such a pair by the luck of its grid)
+    const bool order = sg > 1 || !(sk > 0.0) || sk == ck || sk - ck > WARM_ANOM_GAP;
+    const double f = swd_secular_family<F>(n, loadL, omega, order ? ck : sk);
+    const bool bad = order || ((signbit(f) ? 1 : 0) != (sk < ck ? sg : 1 - sg));
     if (bad && atomicExch(&W.need[chain], 1) == 0) {
         W.list[atomicAdd(W.count, 1)] = chain;
         atomicAdd(&W.stats[0], 1ull);
+        // cause: 8 no root / degenerate start point, 9 another root between the scan's start and the continued root,
+        // 10 / 11 the same for a sequence's first period
+        atomicAdd(&W.stats[(order ? 8 : 9) + (k == 0 ? 2 : 0)], 1ull);
     }
     if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[1], 64ull);
 }
@@ -890,8 +903,13 @@ constexpr int COOP_NP = 8 - COOP_NC;             // producer waves = layers per 
 template <class F, int NCH>                      // chunks held in registers: (n-1-COOP_CL) <= NCH*COOP_NP
 __global__ void __launch_bounds__(512)
 k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
-                 const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag)
+                 const double* __restrict__ mdlc, double* __restrict__ croot, int* __restrict__ sflag,
+                 const int* __restrict__ list, const int* __restrict__ count)
 {
+    // list != nullptr: only the *count chains named there (the chains the warm start handed back, k_swd_warm); the grid
+    // is sized for every chain and the blocks beyond the list leave at once
+    const int nsel = list ? *count : nchain;
+    if ((int)blockIdx.x * 64 >= Q.nseq * nsel) return;
     extern __shared__ double lds[];
     double* req = lds;                           // [4][64]: wvno, wvno2, omega, 1/omega
     int* go = (int*)(lds + 4 * 64);              // go[w]: consumer w has another evaluation
@@ -904,10 +922,11 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
     // block-lane = which of the block's 64 items this thread works on
     const int bl = (wave < COOP_NC) ? wave * IPC + (lane % IPC) : lane;
     int item = blockIdx.x * 64 + bl;
-    int seq = item / nchain, chain = item - seq * nchain;
+    int seq = item / nsel, chain = item - seq * nsel;
     bool live = seq < Q.nseq;
     if (wave < COOP_NC && lane >= IPC) live = false;     // upper lanes of a consumer wave idle
     if (seq >= Q.nseq) { seq = 0; chain = 0; }
+    else if (list) chain = list[chain];
     const int nprod = n - 1 - COOP_CL;           // layers handled by the producers
     const int nch = (nprod + COOP_NP - 1) / COOP_NP;
     int npmax = 0;
@@ -1499,6 +1518,10 @@ struct FlowNext {
     int* have; const double* u; const double* p; const int* rem;
     double* xstart; double* res_x; double* res_val; double* res_dsyn;
     double* gsave; int* kick;        // deferred first half kick (rem == nullptr): gradient at the start model, flag
+    // warm start of the root search (library-internal, nullptr = off): the roots of a trajectory's START model are kept
+    // aside; a rejected trajectory goes back to that model, and with it go its roots -- the evaluation that follows then
+    // continues from "the same model" instead of from the end model a whole trajectory away
+    double* croot; double* crs; double* xw; int nitems;
 };
 __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, const double* U,
                             const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
@@ -1541,6 +1564,8 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
         }
         if (nx_.have)                                           // the model this trajectory starts from (kept for a rejection)
             for (int i = tid; i < nx; i += blockDim.x) nx_.xstart[(size_t)chain * nx + i] = x[(size_t)chain * nx + i];
+        if (nx_.have && nx_.crs)                                // ... and its roots
+            for (int e = tid; e < nx_.nitems; e += blockDim.x) nx_.crs[(size_t)e * nchain + chain] = nx_.croot[(size_t)e * nchain + chain];
         k = wave_sum(k);
         if ((tid & 63) == 0) red[tid >> 6] = k;
         __syncthreads();
@@ -1601,7 +1626,10 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
             nx_.res_x[o] = x[o];                                // end model of the trajectory, whatever its fate
             if (!acc) x[o] = nx_.xstart[o];                     // rejected: back to the start model
             p[o] = nx_.p[o];                                    // momentum of the next trajectory
+            if (!acc && nx_.crs) nx_.xw[o] = nx_.xstart[o];     // ... which is then also "the previous model" of the root search
         }
+        if (!acc && nx_.crs)
+            for (int e = tid; e < nx_.nitems; e += blockDim.x) nx_.croot[(size_t)e * nchain + chain] = nx_.crs[(size_t)e * nchain + chain];
         if (nx_.res_dsyn)
             for (int i = tid; i < ndata; i += blockDim.x) nx_.res_dsyn[(size_t)chain * ndata + i] = dsyn[(size_t)chain * ndata + i];
         __syncthreads();

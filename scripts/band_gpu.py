@@ -27,8 +27,8 @@ for dig in (13, 10, 16):
     print(f"digits {dig}: grad rel diff vs unlimited max {((g - g0).abs().amax(dim=1) / g0.abs().amax(dim=1)).max().item():.3e}; "
           f"misfit equal {torch.equal(res[dig][0], res[0][0])}, dsyn equal {torch.equal(res[dig][2], res[0][2])}")
 bounds = bench.bounds_of(x_true)
-for dig in (13, 0):
-    ctx.set_option("rf_band_limit_digits", dig)
+for dig, ser in ((13, 0), (13, 1), (0, 0)):
+    ctx.set_option("rf_band_limit_digits", dig); ctx.set_option("swd_warm_serial", ser)
     st = j.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
     st["p"].copy_(tt(0.5 * np.random.default_rng(7).standard_normal(xs.shape))); st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
     for _ in range(40): j.flow_step(st)
@@ -42,4 +42,4 @@ for dig in (13, 0):
     for _ in range(K): j.flow_step(st)
     ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / K * 1e3
-    print(f"config {cfgi} band digits {dig}: {el:.3f} ms/step = {nchain / el * 1e3:.0f} evals/s", {k: round(ms[i] / max(cnt[i], 1), 3) for i, k in enumerate(K_NAMES)})
+    print(f"config {cfgi} band digits {dig} serial {ser}: {el:.3f} ms/step = {nchain / el * 1e3:.0f} evals/s", {k: round(ms[i] / max(cnt[i], 1), 3) for i, k in enumerate(K_NAMES)})

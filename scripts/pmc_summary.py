@@ -1,64 +1,71 @@
 #!/usr/bin/env python3
 """Merge rocprofv3 --pmc passes (one counter group per pass, as MI355X_MICROARCH.md prescribes) into
-profiles/<tag>_pmc_joint_8192.csv and profiles/<tag>_traffic.json.
+profiles/<tag>_pmc_config<c>.csv and the per-step, per-group figures bench.py reads: profiles/<tag>_counters.json.
 
-    python3 scripts/pmc_summary.py <tag> <dir_with_pass_subdirs>
+    python3 scripts/pmc_summary.py <tag> <config> <steps> <dir_with_pass_subdirs>
 
-Each pass directory holds a *counter_collection.csv of `python3 scripts/prof_run.py 8192 3`.  Per kernel the LAST
-dispatch (steady state) is kept.  HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 counts
-64 B per 128-B request on wide coalesced reads, hence the factor 2), summed per kernel group of rfs_kernel_id."""
+Each pass directory holds a *counter_collection.csv of `python3 scripts/prof_run.py <config> <steps>` (one full-search
+call + <steps> warm-started calls).  Per kernel: the sum over all dispatches divided by the number of calls it ran in
+(= per leapfrog step; a tiled shape launches a kernel several times per step).  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE
+(KiB counters; gfx950 counts 64 B per 128-B request on wide coalesced reads, hence the factor 2)."""
 import csv, glob, json, os, sys
 
 GROUPS = [("k_prep", "prep"), ("k_rf_passA", "rf_pass_a"), ("k_rf_mid", "rf_mid"), ("k_rf_passB", "rf_pass_b"),
-          ("k_swd_roots", "swd_roots"), ("k_swd_eigen", "swd_eigen"), ("k_rf_reduce", "combine"),
-          ("k_swd_combine", "combine")]
+          ("k_swd_roots_coop", "swd_roots_full_search"), ("k_swd_roots", "swd_roots"), ("k_swd_warm", "swd_roots"),
+          ("k_swd_eigen", "swd_eigen"),
+          ("k_rf_reduce", "rf_pass_b"), ("k_swd_combine", "combine")]
+FULL_ONLY = ("k_swd_roots_coop",)          # run in the first call only
 
 
 def short(name):
-    n = name.split("(")[0]
-    n = n.replace("void ", "").replace("rfs::", "")
-    return n
+    return name.split("(")[0].replace("void ", "").replace("rfs::", "")
 
 
 def main():
-    tag, root = sys.argv[1], sys.argv[2]
-    data = {}      # kernel -> counter -> (value of last dispatch, dispatches)
+    tag, config, steps, root = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    tot, disp = {}, {}
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
-        rows = list(csv.DictReader(open(f)))
-        last = {}
-        for r in rows:
-            k = short(r["Kernel_Name"]); cn = r["Counter_Name"]
-            key = (k, cn)
-            did = int(r["Dispatch_Id"])
-            if key not in last or did >= last[key][0]:
-                # several rows per dispatch (one per XCD / dimension): sum them
-                if key in last and did == last[key][0]:
-                    last[key] = (did, last[key][1] + float(r["Counter_Value"]), last[key][2])
-                else:
-                    last[key] = (did, float(r["Counter_Value"]), last.get(key, (0, 0, 0))[2] + 1)
-        for (k, cn), (did, v, nd) in last.items():
-            data.setdefault(k, {})[cn] = (v, nd)
-    counters = sorted({c for k in data for c in data[k]})
+        seen = {}
+        for r in csv.DictReader(open(f)):
+            k, cn = short(r["Kernel_Name"]), r["Counter_Name"]
+            tot[(k, cn)] = tot.get((k, cn), 0.0) + float(r["Counter_Value"])
+            seen.setdefault((k, cn), set()).add(r["Dispatch_Id"])
+        for key, ids in seen.items():
+            disp[key] = len(ids)
+    kernels = sorted({k for k, _ in tot if k.startswith("k_")})
+    counters = sorted({c for _, c in tot})
+
+    def calls(k):
+        if k.startswith(FULL_ONLY):
+            return 1
+        return steps if k.startswith("k_swd_warm") or (k.startswith("k_swd_roots") and not k.startswith(FULL_ONLY)) else steps + 1
     os.makedirs("profiles", exist_ok=True)
-    out = os.path.join("profiles", f"{tag}_pmc_joint_8192.csv")
+    out = os.path.join("profiles", f"{tag}_pmc_config{config}.csv")
     with open(out, "w") as fo:
-        fo.write("# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 scripts/prof_run.py 8192 3   (one pass per counter group)\n")
-        fo.write("# per-dispatch values of the LAST (steady-state) dispatch of each kernel; FETCH_SIZE / WRITE_SIZE in KiB as reported\n")
-        fo.write("kernel,dispatches," + ",".join(counters) + "\n")
-        for k in sorted(data):
-            if not k.startswith("k_"):
-                continue
-            nd = max(v[1] for v in data[k].values())
-            fo.write(k + f",{nd}," + ",".join("%g" % data[k][c][0] if c in data[k] else "" for c in counters) + "\n")
-    traffic = {"_comment": "HBM bytes per launch of each kernel group at config 2 (8192 chains), from " + out +
-               ": 2*FETCH_SIZE (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; rocFFT kernels not included",
-               "chains": 8192}
-    for k in data:
+        fo.write(f"# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 scripts/prof_run.py {config} {steps}   (one pass per counter group)\n")
+        fo.write("# per LEAPFROG STEP: sum over all dispatches of the kernel / calls it ran in; FETCH_SIZE / WRITE_SIZE in KiB as reported\n")
+        fo.write("kernel,dispatches_per_step," + ",".join(counters) + "\n")
+        for k in kernels:
+            nd = max(disp.get((k, c), 0) for c in counters)
+            fo.write(k + f",{nd / calls(k):g}," + ",".join("%g" % (tot[(k, c)] / calls(k)) if (k, c) in tot else "" for c in counters) + "\n")
+    jpath = os.path.join("profiles", f"{tag}_counters.json")
+    J = json.load(open(jpath)) if os.path.exists(jpath) else {
+        "_comment": "per leapfrog step and kernel group, 8192 chains, from profiles/" + tag + "_pmc_config*.csv: hbm_bytes = "
+                    "2*FETCH_SIZE (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; "
+                    "valu_insts = SQ_INSTS_VALU (wave-instructions); rocFFT kernels not included", "chains": 8192}
+    sec = {}
+    for k in kernels:
         for pat, grp in GROUPS:
-            if k.startswith(pat) and "FETCH_SIZE" in data[k] and "WRITE_SIZE" in data[k]:
-                traffic[grp] = traffic.get(grp, 0.0) + (2 * data[k]["FETCH_SIZE"][0] + data[k]["WRITE_SIZE"][0]) * 1024.0
-    json.dump(traffic, open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
-    print(open(out).read()); print(json.dumps(traffic, indent=1))
+            if k.startswith(pat):
+                g = sec.setdefault(grp, {"hbm_bytes": 0.0, "valu_insts": 0.0})
+                if (k, "FETCH_SIZE") in tot and (k, "WRITE_SIZE") in tot:
+                    g["hbm_bytes"] += (2 * tot[(k, "FETCH_SIZE")] + tot[(k, "WRITE_SIZE")]) * 1024.0 / calls(k)
+                if (k, "SQ_INSTS_VALU") in tot:
+                    g["valu_insts"] += tot[(k, "SQ_INSTS_VALU")] / calls(k)
+                break
+    J[f"config{config}"] = sec
+    json.dump(J, open(jpath, "w"), indent=1)
+    print(open(out).read()); print(json.dumps(sec, indent=1))
 
 
 if __name__ == "__main__":

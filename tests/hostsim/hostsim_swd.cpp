@@ -287,7 +287,7 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
         double f = love ? swd_secular_family<SwdLoveFamily>(n, loadL, omega, sk)
                         : swd_secular_family<SwdRayFamily>(n, loadL, omega, sk);
         nev[k]++;
-        if ((signbit(f) ? 1 : 0) != sgn_lo[k] || !(sk < cout[k])) status[k] = 2;
+        if ((signbit(f) ? 1 : 0) != (sk < cout[k] ? sgn_lo[k] : 1 - sgn_lo[k]) || sk == cout[k] || sk - cout[k] > WARM_ANOM_GAP) status[k] = 2;
     }
     for (int k = 0; k < nt; k++) nfail += status[k] != 1;
     return nfail;

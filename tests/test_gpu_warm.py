@@ -114,6 +114,42 @@ def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc):
           f"{evals / max(items, 1):.2f} secular evaluations per item, {declined} chain evaluations handed back")
 
 
+def test_roots_under_large_steps_against_the_restatement(orc):
+    """The same check at step sizes of a dual-averaging run (dt = 0.03 and 0.08: first-order changes of the roots of
+    several 1e-2 km/s, beyond the point where the first-order model alone brackets the root): 1024 chains x 8 steps;
+    whatever the continuation accepts is within 1.2e-6 c of the reference search, whatever it cannot follow is handed back."""
+    import os
+    import torch
+    import bench
+    n, nt, nchain, nsteps = 30, 512, 1024, 8
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bounds = bench.bounds_of(bench.true_model(n))
+    lo, hi = tt(bounds[:, 0]), tt(bounds[:, 1])
+    nproc = max(1, min(16, len(os.sched_getaffinity(0))))
+    with mp.get_context("fork").Pool(nproc) as pool:
+        for dt in (0.03, 0.08):
+            joint, t = _bench_joint(2)
+            ctx = joint._ensure(n)
+            xs = np.clip(bench.make_models(nchain, 17, n), bounds[:, 0], bounds[:, 1])
+            x = tt(xs); p = tt(0.5 * np.random.default_rng(3).standard_normal(xs.shape))
+            worst = 0.0
+            for s in range(nsteps + 1):
+                m, g, d, f = joint.misfit_and_grad_device(x)
+                co, oko = _oracle_batch(pool, x.cpu().numpy(), t, n, nproc)
+                fl = f.cpu().numpy() != 0
+                assert np.array_equal(oko, fl), (dt, s)
+                r = np.abs(d[:, nt:].cpu().numpy()[oko] - co[oko]) / co[oko]
+                assert r.max() <= 1.2e-6, (dt, s, float(r.max()))
+                worst = max(worst, float(r.max()))
+                # (no gradient in the move: the random momentum alone sets the step length, as intended here)
+                x, p = _leapfrog_move(x, p, torch.zeros_like(g), dt, lo, hi)
+            items, decl = ctx.stat("swd_warm_items"), ctx.stat("swd_warm_declined_chains")
+            print(f"dt {dt}: worst {worst:.3e} c; {items / (nsteps * nchain * 40):.2%} of the items continued, "
+                  f"{decl} chain evaluations handed back, {ctx.stat('swd_warm_secular_evals') / max(items, 1):.2f} evaluations per item")
+            assert items >= 0.5 * nsteps * nchain * 40
+
+
 def test_option_zero_is_the_history_free_search_and_failing_models_keep_their_flags(golden):
     """swd_warm_start = 0 inside the flow entry == the plugin evaluation of the same models, bit for bit; with the warm
     start on, models the reference search fails on (unsorted velocities with strong inversions) get the same flags and the
@@ -270,9 +306,10 @@ def test_reference_sampler_traces_with_the_warm_start_on(kind, golden):
             seq = [(tr, tr["active"].index(c)) for tr in s.trace if c in tr["active"]]
             assert np.array_equal(np.array([tr["L"][k] for tr, k in seq]), g[f"{tag}/L"])
             assert np.array_equal(np.array([tr["accept"][k] for tr, k in seq]), g[f"{tag}/accept"])
-            assert rel(np.array([tr["xres"][k] for tr, k in seq]), g[f"{tag}/x"]) < 2e-5
-            assert rel(np.array([tr["Ures"][k] for tr, k in seq]), g[f"{tag}/U"]) < 1e-4
-            assert rel(mis[c], g[f"{tag}/misfit"]) < 1e-4
+            # (trajectories of 5..20 steps of dt = 0.1 amplify a 1e-6 difference of the synthetics by ~1e2)
+            assert rel(np.array([tr["xres"][k] for tr, k in seq]), g[f"{tag}/x"]) < 1e-4
+            assert rel(np.array([tr["Ures"][k] for tr, k in seq]), g[f"{tag}/U"]) < 1e-3
+            assert rel(mis[c], g[f"{tag}/misfit"]) < 1e-3
     else:
         s = HMCDualAveraging(joint, g["bounds"], 0.1, 10, 2, 0.65, 991206, 6, 3, myrank=0, name="t", outdir=None,
                              nchains=1, verbose=False)
