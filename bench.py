@@ -555,13 +555,15 @@ def run_rank(args):
     nchain = args.chains
     nwarm = max(args.warmup, 2)
     K = args.steps
+    # --seed-rank R (single-rank jobs): run the chains rank R of a multi-rank job would run (tests)
+    srank = rank if args.seed_rank is None else args.seed_rank
     joint, x_true, bounds = make_joint(cfg, local_rank)
     if args.warm_start is not None:
         joint.set_warm_start(args.warm_start)
     ctx = joint._ensure(n)
     extra = {}
     if cfg["sampler"] is None:
-        rep, st, xs, el = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier)
+        rep, st, xs, el = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, K, nwarm, barrier)
         evals_rank = nchain * K
         misfit = st["Unew"]
         extra["setup_steps"] = 33      # start evaluation + 32 untimed steps
@@ -625,7 +627,7 @@ def run_rank(args):
                         "rejects and starts the next trajectory itself (rfs_flow_step2); books and samples are kept on the "
                         "host beside the device steps"}
     else:
-        rep, xs, el, evals_rank = da_leg(cfg, args.config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier)
+        rep, xs, el, evals_rank = da_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, K, nwarm, barrier)
         misfit = torch.zeros(nchain, dtype=torch.float64, device=dev)
 
     total_evals = evals_rank
@@ -638,9 +640,10 @@ def run_rank(args):
         from rfsurfhmc_amd.chains import gather_misfits
         gathered = gather_misfits(misfit.to(cdev))
         assert rank != 0 or gathered.shape[0] == nchain * world
-        if rank == 0 and shared:
-            extra["gathered"] = {"n": int(gathered.shape[0]), "sha": float(gathered.sum().item()),
-                                 "first_of_each_rank": [float(gathered[r * nchain].item()) for r in range(world)]}
+        if rank == 0 and os.environ.get("RFS_BENCH_DUMP"):
+            np.save(os.environ["RFS_BENCH_DUMP"], gathered.cpu().numpy())
+    elif os.environ.get("RFS_BENCH_DUMP"):
+        np.save(os.environ["RFS_BENCH_DUMP"], misfit.cpu().numpy())
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -709,6 +712,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler-leg", action="store_true", help="skip the extra HamitonianMC.sample_flow figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU; gloo)")
+    ap.add_argument("--seed-rank", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--timeout", type=float, default=1500.0, help="seconds before the launcher gives up on its ranks")
     ap.add_argument("--sustain", type=int, default=400, help="device steps of the sampler_flow leg (a real HamitonianMC run, >= 2 s)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline leg (profiling runs)")

@@ -46,10 +46,15 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RFS_SHARED_GPU=1: functional check of a multi-rank job on a box with ONE GPU (every rank on device 0, collectives
+    # over gloo: RCCL refuses two ranks on one device)
+    shared = os.environ.get("RFS_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)                          # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")          # RCCL
+        dist.init_process_group(backend="gloo" if shared else "nccl")          # "nccl" is RCCL
 
     with open(args.param) as f:
         param = yaml.safe_load(f)
@@ -60,11 +65,13 @@ def main():
     model_swd.set_thk(thk); model_rf.set_thk(thk)
     model = Joint_RF_SWD(1.0, 1.0, model_rf, model_swd, device=local)
     hp = dict(param["hmc"])
+    if os.environ.get("RFS_OUTPUT_DIR"):
+        hp["OUTPUT_DIR"] = os.environ["RFS_OUTPUT_DIR"]
     outdir = hp["OUTPUT_DIR"]
     os.makedirs(outdir, exist_ok=True)
 
     dobs = x = None
-    if rank == 0:
+    if rank == 0 or world == 1:                           # (world == 1 with RANK = r: the chains of rank r, alone)
         x = np.hstack((vs, thk))
         drsyn, dssyn, _ = model.forward(x)
         dobs = np.concatenate((drsyn, dssyn))
@@ -82,8 +89,9 @@ def main():
     tmp = chain.sample_flow() if schedule == "flow" else chain.sample()
     tmp = np.atleast_2d(tmp)
     el = time.time() - t0
-    misfit = gather_misfits(torch.from_numpy(np.ascontiguousarray(tmp)).cuda())
-    if rank == 0:
+    tmp_t = torch.from_numpy(np.ascontiguousarray(tmp))
+    misfit = gather_misfits(tmp_t if shared else tmp_t.cuda())
+    if rank == 0 or world == 1:
         misfit = misfit.cpu().numpy()
         np.save(os.path.join(outdir, "misfit.npy"), misfit)
         print(f"{misfit.shape[0]} chains x {misfit.shape[1]} samples on {world} GPU(s) in {el:.1f} s; "
