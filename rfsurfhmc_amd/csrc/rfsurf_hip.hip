@@ -80,6 +80,7 @@ struct rfs_ctx {
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
     int rf_band_digits = 13;   // option "rf_band_limit_digits": adjoint band limit at 1e-digits * water (0 = off)
+    int rf_band_floor = 8;     // option "rf_band_floor_digits": the limit may move down to a multiple of 64 bins, never below this
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
     int warm_serial = 0;       // option "swd_warm_serial": warm-started steps on ONE stream (1) or SWD beside RF (0)
     int exact_final = 0;       // option "swd_exact_final": first and last evaluation of a trajectory by the full search
@@ -270,13 +271,25 @@ int rf_nparts_b(const RfFreq& f) { int bs = rf_block_of(f, 64); return rf_chunks
 // The band limit of the fused gradient (RfFreq::nk): the adjoint weight of frequency k carries G_k = exp(-(w_k / 2 f0)^2)
 // over a denominator >= water * max (RFModule.f90:393,413-419); below eps * water it is lost in the double-precision sum
 // over frequencies.  digits = -log10(eps), 0 = no limit.
-void set_band_limit(RfFreq& f, int digits) {
-    f.nk = f.n2; f.nkp = f.n2p;
-    if (digits <= 0 || f.method != RFS_RF_FREQ || !(f.water > 0.0) || !(f.f0 > 0.0)) return;
-    const double thr = std::pow(10.0, -(double)digits) * std::min(1.0, f.water);
+int band_bins(const RfFreq& f, double digits) {
+    const double thr = std::pow(10.0, -digits) * std::min(1.0, f.water);
     const double wcut = 2.0 * f.f0 * std::sqrt(-std::log(thr));           // G(w) >= thr  <=>  w <= wcut
     const double dw = 2.0 * 3.14159265358979323846 / (f.nft * f.dt);
-    const int nk = (int)std::floor(wcut / dw) + 2;                        // one spare bin: the axis uses a float32 pi
+    return (int)std::floor(wcut / dw) + 2;                                // one spare bin: the axis uses a float32 pi
+}
+// digits: the target (default 13); floor_digits: the least the limit may ever keep (default 8).  A lane is a frequency
+// and a wavefront 64 of them, so a limit just above a multiple of 64 leaves a wavefront mostly idle: when a multiple
+// of 64 lies between the two limits the band ends there (nt = 512, dt = 0.1, f0 = 1.5: 128 bins = two full wavefronts
+// per chain instead of 150 = three; measured gradient difference to the unlimited sum: see DESIGN.md).
+void set_band_limit(RfFreq& f, int digits, int floor_digits) {
+    f.nk = f.n2; f.nkp = f.n2p;
+    if (digits <= 0 || f.method != RFS_RF_FREQ || !(f.water > 0.0) || !(f.f0 > 0.0)) return;
+    int nk = band_bins(f, (double)digits);
+    if (floor_digits > 0 && floor_digits < digits) {
+        const int lo = band_bins(f, (double)floor_digits);
+        const int m = (lo + 63) / 64 * 64;
+        if (m >= 64 && m <= nk) nk = m;
+    }
     if (nk < f.n2) { f.nk = std::max(nk, 1); f.nkp = (f.nk + 15) / 16 * 16; }
 }
 
@@ -632,6 +645,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     ENSURE(c, c->sflag, (size_t)8 * nchain * sizeof(int));
     const float* mdlR = sphere ? c->mdlSR.as<float>() : c->mdl.as<float>();
     int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
+    hipStream_t warm_side = nullptr;         // side stream carrying the full search of the chains a warm start handed back
     if (warm && roots) {
         // Inside a trajectory: every (period, chain) item refines the previous evaluation's root on its own (k_swd_warm);
         // the chains that cannot be continued go through the reference-semantics search right behind, on a list.
@@ -660,6 +674,12 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         HIPCHK(c, hipGetLastError());
         const int* list = c->wlist.as<int>();
         const int* count = c->wneed.as<int>() + nchain;
+        // The hand-back list is nearly always empty, and when it is not, the full search of even ONE chain takes ~3 ms
+        // (about a thousand dependent secular evaluations): it runs on a side stream beside the eigenfunction pass of
+        // all chains, and only the listed chains' eigenfunctions are redone behind it (below)
+        hipStream_t sf = (kernels && c->stream_l && s != c->stream_l) ? c->stream_l : s;
+        if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_lf, s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_lf, 0)); }
+        warm_side = sf != s ? sf : nullptr;
         // the list's length of an earlier step, whenever its copy has arrived (never waited for)
         const int est = std::max(c->warm_est, 64);
         const int gl = std::min((nchain + 63) / 64, std::max(8, (est + 63) / 64));
@@ -674,7 +694,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                 do {                                                                                           \
                     HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<SwdRayFamily, NCH>,            \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));      \
-                    hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, s, nchain, n, Q, \
+                    hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, sf, nchain, n, Q, \
                                        mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>(), list, count); \
                 } while (0)
                 if (cp.nch <= 5) RFS_LAUNCH_COOPL(5);
@@ -684,20 +704,20 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                 rdone = true;
             }
         }
-        if (!rdone && Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+        if (!rdone && Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, sf, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                                                                c->sflag.as<int>(), 0, list, count, est)))
-            hipLaunchKernelGGL(k_swd_roots<false>, dim3(gl * Q.nseq), dim3(64), 0, s, nchain, n, Q, mdlR, c->croot.as<double>(),
+            hipLaunchKernelGGL(k_swd_roots<false>, dim3(gl * Q.nseq), dim3(64), 0, sf, nchain, n, Q, mdlR, c->croot.as<double>(),
                                c->sflag.as<int>(), list, count);
         const bool ldone = P.QL.nseq > 0 && est * P.QL.nseq > SWD_LAT_MAX_ITEMS &&
-                           !launch_love_coop(c, s, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL, list, count, est);
-        if (!ldone && P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                           !launch_love_coop(c, sf, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL, list, count, est);
+        if (!ldone && P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, sf, nchain, n, P.QL, c->mdlL.as<float>(),
                                                                                    c->mdlcL.as<double>(), sflagL, 0, list, count, est)))
-            hipLaunchKernelGGL(k_swd_roots<true>, dim3(gl * P.QL.nseq), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+            hipLaunchKernelGGL(k_swd_roots<true>, dim3(gl * P.QL.nseq), dim3(64), 0, sf, nchain, n, P.QL, c->mdlL.as<float>(),
                                c->croot.as<double>(), sflagL, list, count);
         HIPCHK(c, hipGetLastError());
         if (c->h_wcount) {
             if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
-            HIPCHK(c, hipMemcpyAsync(c->h_wcount, count, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_wcount, count, sizeof(int), hipMemcpyDeviceToHost, sf));
         }
         roots = false;
     }
@@ -758,7 +778,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
 #define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                                \
         hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)),            \
                            dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(),     \
-                           SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (int)(EL1), EARLY, EDONE)
+                           SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (int)(EL1), EARLY, EDONE, \
+                           (const int*)nullptr, (const int*)nullptr)
         int* ed = (eigen_mode == 1 || eigen_mode == 2) ? c->edone.as<int>() : nullptr;
         if (P.QR.nper_total > 0 && eigen_mode != 4) {
             const int el1 = eigen_mode == 1 ? early_items : P.QR.nper_total;
@@ -772,6 +793,31 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         }
 #undef RFS_LAUNCH_EIGEN
         HIPCHK(c, hipGetLastError());
+        if (warm_side) {
+            // behind the full search of the handed-back chains: their eigenfunctions again, from their new roots (the pass
+            // above has read whatever roots they had; it must have finished before these results are written)
+            HIPCHK(c, hipEventRecord(c->ev_lj, s));
+            HIPCHK(c, hipStreamWaitEvent(warm_side, c->ev_lj, 0));
+            const int* list = c->wlist.as<int>();
+            const int* count = c->wneed.as<int>() + nchain;
+#define RFS_LAUNCH_EIGEN_LIST(LOVE, SPH, QQ, SPHP, SFL)                                                              \
+            hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
+                               dim3(64), 0, warm_side, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(), \
+                               SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (QQ).nper_total, 0, \
+                               (int*)nullptr, list, count)
+            if (P.QR.nper_total > 0) {
+                if (sphere) RFS_LAUNCH_EIGEN_LIST(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>());
+                else RFS_LAUNCH_EIGEN_LIST(false, false, P.QR, (const double*)nullptr, c->sflag.as<int>());
+            }
+            if (P.QL.nper_total > 0) {
+                if (sphere) RFS_LAUNCH_EIGEN_LIST(true, true, P.QL, c->sphL.as<double>(), sflagL);
+                else RFS_LAUNCH_EIGEN_LIST(true, false, P.QL, (const double*)nullptr, sflagL);
+            }
+#undef RFS_LAUNCH_EIGEN_LIST
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev_lf, warm_side));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_lf, 0));
+        }
     }
     return RFS_OK;
 }
@@ -1180,7 +1226,14 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "rf_band_limit_digits")) {
         if (value < 0 || value > 300) return fail(c, RFS_ERR_ARG, "rf_band_limit_digits must be within [0, 300]");
         c->rf_band_digits = value;
-        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value); }
+        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value, c->rf_band_floor); }
+        for (auto& kv : c->calib) kv.second.stage = -1;
+        return RFS_OK;
+    }
+    if (!strcmp(name, "rf_band_floor_digits")) {
+        if (value < 0 || value > 300) return fail(c, RFS_ERR_ARG, "rf_band_floor_digits must be within [0, 300]");
+        c->rf_band_floor = value;
+        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, c->rf_band_digits, value); }
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
     }
@@ -1399,7 +1452,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
     c->sphere = sphere;
     c->has_minv = false;
     int nt = 0;
-    if (rf) { c->f = make_freq(*rf, 0); set_band_limit(c->f, c->rf_band_digits); nt = rf->nt; }
+    if (rf) { c->f = make_freq(*rf, 0); set_band_limit(c->f, c->rf_band_digits, c->rf_band_floor); nt = rf->nt; }
     c->ndata = nt + nswd;
     // wt = (sigma1/sigma2)^2 n1/n2, model_rf_swd_vs_thk.py:79
     c->wt = c->has_swd && c->has_rf ? (sigma1 / sigma2) * (sigma1 / sigma2) * nt / (double)nswd : 1.0;

@@ -1142,11 +1142,16 @@ template <bool LOVE, bool SPH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
             const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
-            double* __restrict__ krn, double* __restrict__ ugr, int el0, int el1, int early, int* __restrict__ edone)
+            double* __restrict__ krn, double* __restrict__ ugr, int el0, int el1, int early, int* __restrict__ edone,
+            const int* __restrict__ list, const int* __restrict__ count)
 {
+    // list != nullptr: only the *count chains named there (the chains a warm-started search handed back to the full
+    // search, whose roots have just been rewritten); the grid is sized for every chain
+    const int nsel = list ? *count : nchain;
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)(el1 - el0) * nchain) return;
-    int el = el0 + (int)(g / nchain), chain = (int)(g - (size_t)(el - el0) * nchain);
+    if (g >= (size_t)(el1 - el0) * nsel) return;
+    int el = el0 + (int)(g / nsel), chain = (int)(g - (size_t)(el - el0) * nsel);
+    if (list) chain = list[chain];
     int e = Q.s[0].croot_off + el;
     int seq = 0;
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;

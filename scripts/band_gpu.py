@@ -17,18 +17,21 @@ ctx = j._ensure(n)
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 xs = bench.make_models(nchain, 991206, n); x = tt(xs)
 res = {}
-for dig in (13, 0, 10, 16):
-    ctx.set_option("rf_band_limit_digits", dig)
+ctx.set_option("rf_band_floor_digits", 0)
+for dig in (13, 0, 10, 16, 113):
+    ctx.set_option("rf_band_floor_digits", 8 if dig == 113 else 0)
+    ctx.set_option("rf_band_limit_digits", dig % 100)
     res[dig] = [o.clone() for o in j.misfit_and_grad_device(x)]
     torch.cuda.synchronize()
 g0 = res[0][1]
-for dig in (13, 10, 16):
+for dig in (13, 10, 16, 113):
     g = res[dig][1]
     print(f"digits {dig}: grad rel diff vs unlimited max {((g - g0).abs().amax(dim=1) / g0.abs().amax(dim=1)).max().item():.3e}; "
           f"misfit equal {torch.equal(res[dig][0], res[0][0])}, dsyn equal {torch.equal(res[dig][2], res[0][2])}")
 bounds = bench.bounds_of(x_true)
-for dig, ser in ((13, 0), (13, 1), (0, 0)):
-    ctx.set_option("rf_band_limit_digits", dig); ctx.set_option("swd_warm_serial", ser)
+for dig, ser in ((113, 0), (113, 1), (13, 0)):
+    ctx.set_option("rf_band_floor_digits", 8 if dig > 100 else 0)
+    ctx.set_option("rf_band_limit_digits", dig % 100); ctx.set_option("swd_warm_serial", ser)
     st = j.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
     st["p"].copy_(tt(0.5 * np.random.default_rng(7).standard_normal(xs.shape))); st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
     for _ in range(40): j.flow_step(st)
