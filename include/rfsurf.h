@@ -183,7 +183,9 @@ int rfs_flow_step(rfs_ctx* ctx, int nchain, double* x, double* p, const double* 
  * for its books is parked where the next trajectory does not touch it: res_x (end model), res_val = {Ucur, Hcur, Hnew, Unew},
  * res_dsyn (synthetics at the end model; may be NULL).  have[chain] is cleared when consumed.  A chain without a deposit,
  * or one that fails (ok = 0), behaves exactly as in rfs_flow_step (done = 1, the host restarts it) -- and keeps its deposit,
- * which the host has to withdraw (have = 0).  next == NULL: rfs_flow_step.  The struct lives on the HOST, every pointer in
+ * which the host has to withdraw (have = 0).  The threshold exp(-(Hnew - Hcur)) is evaluated with the device's exp: against
+ * a host that evaluates it with its own libm the decision can differ only where u lies within one ulp of it.
+ * next == NULL: rfs_flow_step.  The struct lives on the HOST, every pointer in
  * it is a DEVICE pointer.
  * Deferred form (rem == NULL, gsave and kick given) for samplers whose next step size depends on the trajectory just
  * completed (dual averaging, pyhmc/hmcda.py:329-345): the deposit holds only u and p; a restarted chain gets a placeholder

@@ -1610,6 +1610,8 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
             Unew[chain] = U[chain];
             Hnew[chain] = hn;
             if (auto_next) {                                    // hmc.py:192-198 on the device, with the caller's draw
+                // (the device's exp against numpy's on the host path: the two can differ in the last bit, so a decision
+                // could differ only where u falls within one ulp of the threshold -- ~1e-16 per trajectory)
                 const int acc = nx_.u[chain] < exp(-(hn - Hcur[chain]));
                 acc_s = acc;
                 double* rv = nx_.res_val + (size_t)chain * 4;

@@ -11,7 +11,8 @@ import numpy as np
 def _load_rngbatch():
     """librngbatch.so (csrc_host/rngbatch.c, built by rfsurfhmc_amd.build): C loop over the chains' streams.  It
     advances the MT19937 states inside numpy in place, so it is only used when numpy's bit generator is the expected
-    one (struct of 624 key words + position; checked against rs.rand() / rs.randn() when the first ChainRNG is made)."""
+    one (struct of 624 key words + position): _rngbatch_selftest compares it with rs.rand() / rs.randn() / get_state()
+    on scratch streams before the first use and the Python path takes over on any mismatch."""
     import ctypes
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "librngbatch.so")
     if not os.path.exists(path):
@@ -27,7 +28,50 @@ def _load_rngbatch():
     L.rngbatch_rand.restype = None
     for f in (L.rngbatch_save, L.rngbatch_load):
         f.argtypes, f.restype = [vp, vp, i64, vp], None
-    return L
+    return L if _rngbatch_selftest(L) else None
+
+
+_RNGBATCH_OK = {}
+
+
+def _rngbatch_selftest(L):
+    """librngbatch.so rewrites numpy's private MT19937 state in place under an assumed layout (624 key words + position
+    behind BitGenerator.ctypes.state_address).  Before it is trusted, scratch streams are driven through it and compared
+    with numpy's own draws, odd counts (the cached second Gaussian), save / load and get_state included; any mismatch --
+    another numpy, a stale library -- and the Python path is used instead (same numbers, slower)."""
+    key = id(L)
+    if key in _RNGBATCH_OK:
+        return _RNGBATCH_OK[key]
+    ok = False
+    try:
+        seeds = (12345, 991206)
+        a = [np.random.RandomState(sd) for sd in seeds]             # driven by the library
+        b = [np.random.RandomState(sd) for sd in seeds]             # driven by numpy
+        bgs = [r._bit_generator for r in a]
+        states = np.array([g.ctypes.state_address for g in bgs], dtype=np.uint64)
+        has = np.zeros(2, dtype=np.int32); gauss = np.zeros(2)
+        idx = np.arange(2, dtype=np.int64)
+        P = lambda x: x.ctypes.data
+        ok = True
+        for n in (3, 1, 4):                                         # odd counts leave a cached deviate behind
+            out = np.empty((2, n)); L.rngbatch_randn(P(states), P(has), P(gauss), P(idx), 2, n, P(out))
+            ok = ok and np.array_equal(out, np.stack([r.randn(n) for r in b]))
+            u = np.empty(2); L.rngbatch_rand(P(states), P(idx), 2, P(u))
+            ok = ok and np.array_equal(u, np.array([r.rand() for r in b]))
+        buf = np.empty((2, 625), dtype=np.uint32); L.rngbatch_save(P(states), P(idx), 2, P(buf))
+        for k in range(2):                                          # the saved words are numpy's own state
+            st = b[k].get_state()
+            ok = ok and np.array_equal(buf[k, :624], st[1]) and int(buf[k, 624]) == int(st[2])
+            ok = ok and int(has[k]) == int(st[3]) and (not st[3] or float(gauss[k]) == float(st[4]))
+        u = np.empty(2); L.rngbatch_rand(P(states), P(idx), 2, P(u))        # advance, rewind, draw again
+        L.rngbatch_load(P(states), P(idx), 2, P(buf))
+        u2 = np.empty(2); L.rngbatch_rand(P(states), P(idx), 2, P(u2))
+        ok = ok and np.array_equal(u, u2) and np.array_equal(u, np.array([r.rand() for r in b]))
+        ok = ok and all(np.array_equal(a[k].get_state()[1], b[k].get_state()[1]) for k in range(2))
+    except Exception:
+        ok = False
+    _RNGBATCH_OK[key] = bool(ok)
+    return _RNGBATCH_OK[key]
 
 
 class ChainRNG:
@@ -417,20 +461,28 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         """Host array (at most one row per chain) -> device tensor.  On a GPU the copy goes through preallocated pinned
         staging buffers and is asynchronous: a plain .to(device) of pageable memory is stream-ordered behind the step that
         was just launched AND blocks the host until it has run, which would serialise the host bookkeeping with the GPU
-        step it is meant to overlap.  Eight buffers per shape rotate (at most four uses per iteration); a buffer's turn comes round
-        two iterations later, and every iteration waits for the event behind the previous one's copies."""
+        step it is meant to overlap.  Eight buffers per shape rotate; each carries an event recorded on the stream that
+        issued its last copy (the main stream or the side stream of the early deposits), and a buffer is only refilled once
+        that event has completed -- however many uploads an iteration makes."""
         a = np.ascontiguousarray(a)
         if dev.type != "cuda":
             return torch.from_numpy(a).to(dev)
         src = torch.from_numpy(a)
         key = (tuple(a.shape[1:]), src.dtype)
         if key not in pinned:
-            pinned[key] = [[torch.empty((nchain_all,) + key[0], dtype=src.dtype, pin_memory=True) for _ in range(8)], 0]
+            pinned[key] = [[[torch.empty((nchain_all,) + key[0], dtype=src.dtype, pin_memory=True), None] for _ in range(8)], 0]
         bufs, nxt = pinned[key]
         pinned[key][1] = (nxt + 1) % len(bufs)
-        h = bufs[nxt][: a.shape[0]]
+        slot = bufs[nxt]
+        if slot[1] is not None:
+            slot[1].synchronize()                 # the copy that last read this buffer has finished
+        h = slot[0][: a.shape[0]]
         h.copy_(src)
-        return h.to(dev, non_blocking=True)
+        out = h.to(dev, non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        return out
 
     # On a GPU with pipeline=True the results of step s are fetched on a side stream WHILE step s+1 runs: step s+1 is
     # launched first, the side stream waits for the event recorded behind step s and gathers the finished chains' rows
@@ -512,7 +564,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         if pipeline and more and not early:
             step()                               # the chains that wait for the host idle in this step (rem = -1, fresh = 0)
         if uploaded:
-            uploaded.pop().synchronize()         # long past in practice; makes the reuse of the staging buffers formal
+            uploaded.pop().synchronize()         # bounds how far the host runs ahead (the staging buffers guard themselves, t())
         if len(idx1):
             if restart is not None:
                 wd = idx1[has_dep[idx1]]
@@ -520,6 +572,8 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                     restart.withdraw(wd)
                     has_dep[wd] = False
                     st["nxt_have"].index_fill_(0, t(wd), 0)
+                    if side is not None:         # a deposit made later on the side stream must land behind this fill
+                        wev = torch.cuda.Event(); wev.record(); side.wait_event(wev)
             xkeep, rs_ = process_done(idx1, res1)
             apply(idx1, xkeep, rs_)              # stream-ordered after the step launched above
             if restart is not None:

@@ -81,6 +81,7 @@ class _Lib:
             "H5Lget_name_by_idx": (ctypes.c_ssize_t, [hid, cp, ci, ci, ctypes.c_uint64, cp, ctypes.c_size_t, hid]),
             "H5Oopen": (hid, [hid, cp, hid]), "H5Oclose": (ci, [hid]), "H5Iget_type": (ci, [hid]),
             "H5Eset_auto2": (ci, [hid, vp, vp]),
+            "H5Pcreate": (hid, [hid]), "H5Pset_fclose_degree": (ci, [hid, ci]), "H5Pclose": (ci, [hid]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -89,6 +90,28 @@ class _Lib:
             ("f8", "H5T_NATIVE_DOUBLE_g"), ("f4", "H5T_NATIVE_FLOAT_g"), ("i8", "H5T_NATIVE_INT64_g"),
             ("i4", "H5T_NATIVE_INT32_g"), ("u1", "H5T_NATIVE_UINT8_g"))}
         L.H5Eset_auto2(0, None, None)    # errors come back as return codes and are raised here, not printed
+        # file-access class id: H5P_CLS_FILE_ACCESS_ID_g (>= 1.8.15 / 1.10), H5P_CLS_FILE_ACCESS_g before
+        self.fapl_class = None
+        for sym in ("H5P_CLS_FILE_ACCESS_ID_g", "H5P_CLS_FILE_ACCESS_g"):
+            try:
+                self.fapl_class = hid.in_dll(L, sym).value
+                break
+            except ValueError:
+                continue
+
+    def strong_close_fapl(self):
+        """File-access property list with H5F_CLOSE_STRONG: closing the file closes every dataset / group handle still
+        open in it, as h5py's File.close() does -- with the library's default (weak) degree a caller that still holds a
+        Dataset would keep the file open and a later File(path, "w") would fail.  0 (default list) where unavailable."""
+        if self.fapl_class is None:
+            return 0
+        fapl = self.L.H5Pcreate(self.fapl_class)
+        if fapl < 0:
+            return 0
+        if self.L.H5Pset_fclose_degree(fapl, 3) < 0:          # H5F_CLOSE_STRONG
+            self.L.H5Pclose(fapl)
+            return 0
+        return fapl
 
 
 def library():
@@ -172,7 +195,9 @@ class Dataset:
 
     def _row(self, key):
         """(file space, mem space, shape) of row ``key`` of the first axis, or (0, 0, shape) for everything."""
-        if key is Ellipsis or (isinstance(key, slice) and key == slice(None)) or key == ():
+        if isinstance(key, (int, np.integer)):
+            pass
+        elif key is Ellipsis or (isinstance(key, slice) and key == slice(None)) or (isinstance(key, tuple) and len(key) == 0):
             return 0, 0, self.shape
         if not isinstance(key, (int, np.integer)) or not self.shape:
             raise IndexError("only [:], [...] and [i] are supported")
@@ -189,7 +214,7 @@ class Dataset:
         return fs, ms, sub
 
     def __getitem__(self, key):
-        if not (key is Ellipsis or isinstance(key, (int, np.integer)) or key == () or
+        if not (key is Ellipsis or isinstance(key, (int, np.integer)) or (isinstance(key, tuple) and len(key) == 0) or
                 (isinstance(key, slice) and key == slice(None))):
             return self[...][key]                # anything fancier: read the lot, let numpy index it
         fs, ms, shape = self._row(key)
@@ -320,14 +345,19 @@ class File(Group):
     def __init__(self, path, mode="r"):
         lib = library()
         p = os.fsencode(path)
+        fapl = lib.strong_close_fapl()
         if mode == "w":
-            fid = lib.L.H5Fcreate(p, _H5F_ACC_TRUNC, 0, 0)
+            fid = lib.L.H5Fcreate(p, _H5F_ACC_TRUNC, 0, fapl)
         elif mode == "r":
-            fid = lib.L.H5Fopen(p, _H5F_ACC_RDONLY, 0)
+            fid = lib.L.H5Fopen(p, _H5F_ACC_RDONLY, fapl)
         elif mode in ("r+", "a"):
-            fid = lib.L.H5Fopen(p, _H5F_ACC_RDWR, 0) if os.path.exists(path) else lib.L.H5Fcreate(p, _H5F_ACC_TRUNC, 0, 0)
+            fid = lib.L.H5Fopen(p, _H5F_ACC_RDWR, fapl) if os.path.exists(path) else lib.L.H5Fcreate(p, _H5F_ACC_TRUNC, 0, fapl)
         else:
+            if fapl:
+                lib.L.H5Pclose(fapl)
             raise ValueError("mode should be w, r, r+ or a")
+        if fapl:
+            lib.L.H5Pclose(fapl)
         if fid < 0:
             raise OSError(f"HDF5: cannot open {path} with mode {mode}")
         super().__init__(lib, fid, "/")

@@ -87,6 +87,8 @@ class HMCDualAveraging:
         with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
             lf = np.floor(self._lambda / np.asarray(dt, dtype=np.float64))
         lf = np.where(np.isfinite(lf), lf, float(self.L_cap))
+        # a run in which this count is not zero departed from the reference's unbounded L; it is kept with the results
+        self.n_L_clamped = getattr(self, "n_L_clamped", 0) + int(np.sum(lf > self.L_cap))
         if not self._cap_warned and np.any(lf > self.L_cap):
             self._cap_warned = True
             print(f"HMCDualAveraging: {int(np.sum(lf > self.L_cap))} chain(s) ask for more than L_cap = {self.L_cap} "

@@ -97,3 +97,24 @@ def test_header_is_plain_c(tmp_path):
     code = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rfsurf.h")).read(), flags=re.S)
     assert "#include <stdint.h>" in code and code.count("#include") == 1          # no HIP / torch headers
     assert not re.search(r"hipStream_t|hipEvent_t|at::|torch::|Tensor", code)
+
+
+def test_rngbatch_selftest_rejects_a_library_that_disagrees_with_numpy():
+    """librngbatch.so drives numpy's private MT19937 state in place; ChainRNG only uses it after a self-test against
+    numpy's own draws (rfsurfhmc_amd/pyhmc/_batched.py::_rngbatch_selftest).  A library whose numbers differ is refused."""
+    from rfsurfhmc_amd.pyhmc import _batched as B
+    real = B._load_rngbatch()
+    if real is None:
+        pytest.skip("librngbatch.so not built")
+    assert B._rngbatch_selftest(real)
+
+    class Off:                                  # same entry points, one of them off by one draw
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def rngbatch_rand(self, states, idx, n, out):
+            real.rngbatch_rand(states, idx, n, out)
+            real.rngbatch_rand(states, idx, n, out)
+    assert not B._rngbatch_selftest(Off())
+    rng = B.ChainRNG(7, 0, 2)                   # and the real one reproduces RandomState(seed + chain)
+    assert np.array_equal(rng.randn([0, 1], 3), np.stack([np.random.RandomState(7 + c).randn(3) for c in range(2)]))
