@@ -1359,11 +1359,34 @@ int rfs_swd_kernel(rfs_ctx* c, int nchain, int nlayer, const double* thk, const 
 }
 
 // ---------------------------------------------------------------- B1 / librf
+static int rf_b1_tile(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* rho, const double* vp,
+                      const double* vs, const double* qa, const double* qb, const rfs_rf_params* par, double* rf, double* kl);
+
+// Host-pointer entry: any number of chains, in tiles (one grid row per chain in the RF sweeps: <= 32768 per launch; with
+// kernels the 4 n partial spectra + traces of a tile stay within ~6 GB) -- every buffer is tile-local, the results of a
+// chain do not depend on the tiling.
 static int rf_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* rho, const double* vp,
                  const double* vs, const double* qa, const double* qb, const rfs_rf_params* par, double* rf, double* kl) {
     TRY(check_batch(c, nchain, nlayer));
     TRY(check_rf(c, par));
     if (!thk || !rho || !vp || !vs || !qa || !qb || !rf) return fail(c, RFS_ERR_ARG, "null argument");
+    const size_t n = (size_t)nlayer, nft = (size_t)rf_nextpow2(par->nt);
+    size_t tile = RF_MAX_CHAINS_PER_LAUNCH;
+    if (kl) {
+        const size_t per_chain = 4 * n * ((nft / 2 + 1) * sizeof(cplx) + nft * sizeof(double) + (size_t)par->nt * sizeof(double));
+        tile = std::min(tile, std::max<size_t>(64, (size_t)6e9 / per_chain / 64 * 64));
+    }
+    for (size_t c0 = 0; c0 < (size_t)nchain; c0 += tile) {
+        const int nc = (int)std::min(tile, (size_t)nchain - c0);
+        const size_t o = c0 * n;
+        TRY(rf_b1_tile(c, nc, nlayer, thk + o, rho + o, vp + o, vs + o, qa + o, qb + o, par, rf + c0 * (size_t)par->nt,
+                       kl ? kl + c0 * 4 * n * (size_t)par->nt : nullptr));
+    }
+    return RFS_OK;
+}
+
+static int rf_b1_tile(rfs_ctx* c, int nchain, int nlayer, const double* thk, const double* rho, const double* vp,
+                      const double* vs, const double* qa, const double* qb, const rfs_rf_params* par, double* rf, double* kl) {
     HIPCHK(c, hipSetDevice(c->device));
     const int n = nlayer;
     RfFreq f = make_freq(*par, kl ? 0 : 1);

@@ -358,3 +358,22 @@ def test_flow_step2_deferred_form_equals_the_plain_step(orc):
     for k in ("x", "p", "Hcur", "Hnew", "Unew", "Ucur", "dsyn_new", "ok", "rem"):
         assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy()), k
     assert int(b["kick"].sum()) == 0 and int((b["done"] == 1).sum()) == nc
+
+
+def test_b1_rf_entry_tiles_any_number_of_chains():
+    """librf.forward / kernel_all with more chains than one launch of the RF sweeps holds (one grid row per chain): the
+    host-pointer entry works through them in tiles; a chain's trace and kernels do not depend on the batch it came in."""
+    from rfsurfhmc_amd.model.lib import librf
+    rng = np.random.default_rng(12)
+    n, nt, nchain = 3, 16, 70000
+    vs = np.sort(2.5 + 1.5 * rng.random((nchain, n)), axis=1); vp = 1.75 * vs; rho = 2.2 + 0.2 * vs
+    thk = 2.0 + 3.0 * rng.random((nchain, n)); thk[:, -1] = 0.0
+    q = np.full((nchain, n), 9999.0)
+    args = (0.045, nt, 0.5, 1.5, 2.0, "freq", 0.001, "P")
+    rf = librf.forward(thk, rho, vp, vs, q, q, *args)
+    assert rf.shape == (nchain, nt) and np.isfinite(rf).all()
+    sub = np.r_[0:50, 32760:32790, 69950:70000]                       # chains either side of the tile boundaries
+    rf2, kl2 = librf.kernel_all(thk[sub], rho[sub], vp[sub], vs[sub], q[sub], q[sub], *args)
+    assert np.array_equal(rf[sub], rf2)
+    rf3, kl3 = librf.kernel_all(thk[:40000], rho[:40000], vp[:40000], vs[:40000], q[:40000], q[:40000], *args)
+    assert np.array_equal(rf3, rf[:40000]) and np.array_equal(kl3[sub[:80]], kl2[:80])
