@@ -54,18 +54,61 @@ def test_batch_invariance_and_permutation(full):
     assert np.array_equal(m2, mis) and np.array_equal(g2, grad) and np.array_equal(d2, dsyn)
 
 
-def test_spot_checks_against_the_oracle(full, orc):
-    joint, xs, (mis, grad, dsyn, flag), t, (drf, dswd) = full
+def test_256_chains_against_the_oracle(full, orc):
+    """256 of the 8192 bench chains (every 32nd) against the oracle's joint AND receiver-function plugins, evaluated in a
+    process pool: RF trace <= 1e-9, RF gradient <= 1e-8 (the O(n) adjoint against the oracle's explicit partials),
+    joint synthetics <= 1e-6 (float32 root rounding), joint misfit / gradient within the north-star 1e-5."""
     import bench
-    jo = orc.Joint_RF_SWD(1.0, 1.0, orc.ReceiverFunc(bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT,
-                                                     bench.WATER, "P", "freq"), orc.SurfWD(tRc=t))
-    jo.set_obsdata(drf, dswd)
-    for i in (0, 1, 63, 64, 4095, 4096, 8000, 8191):
-        m0, g0, d0, f0 = jo.misfit_and_grad(xs[i])
-        assert f0
-        assert rel(dsyn[i], d0) < 1e-6                          # synthetics: float32 root rounding only
-        assert abs(mis[i] - m0) <= 1e-5 * m0                    # the north-star tolerance
-        assert rel(grad[i], g0) < 1e-5, (i, rel(grad[i], g0))
+    from _oracle_pool import joint_batch
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    joint, xs, (mis, grad, dsyn, flag), t, (drf, dswd) = full
+    idx = np.arange(0, 8192, 32)
+    rfpar = (bench.RAY_P, bench.NT, bench.DT, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
+    ref = joint_batch(xs[idx], rfpar, t, drf, dswd)
+    rf = ReceiverFunc(*rfpar); rf.set_obsdata(drf)
+    mr, gr, dr = rf.misfit_and_grad(xs[idx])
+    worst = dict(rf=0.0, grf=0.0, d=0.0, m=0.0, g=0.0)
+    for k, i in enumerate(idx):
+        m0, g0, d0, f0, mr0, gr0, dr0 = ref[k]
+        assert f0 and flag[i]
+        worst["rf"] = max(worst["rf"], rel(dr[k], dr0)); worst["grf"] = max(worst["grf"], rel(gr[k], gr0))
+        worst["d"] = max(worst["d"], rel(dsyn[i], d0)); worst["m"] = max(worst["m"], abs(mis[i] - m0) / m0)
+        worst["g"] = max(worst["g"], rel(grad[i], g0))
+        assert abs(mr[k] - mr0) <= 1e-9 * mr0
+    print("256 chains vs oracle:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert worst["rf"] < 1e-9 and worst["grf"] < 1e-8
+    assert worst["d"] < 1e-6 and worst["m"] <= 1e-5 and worst["g"] < 1e-5, worst
+
+
+def test_wild_population_has_the_reference_flags(orc):
+    """8192 models with UNSORTED layer velocities (a third of them additionally with the velocity falling with depth over a
+    stretch, one in sixteen a fast lid over a slow half-space -- the shape the reference's search fails on): the flag of
+    every chain equals the C restatement's (bit-exact against the compiled reference).  Where the search succeeds, both
+    searches end within nevill's tolerance of the sign change (|c1 - c2| <= 1e-6 c, surfdisp96.f:627): on these crowded
+    spectra a last-bit difference of one secular value can end the device's loop on another iterate of the same bracket,
+    so the float32 roots are identical for ~98 % and within 2 x 1e-6 c (+ the two roundings) for the rest."""
+    import bench
+    from _oracle_pool import roots_batch
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    rng = np.random.default_rng(77)
+    n = bench.N_LAYER
+    xs = bench.make_models(8192, 4242, n)
+    for i in range(8192):
+        xs[i, :n] = rng.permutation(xs[i, :n])
+        if i % 3 == 0:
+            a = rng.integers(0, n - 8)
+            xs[i, a:a + 8] = np.sort(xs[i, a:a + 8])[::-1]
+        if i % 16 == 5:                                         # fast lid over a slow half-space: the search fails (ierr = 1)
+            xs[i, :n - 1] = 4.5 + 0.3 * rng.random(n - 1); xs[i, n - 1] = 1.55 + 0.1 * rng.random()
+    t = np.linspace(5, 44, bench.NPER)
+    c_dev, flag = SurfWD(tRc=t).forward(xs)
+    co, oko = roots_batch(xs, t, n)
+    assert np.array_equal(oko, flag), int((oko != flag).sum())
+    ok = oko
+    r = np.abs(c_dev[ok] - co[ok]) / co[ok]
+    print(f"wild population: {int((~ok).sum())} failing models of 8192, {int((c_dev[ok] != co[ok]).sum())} of {r.size} roots not identical, worst {r.max():.2e}")
+    assert r.max() <= 2.1e-6 and (c_dev[ok] != co[ok]).mean() < 0.03
+    assert int((~ok).sum()) >= 100                            # the population does contain models the search fails on
 
 
 def test_directional_derivatives(full):
