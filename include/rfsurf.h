@@ -31,7 +31,7 @@ typedef enum {
     RFS_ERR_ARG = -1,         /* bad argument (also: unsupported enum value) */
     RFS_ERR_HIP = -2,         /* HIP runtime / rocFFT failure */
     RFS_ERR_STATE = -3,       /* call out of order (e.g. joint eval before joint setup) */
-    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (higher modes; time-domain RF longer than 4096 samples) */
+    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (time-domain RF longer than 4096 samples) */
 } rfs_status;
 
 /* wavetype codes of libsurf (src/SWD/main.cpp:17-24): strings "Rc","Rg","Lc","Lg" */
@@ -72,7 +72,10 @@ int rfs_synchronize(rfs_ctx* ctx);
  * (src/SWD/main.cpp:14-59; _surfdisp surfdisp.cpp:62-109; _LoveGroup :119-141; _RayleighGroup :151-173).
  * All four wavetypes; sphere != 0 applies the earth-flattening transformation (surfdisp96.f:495-564 for the
  * root search, bldsph / sprayl / splove for group velocities) and returns spherical velocities
- * (_flat2sphere surfdisp.cpp:16-49).  mode must be 0 (fundamental).
+ * (_flat2sphere surfdisp.cpp:16-49).  mode: 0 fundamental, k > 0 the k-th higher mode -- the reference's mode loop
+ * (surfdisp96.f:227-316: mode k searches above mode k-1 period by period; a mode that does not exist from some period on
+ * gives c = 0 there WITHOUT clearing the flag, :337-362; only a failing fundamental does) runs inside the search's state
+ * machine, bit for bit.
  * Model arrays [nchain][nlayer] are rounded to float32 first, as the binding does (main.cpp:9).
  * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1); the c values of a failed chain are
  * unspecified (the reference returns whatever roots it found before giving up, surfdisp.cpp:93-100).
@@ -117,7 +120,7 @@ typedef struct {
     int32_t ntRc, ntRg, ntLc, ntLg;
     const double *tRc, *tRg, *tLc, *tLg;
     int32_t sphere;     /* 0 flat earth, != 0 earth flattening */
-    int32_t mode;       /* 0 = fundamental (only value supported) */
+    int32_t mode;       /* 0 = fundamental, k > 0 = k-th higher mode (SurfWD(mode = ...), model_surf.py:5-7) */
 } rfs_swd_params;
 int rfs_joint_setup2(rfs_ctx* ctx, int nlayer, const rfs_rf_params* rf, const rfs_swd_params* swd,
                      double sigma1, double sigma2, const double* dobs);

@@ -356,6 +356,37 @@ def gen_swd_wide(ref_surf, m_surf, M):
     print("swd_love_sphere_reference.npz:", len(g), "arrays")
 
 
+MODE_MODELS = ("yaml7", "cfg1_10", "grad30", "lvz30_0", "lvz30_1", "prior30_0", "wild30_0", "inverted_20")
+
+
+def gen_swd_modes(ref_surf, M):
+    """Higher modes (libsurf's `mode` argument, surfdisp96.f:227-316) from the compiled reference: phase velocities of
+    modes 1 and 2 for Rc and Lc, flat and spherical, with the kernels of the periods at which the mode exists (a mode that
+    does not exist from some period on gives c = 0 there and the reference's eigenfunction routines then divide by it:
+    those rows are not stored)."""
+    g = {}
+    for name in MODE_MODELS:
+        thk, vs, t = M[name]
+        vp, rho = emp(vs)
+        g[f"{name}/thk"], g[f"{name}/vs"], g[f"{name}/t"] = thk, vs, t
+        for wt in ("Rc", "Lc"):
+            for sph in (False, True):
+                for mode in (1, 2):
+                    key = f"{name}/{wt}/{int(sph)}/m{mode}"
+                    c, flag = ref_surf.forward(thk, vp, vs, rho, t, wt, mode, sph)
+                    g[f"{key}/fwd_c"], g[f"{key}/fwd_flag"] = c, np.array(flag)
+                    c, ka, kb, kr, kh, flag = ref_surf.adjoint_kernel(thk, vp, vs, rho, t, wt, mode, sph)
+                    g[f"{key}/c"], g[f"{key}/flag"] = c, np.array(flag)
+                    if flag:
+                        ok = np.nonzero(c != 0.0)[0]
+                        g[f"{key}/rows"] = ok
+                        if wt[0] == "R":
+                            g[f"{key}/dcda"] = ka[ok]
+                        g[f"{key}/dcdb"], g[f"{key}/dcdr"], g[f"{key}/dcdh"] = kb[ok], kr[ok], kh[ok]
+    np.savez_compressed(os.path.join(OUT, "swd_modes_reference.npz"), **g)
+    print("swd_modes_reference.npz:", len(g), "arrays")
+
+
 def gen_rf_full(M):
     """Only where oracle/_ref holds the reference's COMPLETE librf (FFTW3 present, oracle/Makefile): the same cases
     as gen_rf through the reference's own public entry points, frequency AND time method -- no numpy tail, so these
@@ -387,7 +418,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
     M = models()
+    if "--modes-only" in sys.argv:           # (added in round 3: leaves the other fixture files as they are)
+        return gen_swd_modes(ref_surf, M)
     gen_swd(ref_surf, M)
+    gen_swd_modes(ref_surf, M)
     gen_swd_wide(ref_surf, m_surf, M)
     gen_rf(ref_rf, M)
     gen_rf_full(M)

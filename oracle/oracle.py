@@ -89,13 +89,16 @@ class _LibSurf:
         return f32, t
 
     def forward(self, thk, vp, vs, rho, period, wavetype, mode=0, sphere=False):
-        if wavetype not in _WAVETYPES or mode != 0:
-            raise NotImplementedError("oracle covers Rc/Rg/Lc/Lg, fundamental mode")
+        if wavetype not in _WAVETYPES or mode < 0:
+            raise NotImplementedError("oracle covers Rc/Rg/Lc/Lg")
         (h, a, b, r), t = self._prep(thk, vp, vs, rho, period)
         n, nt = len(h), len(t)
         cg = np.zeros(nt)
         L = lib()
-        if wavetype == "Rc" and not sphere:
+        if mode > 0:           # higher modes: the mode loop of surfdisp96.f:227-316 (mode + 1 modes, the last one's roots remain)
+            ierr = L.orc_swd_forward_m(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt,
+                                       _WAVETYPES[wavetype], int(bool(sphere)), int(mode))
+        elif wavetype == "Rc" and not sphere:
             nsec = ctypes.c_long(0)
             ierr = L.orc_surfdisp_rc(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(cg), nt,
                                      ctypes.byref(nsec))
@@ -106,13 +109,17 @@ class _LibSurf:
         return cg, ierr != 1
 
     def adjoint_kernel(self, thk, vp, vs, rho, period, wavetype, mode=0, sphere=False):
-        if wavetype not in _WAVETYPES or mode != 0:
-            raise NotImplementedError("oracle covers Rc/Rg/Lc/Lg, fundamental mode")
+        if wavetype not in _WAVETYPES or mode < 0:
+            raise NotImplementedError("oracle covers Rc/Rg/Lc/Lg")
         (h, a, b, r), t = self._prep(thk, vp, vs, rho, period)
         n, nt = len(h), len(t)
         c = np.zeros(nt)
         ka, kb, kr, kh = (np.zeros((nt, n)) for _ in range(4))
-        if wavetype in ("Rc", "Rg") and not sphere:
+        if mode > 0:
+            ierr = lib().orc_swd_kernel_m(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(c), nt,
+                                          _d(ka), _d(kb), _d(kr), _d(kh), _WAVETYPES[wavetype],
+                                          int(bool(sphere)), int(mode))
+        elif wavetype in ("Rc", "Rg") and not sphere:
             nsec = ctypes.c_long(0)
             ierr = lib().orc_surf_kernel(_f(h), _f(a), _f(b), _f(r), n, _d(t), _d(c), nt,
                                          _d(ka), _d(kb), _d(kr), _d(kh), _WAVETYPES[wavetype],

@@ -390,7 +390,7 @@ static void sd_sphere(int ifunc, int iflag, float *d, float *a, float *b, float 
 
 static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
                          const float *rhom, int nlayer, int kmax, const double *t,
-                         double *cg, long *nsec, int iwave, int iflsph)
+                         double *cg, long *nsec, int iwave, int iflsph, int mode)
 {
     float *wk = (float *)malloc(sizeof(float) * 7 * (size_t)nlayer);
     float *wd = wk, *wa = wk + nlayer, *wb = wk + 2 * nlayer, *wr = wk + 3 * nlayer;
@@ -409,7 +409,7 @@ static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
     }
     if (iflsph == 1) sd_sphere(iwave, 1, wd, wa, wb, wr, rtp, dtp, btp, nlayer, &dhalf);
     float ddc = 0.005f, sone = 1.5f;
-    double one = 1.0e-2; (void)one;
+    double one = 1.0e-2;                 /* `one` of surfdisp96.f (:190 one=1.0d-2) */
     double onea = (double)sone;
     float cc1;
     if (jsol == 0) cc1 = betmn;
@@ -421,21 +421,32 @@ static int sd_surfdisp96(const float *thkm, const float *vpm, const float *vsm,
     double c1 = cc, cm = cc, clow;
     double *c = (double *)calloc((size_t)kmax, sizeof(double));
     double del1st = 0.0;
-    int k, failed = 0;
-    for (k = 0; k < kmax; k++) {
-        double t1 = t[k];
-        int ifirst;
-        if (k == 0) { c1 = cc; clow = cc; ifirst = 1; }
-        else { ifirst = 0; c1 = c[k - 1] - onea * dc; clow = cm; }
-        int iret = sd_getsol(t1, &c1, clow, dc, cm, betmx, ifirst, &M, &del1st);
-        if (iret == -1) { failed = 1; break; }
-        c[k] = c1;
-        float cc0 = (float)c[k];
-        cg[k] = (double)cc0;
-    }
-    if (failed) {
-        ierr = 1;
-        for (int i = k; i < kmax; i++) cg[i] = 0.0;
+    /* :227-316, 337-362  the mode loop `do 1800 iq=1,mode`: mode iq searches above mode iq-1, whose roots c(k) it finds
+     * in the same array it overwrites; cg(k) is overwritten mode after mode, so the LAST mode's values remain.  A mode
+     * that is not found from period k on zeroes cg(k:) and caps every later mode at that period (ift); only the
+     * fundamental sets ierr. */
+    int ift = 1 << 30;
+    for (int iq = 1; iq <= mode; iq++) {
+        int k, failed = 0;
+        for (k = 0; k < kmax; k++) {
+            if (k >= ift) { failed = 1; break; }
+            double t1 = t[k];
+            int ifirst;
+            if (k == 0 && iq == 1) { c1 = cc; clow = cc; ifirst = 1; }
+            else if (k == 0 && iq > 1) { c1 = c[0] + one * dc; clow = c1; ifirst = 1; }
+            else if (k > 0 && iq > 1) { ifirst = 0; clow = c[k] + one * dc; c1 = c[k - 1]; if (c1 < clow) c1 = clow; }
+            else { ifirst = 0; c1 = c[k - 1] - onea * dc; clow = cm; }
+            int iret = sd_getsol(t1, &c1, clow, dc, cm, betmx, ifirst, &M, &del1st);
+            if (iret == -1) { failed = 1; break; }
+            c[k] = c1;
+            float cc0 = (float)c[k];
+            cg[k] = (double)cc0;
+        }
+        if (failed) {
+            if (iq == 1) ierr = 1;
+            ift = k;
+            for (int i = k; i < kmax; i++) cg[i] = 0.0;
+        }
     }
     free(c);
     free(wk);
@@ -453,16 +464,19 @@ static double sd_flat2sphere(double t, double c, char wave, char kind)
     return (kind == 'c') ? c / tm : c * tm;
 }
 
+/* number of modes the search runs through (`mode + 1` of surfdisp.cpp:91: 1 = fundamental only); set by the *_m entries */
+static int g_nmode = 1;
+
 /* surfdisp.cpp:62-109  _surfdisp for phase velocities: iwave 1 Love / 2 Rayleigh */
 static int sd_surfdisp(const float *thk, const float *vp, const float *vs, const float *rho,
                        int nlayer, const double *t, double *cg, int kmax, int iwave, int sphere,
                        int keep_flat, long *nsec)
 {
-    int ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, kmax, t, cg, nsec, iwave, sphere);
+    int ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, kmax, t, cg, nsec, iwave, sphere, g_nmode);
     if (ierr != 0) {
         for (int i = 0; i < kmax; i++) {
             if (cg[i] == 0.0 || isnan(cg[i])) {
-                ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, 1, &t[i], &cg[i], nsec, iwave, sphere);
+                ierr = sd_surfdisp96(thk, vp, vs, rho, nlayer, 1, &t[i], &cg[i], nsec, iwave, sphere, g_nmode);
                 if (ierr != 0) return ierr;
             }
         }
@@ -1399,6 +1413,25 @@ int orc_swd_kernel(const float *thk, const float *vp, const float *vs, const flo
         }
     }
     free(buf);
+    return ierr;
+}
+
+/* the same with libsurf's `mode` argument (0 fundamental, 1 first higher mode, ...: src/SWD/main.cpp:16,63) */
+int orc_swd_forward_m(const float *thk, const float *vp, const float *vs, const float *rho, int nlayer,
+                      const double *t, double *cg, int kmax, int wavetype, int sphere, int mode)
+{
+    g_nmode = mode + 1;
+    int ierr = orc_swd_forward(thk, vp, vs, rho, nlayer, t, cg, kmax, wavetype, sphere);
+    g_nmode = 1;
+    return ierr;
+}
+int orc_swd_kernel_m(const float *thk, const float *vp, const float *vs, const float *rho, int nlayer,
+                     const double *t, double *c, int nt, double *dcda, double *dcdb, double *dcdr,
+                     double *dcdh, int wavetype, int sphere, int mode)
+{
+    g_nmode = mode + 1;
+    int ierr = orc_swd_kernel(thk, vp, vs, rho, nlayer, t, c, nt, dcda, dcdb, dcdr, dcdh, wavetype, sphere);
+    g_nmode = 1;
     return ierr;
 }
 

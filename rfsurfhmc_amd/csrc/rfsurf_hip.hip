@@ -88,7 +88,8 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw;
+    int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     int warm_nitems = 0;       // (sequence, period) items of the joint configuration's evaluation
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -706,14 +707,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         }
         if (!rdone && Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, sf, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                                                                c->sflag.as<int>(), 0, list, count, est)))
-            hipLaunchKernelGGL(k_swd_roots<false>, dim3(gl * Q.nseq), dim3(64), 0, sf, nchain, n, Q, mdlR, c->croot.as<double>(),
-                               c->sflag.as<int>(), list, count);
+            hipLaunchKernelGGL((k_swd_roots<false, false>), dim3(gl * Q.nseq), dim3(64), 0, sf, nchain, n, Q, mdlR, c->croot.as<double>(),
+                               c->sflag.as<int>(), list, count, (double*)nullptr, 1);
         const bool ldone = P.QL.nseq > 0 && est * P.QL.nseq > SWD_LAT_MAX_ITEMS &&
                            !launch_love_coop(c, sf, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL, list, count, est);
         if (!ldone && P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, sf, nchain, n, P.QL, c->mdlL.as<float>(),
                                                                                    c->mdlcL.as<double>(), sflagL, 0, list, count, est)))
-            hipLaunchKernelGGL(k_swd_roots<true>, dim3(gl * P.QL.nseq), dim3(64), 0, sf, nchain, n, P.QL, c->mdlL.as<float>(),
-                               c->croot.as<double>(), sflagL, list, count);
+            hipLaunchKernelGGL((k_swd_roots<true, false>), dim3(gl * P.QL.nseq), dim3(64), 0, sf, nchain, n, P.QL, c->mdlL.as<float>(),
+                               c->croot.as<double>(), sflagL, list, count, (double*)nullptr, 1);
         HIPCHK(c, hipGetLastError());
         if (c->h_wcount) {
             if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
@@ -724,6 +725,23 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
     // the Rayleigh one (a fifth active stream inside the partitioned step would share a hardware queue)
     // -- inside it the Love search goes to the RF half's stream, ahead of the RF sweeps: the Rayleigh search keeps its half
+    if (roots && c->swd_mode_cur > 0) {
+        // higher modes (libsurf's `mode` argument): the mode loop runs inside the lane-per-item kernel's state machine
+        // (latency form only: B1 calls and plugins with SurfWD(mode = ...); not a bench configuration)
+        KTimer t(c, RFS_K_SWD_ROOTS, s);
+        ENSURE(c, c->craw, (size_t)P.nitems * nchain * sizeof(double));
+        const int nmode = c->swd_mode_cur + 1;
+        if (Q.nseq > 0)
+            hipLaunchKernelGGL((k_swd_roots<false, true>), dim3((Q.nseq * nchain + 63) / 64), dim3(64), 0, s, nchain, n, Q, mdlR,
+                               c->croot.as<double>(), c->sflag.as<int>(), (const int*)nullptr, (const int*)nullptr,
+                               c->craw.as<double>(), nmode);
+        if (P.QL.nseq > 0)
+            hipLaunchKernelGGL((k_swd_roots<true, true>), dim3((P.QL.nseq * nchain + 63) / 64), dim3(64), 0, s, nchain, n, P.QL,
+                               c->mdlL.as<float>(), c->croot.as<double>(), sflagL, (const int*)nullptr, (const int*)nullptr,
+                               c->craw.as<double>(), nmode);
+        HIPCHK(c, hipGetLastError());
+        roots = false;
+    }
     const bool love_aside = roots && P.QL.nseq > 0 && Q.nseq > 0 && c->stream_l && s != c->stream3;
     if (roots && P.QL.nseq > 0) {       // Love: 2-vector recurrence, same lanes-per-item search as the small Rayleigh batches
         hipStream_t sl = !love_aside ? s : (s == c->stream2m ? c->stream3 : c->stream_l);
@@ -734,8 +752,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             if (launch_love_coop(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL) &&
                 (n < 3 || launch_roots_split<SwdLoveFamily>(c, sl, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(),
                                                             sflagL, c->swd_lanes)))
-                hipLaunchKernelGGL(k_swd_roots<true>, dim3((nitem + 63) / 64), dim3(64), 0, sl, nchain, n, P.QL,
-                                   c->mdlL.as<float>(), c->croot.as<double>(), sflagL, (const int*)nullptr, (const int*)nullptr);
+                hipLaunchKernelGGL((k_swd_roots<true, false>), dim3((nitem + 63) / 64), dim3(64), 0, sl, nchain, n, P.QL,
+                                   c->mdlL.as<float>(), c->croot.as<double>(), sflagL, (const int*)nullptr, (const int*)nullptr,
+                                   (double*)nullptr, 1);
             HIPCHK(c, hipGetLastError());
         }
         if (love_aside) HIPCHK(c, hipEventRecord(c->ev_lj, sl));
@@ -762,8 +781,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
 #undef RFS_LAUNCH_COOP
         } else if (n < 3 || launch_roots_split<SwdRayFamily>(c, s, nchain, n, Q, mdlR, c->mdlc.as<double>(), c->sflag.as<int>(),
                                                              c->swd_lanes)) {
-            hipLaunchKernelGGL(k_swd_roots<false>, dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
-                               mdlR, c->croot.as<double>(), c->sflag.as<int>(), (const int*)nullptr, (const int*)nullptr);
+            hipLaunchKernelGGL((k_swd_roots<false, false>), dim3((nitem + 63) / 64), dim3(64), 0, s, nchain, n, Q,
+                               mdlR, c->croot.as<double>(), c->sflag.as<int>(), (const int*)nullptr, (const int*)nullptr,
+                               (double*)nullptr, 1);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -845,7 +865,10 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     const int n = c->n;
     HIPCHK(c, hipSetDevice(c->device));
     // track: keep the model / roots / kernels of this evaluation for the next one; warm: use those of the previous one
-    const bool track = c->has_swd && (c->warm_opt == 2 || (c->warm_opt == 1 && traj));
+    // (higher modes: always the reference-semantics search -- the warm start's branch test is the fundamental's)
+    const bool track = c->has_swd && c->swd_mode == 0 && (c->warm_opt == 2 || (c->warm_opt == 1 && traj));
+    struct ModeGuard { rfs_ctx* c; ~ModeGuard() { c->swd_mode_cur = 0; } } mode_guard{c};
+    c->swd_mode_cur = c->swd_mode;
     const bool warm = track && c->warm_primed && c->warm_nchain == nchain && traj != 2;
     if (track) {
         const size_t nn = (size_t)n * nchain;
@@ -900,7 +923,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     }
     const bool tiled = rf_tile < nchain;
     // (a warm-started search is throughput work like the RF sweeps: no partition, everything shares the chip)
-    const bool part_possible = !warm && !rf_time && !tiled && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m &&
+    const bool part_possible = !warm && c->swd_mode == 0 && !rf_time && !tiled && !c->own_stream && c->has_rf && c->has_swd && c->cu_split && c->stream2m &&
                                c->stream3 && cp.ok && cp.blocks <= (c->ncu / 2) * cp.per_cu;
     // Early eigenfunction pass: with the partition on, the RF half of the chip finishes before the search does.  The
     // eigenfunction kernels of the first periods -- whose roots have long been final by then -- fill that gap on the RF
@@ -1137,7 +1160,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     drop_plans(c);
@@ -1288,7 +1311,7 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
                   bool kernels, double* cout, double* dcda, double* dcdb, double* dcdr, double* dcdh, int32_t* flag) {
     TRY(check_batch(c, nchain, nlayer));
     if (wavetype < RFS_WAVE_RC || wavetype > RFS_WAVE_LG) return fail(c, RFS_ERR_ARG, "wavetype should be one of [Rc,Rg,Lc,Lg]");
-    if (mode != 0) return fail(c, RFS_ERR_UNSUPPORTED, "higher modes are out of scope");
+    if (mode < 0 || mode > 64) return fail(c, RFS_ERR_ARG, "mode must be within [0, 64]");
     sphere = sphere ? 1 : 0;
     if (nper < 1 || !period || !thk || !vp || !vs || !rho || !cout || !flag) return fail(c, RFS_ERR_ARG, "null/empty argument");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1312,7 +1335,11 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
     // forward: roots at T only (+ U from sregn96 / slegn96 for the group types); kernel: three passes for groups
     SwdPlan P = make_plan(ntw, tw, kernels, sphere, kernels ? 0 : 1, !kernels, c->sphR.as<double>(), c->sphL.as<double>());
     TRY(launch_family_prep(c, c->stream, nchain, n, P, sphere));
-    TRY(launch_swd(c, c->stream, nchain, n, P, kernels || rg));
+    c->warm_primed = false;
+    c->swd_mode_cur = mode;
+    const int rc_swd = launch_swd(c, c->stream, nchain, n, P, kernels || rg);
+    c->swd_mode_cur = 0;
+    TRY(rc_swd);
     size_t cb = (size_t)nchain * nper * sizeof(double), kb = cb * n;
     ENSURE(c, c->b1e, cb);
     double* dk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1459,7 +1486,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
     if (swd) {
         ntw[0] = swd->ntRc; ntw[1] = swd->ntRg; ntw[2] = swd->ntLc; ntw[3] = swd->ntLg;
         tw[0] = swd->tRc; tw[1] = swd->tRg; tw[2] = swd->tLc; tw[3] = swd->tLg;
-        if (swd->mode != 0) return fail(c, RFS_ERR_UNSUPPORTED, "higher modes are out of scope");
+        if (swd->mode < 0 || swd->mode > 64) return fail(c, RFS_ERR_ARG, "mode must be within [0, 64]");
         sphere = swd->sphere ? 1 : 0;
     }
     int nswd = 0;
@@ -1471,6 +1498,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
     if (rf) TRY(check_rf(c, rf));
     HIPCHK(c, hipSetDevice(c->device));
     c->n = nlayer; c->has_rf = rf != nullptr; c->has_swd = nswd > 0;
+    c->swd_mode = swd ? swd->mode : 0;
     c->mode = (c->has_rf && c->has_swd) ? 0 : (c->has_rf ? 1 : 2);
     c->sphere = sphere;
     c->has_minv = false;
@@ -1576,7 +1604,10 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
         SwdPlan P = make_plan(ntw, tw, false, c->sphere, 1, true, c->sphR.as<double>(), c->sphL.as<double>(),
                               c->share_rc_rg && (c->rg_alias || (quirk && c->ntw[0] > 0)));
         TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
-        TRY(launch_swd(c, c->stream, nchain, n, P, ntw[1] + ntw[3] > 0));
+        c->swd_mode_cur = c->swd_mode;
+        const int rc_swd = launch_swd(c, c->stream, nchain, n, P, ntw[1] + ntw[3] > 0);
+        c->swd_mode_cur = 0;
+        TRY(rc_swd);
         ENSURE(c, c->ugr, 8);
         hipLaunchKernelGGL(k_swd_forward_out, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, nt, P.R,
                            c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(), P.nseq,

@@ -517,10 +517,19 @@ __global__ void k_rf_scale_kl(size_t ntrace, RfFreq f, const double* __restrict_
 struct SwdSeq { const double* t; int nper; double scale; int croot_off; int alt_vp; };   // croot_off in periods
 struct SwdSeqs { SwdSeq s[4]; int nseq; int nper_total; };   // one wave family (Rayleigh or Love) per launch
 
-template <bool LOVE>
+// MODES: libsurf's `mode` argument > 0 -- the mode loop and its retry inside the state machine (RootSearchT<.., true>);
+// craw = scratch of the unrounded roots c(k) of the mode before, laid out like croot; nmode = mode + 1.
+struct SwdRootOut {             // outputs of one lane's search, readable (the retry pass looks for zeroed periods)
+    double* cr; size_t stride; bool live;
+    __device__ __forceinline__ void operator()(int k, double v) const { if (live) cr[(size_t)k * stride] = v; }
+    __device__ __forceinline__ double get(int k) const { return live ? cr[(size_t)k * stride] : 1.0; }
+};
+
+template <bool LOVE, bool MODES>
 __global__ void __launch_bounds__(64)
 k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double* __restrict__ croot,
-            int* __restrict__ sflag, const int* __restrict__ list, const int* __restrict__ count)
+            int* __restrict__ sflag, const int* __restrict__ list, const int* __restrict__ count,
+            double* __restrict__ craw, int nmode)
 {
     // list != nullptr: only the *count chains named there (the chains the warm start handed back, k_swd_warm)
     const int nsel = list ? *count : nchain;
@@ -535,9 +544,9 @@ k_swd_roots(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, double*
     SwdModel M{mdl + chain, mdl + (LOVE && sq.alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
     const double* tp = sq.t; const double sc = sq.scale;
     auto T = [&](int k) { return tp[k] * sc; };
-    double* cr = croot + (size_t)sq.croot_off * nchain + chain;
-    auto out = [&](int k, double v) { if (live) cr[(size_t)k * nchain] = v; };
-    RootSearch rs;
+    const SwdRootOut out{croot + (size_t)sq.croot_off * nchain + chain, (size_t)nchain, live};
+    RootSearchT<NevTabReg, MODES> rs;
+    if (MODES) rs.set_modes(nmode, craw + (size_t)sq.croot_off * nchain + chain, (long)nchain);
     rs.begin(M, T, sq.nper);
     if (!live) rs.done = 1;
     while (__any(!rs.done)) {

@@ -454,7 +454,14 @@ struct NevTabMem {             // x(i) at base[i*stride], y(i) at base[(12+i)*st
 template <class F> RFS_HD auto rs_omega_of(const F& T, int k, int) -> decltype(T.omega(k)) { return T.omega(k); }
 template <class F> RFS_HD double rs_omega_of(const F& T, int k, long) { return (2.0 * 3.141592653589793) / T(k); }
 
-template <class Tab = NevTabReg>
+// MODES = true: the mode loop of surfdisp96.f:227-316 (`do 1800 iq=1,mode`) and its per-period retry
+// (surfdisp.cpp:93-100) around the same getsol / nevill machine.  Mode iq searches above mode iq-1, whose unrounded
+// roots c(k) it reads from -- and overwrites in -- a scratch (cmb); the float32 outputs are overwritten mode after mode,
+// so the LAST mode's values remain; a mode not found from period k on zeroes the outputs from there and caps every
+// later mode at that period (ift); only the fundamental's failure sets ierr and triggers the retry, which redoes every
+// period whose output is zero / NaN on its own (all modes, each starting from the start value).  The Out functor must
+// then also provide get(k).  MODES = false compiles the fundamental-only code unchanged.
+template <class Tab = NevTabReg, bool MODES = false>
 struct RootSearchT {
     enum { PH_START, PH_SCAN, PH_HALF0, PH_HALF_OUT, PH_HALF_B, PH_NEV };
     static constexpr double TWOPI = 2.0 * 3.141592653589793;
@@ -469,14 +476,71 @@ struct RootSearchT {
     int nev, m, nctrl;
     Tab tab;
     long nsec;
+    // MODES only: mode index, number of modes, cap period of the later modes, fundamental failed; scratch of unrounded c(k)
+    int iq = 0, nmode = 1, ift = 1 << 30, fund_failed = 0;
+    double* cmb = nullptr; long cms = 0;
+    RFS_HD double kept(int kk) const { return cmb[(long)kk * cms]; }
 
     template <class PeriodFn>
     RFS_HD void start_period(const PeriodFn& T) {
-        if (retry || k == 0) { c1 = cc; clow = cc; ifirst = 1; }       // surfdisp96.f:257-260
+        if (MODES && iq > 0) {
+            const double one = 1.0e-2;                                 // `one` of surfdisp96.f:141
+            if (retry || k == 0) { c1 = kept(k) + one * dc; clow = c1; ifirst = 1; }          // :261-264
+            else { ifirst = 0; clow = kept(k) + one * dc; c1 = cprev; if (c1 < clow) c1 = clow; }   // :265-271
+        }
+        else if (retry || k == 0) { c1 = cc; clow = cc; ifirst = 1; }  // surfdisp96.f:257-260
         else { ifirst = 0; c1 = cprev - 1.5 * dc; clow = cm; }         // :272-275 (onea = 1.5)
         omega = rs_omega_of(T, k, 0);
         creq = c1; phase = PH_START;
     }
+
+    // MODES: a period's search is over -- found (failed = false; k and iq not advanced yet) or not.  Sets up the next
+    // search (next period, next mode, next retry period) or ends the call.  surfdisp96.f:236, 317-362 (labels 1700 /
+    // 1750), surfdisp.cpp:93-100.
+    template <class PeriodFn, class OutFn>
+    RFS_HD void period_over(const PeriodFn& T, const OutFn& out, bool failed) {
+        for (;;) {
+            int go = 0;                                  // 1: next mode, 2: next retry period
+            if (failed) {
+                if (!retry) {
+                    if (iq == 0) fund_failed = 1;        // only the fundamental sets ierr
+                    ift = k;
+                    for (int i = k; i < kmax; i++) out(i, 0.0);
+                    go = 1;
+                } else {
+                    if (iq == 0) { flag = 0; done = 1; return; }       // the single-period call returns ierr = 1
+                    out(k, 0.0);                         // (every later mode of that call is capped at this period)
+                    go = 2;
+                }
+            } else if (retry) {
+                iq++;
+                if (iq < nmode) { start_period(T); return; }
+                go = 2;
+            } else {
+                k++;
+                if (k >= kmax) go = 1;
+                else if (k >= ift) { failed = true; continue; }        // :236 `if(k.ge.ift) go to 1700`
+                else { start_period(T); return; }
+            }
+            if (go == 1) {
+                iq++;
+                if (iq < nmode) {
+                    k = 0;
+                    if (k >= ift) { failed = true; continue; }
+                    start_period(T); return;
+                }
+                if (!fund_failed) { done = 1; return; }
+                retry = 1; k = -1;
+            }
+            // retry pass: the next period whose output is zero / NaN, all modes again, the period on its own
+            for (k = k + 1; k < kmax; k++) { const double v = out.get(k); if (v == 0.0 || v != v) break; }
+            if (k >= kmax) { done = 1; return; }
+            iq = 0; ift = 1 << 30;
+            start_period(T); return;
+        }
+    }
+
+    RFS_HD void set_modes(int nmode_, double* cmb_, long cms_) { nmode = nmode_; cmb = cmb_; cms = cms_; }
 
     template <class PeriodFn>
     RFS_HD void begin(const SwdModel& M, const PeriodFn& T, int kmax_) {
@@ -485,6 +549,7 @@ struct RootSearchT {
         float bmx; float cc1 = swd_start_value(M, bmx);
         cc = (double)cc1; dc = (double)0.005f; cm = cc; betmx = bmx;
         kmax = kmax_; k = 0; retry = 0; done = 0; flag = 1; nsec = 0;
+        iq = 0; ift = 1 << 30; fund_failed = 0;
         del1st = 0.0; cprev = 0.0; m = 1; nev = 1; nctrl = 1;
         if (!Tab::kDynamic) for (int i = 0; i < 12; i++) { tab.sx(i, 0.0); tab.sy(i, 0.0); }
         if (kmax <= 0) { done = 1; return; }
@@ -534,6 +599,7 @@ struct RootSearchT {
         const bool sfail = cont && (c1 < cm || c1 >= ((double)betmx + dc));
         const bool st_scan = pS || (cont && !sfail);
         bool st_fail = sfail, st_half = chg, st_newperiod = false;
+        bool return_after = false;                                          // (MODES: the next request is already set up)
         int half_phase = PH_HALF0;
         // entries of nevill's loop (:590-594 and the three ways back to its top)
         del3 = (pH0 || pHO || pHB || pN) ? del : del3;
@@ -605,17 +671,24 @@ struct RootSearchT {
             else {
                 out(k, (double)(float)c1);
                 cprev = c1;
-                k = k + 1;
-                if (k >= kmax) done = 1; else st_newperiod = true;
+                if constexpr (MODES) {
+                    cmb[(long)k * cms] = c1;             // c(k) = c1 (:277), unrounded: the next mode's floor
+                    period_over(T, out, false); return_after = true;
+                } else {
+                    k = k + 1;
+                    if (k >= kmax) done = 1; else st_newperiod = true;
+                }
             }
         }
         if (st_fail) {
-            if (!retry) {                                // surfdisp96.f:317-362 + surfdisp.cpp:93-100
+            if constexpr (MODES) { period_over(T, out, true); return_after = true; }
+            else if (!retry) {                           // surfdisp96.f:317-362 + surfdisp.cpp:93-100
                 retry = 1;
                 for (int i = k; i < kmax; i++) out(i, 0.0);
                 st_newperiod = true;
             } else { flag = 0; done = 1; }
         }
+        if (MODES && return_after) return;
         {   // next request of the lanes that stay inside the period: a bisection point or the next scan point
             // (getsol loop 1000, :457-469); predicated, the two cases exclude each other
             const double c2n = (idir > 0) ? c1 + dc : c1 - dc;
@@ -631,6 +704,7 @@ struct RootSearchT {
     }
 };
 using RootSearch = RootSearchT<NevTabReg>;
+using RootSearchModes = RootSearchT<NevTabReg, true>;
 
 // ---------------------------------------------------------------------------
 // Warm-started root refinement for the leapfrog loop (no counterpart in the reference, which searches every model

@@ -21,6 +21,10 @@ class FusedPlugin:
         """(tRc, tRg, tLc, tLg, sphere): the periods each SWD block is evaluated at in misfit_and_grad."""
         return None, None, None, None, False
 
+    def _swd_mode(self):
+        """libsurf's ``mode`` (0 = fundamental, k > 0 = k-th higher mode; model_surf.py:5-7)."""
+        return 0
+
     def _sigmas(self):
         return 1.0, 1.0
 
@@ -38,7 +42,7 @@ class FusedPlugin:
         swd = None
         if sum(len(t) for t in tw) > 0:
             swd = SwdParams(*[len(t) for t in tw], *[t.ctypes.data if len(t) else None for t in tw],
-                            int(bool(sphere)), 0)
+                            int(bool(sphere)), int(self._swd_mode()))
         ctx.check(ctx.L.rfs_joint_setup2(ctx.h, int(nlayer), ctypes.byref(rf) if rf is not None else None,
                                          ctypes.byref(swd) if swd is not None else None,
                                          float(s1), float(s2), hptr(d) if d is not None else None))

@@ -3,11 +3,11 @@ same function names, argument order, defaults and return tuples, executed by the
 library.  Additionally accepts 2-D model arrays [nchain, nlayer] (then every output gains a
 leading chain axis and the flag becomes a bool array).
 
-All four wavetypes (Rc, Rg, Lc, Lg), flat or spherical earth, fundamental mode.
+All four wavetypes (Rc, Rg, Lc, Lg), flat or spherical earth, fundamental and higher modes
+(``mode`` = 0, 1, 2, ...: the reference's mode loop, surfdisp96.f:227-316).
 
 Differences that are deliberate: a bad ``wavetype`` raises ValueError instead of calling
-exit(0) (main.cpp:24); higher modes raise NotImplementedError (out of scope, see DESIGN.md);
-the Love kernels return dcda = 0 where the reference returns an uninitialised array
+exit(0) (main.cpp:24); the Love kernels return dcda = 0 where the reference returns an uninitialised array
 (surfdisp.cpp:258-296 never writes it)."""
 import numpy as np
 
@@ -27,8 +27,8 @@ def _prep(thk, vp, vs, rho, period):
 def _check(wavetype, mode, sphere):
     if wavetype not in _WAVES:
         raise ValueError("wavetype should be one of [Rc,Rg,Lc,Lg]")
-    if mode != 0:
-        raise NotImplementedError("rfsurfhmc_amd covers the fundamental mode only")
+    if int(mode) != mode or mode < 0:
+        raise ValueError("mode should be a non-negative integer (0 = fundamental)")
 
 
 def forward(thk, vp, vs, rho, period, wavetype, mode=0, sphere=False, device=0):

@@ -19,6 +19,9 @@ class Joint_RF_SWD(FusedPlugin):
     def _swd_config(self):
         return self.swdmodel._swd_config()
 
+    def _swd_mode(self):
+        return self.swdmodel._swd_mode()
+
     def _sigmas(self):
         return self.sigma1, self.sigma2
 

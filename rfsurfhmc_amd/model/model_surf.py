@@ -1,7 +1,8 @@
 """SurfWD -- host-side mirror of the reference plugin model/model_surf.py (same constructor,
 ``init(**kargs)`` keys, ``set_obsdata``, ``set_thk``, ``forward``, ``misfit``, ``misfit_and_grad``),
 evaluated on the GPU through the fused B2 entry points.  All four blocks (tRc, tRg, tLc, tLg),
-flat or spherical earth, fundamental mode.
+flat or spherical earth, fundamental or higher modes (``mode``; the warm-started root search of the trajectory entries
+covers the fundamental only, higher modes always go through the reference-semantics search).
 
 Reference behaviour kept by default (``reference_periods=True``): forward() evaluates EVERY block at
 tRc (model_surf.py:104-131) and misfit_and_grad() evaluates the Lc and Lg blocks at tRc
@@ -15,9 +16,9 @@ from ._plugin import FusedPlugin
 class SurfWD(FusedPlugin):
     def __init__(self, mode=0, sphere=False, tRc=None, tRg=None, tLc=None, tLg=None, device=0,
                  reference_periods=True):
-        if mode != 0:
-            raise NotImplementedError("fundamental mode only")
-        self.mode, self.sphere, self.device = mode, bool(sphere), device
+        if int(mode) != mode or mode < 0:
+            raise ValueError("mode should be a non-negative integer (0 = fundamental)")
+        self.mode, self.sphere, self.device = int(mode), bool(sphere), device
         self.reference_periods = reference_periods
         for name, t in (("tRc", tRc), ("tRg", tRg), ("tLc", tLc), ("tLg", tLg)):
             arr = np.asarray(t, dtype=float) if t is not None and len(t) > 0 else None
@@ -43,6 +44,9 @@ class SurfWD(FusedPlugin):
     def _swd_config(self):
         return (self.tRc, self.tRg, self._love_eval_periods(self.tLc, "Lc"),
                 self._love_eval_periods(self.tLg, "Lg"), self.sphere)
+
+    def _swd_mode(self):
+        return self.mode
 
     def set_obsdata(self, dobs):
         self.dobs = dobs

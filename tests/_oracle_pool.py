@@ -10,10 +10,16 @@ _O = {}
 
 def _orc():
     if "o" not in _O:
-        from oracle import oracle
-        oracle.build(ref=False)
+        from oracle import oracle              # (liboracle.so was built by the parent: the `orc` fixture)
         _O["o"] = oracle
     return _O["o"]
+
+
+def _ctx():
+    """Workers are SPAWNED (fresh interpreters), never forked: the parent is a process with an initialised GPU runtime,
+    torch and their threads, and a forked copy of it can come up holding somebody else's lock (seen: a pool that never
+    returned, the third fork pool of a test session)."""
+    return mp.get_context("spawn")
 
 
 def _joint_worker(args):
@@ -50,14 +56,23 @@ def joint_batch(xs, rfpar, t, drf, dswd):
     """[(misfit, grad, dsyn, flag, misfit_rf, grad_rf, rf)] of the oracle's joint and RF-only plugins for every row of xs."""
     p = nproc()
     parts = [q for q in np.array_split(np.arange(len(xs)), p * 2) if len(q)]
-    with mp.get_context("fork").Pool(p) as pool:
+    with _ctx().Pool(p) as pool:
         res = pool.map(_joint_worker, [(xs[q], rfpar, t, drf, dswd) for q in parts])
     return [r for part in res for r in part]
 
 
-def roots_batch(xs, t, n):
+def roots_pool():
+    """A pool for several roots_batch calls (pass it as ``pool``)."""
+    return _ctx().Pool(nproc())
+
+
+def roots_batch(xs, t, n, pool=None):
+    if pool is not None:
+        parts = [q for q in np.array_split(np.arange(len(xs)), nproc() * 4) if len(q)]
+        res = pool.map(_roots_worker, [(xs[q], t, n) for q in parts])
+        return np.vstack([r[0] for r in res]), np.concatenate([r[1] for r in res])
     p = nproc()
     parts = [q for q in np.array_split(np.arange(len(xs)), p * 4) if len(q)]
-    with mp.get_context("fork").Pool(p) as pool:
+    with _ctx().Pool(p) as pool:
         res = pool.map(_roots_worker, [(xs[q], t, n) for q in parts])
     return np.vstack([r[0] for r in res]), np.concatenate([r[1] for r in res])

@@ -292,3 +292,31 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
     for (int k = 0; k < nt; k++) nfail += status[k] != 1;
     return nfail;
 }
+
+// The mode loop (RootSearchModes: surfdisp96.f:227-316 + the per-period retry of surfdisp.cpp:93-100) on the
+// (optionally earth-flattened) float32 model: `mode` = libsurf's argument (0 fundamental, 1 first higher mode, ...).
+extern "C" int hs_rootsearch_modes(int n, const float* thk, const float* vp, const float* vs, const float* rho,
+                                   int kmax, const double* t, double* cg, int love, int sphere, int mode)
+{
+    std::vector<float> w(4 * n);
+    const float *d = thk, *a = vp, *b = vs, *r = rho;
+    if (sphere) {
+        swd_flatten_f32(love != 0, n, thk, vp, vs, rho, 1, &w[0], &w[n], &w[2 * n], &w[3 * n], 1);
+        d = &w[0]; a = &w[n]; b = &w[2 * n]; r = &w[3 * n];
+    }
+    SwdModel M{d, a, b, r, 1, n};
+    std::vector<double> craw(kmax, 0.0);
+    struct Out { double* cg; void operator()(int k, double v) const { cg[k] = v; } double get(int k) const { return cg[k]; } };
+    Out out{cg};
+    for (int k = 0; k < kmax; k++) cg[k] = 0.0;
+    RootSearchModes rs;
+    auto T = [&](int k) { return t[k]; };
+    rs.set_modes(mode + 1, craw.data(), 1);
+    rs.begin(M, T, kmax);
+    while (!rs.done) {
+        double wvno = rs.omega / rs.creq;
+        double del = love ? swd_secular_love(M, wvno, rs.omega) : swd_secular(M, wvno, rs.omega);
+        rs.advance(del, T, out);
+    }
+    return rs.flag;
+}

@@ -42,8 +42,8 @@ def test_no_cpu_fallback(hiplib):
         libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Rc")
     with pytest.raises(ValueError):
         libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Xx")       # bad wavetype
-    with pytest.raises(NotImplementedError):
-        libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Lc", mode=1)   # out of scope
+    with pytest.raises(ValueError):
+        libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Lc", mode=-1)  # bad mode
     with pytest.raises(hiplib.RfsError):                                                         # Love: device only
         libsurf.forward([1.0, 0.0], [5.0, 6.0], [3.0, 3.5], [2.5, 2.7], [10.0], "Lc", sphere=True)
 

@@ -158,7 +158,7 @@ def test_argument_errors_are_reported_not_fatal():
     par.method, par.rf_type = 1, 7
     assert L.rfs_joint_setup(ctx.h, 4, ctypes.byref(par), 0, None, 0, None, 1.0, 1.0, None) == -1
     a = np.ones((1, 4))
-    assert L.rfs_swd_forward(ctx.h, 1, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 2, 1, 0, hptr(out), hptr(fl)) == -4   # higher mode
+    assert L.rfs_swd_forward(ctx.h, 1, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 2, -1, 0, hptr(out), hptr(fl)) == -1   # bad mode
     assert L.rfs_swd_forward(ctx.h, 1, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 7, 0, 0, hptr(out), hptr(fl)) == -1   # bad wavetype
     assert L.rfs_swd_forward(ctx.h, 9, 4, hptr(a), hptr(a), hptr(a), hptr(a), 2, hptr(t), 0, 0, 0, hptr(out), hptr(fl)) == -1   # > max_chains
     assert b"max_chains" in L.rfs_last_error(ctx.h)

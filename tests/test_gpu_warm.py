@@ -9,8 +9,6 @@ as predictor, instead of repeating the reference's sequential scan (surfdisp96.f
   * Love / group-velocity / spherical blocks; the sampler traces of the reference at the tolerance the warm start keeps;
   * "swd_exact_final": the end model of a trajectory carries reference-exact roots.
 """
-import multiprocessing as mp
-
 import numpy as np
 import pytest
 
@@ -48,29 +46,6 @@ def _leapfrog_move(x, p, g, dt, lo, hi):
     return x, p
 
 
-_ORC = {}
-
-
-def _oracle_roots(args):
-    xs, t, n = args
-    if "o" not in _ORC:
-        from oracle import oracle
-        _ORC["o"] = oracle
-    O = _ORC["o"]
-    out = np.zeros((len(xs), len(t))); ok = np.zeros(len(xs), dtype=bool)
-    for i, x in enumerate(xs):
-        vs, thk = x[:n], x[n:]
-        vp, rho, _, _ = O.empirical_relation(vs)
-        out[i], ok[i] = O.libsurf.forward(thk, vp, vs, rho, t, "Rc")
-    return out, ok
-
-
-def _oracle_batch(pool, xs, t, n, nproc):
-    parts = np.array_split(np.arange(len(xs)), nproc * 4)
-    res = pool.map(_oracle_roots, [(xs[p], t, n) for p in parts if len(p)])
-    return np.vstack([r[0] for r in res]), np.concatenate([r[1] for r in res])
-
-
 def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc):
     """8192 bench chains x 20 leapfrog steps x 40 periods: the evaluation of every step continues the one before
     (swd_warm_start = 2: the plugin entry, so that every step's synthetics come back), and every root of every step is
@@ -99,11 +74,11 @@ def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc):
     # from then on nearly every chain is continued
     assert items >= 0.95 * (nsteps - 1) * nchain * 40, (items, declined)
     assert evals <= 4.6 * items, (evals, items)        # ~3 to refine + 1 for the branch test
-    nproc = max(1, min(16, len(os.sched_getaffinity(0))))
+    from _oracle_pool import roots_batch, roots_pool
     worst, nident, ntot = 0.0, 0, 0
-    with mp.get_context("fork").Pool(nproc) as pool:
+    with roots_pool() as pool:
         for s in range(nsteps + 1):
-            co, oko = _oracle_batch(pool, xs_steps[s], t, n, nproc)
+            co, oko = roots_batch(xs_steps[s], t, n, pool)
             assert np.array_equal(oko, f_steps[s]), (s, int((oko != f_steps[s]).sum()))
             ok = oko
             r = np.abs(c_steps[s][ok] - co[ok]) / co[ok]
@@ -126,8 +101,8 @@ def test_roots_under_large_steps_against_the_restatement(orc):
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     bounds = bench.bounds_of(bench.true_model(n))
     lo, hi = tt(bounds[:, 0]), tt(bounds[:, 1])
-    nproc = max(1, min(16, len(os.sched_getaffinity(0))))
-    with mp.get_context("fork").Pool(nproc) as pool:
+    from _oracle_pool import roots_batch, roots_pool
+    with roots_pool() as pool:
         for dt in (0.03, 0.08):
             joint, t = _bench_joint(2)
             ctx = joint._ensure(n)
@@ -136,7 +111,7 @@ def test_roots_under_large_steps_against_the_restatement(orc):
             worst = 0.0
             for s in range(nsteps + 1):
                 m, g, d, f = joint.misfit_and_grad_device(x)
-                co, oko = _oracle_batch(pool, x.cpu().numpy(), t, n, nproc)
+                co, oko = roots_batch(x.cpu().numpy(), t, n, pool)
                 fl = f.cpu().numpy() != 0
                 assert np.array_equal(oko, fl), (dt, s)
                 r = np.abs(d[:, nt:].cpu().numpy()[oko] - co[oko]) / co[oko]
