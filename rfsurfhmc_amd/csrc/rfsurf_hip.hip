@@ -88,7 +88,7 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist;
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     int warm_nitems = 0;       // (sequence, period) items of the joint configuration's evaluation
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
@@ -653,7 +653,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         KTimer t(c, RFS_K_SWD_ROOTS, s);
         SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
                   c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
-                  c->wsgn.as<unsigned char>()};
+                  c->wsgn.as<unsigned char>(), c->wneed.as<int>() + nchain + 1, c->wneed.as<int>() + 2 * nchain + 1,
+                  c->wilist.as<int>()};
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -672,6 +673,17 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (P.QL.nper_total > 0)
             hipLaunchKernelGGL((k_swd_warm_check<SwdLoveFamily>), dim3((unsigned)(((size_t)P.QL.nper_total * nchain + 63) / 64)), dim3(64), 0, s,
                                nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
+        // ... sequences with anomalous dispersion: the reference's scan grid itself, 16 lanes per item (grid: a wavefront
+        // per four items of the irregular chains; their number is only known on the device -- the blocks stride)
+        {
+            const int gw = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 4 + 15) / 16)));
+            if (Q.nper_total > 0)
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily>), dim3(gw), dim3(64), 0, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                                   c->croot.as<double>(), W);
+            if (P.QL.nper_total > 0)
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily>), dim3(gw), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                                   c->mdlcL.as<double>(), c->croot.as<double>(), W);
+        }
         HIPCHK(c, hipGetLastError());
         const int* list = c->wlist.as<int>();
         const int* count = c->wneed.as<int>() + nchain;
@@ -794,6 +806,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
         ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
         ENSURE(c, c->ugr, ntot * sizeof(double));
+        {   // (timed group: the launches of this stream only -- the wait for the side stream below is not kernel time)
         KTimer t(c, eigen_mode == 1 ? -1 : RFS_K_SWD_EIGEN, s);     // the early launch hides behind the search: not timed
 #define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                                \
         hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)),            \
@@ -813,6 +826,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         }
 #undef RFS_LAUNCH_EIGEN
         HIPCHK(c, hipGetLastError());
+        }
         if (warm_side) {
             // behind the full search of the handed-back chains: their eigenfunctions again, from their new roots (the pass
             // above has read whatever roots they had; it must have finished before these results are written)
@@ -876,7 +890,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->xw, 2 * nn * sizeof(double)); ENSURE(c, c->dxT, 2 * nn * sizeof(double));
         ENSURE(c, c->crT, 2 * nn * sizeof(double));
         const size_t before = c->wvalid.cap;
-        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, ((size_t)nchain + 1) * sizeof(int));
+        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (2 * (size_t)nchain + 2) * sizeof(int));
+        ENSURE(c, c->wilist, (size_t)nchain * sizeof(int));
         ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
         ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
@@ -1030,7 +1045,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            c->mdl.as<float>(), c->mdlc.as<double>(),
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
                            early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
-                           early_items > 0 ? ntot / 64 + 1 : (warm ? (size_t)nchain + 1 : (size_t)0),
+                           early_items > 0 ? ntot / 64 + 1 : (warm ? 2 * (size_t)nchain + 2 : (size_t)0),
                            track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>());
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
@@ -1160,7 +1175,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     drop_plans(c);

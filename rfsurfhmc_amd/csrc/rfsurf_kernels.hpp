@@ -764,6 +764,7 @@ struct SwdWarm {
     int* count; int* list;  // ... and the compacted list of those chains
     unsigned long long* stats;   // [0] chains handed back, [1] secular evaluations, [2] items refined
     unsigned char* sgn;     // [item][chain] sign bit of the secular function just below the refined root (2: no root)
+    int* irr; int* icount; int* ilist;   // chains with an irregular sequence (k_swd_warm_check -> k_swd_warm_walk)
 };
 
 template <class F, bool SPH>
@@ -853,15 +854,21 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
     if (W.need[chain]) return;                                       // already on its way to the full search
     const int sg = W.sgn[(size_t)e * nchain + chain];
     const double ck = croot[(size_t)e * nchain + chain];
-    double sk;
-    if (k == 0) {
-        const size_t s = (size_t)n * nchain;
-        SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
-        float bmx;
-        sk = (double)swd_start_value(M, bmx);
-    } else {
-        sk = croot[(size_t)(e - 1) * nchain + chain] - 1.5 * (double)0.005f;
-    }
+    const double dcs = (double)0.005f;
+    const size_t s = (size_t)n * nchain;
+    SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+    // REGULAR sequence (normal dispersion at every period: each root above the scan start of its period): one evaluation at
+    // the start point.  IRREGULAR (some root has dropped more than 1.5 dc under the previous period's: velocity inversions,
+    // crowded spectra -- there the reference's pick among neighbouring modes depends on where its 0.005 km/s grid falls):
+    // every period of the sequence walks the reference's own scan grid (getsol :433-479) from its start point, up or down
+    // as getsol would, and the first cell with a sign change must be the one that holds the continued root.
+    const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
+    bool irregular = false;
+    for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+    float bmx = 0.f;
+    double cc = 0.0;
+    if (k == 0 || irregular) cc = (double)swd_start_value(M, bmx);
+    const double sk = (k == 0) ? cc : cq[(size_t)(k - 1) * nchain] - 1.5 * dcs;
     const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
     const double* lc0 = mdlc + chain;
     auto loadL = [&](int m) {
@@ -869,15 +876,14 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
-    // The scan runs from sk towards the first sign change it meets: upwards when the function at sk has the sign it has
-    // below the lowest root, downwards otherwise (getsol :439-447).  No root may lie between sk and the continued root:
-    // below it the function must have the sign it has just below the root, above it (anomalous dispersion: the root has
-    // dropped more than 1.5 dc under the previous period's) the opposite one.
-    // (downwards only over a short stretch: a long one may hide a PAIR of roots of other modes between two scan points,
-    // which the sign alone cannot show -- the reference itself sees or misses such a pair by the luck of its grid)
-    const bool order = sg > 1 || !(sk > 0.0) || sk == ck || sk - ck > WARM_ANOM_GAP;
+    if (irregular) {                                                 // -> k_swd_warm_walk, one 16-lane group per item
+        if (atomicExch(&W.irr[chain], 1) == 0) W.ilist[atomicAdd(W.icount, 1)] = chain;
+        return;
+    }
+    const bool order = sg > 1 || !(sk > 0.0) || sk == ck;
     const double f = swd_secular_family<F>(n, loadL, omega, order ? ck : sk);
-    const bool bad = order || ((signbit(f) ? 1 : 0) != (sk < ck ? sg : 1 - sg));
+    int nev = 1;
+    const bool bad = order || !(sk < ck) || (signbit(f) ? 1 : 0) != sg;
     if (bad && atomicExch(&W.need[chain], 1) == 0) {
         W.list[atomicAdd(W.count, 1)] = chain;
         atomicAdd(&W.stats[0], 1ull);
@@ -885,7 +891,97 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
         // 10 / 11 the same for a sequence's first period
         atomicAdd(&W.stats[(order ? 8 : 9) + (k == 0 ? 2 : 0)], 1ull);
     }
-    if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[1], 64ull);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nev += __shfl_xor(nev, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[1], (unsigned long long)nev);
+}
+
+// The branch test of IRREGULAR sequences: 16 lanes per (chain, period) item walk the reference's scan grid together --
+// lane j evaluates the j-th next grid point of a round, the group's first sign change is found with a ballot.  getsol
+// :433-479: direction from the sign at the start point against the sign below every root (del1st: the first evaluation
+// of the sequence's first period), steps of dc, abort below the start value or above the fastest layer.  The first cell
+// with a sign change must hold the continued root; otherwise the chain goes to the full search.
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc,
+                const double* __restrict__ croot, SwdWarm W)
+{
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int nsel = *W.icount;
+    const long total = (long)nsel * Q.nper_total;
+    const double dcs = (double)0.005f;
+    for (long base = (long)blockIdx.x * 4; base < total; base += (long)gridDim.x * 4) {
+        const long it = base + sub;
+        bool live = it < total;
+        const int pos = live ? (int)(it / Q.nper_total) : 0, el = live ? (int)(it - (long)pos * Q.nper_total) : 0;
+        const int chain = W.ilist[live ? pos : 0];
+        const int e = Q.s[0].croot_off + el;
+        int seq = 0;
+        while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
+        const int k = e - Q.s[seq].croot_off;
+        const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
+        bool irregular = false;
+        for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+        live = live && irregular && !W.need[chain];
+        const size_t s = (size_t)n * nchain;
+        SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        float bmx = 0.f;
+        const double cc = (double)swd_start_value(M, bmx);
+        const int sg = W.sgn[(size_t)e * nchain + chain];
+        const double ck = croot[(size_t)e * nchain + chain];
+        const double sk = (k == 0) ? cc : cq[(size_t)(k - 1) * nchain] - 1.5 * dcs;
+        const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
+        const double om0 = (2.0 * 3.141592653589793) / (Q.s[seq].t[0] * Q.s[seq].scale);
+        const double* lc0 = mdlc + chain;
+        auto loadL = [&](int m) {
+            const double* o = lc0 + (size_t)m * 6 * nchain;
+            return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                             o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+        };
+        bool bad = live && (sg > 1 || !(sk > 0.0) || sk == ck);
+        bool walking = live && !bad;
+        // round 0: lane 0 of the group evaluates the start point, lane 1 the sign below every root
+        double f0 = 0.0;
+        if (walking && li < 2) f0 = swd_secular_family<F>(n, loadL, li == 0 ? omega : om0, li == 0 ? sk : cc);
+        const int gbase = sub * 16;
+        const double fsk = __shfl(f0, gbase, 64), f1st = __shfl(f0, gbase + 1, 64);
+        const int idir = (k == 0 || signbit(fsk) == signbit(f1st)) ? +1 : -1;
+        int sprev = signbit(fsk) ? 1 : 0;                 // sign at the last point of the round before
+        int nev = (walking && li < 2) ? 1 : 0;
+        for (int round = 0; round < 25 && __any(walking); round++) {
+            const double c = sk + (double)idir * (double)(round * 16 + li + 1) * dcs;
+            double f = 0.0;
+            if (walking) { f = swd_secular_family<F>(n, loadL, omega, c > 1.0e-3 ? c : 1.0e-3); nev++; }
+            const int sgn_me = signbit(f) ? 1 : 0;
+            int sgn_before = __shfl_up(sgn_me, 1, 16);
+            if (li == 0) sgn_before = sprev;
+            // per lane: does the scan END at this point?  a sign change against the point before, or one of getsol's limits
+            // once the scan has moved here without one (:463-479; the clamp at clow is handed back to the full search)
+            const bool clampd = c <= cc;                                   // getsol would clamp here instead of evaluating
+            const bool change = sgn_me != sgn_before && !clampd;
+            const bool limit = clampd || c >= (double)bmx + dcs;
+            const unsigned long long mall = __ballot(walking && (change || limit));
+            const unsigned int mgrp = (unsigned int)((mall >> gbase) & 0xffffu);
+            if (walking && mgrp) {
+                const int first = __ffs((int)mgrp) - 1;                       // the group's first ending point
+                const unsigned long long mchange = __ballot(walking && change);
+                const bool by_change = ((mchange >> (gbase + first)) & 1ull) != 0;
+                const double cend = sk + (double)idir * (double)(round * 16 + first + 1) * dcs, cbefore = cend - (double)idir * dcs;
+                bad = !by_change || !(fmin(cbefore, cend) < ck && ck < fmax(cbefore, cend));
+                walking = false;
+            }
+            sprev = __shfl(sgn_me, gbase + 15, 64);
+            if (round == 24 && walking) { bad = true; walking = false; }
+        }
+        if (live && bad && li == 0 && atomicExch(&W.need[chain], 1) == 0) {
+            W.list[atomicAdd(W.count, 1)] = chain;
+            atomicAdd(&W.stats[0], 1ull);
+            atomicAdd(&W.stats[9 + (k == 0 ? 2 : 0)], 1ull);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nev += __shfl_xor(nev, off, 64);
+        if (lane == 0) atomicAdd(&W.stats[1], (unsigned long long)nev);
+    }
 }
 
 constexpr int COOP_CL = 1;                       // the consumer builds the deepest finite layer itself

@@ -718,9 +718,12 @@ using RootSearchModes = RootSearchT<NevTabReg, true>;
 // about 3 secular evaluations instead of the ~23 of the sequential scan + nevill, and lane = (period, chain).
 // A second, one-evaluation test keeps the continued root on the branch the reference's scan would pick: the scan of
 // period k starts at c(k-1) - 1.5 dc (the first period at the start value of the model, surfdisp96.f:257-276) and takes
-// the first sign change it meets -- upwards, or downwards where the root has dropped below the start point (anomalous
-// dispersion) -- so the secular function at that start point must have the sign it has on the same side of the continued
-// root, right next to it (k_swd_warm_check); otherwise another root has moved in between and the chain is handed back.
+// the first sign change it meets.  Where the dispersion is normal at every period of the sequence (each root above its
+// period's start point) one evaluation at the start point does: the function there must have the sign it has just
+// below the continued root, otherwise another root has moved in between.  A sequence with anomalous dispersion somewhere
+// (velocity inversions: crowded spectra, and the reference's pick among neighbouring modes then depends on where its
+// 0.005 km/s grid falls) walks the reference's own scan grid for every period, up or down as getsol would, and the first
+// cell with a sign change must hold the continued root (k_swd_warm_check).  Anything else: back to the full search.
 // The machine only REQUESTS evaluations, like RootSearchT.  It declines (status W_FAIL) whenever anything is off --
 // no sign change inside the trust radius, no convergence, a root above the fastest layer -- and the caller then runs
 // the reference-semantics search for that chain, which alone decides flags.  Accepted roots lie within WARM_TOL c of
@@ -734,12 +737,7 @@ constexpr double WARM_R0 = 2.0e-4;           // trust radius: R0 c + R1 l1
 constexpr double WARM_R1 = 1.0;              // (a first-order model that misses by more than its own size is no guide)
 constexpr double WARM_L1MAX = 0.5;           // km/s: beyond this first-order change the model is not "the previous one, moved"
 constexpr int WARM_MAXIT = 12;
-// How far ABOVE the continued root the reference's scan may start (anomalous dispersion: it then runs downwards).  Zero:
-// with c(T) falling by more than 1.5 dc per period the spectrum is crowded (channel waves of velocity inversions) and
-// the reference's pick among neighbouring modes depends on where its 0.005 km/s grid falls -- measured on unsorted
-// models: allowing 3 dc let 1 chain in 10^3 continue a root the reference's grid steps over.  Such chains go back to
-// the full search at every step.
-constexpr double WARM_ANOM_GAP = 0.0;
+
 
 struct WarmSearch {
     enum { W_A, W_B, W_X, W_REF, W_DONE, W_FAIL };

@@ -15,6 +15,8 @@ n, nt, nchain = cfg["n"], cfg["nt"], 8192
 t = np.linspace(5, 44, bench.NPER)
 joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(bench.RAY_P, nt, cfg["dt"], bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq"), SurfWD(tRc=t))
 joint.set_warm_start(warm)
+import os
+SERIAL = os.environ.get("RFS_SERIAL") == "1"      # one stream: every kernel alone on the chip (clean per-kernel durations)
 x_true = bench.true_model(n)
 drf, dswd, flag = joint.forward(x_true); joint.set_obsdata(drf, dswd)
 dev = torch.device("cuda")
@@ -23,6 +25,8 @@ bounds = bench.bounds_of(x_true)
 xs = np.clip(bench.make_models(nchain, 991206, n), bounds[:, 0], bounds[:, 1])
 st = joint.flow_state(tt(xs), torch.full((nchain,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
 st["p"].copy_(tt(0.5 * np.random.default_rng(7).standard_normal(xs.shape))); st["rem"].fill_(1 << 30); st["fresh"].fill_(1)
+if SERIAL:
+    joint._ensure(n).set_option("swd_warm_serial", 1)
 for _ in range(nrep + 1):
     joint.flow_step(st)
 torch.cuda.synchronize()

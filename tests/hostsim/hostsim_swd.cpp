@@ -274,20 +274,36 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
         nev[k] = ws.nev; status[k] = ok ? 1 : 0;
         sgn_lo[k] = signbit(ws.fa) ? 1 : 0;
     }
-    // the check of k_swd_warm_check: the secular function at the point the reference's scan of period k starts from
-    // must have the sign it has just below the root
+    // the branch test of k_swd_warm_check: regular sequence -> one evaluation at the scan's start point; irregular -> the
+    // reference's own scan grid is walked from there
     SwdModel M{d, a, b, r, 1, n};
-    RootSearch rs;
-    auto T = [&](int k) { return t[k]; };
-    rs.begin(M, T, nt);
-    for (int k = 0; k < nt; k++) {
-        if (!status[k] || (k > 0 && !status[k - 1])) continue;
+    float bmx;
+    const double cc = (double)swd_start_value(M, bmx), dcs = (double)0.005f;
+    bool irregular = false, all_ok = true;
+    for (int k = 0; k < nt; k++) all_ok = all_ok && status[k] == 1;
+    for (int k = 1; k < nt && all_ok; k++) irregular = irregular || (cout[k - 1] - 1.5 * dcs >= cout[k]);
+    for (int k = 0; k < nt && all_ok; k++) {
         const double omega = (2.0 * 3.141592653589793) / t[k];
-        const double sk = k == 0 ? rs.cc : cout[k - 1] - 1.5 * rs.dc;
-        double f = love ? swd_secular_family<SwdLoveFamily>(n, loadL, omega, sk)
-                        : swd_secular_family<SwdRayFamily>(n, loadL, omega, sk);
+        auto sec = [&](double w, double c) { return love ? swd_secular_family<SwdLoveFamily>(n, loadL, w, c)
+                                                          : swd_secular_family<SwdRayFamily>(n, loadL, w, c); };
+        const double ck = cout[k], sk = k == 0 ? cc : cout[k - 1] - 1.5 * dcs;
+        if (!(sk > 0.0) || sk == ck) { status[k] = 2; continue; }
+        double f = sec(omega, sk);
         nev[k]++;
-        if ((signbit(f) ? 1 : 0) != (sk < cout[k] ? sgn_lo[k] : 1 - sgn_lo[k]) || sk == cout[k] || sk - cout[k] > WARM_ANOM_GAP) status[k] = 2;
+        if (!irregular) { if (!(sk < ck) || (signbit(f) ? 1 : 0) != sgn_lo[k]) status[k] = 2; continue; }
+        int s1st = signbit(f) ? 1 : 0;
+        if (k > 0) { s1st = signbit(sec((2.0 * 3.141592653589793) / t[0], cc)) ? 1 : 0; nev[k]++; }
+        int idir = (k == 0 || (signbit(f) ? 1 : 0) == s1st) ? +1 : -1;
+        double c1 = sk;
+        for (int steps = 0;; steps++) {
+            double c2 = idir > 0 ? c1 + dcs : c1 - dcs;
+            if (c2 <= cc || steps > 400) { status[k] = 2; break; }
+            const double f2 = sec(omega, c2);
+            nev[k]++;
+            if (diffsign(f, f2)) { if (!(fmin(c1, c2) < ck && ck < fmax(c1, c2))) status[k] = 2; break; }
+            c1 = c2; f = f2;
+            if (c1 < cc || c1 >= (double)bmx + dcs) { status[k] = 2; break; }
+        }
     }
     for (int k = 0; k < nt; k++) nfail += status[k] != 1;
     return nfail;
