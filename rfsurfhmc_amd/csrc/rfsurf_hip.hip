@@ -88,7 +88,8 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2;
+    hipEvent_t ev_w[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     int warm_nitems = 0;       // (sequence, period) items of the joint configuration's evaluation
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
@@ -654,7 +655,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
                   c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
                   c->wsgn.as<unsigned char>(), c->wneed.as<int>() + nchain + 1, c->wneed.as<int>() + 2 * nchain + 1,
-                  c->wilist.as<int>()};
+                  c->wilist.as<int>(), c->wneed.as<int>() + 2 * nchain + 2, c->wlist2.as<int>()};
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -666,6 +667,58 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
         if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
 #undef RFS_LAUNCH_WARM
+        HIPCHK(c, hipGetLastError());
+        // The hand-back lists are nearly always empty, and when one is not, the full search of even ONE chain takes ~3 ms
+        // (about a thousand dependent secular evaluations): it runs on a side stream -- for the chains k_swd_warm itself
+        // declines (moves too large for a first-order model: the bulk) from here on, beside the branch test; for the chains
+        // the branch test declines behind it -- beside the eigenfunction pass of all chains; only the listed chains'
+        // eigenfunctions are redone afterwards (below).
+        hipStream_t sf = (kernels && c->stream_l && s != c->stream_l) ? c->stream_l : s;
+        warm_side = sf != s ? sf : nullptr;
+        // the first list's length of an earlier step, whenever its copy has arrived (never waited for)
+        const int est = std::max(c->warm_est, 64);
+        auto launch_fallback = [&](const int* list, const int* count, int estc) -> int {
+            const int gl = std::min((nchain + 63) / 64, std::max(8, (estc + 63) / 64));
+            bool rdone = false;
+            if (Q.nseq > 0 && estc * Q.nseq > SWD_LAT_MAX_ITEMS) {
+                // many chains handed back (large steps): the cooperative blocks of the full search, over the list
+                const CoopPlan cp = coop_plan(c, Q, nchain, n);
+                if (cp.ok) {
+                    dim3 grid(cp.blocks);
+                    size_t lds2 = cp.lds;
+#define RFS_LAUNCH_COOPL(NCH)                                                                                  \
+                    do {                                                                                       \
+                        HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<SwdRayFamily, NCH>,        \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));  \
+                        hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, sf, nchain, n, Q, \
+                                           mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>(), list, count); \
+                    } while (0)
+                    if (cp.nch <= 5) RFS_LAUNCH_COOPL(5);
+                    else if (cp.nch <= 8) RFS_LAUNCH_COOPL(8);
+                    else RFS_LAUNCH_COOPL(16);
+#undef RFS_LAUNCH_COOPL
+                    rdone = true;
+                }
+            }
+            if (!rdone && Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, sf, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                                                                                   c->sflag.as<int>(), 0, list, count, estc)))
+                hipLaunchKernelGGL((k_swd_roots<false, false>), dim3(gl * Q.nseq), dim3(64), 0, sf, nchain, n, Q, mdlR, c->croot.as<double>(),
+                                   c->sflag.as<int>(), list, count, (double*)nullptr, 1);
+            const bool ldone = P.QL.nseq > 0 && estc * P.QL.nseq > SWD_LAT_MAX_ITEMS &&
+                               !launch_love_coop(c, sf, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL, list, count, estc);
+            if (!ldone && P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, sf, nchain, n, P.QL, c->mdlL.as<float>(),
+                                                                                       c->mdlcL.as<double>(), sflagL, 0, list, count, estc)))
+                hipLaunchKernelGGL((k_swd_roots<true, false>), dim3(gl * P.QL.nseq), dim3(64), 0, sf, nchain, n, P.QL, c->mdlL.as<float>(),
+                                   c->croot.as<double>(), sflagL, list, count, (double*)nullptr, 1);
+            HIPCHK(c, hipGetLastError());
+            return RFS_OK;
+        };
+        if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[0], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[0], 0)); }
+        if (sf != s) TRY(launch_fallback(W.list, W.count, est));      // (one stream only: both lists after the branch test)
+        if (c->h_wcount && sf != s) {
+            if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
+            HIPCHK(c, hipMemcpyAsync(c->h_wcount, W.count, sizeof(int), hipMemcpyDeviceToHost, sf));
+        }
         // ... and is the continued root still the one the reference's scan would stop at?  (one evaluation per item)
         if (Q.nper_total > 0)
             hipLaunchKernelGGL((k_swd_warm_check<SwdRayFamily>), dim3((unsigned)(((size_t)Q.nper_total * nchain + 63) / 64)), dim3(64), 0, s,
@@ -673,65 +726,30 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (P.QL.nper_total > 0)
             hipLaunchKernelGGL((k_swd_warm_check<SwdLoveFamily>), dim3((unsigned)(((size_t)P.QL.nper_total * nchain + 63) / 64)), dim3(64), 0, s,
                                nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
-        // ... sequences with anomalous dispersion: the reference's scan grid itself, 16 lanes per item (grid: a wavefront
-        // per four items of the irregular chains; their number is only known on the device -- the blocks stride)
+        // ... sequences with anomalous dispersion: the reference's scan grid itself -- 64 lanes per item for the first period
+        // of a sequence (a scan of ~100 cells), 16 for the others (grids: sized for a share of the chains, the number of
+        // irregular ones is only known on the device -- the blocks stride)
         {
             const int gw = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 4 + 15) / 16)));
-            if (Q.nper_total > 0)
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily>), dim3(gw), dim3(64), 0, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+            const int g1 = std::max(64, std::min(2048, nchain / 4));
+            if (Q.nper_total > 0) {
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, true>), dim3(g1), dim3(64), 0, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                    c->croot.as<double>(), W);
-            if (P.QL.nper_total > 0)
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily>), dim3(gw), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, false>), dim3(gw), dim3(64), 0, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                                   c->croot.as<double>(), W);
+            }
+            if (P.QL.nper_total > 0) {
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, true>), dim3(g1), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
                                    c->mdlcL.as<double>(), c->croot.as<double>(), W);
-        }
-        HIPCHK(c, hipGetLastError());
-        const int* list = c->wlist.as<int>();
-        const int* count = c->wneed.as<int>() + nchain;
-        // The hand-back list is nearly always empty, and when it is not, the full search of even ONE chain takes ~3 ms
-        // (about a thousand dependent secular evaluations): it runs on a side stream beside the eigenfunction pass of
-        // all chains, and only the listed chains' eigenfunctions are redone behind it (below)
-        hipStream_t sf = (kernels && c->stream_l && s != c->stream_l) ? c->stream_l : s;
-        if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_lf, s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_lf, 0)); }
-        warm_side = sf != s ? sf : nullptr;
-        // the list's length of an earlier step, whenever its copy has arrived (never waited for)
-        const int est = std::max(c->warm_est, 64);
-        const int gl = std::min((nchain + 63) / 64, std::max(8, (est + 63) / 64));
-        bool rdone = false;
-        if (Q.nseq > 0 && est * Q.nseq > SWD_LAT_MAX_ITEMS) {
-            // many chains handed back (large steps): the cooperative blocks of the full search, over the list
-            const CoopPlan cp = coop_plan(c, Q, nchain, n);
-            if (cp.ok) {
-                dim3 grid(cp.blocks);
-                size_t lds2 = cp.lds;
-#define RFS_LAUNCH_COOPL(NCH)                                                                                  \
-                do {                                                                                           \
-                    HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_roots_coop<SwdRayFamily, NCH>,            \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));      \
-                    hipLaunchKernelGGL((k_swd_roots_coop<SwdRayFamily, NCH>), grid, dim3(512), lds2, sf, nchain, n, Q, \
-                                       mdlR, c->mdlc.as<double>(), c->croot.as<double>(), c->sflag.as<int>(), list, count); \
-                } while (0)
-                if (cp.nch <= 5) RFS_LAUNCH_COOPL(5);
-                else if (cp.nch <= 8) RFS_LAUNCH_COOPL(8);
-                else RFS_LAUNCH_COOPL(16);
-#undef RFS_LAUNCH_COOPL
-                rdone = true;
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, false>), dim3(gw), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                                   c->mdlcL.as<double>(), c->croot.as<double>(), W);
             }
         }
-        if (!rdone && Q.nseq > 0 && (n < 3 || launch_roots_split<SwdRayFamily>(c, sf, nchain, n, Q, mdlR, c->mdlc.as<double>(),
-                                                                               c->sflag.as<int>(), 0, list, count, est)))
-            hipLaunchKernelGGL((k_swd_roots<false, false>), dim3(gl * Q.nseq), dim3(64), 0, sf, nchain, n, Q, mdlR, c->croot.as<double>(),
-                               c->sflag.as<int>(), list, count, (double*)nullptr, 1);
-        const bool ldone = P.QL.nseq > 0 && est * P.QL.nseq > SWD_LAT_MAX_ITEMS &&
-                           !launch_love_coop(c, sf, nchain, n, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL, list, count, est);
-        if (!ldone && P.QL.nseq > 0 && (n < 3 || launch_roots_split<SwdLoveFamily>(c, sf, nchain, n, P.QL, c->mdlL.as<float>(),
-                                                                                   c->mdlcL.as<double>(), sflagL, 0, list, count, est)))
-            hipLaunchKernelGGL((k_swd_roots<true, false>), dim3(gl * P.QL.nseq), dim3(64), 0, sf, nchain, n, P.QL, c->mdlL.as<float>(),
-                               c->croot.as<double>(), sflagL, list, count, (double*)nullptr, 1);
         HIPCHK(c, hipGetLastError());
-        if (c->h_wcount) {
-            if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
-            HIPCHK(c, hipMemcpyAsync(c->h_wcount, count, sizeof(int), hipMemcpyDeviceToHost, sf));
-        }
+        // the chains the branch test handed back (and, on one stream, those of the first list)
+        if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[1], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[1], 0)); }
+        else TRY(launch_fallback(W.list, W.count, est));
+        TRY(launch_fallback(W.list2, W.count2, 64));
         roots = false;
     }
     // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
@@ -830,27 +848,29 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (warm_side) {
             // behind the full search of the handed-back chains: their eigenfunctions again, from their new roots (the pass
             // above has read whatever roots they had; it must have finished before these results are written)
-            HIPCHK(c, hipEventRecord(c->ev_lj, s));
-            HIPCHK(c, hipStreamWaitEvent(warm_side, c->ev_lj, 0));
-            const int* list = c->wlist.as<int>();
-            const int* count = c->wneed.as<int>() + nchain;
-#define RFS_LAUNCH_EIGEN_LIST(LOVE, SPH, QQ, SPHP, SFL)                                                              \
+            HIPCHK(c, hipEventRecord(c->ev_w[2], s));
+            HIPCHK(c, hipStreamWaitEvent(warm_side, c->ev_w[2], 0));
+            const int* lists[2] = {c->wlist.as<int>(), c->wlist2.as<int>()};
+            const int* counts[2] = {c->wneed.as<int>() + nchain, c->wneed.as<int>() + 2 * nchain + 2};
+#define RFS_LAUNCH_EIGEN_LIST(LOVE, SPH, QQ, SPHP, SFL, LI)                                                          \
             hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
                                dim3(64), 0, warm_side, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(), \
                                SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (QQ).nper_total, 0, \
-                               (int*)nullptr, list, count)
-            if (P.QR.nper_total > 0) {
-                if (sphere) RFS_LAUNCH_EIGEN_LIST(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>());
-                else RFS_LAUNCH_EIGEN_LIST(false, false, P.QR, (const double*)nullptr, c->sflag.as<int>());
-            }
-            if (P.QL.nper_total > 0) {
-                if (sphere) RFS_LAUNCH_EIGEN_LIST(true, true, P.QL, c->sphL.as<double>(), sflagL);
-                else RFS_LAUNCH_EIGEN_LIST(true, false, P.QL, (const double*)nullptr, sflagL);
+                               (int*)nullptr, lists[LI], counts[LI])
+            for (int li = 0; li < 2; li++) {
+                if (P.QR.nper_total > 0) {
+                    if (sphere) RFS_LAUNCH_EIGEN_LIST(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>(), li);
+                    else RFS_LAUNCH_EIGEN_LIST(false, false, P.QR, (const double*)nullptr, c->sflag.as<int>(), li);
+                }
+                if (P.QL.nper_total > 0) {
+                    if (sphere) RFS_LAUNCH_EIGEN_LIST(true, true, P.QL, c->sphL.as<double>(), sflagL, li);
+                    else RFS_LAUNCH_EIGEN_LIST(true, false, P.QL, (const double*)nullptr, sflagL, li);
+                }
             }
 #undef RFS_LAUNCH_EIGEN_LIST
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipEventRecord(c->ev_lf, warm_side));
-            HIPCHK(c, hipStreamWaitEvent(s, c->ev_lf, 0));
+            HIPCHK(c, hipEventRecord(c->ev_w[3], warm_side));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_w[3], 0));
         }
     }
     return RFS_OK;
@@ -890,8 +910,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->xw, 2 * nn * sizeof(double)); ENSURE(c, c->dxT, 2 * nn * sizeof(double));
         ENSURE(c, c->crT, 2 * nn * sizeof(double));
         const size_t before = c->wvalid.cap;
-        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (2 * (size_t)nchain + 2) * sizeof(int));
-        ENSURE(c, c->wilist, (size_t)nchain * sizeof(int));
+        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (2 * (size_t)nchain + 3) * sizeof(int));
+        ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, (size_t)nchain * sizeof(int));
+        for (auto& e : c->ev_w) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
         ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
@@ -1045,7 +1066,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            c->mdl.as<float>(), c->mdlc.as<double>(),
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
                            early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
-                           early_items > 0 ? ntot / 64 + 1 : (warm ? 2 * (size_t)nchain + 2 : (size_t)0),
+                           early_items > 0 ? ntot / 64 + 1 : (warm ? 2 * (size_t)nchain + 3 : (size_t)0),
                            track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>());
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
@@ -1175,9 +1196,10 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
+    for (auto e : c->ev_w) if (e) hipEventDestroy(e);
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);

@@ -765,6 +765,7 @@ struct SwdWarm {
     unsigned long long* stats;   // [0] chains handed back, [1] secular evaluations, [2] items refined
     unsigned char* sgn;     // [item][chain] sign bit of the secular function just below the refined root (2: no root)
     int* irr; int* icount; int* ilist;   // chains with an irregular sequence (k_swd_warm_check -> k_swd_warm_walk)
+    int* count2; int* list2;             // chains handed back by the branch test (the search of `list` is under way by then)
 };
 
 template <class F, bool SPH>
@@ -885,7 +886,7 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
     int nev = 1;
     const bool bad = order || !(sk < ck) || (signbit(f) ? 1 : 0) != sg;
     if (bad && atomicExch(&W.need[chain], 1) == 0) {
-        W.list[atomicAdd(W.count, 1)] = chain;
+        W.list2[atomicAdd(W.count2, 1)] = chain;
         atomicAdd(&W.stats[0], 1ull);
         // cause: 8 no root / degenerate start point, 9 another root between the scan's start and the continued root,
         // 10 / 11 the same for a sequence's first period
@@ -901,24 +902,32 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
 // :433-479: direction from the sign at the start point against the sign below every root (del1st: the first evaluation
 // of the sequence's first period), steps of dc, abort below the start value or above the fastest layer.  The first cell
 // with a sign change must hold the continued root; otherwise the chain goes to the full search.
-template <class F>
-__global__ void __launch_bounds__(64)
+template <class F, bool FIRST>      // FIRST: the first period of every sequence (a scan of ~100 cells from the start value): 64 lanes
+__global__ void __launch_bounds__(64)   // per item; otherwise the later periods (~10 cells): 16 lanes per item, four items per wavefront
 k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc,
                 const double* __restrict__ croot, SwdWarm W)
 {
-    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    constexpr int LPI = FIRST ? 64 : 16, IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63, sub = lane / LPI, li = lane % LPI;
     const int nsel = *W.icount;
-    const long total = (long)nsel * Q.nper_total;
+    const int per_chain = FIRST ? Q.nseq : Q.nper_total;
+    const long total = (long)nsel * per_chain;
     const double dcs = (double)0.005f;
-    for (long base = (long)blockIdx.x * 4; base < total; base += (long)gridDim.x * 4) {
+    for (long base = (long)blockIdx.x * IPW; base < total; base += (long)gridDim.x * IPW) {
         const long it = base + sub;
         bool live = it < total;
-        const int pos = live ? (int)(it / Q.nper_total) : 0, el = live ? (int)(it - (long)pos * Q.nper_total) : 0;
+        const int pos = live ? (int)(it / per_chain) : 0, sub_it = live ? (int)(it - (long)pos * per_chain) : 0;
         const int chain = W.ilist[live ? pos : 0];
-        const int e = Q.s[0].croot_off + el;
-        int seq = 0;
-        while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
-        const int k = e - Q.s[seq].croot_off;
+        int seq, k;
+        if (FIRST) { seq = sub_it; k = 0; }
+        else {
+            const int e0 = Q.s[0].croot_off + sub_it;
+            seq = 0;
+            while (seq + 1 < Q.nseq && e0 >= Q.s[seq + 1].croot_off) seq++;
+            k = e0 - Q.s[seq].croot_off;
+            live = live && k > 0;
+        }
+        const int e = Q.s[seq].croot_off + k;
         const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
         bool irregular = false;
         for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
@@ -940,41 +949,42 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         };
         bool bad = live && (sg > 1 || !(sk > 0.0) || sk == ck);
         bool walking = live && !bad;
-        // round 0: lane 0 of the group evaluates the start point, lane 1 the sign below every root
+        // round 0: lane 0 of the group evaluates the start point, lane 1 the sign below every root (del1st)
         double f0 = 0.0;
         if (walking && li < 2) f0 = swd_secular_family<F>(n, loadL, li == 0 ? omega : om0, li == 0 ? sk : cc);
-        const int gbase = sub * 16;
+        const int gbase = sub * LPI;
         const double fsk = __shfl(f0, gbase, 64), f1st = __shfl(f0, gbase + 1, 64);
         const int idir = (k == 0 || signbit(fsk) == signbit(f1st)) ? +1 : -1;
         int sprev = signbit(fsk) ? 1 : 0;                 // sign at the last point of the round before
         int nev = (walking && li < 2) ? 1 : 0;
-        for (int round = 0; round < 25 && __any(walking); round++) {
-            const double c = sk + (double)idir * (double)(round * 16 + li + 1) * dcs;
+        constexpr int MAXR = 400 / LPI;
+        for (int round = 0; round < MAXR && __any(walking); round++) {
+            const double c = sk + (double)idir * (double)(round * LPI + li + 1) * dcs;
             double f = 0.0;
             if (walking) { f = swd_secular_family<F>(n, loadL, omega, c > 1.0e-3 ? c : 1.0e-3); nev++; }
             const int sgn_me = signbit(f) ? 1 : 0;
-            int sgn_before = __shfl_up(sgn_me, 1, 16);
+            int sgn_before = __shfl_up(sgn_me, 1, LPI);
             if (li == 0) sgn_before = sprev;
             // per lane: does the scan END at this point?  a sign change against the point before, or one of getsol's limits
             // once the scan has moved here without one (:463-479; the clamp at clow is handed back to the full search)
             const bool clampd = c <= cc;                                   // getsol would clamp here instead of evaluating
             const bool change = sgn_me != sgn_before && !clampd;
             const bool limit = clampd || c >= (double)bmx + dcs;
-            const unsigned long long mall = __ballot(walking && (change || limit));
-            const unsigned int mgrp = (unsigned int)((mall >> gbase) & 0xffffu);
-            if (walking && mgrp) {
-                const int first = __ffs((int)mgrp) - 1;                       // the group's first ending point
-                const unsigned long long mchange = __ballot(walking && change);
+            const unsigned long long gmask = LPI == 64 ? ~0ull : (((1ull << (LPI & 63)) - 1ull) << gbase);
+            const unsigned long long mend = __ballot(walking && (change || limit)) & gmask;
+            const unsigned long long mchange = __ballot(walking && change) & gmask;
+            if (walking && mend) {
+                const int first = __ffsll((long long)mend) - 1 - gbase;   // the group's first ending point
                 const bool by_change = ((mchange >> (gbase + first)) & 1ull) != 0;
-                const double cend = sk + (double)idir * (double)(round * 16 + first + 1) * dcs, cbefore = cend - (double)idir * dcs;
+                const double cend = sk + (double)idir * (double)(round * LPI + first + 1) * dcs, cbefore = cend - (double)idir * dcs;
                 bad = !by_change || !(fmin(cbefore, cend) < ck && ck < fmax(cbefore, cend));
                 walking = false;
             }
-            sprev = __shfl(sgn_me, gbase + 15, 64);
-            if (round == 24 && walking) { bad = true; walking = false; }
+            sprev = __shfl(sgn_me, gbase + LPI - 1, 64);
+            if (round == MAXR - 1 && walking) { bad = true; walking = false; }
         }
         if (live && bad && li == 0 && atomicExch(&W.need[chain], 1) == 0) {
-            W.list[atomicAdd(W.count, 1)] = chain;
+            W.list2[atomicAdd(W.count2, 1)] = chain;
             atomicAdd(&W.stats[0], 1ull);
             atomicAdd(&W.stats[9 + (k == 0 ? 2 : 0)], 1ull);
         }
