@@ -18,7 +18,12 @@ Synthetic sorted-prior models, dobs = forward(true model).
 
 A "step" = ONE LEAPFROG STEP OF EVERY CHAIN of the rank through the C ABI (rfs_flow_step: drift with mirror
 reflection, misfit + gradient evaluation, kick; pyhmc/hmc.py:164-183); state resident in HBM when the timed
-region starts.  value = leapfrog steps (= evaluations) of all ranks / max-over-ranks wall time.  Independent
+region starts.  value = leapfrog steps (= evaluations) of all ranks / max-over-ranks wall time.
+The JSON line of the default run (N = 1, configs[1]) also carries: `roofline` (the kernel group with the largest
+per-step sum), `valu_issue` (SQ_INSTS_VALU per step from the committed PMC passes against the measured time),
+`root_search` (items continued from the previous step, evaluations per item, chains handed back), `sampler_flow` (a real
+HamitonianMC run on the same chains, >= 2 s), `full_search_every_step` (the warm start off), `config4` / `config3`
+(short legs of the other single-GPU configurations, each with its own roofline) and `cpu_baseline`.  Independent
 chains shard across ranks (weak scaling, no data-path collective); the only collective is the RCCL gather of the
 per-chain misfits after the timed region (comm.Gather, main_base.py:90).
 """
