@@ -719,7 +719,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU; gloo)")
     ap.add_argument("--seed-rank", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--timeout", type=float, default=1500.0, help="seconds before the launcher gives up on its ranks")
-    ap.add_argument("--sustain", type=int, default=400, help="device steps of the sampler_flow leg (a real HamitonianMC run, >= 2 s)")
+    ap.add_argument("--sustain", type=int, default=500, help="device steps of the sampler_flow leg (a real HamitonianMC run, >= 2 s)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline leg (profiling runs)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] legs of the default run")
     ap.add_argument("--warm-start", type=int, default=None, choices=[0, 1], help="rfs_set_option swd_warm_start (default: library's, 1)")

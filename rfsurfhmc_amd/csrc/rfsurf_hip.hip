@@ -853,7 +853,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             const int* lists[2] = {c->wlist.as<int>(), c->wlist2.as<int>()};
             const int* counts[2] = {c->wneed.as<int>() + nchain, c->wneed.as<int>() + 2 * nchain + 2};
 #define RFS_LAUNCH_EIGEN_LIST(LOVE, SPH, QQ, SPHP, SFL, LI)                                                          \
-            hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
+            hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH, true>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
                                dim3(64), 0, warm_side, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(), \
                                SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (QQ).nper_total, 0, \
                                (int*)nullptr, lists[LI], counts[LI])

@@ -1253,7 +1253,8 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
 // whose 64 roots are not all final yet (zero = not written) leaves without a trace, one that is processed marks
 // edone[wave].  MOP-UP (early = 0, edone given): everything the early launch did not do.  nchain % 64 == 0 is
 // required when edone is used (a wavefront = 64 chains of one item).
-template <bool LOVE, bool SPH>
+// LIST (a template argument so that the two uses are two kernels in a profile): only the chains of a hand-back list
+template <bool LOVE, bool SPH, bool LIST = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
             const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
@@ -1262,11 +1263,11 @@ k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__
 {
     // list != nullptr: only the *count chains named there (the chains a warm-started search handed back to the full
     // search, whose roots have just been rewritten); the grid is sized for every chain
-    const int nsel = list ? *count : nchain;
+    const int nsel = LIST ? *count : nchain;
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (size_t)(el1 - el0) * nsel) return;
     int el = el0 + (int)(g / nsel), chain = (int)(g - (size_t)(el - el0) * nsel);
-    if (list) chain = list[chain];
+    if (LIST) chain = list[chain];
     int e = Q.s[0].croot_off + el;
     int seq = 0;
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
