@@ -254,6 +254,10 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          skips them: 42 % of the frequencies at nt = 512, dt = 0.1, f0 = 1.5, 85 % at nt = 2048,
  *                          dt = 0.025.  Default 13 (gradients agree with the unlimited sum to ~1e-13); 0 = no limit.
  *                          librf's kernel_all (rfs_rf_kernel_all) and the time-domain method are never limited.
+ *   "rf_band_floor_digits" a lane of the RF sweeps is a frequency and a wavefront 64 of them: where a multiple of 64 bins lies
+ *                          between the limits of "rf_band_floor_digits" (default 8) and "rf_band_limit_digits" the band
+ *                          ends there, so that no wavefront runs mostly idle (nt = 512, dt = 0.1, f0 = 1.5: 128 bins instead
+ *                          of 150; measured difference to the unlimited gradient 8e-16).  0 = never move the limit down.
  *   "swd_warm_start"       the root search inside a trajectory.  The reference searches every model from scratch, period
  *                          after period (surfdisp96.f:257-316: ~23 secular evaluations per period, each period starting
  *                          from the root before it).  Inside a leapfrog trajectory the model of step s is the model of
@@ -276,6 +280,9 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *   "swd_warm_reset"       (any value) forget the previous evaluation: the next one goes through the reference-semantics
  *                          search for every chain.  A sampler calls it where a run may be cut and resumed (a checkpoint),
  *                          so that the resumed run and the uninterrupted one evaluate the same way from there on.
+ *   "swd_warm_serial"      1: a warm-started step runs on ONE stream (every kernel alone on the chip: clean per-kernel
+ *                          durations for profiling); 0 (default): the surface-wave kernels on a second stream beside the
+ *                          receiver-function sweeps (~5 % faster).  Results are identical.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.
