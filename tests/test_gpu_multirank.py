@@ -58,8 +58,12 @@ def test_example_driver_two_ranks_share_the_gpu(tmp_path):
     pfile = tmp_path / "param.yaml"
     pfile.write_text(yaml.safe_dump(param))
     out2 = tmp_path / "two"
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "examples", "main_hmc.py"), "--param", str(pfile)],
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "examples", "main_hmc.py"), "--param", str(pfile)],
                        capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env=_env({"RFS_SHARED_GPU": "1", "RFS_OUTPUT_DIR": str(out2), "OMP_NUM_THREADS": "1"}))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
