@@ -59,3 +59,71 @@ def test_random_joint_configuration(orc, seed):
         assert abs(mh[i] - mo) <= 1e-5 * max(mo, 1e-12), (cfg, mh[i], mo)
         # group-velocity kernels difference two phase kernels 10 % apart in period: 2e-5 (see test_gpu_parity.py)
         assert rel(gh[i], go) < 2e-5, (cfg, rel(gh[i], go))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configuration_warm_started_against_the_full_search(seed):
+    """The same random configurations (2..25 layers, any subset of the Rc / Rg / Lc / Lg blocks -- also without Rc --, flat
+    or spherical, freq / time RF or none, odd chain counts) moved through a few leapfrog-like steps: the warm-started
+    sequence of evaluations (swd_warm_start = 2) against the history-free one at every step -- same flags, phase
+    velocities within 1.2e-6 c, group velocities within 2e-4 (test_gpu_warm.py), RF part unchanged."""
+    import torch
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(2, 26))
+    thk = 1.0 + 5.0 * rng.random(n); thk[-1] = 0.0
+    vs = np.sort(2.4 + 2.2 * rng.random(n))
+    x0 = np.hstack((vs, thk))
+    nper = int(rng.integers(1, 14))
+    t = np.sort(4.0 + 36.0 * rng.random(nper))
+    names = [k for k in ("tRc", "tRg", "tLc", "tLg") if rng.random() < 0.5] or ["tRg"]
+    blocks = {k: t for k in names}
+    sphere = bool(rng.random() < 0.4)
+    with_rf = rng.random() < 0.6
+    kw = dict(sphere=sphere, reference_periods=False, **blocks)
+    rfargs = (0.045, int(rng.integers(40, 160)), 0.2, 1.5, 4.0, 0.001, "P", "time" if rng.random() < 0.3 else "freq")
+
+    def make(warm):
+        s = SurfWD(**kw)
+        j = Joint_RF_SWD(1.0, 1.3, ReceiverFunc(*rfargs), s) if with_rf else s
+        j.set_warm_start(warm)
+        return j
+    jw, je = make(2), make(0)
+    d0 = je.forward(x0)
+    if with_rf:
+        assert d0[2]
+        jw.set_obsdata(d0[0], d0[1] * 1.01); je.set_obsdata(d0[0], d0[1] * 1.01)
+        nt = rfargs[1]
+    else:
+        assert d0[1]
+        jw.set_obsdata(d0[0] * 1.01); je.set_obsdata(d0[0] * 1.01)
+        nt = 0
+    nchain = int(rng.choice([1, 3, 37, 64, 130]))
+    xs = np.tile(x0, (nchain, 1)) * (1 + 0.02 * rng.standard_normal((nchain, 2 * n)))
+    xs[:, :n] = np.sort(xs[:, :n], axis=1); xs[:, -1] = 0.0
+    dev = torch.device("cuda")
+    x = torch.from_numpy(xs).to(dev); p = torch.from_numpy(0.5 * rng.standard_normal(xs.shape)).to(dev)
+    lo, hi = torch.from_numpy(0.7 * xs.min(0)).to(dev), torch.from_numpy(1.3 * xs.max(0) + 1e-9).to(dev)
+    cfg = (n, names, sphere, with_rf, rfargs[-1], nchain, nper)
+    order = [k for k in ("tRc", "tRg", "tLc", "tLg") if k in blocks]
+    for s in range(5):
+        mw, gw, dw, fw = jw.misfit_and_grad_device(x)
+        me, ge, de, fe = je.misfit_and_grad_device(x)
+        assert torch.equal(fw, fe), (cfg, s)
+        ok = fe != 0
+        if nt:
+            assert torch.equal(dw[:, :nt], de[:, :nt]), (cfg, s)                   # the RF part does not depend on the search
+        for b, name in enumerate(order):
+            a_, b_ = dw[ok][:, nt + b * nper: nt + (b + 1) * nper], de[ok][:, nt + b * nper: nt + (b + 1) * nper]
+            if a_.numel():
+                tol = 1.2e-6 if name in ("tRc", "tLc") else 2e-4
+                assert ((a_ - b_).abs() / b_.abs()).max().item() <= tol, (cfg, s, name)
+        g = torch.where(ok[:, None], gw, torch.zeros_like(gw))
+        p = p - 0.003 * g
+        x = x + 0.003 * p
+        for _ in range(3):
+            over, under = x > hi, x < lo
+            x = torch.where(over, 2 * hi - x, x); x = torch.where(under, 2 * lo - x, x)
+            p = torch.where(over | under, -p, p)
