@@ -31,7 +31,7 @@ typedef enum {
     RFS_ERR_ARG = -1,         /* bad argument (also: unsupported enum value) */
     RFS_ERR_HIP = -2,         /* HIP runtime / rocFFT failure */
     RFS_ERR_STATE = -3,       /* call out of order (e.g. joint eval before joint setup) */
-    RFS_ERR_UNSUPPORTED = -4  /* feature of the reference that is out of scope (time-domain RF longer than 4096 samples) */
+    RFS_ERR_UNSUPPORTED = -4  /* a request this library declines (see rfs_last_error; e.g. the forward quirk with unequal period blocks) */
 } rfs_status;
 
 /* wavetype codes of libsurf (src/SWD/main.cpp:17-24): strings "Rc","Rg","Lc","Lg" */
@@ -79,14 +79,20 @@ int rfs_synchronize(rfs_ctx* ctx);
  * Model arrays [nchain][nlayer] are rounded to float32 first, as the binding does (main.cpp:9).
  * c: [nchain][nper]; flag[chain] = 1 ok, 0 root search failed (ierr == 1); the c values of a failed chain are
  * unspecified (the reference returns whatever roots it found before giving up, surfdisp.cpp:93-100).
- * "Lg" searches with vp = 1.732 vs as _LoveGroup does (it ignores the caller's vp). */
+ * "Lg" searches with vp = 1.732 vs as _LoveGroup does (it ignores the caller's vp).
+ * Water layer: vs[0] <= 0 marks the top layer as a fluid (surfdisp96.f:138-139); the search then takes the reference's
+ * water branch (:201-206 start value, :870-886 the fluid layer; Love: the layers below it, :750).  A fluid layer anywhere
+ * else is as undefined here as in the reference (division by vs). */
 int rfs_swd_forward(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
                     const double* vs, const double* rho, int nper, const double* period,
                     int wavetype, int mode, int sphere, double* c, int32_t* flag);
 /* libsurf.adjoint_kernel(...) -> (c, dcda, dcdb, dcdr, dcdh, bool)
  * (src/SWD/main.cpp:61-82; _SurfKernel surfdisp.cpp:190-297; sregn96 / sregnpu
  * sregn96.f90:1637-1888; slegn96 / slegnpu slegn96.f90:672-919).  Kernel arrays: [nchain][nper][nlayer].
- * Love types: dcda is written as zeros (the reference leaves that array uninitialised, surfdisp.cpp:258-296). */
+ * Love types: dcda is written as zeros (the reference leaves that array uninitialised, surfdisp.cpp:258-296).
+ * Water layer on top (vs[0] <= 0): Rayleigh kernels from the fluid branches of sregn96 (sregn96.f90:555-575, 778-811,
+ * 858-877, 931-945, 1122-1140, 1245-1262, 1456-1509); dcdb of the water layer is 0 (never assigned there); Love
+ * kernels and Love group velocities are NaN, as the reference's are (slegn96 reads elements it never set). */
 int rfs_swd_kernel(rfs_ctx* ctx, int nchain, int nlayer, const double* thk, const double* vp,
                    const double* vs, const double* rho, int nper, const double* period,
                    int wavetype, int mode, int sphere, double* c, double* dcda, double* dcdb,

@@ -387,6 +387,47 @@ def gen_swd_modes(ref_surf, M):
     print("swd_modes_reference.npz:", len(g), "arrays")
 
 
+def water_models():
+    """Models with a water layer on top (vs = 0, the one fluid configuration surfdisp96 searches: :138-139, :870-886):
+    shallow shelf to deep ocean over crusts of 7 to 30 layers, one with a low-velocity zone under the sea floor."""
+    W = {}
+    def add(name, h, thk, vs, t, vpw=1.5, rhow=1.03):
+        vp, rho = emp(np.asarray(vs, dtype=np.float64))
+        W[name] = (np.concatenate(([h], thk)), np.concatenate(([vpw], vp)), np.concatenate(([0.0], vs)),
+                   np.concatenate(([rhow], rho)), np.asarray(t, dtype=np.float64))
+    add("shelf_0p2", 0.2, np.array([6., 6, 13, 5, 10, 30, 0]), np.array([3.2, 3.4, 3.46, 3.7, 3.9, 4.5, 4.7]), np.linspace(3, 40, 14))
+    add("ocean_2", 2.0, np.array([6., 6, 13, 5, 10, 30, 0]), np.array([3.2, 3.4, 3.46, 3.7, 3.9, 4.5, 4.7]), np.linspace(3, 40, 14))
+    add("ocean_4p5", 4.5, np.array([1., 2, 4, 8, 20, 0]), np.array([2.2, 3.4, 3.8, 4.3, 4.5, 4.7]), np.linspace(4, 60, 16), vpw=1.48, rhow=1.0)
+    add("ocean_lvz", 3.0, np.array([2., 3, 4, 6, 10, 20, 0]), np.array([3.0, 2.6, 3.3, 3.7, 4.0, 4.4, 4.6]), np.linspace(3, 50, 12))
+    n = 29
+    add("ocean_30", 1.5, np.r_[np.full(n - 1, 2.0), 0.0], np.linspace(2.8, 4.6, n), np.linspace(5, 44, 12))
+    add("sediment", 1.0, np.array([0.5, 1.5, 5, 10, 0]), np.array([0.8, 2.4, 3.4, 3.9, 4.5]), np.linspace(2, 25, 12))
+    return W
+
+
+def gen_swd_water(ref_surf):
+    """tests/golden/swd_water_reference.npz: the compiled reference on the water_models -- all four wave types'
+    forward values (flat and spherical, modes 0 and 1 for the phase types) and the Rayleigh kernels (Rc, Rg).  dcdb of the
+    water layer is not stored: the reference never assigns it (sregn96.f90:1122-1140 leave dcdb(m) as allocated).  Love
+    kernels are not stored either: slegn96 reads elements it never set for such a model and returns NaN."""
+    g = {}
+    for name, (thk, vp, vs, rho, t) in water_models().items():
+        for k, v in (("thk", thk), ("vp", vp), ("vs", vs), ("rho", rho), ("t", t)):
+            g[f"{name}/{k}"] = v
+        for wt in ("Rc", "Rg", "Lc", "Lg"):
+            for sph in (False, True):
+                for mode in ((0, 1) if wt[1] == "c" else (0,)):
+                    key = f"{name}/{wt}/{int(sph)}/m{mode}"
+                    c, flag = ref_surf.forward(thk, vp, vs, rho, t, wt, mode, sph)
+                    g[f"{key}/fwd_c"], g[f"{key}/fwd_flag"] = c, np.array(flag)
+                    if wt[0] == "R" and mode == 0:
+                        c, ka, kb, kr, kh, flag = ref_surf.adjoint_kernel(thk, vp, vs, rho, t, wt, mode, sph)
+                        g[f"{key}/c"], g[f"{key}/flag"] = c, np.array(flag)
+                        g[f"{key}/dcda"], g[f"{key}/dcdb_solid"], g[f"{key}/dcdr"], g[f"{key}/dcdh"] = ka, kb[:, 1:], kr, kh
+    np.savez_compressed(os.path.join(OUT, "swd_water_reference.npz"), **g)
+    print("swd_water_reference.npz:", len(g), "arrays")
+
+
 def gen_rf_full(M):
     """Only where oracle/_ref holds the reference's COMPLETE librf (FFTW3 present, oracle/Makefile): the same cases
     as gen_rf through the reference's own public entry points, frequency AND time method -- no numpy tail, so these
@@ -420,8 +461,11 @@ def main():
     M = models()
     if "--modes-only" in sys.argv:           # (added in round 3: leaves the other fixture files as they are)
         return gen_swd_modes(ref_surf, M)
+    if "--water-only" in sys.argv:
+        return gen_swd_water(ref_surf)
     gen_swd(ref_surf, M)
     gen_swd_modes(ref_surf, M)
+    gen_swd_water(ref_surf)
     gen_swd_wide(ref_surf, m_surf, M)
     gen_rf(ref_rf, M)
     gen_rf_full(M)

@@ -2,7 +2,8 @@
  * oracle/swd_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
  * Plain-C CPU restatement of the reference's Rayleigh-wave dispersion path
- * (flat earth, fundamental mode, no water layer), one function per reference
+ * (no water layer: the water branches are checked against fixtures of the compiled reference
+ * instead, tests/test_water.py), one function per reference
  * routine, each citing the file:line it follows under /root/reference:
  *
  *   src/SWD/surfdisp96.f   root search  (surfdisp96, gtsolh, getsol, nevill,

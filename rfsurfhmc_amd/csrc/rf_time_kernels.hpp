@@ -319,6 +319,145 @@ k_rft_deconv(int ntrace, int trace_per_chain, RfFreq f, const double* __restrict
     }
 }
 
+// Traces longer than 4096 samples (nft >= 8192): the lags of a trace no longer fit one wavefront's registers nor the
+// autocorrelation the LDS, so ONE BLOCK owns the trace -- thread t the lags t, t + blockDim, ... -- with cuw updated in
+// place in the c2r output it arrives in (scratch), the autocorrelation read through L2 and the arg-max combined
+// across the block's waves in LDS.  Same arithmetic, statement for statement, as k_rft_deconv; any power-of-two nft.
+template <bool WANT_P>
+__global__ void __launch_bounds__(1024)
+k_rft_deconv_big(int ntrace, int trace_per_chain, RfFreq f, double* __restrict__ cuw0ts, size_t cuw_stride,
+                 const double* __restrict__ awts, size_t aw_stride, const double* __restrict__ S0parts, int nS0,
+                 size_t s0_chain_stride, size_t s0_part_stride, const double* __restrict__ Cres,
+                 double* __restrict__ Pout, double* __restrict__ gout)
+{
+    __shared__ unsigned long long wkey[2][16];
+    __shared__ int widx[2][16];
+    __shared__ double wval[2][16];
+    const int trace = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    const int chain = trace / trace_per_chain, tl = trace - chain * trace_per_chain;
+    const int nft = f.nft, half = nft >> 1, mask = nft - 1;
+    const double dt = f.dt, inft = 1.0 / nft;
+    double* cu = cuw0ts + (size_t)trace * cuw_stride;
+    const double* aw = awts + (size_t)chain * aw_stride;
+    double* P = WANT_P ? Pout + (size_t)trace * half : nullptr;
+    double S0 = 0.0;
+    {
+        const double* sp = S0parts + (size_t)chain * s0_chain_stride + tl;
+        for (int p = 0; p < nS0; p++) S0 += sp[(size_t)p * s0_part_stride];
+        S0 = S0 * inft;
+    }
+    const double Aw0 = aw[0] * inft;
+    const double invpw = 1. / Aw0 / dt, invpu = 1. / S0 / dt;
+    for (int j = tid; j < half; j += blockDim.x) {
+        cu[j] = cu[j] * inft * dt;
+        if (WANT_P) P[j] = 0.0;
+    }
+    double S = S0, sumsq_i = 1.0, d_error = 100 * invpw + 0.001, gacc = 0.0;
+    const double rA = 1.0 / aw[0];
+    const double ka = invpw / dt, ks = dt * invpu;
+    for (int it = 0; it < 200; it++) {
+        if (fabs(d_error) <= 0.001) break;                        // block-uniform: every thread carries the same scalars
+        // first position of the largest |cuw|; |v| compared through its bit pattern (a NaN wins and ends the loop)
+        unsigned long long key = 0ull; int idx = -1; double val = 0.0;
+        for (int j = tid; j < half; j += blockDim.x) {
+            double v = cu[j];
+            unsigned long long k = (unsigned long long)__double_as_longlong(fabs(v));
+            if (k > key) { key = k; idx = j; val = v; }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            unsigned long long ok = __shfl_xor(key, off); int oi = __shfl_xor(idx, off); double ov = __shfl_xor(val, off);
+            if (ok > key || (ok == key && oi >= 0 && (idx < 0 || oi < idx))) { key = ok; idx = oi; val = ov; }
+        }
+        const int b = it & 1;
+        if (lane == 0) { wkey[b][wv] = key; widx[b][wv] = idx; wval[b][wv] = val; }
+        __syncthreads();
+        key = wkey[b][0]; int bj = widx[b][0]; double c = wval[b][0];
+        for (int w = 1; w < nw; w++) {
+            unsigned long long ok = wkey[b][w]; int oi = widx[b][w];
+            if (ok > key || (ok == key && oi >= 0 && (bj < 0 || oi < bj))) { key = ok; bj = oi; c = wval[b][w]; }
+        }
+        const double bv = __longlong_as_double((long long)key);
+        if (!(bv > 0.0)) break;
+        const double cr = Cres ? Cres[(size_t)chain * half + bj] : 0.0;
+        const double a = c * ka;
+        const double r = c * rA;
+        for (int j = tid; j < half; j += blockDim.x) cu[j] -= r * aw[(j - bj) & mask];
+        if (WANT_P && tid == 0) P[bj] += a;
+        gacc += a * cr;
+        S -= a * c;
+        double sumsq = S * ks;
+        d_error = 100. * (sumsq_i - sumsq);
+        sumsq_i = sumsq;
+    }
+    if (tid == 0 && gout) gout[trace] = gacc;
+}
+
+// k_rft_synth for nft >= 8192: the pulse read through L2, the (at most 200) spikes compacted into LDS in lag order
+__global__ void __launch_bounds__(256)
+k_rft_synth_big(int ntrace, RfFreq f, const double* __restrict__ P, const double* __restrict__ gshts,
+                double* __restrict__ out, size_t ostride)
+{
+    __shared__ double amp[256];
+    __shared__ int lag[256];
+    __shared__ int nsp;
+    const int nft = f.nft, half = nft >> 1, mask = nft - 1;
+    const int trace = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {
+        int m = 0;
+        const double* p = P + (size_t)trace * half;
+        for (int base = 0; base < half; base += 64) {
+            double v = p[base + tid];
+            unsigned long long bal = __ballot(v != 0.0);
+            int pos = m + __popcll(bal & ((1ull << tid) - 1ull));
+            if (v != 0.0 && pos < 256) { amp[pos] = v; lag[pos] = base + tid; }
+            m += __popcll(bal);
+        }
+        if (tid == 0) nsp = m < 256 ? m : 256;
+    }
+    __syncthreads();
+    const int m = nsp;
+    for (int t = tid; t < f.nt; t += blockDim.x) {
+        double s = 0.0;
+        for (int q = 0; q < m; q++) s += amp[q] * (gshts[(t - lag[q]) & mask] / nft);
+        out[(size_t)trace * ostride + t] = s;
+    }
+}
+
+// k_rft_resid_cres for nft >= 8192: the residual staged through LDS in tiles of 2048 samples, Cres accumulated in place
+// (the running sum of a lag continues from the stored value, so the summation order over t is unchanged)
+__global__ void __launch_bounds__(256)
+k_rft_resid_cres_big(RfFreq f, const double* __restrict__ dsyn, int ndata, const double* __restrict__ dobs,
+                     const double* __restrict__ gshts, double* __restrict__ misfit_rf, double* __restrict__ Cres)
+{
+    __shared__ double res[2048];
+    __shared__ double red[4];
+    const int nft = f.nft, half = nft >> 1, mask = nft - 1;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    for (int t0 = 0; t0 < f.nt; t0 += 2048) {
+        const int m = min(2048, f.nt - t0);
+        __syncthreads();
+        for (int t = tid; t < m; t += blockDim.x) {
+            double r = dsyn[(size_t)chain * ndata + t0 + t] - dobs[t0 + t];
+            res[t] = r; acc += r * r;
+        }
+        __syncthreads();
+        for (int i = tid; i < half; i += blockDim.x) {
+            double s = t0 ? Cres[(size_t)chain * half + i] : 0.0;
+            for (int t = 0; t < m; t++) s += (gshts[(t0 + t - i) & mask] / nft) * res[t];
+            Cres[(size_t)chain * half + i] = s;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+        misfit_rf[chain] = 0.5 * s;
+    }
+}
+
 // out[trace][t] = sum_j P[j] gsh[(t - j) mod nft], t < nt  (apply_gaussian + shift_data of the spike train)
 // gshts: c2r output of the pulse spectrum (unnormalised).  out row stride = ostride.
 __global__ void __launch_bounds__(256)

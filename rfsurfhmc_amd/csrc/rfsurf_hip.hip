@@ -91,6 +91,7 @@ struct rfs_ctx {
     Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2;
     hipEvent_t ev_w[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
+    bool swd_water_cur = false;           // the batch being launched holds models with a water layer on top (B1 entries)
     int warm_nitems = 0;       // (sequence, period) items of the joint configuration's evaluation
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
@@ -227,8 +228,6 @@ int make_partition_streams(rfs_ctx* c) {
 int check_rf(rfs_ctx* c, const rfs_rf_params* p) {
     if (!p) return fail(c, RFS_ERR_ARG, "rf params missing");
     if (p->method != RFS_RF_TIME && p->method != RFS_RF_FREQ && p->method != RFS_RF_TIME_PAR) return fail(c, RFS_ERR_ARG, "bad rf method");
-    if (p->method != RFS_RF_FREQ && rf_nextpow2(p->nt) > 4096)
-        return fail(c, RFS_ERR_UNSUPPORTED, "time-domain RF: at most 4096 samples");
     if (p->rf_type != RFS_RF_P && p->rf_type != RFS_RF_S) return fail(c, RFS_ERR_ARG, "rf_type should be one of [P,p,S,s]");
     if (p->nt < 2 || p->dt <= 0 || p->ray_p <= 0) return fail(c, RFS_ERR_ARG, "bad rf scalars");
     return RFS_OK;
@@ -377,6 +376,15 @@ template <int WPB>
 int rft_launch_deconv(rfs_ctx* c, int ntrace, int tpc, const RfFreq& f, const double* cuw0, size_t cuw_stride,
                       const double* aw, size_t aw_stride, const double* S0, int nS0, size_t s0c, size_t s0p,
                       const double* Cres, double* Pout, double* gout) {
+    if (f.nft > 4096) {                  // one block per trace, lags in place (k_rft_deconv_big)
+        const int bt = (int)std::min<size_t>(1024, (size_t)f.nft / 2);
+        if (Pout) hipLaunchKernelGGL(k_rft_deconv_big<true>, dim3(ntrace), dim3(bt), 0, c->stream, ntrace, tpc, f, const_cast<double*>(cuw0),
+                                     cuw_stride, aw, aw_stride, S0, nS0, s0c, s0p, Cres, Pout, gout);
+        else hipLaunchKernelGGL(k_rft_deconv_big<false>, dim3(ntrace), dim3(bt), 0, c->stream, ntrace, tpc, f, const_cast<double*>(cuw0),
+                                cuw_stride, aw, aw_stride, S0, nS0, s0c, s0p, Cres, Pout, gout);
+        HIPCHK(c, hipGetLastError());
+        return RFS_OK;
+    }
     int npl = f.nft / 128; if (npl < 1) npl = 1;
     dim3 grid((ntrace + WPB - 1) / WPB), block(64 * WPB);
     size_t lds = ((size_t)2 * f.nft + (Cres ? f.nft / 2 : 0)) * sizeof(double);
@@ -420,6 +428,9 @@ int rft_forward(rfs_ctx* c, int nchain, const RfFreq& f, double* out, size_t ost
     TRY(rft_launch_deconv<1>(c, nchain, 1, f, c->ts3.as<double>() + nft, 3 * nft, c->ts3.as<double>(), 3 * nft,
                              c->S0f.as<double>(), 1, 1, 0, nullptr, c->Pbuf.as<double>(), nullptr));
     size_t lds = (nft + half + half / 2 + 1) * sizeof(double);
+    if (nft > 4096) hipLaunchKernelGGL(k_rft_synth_big, dim3(nchain), dim3(256), 0, c->stream, nchain, f, c->Pbuf.as<double>(),
+                                       c->pulse_ts.as<double>(), out, ostride);
+    else
     hipLaunchKernelGGL(k_rft_synth, dim3(nchain), dim3(256), lds, c->stream, nchain, f, c->Pbuf.as<double>(),
                        c->pulse_ts.as<double>(), out, ostride);
     HIPCHK(c, hipGetLastError());
@@ -457,6 +468,9 @@ int rft_partials(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* C
                                  kl ? c->Pbuf.as<double>() : nullptr, PG ? PG + (size_t)c0 * ntr : nullptr));
         if (kl) {
             size_t lds = (nft + half + half / 2 + 1) * sizeof(double);
+            if (nft > 4096) hipLaunchKernelGGL(k_rft_synth_big, dim3((unsigned)(nc * ntr)), dim3(256), 0, c->stream, (int)(nc * ntr), f,
+                               c->Pbuf.as<double>(), c->pulse_ts.as<double>(), kl + (size_t)c0 * ntr * f.nt, (size_t)f.nt);
+            else
             hipLaunchKernelGGL(k_rft_synth, dim3((unsigned)(nc * ntr)), dim3(256), lds, c->stream, (int)(nc * ntr), f,
                                c->Pbuf.as<double>(), c->pulse_ts.as<double>(), kl + (size_t)c0 * ntr * f.nt, (size_t)f.nt);
             HIPCHK(c, hipGetLastError());
@@ -755,6 +769,19 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
     // the Rayleigh one (a fifth active stream inside the partitioned step would share a hardware queue)
     // -- inside it the Love search goes to the RF half's stream, ahead of the RF sweeps: the Rayleigh search keeps its half
+    if (roots && c->swd_water_cur && c->swd_mode_cur == 0) {
+        // models with a water layer on top (vs(1) = 0, surfdisp96.f:138-139): the lane-per-item kernel, whose secular
+        // functions carry the reference's water branch (:870-886; Love: the layers below the water, :750)
+        KTimer t(c, RFS_K_SWD_ROOTS, s);
+        if (Q.nseq > 0)
+            hipLaunchKernelGGL((k_swd_roots<false, false>), dim3((Q.nseq * nchain + 63) / 64), dim3(64), 0, s, nchain, n, Q, mdlR,
+                               c->croot.as<double>(), c->sflag.as<int>(), (const int*)nullptr, (const int*)nullptr, (double*)nullptr, 1);
+        if (P.QL.nseq > 0)
+            hipLaunchKernelGGL((k_swd_roots<true, false>), dim3((P.QL.nseq * nchain + 63) / 64), dim3(64), 0, s, nchain, n, P.QL,
+                               c->mdlL.as<float>(), c->croot.as<double>(), sflagL, (const int*)nullptr, (const int*)nullptr, (double*)nullptr, 1);
+        HIPCHK(c, hipGetLastError());
+        roots = false;
+    }
     if (roots && c->swd_mode_cur > 0) {
         // higher modes (libsurf's `mode` argument): the mode loop runs inside the lane-per-item kernel's state machine
         // (latency form only: B1 calls and plugins with SurfWD(mode = ...); not a bench configuration)
@@ -826,11 +853,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         ENSURE(c, c->ugr, ntot * sizeof(double));
         {   // (timed group: the launches of this stream only -- the wait for the side stream below is not kernel time)
         KTimer t(c, eigen_mode == 1 ? -1 : RFS_K_SWD_EIGEN, s);     // the early launch hides behind the search: not timed
-#define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                                \
-        hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)),            \
+#define RFS_LAUNCH_EIGEN2(LOVE, SPH, WAT, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                          \
+        hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH, false, WAT>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)), \
                            dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(),     \
                            SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (int)(EL1), EARLY, EDONE, \
                            (const int*)nullptr, (const int*)nullptr)
+#define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                                \
+        do { if (c->swd_water_cur) RFS_LAUNCH_EIGEN2(LOVE, SPH, true, QQ, SPHP, SFL, EL1, EARLY, EDONE);              \
+             else RFS_LAUNCH_EIGEN2(LOVE, SPH, false, QQ, SPHP, SFL, EL1, EARLY, EDONE); } while (0)
         int* ed = (eigen_mode == 1 || eigen_mode == 2) ? c->edone.as<int>() : nullptr;
         if (P.QR.nper_total > 0 && eigen_mode != 4) {
             const int el1 = eigen_mode == 1 ? early_items : P.QR.nper_total;
@@ -843,6 +873,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             else RFS_LAUNCH_EIGEN(true, false, P.QL, nullptr, sflagL, P.QL.nper_total, 0, (int*)nullptr);
         }
 #undef RFS_LAUNCH_EIGEN
+#undef RFS_LAUNCH_EIGEN2
         HIPCHK(c, hipGetLastError());
         }
         if (warm_side) {
@@ -1098,6 +1129,11 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                 if (!rc) rc = ensure(c, c->Cres, (size_t)nchain * (c->f.nft / 2) * sizeof(double));
                 if (!rc) {
                     size_t lds = ((size_t)c->f.nft + c->f.nt) * sizeof(double);
+                    if (c->f.nft > 4096)
+                        hipLaunchKernelGGL(k_rft_resid_cres_big, dim3(nchain), dim3(256), 0, c->stream, c->f, ds, c->ndata,
+                                           c->d_dobs.as<double>(), c->pulse_ts.as<double>(), c->mrf.as<double>(),
+                                           c->Cres.as<double>());
+                    else
                     hipLaunchKernelGGL(k_rft_resid_cres, dim3(nchain), dim3(256), lds, c->stream, c->f, ds, c->ndata,
                                        c->d_dobs.as<double>(), c->pulse_ts.as<double>(), c->mrf.as<double>(),
                                        c->Cres.as<double>());
@@ -1374,8 +1410,10 @@ static int swd_b1(rfs_ctx* c, int nchain, int nlayer, const double* thk, const d
     TRY(launch_family_prep(c, c->stream, nchain, n, P, sphere));
     c->warm_primed = false;
     c->swd_mode_cur = mode;
+    c->swd_water_cur = false;
+    for (int ch = 0; ch < nchain; ch++) c->swd_water_cur = c->swd_water_cur || (float)vs[(size_t)ch * n] <= 0.0f;
     const int rc_swd = launch_swd(c, c->stream, nchain, n, P, kernels || rg);
-    c->swd_mode_cur = 0;
+    c->swd_mode_cur = 0; c->swd_water_cur = false;
     TRY(rc_swd);
     size_t cb = (size_t)nchain * nper * sizeof(double), kb = cb * n;
     ENSURE(c, c->b1e, cb);

@@ -1187,13 +1187,25 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 // the interface partial -- and U.  LOVE: slegn96 (alpha kernel = 0); SPH: f64 bldsph model.
 // Scratch / outputs are indexed by the GLOBAL item e (both families share croot, krn, ugr, cds).
 // ---------------------------------------------------------------------------------------
-template <bool LOVE, class Mdl>
+// WATER: the top layer may be a fluid (vs = 0).  Rayleigh: the fluid branches of sregn96 (swd_math.hpp).  Love: slegn96
+// reads array elements it never assigned for such a model (uu(1), exl(1): slegn96.f90:211-222 after :417) and the
+// compiled reference returns NaN kernels and NaN group velocities -- so does this (phase velocities are the search's).
+template <bool LOVE, bool WATER, class Mdl>
 __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, size_t ntot, double t, double cp,
                                                double* __restrict__ sc, double* __restrict__ ko,
                                                double* __restrict__ uout)
 {
     const size_t s = (size_t)n * nchain;
     const double omega = 2.0 * SR_PI32 / t, wvno = omega / cp;
+    if (LOVE && WATER && M.B(0) <= 0.0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int m = 0; m < n; m++) {
+            ko[0 * s + (size_t)m * nchain] = 0.0; ko[1 * s + (size_t)m * nchain] = qnan;
+            ko[2 * s + (size_t)m * nchain] = qnan; ko[3 * s + (size_t)m * nchain] = qnan;
+        }
+        *uout = qnan;
+        return;
+    }
     if (LOVE) {
         sl_up(M, omega, wvno, [&](int m, double uu, double tt, double exl) {
             double* o = sc + (size_t)m * 6 * ntot;
@@ -1221,7 +1233,7 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
             for (int i = 0; i < 5; i++) o[(size_t)i * ntot] = cd[i];
             o[(size_t)5 * ntot] = exe;
         };
-        sr_up(M, omega, wvno, store);
+        sr_up<WATER>(M, omega, wvno, store);
         auto load = [&](int m, double* cd, double& exe) {
             const double* o = sc + (size_t)m * 6 * ntot;
 #pragma unroll
@@ -1232,7 +1244,7 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
             ko[0 * s + (size_t)m * nchain] = da; ko[1 * s + (size_t)m * nchain] = db;
             ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
         };
-        SrTotals R = sr_down_energy(M, omega, wvno, load, emit);
+        SrTotals R = sr_down_energy<WATER>(M, omega, wvno, load, emit);
         double sca = 1.0 / (R.ugr * R.sumi0);
         for (int m = 0; m < n; m++) {
             ko[0 * s + (size_t)m * nchain] *= sca; ko[1 * s + (size_t)m * nchain] *= sca;
@@ -1254,7 +1266,7 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
 // edone[wave].  MOP-UP (early = 0, edone given): everything the early launch did not do.  nchain % 64 == 0 is
 // required when edone is used (a wavefront = 64 chains of one item).
 // LIST (a template argument so that the two uses are two kernels in a profile): only the chains of a hand-back list
-template <bool LOVE, bool SPH, bool LIST = false>
+template <bool LOVE, bool SPH, bool LIST = false, bool WATER = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
             const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
@@ -1288,10 +1300,10 @@ k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__
     double* ko = krn + (size_t)e * 4 * s + chain;       // [e][q][m][chain]
     if (SPH) {
         SwdModelD M{sph + chain, sph + s + chain, sph + 2 * s + chain, sph + 3 * s + chain, nchain, n};
-        swd_eigen_lane<LOVE>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
+        swd_eigen_lane<LOVE, WATER>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
     } else {
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
-        swd_eigen_lane<LOVE>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
+        swd_eigen_lane<LOVE, WATER>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
     }
     if (early && (threadIdx.x & 63) == 0) edone[widx] = 1;
 }

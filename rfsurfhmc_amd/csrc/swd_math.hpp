@@ -72,7 +72,8 @@ RFS_HD double swd_secular_love(const SwdModel& M, double wvno, double omega) {
     double xkb = omega / beta1;
     double rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
     double e1 = rho1 * rb, e2 = 1.0 / (beta1 * beta1);
-    for (int m = last - 1; m >= 0; m--) {
+    const int llw = (M.B(0) <= 0.0) ? 1 : 0;        // water on top (surfdisp96.f:138-139): SH waves stop at its base (:750)
+    for (int m = last - 1; m >= llw; m--) {
         beta1 = M.B(m); rho1 = M.R(m);
         double xmu = rho1 * beta1 * beta1;
         xkb = omega / beta1;
@@ -120,7 +121,8 @@ RFS_HD double swd_secular(const SwdModel& M, double wvno, double omga) {
         e3 = rho1 * rb;
         e4 = wvno2 - ra * rb;
     }
-    for (int m = last - 1; m >= 0; m--) {
+    const int llw = (M.B(0) <= 0.0) ? 1 : 0;        // water on top, surfdisp96.f:138-139
+    for (int m = last - 1; m >= llw; m--) {
         double xka = omega / M.A(m), xkb = omega / M.B(m);
         double t = M.B(m) / omega;
         double gammk = 2.0 * t * t, gam = gammk * wvno2;
@@ -188,6 +190,22 @@ RFS_HD double swd_secular(const SwdModel& M, double wvno, double omga) {
         double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
         if (t1 < 1.0e-40) t1 = 1.0;
         e0 = n0 / t1; e1 = n1 / t1; e2 = n2 / t1; e3 = n3 / t1; e4 = n4 / t1;
+    }
+    if (llw) {                                       // the water layer, surfdisp96.f:870-886 (only the P part of var)
+        double xka = omega / M.A(0);
+        double ra = sqrt((wvno + xka) * fabs(wvno - xka));
+        double dpth = M.D(0), p = ra * dpth, cosp, w;
+        if (wvno < xka) {
+            double s, c; sincos(p, &s, &c);
+            w = s / ra; cosp = c;
+        } else if (wvno == xka) {
+            cosp = 1.0; w = dpth;
+        } else {
+            double fac = (p < 16.0) ? exp(-2.0 * p) : 0.0;
+            cosp = (1.0 + fac) * 0.5;
+            w = ((1.0 - fac) * 0.5) / ra;
+        }
+        return cosp * e0 + (-M.R(0) * w) * e1;
     }
     return e0;
 }
@@ -947,6 +965,36 @@ RFS_HD double sr_haskell_step(double vv[4], const SvTrig& t, float rhof, float b
     return log(t1);
 }
 
+// The same two steps through a FLUID layer (dnka :555-575, hska :931-945; varsv's fluid branch :858-877 is the P
+// half of the elastic one): cosp, rsinp, sinpr, pex from sv_trig_one.
+RFS_HD double sr_compound_step_fluid(double cd[5], double cosp, double rsinp, double sinpr, double pex, float rhof, double om2) {
+    const double dfac = (pex > 35.0) ? 0.0 : fm_exp(-pex);
+    const double rom = (double)rhof * om2;
+    const double c12 = -rsinp / rom, c21 = -(double)rhof * sinpr * om2;
+    double n0 = cd[0] * cosp + cd[1] * c21;
+    double n1 = cd[0] * c12 + cd[1] * cosp;
+    double n2 = cd[2] * dfac;
+    double n3 = cd[3] * cosp + cd[4] * c21;
+    double n4 = cd[3] * c12 + cd[4] * cosp;
+    double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    cd[0] = n0 / t1; cd[1] = n1 / t1; cd[2] = n2 / t1; cd[3] = n3 / t1; cd[4] = n4 / t1;
+    return log(t1);
+}
+RFS_HD double sr_haskell_step_fluid(double vv[4], double cosp, double rsinp, double sinpr, double pex, float rhof, double om2) {
+    const double dfac = (pex > 35.0) ? 0.0 : fm_exp(-pex);
+    const double rom = (double)rhof * om2;
+    const double a23 = -rsinp / rom, a32 = -rom * sinpr;
+    double n0 = dfac * vv[0];
+    double n1 = cosp * vv[1] + a23 * vv[2];
+    double n2 = a32 * vv[1] + cosp * vv[2];
+    double n3 = dfac * vv[3];
+    double t1 = fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3)));
+    if (t1 < 1.0e-40) t1 = 1.0;
+    vv[0] = n0 / t1; vv[1] = n1 / t1; vv[2] = n2 / t1; vv[3] = n3 / t1;
+    return log(t1);
+}
+
 // Half-space compound vector (evalg, jbdry=0, elastic: sregn96.f90:760-776), real parts (up :442-446).
 RFS_HD void sr_halfspace_vector(double a, double b, double rho, double wvno, double om, double cd[5]) {
     double wvno2 = wvno * wvno, om2 = om * om;
@@ -967,7 +1015,8 @@ RFS_HD void sr_halfspace_vector(double a, double b, double rho, double wvno, dou
 }
 
 // Up-sweep (sregn96.f90:404-492): Store(m, cd[5], exe) is called for m = n-1 .. 0.
-template <class Mdl, class StoreFn>
+// WATER: the top layer may be a fluid (vs = 0: the one place surfdisp96 can find roots for, :138-139, :870-886).
+template <bool WATER = false, class Mdl, class StoreFn>
 RFS_HD void sr_up(const Mdl& M, double omega, double wvno, const StoreFn& store) {
     const int n = M.n;
     double wvno2 = wvno * wvno, om2 = omega * omega;
@@ -976,6 +1025,15 @@ RFS_HD void sr_up(const Mdl& M, double omega, double wvno, const StoreFn& store)
     double exsum = 0.0;
     store(n - 1, cd, 0.0);
     for (int m = n - 2; m >= 0; m--) {
+        if (WATER && m == 0 && M.B(0) <= 0.0) {
+            const double xka = omega / M.A(0);
+            double cosp, rsinp, sinpr, pex;
+            sv_trig_one(wvno2 - xka * xka, M.D(0), cosp, rsinp, sinpr, pex);
+            double exn = sr_compound_step_fluid(cd, cosp, rsinp, sinpr, pex, M.Rf(0), om2);
+            exsum = exsum + pex + exn;
+            store(m, cd, exsum);
+            continue;
+        }
         SvTrig t;
         sv_trig(wvno2, omega, M.A(m), M.B(m), M.D(m), t);
         double exn = sr_compound_step(cd, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
@@ -1061,8 +1119,23 @@ RFS_HD void sr_layer_integrals(double a, double b, double rho, double d, bool ha
 // (m == 0: "above" is vacuum).
 RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, double lam_m,
                                 double rho_u, double mu_u, double lam_u, const Eig4& u,
-                                double om2, double wvno, double wvno2) {
+                                double om2, double wvno, double wvno2, bool fluid_above = false) {
     double tur = u.ur, tuz = u.uz, ttz = u.tz, ttr = u.tr;
+    if (fluid_above) {                       // solid under the water layer: Ur jumps across the interface, :1504-1508
+        const double xl2mp = lam_m + mu_m + mu_m, xl2mm = lam_u + mu_u + mu_u;
+        const double duzdzp = (ttz + wvno * lam_m * tur) / xl2mp;
+        const double durdzp = (ttr / mu_m) - wvno * tuz;
+        const double urb = -wvno * ttz / (rho_u * om2);
+        const double drur2 = tur * tur * rho_m - urb * urb * rho_u;
+        const double dlur2 = tur * tur * xl2mp - urb * urb * xl2mm;
+        const double duzdzm = (ttz + wvno * lam_u * urb) / lam_u;
+        const double durdzm = wvno * tuz;
+        const double g1 = om2 * (rho_m - rho_u) * tuz * tuz, g2 = om2 * drur2;
+        const double g3 = -wvno2 * (mu_m - mu_u) * tuz * tuz, g4 = -wvno2 * dlur2;
+        const double g5 = xl2mp * duzdzp * duzdzp - xl2mm * duzdzm * duzdzm;
+        const double g6 = mu_m * durdzp * durdzp - mu_u * durdzm * durdzm;
+        return g1 + g2 + g3 + g4 + g5 + g6;
+    }
     double xl2mp = lam_m + mu_m + mu_m;
     double duzdzp = (ttz + wvno * lam_m * tur) / xl2mp;
     double durdzp = (mu_m == 0.0) ? wvno * tuz : (ttr / mu_m) - wvno * tuz;
@@ -1093,7 +1166,7 @@ RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, dou
 // the returned (ugr, sumi0, fac) -- see sr_finish_scale.
 struct SrTotals { double ugr, sumi0, fac; };
 
-template <class Mdl, class LoadFn, class EmitFn>
+template <bool WATER = false, class Mdl, class LoadFn, class EmitFn>
 RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const LoadFn& load,
                                const EmitFn& emit) {
     const int n = M.n;
@@ -1102,6 +1175,8 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
     load(0, cd, exe0);
     const double f1213 = -cd[1];
     Eig4 top{cd[2] / cd[1], 1.0, 0.0, 0.0};
+    const bool wat0 = WATER && M.B(0) <= 0.0;
+    if (wat0) top.ur = 0.0;                  // svfunc :319-330 (Ur, Tr of the fluid's top), energy :1140 (Ur from Tz = 0)
     double vv[4] = {1.0, 0.0, 0.0, 0.0};
     double exa = 0.0;
     double sumi0 = 0.0, sumi1 = 0.0, sumi2 = 0.0, sumi3 = 0.0;
@@ -1111,11 +1186,20 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
         double a = M.A(m), b = M.B(m), rho = M.R(m), d = M.D(m);
         double mu = rho * (b * b), lam = rho * (a * a) - 2 * mu;
         Eig4 bot = top;
+        const bool fluid = wat0 && m == 0;
         if (!half) {
-            SvTrig t;
-            sv_trig(wvno2, omega, a, b, d, t);
-            double ex2 = sr_haskell_step(vv, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
-            exa = exa + t.pex + ex2;
+            if (fluid) {
+                const double xka = omega / a;
+                double cosp, rsinp, sinpr, pex;
+                sv_trig_one(wvno2 - xka * xka, d, cosp, rsinp, sinpr, pex);
+                double ex2 = sr_haskell_step_fluid(vv, cosp, rsinp, sinpr, pex, M.Rf(m), om2);
+                exa = exa + pex + ex2;
+            } else {
+                SvTrig t;
+                sv_trig(wvno2, omega, a, b, d, t);
+                double ex2 = sr_haskell_step(vv, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
+                exa = exa + t.pex + ex2;
+            }
             load(m + 1, cd, exe_m);
             // svfunc :283-315
             double cd1 = cd[0], cd2 = cd[1], cd3 = cd[2], cd4 = -cd[2], cd5 = cd[3], cd6 = cd[4];
@@ -1131,6 +1215,33 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
             } else {
                 bot = Eig4{0.0, 0.0, 0.0, 0.0};
             }
+        }
+        if (fluid) {
+            // fluid layer: 2 x 2 potentials (evalg :800-811, intijr :1245-1262), getmat :1551-1565, energy :1122-1140
+            const double xka = omega / a, rom = rho * om2;
+            const cplx ra = csqrt_p(C(wvno2 - xka * xka)), ira = inv(ra);
+            const cplx km1pd = (-0.5 * top.uz) * ira - C(0.5 / rom * top.tz);
+            const cplx kmpu = (0.5 * bot.uz) * ira - C(0.5 / rom * bot.tz);
+            const cplx ea = (ra.re * d < 75.0) ? cexp_p(-(d * ra)) : C(0.0);
+            const cplx ea40 = (ra.re * d < 40.0) ? ea : C(0.0);
+            const cplx FA = (sqrt(norm2(ra)) < 1.0e-8) ? C(d) : (1.0 - ea40 * ea40) * (0.5 * ira);
+            const cplx GA = d * ea;
+            const cplx uu = kmpu * kmpu * FA, ud = kmpu * km1pd * GA, dd = km1pd * km1pd * FA;
+            const double i11 = (ra * ra * (uu - 2.0 * ud + dd)).re;          // e(1,1) = ra, e(1,2) = -ra
+            const double i22 = (rom * rom) * (uu + 2.0 * ud + dd).re;        // e(2,1) = e(2,2) = -rho om2
+            const double TA = rho * a * a, a12 = -(wvno2 - om2 / (a * a)) / rom, kr = wvno / rom;
+            const double URUR = i22 * kr * kr, UZUZ = i11, URDUZ = -kr * a12 * i22, DUZDUZ = a12 * a12 * i22;
+            sumi0 += rho * (URUR + UZUZ);
+            sumi1 += TA * URUR;
+            sumi2 -= TA * URDUZ;                                             // TF = TA (TN = 0)
+            sumi3 += TA * DUZDUZ;
+            const double facah = rho * a * (URUR - 2. * URDUZ / wvno), facav = rho * a * DUZDUZ / wvno2;
+            const double facr = -0.5 * c * c * (URUR + UZUZ);
+            const double dh = sr_interface_term(true, rho, mu, lam, 0.0, 0.0, 0.0, top, om2, wvno, wvno2);
+            emit(m, facah + facav, 0.0, 0.5 * (a * facav + a * facah) / rho + facr, dh);     // (dcdb: never assigned there)
+            rho_u = rho; mu_u = mu; lam_u = lam;
+            top = bot;
+            continue;
         }
         LayerInt I;
         sr_layer_integrals(a, b, rho, d, half, wvno, omega, top, bot, I);
@@ -1152,7 +1263,7 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
         double facr = -0.5 * c * c * (URUR + UZUZ);
         double da = facah + facav, db = facbv;
         double dr = 0.5 * (a * facav + a * facah + b * facbv) / rho + facr;
-        double dh = sr_interface_term(m == 0, rho, mu, lam, rho_u, mu_u, lam_u, top, om2, wvno, wvno2);
+        double dh = sr_interface_term(m == 0, rho, mu, lam, rho_u, mu_u, lam_u, top, om2, wvno, wvno2, wat0 && m == 1);
         emit(m, da, db, dr, dh);
         rho_u = rho; mu_u = mu; lam_u = lam;
         top = bot;

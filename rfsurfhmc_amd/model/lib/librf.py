@@ -7,7 +7,8 @@ Both methods: "time" (iterative time-domain deconvolution, the reference's defau
 "freq" (water-level spectral division), as src/RF/main.cpp:43,115,168 dispatch.
 
 Deliberate differences: bad rf_type / par_type raise ValueError instead of exit(-1)
-(main.cpp:40,101,162); time-domain traces longer than 4096 samples raise RfsError."""
+(main.cpp:40,101,162); traces of any length (those longer than 4096 samples take a
+block-per-trace deconvolution kernel)."""
 import numpy as np
 
 from ..._lib import RfParams, default_context, hptr

@@ -101,11 +101,11 @@ double hs_sregn96(int n, const float* thk, const float* vp, const float* vs, con
     SwdModel M{thk, vp, vs, rho, 1, n};
     std::vector<double> cds(6 * n);
     double omega = 2.0 * SR_PI32 / t, wvno = omega / cp;
-    sr_up(M, omega, wvno, [&](int m, const double* cd, double exe) {
+    sr_up<true>(M, omega, wvno, [&](int m, const double* cd, double exe) {         // (<true>: a water top layer is allowed)
         for (int i = 0; i < 5; i++) cds[6 * m + i] = cd[i];
         cds[6 * m + 5] = exe;
     });
-    SrTotals T = sr_down_energy(M, omega, wvno,
+    SrTotals T = sr_down_energy<true>(M, omega, wvno,
         [&](int m, double* cd, double& exe) { for (int i = 0; i < 5; i++) cd[i] = cds[6 * m + i]; exe = cds[6 * m + 5]; },
         [&](int m, double da, double db, double dr, double dh) { dcda[m] = da; dcdb[m] = db; dcdr[m] = dr; dcdh[m] = dh; });
     double s = 1.0 / (T.ugr * T.sumi0);
@@ -175,11 +175,11 @@ static double rayleigh_flat_kernels(const Mdl& M, int n, double omega, double wv
                                     double* dcdh, double* dcdr)
 {
     std::vector<double> cds(6 * n);
-    sr_up(M, omega, wvno, [&](int m, const double* cd, double exe) {
+    sr_up<true>(M, omega, wvno, [&](int m, const double* cd, double exe) {         // (<true>: a water top layer is allowed)
         for (int i = 0; i < 5; i++) cds[6 * m + i] = cd[i];
         cds[6 * m + 5] = exe;
     });
-    SrTotals T = sr_down_energy(M, omega, wvno,
+    SrTotals T = sr_down_energy<true>(M, omega, wvno,
         [&](int m, double* cd, double& exe) { for (int i = 0; i < 5; i++) cd[i] = cds[6 * m + i]; exe = cds[6 * m + 5]; },
         [&](int m, double da, double db, double dr, double dh) { dcda[m] = da; dcdb[m] = db; dcdr[m] = dr; dcdh[m] = dh; });
     double s = 1.0 / (T.ugr * T.sumi0);

@@ -150,8 +150,6 @@ def test_argument_errors_are_reported_not_fatal():
     t = np.array([5.0, 10.0])
     assert L.rfs_joint_setup(ctx.h, 40, None, 2, hptr(t), 0, None, 1.0, 1.0, None) == -1                    # > max_layers
     assert L.rfs_joint_setup(ctx.h, 4, None, 0, None, 0, None, 1.0, 1.0, None) == -1                        # no data at all
-    par = RfParams(0.05, 8192, 0.2, 1.5, 2.0, 0.001, 1, 0)                                                  # method "time", > 4096 samples
-    assert L.rfs_joint_setup(ctx.h, 4, ctypes.byref(par), 0, None, 0, None, 1.0, 1.0, None) == -4
     par = RfParams(0.05, 64, 0.2, 1.5, 2.0, 0.001, 1, 5)                                                    # unknown method
     assert L.rfs_joint_setup(ctx.h, 4, ctypes.byref(par), 0, None, 0, None, 1.0, 1.0, None) == -1
     par = RfParams(0.05, 64, 0.2, 1.5, 2.0, 0.001, 1, 0)

@@ -113,10 +113,12 @@ def test_plugin_time_misfit_and_grad(hip, orc):
         assert abs(m1[i] - m0) <= 1e-5 * m0 and rel(g1[i], g0) < 1e-5
 
 
-@pytest.mark.parametrize("nt,dt", [(10, 1.0), (33, 0.5), (100, 0.4), (1000, 0.05), (2048, 0.025), (4096, 0.0125)])
+@pytest.mark.parametrize("nt,dt", [(10, 1.0), (33, 0.5), (100, 0.4), (1000, 0.05), (2048, 0.025), (4096, 0.0125),
+                                   (5000, 0.01), (9000, 0.006)])
 def test_time_domain_length_extremes(hip, orc, nt, dt):
     """FFT lengths 16 (fewer lags than a wavefront), 64, 128 (exactly one lag per lane), 1024 (8 lags per lane),
-    2048 and 4096 (the longest supported trace: 32 lags per lane, > 64 KB of LDS per block)."""
+    2048 and 4096 (the longest trace one wavefront holds: 32 lags per lane, > 64 KB of LDS per block), and 8192 /
+    16384 (one block per trace, lags in place: k_rft_deconv_big -- the reference has no length limit, deconit.f90)."""
     thk, vs = YAML7
     vp, rho, _, _ = orc.empirical_relation(vs)
     q = np.full(len(vs), 9999.)
@@ -127,6 +129,23 @@ def test_time_domain_length_extremes(hip, orc, nt, dt):
     for ip in range(4):
         for j in range(len(vs)):
             assert rel(kl1[ip, j], kl0[ip, j]) < 1e-7 or not np.any(kl0[ip, j]), (ip, j, rel(kl1[ip, j], kl0[ip, j]))
+
+
+def test_plugin_time_long_trace(hip, orc):
+    """B2 with method "time" and nt = 5000 (8192-point transforms): the block-per-trace deconvolution, the L2-read
+    pulse and the tiled residual correlation behind misfit_and_grad."""
+    thk, vs = YAML7
+    n = len(vs)
+    x0 = np.hstack((vs, thk))
+    xs = np.tile(x0, (2, 1)); xs[1, :n] *= 1.015
+    args = (0.045, 5000, 0.01, 1.5, 5.0, 0.001, "P", "time")
+    mo = orc.ReceiverFunc(*args); mh = hip.ReceiverFunc(*args)
+    d0 = mo.forward(x0)
+    assert rel(mh.forward(x0), d0) < 1e-8
+    mo.set_obsdata(d0); mh.set_obsdata(d0)
+    mfh, gh, dh = mh.misfit_and_grad(xs)
+    mf, g, d = mo.misfit_and_grad(xs[1])
+    assert rel(dh[1], d) < 1e-8 and abs(mfh[1] - mf) <= 1e-8 * mf and rel(gh[1], g) < 1e-7, (rel(dh[1], d), rel(gh[1], g))
 
 
 def test_time_domain_two_layers_and_many_layers(hip, orc):
