@@ -853,77 +853,112 @@ RFS_HD double swd_secular_family(int n, const LoadL& loadL, double omega_raw, do
 // ---------------------------------------------------------------------------
 constexpr double SR_PI32 = 3.1415927410125732;
 
-struct SvTrig { double cosp, rsinp, sinpr, cossv, rsinsv, sinsvr, pex, svex; };
+// Vertical wavenumber nu = sqrt(nu2) of a REAL nu2 (every nu of this problem: wvno^2 - (omega/v)^2): it lies on the
+// real axis (evanescent, ev) or on the imaginary one (nu = i |nu|).  One rsqrt gives |nu| and 1/|nu| (inf at 0).
+struct SvNu { double nu, inu; bool ev; };
+RFS_HD SvNu sv_nu(double nu2) {
+    SvNu r;
+    r.ev = nu2 >= 0.0;
+    const double ax = fabs(nu2);
+    r.inu = rsqrt_p(ax);
+    r.nu = (ax > 1.0e-290) ? ax * r.inu : 0.0;
+    return r;
+}
+RFS_HD cplx sv_cplx(const SvNu& N) { return N.ev ? C(N.nu, 0.0) : C(0.0, N.nu); }            // nu  (principal root)
+RFS_HD cplx sv_cinv(const SvNu& N) { return N.ev ? C(N.inu, 0.0) : C(0.0, -N.inu); }         // 1 / nu
+
+// what one layer's sweeps share: the scaled hyperbolic functions of varsv, and -- for the layer integrals of the
+// down-sweep -- the wavenumbers themselves and exp(-d nu) (which the functions above are made of anyway)
+struct SvTrig { double cosp, rsinp, sinpr, cossv, rsinsv, sinsvr, pex, svex; SvNu na, nb; cplx ea, eb; };
 
 // sregn96.f90:831-915 varsv for an elastic layer, specialised to the only two cases that
 // occur (vertical wavenumbers are square roots of REAL numbers: pure real or pure imaginary).
-RFS_HD void sv_trig_one(double nu2, double d, double& cosx, double& rsinx, double& sinxr, double& ex) {
+// e = exp(-d nu) with gfunc's cut-off (0 beyond Re >= 75, :1348-1352).
+RFS_HD void sv_trig_one(double nu2, double d, double& cosx, double& rsinx, double& sinxr, double& ex, SvNu& N, cplx& e) {
     const double tiny = (double)1.0e-5f;
-    if (nu2 >= 0.0) {                      // evanescent: nu real
-        double nu = sqrt(nu2), pr = nu * d;
-        double fac = (pr < 30.0) ? fm_exp(-2.0 * pr) : 0.0;
+    N = sv_nu(nu2);
+    const double arg = N.nu * d;
+    if (N.ev) {                            // evanescent: nu real
+        const double eh = fm_exp(-arg);
+        const double fac = (arg < 30.0) ? eh * eh : 0.0;
         cosx = 0.5 * (1.0 + fac);
-        double sh = 0.5 * (1.0 - fac);
-        rsinx = nu * sh;
-        sinxr = (fabs(pr) < tiny && nu < tiny) ? d : sh / nu;
-        ex = pr;
+        const double sh = 0.5 * (1.0 - fac);
+        rsinx = N.nu * sh;
+        sinxr = (arg < tiny && N.nu < tiny) ? d : sh * N.inu;
+        ex = arg;
+        e = C((arg < 75.0) ? eh : 0.0, 0.0);
     } else {                               // propagating: nu = i*kap
-        double kap = sqrt(-nu2), s, c;
-        fm_sincos(kap * d, &s, &c);
+        double s, c;
+        fm_sincos(arg, &s, &c);
         cosx = c;                          // pfac = exp(0) = 1
-        rsinx = -kap * s;
-        sinxr = (kap < tiny) ? d : s / kap;
+        rsinx = -N.nu * s;
+        sinxr = (N.nu < tiny) ? d : s * N.inu;
         ex = 0.0;
+        e = C(c, -s);
     }
 }
-
-RFS_HD void sv_trig(double wvno2, double omega, double a, double b, double d, SvTrig& t) {
-    double xka = omega / a, xkb = omega / b;
-    sv_trig_one(wvno2 - xka * xka, d, t.cosp, t.rsinp, t.sinpr, t.pex);
-    sv_trig_one(wvno2 - xkb * xkb, d, t.cossv, t.rsinsv, t.sinsvr, t.svex);
+RFS_HD void sv_trig_one(double nu2, double d, double& cosx, double& rsinx, double& sinxr, double& ex) {
+    SvNu N; cplx e;
+    sv_trig_one(nu2, d, cosx, rsinx, sinxr, ex, N, e);
 }
 
+// ia, ib: reciprocals of the layer's velocities
+RFS_HD void sv_trig(double wvno2, double omega, double ia, double ib, double d, SvTrig& t) {
+    double xka = omega * ia, xkb = omega * ib;
+    sv_trig_one(wvno2 - xka * xka, d, t.cosp, t.rsinp, t.sinpr, t.pex, t.na, t.ea);
+    sv_trig_one(wvno2 - xkb * xkb, d, t.cossv, t.rsinsv, t.sinsvr, t.svex, t.nb, t.eb);
+}
+
+// per (period, chain) item: the scalars every layer step divides by, as reciprocals
+struct SrItem {
+    double omega, wvno, wvno2, om2, iwvno, iwvno2, iom2, iom;
+    RFS_HD SrItem(double om, double k) : omega(om), wvno(k), wvno2(k * k), om2(om * om) {
+        iwvno = rcp_p(k); iwvno2 = iwvno * iwvno; iom = rcp_p(om); iom2 = iom * iom;
+    }
+};
+
 // cd <- normalise(cd . CA) with CA the hspec96-convention compound matrix (sregn96.f90:494-650);
-// returns the log of the normalisation (normc :1405-1434).
-RFS_HD double sr_compound_step(double cd[5], const SvTrig& t, float rhof, float bf, double wvno,
-                               double wvno2, double om2) {
+// returns the log of the normalisation (normc :1405-1434).  Divisions: one reciprocal of rho om^2, one of the
+// (float32) rho^2 times om^4, one of the norm; everything else multiplies by the item's reciprocals.
+RFS_HD double sr_compound_step(double cd[5], const SvTrig& t, float rhof, float bf, const SrItem& Q) {
+    const double wvno = Q.wvno, wvno2 = Q.wvno2, om2 = Q.om2;
     double exa = t.pex + t.svex;
     double a0 = (exa < 60.0) ? fm_exp(-exa) : 0.0;
     double cpcq = t.cosp * t.cossv, cpy = t.cosp * t.sinsvr, cpz = t.cosp * t.rsinsv;
     double cqw = t.cossv * t.sinpr, cqx = t.cossv * t.rsinp;
     double xy = t.rsinp * t.sinsvr, xz = t.rsinp * t.rsinsv, wy = t.sinpr * t.sinsvr, wz = t.sinpr * t.rsinsv;
     double rho = (double)rhof, rho2 = (double)(rhof * rhof);      // float32 rho*rho (:508,596)
-    double gam = (double)((2.0f * bf) * bf) * wvno2 / om2;        // float32 2*b*b (:597)
+    double gam = (double)((2.0f * bf) * bf) * wvno2 * Q.iom2;     // float32 2*b*b (:597)
     double gam2 = gam * gam, gamm1 = gam - 1.0, gamm2 = gamm1 * gamm1;
-    double cqww2 = cqw * wvno2, cqxw2 = cqx / wvno2, gg1 = gam * gamm1;
+    double cqww2 = cqw * wvno2, cqxw2 = cqx * Q.iwvno2, gg1 = gam * gamm1;
     double a0c = 2.0 * (a0 - cpcq);
-    double xz2 = xz / wvno2, gxz2 = gam * xz2, g2xz2 = gam2 * xz2;
+    double xz2 = xz * Q.iwvno2, gxz2 = gam * xz2, g2xz2 = gam2 * xz2;
     double a0cgg1 = a0c * (gam + gamm1);
     double wy2 = wy * wvno2, g2wy2 = gamm2 * wy2, g1wy2 = gamm1 * wy2;
-    double rom = rho * om2;
+    double rom = rho * om2, irom = rcp_p(rom), r2o4 = rho2 * om2 * om2, ir2o4 = rcp_p(r2o4);
     double temp = a0c * gg1 + g2xz2 + g2wy2;
     double c33 = a0 + temp + temp;
     double c11 = cpcq - temp;
-    double c12 = (-cqx + wvno2 * cpy) / rom;
+    double c12 = (-cqx + wvno2 * cpy) * irom;
     temp = 0.5 * a0cgg1 + gxz2 + g1wy2;
-    double c13 = wvno * temp / rom;
-    double c14 = (-cqww2 + cpz) / rom;
+    double c13 = wvno * temp * irom;
+    double c14 = (-cqww2 + cpz) * irom;
     temp = wvno2 * (a0c + wy2) + xz;
-    double c15 = -temp / (rho2 * om2 * om2);
-    double c21 = (-gamm2 * cqw + gam2 * cpz / wvno2) * rom;
+    double c15 = -temp * ir2o4;
+    double c21 = (-gamm2 * cqw + gam2 * cpz * Q.iwvno2) * rom;
     double c22 = cpcq;
-    double c23 = (gamm1 * cqww2 - gam * cpz) / wvno;
+    double c23 = (gamm1 * cqww2 - gam * cpz) * Q.iwvno;
     double c24 = -wz;
     temp = 0.5 * a0cgg1 * gg1 + gam2 * gxz2 + gamm2 * g1wy2;
-    double c31 = -2.0 * temp * rom / wvno;
+    double c31 = -2.0 * temp * rom * Q.iwvno;
     double c32 = -wvno * (gam * cqxw2 - gamm1 * cpy) * 2.0;
     double c34 = -2.0 * c23, c35 = -2.0 * c13;
     double c41 = (-gam2 * cqxw2 + gamm2 * cpy) * rom;
     double c42 = -xy;
-    double c43 = -c32 / 2.0;
+    double c43 = -0.5 * c32;
     temp = gamm2 * (a0c * gam2 + g2wy2) + gam2 * g2xz2;
-    double c51 = -rho2 * om2 * om2 * temp / wvno2;
-    double c53 = -c31 / 2.0;
+    double c51 = -r2o4 * temp * Q.iwvno2;
+    double c53 = -0.5 * c31;
     // ca(2,5)=ca(1,4) ca(4,4)=ca(2,2) ca(4,5)=ca(1,2) ca(5,2)=ca(4,1) ca(5,4)=ca(2,1) ca(5,5)=ca(1,1)
     double n0 = cd[0] * c11 + cd[1] * c21 + cd[2] * c31 + cd[3] * c41 + cd[4] * c51;
     double n1 = cd[0] * c12 + cd[1] * c22 + cd[2] * c32 + cd[3] * c42 + cd[4] * c41;
@@ -932,28 +967,29 @@ RFS_HD double sr_compound_step(double cd[5], const SvTrig& t, float rhof, float 
     double n4 = cd[0] * c15 + cd[1] * c14 + cd[2] * c35 + cd[3] * c12 + cd[4] * c11;
     double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
     if (t1 < 1.0e-40) t1 = 1.0;
-    cd[0] = n0 / t1; cd[1] = n1 / t1; cd[2] = n2 / t1; cd[3] = n3 / t1; cd[4] = n4 / t1;
+    const double it1 = rcp_p(t1);
+    cd[0] = n0 * it1; cd[1] = n1 * it1; cd[2] = n2 * it1; cd[3] = n3 * it1; cd[4] = n4 * it1;
     return log(t1);
 }
 
 // vv <- normalise(AA . vv) with AA the Haskell matrix (sregn96.f90:917-991); returns log-norm.
-RFS_HD double sr_haskell_step(double vv[4], const SvTrig& t, float rhof, float bf, double wvno,
-                              double wvno2, double om2) {
+RFS_HD double sr_haskell_step(double vv[4], const SvTrig& t, float rhof, float bf, const SrItem& Q) {
+    const double wvno = Q.wvno, wvno2 = Q.wvno2, om2 = Q.om2;
     double dfac = ((t.pex - t.svex) > 70.0) ? 0.0 : fm_exp(t.svex - t.pex);
     double cossv = dfac * t.cossv, rsinsv = dfac * t.rsinsv, sinsvr = dfac * t.sinsvr;
     double cosp = t.cosp, rsinp = t.rsinp, sinpr = t.sinpr;
-    double gam = (double)((2.0f * bf) * bf) * wvno2 / om2, gamm1 = gam - 1.0;
-    double rom = (double)rhof * om2;
+    double gam = (double)((2.0f * bf) * bf) * wvno2 * Q.iom2, gamm1 = gam - 1.0;
+    double rom = (double)rhof * om2, irom = rcp_p(rom);
     double a11 = cossv + gam * (cosp - cossv);
-    double a12 = -wvno * gamm1 * sinpr + gam * rsinsv / wvno;
-    double a13 = -wvno * (cosp - cossv) / rom;
-    double a14 = (wvno2 * sinpr - rsinsv) / rom;
-    double a21 = gam * rsinp / wvno - wvno * gamm1 * sinsvr;
+    double a12 = -wvno * gamm1 * sinpr + gam * rsinsv * Q.iwvno;
+    double a13 = -wvno * (cosp - cossv) * irom;
+    double a14 = (wvno2 * sinpr - rsinsv) * irom;
+    double a21 = gam * rsinp * Q.iwvno - wvno * gamm1 * sinsvr;
     double a22 = cosp - gam * (cosp - cossv);
-    double a23 = (-rsinp + wvno2 * sinsvr) / rom;
-    double a31 = rom * gam * gamm1 * (cosp - cossv) / wvno;
-    double a32 = rom * (-gamm1 * gamm1 * sinpr + gam * gam * rsinsv / wvno2);
-    double a41 = rom * (gam * gam * rsinp / wvno2 - gamm1 * gamm1 * sinsvr);
+    double a23 = (-rsinp + wvno2 * sinsvr) * irom;
+    double a31 = rom * gam * gamm1 * (cosp - cossv) * Q.iwvno;
+    double a32 = rom * (-gamm1 * gamm1 * sinpr + gam * gam * rsinsv * Q.iwvno2);
+    double a41 = rom * (gam * gam * rsinp * Q.iwvno2 - gamm1 * gamm1 * sinsvr);
     // a24=-a13 a33=a22 a34=-a12 a42=-a31 a43=-a21 a44=a11
     double n0 = a11 * vv[0] + a12 * vv[1] + a13 * vv[2] + a14 * vv[3];
     double n1 = a21 * vv[0] + a22 * vv[1] + a23 * vv[2] - a13 * vv[3];
@@ -961,7 +997,8 @@ RFS_HD double sr_haskell_step(double vv[4], const SvTrig& t, float rhof, float b
     double n3 = a41 * vv[0] - a31 * vv[1] - a21 * vv[2] + a11 * vv[3];
     double t1 = fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3)));
     if (t1 < 1.0e-40) t1 = 1.0;
-    vv[0] = n0 / t1; vv[1] = n1 / t1; vv[2] = n2 / t1; vv[3] = n3 / t1;
+    const double it1 = rcp_p(t1);
+    vv[0] = n0 * it1; vv[1] = n1 * it1; vv[2] = n2 * it1; vv[3] = n3 * it1;
     return log(t1);
 }
 
@@ -1019,7 +1056,7 @@ RFS_HD void sr_halfspace_vector(double a, double b, double rho, double wvno, dou
 template <bool WATER = false, class Mdl, class StoreFn>
 RFS_HD void sr_up(const Mdl& M, double omega, double wvno, const StoreFn& store) {
     const int n = M.n;
-    double wvno2 = wvno * wvno, om2 = omega * omega;
+    const SrItem Q(omega, wvno);
     double cd[5];
     sr_halfspace_vector(M.A(n - 1), M.B(n - 1), M.R(n - 1), wvno, omega, cd);
     double exsum = 0.0;
@@ -1028,15 +1065,15 @@ RFS_HD void sr_up(const Mdl& M, double omega, double wvno, const StoreFn& store)
         if (WATER && m == 0 && M.B(0) <= 0.0) {
             const double xka = omega / M.A(0);
             double cosp, rsinp, sinpr, pex;
-            sv_trig_one(wvno2 - xka * xka, M.D(0), cosp, rsinp, sinpr, pex);
-            double exn = sr_compound_step_fluid(cd, cosp, rsinp, sinpr, pex, M.Rf(0), om2);
+            sv_trig_one(Q.wvno2 - xka * xka, M.D(0), cosp, rsinp, sinpr, pex);
+            double exn = sr_compound_step_fluid(cd, cosp, rsinp, sinpr, pex, M.Rf(0), Q.om2);
             exsum = exsum + pex + exn;
             store(m, cd, exsum);
             continue;
         }
         SvTrig t;
-        sv_trig(wvno2, omega, M.A(m), M.B(m), M.D(m), t);
-        double exn = sr_compound_step(cd, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
+        sv_trig(Q.wvno2, omega, rcp_p(M.A(m)), rcp_p(M.B(m)), M.D(m), t);
+        double exn = sr_compound_step(cd, t, M.Rf(m), M.Bf(m), Q);
         exsum = exsum + t.pex + t.svex + exn;
         store(m, cd, exsum);
     }
@@ -1045,26 +1082,28 @@ RFS_HD void sr_up(const Mdl& M, double omega, double wvno, const StoreFn& store)
 struct Eig4 { double ur, uz, tz, tr; };
 
 // E and E^-1 of an elastic layer plus the closed-form integrals shared by the six
-// intijr calls (sregn96.f90:719-758, 1203-1323, 1325-1403).
+// intijr calls (sregn96.f90:719-758, 1203-1323, 1325-1403).  na, nb: the layer's vertical wavenumbers; ea, eb:
+// exp(-d nu) of both (inner layers only), as sv_trig leaves them.
 struct LayerInt { double i11, i13, i22, i24, i33, i44; };
 
-RFS_HD void sr_layer_integrals(double a, double b, double rho, double d, bool halfspace,
-                               double wvno, double om, const Eig4& top, const Eig4& bot, LayerInt& I) {
-    double wvno2 = wvno * wvno, om2 = om * om;
-    double xka = om / a, xkb = om / b;
-    cplx ra = csqrt_p(C(wvno2 - xka * xka)), rb = csqrt_p(C(wvno2 - xkb * xkb));
-    double gam = b * wvno / om; gam = 2.0 * (gam * gam);
+RFS_HD void sr_layer_integrals(double b, double rho, double irho, double d, bool halfspace, const SrItem& Q,
+                               const SvNu& na, const SvNu& nb, cplx ea, cplx eb,
+                               const Eig4& top, const Eig4& bot, LayerInt& I) {
+    const double wvno = Q.wvno;
+    const cplx ra = sv_cplx(na), rb = sv_cplx(nb), ira = sv_cinv(na), irb = sv_cinv(nb);
+    double gam = b * wvno * Q.iom; gam = 2.0 * (gam * gam);
     double gamm1 = gam - 1.0;
-    double rom = rho * om2;
-    cplx ira = inv(ra), irb = inv(rb);
+    double rom = rho * Q.om2, irom = irho * Q.iom2;
     // E columns: [PU, SvU, PD, SvD]; rows: Ur, Uz, Tz, Tr
     cplx e12 = rb, e21 = ra;
     double e11 = wvno, e22 = wvno, e31 = rom * gamm1, e42 = rom * gamm1;
-    cplx e32 = (rom * gam / wvno) * rb, e41 = (rom * gam / wvno) * ra;
+    const double rgk = rom * gam * Q.iwvno;
+    cplx e32 = rgk * rb, e41 = rgk * ra;
     // E^-1 rows 1..4 (columns Ur, Uz, Tz, Tr)
-    double hg = 0.5 * gam / wvno, hr = 0.5 / rom;
-    cplx i12 = (-0.5 * gamm1) * ira, i14 = (0.5 * wvno / rom) * ira;
-    cplx i21 = (-0.5 * gamm1) * irb, i23 = (0.5 * wvno / rom) * irb;
+    double hg = 0.5 * gam * Q.iwvno, hr = 0.5 * irom;
+    const double hk = 0.5 * wvno * irom;
+    cplx i12 = (-0.5 * gamm1) * ira, i14 = hk * ira;
+    cplx i21 = (-0.5 * gamm1) * irb, i23 = hk * irb;
     // downgoing potentials at the top of the layer (rows 3,4)
     cplx km1pd = C(hg * top.ur) - i12 * top.uz - C(hr * top.tz) - i14 * top.tr;
     cplx km1sd = C(hg * top.uz) - i21 * top.ur - i23 * top.tz - C(hr * top.tr);
@@ -1082,13 +1121,11 @@ RFS_HD void sr_layer_integrals(double a, double b, double rho, double d, bool ha
         P[1] = c_uz_pu * kmpu; S[1] = c_uz_su * kmsu; p[1] = c_uz_pd * km1pd; s[1] = c_uz_sd * km1sd;
         P[2] = c_tz_pu * kmpu; S[2] = c_tz_su * kmsu; p[2] = c_tz_pd * km1pd; s[2] = c_tz_sd * km1sd;
         P[3] = c_tr_pu * kmpu; S[3] = c_tr_su * kmsu; p[3] = c_tr_pd * km1pd; s[3] = c_tr_sd * km1sd;
-        // f, g, h1, h2 with the reference's guards
+        // f, g, h1, h2 with the reference's guards (ea, eb arrive with gfunc's cut-off at 75 applied)
         cplx FA, GA, FB, GB, H1, H2;
-        cplx ea = (ra.re * d < 75.0) ? cexp_p(-(d * ra)) : C(0.0);
-        cplx eb = (rb.re * d < 75.0) ? cexp_p(-(d * rb)) : C(0.0);
         cplx ea40 = (ra.re * d < 40.0) ? ea : C(0.0), eb40 = (rb.re * d < 40.0) ? eb : C(0.0);
-        FA = (sqrt(norm2(ra)) < 1.0e-8) ? C(d) : (1.0 - ea40 * ea40) * (0.5 * ira);
-        FB = (sqrt(norm2(rb)) < 1.0e-8) ? C(d) : (1.0 - eb40 * eb40) * (0.5 * irb);
+        FA = (na.nu < 1.0e-8) ? C(d) : (1.0 - ea40 * ea40) * (0.5 * ira);
+        FB = (nb.nu < 1.0e-8) ? C(d) : (1.0 - eb40 * eb40) * (0.5 * irb);
         GA = d * ea; GB = d * eb;
         cplx rsum = ra + rb, rdif = ra - rb;
         cplx esum = ((rsum.re * d) < 40.0) ? ea * eb : C(0.0);
@@ -1115,10 +1152,10 @@ RFS_HD void sr_layer_integrals(double a, double b, double rho, double d, bool ha
     }
 }
 
-// Interface term of getdcdh (sregn96.f90:1436-1535, all-solid model) WITHOUT the final `fac`:
-// (m == 0: "above" is vacuum).
-RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, double lam_m,
-                                double rho_u, double mu_u, double lam_u, const Eig4& u,
+// Interface term of getdcdh (sregn96.f90:1436-1535) WITHOUT the final `fac` (m == 0: "above" is vacuum).
+// il2m_*, imu_*: reciprocals of lambda + 2 mu and of mu on the two sides (imu only used where mu != 0).
+RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, double lam_m, double il2m_m, double imu_m,
+                                double rho_u, double mu_u, double lam_u, double il2m_u, double imu_u, const Eig4& u,
                                 double om2, double wvno, double wvno2, bool fluid_above = false) {
     double tur = u.ur, tuz = u.uz, ttz = u.tz, ttr = u.tr;
     if (fluid_above) {                       // solid under the water layer: Ur jumps across the interface, :1504-1508
@@ -1137,8 +1174,8 @@ RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, dou
         return g1 + g2 + g3 + g4 + g5 + g6;
     }
     double xl2mp = lam_m + mu_m + mu_m;
-    double duzdzp = (ttz + wvno * lam_m * tur) / xl2mp;
-    double durdzp = (mu_m == 0.0) ? wvno * tuz : (ttr / mu_m) - wvno * tuz;
+    double duzdzp = (ttz + wvno * lam_m * tur) * il2m_m;
+    double durdzp = (mu_m == 0.0) ? wvno * tuz : (ttr * imu_m) - wvno * tuz;
     double drho, dmu, dl2mu, g5, g6;
     if (top_surface) {
         drho = rho_m; dmu = mu_m; dl2mu = lam_m + mu_m + mu_m;
@@ -1148,8 +1185,8 @@ RFS_HD double sr_interface_term(bool top_surface, double rho_m, double mu_m, dou
         drho = rho_m - rho_u; dmu = mu_m - mu_u;
         dl2mu = (lam_m - lam_u) + dmu + dmu;
         double xl2mm = lam_u + mu_u + mu_u;
-        double durdzm = (mu_u == 0.0) ? wvno * tuz : (ttr / mu_u) - wvno * tuz;
-        double duzdzm = (ttz + wvno * lam_u * tur) / xl2mm;
+        double durdzm = (mu_u == 0.0) ? wvno * tuz : (ttr * imu_u) - wvno * tuz;
+        double duzdzm = (ttz + wvno * lam_u * tur) * il2m_u;
         g5 = xl2mp * duzdzp * duzdzp - xl2mm * duzdzm * duzdzm;
         g6 = mu_m * durdzp * durdzp - mu_u * durdzm * durdzm;
     }
@@ -1170,23 +1207,26 @@ template <bool WATER = false, class Mdl, class LoadFn, class EmitFn>
 RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const LoadFn& load,
                                const EmitFn& emit) {
     const int n = M.n;
-    const double om2 = omega * omega, wvno2 = wvno * wvno, c = omega / wvno;
+    const SrItem Q(omega, wvno);
+    const double om2 = Q.om2, wvno2 = Q.wvno2, c = omega * Q.iwvno;
     double cd[5], exe0, exe_m;
     load(0, cd, exe0);
-    const double f1213 = -cd[1];
+    const double f1213 = -cd[1], if1213 = rcp_p(f1213);
     Eig4 top{cd[2] / cd[1], 1.0, 0.0, 0.0};
     const bool wat0 = WATER && M.B(0) <= 0.0;
     if (wat0) top.ur = 0.0;                  // svfunc :319-330 (Ur, Tr of the fluid's top), energy :1140 (Ur from Tz = 0)
     double vv[4] = {1.0, 0.0, 0.0, 0.0};
     double exa = 0.0;
     double sumi0 = 0.0, sumi1 = 0.0, sumi2 = 0.0, sumi3 = 0.0;
-    double rho_u = 0.0, mu_u = 0.0, lam_u = 0.0;
+    double rho_u = 0.0, mu_u = 0.0, lam_u = 0.0, il2m_u = 0.0, imu_u = 0.0;
     for (int m = 0; m < n; m++) {
         const bool half = (m == n - 1);
         double a = M.A(m), b = M.B(m), rho = M.R(m), d = M.D(m);
         double mu = rho * (b * b), lam = rho * (a * a) - 2 * mu;
         Eig4 bot = top;
         const bool fluid = wat0 && m == 0;
+        SvTrig t;
+        const double ia = rcp_p(a), ib = fluid ? 0.0 : rcp_p(b), irho = rcp_p(rho);
         if (!half) {
             if (fluid) {
                 const double xka = omega / a;
@@ -1195,9 +1235,8 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
                 double ex2 = sr_haskell_step_fluid(vv, cosp, rsinp, sinpr, pex, M.Rf(m), om2);
                 exa = exa + pex + ex2;
             } else {
-                SvTrig t;
-                sv_trig(wvno2, omega, a, b, d, t);
-                double ex2 = sr_haskell_step(vv, t, M.Rf(m), M.Bf(m), wvno, wvno2, om2);
+                sv_trig(wvno2, omega, ia, ib, d, t);
+                double ex2 = sr_haskell_step(vv, t, M.Rf(m), M.Bf(m), Q);
                 exa = exa + t.pex + ex2;
             }
             load(m + 1, cd, exe_m);
@@ -1210,11 +1249,15 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
             double uu4 = -tz1 * cd4 + tz2 * cd2 - tz3 * cd1;
             double ext = exa + exe_m - exe0;
             if (ext > -80.0 && ext < 80.0) {
-                double fact = fm_exp(ext);
-                bot = Eig4{uu1 * fact / f1213, uu2 * fact / f1213, uu3 * fact / f1213, uu4 * fact / f1213};
+                double fact = fm_exp(ext) * if1213;
+                bot = Eig4{uu1 * fact, uu2 * fact, uu3 * fact, uu4 * fact};
             } else {
                 bot = Eig4{0.0, 0.0, 0.0, 0.0};
             }
+        } else {
+            const double xka = omega * ia, xkb = omega * ib;
+            t.na = sv_nu(wvno2 - xka * xka); t.nb = sv_nu(wvno2 - xkb * xkb);
+            t.ea = C(0.0); t.eb = C(0.0);
         }
         if (fluid) {
             // fluid layer: 2 x 2 potentials (evalg :800-811, intijr :1245-1262), getmat :1551-1565, energy :1122-1140
@@ -1237,17 +1280,19 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
             sumi3 += TA * DUZDUZ;
             const double facah = rho * a * (URUR - 2. * URDUZ / wvno), facav = rho * a * DUZDUZ / wvno2;
             const double facr = -0.5 * c * c * (URUR + UZUZ);
-            const double dh = sr_interface_term(true, rho, mu, lam, 0.0, 0.0, 0.0, top, om2, wvno, wvno2);
+            const double il2m = 1.0 / (lam + mu + mu);
+            const double dh = sr_interface_term(true, rho, mu, lam, il2m, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, top, om2, wvno, wvno2);
             emit(m, facah + facav, 0.0, 0.5 * (a * facav + a * facah) / rho + facr, dh);     // (dcdb: never assigned there)
-            rho_u = rho; mu_u = mu; lam_u = lam;
+            rho_u = rho; mu_u = mu; lam_u = lam; il2m_u = il2m; imu_u = 0.0;
             top = bot;
             continue;
         }
         LayerInt I;
-        sr_layer_integrals(a, b, rho, d, half, wvno, omega, top, bot, I);
+        sr_layer_integrals(b, rho, irho, d, half, Q, t.na, t.nb, t.ea, t.eb, top, bot, I);
         // getmat :1566-1586 (isotropic)
         double TL = rho * b * b, TC = rho * a * a, TA = TC, TF = TA - 2. * TL;
-        double a12 = -wvno, a14 = 1.0 / TL, a21 = wvno * TF / TC, a23 = 1.0 / TC;
+        const double iTL = irho * (ib * ib), iTC = irho * (ia * ia);
+        double a12 = -wvno, a14 = iTL, a21 = wvno * TF * iTC, a23 = iTC;
         double URUR = I.i11, UZUZ = I.i22;
         double DURDUR = a12 * a12 * I.i22 + 2. * a12 * a14 * I.i24 + a14 * a14 * I.i44;
         double DUZDUZ = a21 * a21 * I.i11 + 2. * a21 * a23 * I.i13 + a23 * a23 * I.i33;
@@ -1257,15 +1302,16 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
         sumi1 += TL * UZUZ + TA * URUR;
         sumi2 += TL * UZDUR - TF * URDUZ;
         sumi3 += TL * DURDUR + TC * DUZDUZ;
-        double facah = rho * a * (URUR - 2. * URDUZ / wvno);
-        double facav = rho * a * DUZDUZ / wvno2;
-        double facbv = rho * b * (UZUZ + 2. * UZDUR / wvno + DURDUR / wvno2 + 4. * URDUZ / wvno);
+        double facah = rho * a * (URUR - 2. * URDUZ * Q.iwvno);
+        double facav = rho * a * DUZDUZ * Q.iwvno2;
+        double facbv = rho * b * (UZUZ + 2. * UZDUR * Q.iwvno + DURDUR * Q.iwvno2 + 4. * URDUZ * Q.iwvno);
         double facr = -0.5 * c * c * (URUR + UZUZ);
         double da = facah + facav, db = facbv;
-        double dr = 0.5 * (a * facav + a * facah + b * facbv) / rho + facr;
-        double dh = sr_interface_term(m == 0, rho, mu, lam, rho_u, mu_u, lam_u, top, om2, wvno, wvno2, wat0 && m == 1);
+        double dr = 0.5 * (a * facav + a * facah + b * facbv) * irho + facr;
+        double dh = sr_interface_term(m == 0, rho, mu, lam, iTC, iTL, rho_u, mu_u, lam_u, il2m_u, imu_u, top, om2, wvno, wvno2,
+                                      wat0 && m == 1);
         emit(m, da, db, dr, dh);
-        rho_u = rho; mu_u = mu; lam_u = lam;
+        rho_u = rho; mu_u = mu; lam_u = lam; il2m_u = iTC; imu_u = iTL;
         top = bot;
     }
     SrTotals T;

@@ -336,3 +336,10 @@ extern "C" int hs_rootsearch_modes(int n, const float* thk, const float* vp, con
     }
     return rs.flag;
 }
+
+// the plain secular functions, one evaluation (experiments and checks of derivative identities)
+extern "C" double hs_secular(int n, const float* thk, const float* vp, const float* vs, const float* rho, double omega, double c, int love)
+{
+    SwdModel M{thk, vp, vs, rho, 1, n};
+    return love ? swd_secular_love(M, omega / c, omega) : swd_secular(M, omega / c, omega);
+}
