@@ -669,7 +669,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
                   c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
                   c->wsgn.as<unsigned char>(), c->wneed.as<int>() + nchain + 1, c->wneed.as<int>() + 2 * nchain + 1,
-                  c->wilist.as<int>(), c->wneed.as<int>() + 2 * nchain + 2, c->wlist2.as<int>()};
+                  c->wilist.as<int>(), c->wneed.as<int>() + 2 * nchain + 2, c->wlist2.as<int>(), c->wneed.as<int>() + 2 * nchain + 3};
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -941,7 +941,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->xw, 2 * nn * sizeof(double)); ENSURE(c, c->dxT, 2 * nn * sizeof(double));
         ENSURE(c, c->crT, 2 * nn * sizeof(double));
         const size_t before = c->wvalid.cap;
-        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (2 * (size_t)nchain + 3) * sizeof(int));
+        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (3 * (size_t)nchain + 3) * sizeof(int));
         ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, (size_t)nchain * sizeof(int));
         for (auto& e : c->ev_w) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
@@ -1097,7 +1097,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            c->mdl.as<float>(), c->mdlc.as<double>(),
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
                            early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
-                           early_items > 0 ? ntot / 64 + 1 : (warm ? 2 * (size_t)nchain + 3 : (size_t)0),
+                           early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 3 : (size_t)0),
                            track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>());
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));

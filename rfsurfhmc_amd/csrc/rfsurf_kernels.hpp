@@ -766,6 +766,7 @@ struct SwdWarm {
     unsigned char* sgn;     // [item][chain] sign bit of the secular function just below the refined root (2: no root)
     int* irr; int* icount; int* ilist;   // chains with an irregular sequence (k_swd_warm_check -> k_swd_warm_walk)
     int* count2; int* list2;             // chains handed back by the branch test (the search of `list` is under way by then)
+    int* wide;              // [chain] a first-order change above WARM_L1MAX somewhere: every sequence of the chain walks the grid
 };
 
 template <class F, bool SPH>
@@ -822,6 +823,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     WarmSearch ws;
     ws.begin(cprev, dc, l1);
     if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
+    if (l1 > WARM_L1MAX && ws.active()) W.wide[chain] = 1;
     const bool refused = !ws.active();
     while (__any(ws.active())) {
         if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
@@ -866,6 +868,7 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
     const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
     bool irregular = false;
     for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+    irregular = irregular || W.wide[chain] != 0;
     float bmx = 0.f;
     double cc = 0.0;
     if (k == 0 || irregular) cc = (double)swd_start_value(M, bmx);
@@ -931,6 +934,7 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
         bool irregular = false;
         for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+        irregular = irregular || W.wide[chain] != 0;
         live = live && irregular && !W.need[chain];
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};

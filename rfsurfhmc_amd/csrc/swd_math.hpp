@@ -753,7 +753,9 @@ constexpr double WARM_EPS0 = 1.0e-5;         // first bracket half-width, relati
 constexpr double WARM_EPS1 = 0.03;
 constexpr double WARM_R0 = 2.0e-4;           // trust radius: R0 c + R1 l1
 constexpr double WARM_R1 = 1.0;              // (a first-order model that misses by more than its own size is no guide)
-constexpr double WARM_L1MAX = 0.5;           // km/s: beyond this first-order change the model is not "the previous one, moved"
+constexpr double WARM_L1MAX = 0.5;           // km/s: beyond this first-order change the one-evaluation branch test is not trusted:
+                                             // the chain's sequences walk the reference's scan grid (k_swd_warm_walk) like irregular ones
+constexpr double WARM_L1WIDE = 2.0;          // km/s: and beyond this the model is not "the previous one, moved" at all
 constexpr int WARM_MAXIT = 12;
 
 
@@ -774,7 +776,7 @@ struct WarmSearch {
         a = cpred - eps; b = cpred + eps; creq = a;
         phase = W_A;
         // not a continuation of the previous model (or no previous root at all): leave it to the full search
-        if (!(cprev > 0.0) || !(l1 <= WARM_L1MAX) || !(a > 0.0)) phase = W_FAIL;
+        if (!(cprev > 0.0) || !(l1 <= WARM_L1WIDE) || !(a > 0.0)) phase = W_FAIL;
     }
 
     RFS_HD void refine_from_bracket() {          // (a, fa), (b, fb) hold a sign change

@@ -282,6 +282,7 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
     bool irregular = false, all_ok = true;
     for (int k = 0; k < nt; k++) all_ok = all_ok && status[k] == 1;
     for (int k = 1; k < nt && all_ok; k++) irregular = irregular || (cout[k - 1] - 1.5 * dcs >= cout[k]);
+    for (int k = 0; k < nt; k++) irregular = irregular || l1[k] > WARM_L1MAX;          // wide moves walk the grid too
     for (int k = 0; k < nt && all_ok; k++) {
         const double omega = (2.0 * 3.141592653589793) / t[k];
         auto sec = [&](double w, double c) { return love ? swd_secular_family<SwdLoveFamily>(n, loadL, w, c)
