@@ -857,9 +857,10 @@ constexpr double SR_PI32 = 3.1415927410125732;
 
 // Vertical wavenumber nu = sqrt(nu2) of a REAL nu2 (every nu of this problem: wvno^2 - (omega/v)^2): it lies on the
 // real axis (evanescent, ev) or on the imaginary one (nu = i |nu|).  One rsqrt gives |nu| and 1/|nu| (inf at 0).
-struct SvNu { double nu, inu; bool ev; };
+struct SvNu { double nu, inu, nu2; bool ev; };
 RFS_HD SvNu sv_nu(double nu2) {
     SvNu r;
+    r.nu2 = nu2;
     r.ev = nu2 >= 0.0;
     const double ax = fabs(nu2);
     r.inu = rsqrt_p(ax);
@@ -1096,33 +1097,26 @@ RFS_HD void sr_layer_integrals(double b, double rho, double irho, double d, bool
     double gam = b * wvno * Q.iom; gam = 2.0 * (gam * gam);
     double gamm1 = gam - 1.0;
     double rom = rho * Q.om2, irom = irho * Q.iom2;
-    // E columns: [PU, SvU, PD, SvD]; rows: Ur, Uz, Tz, Tr
-    cplx e12 = rb, e21 = ra;
-    double e11 = wvno, e22 = wvno, e31 = rom * gamm1, e42 = rom * gamm1;
-    const double rgk = rom * gam * Q.iwvno;
-    cplx e32 = rgk * rb, e41 = rgk * ra;
+    // E (evalg :719-737), columns [PU, SvU, PD, SvD], rows Ur, Uz, Tz, Tr:
+    //   Ur: ( k,      nu_b,       k,    -nu_b     )      Uz: ( nu_a,      k,    -nu_a,       k   )
+    //   Tz: ( e31,  rgk nu_b,   e31,  -rgk nu_b   )      Tr: ( rgk nu_a, e31,  -rgk nu_a,   e31  )
+    const double e31 = rom * gamm1, rgk = rom * gam * Q.iwvno;
     // E^-1 rows 1..4 (columns Ur, Uz, Tz, Tr)
     double hg = 0.5 * gam * Q.iwvno, hr = 0.5 * irom;
     const double hk = 0.5 * wvno * irom;
     cplx i12 = (-0.5 * gamm1) * ira, i14 = hk * ira;
     cplx i21 = (-0.5 * gamm1) * irb, i23 = hk * irb;
     // downgoing potentials at the top of the layer (rows 3,4)
-    cplx km1pd = C(hg * top.ur) - i12 * top.uz - C(hr * top.tz) - i14 * top.tr;
-    cplx km1sd = C(hg * top.uz) - i21 * top.ur - i23 * top.tz - C(hr * top.tr);
-    // row-wise potential-weighted E entries: row i -> (P_i, S_i, p_i, s_i)
-    // E(i,3) = +-E(i,1), E(i,4) = +-E(i,2): rows 1,4: (e,  e2, e, -e2)... written out explicitly
-    cplx P[4], S[4], p[4], s[4];
-    cplx c_ur_pu = C(e11), c_ur_su = e12, c_ur_pd = C(e11), c_ur_sd = -e12;
-    cplx c_uz_pu = e21, c_uz_su = C(e22), c_uz_pd = -e21, c_uz_sd = C(e22);
-    cplx c_tz_pu = C(e31), c_tz_su = e32, c_tz_pd = C(e31), c_tz_sd = -e32;
-    cplx c_tr_pu = e41, c_tr_su = C(e42), c_tr_pd = -e41, c_tr_sd = C(e42);
+    const cplx D = C(hg * top.ur) - i12 * top.uz - C(hr * top.tz) - i14 * top.tr;      // km1pd
+    const cplx W = C(hg * top.uz) - i21 * top.ur - i23 * top.tz - C(hr * top.tr);      // km1sd
+    // intijr's integrand for rows i, j of E is quadratic in the four potentials, with E(i,3) = s_i E(i,1) and
+    // E(i,4) = t_i E(i,2), (s, t) = (+,-) for Ur, Tz and (-,+) for Uz, Tr.  The six integrals the energy sums need pair rows
+    // of the SAME sign class, so they share three numbers per class -- the P-P, S-S and P-S weights below -- and differ only
+    // in REAL coefficients (nu_a^2, nu_b^2 are real): 18 complex products per layer instead of 6 x 22.
+    double reAp, reAm, reBp, reBm, rC, rCp;
     if (!halfspace) {
-        cplx kmpu = C(hg * bot.ur) + i12 * bot.uz - C(hr * bot.tz) + i14 * bot.tr;
-        cplx kmsu = i21 * bot.ur + C(hg * bot.uz) + i23 * bot.tz - C(hr * bot.tr);
-        P[0] = c_ur_pu * kmpu; S[0] = c_ur_su * kmsu; p[0] = c_ur_pd * km1pd; s[0] = c_ur_sd * km1sd;
-        P[1] = c_uz_pu * kmpu; S[1] = c_uz_su * kmsu; p[1] = c_uz_pd * km1pd; s[1] = c_uz_sd * km1sd;
-        P[2] = c_tz_pu * kmpu; S[2] = c_tz_su * kmsu; p[2] = c_tz_pd * km1pd; s[2] = c_tz_sd * km1sd;
-        P[3] = c_tr_pu * kmpu; S[3] = c_tr_su * kmsu; p[3] = c_tr_pd * km1pd; s[3] = c_tr_sd * km1sd;
+        const cplx U = C(hg * bot.ur) + i12 * bot.uz - C(hr * bot.tz) + i14 * bot.tr;  // kmpu
+        const cplx V = i21 * bot.ur + C(hg * bot.uz) + i23 * bot.tz - C(hr * bot.tr);  // kmsu
         // f, g, h1, h2 with the reference's guards (ea, eb arrive with gfunc's cut-off at 75 applied)
         cplx FA, GA, FB, GB, H1, H2;
         cplx ea40 = (ra.re * d < 40.0) ? ea : C(0.0), eb40 = (rb.re * d < 40.0) ? eb : C(0.0);
@@ -1133,25 +1127,27 @@ RFS_HD void sr_layer_integrals(double b, double rho, double irho, double d, bool
         cplx esum = ((rsum.re * d) < 40.0) ? ea * eb : C(0.0);
         H1 = (sqrt(norm2(rsum)) < 1.0e-8) ? C(d) : (1.0 - esum) * inv(rsum);
         H2 = (sqrt(norm2(rdif)) < 1.0e-8) ? C(d) : (eb40 - ea40) * inv(rdif);
-#define RFS_INT(i, j)                                                                              \
-        (((P[i] * P[j] + p[i] * p[j]) * FA + (S[i] * S[j] + s[i] * s[j]) * FB +                     \
-          H1 * ((P[i] * S[j] + S[i] * P[j]) + (p[i] * s[j] + s[i] * p[j])) +                       \
-          H2 * ((P[i] * s[j] + s[i] * P[j]) + (p[i] * S[j] + S[i] * p[j])) +                       \
-          GA * (P[i] * p[j] + p[i] * P[j]) + GB * (S[i] * s[j] + s[i] * S[j])).re)
-        I.i11 = RFS_INT(0, 0); I.i13 = RFS_INT(0, 2); I.i22 = RFS_INT(1, 1);
-        I.i24 = RFS_INT(1, 3); I.i33 = RFS_INT(2, 2); I.i44 = RFS_INT(3, 3);
-#undef RFS_INT
+        const double aF = re_mul(U * U + D * D, FA), aG = 2.0 * re_mul(U * D, GA);
+        const double bF = re_mul(V * V + W * W, FB), bG = 2.0 * re_mul(V * W, GB);
+        reAp = aF + aG; reAm = aF - aG;
+        reBp = bF + bG; reBm = bF - bG;
+        const cplx h1 = (U * V - D * W) * H1, uw = U * W, dv = D * V;
+        rC = re_mul(rb, h1 + (dv - uw) * H2);
+        rCp = re_mul(ra, h1 + (uw - dv) * H2);
     } else {
-        p[0] = c_ur_pd * km1pd; s[0] = c_ur_sd * km1sd;
-        p[1] = c_uz_pd * km1pd; s[1] = c_uz_sd * km1sd;
-        p[2] = c_tz_pd * km1pd; s[2] = c_tz_sd * km1sd;
-        p[3] = c_tr_pd * km1pd; s[3] = c_tr_sd * km1sd;
-        cplx fa = 0.5 * ira, fb = 0.5 * irb, fab = inv(ra + rb);
-#define RFS_INTH(i, j) ((p[i] * p[j] * fa + (p[i] * s[j] + s[i] * p[j]) * fab + s[i] * s[j] * fb).re)
-        I.i11 = RFS_INTH(0, 0); I.i13 = RFS_INTH(0, 2); I.i22 = RFS_INTH(1, 1);
-        I.i24 = RFS_INTH(1, 3); I.i33 = RFS_INTH(2, 2); I.i44 = RFS_INTH(3, 3);
-#undef RFS_INTH
+        const cplx fa = 0.5 * ira, fb = 0.5 * irb, fab = inv(ra + rb);
+        reAp = reAm = re_mul(D * D, fa);
+        reBp = reBm = re_mul(W * W, fb);
+        const cplx cm = -((D * W) * fab);
+        rC = re_mul(rb, cm); rCp = re_mul(ra, cm);
     }
+    const double na2 = na.nu2, nb2 = nb.nu2, e3 = e31;                 // e31 = e42 = rho om^2 (gamma - 1)
+    I.i11 = wvno * wvno * reAp + nb2 * reBm + 2.0 * wvno * rC;
+    I.i33 = e3 * e3 * reAp + (rgk * rgk) * nb2 * reBm + 2.0 * (e3 * rgk) * rC;
+    I.i13 = wvno * e3 * reAp + rgk * nb2 * reBm + (wvno * rgk + e3) * rC;
+    I.i22 = na2 * reAm + wvno * wvno * reBp + 2.0 * wvno * rCp;
+    I.i44 = (rgk * rgk) * na2 * reAm + e3 * e3 * reBp + 2.0 * (rgk * e3) * rCp;
+    I.i24 = rgk * na2 * reAm + wvno * e3 * reBp + (e3 + wvno * rgk) * rCp;
 }
 
 // Interface term of getdcdh (sregn96.f90:1436-1535) WITHOUT the final `fac` (m == 0: "above" is vacuum).
