@@ -527,7 +527,7 @@ SwdPlan make_plan(const int nt[4], const double* const t[4], bool group_passes, 
         P.R.b[P.R.nblk++] = B;
         P.R.nswd += nt[type];
     }
-    P.R.sphere = sphere; P.R.fwd = fwd; P.R.sphR = sphR; P.R.sphL = sphL;
+    P.R.sphere = sphere; P.R.fwd = fwd; P.R.sphR = sphR; P.R.sphL = sphL; P.R.nitems = P.nitems;
     return P;
 }
 
@@ -674,9 +674,11 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
             if (sphere) hipLaunchKernelGGL((k_swd_warm<FAM, true>), grid, dim3(64), 0, s, nchain, n, QQ, MDLC, SPHP,   \
-                                           c->krn.as<double>(), c->croot.as<double>(), W);                            \
+                                           c->krn.as<double>(), c->ugr.as<double>(), (size_t)P.nitems * nchain,       \
+                                           c->croot.as<double>(), W);                                                 \
             else hipLaunchKernelGGL((k_swd_warm<FAM, false>), grid, dim3(64), 0, s, nchain, n, QQ, MDLC,              \
-                                    (const double*)nullptr, c->krn.as<double>(), c->croot.as<double>(), W);           \
+                                    (const double*)nullptr, c->krn.as<double>(), c->ugr.as<double>(),                 \
+                                    (size_t)P.nitems * nchain, c->croot.as<double>(), W);                             \
         } while (0)
         if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
         if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
@@ -850,7 +852,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         size_t ntot = (size_t)P.nitems * nchain;
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
         ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
-        ENSURE(c, c->ugr, ntot * sizeof(double));
+        ENSURE(c, c->ugr, 3 * ntot * sizeof(double));      // U and the two kernel scale slots of every item (swd_krn)
         {   // (timed group: the launches of this stream only -- the wait for the side stream below is not kernel time)
         KTimer t(c, eigen_mode == 1 ? -1 : RFS_K_SWD_EIGEN, s);     // the early launch hides behind the search: not timed
 #define RFS_LAUNCH_EIGEN2(LOVE, SPH, WAT, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                          \
@@ -1085,7 +1087,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->sflag, (size_t)8 * nchain * sizeof(int));
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
         ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
-        ENSURE(c, c->ugr, ntot * sizeof(double));
+        ENSURE(c, c->ugr, 3 * ntot * sizeof(double));
         ENSURE(c, c->edone, (ntot / 64 + 1) * sizeof(int));
     }
     {   // layer constants, search models -- and, for the early launch, the cleared root buffer (zero = not final) and done map
@@ -1177,12 +1179,15 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                                (int)!c->has_swd, rf_time ? 1 : rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
                                c->cr.as<double>(), misfit, grad, flag);
         if (c->has_swd) {
+            // (row cache in LDS: residual + kernel scales of every data row of the block's 32 chains, while it fits)
+            const int rowc = ((size_t)(n + 3 * R.nswd) * 32 * sizeof(double) <= 56 * 1024) ? 1 : 0;
+            const size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
 #define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
-            hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 16), (size_t)n * 32 * sizeof(double), \
+            hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 16), lds_c,                         \
                                c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),     \
                                c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),      \
                                P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                  \
-                               track ? c->wvalid.as<int>() : (int*)nullptr)
+                               track ? c->wvalid.as<int>() : (int*)nullptr, rowc)
             if (c->sphere) RFS_LAUNCH_COMBINE(true); else RFS_LAUNCH_COMBINE(false);
 #undef RFS_LAUNCH_COMBINE
         }

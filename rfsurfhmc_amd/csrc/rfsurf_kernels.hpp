@@ -15,7 +15,7 @@
 //   PG       [chain][npart][4][n]        per-wave partial gradient sums (deterministic reduce)
 //   croot    [seq][nper][chain]          phase velocities per root-search sequence
 //   cds      [n][6][item]                compound up-sweep scratch of the eigenfunction pass
-//   krn      [item-class][4][n][chain]   scaled kernels d(c)/d(alpha,beta,rho,interface)
+//   krn      [item-class][4][n][chain]   kernels d(c)/d(alpha,beta,rho,interface) before their per-item scales (swd_krn)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rf_math.hpp"
@@ -772,7 +772,7 @@ struct SwdWarm {
 template <class F, bool SPH>
 __global__ void __launch_bounds__(64)
 k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const double* __restrict__ sph,
-           const double* __restrict__ krn, double* __restrict__ croot, SwdWarm W)
+           const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot, double* __restrict__ croot, SwdWarm W)
 {
     const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (g >= (size_t)Q.nper_total * nchain) return;
@@ -797,11 +797,13 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
     // vtp / dtp / rtp as swd_kernel_value does
     const double* kr0 = krn + (size_t)e * 4 * s + chain;
+    const double ksc = ugr[ntot + (size_t)e * nchain + chain], kfac = ugr[2 * ntot + (size_t)e * nchain + chain];    // swd_krn's scales
     double dc = 0.0, l1 = 0.0, suf = 0.0;
     float betmx = -1.e20f;
     for (int m = n - 1; m >= 0; m--) {
         const size_t lm = (size_t)m * nchain;
-        double ka = kr0[lm], kb = kr0[s + lm], kr = kr0[2 * s + lm], kh = kr0[3 * s + lm];
+        double ka = kr0[lm] * ksc, kb = kr0[s + lm] * ksc, kr = kr0[2 * s + lm] * ksc, kh = kr0[3 * s + lm] * kfac;
+        if (fabs(kh) < 1.0e-38) kh = 0.0;
         if (SPH) {
             const double vtp = sph[4 * s + lm + chain], dtp = sph[5 * s + lm + chain], rtp = sph[6 * s + lm + chain];
             ka *= vtp; kb *= vtp; kr *= rtp; kh *= dtp;
@@ -1207,7 +1209,7 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
             ko[0 * s + (size_t)m * nchain] = 0.0; ko[1 * s + (size_t)m * nchain] = qnan;
             ko[2 * s + (size_t)m * nchain] = qnan; ko[3 * s + (size_t)m * nchain] = qnan;
         }
-        *uout = qnan;
+        *uout = qnan; uout[ntot] = 1.0; uout[2 * ntot] = 1.0;
         return;
     }
     if (LOVE) {
@@ -1224,11 +1226,9 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
                 ko[0 * s + (size_t)m * nchain] = 0.0; ko[1 * s + (size_t)m * nchain] = db;
                 ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
             });
-        for (int m = 0; m < n; m++) {
-            ko[1 * s + (size_t)m * nchain] /= R.sumi1; ko[2 * s + (size_t)m * nchain] /= R.sumi1;
-            double dfac = R.fac * ko[3 * s + (size_t)m * nchain];
-            ko[3 * s + (size_t)m * nchain] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;   // slegn96.f90:598-602
-        }
+        // the kernels stay as emitted: their common factors -- 1 / I1, and `fac` of the interface terms with its flush
+        // (slegn96.f90:598-602) -- go to the item's two scale slots and are applied by whoever reads krn (swd_krn)
+        uout[ntot] = 1.0 / R.sumi1; uout[2 * ntot] = R.fac;
         *uout = R.ugr;
     } else {
         auto store = [&](int m, const double* cd, double exe) {
@@ -1249,13 +1249,8 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
             ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
         };
         SrTotals R = sr_down_energy<WATER>(M, omega, wvno, load, emit);
-        double sca = 1.0 / (R.ugr * R.sumi0);
-        for (int m = 0; m < n; m++) {
-            ko[0 * s + (size_t)m * nchain] *= sca; ko[1 * s + (size_t)m * nchain] *= sca;
-            ko[2 * s + (size_t)m * nchain] *= sca;
-            double dfac = R.fac * ko[3 * s + (size_t)m * nchain];
-            ko[3 * s + (size_t)m * nchain] = (fabs(dfac) < 1.0e-38) ? 0.0 : dfac;   // sregn96.f90:1529-1531
-        }
+        // (1 / (U I0) of energy :1181-1186 and `fac` of getdcdh with its flush :1529-1531: the item's scale slots, swd_krn)
+        uout[ntot] = 1.0 / (R.ugr * R.sumi0); uout[2 * ntot] = R.fac;
         double u = R.ugr;
         if (fabs(u) < 1.0e-36) u = 0.0;                                             // :1703
         *uout = u;
@@ -1319,7 +1314,7 @@ k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__
 // the tail of sregnpu / slegnpu); fwd != 0 selects the phase-velocity conversion of libsurf.forward
 // (_flat2sphere) instead of sprayl's.
 struct SwdBlk { int type, nrow, off, off1, off2; const double* t; };    // type 0 Rc, 1 Rg, 2 Lc, 3 Lg; off* in items
-struct SwdRows { SwdBlk b[4]; int nblk, nswd, sphere, fwd; const double* sphR; const double* sphL; };
+struct SwdRows { SwdBlk b[4]; int nblk, nswd, sphere, fwd; const double* sphR; const double* sphL; int nitems; };
 
 template <bool SPH>
 __device__ __forceinline__ double swd_data_value(const SwdRows& R, const SwdBlk& B, int k, int chain, int nchain,
@@ -1338,6 +1333,18 @@ __device__ __forceinline__ double swd_data_value(const SwdRows& R, const SwdBlk&
     return u * sr_tm(love, croot[i0], 2.0 * SR_PI32 / B.t[k]);
 }
 
+// One kernel value of item e as the eigenfunction pass defines it: the emitted per-layer factor times the item's scale
+// (slot 0: alpha, beta, rho; slot 1: interface, flushed below 1e-38 as the reference does).  ugr: [3][item][chain] = U and
+// the two scale slots; s = n * nchain, lm = m * nchain + chain.
+__device__ __forceinline__ double swd_krn(const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot,
+                                          int e, int q, size_t s, size_t lm, int nchain, int chain)
+{
+    const double v = krn[((size_t)e * 4 + q) * s + lm];
+    const double sc = ugr[(size_t)(q == 3 ? 2 : 1) * ntot + (size_t)e * nchain + chain];
+    const double r = v * sc;
+    return (q == 3 && fabs(r) < 1.0e-38) ? 0.0 : r;
+}
+
 // kernel q (0 alpha, 1 beta, 2 rho, 3 interface) of row k of block B at layer m
 template <bool SPH>
 __device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBlk& B, int k, int q, int m, int chain,
@@ -1347,7 +1354,8 @@ __device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBl
     const size_t s = (size_t)n * nchain, lm = (size_t)m * nchain + chain;
     const bool love = B.type >= 2;
     const int e0 = B.off + k;
-    const double k0 = krn[((size_t)e0 * 4 + q) * s + lm];
+    const size_t ntot = (size_t)R.nitems * nchain;
+    const double k0 = swd_krn(krn, ugr, ntot, e0, q, s, lm, nchain, chain);
     double fac = 1.0;
     if (SPH) fac = (love ? R.sphL : R.sphR)[(size_t)((q < 2) ? 4 : (q == 2 ? 6 : 5)) * s + lm];
     if (!(B.type & 1)) {
@@ -1359,8 +1367,8 @@ __device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBl
     const double t = B.t[k], t1 = t * (1.0 + 0.05), t2 = t * (1.0 - 0.05);
     const double cg = ugr[(size_t)e0 * nchain + chain], cp = croot[(size_t)e0 * nchain + chain];
     const double uc1 = cg / cp;
-    const double k1 = krn[((size_t)e1 * 4 + q) * s + lm];
-    const double k2 = krn[((size_t)e2 * 4 + q) * s + lm];
+    const double k1 = swd_krn(krn, ugr, ntot, e1, q, s, lm, nchain, chain);
+    const double k2 = swd_krn(krn, ugr, ntot, e2, q, s, lm, nchain, chain);
     const double du = uc1 * (2.0 - uc1) * k2 - uc1 * uc1 * t * (k2 - k1) / (t2 - t1);
     if (!SPH) return du;
     const double omega = 2.0 * SR_PI32 / t, tm = sr_tm(love, cp, omega), tm1 = sr_tm1(love, omega, tm);
@@ -1424,9 +1432,9 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
               const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
               const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
               const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
-              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid)
+              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid, int rowc)
 {
-    extern __shared__ double hs[];               // [n][32] interface partial sums
+    extern __shared__ double hs[];               // [n][32] interface partial sums (+ [3][nswd][32] row cache when rowc)
     // 32 chains x 32 layer slots per block: a wavefront = 32 consecutive chains (256 B segments of the chain-minor
     // arrays) x 2 layer slots, so the grid has nchain/32 blocks -- one per CU at 8192 chains instead of one per two
     const int tx = threadIdx.x & 31, slot = threadIdx.y * 2 + (threadIdx.x >> 5), NS = blockDim.y * 2;
@@ -1434,23 +1442,58 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
     const bool inb = chain < nchain;
     if (!inb) chain = nchain - 1;
     const int nswd = R.nswd, ndata = nt + nswd;
+    const size_t ntot = (size_t)R.nitems * nchain, s = (size_t)n * nchain;
     bool ok = true;
-    for (int s = 0; s < nseq; s++) ok = ok && (sflag[(size_t)s * nchain + chain] != 0);
+    for (int q = 0; q < nseq; q++) ok = ok && (sflag[(size_t)q * nchain + chain] != 0);
     const double w = (mode == 0) ? wt : 1.0;
     double m_swd = 0.0;
+    // Row cache (rowc): what a data row contributes is the same for every layer -- its residual r and, for a phase-velocity
+    // row, the item's two kernel scales (swd_krn) -- so each (row, chain) pair is formed ONCE per block, by one of its 32
+    // layer slots, and read back from LDS by all of them: rc[0] = r, rc[1] = r x scale(alpha, beta, rho), rc[2] = interface scale
+    double* rc = hs + (size_t)n * 32;
+    if (rowc) {
+        int row = 0;
+        for (int b = 0; b < R.nblk; b++) {
+            const SwdBlk B = R.b[b];
+            for (int k = slot; k < B.nrow; k += NS) {
+                double d = ok ? swd_data_value<SPH>(R, B, k, chain, nchain, croot, ugr) : 0.0;
+                double r = d - dobs[nt + row + k];
+                const size_t gi = (size_t)(B.off + k) * nchain + chain;
+                rc[(size_t)(row + k) * 32 + tx] = r;
+                rc[(size_t)(nswd + row + k) * 32 + tx] = r * ugr[ntot + gi];
+                rc[(size_t)(2 * nswd + row + k) * 32 + tx] = ugr[2 * ntot + gi];
+                if (ok && inb && dsyn) dsyn[(size_t)chain * ndata + nt + row + k] = d;
+            }
+            row += B.nrow;
+        }
+        __syncthreads();
+    }
     for (int j = slot; j < n; j += NS) {
         double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
         double gs = 0.0, hj = 0.0;
+        const size_t lm = (size_t)j * nchain + chain;
         if (ok) {
             int row = 0;
             for (int b = 0; b < R.nblk; b++) {
                 const SwdBlk B = R.b[b];
+                const bool plain = rowc && !SPH && !(B.type & 1);          // phase velocities of the flat model: k0 itself
                 for (int k = 0; k < B.nrow; k++, row++) {
-                    double d = swd_data_value<SPH>(R, B, k, chain, nchain, croot, ugr);
-                    double r = d - dobs[nt + row];
-                    if (j == slot && slot == 0) {
-                        m_swd += r * r;
-                        if (inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
+                    double r;
+                    if (rowc) r = rc[(size_t)row * 32 + tx];
+                    else {
+                        double d = swd_data_value<SPH>(R, B, k, chain, nchain, croot, ugr);
+                        r = d - dobs[nt + row];
+                        if (j == slot && slot == 0 && inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
+                    }
+                    if (j == slot && slot == 0) m_swd += r * r;
+                    if (plain) {
+                        const double* kq = krn + (size_t)(B.off + k) * 4 * s + lm;
+                        const double ka = kq[0], kb = kq[s], kr = kq[2 * s];
+                        double kh = kq[3 * s] * rc[(size_t)(2 * nswd + row) * 32 + tx];
+                        if (fabs(kh) < 1.0e-38) kh = 0.0;
+                        gs += rc[(size_t)(nswd + row) * 32 + tx] * (kb + ka * dadb + kr * drdadb);
+                        hj += r * kh;
+                        continue;
                     }
                     double ka = swd_kernel_value<SPH>(R, B, k, 0, j, chain, nchain, n, krn, croot, ugr);
                     double kb = swd_kernel_value<SPH>(R, B, k, 1, j, chain, nchain, n, krn, croot, ugr);
