@@ -467,25 +467,23 @@ def da_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barr
     # given the chains different step sizes) finish in bursts; time a window behind them
     nwarm = max(nwarm, 40)
     marks = {}
-    active = torch.zeros((), dtype=torch.int64, device=dev)
 
     def hook(s, st):
         if s == 1:
             gt.on()
-            active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum()); active.zero_()   # first use loads torch kernels
         if s == nwarm:
             marks["warm"] = gt.read()
             marks["dom"] = int(np.argmax(marks["warm"][0]))
             gt.on(1 << marks["dom"])
             marks["stat0"] = (ctx.stat("swd_warm_declined_chains"), ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals"))
+            marks["fs0"] = ctx.stat("flow_chain_steps")     # chains inside a trajectory, summed over the steps = leapfrog steps done
             barrier()
             marks["t0"] = time.perf_counter()
-        if nwarm <= s < nwarm + K:          # chains inside a trajectory in this step = leapfrog steps done
-            active.add_(((st["rem"] > 0) | (st["fresh"] != 0)).sum())
         if s == nwarm + K:
             ctx.check(ctx.L.rfs_synchronize(ctx.h))
             barrier()
             marks["t1"] = time.perf_counter()
+            marks["fs1"] = ctx.stat("flow_chain_steps")
             marks["dt"] = st["dt"].clone()
             marks["stat1"] = (ctx.stat("swd_warm_declined_chains"), ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals"))
 
@@ -499,7 +497,7 @@ def da_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barr
     launches = {k: cnt_w[i] / nw for i, k in enumerate(gt.names)}
     dom_id = marks["dom"]; dom = gt.names[dom_id]
     ms_step[dom] = ms[dom_id] / K; launches[dom] = cnt[dom_id] / K
-    evals = int(active.item())
+    evals = int(marks["fs1"] - marks["fs0"])
     rep = leg_report(cfg, config, nchain, K, el, evals, ms_step, launches, dom, ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0)
     d0, i0, e0 = marks["stat0"]
     d1, i1, e1 = marks["stat1"]
@@ -605,27 +603,22 @@ def run_rank(args):
             smp = HamitonianMC(joint, bounds, 0.002, [5, 20], 10, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
                                nchains=nchain, verbose=False, store_syn=False)
             mk = {}
-            act = torch.zeros((), dtype=torch.int64, device=dev)
             # (a window of >= 2 s: this is also the leg a coarse utilisation sampler can see the device busy in)
             w2, K2 = 25, max(K, args.sustain)
 
             def hook2(s, stt):
-                if s == 1:                                   # torch loads these kernels on first use (~30 ms): not in the window
-                    act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum()); act.zero_()
                 if s == w2:
+                    mk["d0"], mk["f0"] = ctx.stat("swd_warm_declined_chains"), ctx.stat("flow_chain_steps")
                     torch.cuda.synchronize(); mk["t0"] = time.perf_counter()
-                    mk["d0"] = ctx.stat("swd_warm_declined_chains")
-                if w2 <= s < w2 + K2:
-                    act.add_(((stt["rem"] > 0) | (stt["fresh"] != 0)).sum())
                 if s == w2 + K2:
                     ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); mk["t1"] = time.perf_counter()
-                    mk["d1"] = ctx.stat("swd_warm_declined_chains")
+                    mk["d1"], mk["f1"] = ctx.stat("swd_warm_declined_chains"), ctx.stat("flow_chain_steps")
 
             smp.sample_flow(x_init=xs, max_steps=w2 + K2 + 1, step_hook=hook2)
             el2 = mk["t1"] - mk["t0"]
             extra["sampler_flow"] = {
-                "value": int(act.item()) / el2, "unit": "evals/s", "steps": K2, "ms_per_step": el2 / K2 * 1e3,
-                "chains_in_a_trajectory_per_step": int(act.item()) / K2,
+                "value": (mk["f1"] - mk["f0"]) / el2, "unit": "evals/s", "steps": K2, "ms_per_step": el2 / K2 * 1e3,
+                "chains_in_a_trajectory_per_step": (mk["f1"] - mk["f0"]) / K2,
                 "chains_handed_back_to_the_full_search_per_step": (mk["d1"] - mk["d0"]) / K2,
                 "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): every chain's acceptance draw, "
                         "next L and momentum come from its own MT19937 stream on the host, ahead of time; the device accepts / "

@@ -298,6 +298,8 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          first k periods.  Results are bit-identical for every value. */
 int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
 /* Counters (cumulative since the context's warm-start buffers were made; the call synchronises):
+ *   "flow_chain_steps"          (chain, step) pairs by which rfs_flow_step / rfs_flow_step2 advanced a trajectory (idle chains
+ *                               -- waiting for the host, or failed -- do not count): the evaluations a sampler used
  *   "swd_warm_declined_chains"  chain evaluations the warm start handed back to the reference-semantics search
  *   "swd_warm_items"            (period, chain) items the warm start refined
  *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items

@@ -88,7 +88,7 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, fstat;
     hipEvent_t ev_w[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     bool swd_water_cur = false;           // the batch being launched holds models with a water layer on top (B1 entries)
@@ -1237,7 +1237,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
@@ -1369,6 +1369,15 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     if (!c || !name || !value) return RFS_ERR_ARG;
     *value = 0;
     int idx = -1;
+    if (!strcmp(name, "flow_chain_steps")) {          // (chain, step) pairs the flow entries advanced a trajectory by
+        if (!c->fstat.p) return RFS_OK;
+        HIPCHK(c, hipSetDevice(c->device));
+        TRY(rfs_synchronize(c));
+        unsigned long long v = 0;
+        HIPCHK(c, hipMemcpy(&v, c->fstat.p, sizeof(v), hipMemcpyDeviceToHost));
+        *value = (int64_t)v;
+        return RFS_OK;
+    }
     if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
     else if (!strcmp(name, "swd_warm_secular_evals")) idx = 1;
     else if (!strcmp(name, "swd_warm_items")) idx = 2;
@@ -1807,8 +1816,12 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
             fn.croot = c->croot.as<double>(); fn.crs = c->crs.as<double>(); fn.xw = c->xw.as<double>(); fn.nitems = nit;
         }
     }
+    if (!c->fstat.p) {
+        ENSURE(c, c->fstat, sizeof(unsigned long long));
+        HIPCHK(c, hipMemsetAsync(c->fstat.p, 0, sizeof(unsigned long long), c->stream));
+    }
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
-                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn);
+                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>());
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }

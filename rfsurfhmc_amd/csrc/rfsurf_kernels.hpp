@@ -1706,7 +1706,7 @@ struct FlowNext {
 __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, const double* U,
                             const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
                             double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
-                            double* dsyn_new, int* ok, int* done, FlowNext nx_)
+                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount)
 {
     __shared__ double red[4];
     __shared__ int bad;
@@ -1715,6 +1715,7 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
     const int fr = fresh[chain], rm = rem[chain];
     if (tid == 0) done[chain] = 0;
     if (!fr && (rm <= 0 || !ok[chain])) return;                // idle chain (block-uniform)
+    if (tid == 0 && fcount) atomicAdd(fcount, 1ull);           // statistic "flow_chain_steps": evaluations a trajectory used
     if (tid == 0) bad = 0;
     __syncthreads();
     int mybad = 0;

@@ -186,6 +186,15 @@ def test_flow_schedule_equals_batch_schedule(golden):
     assert rel(mb[0], g["hmc_r0/misfit"]) < 1e-5
     # batch: every round costs max(L) + 1 evaluations of every chain; flow: one evaluation per chain and step
     assert b.flow_steps > 0
+    # the library's own count of the evaluations the trajectories used (statistic "flow_chain_steps", what bench.py
+    # divides by the time): the chains inside a trajectory at every step, counted here on the host side of the same run
+    import torch
+    c = mk(); seen = []
+    ctx = c.model._ensure(len(g["bounds"]) // 2)
+    f0 = ctx.stat("flow_chain_steps")
+    c.sample_flow(step_hook=lambda s_, st: seen.append(int(((st["rem"] > 0) | (st["fresh"] != 0)).sum().item())))
+    n_lib = ctx.stat("flow_chain_steps") - f0
+    assert 0 < n_lib <= sum(seen) and n_lib >= sum(seen) - 7 * 3          # (a failed chain idles with rem > 0 until the host takes it)
 
 
 def test_flow_schedule_equals_batch_schedule_dual_averaging(golden):
