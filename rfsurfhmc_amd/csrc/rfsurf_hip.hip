@@ -1373,9 +1373,9 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
         if (!c->fstat.p) return RFS_OK;
         HIPCHK(c, hipSetDevice(c->device));
         TRY(rfs_synchronize(c));
-        unsigned long long v = 0;
-        HIPCHK(c, hipMemcpy(&v, c->fstat.p, sizeof(v), hipMemcpyDeviceToHost));
-        *value = (int64_t)v;
+        unsigned long long v[64];
+        HIPCHK(c, hipMemcpy(v, c->fstat.p, sizeof(v), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 64; i++) *value += (int64_t)v[i];
         return RFS_OK;
     }
     if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
@@ -1817,8 +1817,8 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
         }
     }
     if (!c->fstat.p) {
-        ENSURE(c, c->fstat, sizeof(unsigned long long));
-        HIPCHK(c, hipMemsetAsync(c->fstat.p, 0, sizeof(unsigned long long), c->stream));
+        ENSURE(c, c->fstat, 64 * sizeof(unsigned long long));
+        HIPCHK(c, hipMemsetAsync(c->fstat.p, 0, 64 * sizeof(unsigned long long), c->stream));
     }
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>());
