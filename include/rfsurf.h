@@ -289,6 +289,13 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *   "swd_warm_serial"      1: a warm-started step runs on ONE stream (every kernel alone on the chip: clean per-kernel
  *                          durations for profiling); 0 (default): the surface-wave kernels on a second stream beside the
  *                          receiver-function sweeps (~5 % faster).  Results are identical.
+ *   "rf_row_peeling"       frequency-domain RF adjoint of the joint entries: 1 = the column sweep (pass B) obtains the row
+ *                          of layer j from the row of layer j-1 times A_j^-1 (the propagator over -h), starting from the
+ *                          row sweep's final row, instead of reading one stored row per (layer, frequency): no row
+ *                          scratch (2 GB per 8192 chains at 30 layers), no chain tiles.  Exact where every wave propagates
+ *                          inside the layers (|exp(nu h)| ~ 1: nothing is amplified; rows agree with the stored ones to
+ *                          1e-14 over 50 layers); 0 = stored rows.  -1 (default) = 1 for |ray_p| <= 0.1 s/km
+ *                          (p alpha < 1 up to alpha = 10 km/s), 0 beyond.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.

@@ -114,6 +114,19 @@ RFS_HD V4 rf_row_times_A(const V4& r, const RfA& A) {   // r' = r . A
     return o;
 }
 
+// r' = r . A^-1.  A is the layer's propagator over its thickness h (the factor gamma does not depend on h), so its inverse
+// is the propagator over -h: the cosh-type entries stay, the sinh-type ones (a12, a14, a21, a23, a32, a41) change sign.
+// Pass B peels the layers off pass A's FINAL row with it instead of reading a stored row per layer -- sound where the
+// waves propagate inside the layers (teleseismic slownesses: |exp(nu h)| stays near 1 and nothing is amplified).
+RFS_HD V4 rf_row_times_Ainv(const V4& r, const RfA& A) {
+    V4 o;
+    o.v[0] = A.g * (r.v[0] * A.a11 - r.v[1] * A.a21 + r.v[2] * A.a31 - r.v[3] * A.a41);
+    o.v[1] = A.g * (r.v[1] * A.a22 - r.v[0] * A.a12 - r.v[2] * A.a32 - r.v[3] * A.a31);
+    o.v[2] = A.g * (r.v[0] * A.a13 - r.v[1] * A.a23 + r.v[2] * A.a22 + r.v[3] * A.a21);
+    o.v[3] = A.g * (r.v[1] * A.a24 - r.v[0] * A.a14 + r.v[2] * A.a12 + r.v[3] * A.a11);
+    return o;
+}
+
 RFS_HD V4 rf_A_times_col(const RfA& A, const V4& y) {   // y' = A . y
     V4 o;
     o.v[0] = A.g * (A.a11 * y.v[0] + A.a12 * y.v[1] + A.a13 * y.v[2] + A.a14 * y.v[3]);

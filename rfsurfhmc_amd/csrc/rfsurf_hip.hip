@@ -79,6 +79,7 @@ struct rfs_ctx {
     int swd_segments = -1; // segments of the vector recurrence in the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
+    int rf_peel = -1;          // option "rf_row_peeling": pass B peels the layers off pass A's final row instead of reading stored rows (-1 = where the waves propagate: ray_p <= 0.1 s/km)
     int rf_band_digits = 13;   // option "rf_band_limit_digits": adjoint band limit at 1e-digits * water (0 = off)
     int rf_band_floor = 8;     // option "rf_band_floor_digits": the limit may move down to a multiple of 64 bins, never below this
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
@@ -96,6 +97,7 @@ struct rfs_ctx {
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
+    Buf RT;                               // final rows of pass A (row peeling, k_rf_passB<., true>)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
     // leapfrog state
@@ -298,18 +300,21 @@ constexpr int RF_MAX_CHAINS_PER_LAUNCH = 32768;      // the RF sweeps use one gr
 
 // pass A (+ scratch) for the nchain chains that start at chain c0 of the batch (RR, Rs are tile-local: offset 0); lc must
 // be ready
-int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, size_t c0 = 0) {
+// peel: pass B will peel the layers off the final row (k_rf_passB<., true>): only that row is kept, no row scratch
+int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, size_t c0 = 0, bool peel = false) {
     if (nchain > 2 * RF_MAX_CHAINS_PER_LAUNCH - 4096)
         return fail(c, RFS_ERR_UNSUPPORTED, "more than 61440 chains in one receiver-function launch: split the batch");
     ENSURE(c, c->RR, (size_t)nchain * 4 * f.n2p * sizeof(double));
-    if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.nkp * sizeof(double));
-    double* Rs = scratch ? c->Rs.as<double>() : nullptr;
+    if (scratch && !peel) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.nkp * sizeof(double));
+    if (scratch && peel) ENSURE(c, c->RT, (size_t)nchain * 8 * f.nkp * sizeof(double));
+    double* Rs = (scratch && !peel) ? c->Rs.as<double>() : nullptr;
+    double* RT = (scratch && peel) ? c->RT.as<double>() : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 128);
     dim3 grid(rf_chunks_of(f, bs), nchain);
-    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs);
+    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs, RT);
     hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                       c->RR.as<double>(), Rs);
+                       c->RR.as<double>(), Rs, RT);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -342,19 +347,23 @@ int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dob
     return RFS_OK;
 }
 
-int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0) {
+int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0, bool peel = false) {
     int npart = rf_nparts_b(f);
     ENSURE(c, c->PG, (size_t)nchain * npart * 4 * n * sizeof(double));
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 64);
     dim3 grid(rf_chunks_b(f), nchain);
-    hipLaunchKernelGGL(k_rf_passB<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
-                       c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
-                       c->PG.as<double>());
-    if (f.nk >= f.n2)       // the Nyquist bin, lane = chain (no band limit: it is the first bin to go)
-        hipLaunchKernelGGL(k_rf_passB<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                           c->RR.as<double>(), c->Rs.as<double>(), c->W.as<cplx>(), c->wmax2.as<double>(), npart,
-                           c->PG.as<double>());
+    const double* rows = peel ? c->RT.as<double>() : c->Rs.as<double>();
+    if (peel) hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
+                                 c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+    else hipLaunchKernelGGL((k_rf_passB<false, false>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
+                            c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+    if (f.nk >= f.n2) {     // the Nyquist bin, lane = chain (no band limit: it is the first bin to go)
+        if (peel) hipLaunchKernelGGL((k_rf_passB<true, true>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
+                                     c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+        else hipLaunchKernelGGL((k_rf_passB<true, false>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
+                                c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+    }
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -984,7 +993,11 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     const bool rf_time = c->has_rf && c->f.method != RFS_RF_FREQ;
     // chain tiles of the RF pipeline: the pass-A row scratch of one tile stays within rf_scratch_budget
     int rf_tile = nchain;
-    if (c->has_rf && !rf_time) {
+    // rows by peeling (no row scratch, no tiles): in the layers of a teleseismic receiver function every wave propagates
+    // (p < 1 / alpha: |exp(nu h)| ~ 1), so A_j^-1 amplifies nothing; post-critical slownesses keep the stored rows
+    const bool rf_peel = c->has_rf && !rf_time && (c->rf_peel == 1 || (c->rf_peel < 0 && std::fabs(c->f.p) <= 0.1));
+    if (c->has_rf && !rf_time && rf_peel) rf_tile = std::min(nchain, RF_MAX_CHAINS_PER_LAUNCH);
+    else if (c->has_rf && !rf_time) {
         const size_t per_chain = (size_t)(n - 1) * 8 * c->f.nkp * sizeof(double);
         size_t fit = per_chain ? c->rf_scratch_budget / per_chain : (size_t)nchain;
         if (fit < (size_t)nchain) rf_tile = (int)std::max<size_t>(64, fit / 64 * 64);
@@ -1149,11 +1162,11 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
             // the gradient.  The reduction does not wait for the search, so it runs here, on the RF stream.
             for (int c0 = 0; c0 < nchain && !rc; c0 += rf_tile) {
                 const int nc = std::min(rf_tile, nchain - c0);
-                { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nc, n, c->f, true, (size_t)c0); }
+                { KTimer t(c, RFS_K_RF_PASS_A, c->stream); rc = launch_passA(c, nc, n, c->f, true, (size_t)c0, rf_peel); }
                 if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
                     rc = launch_mid(c, nc, n, c->f, c->d_dobs.as<double>(), c->ndata,
                                     dsyn ? dsyn + (size_t)c0 * c->ndata : nullptr, true, (size_t)c0, (size_t)nchain); }
-                if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0);
+                if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0, rf_peel);
                     if (!rc) {
                         hipLaunchKernelGGL(k_rf_reduce, dim3(nc), dim3(n <= 64 ? 64 : 128), 0, c->stream, nc, n,
                                            (int)!c->has_swd, rf_nparts_b(c->f), c->PG.as<double>(), c->mrf.as<double>() + c0,
@@ -1237,7 +1250,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
@@ -1328,6 +1341,12 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 300) return fail(c, RFS_ERR_ARG, "rf_band_limit_digits must be within [0, 300]");
         c->rf_band_digits = value;
         if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value, c->rf_band_floor); }
+        for (auto& kv : c->calib) kv.second.stage = -1;
+        return RFS_OK;
+    }
+    if (!strcmp(name, "rf_row_peeling")) {
+        if (value < -1 || value > 1) return fail(c, RFS_ERR_ARG, "rf_row_peeling must be -1 (automatic), 0 or 1");
+        c->rf_peel = value;
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
     }

@@ -238,7 +238,7 @@ __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ m
 template <bool TAIL>
 __global__ void __launch_bounds__(256)
 k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
-           double* __restrict__ Rs)
+           double* __restrict__ Rs, double* __restrict__ RT)
 {
     int chain, k;
     if (TAIL) {
@@ -263,6 +263,11 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
         rf_hyp(L[j], omega, H);
         rf_build_A(L[j], H, A);
         r = rf_row_times_A(r, A);
+    }
+    if (RT && k < f.nk) {            // pass B peels the layers off this FINAL row itself (rf_row_times_Ainv): no row scratch
+        double* o = RT + (size_t)chain * 8 * nkp + k;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { o[(2 * i) * nkp] = r.v[i].re; o[(2 * i + 1) * nkp] = r.v[i].im; }
     }
     int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
     cplx r21 = r.v[c21];
@@ -368,7 +373,9 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
     return y;
 }
 
-template <bool TAIL>
+// INV: no stored rows -- the row of layer j is the row of layer j-1 times A_j^-1, starting from pass A's final row (Rs then
+// points at that: [chain][8][nkp])
+template <bool TAIL, bool INV = false>
 __global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
 k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
            const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
@@ -392,21 +399,31 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
     cplx omega = C(rf_wk(f, k), -f.sigma), kk = f.p * omega;
     V4 y = rf_adjoint_seed(f, k, r21, r22, W[(size_t)chain * f.n2 + k], wmax2[chain]);
     if (!live) { y.v[0] = C(0.0); y.v[1] = C(0.0); }
-    const double* rs = Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k;
+    const double* rs = Rs + (INV ? (size_t)chain * 8 * nkp : ((size_t)chain * (n - 1)) * 8 * nkp) + k;
     double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const int lane = threadIdx.x & 63;
     double* pg = PG + ((size_t)chain * npart + part) * 4 * n;
+    V4 r;
+    if (INV) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.v[i] = C(rs[(2 * i) * nkp], rs[(2 * i + 1) * nkp]);
+    }
     for (int j = 0; j < n; j++) {
         cplx T[4];
         if (j < n - 1) {
-            const double* o = rs + (size_t)j * 8 * nkp;
-            V4 r;
-#pragma unroll
-            for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * nkp], o[(2 * i + 1) * nkp]);
             RfHyp H; RfA A;
             rf_hyp(L[j], omega, H);
-            rf_layer_partials(L[j], H, kk, r, y, T);
-            rf_build_A(L[j], H, A);
+            if (INV) {
+                rf_build_A(L[j], H, A);
+                r = rf_row_times_Ainv(r, A);
+                rf_layer_partials(L[j], H, kk, r, y, T);
+            } else {
+                const double* o = rs + (size_t)j * 8 * nkp;
+#pragma unroll
+                for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * nkp], o[(2 * i + 1) * nkp]);
+                rf_layer_partials(L[j], H, kk, r, y, T);
+                rf_build_A(L[j], H, A);
+            }
             y = rf_A_times_col(A, y);
         } else {
             rf_half_partials(L[j], omega, f.rf_type, y, T);
