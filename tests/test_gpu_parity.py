@@ -199,3 +199,37 @@ def test_b2_against_oracle_seeded_batch(hip, orc):
     for i in range(0, nchain, 8):
         mo, go, do, fo = o_joint.misfit_and_grad(xs[i])
         assert fo and abs(m[i] - mo) / mo < 2e-6 and rel(g[i], go) < 2e-6 and rel(d[i], do) < 1e-6, i
+
+
+@pytest.mark.parametrize("n,thk_each,rf_type", [(30, 2.0, "P"), (50, 1.2, "P"), (12, 3.0, "S")])
+def test_rf_gradient_by_row_peeling_equals_stored_rows(hip, orc, n, thk_each, rf_type):
+    """Option rf_row_peeling: the column sweep takes the row of layer j from the row of layer j-1 times A_j^-1 (no row
+    scratch) -- the same RF gradient as with one stored row per (layer, frequency) to 1e-11 (observed 1e-13), both within
+    1e-8 of the oracle; a post-critical slowness switches the automatic choice back to stored rows."""
+    rng = np.random.default_rng(5 + n)
+    nt = 512
+    vs0 = np.linspace(2.4, 4.6, n); thk0 = np.full(n, thk_each); thk0[-1] = 0
+    xs = np.tile(np.hstack((vs0, thk0)), (6, 1))
+    xs[:, :n] *= 0.97 + 0.06 * rng.random((6, n)); xs[:, n:2 * n - 1] *= 0.8 + 0.4 * rng.random((6, n - 1))
+    args = (0.06, nt, 0.1, 1.5, 5.0, 0.001, rf_type, "freq")
+    rf = hip.ReceiverFunc(*args); o_rf = orc.ReceiverFunc(*args)
+    d0 = o_rf.forward(np.hstack((vs0, thk0)))
+    rf.set_obsdata(d0); o_rf.set_obsdata(d0)
+    ctx = rf._ensure(n)
+    out = {}
+    for mode in (0, 1, -1):
+        ctx.set_option("rf_row_peeling", mode)
+        out[mode] = rf.misfit_and_grad(xs)
+    assert np.array_equal(out[1][1], out[-1][1])                       # automatic = peeling at ray_p = 0.06
+    assert rel(out[1][1], out[0][1]) < 1e-11 and np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][2], out[0][2])
+    for i in (0, 3, 5):
+        mo, go, do = o_rf.misfit_and_grad(xs[i])
+        assert rel(out[1][1][i], go) < 1e-8 and rel(out[0][1][i], go) < 1e-8 and abs(out[1][0][i] - mo) <= 1e-9 * mo
+    # beyond p = 0.1 s/km the automatic choice keeps the stored rows (bit-identical to mode 0)
+    rf2 = hip.ReceiverFunc(0.12, nt, 0.1, 1.5, 5.0, 0.001, rf_type, "freq")
+    rf2.set_obsdata(d0)
+    c2 = rf2._ensure(n)
+    a = rf2.misfit_and_grad(xs)
+    c2.set_option("rf_row_peeling", 0)
+    b = rf2.misfit_and_grad(xs)
+    assert np.array_equal(a[1], b[1])
