@@ -1225,6 +1225,7 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
         const bool fluid = wat0 && m == 0;
         SvTrig t;
         const double ia = rcp_p(a), ib = fluid ? 0.0 : rcp_p(b), irho = rcp_p(rho);
+        if (!half) load(m + 1, cd, exe_m);       // (issued here: the Haskell step below hides the scratch round trip)
         if (!half) {
             if (fluid) {
                 const double xka = omega / a;
@@ -1237,7 +1238,6 @@ RFS_HD SrTotals sr_down_energy(const Mdl& M, double omega, double wvno, const Lo
                 double ex2 = sr_haskell_step(vv, t, M.Rf(m), M.Bf(m), Q);
                 exa = exa + t.pex + ex2;
             }
-            load(m + 1, cd, exe_m);
             // svfunc :283-315
             double cd1 = cd[0], cd2 = cd[1], cd3 = cd[2], cd4 = -cd[2], cd5 = cd[3], cd6 = cd[4];
             double tz1 = -vv[3], tz2 = -vv[2], tz3 = vv[1], tz4 = vv[0];
