@@ -157,6 +157,9 @@ RFS_HD V4 rf_einv_row(const RfLayer& L, int rf_type) {
 // r . (dA/dm) . y for the four parameter classes of one finite layer, in the
 // reference's order [rho, vp, vs, thk] (RFModule.f90:771, 811-874), including the
 // complex-velocity rescaling alpha/vp, beta/vs (:624-628).  k = omega * p.
+// RHO = false leaves T[0] to the caller (pass B with row peeling has both neighbouring rows and forms it from the
+// commutator, rf_rho_partial).
+template <bool RHO = true>
 RFS_HD void rf_layer_partials(const RfLayer& L, const RfHyp& H, cplx k, const V4& r,
                               const V4& y, cplx T[4]) {
     const cplx g = L.gam, g1 = L.gam1, g2 = L.gam2, g3 = L.gam3;
@@ -178,7 +181,7 @@ RFS_HD void rf_layer_partials(const RfLayer& L, const RfHyp& H, cplx k, const V4
     const cplx m41 = L.mu2 * (r.v[3] * y.v[0]);
     const cplx g1sq = g1 * g1;
     // ---- rho (ipars = 1, :847-855): entries gamma/(2 rho mu) (.) and 2 mu gamma / rho (.) ----
-    {
+    if (RHO) {
         cplx t = dc * (i13 + g1 * m31) + (ya - xb) * i14 + (yb - xa) * i23 + (g1sq * ya - xb) * m32 + (g1sq * yb - xa) * m41;
         T[0] = (g / L.rho) * t;
     }
@@ -221,6 +224,14 @@ RFS_HD void rf_layer_partials(const RfLayer& L, const RfHyp& H, cplx k, const V4
                  + (g1 * kdx) * m31 + (g1sq * kca - nbcb) * m32 + (g1sq * kcb - naca) * m41;
         T[3] = g * t;
     }
+}
+
+// The density enters a layer matrix only through mu = rho beta^2, and mu only as the similarity A = D^-1 A' D with
+// D = diag(mu, mu, 1, 1) (entries (1:2, 3:4) carry 1/mu, entries (3:4, 1:2) carry mu), so dA/drho = (A K - K A) / rho with
+// K = diag(1, 1, 0, 0), and   r . dA/drho . y = ((r A)_{1:2} . y_{1:2} - r_{1:2} . (A y)_{1:2}) / rho:
+// with the row above (ra = r A) and the column below (ya = A y) at hand, four products.  Only the real part is used.
+RFS_HD double rf_rho_partial(const RfLayer& L, const V4& ra, const V4& y, const V4& r, const V4& ya) {
+    return ((re_mul(ra.v[0], y.v[0]) + re_mul(ra.v[1], y.v[1])) - (re_mul(r.v[0], ya.v[0]) + re_mul(r.v[1], ya.v[1]))) / L.rho;
 }
 
 // e_row . (dE^-1/dm) . y for the half-space (RFModule.f90:924-987).  For rf_type 1

@@ -415,16 +415,20 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
             rf_hyp(L[j], omega, H);
             if (INV) {
                 rf_build_A(L[j], H, A);
+                const V4 ra = r;                                  // the row above this layer (= r A)
                 r = rf_row_times_Ainv(r, A);
-                rf_layer_partials(L[j], H, kk, r, y, T);
+                rf_layer_partials<false>(L[j], H, kk, r, y, T);
+                const V4 ya = rf_A_times_col(A, y);
+                T[0] = C(rf_rho_partial(L[j], ra, y, r, ya));
+                y = ya;
             } else {
                 const double* o = rs + (size_t)j * 8 * nkp;
 #pragma unroll
                 for (int i = 0; i < 4; i++) r.v[i] = C(o[(2 * i) * nkp], o[(2 * i + 1) * nkp]);
                 rf_layer_partials(L[j], H, kk, r, y, T);
                 rf_build_A(L[j], H, A);
+                y = rf_A_times_col(A, y);
             }
-            y = rf_A_times_col(A, y);
         } else {
             rf_half_partials(L[j], omega, f.rf_type, y, T);
         }
