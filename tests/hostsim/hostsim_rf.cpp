@@ -55,4 +55,44 @@ void hs_rf_response_par_all(int n, const double* thk, const double* rho, const d
         }
     }
 }
+
+// Row peeling (k_rf_passB<., true>): the stored rows of the bottom-up sweep against the rows rebuilt from the final row
+// with rf_row_times_Ainv, and the density partial from the commutator (rf_rho_partial) against the closed form, one
+// frequency.  out[0] = worst relative row error, out[1] = worst relative error of Re(T_rho) against max |Re(T_rho)|.
+void hs_rf_peeling_errors(int n, const double* thk, const double* rho, const double* vp, const double* vs,
+                          const double* qa, const double* qb, double p, double w_re, double w_im, int rf_type, double* out)
+{
+    std::vector<RfLayer> L(n);
+    for (int j = 0; j < n; j++) rf_make_layer(L[j], thk[j], rho[j], vp[j], vs[j], qa[j], qb[j], p);
+    cplx omega = C(w_re, w_im), k = omega * p;
+    std::vector<V4> rs(n);
+    V4 r = rf_einv_row(L[n - 1], rf_type);
+    for (int j = n - 2; j >= 0; j--) {
+        rs[j] = r;
+        RfHyp H; RfA A;
+        rf_hyp(L[j], omega, H); rf_build_A(L[j], H, A);
+        r = rf_row_times_A(r, A);
+    }
+    V4 y; for (int i = 0; i < 4; i++) y.v[i] = C(0.0);
+    y.v[0] = C(0.3, -0.2); y.v[1] = C(-0.1, 0.7);
+    double erow = 0.0, etr = 0.0, tmax = 0.0;
+    std::vector<double> ta(n), tb(n);
+    for (int j = 0; j < n - 1; j++) {
+        RfHyp H; RfA A;
+        rf_hyp(L[j], omega, H); rf_build_A(L[j], H, A);
+        const V4 ra = r;
+        r = rf_row_times_Ainv(r, A);
+        double d = 0.0, m = 0.0;
+        for (int i = 0; i < 4; i++) { d += norm2(r.v[i] - rs[j].v[i]); m += norm2(rs[j].v[i]); }
+        if (sqrt(d / m) > erow) erow = sqrt(d / m);
+        cplx T[4];
+        rf_layer_partials(L[j], H, k, rs[j], y, T);
+        const V4 ya = rf_A_times_col(A, y);
+        ta[j] = T[0].re; tb[j] = rf_rho_partial(L[j], ra, y, r, ya);
+        if (fabs(ta[j]) > tmax) tmax = fabs(ta[j]);
+        y = ya;
+    }
+    for (int j = 0; j < n - 1; j++) if (fabs(ta[j] - tb[j]) / tmax > etr) etr = fabs(ta[j] - tb[j]) / tmax;
+    out[0] = erow; out[1] = etr;
+}
 }

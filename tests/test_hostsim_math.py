@@ -52,6 +52,30 @@ def test_rf_row_column_sweeps_equal_reference_partials(hs, orc, golden):
             assert rel(R21m, g[f"{name}/R21_m"][i]) < 1e-9 and rel(R22m, g[f"{name}/R22_m"][i]) < 1e-9
 
 
+def test_rf_row_peeling_and_commutator_density_partial(hs):
+    """Pass B's row peeling (option rf_row_peeling): the rows rebuilt from the final row with the inverse layer
+    matrices equal the stored rows of the bottom-up sweep, and the density partial from the commutator of the layer
+    matrix equals the closed form -- 30 and 50 layers, P and S type, teleseismic slownesses, the bench's frequency band."""
+    import ctypes
+    H = hs["rf"] if isinstance(hs, dict) else hs.rf
+    H.hs_rf_peeling_errors.restype = None
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    worst = [0.0, 0.0]
+    for n, h in ((30, 2.0), (50, 1.2)):
+        vs = np.linspace(2.0, 4.6, n); thk = np.full(n, h)
+        vp = 0.9409 + 2.0947 * vs - 0.8206 * vs ** 2 + 0.2683 * vs ** 3 - 0.0251 * vs ** 4
+        rho = 1.6612 * vp - 0.4721 * vp ** 2 + 0.0671 * vp ** 3 - 0.0043 * vp ** 4 + 0.000106 * vp ** 5
+        q = np.full(n, 9999.0)
+        for p in (0.045, 0.08):
+            for rf_type in (1, 2):
+                for kbin in (1, 17, 64, 127):
+                    out = np.zeros(2)
+                    H.hs_rf_peeling_errors(n, dp(thk), dp(rho), dp(vp), dp(vs), dp(q), dp(q), ctypes.c_double(p),
+                                           ctypes.c_double(2 * np.pi * kbin / 51.2), ctypes.c_double(-4.0 / 51.2), rf_type, dp(out))
+                    worst = [max(worst[0], out[0]), max(worst[1], out[1])]
+    assert worst[0] < 1e-12 and worst[1] < 1e-11, worst
+
+
 @pytest.mark.parametrize("entry", ["hs_swd_rootsearch", "hs_swd_rootsearch_split"])
 def test_root_search_state_machine(hs, orc, golden, entry):
     """Request/advance state machine (+ the split secular function of the multi-lane kernels)."""
