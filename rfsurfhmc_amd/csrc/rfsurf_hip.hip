@@ -1117,6 +1117,29 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
     }
+    // K.r of the surface-wave rows, thickness suffix sums, weighting, misfit, flags (k_swd_combine).  first: launched on the
+    // surface-wave stream right behind the eigenfunction pass, BESIDE the RF sweeps -- it then writes gradient / misfit /
+    // flag first and the RF reduction adds its part behind the join (k_rf_reduce, merge): the same sums, and ~0.1 ms of
+    // the step's serial tail gone
+    auto launch_combine = [&](hipStream_t st, int first) -> int {
+        KTimer t(c, RFS_K_COMBINE, st);
+        const SwdRows& R = P.R;
+        const int nt = c->has_rf ? c->f.nt : 0;
+        // (row cache in LDS: residual + kernel scales of every data row of the block's 32 chains, while it fits)
+        const int rowc = ((size_t)(n + 3 * R.nswd) * 32 * sizeof(double) <= 56 * 1024) ? 1 : 0;
+        const size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
+#define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
+        hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 16), lds_c,                             \
+                           st, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),                \
+                           c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),          \
+                           P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                      \
+                           track ? c->wvalid.as<int>() : (int*)nullptr, rowc, first)
+        if (c->sphere) RFS_LAUNCH_COMBINE(true); else RFS_LAUNCH_COMBINE(false);
+#undef RFS_LAUNCH_COMBINE
+        HIPCHK(c, hipGetLastError());
+        return RFS_OK;
+    };
+    const bool early_combine = c->has_swd && c->has_rf && c->mode == 0 && !part && !tiled && !rf_time;
     if (c->has_swd && c->has_rf) {     // the latency-bound root search runs beside the RF kernels
         hipStream_t ss = part ? c->stream2m : ((warm && c->warm_serial) ? user : c->stream2);
         HIPCHK(c, hipEventRecord(c->ev_fork, user));
@@ -1125,6 +1148,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         // partitioned step with a Love block: the RF half carries the Love search ahead of its sweeps and ends last, so the
         // Rayleigh eigenfunction pass runs on the search half right behind the search instead of waiting for the join
         if (a_eigen) TRY(launch_swd(c, ss, nchain, n, P, true, false, 3));
+        if (early_combine) { ENSURE(c, c->mrf, (size_t)nchain * sizeof(double)); TRY(launch_combine(ss, 1)); }
         HIPCHK(c, hipEventRecord(c->ev_join, ss));
     } else if (c->has_swd) {
         TRY(launch_swd(c, user, nchain, n, P, true, true, 0, 0, warm));
@@ -1168,10 +1192,13 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                                     dsyn ? dsyn + (size_t)c0 * c->ndata : nullptr, true, (size_t)c0, (size_t)nchain); }
                 if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0, rf_peel);
                     if (!rc) {
+                        // (early_combine: one tile; the surface-wave part is in place once the join has passed)
+                        if (early_combine) { if (hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess) rc = RFS_ERR_HIP; }
                         hipLaunchKernelGGL(k_rf_reduce, dim3(nc), dim3(n <= 64 ? 64 : 128), 0, c->stream, nc, n,
                                            (int)!c->has_swd, rf_nparts_b(c->f), c->PG.as<double>(), c->mrf.as<double>() + c0,
                                            c->cr.as<double>() + (size_t)c0 * 2 * n, misfit + c0, grad + (size_t)c0 * 2 * n,
-                                           flag + c0);
+                                           flag + c0, (int)early_combine, c->d_dobs.as<double>(),
+                                           dsyn ? dsyn + (size_t)c0 * c->ndata : (double*)nullptr, c->ndata, c->wt);
                     } }
             }
             rf_reduced = true;
@@ -1181,31 +1208,16 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         if (rc) return rc;
         if (part) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(user, c->ev_join3, 0)); }
     }
-    if (c->has_swd && c->has_rf) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));
+    if (c->has_swd && c->has_rf && !early_combine) HIPCHK(c, hipStreamWaitEvent(user, c->ev_join, 0));      // (early_combine: joined before the reduction)
     if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, a_eigen ? 4 : (early_items > 0 ? 2 : 0)));   // (rest of the) eigenfunction pass, whole chip
-    {
+    if (c->has_rf && !rf_reduced) {
         KTimer t(c, RFS_K_COMBINE, c->stream);
-        const SwdRows& R = P.R;
-        int nt = c->has_rf ? c->f.nt : 0;
-        if (c->has_rf && !rf_reduced)
-            hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
-                               (int)!c->has_swd, rf_time ? 1 : rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
-                               c->cr.as<double>(), misfit, grad, flag);
-        if (c->has_swd) {
-            // (row cache in LDS: residual + kernel scales of every data row of the block's 32 chains, while it fits)
-            const int rowc = ((size_t)(n + 3 * R.nswd) * 32 * sizeof(double) <= 56 * 1024) ? 1 : 0;
-            const size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
-#define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
-            hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 16), lds_c,                         \
-                               c->stream, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),     \
-                               c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),      \
-                               P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                  \
-                               track ? c->wvalid.as<int>() : (int*)nullptr, rowc)
-            if (c->sphere) RFS_LAUNCH_COMBINE(true); else RFS_LAUNCH_COMBINE(false);
-#undef RFS_LAUNCH_COMBINE
-        }
+        hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
+                           (int)!c->has_swd, rf_time ? 1 : rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
+                           c->cr.as<double>(), misfit, grad, flag, 0, (const double*)nullptr, (double*)nullptr, 0, 1.0);
         HIPCHK(c, hipGetLastError());
     }
+    if (c->has_swd && !early_combine) TRY(launch_combine(c->stream, 0));
     if (timed) { HIPCHK(c, hipEventRecord(cal->ev[2 * cal->stage + 1], user)); cal->stage++; }
     if (track) { c->warm_primed = true; c->warm_nchain = nchain; c->warm_nitems = P.nitems; }
     return RFS_OK;

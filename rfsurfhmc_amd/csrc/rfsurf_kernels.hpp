@@ -1427,12 +1427,20 @@ __global__ void k_swd_export(int nchain, int n, SwdRows R, const double* __restr
 //   k_swd_combine block = 32 chains x 32 layer slots, half-wave = 32 chains : K.r over the periods (krn is chain-minor),
 //                 interface -> thickness suffix sums, weighting, misfit, failure returns
 // mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198), 2 SWD only (model_surf.py:155-228)
+// merge != 0 (joint evaluation whose surface-wave part is already in place: k_swd_combine ran first, beside the RF
+// sweeps, and wrote its weighted gradient, misfit and flag): the RF part is ADDED, and a chain whose root search failed gets
+// the joint failure return (0, zeros, dobs, False: model_rf_swd_vs_thk.py:73-74) -- dsyn here, behind the RF synthetics.
 __global__ void __launch_bounds__(MAXL)
 k_rf_reduce(int nchain, int n, int rf_only, int npart, const double* __restrict__ PG,
             const double* __restrict__ misfit_rf, const double* __restrict__ cr,
-            double* __restrict__ misfit, double* __restrict__ grad, int* __restrict__ flag)
+            double* __restrict__ misfit, double* __restrict__ grad, int* __restrict__ flag,
+            int merge, const double* __restrict__ dobs, double* __restrict__ dsyn, int ndata, double wt)
 {
     int chain = blockIdx.x, j = threadIdx.x;
+    if (merge && !flag[chain]) {
+        if (dsyn) for (int i = j; i < ndata; i += blockDim.x) dsyn[(size_t)chain * ndata + i] = dobs[i];
+        return;
+    }
     if (j < n) {
         double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -1441,10 +1449,13 @@ k_rf_reduce(int nchain, int n, int rf_only, int npart, const double* __restrict_
             s0 += pg[((size_t)p * 4 + 0) * n + j]; s1 += pg[((size_t)p * 4 + 1) * n + j];
             s2 += pg[((size_t)p * 4 + 2) * n + j]; s3 += pg[((size_t)p * 4 + 3) * n + j];
         }
-        grad[(size_t)chain * 2 * n + j] = s2 + dadb * s1 + drdadb * s0;       // model_rf.py:189
-        grad[(size_t)chain * 2 * n + n + j] = s3;
+        const double gv = s2 + dadb * s1 + drdadb * s0;                         // model_rf.py:189
+        const size_t o = (size_t)chain * 2 * n + j;
+        grad[o] = merge ? ::fma(wt, grad[o], gv) : gv;                            // (k_swd_combine left its unweighted sums)
+        grad[o + n] = merge ? ::fma(wt, grad[o + n], s3) : s3;
     }
     if (rf_only && j == 0) { misfit[chain] = misfit_rf[chain]; flag[chain] = 1; }
+    if (merge && j == 0) misfit[chain] = ::fma(wt, misfit[chain], misfit_rf[chain]);
 }
 
 template <bool SPH>
@@ -1453,8 +1464,10 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
               const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
               const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
               const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
-              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid, int rowc)
+              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid, int rowc, int first)
 {
+    // first != 0 (joint evaluation, launched beside the RF sweeps): this kernel writes gradient, misfit and flag FIRST and
+    // k_rf_reduce adds the RF part behind it (same sums, the other way round); dsyn of a failed chain is left to it as well
     extern __shared__ double hs[];               // [n][32] interface partial sums (+ [3][nswd][32] row cache when rowc)
     // 32 chains x 32 layer slots per block: a wavefront = 32 consecutive chains (256 B segments of the chain-minor
     // arrays) x 2 layer slots, so the grid has nchain/32 blocks -- one per CU at 8192 chains instead of one per two
@@ -1529,7 +1542,7 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
         if (inb) {
             size_t o = (size_t)chain * 2 * n + j;
             if (!ok) grad[o] = 0.0;
-            else grad[o] = ((mode == 0) ? grad[o] : 0.0) + w * gs;
+            else grad[o] = first ? gs : ::fma(w, gs, (mode == 0) ? grad[o] : 0.0);     // (first: unweighted; k_rf_reduce forms the same fma)
         }
     }
     __syncthreads();
@@ -1539,19 +1552,19 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
         if (inb) {
             size_t o = (size_t)chain * 2 * n + n + j;
             if (!ok) grad[o] = 0.0;
-            else grad[o] = ((mode == 0) ? grad[o] : 0.0) + w * t;
+            else grad[o] = first ? t : ::fma(w, t, (mode == 0) ? grad[o] : 0.0);
         }
     }
     if (!inb) return;
     if (!ok) {
         // failure returns: joint -> (0, zeros, dobs, False); SWD only -> (0, zeros, zeros, False)
-        if (dsyn) for (int i = slot; i < ndata; i += NS) dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
+        if (dsyn && !first) for (int i = slot; i < ndata; i += NS) dsyn[(size_t)chain * ndata + i] = (mode == 0) ? dobs[i] : 0.0;
         if (slot == 0) { misfit[chain] = 0.0; flag[chain] = 0; if (wvalid) wvalid[chain] = 0; }
         return;
     }
     if (slot == 0) {
         double mr = (mode == 0) ? misfit_rf[chain] : 0.0;
-        misfit[chain] = mr + w * (0.5 * m_swd);
+        misfit[chain] = first ? 0.5 * m_swd : ::fma(w, 0.5 * m_swd, mr);
         flag[chain] = 1;
         if (wvalid) wvalid[chain] = 1;          // roots + kernels of this chain can seed the next evaluation (k_swd_warm)
     }
