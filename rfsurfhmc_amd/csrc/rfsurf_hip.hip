@@ -937,7 +937,7 @@ int upload(rfs_ctx* c, Buf& b, const void* host, size_t bytes) {
 // (rfs_leapfrog_dev): always the reference-semantics search, whose roots and kernels then seed the steps; 0 = a
 // plugin evaluation
 int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn, int32_t* flag,
-               int traj = 0) {
+               int traj = 0, const FlowPre* fpre = nullptr) {
     const int n = c->n;
     HIPCHK(c, hipSetDevice(c->device));
     // track: keep the model / roots / kernels of this evaluation for the next one; warm: use those of the previous one
@@ -1113,7 +1113,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
                            early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
                            early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 3 : (size_t)0),
-                           track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>());
+                           track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>(),
+                           fpre ? *fpre : FlowPre{});      // (flow entries: the step's drift rides in this kernel)
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
     }
@@ -1696,7 +1697,7 @@ int rfs_joint_forward(rfs_ctx* c, int nchain, const double* x, int quirk, double
     hipLaunchKernelGGL(k_prep_joint, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, n, c->x.as<double>(),
                        (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd, c->mdl.as<float>(),
                        c->mdlc.as<double>(), (double*)nullptr, (size_t)0, (int*)nullptr, (size_t)0,
-                       (double*)nullptr, (double*)nullptr, (double*)nullptr);
+                       (double*)nullptr, (double*)nullptr, (double*)nullptr, FlowPre{});
     c->warm_primed = false;                    // croot / krn are about to be overwritten by an unrelated evaluation
     int nt = c->has_rf ? c->f.nt : 0;
     if (c->has_rf) {
@@ -1835,9 +1836,9 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
     int* wforce = nullptr;
     if (c->exact_final && c->has_swd && c->warm_opt) { ENSURE(c, c->wforce, (size_t)nchain * sizeof(int)); wforce = c->wforce.as<int>(); }
-    hipLaunchKernelGGL(k_flow_pre, dim3((nth + 255) / 256), dim3(256), 0, c->stream, nchain, nx, minv, dt, rem, fresh, ok, bounds, x, p,
-                       fn.gsave, fn.kick, wforce);
-    TRY(joint_eval(c, nchain, x, U, g, d, fl, 1));
+    const FlowPre fpre{minv, dt, rem, fresh, ok, bounds, x, p, fn.gsave, fn.kick, wforce};
+    (void)nth;
+    TRY(joint_eval(c, nchain, x, U, g, d, fl, 1, &fpre));      // (drift with mirror reflection inside k_prep_joint)
     if (next && c->has_swd && c->warm_opt && c->warm_primed && c->warm_nchain == nchain && c->xw.p) {
         // the start roots of every running trajectory, restored with the start model when it is rejected (k_flow_post)
         const int nitems = (int)(c->croot.cap / sizeof(double) / (size_t)nchain);

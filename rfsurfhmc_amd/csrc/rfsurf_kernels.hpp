@@ -120,11 +120,35 @@ __device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int 
 // K_PREP: one thread per (chain, layer).  model_rf.py:52-77 / model_surf.py:47-79 empirical
 // relations, RfLayer constants, float32 SWD model.
 // ---------------------------------------------------------------------------------------
-__global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, int has_rf, double ray_p,
+// The drift of a leapfrog step (pyhmc/hmc.py:164-183: x += dt M^-1 p with mirror reflection at the bounds, preceded by
+// the half kick a deferred start left open), one component.  Called by k_flow_pre and -- fused, for the flow entries --
+// by k_prep_joint, whose thread (chain, layer) owns the components vs_j and thk_j.  p == nullptr: off.
+struct FlowPre {
+    const double* minv; const double* dt; const int* rem; const int* fresh; const int* ok; const double* bounds;
+    double* x; double* p; const double* gsave; const int* kick; int* wforce;
+};
+__device__ __forceinline__ void flow_drift(const FlowPre& F, int chain, int i, int nx) {
+    // option swd_exact_final: start and end models of a trajectory by the reference-semantics search (k_swd_warm's force)
+    if (F.wforce && i == 0) F.wforce[chain] = F.fresh[chain] || F.rem[chain] == 1;
+    if (F.fresh[chain] || F.rem[chain] <= 0 || !F.ok[chain]) return;
+    const size_t g = (size_t)chain * nx + i;
+    double pv = F.p[g];
+    if (F.kick && F.kick[chain]) pv = pv - F.dt[chain] * F.gsave[g] * 0.5;      // the half kick a deferred start left open (hmc.py:164)
+    // (same expression as in k_flow_post's start branch: the two forms give the same p bit for bit)
+    double xv = F.x[g] + F.dt[chain] * (pv * (F.minv ? F.minv[i] : 1.0));
+    double lo = F.bounds[2 * i], hi = F.bounds[2 * i + 1];
+    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
+        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
+        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
+    }
+    F.x[g] = xv; F.p[g] = pv;
+}
+
+__global__ void k_prep_joint(int nchain, int n, const double* x /* may be fpre.x */, int has_rf, double ray_p,
                              RfLayer* __restrict__ lc, double* __restrict__ cr, int has_swd,
                              float* __restrict__ mdl, double* __restrict__ mdlc,
                              double* __restrict__ zero_d, size_t nzero_d, int* __restrict__ zero_i, size_t nzero_i,
-                             double* __restrict__ xw, double* __restrict__ dxT, double* __restrict__ crT)
+                             double* __restrict__ xw, double* __restrict__ dxT, double* __restrict__ crT, FlowPre fpre)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     // per-step clearing for the early eigenfunction launch (roots: zero = not final; done map), folded in here
@@ -133,6 +157,7 @@ __global__ void k_prep_joint(int nchain, int n, const double* __restrict__ x, in
     for (size_t i = g; i < nzero_i; i += (size_t)gridDim.x * blockDim.x) zero_i[i] = 0;
     if (g >= nchain * n) return;
     int chain = g / n, j = g - chain * n;
+    if (fpre.p) { flow_drift(fpre, chain, j, 2 * n); flow_drift(fpre, chain, n + j, 2 * n); }      // (x below is fpre.x)
     double vs = x[(size_t)chain * 2 * n + j], thk = x[(size_t)chain * 2 * n + n + j];
     double vp = 0.9409 + 2.0947 * vs - 0.8206 * (vs * vs) + 0.2683 * (vs * vs * vs) - 0.0251 * (vs * vs * vs * vs);
     double vp2 = vp * vp;
@@ -1706,25 +1731,11 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
 // evaluation per chain.  rem[chain] = leapfrog steps still to do (-1: idle), fresh[chain] = 1: the trajectory starts
 // with this call (x = start model, p = drawn momentum).  Same arithmetic as k_leap_begin / drift / kick.
 // ---------------------------------------------------------------------------------------
-__global__ void k_flow_pre(int nchain, int nx, const double* minv, const double* dt, const int* rem, const int* fresh, const int* ok,
-                           const double* bounds, double* x, double* p, const double* gsave, const int* kick, int* wforce)
+__global__ void k_flow_pre(int nchain, int nx, FlowPre F)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nchain * nx) return;
-    int chain = g / nx, i = g - chain * nx;
-    // option swd_exact_final: start and end models of a trajectory by the reference-semantics search (k_swd_warm's force)
-    if (wforce && i == 0) wforce[chain] = fresh[chain] || rem[chain] == 1;
-    if (fresh[chain] || rem[chain] <= 0 || !ok[chain]) return;
-    double pv = p[g];
-    if (kick && kick[chain]) pv = pv - dt[chain] * gsave[g] * 0.5;      // the half kick a deferred start left open (hmc.py:164)
-    // (same expression as in k_flow_post's start branch: the two forms give the same p bit for bit)
-    double xv = x[g] + dt[chain] * (pv * (minv ? minv[i] : 1.0));
-    double lo = bounds[2 * i], hi = bounds[2 * i + 1];
-    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
-        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
-        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
-    }
-    x[g] = xv; p[g] = pv;
+    flow_drift(F, g / nx, g % nx, nx);
 }
 
 // Device-side restart of a completed trajectory (rfs_flow_next, include/rfsurf.h): all pointers device, have == nullptr = off
