@@ -937,7 +937,8 @@ int upload(rfs_ctx* c, Buf& b, const void* host, size_t bytes) {
 // (rfs_leapfrog_dev): always the reference-semantics search, whose roots and kernels then seed the steps; 0 = a
 // plugin evaluation
 int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* grad, double* dsyn, int32_t* flag,
-               int traj = 0, const FlowPre* fpre = nullptr) {
+               int traj = 0, const FlowPre* fpre = nullptr, RfReduce* defer = nullptr) {
+    if (defer) defer->PG = nullptr;
     const int n = c->n;
     HIPCHK(c, hipSetDevice(c->device));
     // track: keep the model / roots / kernels of this evaluation for the next one; warm: use those of the previous one
@@ -1195,11 +1196,12 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                     if (!rc) {
                         // (early_combine: one tile; the surface-wave part is in place once the join has passed)
                         if (early_combine) { if (hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess) rc = RFS_ERR_HIP; }
-                        hipLaunchKernelGGL(k_rf_reduce, dim3(nc), dim3(n <= 64 ? 64 : 128), 0, c->stream, nc, n,
-                                           (int)!c->has_swd, rf_nparts_b(c->f), c->PG.as<double>(), c->mrf.as<double>() + c0,
-                                           c->cr.as<double>() + (size_t)c0 * 2 * n, misfit + c0, grad + (size_t)c0 * 2 * n,
-                                           flag + c0, (int)early_combine, c->d_dobs.as<double>(),
-                                           dsyn ? dsyn + (size_t)c0 * c->ndata : (double*)nullptr, c->ndata, c->wt);
+                        const RfReduce rr{c->PG.as<double>(), c->mrf.as<double>() + c0, c->cr.as<double>() + (size_t)c0 * 2 * n,
+                                          c->d_dobs.as<double>(), n, rf_nparts_b(c->f), (int)!c->has_swd, (int)early_combine, c->wt};
+                        if (defer && !tiled && (early_combine || !c->has_swd)) *defer = rr;      // the caller's next kernel reduces (k_flow_post)
+                        else hipLaunchKernelGGL(k_rf_reduce, dim3(nc), dim3(n <= 64 ? 64 : 128), 0, c->stream, nc, rr, misfit + c0,
+                                                grad + (size_t)c0 * 2 * n, flag + c0,
+                                                dsyn ? dsyn + (size_t)c0 * c->ndata : (double*)nullptr, c->ndata);
                     } }
             }
             rf_reduced = true;
@@ -1213,9 +1215,10 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     if (part) TRY(launch_swd(c, user, nchain, n, P, true, false, a_eigen ? 4 : (early_items > 0 ? 2 : 0)));   // (rest of the) eigenfunction pass, whole chip
     if (c->has_rf && !rf_reduced) {
         KTimer t(c, RFS_K_COMBINE, c->stream);
-        hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, n,
-                           (int)!c->has_swd, rf_time ? 1 : rf_nparts(c->f), c->PG.as<double>(), c->mrf.as<double>(),
-                           c->cr.as<double>(), misfit, grad, flag, 0, (const double*)nullptr, (double*)nullptr, 0, 1.0);
+        const RfReduce rr{c->PG.as<double>(), c->mrf.as<double>(), c->cr.as<double>(), nullptr, n, rf_time ? 1 : rf_nparts(c->f),
+                          (int)!c->has_swd, 0, 1.0};
+        hipLaunchKernelGGL(k_rf_reduce, dim3(nchain), dim3(n <= 64 ? 64 : 128), 0, c->stream, nchain, rr, misfit, grad, flag,
+                           (double*)nullptr, 0);
         HIPCHK(c, hipGetLastError());
     }
     if (c->has_swd && !early_combine) TRY(launch_combine(c->stream, 0));
@@ -1838,7 +1841,8 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     if (c->exact_final && c->has_swd && c->warm_opt) { ENSURE(c, c->wforce, (size_t)nchain * sizeof(int)); wforce = c->wforce.as<int>(); }
     const FlowPre fpre{minv, dt, rem, fresh, ok, bounds, x, p, fn.gsave, fn.kick, wforce};
     (void)nth;
-    TRY(joint_eval(c, nchain, x, U, g, d, fl, 1, &fpre));      // (drift with mirror reflection inside k_prep_joint)
+    RfReduce rr{};
+    TRY(joint_eval(c, nchain, x, U, g, d, fl, 1, &fpre, &rr));      // (drift with mirror reflection inside k_prep_joint; RF reduction left to k_flow_post)
     if (next && c->has_swd && c->warm_opt && c->warm_primed && c->warm_nchain == nchain && c->xw.p) {
         // the start roots of every running trajectory, restored with the start model when it is rejected (k_flow_post)
         const int nitems = (int)(c->croot.cap / sizeof(double) / (size_t)nchain);
@@ -1853,7 +1857,7 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
         HIPCHK(c, hipMemsetAsync(c->fstat.p, 0, 64 * sizeof(unsigned long long), c->stream));
     }
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
-                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>());
+                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>(), rr);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }

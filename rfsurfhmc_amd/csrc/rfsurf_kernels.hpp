@@ -1453,34 +1453,43 @@ __global__ void k_swd_export(int nchain, int n, SwdRows R, const double* __restr
 //                 interface -> thickness suffix sums, weighting, misfit, failure returns
 // mode: 0 joint (model_rf_swd_vs_thk.py:66-86), 1 RF only (model_rf.py:137-198), 2 SWD only (model_surf.py:155-228)
 // merge != 0 (joint evaluation whose surface-wave part is already in place: k_swd_combine ran first, beside the RF
-// sweeps, and wrote its weighted gradient, misfit and flag): the RF part is ADDED, and a chain whose root search failed gets
-// the joint failure return (0, zeros, dobs, False: model_rf_swd_vs_thk.py:73-74) -- dsyn here, behind the RF synthetics.
-__global__ void __launch_bounds__(MAXL)
-k_rf_reduce(int nchain, int n, int rf_only, int npart, const double* __restrict__ PG,
-            const double* __restrict__ misfit_rf, const double* __restrict__ cr,
-            double* __restrict__ misfit, double* __restrict__ grad, int* __restrict__ flag,
-            int merge, const double* __restrict__ dobs, double* __restrict__ dsyn, int ndata, double wt)
+// sweeps, and wrote its unweighted gradient sums, misfit and flag): the RF part is ADDED, and a chain whose root search failed
+// gets the joint failure return (0, zeros, dobs, False: model_rf_swd_vs_thk.py:73-74) -- dsyn here, behind the RF synthetics.
+// One chain, all threads of the block (k_rf_reduce; the flow entries run it at the head of k_flow_post instead).
+struct RfReduce {
+    const double* PG; const double* misfit_rf; const double* cr; const double* dobs;
+    int n, npart, rf_only, merge; double wt;
+};
+__device__ __forceinline__ void rf_reduce_chain(const RfReduce& R, int chain, double* __restrict__ misfit,
+                                                double* __restrict__ grad, int* __restrict__ flag,
+                                                double* __restrict__ dsyn, int ndata)
 {
-    int chain = blockIdx.x, j = threadIdx.x;
-    if (merge && !flag[chain]) {
-        if (dsyn) for (int i = j; i < ndata; i += blockDim.x) dsyn[(size_t)chain * ndata + i] = dobs[i];
+    const int n = R.n;
+    if (R.merge && !flag[chain]) {
+        if (dsyn) for (int i = threadIdx.x; i < ndata; i += blockDim.x) dsyn[(size_t)chain * ndata + i] = R.dobs[i];
         return;
     }
-    if (j < n) {
-        double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double dadb = R.cr[((size_t)chain * 2) * n + j], drdadb = R.cr[((size_t)chain * 2 + 1) * n + j];
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        const double* pg = PG + (size_t)chain * npart * 4 * n;
-        for (int p = 0; p < npart; p++) {
+        const double* pg = R.PG + (size_t)chain * R.npart * 4 * n;
+        for (int p = 0; p < R.npart; p++) {
             s0 += pg[((size_t)p * 4 + 0) * n + j]; s1 += pg[((size_t)p * 4 + 1) * n + j];
             s2 += pg[((size_t)p * 4 + 2) * n + j]; s3 += pg[((size_t)p * 4 + 3) * n + j];
         }
         const double gv = s2 + dadb * s1 + drdadb * s0;                         // model_rf.py:189
         const size_t o = (size_t)chain * 2 * n + j;
-        grad[o] = merge ? ::fma(wt, grad[o], gv) : gv;                            // (k_swd_combine left its unweighted sums)
-        grad[o + n] = merge ? ::fma(wt, grad[o + n], s3) : s3;
+        grad[o] = R.merge ? ::fma(R.wt, grad[o], gv) : gv;                      // (k_swd_combine left its unweighted sums)
+        grad[o + n] = R.merge ? ::fma(R.wt, grad[o + n], s3) : s3;
     }
-    if (rf_only && j == 0) { misfit[chain] = misfit_rf[chain]; flag[chain] = 1; }
-    if (merge && j == 0) misfit[chain] = ::fma(wt, misfit[chain], misfit_rf[chain]);
+    if (R.rf_only && threadIdx.x == 0) { misfit[chain] = R.misfit_rf[chain]; flag[chain] = 1; }
+    if (R.merge && threadIdx.x == 0) misfit[chain] = ::fma(R.wt, misfit[chain], R.misfit_rf[chain]);
+}
+__global__ void __launch_bounds__(MAXL)
+k_rf_reduce(int nchain, RfReduce R, double* __restrict__ misfit, double* __restrict__ grad, int* __restrict__ flag,
+            double* __restrict__ dsyn, int ndata)
+{
+    rf_reduce_chain(R, blockIdx.x, misfit, grad, flag, dsyn, ndata);
 }
 
 template <bool SPH>
@@ -1748,10 +1757,11 @@ struct FlowNext {
     // continues from "the same model" instead of from the end model a whole trajectory away
     double* croot; double* crs; double* xw; int nitems;
 };
-__global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, const double* U,
-                            const double* grad, const double* dsyn, const int* flag, double* p, int* rem, int* fresh,
+// rr.PG != nullptr: the RF reduction of this chain's evaluation is still open (joint_eval left it to this kernel)
+__global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, double* U,
+                            double* grad, double* dsyn, int* flag, double* p, int* rem, int* fresh,
                             double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
-                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount)
+                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount, RfReduce rr)
 {
     __shared__ double red[4];
     __shared__ int bad;
@@ -1761,6 +1771,7 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
     if (tid == 0) done[chain] = 0;
     if (!fr && (rm <= 0 || !ok[chain])) return;                // idle chain (block-uniform)
     if (tid == 0 && fcount) atomicAdd(&fcount[chain & 63], 1ull);   // statistic "flow_chain_steps" (64 slots: 8192 atomics on ONE address cost 70 us)
+    if (rr.PG) rf_reduce_chain(rr, chain, U, grad, flag, dsyn, ndata);
     if (tid == 0) bad = 0;
     __syncthreads();
     int mybad = 0;
