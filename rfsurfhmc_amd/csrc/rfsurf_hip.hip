@@ -1192,8 +1192,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                 if (!rc) { KTimer t(c, RFS_K_RF_MID, c->stream);
                     rc = launch_mid(c, nc, n, c->f, c->d_dobs.as<double>(), c->ndata,
                                     dsyn ? dsyn + (size_t)c0 * c->ndata : nullptr, true, (size_t)c0, (size_t)nchain); }
-                if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0, rf_peel);
-                    if (!rc) {
+                if (!rc) { KTimer t(c, RFS_K_RF_PASS_B, c->stream); rc = launch_passB(c, nc, n, c->f, (size_t)c0, rf_peel); }
+                if (!rc) { {      // (outside the timed group: the join below is not pass B's time)
                         // (early_combine: one tile; the surface-wave part is in place once the join has passed)
                         if (early_combine) { if (hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess) rc = RFS_ERR_HIP; }
                         const RfReduce rr{c->PG.as<double>(), c->mrf.as<double>() + c0, c->cr.as<double>() + (size_t)c0 * 2 * n,

@@ -4,7 +4,7 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DISPATCH"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-pre = [i for i, r in enumerate(rows) if "k_flow_pre" in r["Kernel_Name"]]
+pre = [i for i, r in enumerate(rows) if "k_prep_joint" in r["Kernel_Name"]]
 i0, i1 = pre[-N - 1], pre[-1]
 t0, t1 = int(rows[i0]["Start_Timestamp"]), int(rows[i1]["Start_Timestamp"])
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows[i0:i1])
