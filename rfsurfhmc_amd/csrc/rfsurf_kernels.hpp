@@ -813,6 +813,7 @@ struct SwdWarm {
     int* irr; int* icount; int* ilist;   // chains with an irregular sequence (k_swd_warm_check -> k_swd_warm_walk)
     int* count2; int* list2;             // chains handed back by the branch test (the search of `list` is under way by then)
     int* wide;              // [chain] a first-order change above WARM_L1MAX somewhere: every sequence of the chain walks the grid
+    double* slope;          // [item][chain] d(secular)/dc at the root as the last warm search of the item left it (0 = unknown)
 };
 
 template <class F, bool SPH>
@@ -869,7 +870,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
     WarmSearch ws;
-    ws.begin(cprev, dc, l1);
+    ws.begin(cprev, dc, l1, W.slope[(size_t)e * nchain + chain]);
     if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
     if (l1 > WARM_L1MAX && ws.active()) W.wide[chain] = 1;
     const bool refused = !ws.active();
@@ -881,6 +882,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
         W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
     } else decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
+    W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
     int nev = ws.nev, nok = ok ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }

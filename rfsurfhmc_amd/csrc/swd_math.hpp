@@ -734,6 +734,11 @@ using RootSearchModes = RootSearchT<NevTabReg, true>;
 //               sign, never beyond the trust radius R = R0 c + R1 sum_j |G_j dx_j|
 //     refine    false position with the Illinois rule until two successive estimates agree to WARM_TOL c
 // about 3 secular evaluations instead of the ~23 of the sequential scan + nevill, and lane = (period, chain).
+// From the second continued step on the item also has the SLOPE of the secular function at its previous root: the search
+// then starts with a Newton step from c_pred, overshot by a quarter, so that two evaluations bracket the root within a
+// fraction of the prediction error; where that bracket is narrow and its slope agrees with the one the step was taken
+// with (the function is linear across it), its secant point is the root: 2 evaluations.  Anything else falls back to the
+// bracket above.
 // A second, one-evaluation test keeps the continued root on the branch the reference's scan would pick: the scan of
 // period k starts at c(k-1) - 1.5 dc (the first period at the start value of the model, surfdisp96.f:257-276) and takes
 // the first sign change it meets.  Where the dispersion is normal at every period of the sequence (each root above its
@@ -759,27 +764,40 @@ constexpr double WARM_L1WIDE = 2.0;          // km/s: and beyond this the model 
 constexpr int WARM_MAXIT = 12;
 
 
+constexpr double WARM_OVER = 0.25;           // Newton start: overshoot of the step, so that the second point lands beyond the root
+constexpr double WARM_W2 = 3.0e-5;           // ... and a bracket this narrow (relative to c) whose slope agrees with the slope the step
+constexpr double WARM_LIN = 0.02;            // was taken with to WARM_LIN is settled by its secant point: the secant's error is
+                                             // (slope change across the bracket) x w / 8 <= 0.02 x 3e-5 c / 8 < 1e-7 c; between crowded
+                                             // modes the slopes disagree and the third evaluation is made
+
 struct WarmSearch {
-    enum { W_A, W_B, W_X, W_REF, W_DONE, W_FAIL };
-    double cpred, eps, R, a, fa, b, fb, creq, root;
-    int phase, it, side, second, lastside, nev;
+    enum { W_A, W_B, W_X, W_REF, W_N0, W_N1, W_DONE, W_FAIL };
+    double cpred, eps, R, a, fa, b, fb, creq, root, slope, f0, mlast;
+    int phase, it, side, second, lastside, nev, ntry;
 
     RFS_HD bool active() const { return phase < W_DONE; }
 
-    // cprev: root of the previous model; dc: first-order change; l1: sum of |first-order terms|
-    RFS_HD void begin(double cprev, double dc, double l1) {
+    // cprev: root of the previous model; dc: first-order change; l1: sum of |first-order terms|; slope0: d(secular)/dc at
+    // the previous model's root as its own search left it (0 = unknown).  With a slope the search starts with a Newton
+    // step from the prediction, overshot by WARM_OVER: two evaluations bracket the root within a fraction of the
+    // prediction error, and a bracket that narrow needs no third.
+    RFS_HD void begin(double cprev, double dc, double l1, double slope0 = 0.0) {
         cpred = cprev + dc;
         R = WARM_R0 * cpred + WARM_R1 * l1;
-        nev = 0; it = 0; side = 0; second = 0; lastside = -1; root = 0.0;
+        nev = 0; it = 0; side = 0; second = 0; lastside = -1; root = 0.0; slope = 0.0; f0 = 0.0; ntry = 0; mlast = 0.0;
         fa = fb = 0.0;
         eps = WARM_EPS0 * cpred + WARM_EPS1 * l1;
         a = cpred - eps; b = cpred + eps; creq = a;
         phase = W_A;
         // not a continuation of the previous model (or no previous root at all): leave it to the full search
         if (!(cprev > 0.0) || !(l1 <= WARM_L1WIDE) || !(a > 0.0)) phase = W_FAIL;
+        else if (slope0 != 0.0 && slope0 == slope0 && l1 <= WARM_L1MAX) { slope = slope0; creq = cpred; phase = W_N0; }
     }
 
+    RFS_HD void start_bracket() { a = cpred - eps; b = cpred + eps; creq = a; phase = W_A; }
+
     RFS_HD void refine_from_bracket() {          // (a, fa), (b, fb) hold a sign change
+        slope = (fb - fa) / (b - a);
         const double c3 = a - fa * (b - a) / (fb - fa);
         creq = c3; phase = W_REF; lastside = -1;
     }
@@ -788,6 +806,24 @@ struct WarmSearch {
         nev++;
         if (f != f) { phase = W_FAIL; return; }
         bool widen = false;
+        if (phase == W_N0 || phase == W_N1) {
+            // (a, f0): the point before this one (W_N1); creq: the point just evaluated
+            if (phase == W_N1 && diffsign(f0, f)) {                 // the two points bracket the root
+                const double c0 = a, c1 = creq;
+                if (c0 < c1) { a = c0; fa = f0; b = c1; fb = f; } else { a = c1; fa = f; b = c0; fb = f0; }
+                const double mb = (fb - fa) / (b - a);
+                if (b - a <= WARM_W2 * b && fabs(mb - mlast) <= WARM_LIN * fabs(mb)) { slope = mb; root = a - fa * (b - a) / (fb - fa); phase = W_DONE; }
+                else refine_from_bracket();
+                return;
+            }
+            // the first point, or a second one on the same side: step on with the best slope at hand
+            const double m = (phase == W_N1) ? (f - f0) / (creq - a) : slope;
+            const double step = -(1.0 + WARM_OVER) * f / m;
+            if (ntry >= 2 || !(fabs(step) <= R) || step == 0.0 || !(fabs(creq + step - cpred) <= R)) { start_bracket(); return; }
+            a = creq; f0 = f; ntry++; mlast = m;
+            creq = creq + step; phase = (creq > 0.0) ? (int)W_N1 : (int)W_FAIL;
+            return;
+        }
         if (phase == W_A) { fa = f; creq = b; phase = W_B; }
         else if (phase == W_B) {
             fb = f;
