@@ -121,8 +121,8 @@ __device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int 
 // relations, RfLayer constants, float32 SWD model.
 // ---------------------------------------------------------------------------------------
 // The drift of a leapfrog step (pyhmc/hmc.py:164-183: x += dt M^-1 p with mirror reflection at the bounds, preceded by
-// the half kick a deferred start left open), one component.  Called by k_flow_pre and -- fused, for the flow entries --
-// by k_prep_joint, whose thread (chain, layer) owns the components vs_j and thk_j.  p == nullptr: off.
+// the half kick a deferred start left open), one component.  Runs inside k_prep_joint for the flow entries,
+// whose thread (chain, layer) owns the components vs_j and thk_j.  p == nullptr: off.
 struct FlowPre {
     const double* minv; const double* dt; const int* rem; const int* fresh; const int* ok; const double* bounds;
     double* x; double* p; const double* gsave; const int* kick; int* wforce;
@@ -1742,13 +1742,6 @@ __global__ void k_leap_kick(int nchain, int nx, int ndata, int step, const doubl
 // evaluation per chain.  rem[chain] = leapfrog steps still to do (-1: idle), fresh[chain] = 1: the trajectory starts
 // with this call (x = start model, p = drawn momentum).  Same arithmetic as k_leap_begin / drift / kick.
 // ---------------------------------------------------------------------------------------
-__global__ void k_flow_pre(int nchain, int nx, FlowPre F)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nchain * nx) return;
-    flow_drift(F, g / nx, g % nx, nx);
-}
-
 // Device-side restart of a completed trajectory (rfs_flow_next, include/rfsurf.h): all pointers device, have == nullptr = off
 struct FlowNext {
     int* have; const double* u; const double* p; const int* rem;
@@ -1821,7 +1814,7 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
         }
         return;
     }
-    if (tid == 0 && nx_.kick) nx_.kick[chain] = 0;              // k_flow_pre has applied the deferred half kick (p holds it)
+    if (tid == 0 && nx_.kick) nx_.kick[chain] = 0;              // the drift (k_prep_joint) has applied the deferred half kick (p holds it)
     if (fail) { if (tid == 0) { ok[chain] = 0; rem[chain] = -1; done[chain] = 1; } return; }
     const bool last = (rm == 1);                                // hmc.py:170-190
     double k = 0.0;
