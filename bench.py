@@ -508,6 +508,9 @@ def da_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barr
                           "secular_evals_per_item": (e1 - e0) / max(items, 1),
                           "chains_handed_back_to_the_full_search_per_step": (d1 - d0) / K,
                           "handed_back_by_cause_total": {k: ctx.stat(f"swd_warm_cause_{k}") for k in range(4, 12)},
+                          "chains_walking_the_scan_grid_total": ctx.stat("swd_warm_walked_chains"),
+                          "chains_with_wide_moves_total": ctx.stat("swd_warm_wide_chains"),
+                          "warm_evaluations_total": ctx.stat("swd_warm_items") // (nchain * NPER),
                           "adapted_dt_median": float(np.median(dtv)), "adapted_dt_max": float(dtv.max())}
     return rep, xs, el, evals
 

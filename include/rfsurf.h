@@ -310,6 +310,8 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *   "swd_warm_declined_chains"  chain evaluations the warm start handed back to the reference-semantics search
  *   "swd_warm_items"            (period, chain) items the warm start refined
  *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items
+ *   "swd_warm_walked_chains"    chain evaluations whose sequences walked the reference's scan grid (anomalous dispersion, or
+ *                               a first-order change above 0.5 km/s: "swd_warm_wide_chains" counts the latter)
  *   "swd_warm_cause_<k>"        chains handed back, by (first) cause: 4 no usable previous evaluation / forced, 5 step too
  *                               large for a first-order model, 6 no sign change inside the trust radius, 7 root above the
  *                               fastest layer, 9 / 11 another root lies between the point the reference's scan of that

@@ -1420,6 +1420,8 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
     else if (!strcmp(name, "swd_warm_secular_evals")) idx = 1;
     else if (!strcmp(name, "swd_warm_items")) idx = 2;
+    else if (!strcmp(name, "swd_warm_walked_chains")) idx = 12;
+    else if (!strcmp(name, "swd_warm_wide_chains")) idx = 13;
     else if (!strncmp(name, "swd_warm_cause_", 15)) { idx = atoi(name + 15); if (idx < 4 || idx > 11) idx = -1; }
     if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
     if (!c->wstats.p) return RFS_OK;

@@ -872,7 +872,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     WarmSearch ws;
     ws.begin(cprev, dc, l1, W.slope[(size_t)e * nchain + chain]);
     if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
-    if (l1 > WARM_L1MAX && ws.active()) W.wide[chain] = 1;
+    if (l1 > WARM_L1MAX && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
     const bool refused = !ws.active();
     while (__any(ws.active())) {
         if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
@@ -963,6 +963,7 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
     constexpr int LPI = FIRST ? 64 : 16, IPW = 64 / LPI;
     const int lane = threadIdx.x & 63, sub = lane / LPI, li = lane % LPI;
     const int nsel = *W.icount;
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&W.stats[12], (unsigned long long)nsel);     // chains whose sequences walk the grid
     const int per_chain = FIRST ? Q.nseq : Q.nper_total;
     const long total = (long)nsel * per_chain;
     const double dcs = (double)0.005f;
