@@ -296,6 +296,9 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          inside the layers (|exp(nu h)| ~ 1: nothing is amplified; rows agree with the stored ones to
  *                          1e-14 over 50 layers); 0 = stored rows.  -1 (default) = 1 for |ray_p| <= 0.1 s/km
  *                          (p alpha < 1 up to alpha = 10 km/s), 0 beyond.
+ *   "rf_peel_check"        1: the column sweep also checks the peeling's closure -- with every layer taken off, the row must
+ *                          be the half-space's own -- and keeps the largest relative miss (rfs_get_stat "rf_peel_residual",
+ *                          in units of 1e-18: ~1e4 = 1e-14 where the waves propagate).  0 (default) = off.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.

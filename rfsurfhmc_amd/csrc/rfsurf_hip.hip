@@ -97,7 +97,8 @@ struct rfs_ctx {
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
-    Buf RT;                               // final rows of pass A (row peeling, k_rf_passB<., true>)
+    Buf RT, rstat;                        // final rows of pass A (row peeling, k_rf_passB<., true>); closure residual of the peeling
+    int rf_peel_check = 0;                // option "rf_peel_check": pass B records the closure residual (statistic rf_peel_residual)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
     // leapfrog state
@@ -354,15 +355,17 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0, 
     const int bs = rf_block_of(f, 64);
     dim3 grid(rf_chunks_b(f), nchain);
     const double* rows = peel ? c->RT.as<double>() : c->Rs.as<double>();
+    if (peel && !c->rstat.p) { ENSURE(c, c->rstat, sizeof(unsigned)); HIPCHK(c, hipMemsetAsync(c->rstat.p, 0, sizeof(unsigned), c->stream)); }
+    unsigned* pr = c->rf_peel_check ? c->rstat.as<unsigned>() : nullptr;
     if (peel) hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
-                                 c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+                                 c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
     else hipLaunchKernelGGL((k_rf_passB<false, false>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
-                            c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+                            c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
     if (f.nk >= f.n2) {     // the Nyquist bin, lane = chain (no band limit: it is the first bin to go)
         if (peel) hipLaunchKernelGGL((k_rf_passB<true, true>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                                     c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+                                     c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
         else hipLaunchKernelGGL((k_rf_passB<true, false>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                                c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>());
+                                c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
     }
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
@@ -1270,7 +1273,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope, &c->rstat};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
@@ -1364,6 +1367,12 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
     }
+    if (!strcmp(name, "rf_peel_check")) {
+        if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "rf_peel_check must be 0 or 1");
+        c->rf_peel_check = value;
+        if (c->rstat.p) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->rstat.p, 0, sizeof(unsigned), c->stream)); }
+        return RFS_OK;
+    }
     if (!strcmp(name, "rf_row_peeling")) {
         if (value < -1 || value > 1) return fail(c, RFS_ERR_ARG, "rf_row_peeling must be -1 (automatic), 0 or 1");
         c->rf_peel = value;
@@ -1408,6 +1417,16 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     if (!c || !name || !value) return RFS_ERR_ARG;
     *value = 0;
     int idx = -1;
+    if (!strcmp(name, "rf_peel_residual")) {          // largest closure residual of the row peeling since rf_peel_check was set, in units of 1e-18
+        if (!c->rstat.p) return RFS_OK;
+        HIPCHK(c, hipSetDevice(c->device));
+        TRY(rfs_synchronize(c));
+        unsigned u = 0; float q;
+        HIPCHK(c, hipMemcpy(&u, c->rstat.p, sizeof(u), hipMemcpyDeviceToHost));
+        std::memcpy(&q, &u, sizeof(q));
+        *value = (q > 9.0e0f) ? INT64_MAX : (int64_t)((double)q * 1.0e18);
+        return RFS_OK;
+    }
     if (!strcmp(name, "flow_chain_steps")) {          // (chain, step) pairs the flow entries advanced a trajectory by
         if (!c->fstat.p) return RFS_OK;
         HIPCHK(c, hipSetDevice(c->device));

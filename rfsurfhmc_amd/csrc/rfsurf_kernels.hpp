@@ -404,7 +404,7 @@ template <bool TAIL, bool INV = false>
 __global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
 k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
            const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
-           int npart, double* __restrict__ PG)
+           int npart, double* __restrict__ PG, unsigned* __restrict__ peel_resid)
 {
     int chain, k, part;
     bool live = true;
@@ -456,6 +456,18 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
             }
         } else {
             rf_half_partials(L[j], omega, f.rf_type, y, T);
+            if (INV && peel_resid) {
+                // closure of the peeling: with every layer taken off, the row must be the half-space's own (rf_einv_row).
+                // The largest relative miss of the call is kept (statistic "rf_peel_residual"): ~1e-14 where the waves
+                // propagate; a post-critical slowness would show here
+                const V4 e = rf_einv_row(L[j], f.rf_type);
+                double d = 0.0, m = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { d += norm2(r.v[i] - e.v[i]); m += norm2(e.v[i]); }
+                float q = (float)sqrt(d / m);
+                if (!(q == q)) q = __builtin_inff();
+                if (live) atomicMax(peel_resid, __float_as_uint(q));
+            }
         }
         double v4[4];
 #pragma unroll

@@ -233,3 +233,24 @@ def test_rf_gradient_by_row_peeling_equals_stored_rows(hip, orc, n, thk_each, rf
     c2.set_option("rf_row_peeling", 0)
     b = rf2.misfit_and_grad(xs)
     assert np.array_equal(a[1], b[1])
+
+
+def test_row_peeling_closure_residual(hip, orc):
+    """Option rf_peel_check / statistic rf_peel_residual: after the last layer has been peeled off the row must be the
+    half-space's own.  Teleseismic slowness: ~1e-14.  Peeling FORCED at a slowness beyond the crustal P velocities (evanescent P
+    in the layers: the inverse layer matrices amplify rounding) shows up there -- which is why the automatic choice stores rows."""
+    n, nt = 30, 512
+    vs0 = np.linspace(2.4, 4.6, n); thk0 = np.full(n, 2.0); thk0[-1] = 0
+    xs = np.tile(np.hstack((vs0, thk0)), (4, 1))
+    d0 = orc.ReceiverFunc(0.06, nt, 0.1, 1.5, 5.0, 0.001, "P", "freq").forward(xs[0])
+    res = {}
+    for p, mode in ((0.06, -1), (0.22, 1)):
+        rf = hip.ReceiverFunc(p, nt, 0.1, 1.5, 5.0, 0.001, "P", "freq")
+        rf.set_obsdata(d0)
+        ctx = rf._ensure(n)
+        ctx.set_option("rf_row_peeling", mode)
+        ctx.set_option("rf_peel_check", 1)
+        rf.misfit_and_grad(xs)
+        res[p] = ctx.stat("rf_peel_residual") * 1e-18
+    assert 0 < res[0.06] < 1e-12, res
+    assert res[0.22] > 100 * res[0.06], res
