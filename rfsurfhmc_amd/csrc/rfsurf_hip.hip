@@ -89,7 +89,7 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, fstat, wslope;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, fstat, wslope, wbetmx;
     hipEvent_t ev_w[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     bool swd_water_cur = false;           // the batch being launched holds models with a water layer on top (B1 entries)
@@ -682,7 +682,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
                   c->wsgn.as<unsigned char>(), c->wneed.as<int>() + nchain + 1, c->wneed.as<int>() + 2 * nchain + 1,
                   c->wilist.as<int>(), c->wneed.as<int>() + 2 * nchain + 2, c->wlist2.as<int>(), c->wneed.as<int>() + 2 * nchain + 3,
-                  c->wslope.as<double>()};
+                  c->wslope.as<double>(), c->wbetmx.as<float>()};
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -964,6 +964,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         ENSURE(c, c->wslope, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
+        ENSURE(c, c->wbetmx, (size_t)2 * nchain * sizeof(float));
         // slopes of the secular function belong to roots a warm search found: an evaluation by the full search leaves none
         if (!warm) HIPCHK(c, hipMemsetAsync(c->wslope.p, 0, c->wslope.cap, c->stream));
         if (c->wvalid.cap != before) {
@@ -1273,7 +1274,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope, &c->rstat};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);

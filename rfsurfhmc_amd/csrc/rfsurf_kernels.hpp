@@ -826,6 +826,7 @@ struct SwdWarm {
     int* count2; int* list2;             // chains handed back by the branch test (the search of `list` is under way by then)
     int* wide;              // [chain] a first-order change above WARM_L1MAX somewhere: every sequence of the chain walks the grid
     double* slope;          // [item][chain] d(secular)/dc at the root as the last warm search of the item left it (0 = unknown)
+    float* betmx;           // [2][chain] fastest S velocity of the Rayleigh / Love search model (k_swd_warm -> k_swd_warm_check)
 };
 
 template <class F, bool SPH>
@@ -874,6 +875,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);
     }
     const double cprev = croot[(size_t)e * nchain + chain];
+    if (k == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
     const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
     const double* lc0 = mdlc + chain;
     auto loadL = [&](int m) {
@@ -942,6 +944,14 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
+    // The reference's scan ends at the first GRID point beyond the root (start + m dc), and above the fastest layer the
+    // secular function no longer changes sign there (the half-space term is taken by its absolute value, surfdisp96.f:744,
+    // :815): a root within dc of that velocity -- Love waves at long periods -- is found or missed by the grid.  Such a
+    // sequence walks the grid as well.
+    if (!irregular && sg <= 1 && sk > 0.0 && sk < ck) {
+        const double gup = sk + (floor((ck - sk) / dcs) + 1.0) * dcs;
+        if (gup > (double)W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain]) { W.wide[chain] = 1; irregular = true; }
+    }
     if (irregular) {                                                 // -> k_swd_warm_walk, one 16-lane group per item
         if (atomicExch(&W.irr[chain], 1) == 0) W.ilist[atomicAdd(W.icount, 1)] = chain;
         return;

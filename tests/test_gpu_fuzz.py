@@ -61,7 +61,9 @@ def test_random_joint_configuration(orc, seed):
         assert rel(gh[i], go) < 2e-5, (cfg, rel(gh[i], go))
 
 
-@pytest.mark.parametrize("seed", range(16))
+# (106, 308: found by a 300-seed soak -- Love roots within one scan step of the fastest layer, where the reference's scan
+# finds or misses the root by its grid: such sequences walk the grid since)
+@pytest.mark.parametrize("seed", list(range(16)) + [106, 308])
 def test_random_configuration_warm_started_against_the_full_search(seed):
     """The same random configurations (2..25 layers, any subset of the Rc / Rg / Lc / Lg blocks -- also without Rc --, flat
     or spherical, freq / time RF or none, odd chain counts) moved through a few leapfrog-like steps: the warm-started
