@@ -289,13 +289,14 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *   "swd_warm_serial"      1: a warm-started step runs on ONE stream (every kernel alone on the chip: clean per-kernel
  *                          durations for profiling); 0 (default): the surface-wave kernels on a second stream beside the
  *                          receiver-function sweeps (~5 % faster).  Results are identical.
- *   "rf_row_peeling"       frequency-domain RF adjoint of the joint entries: 1 = the column sweep (pass B) obtains the row
- *                          of layer j from the row of layer j-1 times A_j^-1 (the propagator over -h), starting from the
- *                          row sweep's final row, instead of reading one stored row per (layer, frequency): no row
- *                          scratch (2 GB per 8192 chains at 30 layers), no chain tiles.  Exact where every wave propagates
- *                          inside the layers (|exp(nu h)| ~ 1: nothing is amplified; rows agree with the stored ones to
- *                          1e-14 over 50 layers); 0 = stored rows.  -1 (default) = 1 for |ray_p| <= 0.1 s/km
- *                          (p alpha < 1 up to alpha = 10 km/s), 0 beyond.
+ *   "rf_row_peeling"       frequency-domain RF adjoint of the joint entries: the column sweep (pass B) obtains the row of
+ *                          layer j from the row of layer j-1 times A_j^-1 (the propagator over -h), starting from the row
+ *                          sweep's final row, instead of reading one stored row per (layer, frequency) -- for every chain whose
+ *                          layer matrices stay close to unitary: growth exponent sum_j h_j (sigma |Im p_beta| + w_max |Re p_beta|)
+ *                          <= 5, i.e. a teleseismic slowness and a time window (sigma = 4 / window) not much shorter than the
+ *                          S travel time through the stack; decided per chain on the device, the other chains keep their
+ *                          stored rows.  Rows agree with the stored ones to 1e-14 over 50 layers at the bench's window.
+ *                          -1 (default) / 1 = as described, 0 = stored rows for every chain, 2 = peel every chain (diagnostics).
  *   "rf_peel_check"        1: the column sweep also checks the peeling's closure -- with every layer taken off, the row must
  *                          be the half-space's own -- and keeps the largest relative miss (rfs_get_stat "rf_peel_residual",
  *                          in units of 1e-18: ~1e4 = 1e-14 where the waves propagate).  0 (default) = off.

@@ -79,7 +79,7 @@ struct rfs_ctx {
     int swd_segments = -1; // segments of the vector recurrence in the lanes-per-chain search (-1 = automatic, 1 / 2 / 4)
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
-    int rf_peel = -1;          // option "rf_row_peeling": pass B peels the layers off pass A's final row instead of reading stored rows (-1 = where the waves propagate: ray_p <= 0.1 s/km)
+    int rf_peel = -1;          // option "rf_row_peeling": pass B peels the layers off pass A's final row instead of reading stored rows: -1 / 1 = for the chains whose growth exponent allows it (decided on the device), 0 = never, 2 = always (diagnostics)
     int rf_band_digits = 13;   // option "rf_band_limit_digits": adjoint band limit at 1e-digits * water (0 = off)
     int rf_band_floor = 8;     // option "rf_band_floor_digits": the limit may move down to a multiple of 64 bins, never below this
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
@@ -97,6 +97,8 @@ struct rfs_ctx {
     Buf spec3, ts3, S0f, S0p, pulse_spec, pulse_ts, Pbuf, Cres;   // time-domain RF (rf_time_kernels.hpp)
     double pulse_key[4] = {0, 0, 0, 0};
     Buf mdlc, mdlSR, mdlL, sphR, sphL, mdlcL;   // per-family search models / bldsph arrays (sphere, Love)
+    Buf slist, scount;                    // chains of a peeling evaluation that kept stored rows (k_rf_passA -> k_rf_passB<., false>)
+    int* h_scount = nullptr; int* d_hscount = nullptr; int stored_est = -1; unsigned speel_eval = 0;   // their number in an earlier evaluation (host-mapped word the device writes; -1 = unknown); evaluation parity of the two counters
     Buf RT, rstat;                        // final rows of pass A (row peeling, k_rf_passB<., true>); closure residual of the peeling
     int rf_peel_check = 0;                // option "rf_peel_check": pass B records the closure residual (statistic rf_peel_residual)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
@@ -306,16 +308,25 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     if (nchain > 2 * RF_MAX_CHAINS_PER_LAUNCH - 4096)
         return fail(c, RFS_ERR_UNSUPPORTED, "more than 61440 chains in one receiver-function launch: split the batch");
     ENSURE(c, c->RR, (size_t)nchain * 4 * f.n2p * sizeof(double));
-    if (scratch && !peel) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.nkp * sizeof(double));
+    // (with peeling the row scratch is still there for the chains that cannot peel -- allocated, untouched by the others)
+    if (scratch) ENSURE(c, c->Rs, (size_t)nchain * (n - 1) * 8 * f.nkp * sizeof(double));
     if (scratch && peel) ENSURE(c, c->RT, (size_t)nchain * 8 * f.nkp * sizeof(double));
-    double* Rs = (scratch && !peel) ? c->Rs.as<double>() : nullptr;
+    double* Rs = scratch ? c->Rs.as<double>() : nullptr;
     double* RT = (scratch && peel) ? c->RT.as<double>() : nullptr;
+    int *sl = nullptr, *sc = nullptr;
+    if (RT) {
+        ENSURE(c, c->slist, (size_t)nchain * sizeof(int));
+        if (!c->scount.p) { ENSURE(c, c->scount, 2 * sizeof(int)); HIPCHK(c, hipMemsetAsync(c->scount.p, 0, 2 * sizeof(int), c->stream)); }
+        c->speel_eval++;                          // two counters: this evaluation's, and the next one's, which pass A clears
+        sl = c->slist.as<int>(); sc = c->scount.as<int>() + (c->speel_eval & 1);
+    }
+    int* scn = sc ? c->scount.as<int>() + ((c->speel_eval + 1) & 1) : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 128);
     dim3 grid(rf_chunks_of(f, bs), nchain);
-    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs, RT);
+    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn);
     hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                       c->RR.as<double>(), Rs, RT);
+                       c->RR.as<double>(), Rs, RT, sl, sc, (int*)nullptr);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -354,18 +365,36 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0, 
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 64);
     dim3 grid(rf_chunks_b(f), nchain);
-    const double* rows = peel ? c->RT.as<double>() : c->Rs.as<double>();
+    const double* rows = c->Rs.as<double>();
+    const double* rt = peel ? c->RT.as<double>() : (const double*)nullptr;
     if (peel && !c->rstat.p) { ENSURE(c, c->rstat, sizeof(unsigned)); HIPCHK(c, hipMemsetAsync(c->rstat.p, 0, sizeof(unsigned), c->stream)); }
     unsigned* pr = c->rf_peel_check ? c->rstat.as<unsigned>() : nullptr;
-    if (peel) hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
-                                 c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
-    else hipLaunchKernelGGL((k_rf_passB<false, false>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc,
-                            c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
+    // with peeling: one launch per kind of chain.  The stored-row one strides over the list pass A made of its chains --
+    // normally empty, so its grid follows the length seen in an earlier evaluation (never waited for) and a handful of blocks
+    // find nothing to do; whatever the list holds is processed, only slower while the estimate lags
+    const int* nol = nullptr; int* noe = nullptr;
+    if (peel) {
+        if (!c->h_scount) {
+            HIPCHK(c, hipHostMalloc((void**)&c->h_scount, sizeof(int), hipHostMallocMapped));
+            *c->h_scount = -1;
+            HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_hscount, c->h_scount, 0));
+        }
+        if (*c->h_scount >= 0) c->stored_est = *c->h_scount;
+        hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
+                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
+        const int gy = c->stored_est < 0 ? nchain : std::max(8, std::min(nchain, c->stored_est + c->stored_est / 8));
+        hipLaunchKernelGGL((k_rf_passB<false, false>), dim3(rf_chunks_b(f), gy), dim3(bs), 0, c->stream, nchain, n, f, lc,
+                           c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr,
+                           c->slist.as<int>(), c->scount.as<int>() + (c->speel_eval & 1), c->d_hscount);
+    } else {
+        hipLaunchKernelGGL((k_rf_passB<false, false>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
+                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
+    }
     if (f.nk >= f.n2) {     // the Nyquist bin, lane = chain (no band limit: it is the first bin to go)
         if (peel) hipLaunchKernelGGL((k_rf_passB<true, true>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                                     c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
-        else hipLaunchKernelGGL((k_rf_passB<true, false>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                                c->RR.as<double>(), rows, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr);
+                                     c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
+        hipLaunchKernelGGL((k_rf_passB<true, false>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
+                           c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
     }
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
@@ -1002,11 +1031,12 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     const bool rf_time = c->has_rf && c->f.method != RFS_RF_FREQ;
     // chain tiles of the RF pipeline: the pass-A row scratch of one tile stays within rf_scratch_budget
     int rf_tile = nchain;
-    // rows by peeling (no row scratch, no tiles): in the layers of a teleseismic receiver function every wave propagates
-    // (p < 1 / alpha: |exp(nu h)| ~ 1), so A_j^-1 amplifies nothing; post-critical slownesses keep the stored rows
-    const bool rf_peel = c->has_rf && !rf_time && (c->rf_peel == 1 || (c->rf_peel < 0 && std::fabs(c->f.p) <= 0.1));
-    if (c->has_rf && !rf_time && rf_peel) rf_tile = std::min(nchain, RF_MAX_CHAINS_PER_LAUNCH);
-    else if (c->has_rf && !rf_time) {
+    // rows by peeling: a chain whose layer matrices stay close to unitary (rf_growth_exponent: teleseismic slowness, a time
+    // window not much shorter than the S travel time through the stack) rebuilds its rows in pass B; the kernels decide per
+    // chain, the scratch is sized for everyone and written by the others only
+    const bool rf_peel = c->has_rf && !rf_time && c->rf_peel != 0;
+    c->f.peel_emax = (c->rf_peel == 2) ? 1.0e300 : RF_PEEL_EMAX;
+    if (c->has_rf && !rf_time) {
         const size_t per_chain = (size_t)(n - 1) * 8 * c->f.nkp * sizeof(double);
         size_t fit = per_chain ? c->rf_scratch_budget / per_chain : (size_t)nchain;
         if (fit < (size_t)nchain) rf_tile = (int)std::max<size_t>(64, fit / 64 * 64);
@@ -1274,9 +1304,10 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
+    if (c->h_scount) hipHostFree(c->h_scount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1375,7 +1406,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         return RFS_OK;
     }
     if (!strcmp(name, "rf_row_peeling")) {
-        if (value < -1 || value > 1) return fail(c, RFS_ERR_ARG, "rf_row_peeling must be -1 (automatic), 0 or 1");
+        if (value < -1 || value > 2) return fail(c, RFS_ERR_ARG, "rf_row_peeling must be -1 / 1 (per chain, where safe), 0 (never) or 2 (always)");
         c->rf_peel = value;
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;

@@ -34,6 +34,7 @@ struct RfFreq {             // frequency axis + RF scalars shared by the RF kern
     // maximum over ALL frequencies, RFModule.f90:396-398) but keeps no rows for them, pass B does not run them.
     // nk = n2, nkp = n2p: no limit (B1 kernel_all, time-domain method).  nkp = row-scratch stride (nk padded to 16).
     int nk, nkp;
+    double peel_emax;       // growth exponent up to which a chain's rows are rebuilt by peeling (rf_growth_exponent; 0 = never)
 };
 
 __device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
@@ -104,6 +105,17 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
     return v;
+}
+
+// rf_growth_exponent with the layers spread over the lanes of the wavefront (every lane gets the sum): ~20 instructions
+// instead of a loop over the layers in every lane
+__device__ __forceinline__ double rf_growth_exponent_wave(const RfLayer* __restrict__ L, int n, double sigma, double wmax) {
+    double e = 0.0;
+    for (int j = threadIdx.x & 63; j < n - 1; j += 64)
+        e += L[j].h * (sigma * fabs(L[j].pvb.im) + wmax * (fabs(L[j].pva.re) + fabs(L[j].pvb.re)));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off, 64);
+    return e;
 }
 
 // f64 per-layer constants of the split secular function, from the float32-rounded model:
@@ -263,7 +275,8 @@ __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ m
 template <bool TAIL>
 __global__ void __launch_bounds__(256)
 k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
-           double* __restrict__ Rs, double* __restrict__ RT)
+           double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
+           int* __restrict__ scount_next)
 {
     int chain, k;
     if (TAIL) {
@@ -277,7 +290,14 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
     cplx omega = C(rf_wk(f, k), -f.sigma);
     V4 r = rf_einv_row(L[n - 1], f.rf_type);
     const size_t n2p = f.n2p, nkp = f.nkp;
-    double* rs = (Rs && k < f.nk) ? Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k : nullptr;
+    // RT given = row peeling allowed: rows are then stored only for a chain whose layer matrices grow too much to be
+    // peeled off again (rf_growth_exponent; the same test picks the path in pass B)
+    const bool store = Rs && (!RT || (TAIL ? rf_growth_exponent(L, n, f.sigma, rf_wk(f, f.nk))
+                                           : rf_growth_exponent_wave(L, n, f.sigma, rf_wk(f, f.nk))) > f.peel_emax);
+    double* rs = (store && k < f.nk) ? Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k : nullptr;
+    // (the chains that keep stored rows, for pass B's launch over them: normally none)
+    if (!TAIL && RT && store && slist && blockIdx.x == 0 && threadIdx.x == 0) slist[atomicAdd(scount, 1)] = chain;
+    if (!TAIL && scount_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scount_next = 0;   // the NEXT evaluation's counter
     for (int j = n - 2; j >= 0; j--) {
         if (rs) {
             double* o = rs + (size_t)j * 8 * nkp;
@@ -289,7 +309,7 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
         rf_build_A(L[j], H, A);
         r = rf_row_times_A(r, A);
     }
-    if (RT && k < f.nk) {            // pass B peels the layers off this FINAL row itself (rf_row_times_Ainv): no row scratch
+    if (RT && !store && k < f.nk) {  // pass B peels the layers off this FINAL row itself (rf_row_times_Ainv): no row scratch
         double* o = RT + (size_t)chain * 8 * nkp + k;
 #pragma unroll
         for (int i = 0; i < 4; i++) { o[(2 * i) * nkp] = r.v[i].re; o[(2 * i + 1) * nkp] = r.v[i].im; }
@@ -398,21 +418,27 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
     return y;
 }
 
-// INV: no stored rows -- the row of layer j is the row of layer j-1 times A_j^-1, starting from pass A's final row (Rs then
-// points at that: [chain][8][nkp])
+// INV: the row of layer j is the row of layer j-1 times A_j^-1, starting from pass A's final row (RT: [chain][8][nkp]) --
+// for the chains whose growth exponent allows it; the others read their stored rows (Rs).  With RT given both
+// instantiations are launched and each takes its own chains (a block = one chain: the other kind leaves at once).
 template <bool TAIL, bool INV = false>
 __global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
 k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
-           const double* __restrict__ Rs, const cplx* __restrict__ W, const double* __restrict__ wmax2,
-           int npart, double* __restrict__ PG, unsigned* __restrict__ peel_resid)
+           const double* __restrict__ Rs, const double* __restrict__ RT, const cplx* __restrict__ W,
+           const double* __restrict__ wmax2, int npart, double* __restrict__ PG, unsigned* __restrict__ peel_resid,
+           const int* __restrict__ slist, const int* __restrict__ scount, int* __restrict__ est_out)
 {
+  // slist (stored-row launch beside a peeling one): the blocks' y index strides over the chains pass A listed
+  const int nsel = (!TAIL && slist) ? *scount : 1;
+  if (!TAIL && est_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *est_out = nsel;   // (host-mapped: sizes the next launch)
+  for (int sel = (!TAIL && slist) ? (int)blockIdx.y : 0; sel < nsel; sel += (!TAIL && slist) ? (int)gridDim.y : 1) {
     int chain, k, part;
     bool live = true;
     if (TAIL) {
         chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1; part = npart - 1;
         if (chain >= nchain) return;
     } else {
-        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
+        chain = slist ? slist[sel] : (int)blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
         part = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         const int kmax = f.nk < f.n2 - 1 ? f.nk : f.n2 - 1;       // (the Nyquist bin has its own launch, TAIL)
         if (k >= kmax) { live = false; k = kmax - 1; }
@@ -424,7 +450,9 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
     cplx omega = C(rf_wk(f, k), -f.sigma), kk = f.p * omega;
     V4 y = rf_adjoint_seed(f, k, r21, r22, W[(size_t)chain * f.n2 + k], wmax2[chain]);
     if (!live) { y.v[0] = C(0.0); y.v[1] = C(0.0); }
-    const double* rs = Rs + (INV ? (size_t)chain * 8 * nkp : ((size_t)chain * (n - 1)) * 8 * nkp) + k;
+    if (INV != (RT && (TAIL ? rf_growth_exponent(L, n, f.sigma, rf_wk(f, f.nk))
+                            : rf_growth_exponent_wave(L, n, f.sigma, rf_wk(f, f.nk))) <= f.peel_emax)) continue;   // the other launch's chain
+    const double* rs = (INV ? RT + (size_t)chain * 8 * nkp : Rs + ((size_t)chain * (n - 1)) * 8 * nkp) + k;
     double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const int lane = threadIdx.x & 63;
     double* pg = PG + ((size_t)chain * npart + part) * 4 * n;
@@ -495,6 +523,7 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
             }
         }
     }
+  }
 }
 // B1 kernel_all: materialise the partial spectra S_{p,j,k} (RFModule.f90:416-419) with one column sweep
 // (the two unit-seed columns for R21_m and R22_m combined up front).  specp: [chain][4][n][n2] complex.

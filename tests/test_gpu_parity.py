@@ -220,31 +220,33 @@ def test_rf_gradient_by_row_peeling_equals_stored_rows(hip, orc, n, thk_each, rf
     for mode in (0, 1, -1):
         ctx.set_option("rf_row_peeling", mode)
         out[mode] = rf.misfit_and_grad(xs)
-    assert np.array_equal(out[1][1], out[-1][1])                       # automatic = peeling at ray_p = 0.06
+    assert np.array_equal(out[1][1], out[-1][1])                       # (1 and -1: the same per-chain choice, peeling here)
     assert rel(out[1][1], out[0][1]) < 1e-11 and np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][2], out[0][2])
     for i in (0, 3, 5):
         mo, go, do = o_rf.misfit_and_grad(xs[i])
         assert rel(out[1][1][i], go) < 1e-8 and rel(out[0][1][i], go) < 1e-8 and abs(out[1][0][i] - mo) <= 1e-9 * mo
-    # beyond p = 0.1 s/km the automatic choice keeps the stored rows (bit-identical to mode 0)
-    rf2 = hip.ReceiverFunc(0.12, nt, 0.1, 1.5, 5.0, 0.001, rf_type, "freq")
-    rf2.set_obsdata(d0)
-    c2 = rf2._ensure(n)
-    a = rf2.misfit_and_grad(xs)
-    c2.set_option("rf_row_peeling", 0)
-    b = rf2.misfit_and_grad(xs)
-    assert np.array_equal(a[1], b[1])
+    # a window much shorter than the S travel time through the stack (sigma = 4 / window: the layer matrices grow), or a
+    # post-critical slowness: the device keeps the stored rows for such chains (bit-identical to mode 0)
+    for p2, nt2, dt2 in ((0.06, 64, 0.05), (0.22, nt, 0.1)):
+        rf2 = hip.ReceiverFunc(p2, nt2, dt2, 1.5, 2.0, 0.001, rf_type, "freq")
+        rf2.set_obsdata(np.zeros(nt2))
+        c2 = rf2._ensure(n)
+        a = rf2.misfit_and_grad(xs)
+        c2.set_option("rf_row_peeling", 0)
+        b = rf2.misfit_and_grad(xs)
+        assert np.array_equal(a[1], b[1]) and np.all(np.isfinite(a[1])), (p2, nt2)
 
 
 def test_row_peeling_closure_residual(hip, orc):
     """Option rf_peel_check / statistic rf_peel_residual: after the last layer has been peeled off the row must be the
-    half-space's own.  Teleseismic slowness: ~1e-14.  Peeling FORCED at a slowness beyond the crustal P velocities (evanescent P
+    half-space's own.  Teleseismic slowness: ~1e-14.  Peeling FORCED (mode 2) at a slowness beyond the crustal P velocities (evanescent P
     in the layers: the inverse layer matrices amplify rounding) shows up there -- which is why the automatic choice stores rows."""
     n, nt = 30, 512
     vs0 = np.linspace(2.4, 4.6, n); thk0 = np.full(n, 2.0); thk0[-1] = 0
     xs = np.tile(np.hstack((vs0, thk0)), (4, 1))
     d0 = orc.ReceiverFunc(0.06, nt, 0.1, 1.5, 5.0, 0.001, "P", "freq").forward(xs[0])
     res = {}
-    for p, mode in ((0.06, -1), (0.22, 1)):
+    for p, mode in ((0.06, -1), (0.22, 2)):
         rf = hip.ReceiverFunc(p, nt, 0.1, 1.5, 5.0, 0.001, "P", "freq")
         rf.set_obsdata(d0)
         ctx = rf._ensure(n)
