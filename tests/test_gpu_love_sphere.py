@@ -167,3 +167,31 @@ def test_joint_with_love_and_sphere_against_oracle(hip, orc):
             assert rel(dh[i], do) < 2e-6
             assert abs(mh[i] - mo) <= 1e-5 * mo
             assert rel(gh[i], go) < 1e-5, (i, sph, rel(gh[i], go))
+
+
+def test_many_data_rows_take_the_uncached_combine(hip, orc):
+    """4 blocks x 40 periods = 160 surface-wave rows at 30 layers: more than the combine's LDS row cache holds (rowc = 0 in
+    rfs_joint_misfit_grad's launch), so the per-layer loops read every row's residual and kernel scales from memory -- the
+    same misfit and gradient as the oracle's plugin, and as the same data in two halves (80 rows each: cached)."""
+    n = 30
+    rng = np.random.default_rng(77)
+    vs0 = np.linspace(2.8, 4.6, n); thk0 = np.full(n, 2.0); thk0[-1] = 0
+    x0 = np.hstack((vs0, thk0))
+    t = np.linspace(5, 44, 40)
+    xs = np.tile(x0, (3, 1)); xs[:, :n] *= 0.98 + 0.04 * rng.random((3, n)); xs[:, :n] = np.sort(xs[:, :n], axis=1)
+    kw = dict(tRc=t, tRg=t, tLc=t, tLg=t)
+    m = hip.SurfWD(**kw); o = orc.SurfWD(**kw)
+    d0, fl = o.forward(x0)
+    assert fl
+    m.set_obsdata(d0); o.set_obsdata(d0)
+    mf, g, d, f = m.misfit_and_grad(xs)
+    assert f.all()
+    for i in range(3):
+        mo, go, do, fo = o.misfit_and_grad(xs[i])
+        assert fo and rel(d[i], do) < 2e-5 and abs(mf[i] - mo) <= 2e-4 * mo and rel(g[i], go) < 2e-4, (i, rel(g[i], go))
+    # the two halves (Rayleigh blocks, Love blocks) evaluated separately add up to the whole
+    ma = hip.SurfWD(tRc=t, tRg=t); mb = hip.SurfWD(tLc=t, tLg=t, reference_periods=False)
+    ma.set_obsdata(d0[:80]); mb.set_obsdata(d0[80:])
+    m1, g1, _, f1 = ma.misfit_and_grad(xs); m2, g2, _, f2 = mb.misfit_and_grad(xs)
+    assert f1.all() and f2.all()
+    assert np.all(np.abs(m1 + m2 - mf) <= 1e-12 * mf) and rel(g1 + g2, g) < 1e-12
