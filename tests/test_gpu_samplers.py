@@ -364,3 +364,41 @@ def test_flow_with_device_restarts_at_scale_equals_the_synchronous_host_path(kin
     assert np.array_equal(a.naccepted, b.naccepted) and np.array_equal(a.ntrajectories, b.ntrajectories)
     if kind == "da":
         assert np.array_equal(a.dt_final, b.dt_final)
+
+
+@pytest.mark.parametrize("kind", ["rf_freq", "rf_time", "swd", "joint_time", "joint_warm"])
+def test_flow_schedule_on_every_plugin_kind(kind, golden):
+    """The flow entry fuses the drift into the preparation kernel and (frequency-domain RF) the RF reduction into the kick
+    kernel; the same samples as the batch schedule must come out for every kind of plugin behind it: RF only (both methods),
+    surface waves only, joint with the time-domain RF -- bit for bit with the history-free search -- and, with the warm
+    start on, the same accept counts and samples to 1e-4."""
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+    g = golden["sampler_hybrid"]
+    t = g["t"]
+
+    def model():
+        if kind in ("rf_freq", "rf_time"):
+            m = ReceiverFunc(0.045, 125, 0.4, 1.5, 5.0, 0.001, "P", "freq" if kind == "rf_freq" else "time")
+            m.set_obsdata(g["dobs"][:125])
+        elif kind == "swd":
+            m = SurfWD(tRc=t, tRg=t); m.set_warm_start(0)
+            m.set_obsdata(g["dobs"][125:])
+        else:
+            m = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(0.045, 125, 0.4, 1.5, 5.0, 0.001, "P", "time" if kind == "joint_time" else "freq"),
+                             SurfWD(tRc=t, tRg=t))
+            m.set_warm_start(1 if kind == "joint_warm" else 0)
+            m.set_obsdata(g["dobs"][:125], g["dobs"][125:])
+        return m
+    mk = lambda: HamitonianMC(model(), g["bounds"], 0.05, [3, 9], 2, 991206, 5, 2, myrank=0, name="t", outdir=None,
+                              nchains=6, verbose=False)
+    a = mk(); ma = a.sample()
+    b = mk(); mb = b.sample_flow()
+    if kind == "joint_warm":
+        assert np.array_equal(a.accept_ratio, b.accept_ratio)
+        assert np.all(np.abs(ma - mb) <= 1e-4 * np.abs(ma)) and rel(b.x_cache, a.x_cache) < 1e-4
+    else:
+        assert np.array_equal(ma, mb) and np.array_equal(a.x_cache, b.x_cache) and np.array_equal(a.accept_ratio, b.accept_ratio)
+    assert np.all(np.isfinite(mb)) and b.flow_steps > 0
