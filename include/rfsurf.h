@@ -300,6 +300,15 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *   "rf_peel_check"        1: the column sweep also checks the peeling's closure -- with every layer taken off, the row must
  *                          be the half-space's own -- and keeps the largest relative miss (rfs_get_stat "rf_peel_residual",
  *                          in units of 1e-18: ~1e4 = 1e-14 where the waves propagate).  0 (default) = off.
+ *   "rf_f32_beyond_band"   frequency-domain RF with a band limit (rf_band_limit_digits): the frequencies beyond the band reach
+ *                          the results only through the water level (a maximum of |R21|^2 over ALL frequencies,
+ *                          RFModule.f90:396-398) and through spectrum values weighted by exp(-(w/2f0)^2) < 1e-11.  1 (default):
+ *                          the row sweep takes them in float32 for every chain whose layer matrices stay tame up to the
+ *                          Nyquist frequency (n e^{2E} <= 1e4, E the growth exponent above), then decides per chain from the
+ *                          EXACT band values whether more is needed: not if the band holds both maxima, or if no band
+ *                          frequency can reach a water level set by 1.01 x the float32 maxima; otherwise that chain's
+ *                          frequencies are swept again in f64 (rfs_get_stat "rf_f32_resweeps").  Trace, misfit and gradient
+ *                          equal the all-f64 sweep to 1e-13.  0 = f64 for every frequency.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.
@@ -311,6 +320,8 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
 /* Counters (cumulative since the context's warm-start buffers were made; the call synchronises):
  *   "flow_chain_steps"          (chain, step) pairs by which rfs_flow_step / rfs_flow_step2 advanced a trajectory (idle chains
  *                               -- waiting for the host, or failed -- do not count): the evaluations a sampler used
+ *   "rf_f32_chains"             chain evaluations whose frequencies beyond the band were swept in float32; "rf_f32_resweeps":
+ *                               those of them swept again in f64 (see "rf_f32_beyond_band")
  *   "swd_warm_declined_chains"  chain evaluations the warm start handed back to the reference-semantics search
  *   "swd_warm_items"            (period, chain) items the warm start refined
  *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items

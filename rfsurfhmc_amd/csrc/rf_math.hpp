@@ -21,6 +21,54 @@ namespace rfs {
 // rf_type: 1 = P (row 2: R21 = M(2,1), R22 = i M(2,2)), 2 = S (row 1: R21 = M(1,2), R22 = -i M(1,1))
 // RFModule.f90:653-658.
 
+// ---- float32 complex numbers of the sweep beyond the band (rf_row_step_f32 below) ----
+#if defined(__clang__) && !defined(RFS_NO_PK)
+// (re, im) as one two-lane vector: sums, differences and the two halves of a complex product map onto the packed f32
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, half selection and negation folded into their modifiers)
+typedef float rfs_f32x2 __attribute__((ext_vector_type(2)));
+struct cplxf { rfs_f32x2 v; };
+RFS_HD cplxf cf(float re, float im) { cplxf o; o.v = rfs_f32x2{re, im}; return o; }
+RFS_HD float cf_re(cplxf a) { return a.v.x; }
+RFS_HD float cf_im(cplxf a) { return a.v.y; }
+RFS_HD cplxf operator+(cplxf a, cplxf b) { cplxf o; o.v = a.v + b.v; return o; }
+RFS_HD cplxf operator-(cplxf a, cplxf b) { cplxf o; o.v = a.v - b.v; return o; }
+RFS_HD cplxf operator-(cplxf a) { cplxf o; o.v = -a.v; return o; }
+RFS_HD cplxf operator*(cplxf a, cplxf b) {
+    cplxf o;
+    const rfs_f32x2 bs = __builtin_shufflevector(b.v, -b.v, 3, 0);          // (-b.im, b.re)
+    o.v = a.v.xx * b.v + a.v.yy * bs;
+    return o;
+}
+RFS_HD cplxf operator*(float s, cplxf a) { cplxf o; o.v = a.v * s; return o; }
+RFS_HD cplxf cmadd(cplxf acc, cplxf a, cplxf b) {      // acc + a b: two packed FMAs
+    cplxf o;
+    const rfs_f32x2 bs = __builtin_shufflevector(b.v, -b.v, 3, 0);
+    o.v = a.v.yy * bs + (a.v.xx * b.v + acc.v);
+    return o;
+}
+RFS_HD cplxf cmsub(cplxf acc, cplxf a, cplxf b) {      // acc - a b
+    cplxf o;
+    const rfs_f32x2 bs = __builtin_shufflevector(b.v, -b.v, 3, 0);
+    o.v = (acc.v - a.v.xx * b.v) - a.v.yy * bs;
+    return o;
+}
+RFS_HD cplxf cf_pmul(float a0, float a1, float b0, float b1) { cplxf o; o.v = rfs_f32x2{a0, a1} * rfs_f32x2{b0, b1}; return o; }   // (a0 b0, a1 b1)
+#else
+struct cplxf { float re, im; };
+RFS_HD cplxf cf(float re, float im) { return cplxf{re, im}; }
+RFS_HD float cf_re(cplxf a) { return a.re; }
+RFS_HD float cf_im(cplxf a) { return a.im; }
+RFS_HD cplxf operator+(cplxf a, cplxf b) { return cplxf{a.re + b.re, a.im + b.im}; }
+RFS_HD cplxf operator-(cplxf a, cplxf b) { return cplxf{a.re - b.re, a.im - b.im}; }
+RFS_HD cplxf operator-(cplxf a) { return cplxf{-a.re, -a.im}; }
+RFS_HD cplxf operator*(cplxf a, cplxf b) { return cplxf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+RFS_HD cplxf operator*(float s, cplxf a) { return cplxf{s * a.re, s * a.im}; }
+RFS_HD cplxf cmadd(cplxf acc, cplxf a, cplxf b) { return acc + a * b; }
+RFS_HD cplxf cmsub(cplxf acc, cplxf a, cplxf b) { return acc - a * b; }
+RFS_HD cplxf cf_pmul(float a0, float a1, float b0, float b1) { return cplxf{a0 * b0, a1 * b1}; }
+#endif
+RFS_HD cplxf to_f32(cplx a) { return cf((float)a.re, (float)a.im); }
+
 struct RfLayer {          // frequency-independent constants of one finite layer / the half-space
     cplx pva, pvb;        // sqrt(p^2 - 1/alpha^2), sqrt(p^2 - 1/beta^2)  (= p*va_k, p*vb_k)
     cplx va, vb, iva, ivb;// va_k, vb_k and reciprocals
@@ -30,6 +78,8 @@ struct RfLayer {          // frequency-independent constants of one finite layer
     cplx ia, ib;          // 1/alpha, 1/beta
     cplx sca, scb;        // alpha/vp, beta/vs  (RFModule.f90:624-628)
     double h, rho;
+    // float32 copies for rf_row_step_f32: va, vb, 1/va, 1/vb, gam1, gam1^2, 1/(2 mu), 2 mu, 2 mu gam1, gam
+    cplxf fva, fvb, fiva, fivb, fg1, fg1sq, fim2, fm2, fm2g1, fgam;
 };
 constexpr int RF_LAYER_DOUBLES = sizeof(RfLayer) / sizeof(double);
 
@@ -55,6 +105,9 @@ RFS_HD void rf_make_layer(RfLayer& L, double h, double rho, double vp, double vs
     L.ia = ia; L.ib = ib;
     L.sca = alpha / vp; L.scb = beta / vs;
     L.h = h; L.rho = rho;
+    L.fva = to_f32(L.va); L.fvb = to_f32(L.vb); L.fiva = to_f32(L.iva); L.fivb = to_f32(L.ivb);
+    L.fg1 = to_f32(L.gam1); L.fg1sq = to_f32(L.gam1 * L.gam1); L.fim2 = to_f32(L.imu2); L.fm2 = to_f32(L.mu2);
+    L.fm2g1 = to_f32(L.mu2 * L.gam1); L.fgam = to_f32(L.gam);
 }
 
 struct RfHyp {            // per (layer, frequency): cosh and the four scaled sinh terms
@@ -145,6 +198,73 @@ RFS_HD V4 rf_A_times_col(const RfA& A, const V4& y) {   // y' = A . y
     o.v[1] = A.g * (A.a21 * y.v[0] + A.a22 * y.v[1] + A.a23 * y.v[2] + A.a24 * y.v[3]);
     o.v[2] = A.g * (A.a31 * y.v[0] + A.a32 * y.v[1] + A.a22 * y.v[2] - A.a12 * y.v[3]);
     o.v[3] = A.g * (A.a41 * y.v[0] - A.a31 * y.v[1] - A.a21 * y.v[2] + A.a11 * y.v[3]);
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// float32 form of one pass-A step r' = r . A_j, for the frequencies BEYOND the Gaussian band.  Those frequencies reach
+// the results only through the water level (a maximum of |R21|^2 over all frequencies, RFModule.f90:396-398) and through
+// spectrum values weighted by exp(-(w/2f0)^2) < 1e-11: what is needed from them is an upper bound of their maximum
+// (k_rf_mid1 decides from it, exactly, whether their exact values can matter at all, and recomputes them in f64 where
+// they can).  Phases are reduced in f64 (a layer holds up to ~100 rad of them), everything else runs on the f32 VALU
+// with the hardware exp2 / sin / cos.  Relative error of |R21|^2 for n layers of growth exponent E: ~ n eps32 e^{2E}
+// (measured 4e-6 at 30 layers, E = 1.5), see RF_F32_BOUND.
+// ---------------------------------------------------------------------------------------------------------------
+struct V4f { cplxf v[4]; };
+
+RFS_HD float f32_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x * 1.44269504f);
+#else
+    return expf(x);
+#endif
+}
+RFS_HD void f32_sincos_rev(float x, float* s, float* c) {     // sin / cos of 2 pi x, x in [0, 1)
+#if defined(__HIP_DEVICE_COMPILE__)
+    *s = __builtin_amdgcn_sinf(x); *c = __builtin_amdgcn_cosf(x);
+#else
+    *s = sinf(6.28318531f * x); *c = cosf(6.28318531f * x);
+#endif
+}
+RFS_HD float f32_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// the f32 sweep is used for a chain only while  RF_F32_BOUND n e^{2E} <= RF_F32_MARGIN  (E: rf_growth_exponent at the
+// Nyquist frequency); k_rf_mid1 then takes (1 + RF_F32_MARGIN) x the f32 maximum as the bound of the true one
+constexpr double RF_F32_MARGIN = 1.0e-2, RF_F32_BOUND = 16.0 * 6.0e-8;
+RFS_HD double rf_f32_emax(int n) { return 0.5 * log(RF_F32_MARGIN / (RF_F32_BOUND * (n > 1 ? n : 1))); }
+
+RFS_HD V4f rf_row_step_f32(const RfLayer& L, cplx omega, const V4f& r) {
+    const cplx ta = omega * L.pva, tb = omega * L.pvb;
+    const float sa = (ta.re > 0.0 || (ta.re == 0.0 && ta.im >= 0.0)) ? 1.0f : -1.0f;
+    const float sb = (tb.re > 0.0 || (tb.re == 0.0 && tb.im >= 0.0)) ? 1.0f : -1.0f;
+    double pa = (L.h * ta.im) * 0.15915494309189535, pb = (L.h * tb.im) * 0.15915494309189535;
+    pa -= floor(pa); pb -= floor(pb);
+    float s1, c1, s2, c2;
+    f32_sincos_rev((float)pa, &s1, &c1); f32_sincos_rev((float)pb, &s2, &c2);
+    const float e1 = f32_exp((float)(L.h * ta.re)), e2 = f32_exp((float)(L.h * tb.re));
+    const float i1 = f32_rcp(e1), i2 = f32_rcp(e2);
+    const float ch1 = 0.5f * (e1 + i1), sh1 = 0.5f * (e1 - i1), ch2 = 0.5f * (e2 + i2), sh2 = 0.5f * (e2 - i2);
+    const cplxf ca = cf_pmul(ch1, sh1, c1, s1), cb = cf_pmul(ch2, sh2, c2, s2);
+    const cplxf sha = sa * cf_pmul(sh1, ch1, c1, s1), shb = sb * cf_pmul(sh2, ch2, c2, s2);
+    const cplxf xa = L.fva * sha, ya = sha * L.fiva, xb = L.fvb * shb, yb = shb * L.fivb;
+    const cplxf g1 = L.fg1, g1sq = L.fg1sq, im2 = L.fim2, m2 = L.fm2;
+    const cplxf dc = ca - cb, dci = dc * im2;
+    const cplxf a11 = cmsub(ca, g1, cb), a22 = cmsub(cb, g1, ca);
+    const cplxf a12 = cmadd(-xb, g1, ya), a21 = cmadd(-xa, g1, yb);
+    const cplxf a14 = (xb - ya) * im2, a23 = (xa - yb) * im2;
+    const cplxf a31 = L.fm2g1 * dc, a32 = m2 * cmadd(-xb, g1sq, ya), a41 = m2 * cmadd(-xa, g1sq, yb);
+    // a13 = -dci, a24 = dci; a33 = a22, a34 = -a12, a42 = -a31, a43 = -a21, a44 = a11
+    V4f o;
+    o.v[0] = L.fgam * cmadd(cmadd(cmadd(r.v[0] * a11, r.v[1], a21), r.v[2], a31), r.v[3], a41);
+    o.v[1] = L.fgam * cmsub(cmadd(cmadd(r.v[0] * a12, r.v[1], a22), r.v[2], a32), r.v[3], a31);
+    o.v[2] = L.fgam * cmsub(cmadd(cmsub(r.v[1] * a23, r.v[0], dci), r.v[2], a22), r.v[3], a21);
+    o.v[3] = L.fgam * cmadd(cmsub(cmadd(r.v[0] * a14, r.v[1], dci), r.v[2], a12), r.v[3], a11);
     return o;
 }
 

@@ -19,6 +19,9 @@
 
 using namespace rfs;
 
+#ifndef RFS_F32_DEFAULT
+#define RFS_F32_DEFAULT 1      // (A/B builds: -DRFS_F32_DEFAULT=0)
+#endif
 namespace {
 
 struct Buf {
@@ -100,6 +103,8 @@ struct rfs_ctx {
     Buf slist, scount;                    // chains of a peeling evaluation that kept stored rows (k_rf_passA -> k_rf_passB<., false>)
     int* h_scount = nullptr; int* d_hscount = nullptr; int stored_est = -1; unsigned speel_eval = 0;   // their number in an earlier evaluation (host-mapped word the device writes; -1 = unknown); evaluation parity of the two counters
     Buf RT, rstat;                        // final rows of pass A (row peeling, k_rf_passB<., true>); closure residual of the peeling
+    int rf_f32 = RFS_F32_DEFAULT;                       // option "rf_f32_beyond_band": pass A sweeps the frequencies beyond the gradient's band in float32 where that is provably enough
+    Buf hi32, stat32;                     // [chain] pass A's choice; [66] chains swept again in f64 by k_rf_mid1, chains swept in float32 (64 slots)
     int rf_peel_check = 0;                // option "rf_peel_check": pass B records the closure residual (statistic rf_peel_residual)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
@@ -304,6 +309,9 @@ constexpr int RF_MAX_CHAINS_PER_LAUNCH = 32768;      // the RF sweeps use one gr
 // pass A (+ scratch) for the nchain chains that start at chain c0 of the batch (RR, Rs are tile-local: offset 0); lc must
 // be ready
 // peel: pass B will peel the layers off the final row (k_rf_passB<., true>): only that row is kept, no row scratch
+// float32 beyond the band: only where there is a band limit (the fused gradient of the frequency-domain method)
+bool rf_f32_on(const rfs_ctx* c, const RfFreq& f) { return c->rf_f32 && f.method == RFS_RF_FREQ && f.nk < f.n2 - 64 && f.water > 0.0; }
+
 int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, size_t c0 = 0, bool peel = false) {
     if (nchain > 2 * RF_MAX_CHAINS_PER_LAUNCH - 4096)
         return fail(c, RFS_ERR_UNSUPPORTED, "more than 61440 chains in one receiver-function launch: split the batch");
@@ -323,10 +331,13 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     int* scn = sc ? c->scount.as<int>() + ((c->speel_eval + 1) & 1) : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 128);
-    dim3 grid(rf_chunks_of(f, bs), nchain);
-    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn);
-    hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                       c->RR.as<double>(), Rs, RT, sl, sc, (int*)nullptr);
+    dim3 grid(nchain, rf_chunks_of(f, bs));          // chain = fast index (XCD balance, see k_rf_passA)
+    RfFreq fa = f;
+    int* hi = nullptr;
+    if (rf_f32_on(c, f)) { fa.e32max = rf_f32_emax(n); ENSURE(c, c->hi32, (size_t)nchain * sizeof(int)); hi = c->hi32.as<int>(); }
+    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, fa, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn, hi);
+    hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, fa, lc,
+                       c->RR.as<double>(), Rs, RT, sl, sc, (int*)nullptr, (int*)nullptr);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -341,8 +352,13 @@ int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dob
     ENSURE(c, c->wmax2, (size_t)nchain * sizeof(double));
     ENSURE(c, c->spec, nb * f.n2 * sizeof(cplx));
     ENSURE(c, c->tser, nb * f.nft * sizeof(double));
-    hipLaunchKernelGGL(k_rf_mid1, dim3(nchain), dim3(256), 0, c->stream, n, f, c->RR.as<double>(),
-                       c->wmax2.as<double>(), c->spec.as<cplx>());
+    const int* hi = nullptr; unsigned long long* st = nullptr;
+    if (rf_f32_on(c, f)) {
+        if (!c->stat32.p) { ENSURE(c, c->stat32, 66 * sizeof(unsigned long long)); HIPCHK(c, hipMemsetAsync(c->stat32.p, 0, 66 * sizeof(unsigned long long), c->stream)); }
+        hi = c->hi32.as<int>(); st = c->stat32.as<unsigned long long>();
+    }
+    hipLaunchKernelGGL(k_rf_mid1, dim3(nchain), dim3(256), 0, c->stream, n, f, c->lc.as<RfLayer>() + c0 * n, c->RR.as<double>(),
+                       c->wmax2.as<double>(), c->spec.as<cplx>(), hi, st);
     HIPCHK(c, hipGetLastError());
     TRY(run_fft(c, f.nft, nb, 1, c->spec.p, c->tser.p));
     double* wres = nullptr; double* mrf = nullptr;
@@ -1399,6 +1415,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
     }
+    if (!strcmp(name, "rf_f32_beyond_band")) {
+        if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "rf_f32_beyond_band must be 0 or 1");
+        c->rf_f32 = value; return RFS_OK;
+    }
     if (!strcmp(name, "rf_peel_check")) {
         if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "rf_peel_check must be 0 or 1");
         c->rf_peel_check = value;
@@ -1457,6 +1477,16 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
         HIPCHK(c, hipMemcpy(&u, c->rstat.p, sizeof(u), hipMemcpyDeviceToHost));
         std::memcpy(&q, &u, sizeof(q));
         *value = (q > 9.0e0f) ? INT64_MAX : (int64_t)((double)q * 1.0e18);
+        return RFS_OK;
+    }
+    if (!strcmp(name, "rf_f32_chains") || !strcmp(name, "rf_f32_resweeps")) {    // (chain, evaluation) pairs swept in float32 beyond the band / swept again in f64
+        if (!c->stat32.p) return RFS_OK;
+        HIPCHK(c, hipSetDevice(c->device));
+        TRY(rfs_synchronize(c));
+        unsigned long long v[66];
+        HIPCHK(c, hipMemcpy(v, c->stat32.p, sizeof(v), hipMemcpyDeviceToHost));
+        if (!strcmp(name, "rf_f32_resweeps")) *value = (int64_t)v[0];
+        else for (int i = 2; i < 66; i++) *value += (int64_t)v[i];
         return RFS_OK;
     }
     if (!strcmp(name, "flow_chain_steps")) {          // (chain, step) pairs the flow entries advanced a trajectory by

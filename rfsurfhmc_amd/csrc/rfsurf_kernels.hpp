@@ -35,6 +35,8 @@ struct RfFreq {             // frequency axis + RF scalars shared by the RF kern
     // nk = n2, nkp = n2p: no limit (B1 kernel_all, time-domain method).  nkp = row-scratch stride (nk padded to 16).
     int nk, nkp;
     double peel_emax;       // growth exponent up to which a chain's rows are rebuilt by peeling (rf_growth_exponent; 0 = never)
+    double e32max;          // growth exponent (at the Nyquist frequency) up to which pass A sweeps a chain's frequencies beyond
+                            // the band in float32 (rf_row_step_f32, rf_f32_emax; 0 = never)
 };
 
 __device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
@@ -272,37 +274,82 @@ __global__ void k_prep_swd_family(int nchain, int n, const float* __restrict__ m
 // constants are wave-uniform -> scalar loads) or lane = chain at the last frequency
 // (TAIL=true: n2 = nft/2 + 1 is odd, the Nyquist bin is swept "chain-wide" instead).
 // ---------------------------------------------------------------------------------------
+// one frequency's sweep up the stack in f64: R21, R22 (NaN scrubbed, RFModule.f90:662-667)
+__device__ __forceinline__ void rf_r21_r22(const RfFreq& f, const V4& r, cplx& r21, cplx& r22) {
+    const int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
+    r21 = r.v[c21];
+    r22 = (f.rf_type == 1) ? mul_i(r.v[c22]) : -mul_i(r.v[c22]);
+    if (r21.re != r21.re || r21.im != r21.im) r21 = C(0.0);
+    if (r22.re != r22.re || r22.im != r22.im) r22 = C(0.0);
+}
+__device__ __forceinline__ void rf_sweep_plain(const RfLayer* __restrict__ L, int n, const RfFreq& f, int k, cplx& r21, cplx& r22) {
+    const cplx omega = C(rf_wk(f, k), -f.sigma);
+    V4 r = rf_einv_row(L[n - 1], f.rf_type);
+    for (int j = n - 2; j >= 0; j--) {
+        RfHyp H; RfA A;
+        rf_hyp(L[j], omega, H);
+        rf_build_A(L[j], H, A);
+        r = rf_row_times_A(r, A);
+    }
+    rf_r21_r22(f, r, r21, r22);
+}
+
 template <bool TAIL>
 __global__ void __launch_bounds__(256)
 k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
            double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
-           int* __restrict__ scount_next)
+           int* __restrict__ scount_next, int* __restrict__ hi32)
 {
     int chain, k;
+    bool live = true;
     if (TAIL) {
         chain = blockIdx.x * blockDim.x + threadIdx.x; k = f.n2 - 1;
         if (chain >= nchain) return;
     } else {
-        chain = blockIdx.y; k = blockIdx.x * blockDim.x + threadIdx.x;
-        if (k >= f.n2 - 1) return;
+        // grid = (chain, chunk of frequencies): workgroups go round-robin over the 8 XCDs by their linear index, so the chain
+        // must be the fast index -- with the chunk there, each XCD would get ONE kind of chunk (all f64 band chunks on one XCD)
+        chain = blockIdx.x; k = blockIdx.y * blockDim.x + threadIdx.x;
+        if (k >= f.n2 - 1) { live = false; k = f.n2 - 2; }      // (kept until the wave-wide sums below are done)
     }
     const RfLayer* L = lc + (size_t)chain * n;
     cplx omega = C(rf_wk(f, k), -f.sigma);
-    V4 r = rf_einv_row(L[n - 1], f.rf_type);
     const size_t n2p = f.n2p, nkp = f.nkp;
     // RT given = row peeling allowed: rows are then stored only for a chain whose layer matrices grow too much to be
     // peeled off again (rf_growth_exponent; the same test picks the path in pass B)
     const bool store = Rs && (!RT || (TAIL ? rf_growth_exponent(L, n, f.sigma, rf_wk(f, f.nk))
                                            : rf_growth_exponent_wave(L, n, f.sigma, rf_wk(f, f.nk))) > f.peel_emax);
-    double* rs = (store && k < f.nk) ? Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k : nullptr;
+    // beyond the band: float32 for the chains whose matrices stay tame up to the Nyquist frequency (k_rf_mid1 takes it from there)
+    bool c32 = false;
+    if (!TAIL && f.e32max > 0.0 && f.nk < f.n2) {
+        c32 = rf_growth_exponent_wave(L, n, f.sigma, rf_wk(f, f.n2 - 1)) <= f.e32max;
+        if (hi32 && blockIdx.y == 0 && threadIdx.x == 0) hi32[chain] = c32 ? 1 : 0;
+    }
     // (the chains that keep stored rows, for pass B's launch over them: normally none)
-    if (!TAIL && RT && store && slist && blockIdx.x == 0 && threadIdx.x == 0) slist[atomicAdd(scount, 1)] = chain;
+    if (!TAIL && RT && store && slist && blockIdx.y == 0 && threadIdx.x == 0) slist[atomicAdd(scount, 1)] = chain;
     if (!TAIL && scount_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scount_next = 0;   // the NEXT evaluation's counter
+    if (!live) return;
+    double* o = RR + (size_t)chain * 4 * n2p + k;
+    if (!TAIL && c32 && k - (int)(threadIdx.x & 63) >= f.nk) {          // a whole wavefront beyond the band
+        const V4 r0 = rf_einv_row(L[n - 1], f.rf_type);
+        V4f r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.v[i] = to_f32(r0.v[i]);
+        for (int j = n - 2; j >= 0; j--) r = rf_row_step_f32(L[j], omega, r);
+        V4 rd;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rd.v[i] = C((double)cf_re(r.v[i]), (double)cf_im(r.v[i]));
+        cplx r21, r22;
+        rf_r21_r22(f, rd, r21, r22);
+        o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
+        return;
+    }
+    V4 r = rf_einv_row(L[n - 1], f.rf_type);
+    double* rs = (store && k < f.nk) ? Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k : nullptr;
     for (int j = n - 2; j >= 0; j--) {
         if (rs) {
-            double* o = rs + (size_t)j * 8 * nkp;
+            double* q = rs + (size_t)j * 8 * nkp;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { o[(2 * i) * nkp] = r.v[i].re; o[(2 * i + 1) * nkp] = r.v[i].im; }
+            for (int i = 0; i < 4; i++) { q[(2 * i) * nkp] = r.v[i].re; q[(2 * i + 1) * nkp] = r.v[i].im; }
         }
         RfHyp H; RfA A;
         rf_hyp(L[j], omega, H);
@@ -310,16 +357,12 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
         r = rf_row_times_A(r, A);
     }
     if (RT && !store && k < f.nk) {  // pass B peels the layers off this FINAL row itself (rf_row_times_Ainv): no row scratch
-        double* o = RT + (size_t)chain * 8 * nkp + k;
+        double* q = RT + (size_t)chain * 8 * nkp + k;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { o[(2 * i) * nkp] = r.v[i].re; o[(2 * i + 1) * nkp] = r.v[i].im; }
+        for (int i = 0; i < 4; i++) { q[(2 * i) * nkp] = r.v[i].re; q[(2 * i + 1) * nkp] = r.v[i].im; }
     }
-    int c21 = (f.rf_type == 1) ? 0 : 1, c22 = 1 - c21;
-    cplx r21 = r.v[c21];
-    cplx r22 = (f.rf_type == 1) ? mul_i(r.v[c22]) : -mul_i(r.v[c22]);
-    if (r21.re != r21.re || r21.im != r21.im) r21 = C(0.0);      // NaN scrub, RFModule.f90:662-667
-    if (r22.re != r22.re || r22.im != r22.im) r22 = C(0.0);
-    double* o = RR + (size_t)chain * 4 * n2p + k;
+    cplx r21, r22;
+    rf_r21_r22(f, r, r21, r22);
     o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
 }
 // ---------------------------------------------------------------------------------------
@@ -328,25 +371,57 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
 // imaginary parts of DC / Nyquist zeroed (FFTW's c2r ignores them, rocFFT must not see them).
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_rf_mid1(int n, RfFreq f, const double* __restrict__ RR, double* __restrict__ wmax2, cplx* __restrict__ spec)
+k_rf_mid1(int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR, double* __restrict__ wmax2,
+          cplx* __restrict__ spec, const int* __restrict__ hi32, unsigned long long* __restrict__ stat32)
 {
-    __shared__ double red[8];
+    __shared__ double red[6][4];
     int chain = blockIdx.x, tid = threadIdx.x;
-    const double* rr = RR + (size_t)chain * 4 * f.n2p;
+    double* rr = RR + (size_t)chain * 4 * f.n2p;
+    const int wv = tid >> 6, nw = blockDim.x >> 6;
+    // Pass A swept this chain's frequencies beyond the band in float32 (h32): the maxima are taken apart -- band values are
+    // exact, the others carry a relative error below RF_F32_MARGIN.  Where the band holds both maxima, or no band
+    // frequency can reach a water level set by (1 + margin) x the others' maxima, every number that reaches the results
+    // with a weight above exp(-(w_nk/2f0)^2) is what the all-f64 sweep gives; otherwise the block sweeps those
+    // frequencies again in f64 (statistic rf_f32_resweeps) and nothing of the float32 pass is left.
+    bool h32 = hi32 && hi32[chain] != 0;
     double m1 = 0.0, m2 = 0.0;
-    for (int k = tid; k < f.n2; k += blockDim.x) {
-        cplx r21 = C(rr[k], rr[f.n2p + k]);
-        double wa = (r21 * conj(r21)).re;
-        cplx sq = r21 * r21;
-        double wb = (sq * conj(sq)).re;
-        m1 = fmax(m1, wa); m2 = fmax(m2, wb);
+    for (int pass = 0; pass < 2; pass++) {
+        double b1 = 0.0, b2 = 0.0, h1 = 0.0, h2 = 0.0, lo1 = 1.0e300, lo2 = 1.0e300;
+        for (int k = tid; k < f.n2; k += blockDim.x) {
+            cplx r21 = C(rr[k], rr[f.n2p + k]);
+            double wa = (r21 * conj(r21)).re;
+            cplx sq = r21 * r21;
+            double wb = (sq * conj(sq)).re;
+            if (h32 && k >= f.nk) { h1 = fmax(h1, wa); h2 = fmax(h2, wb); }
+            else { b1 = fmax(b1, wa); b2 = fmax(b2, wb); lo1 = fmin(lo1, wa); lo2 = fmin(lo2, wb); }
+        }
+        b1 = wave_max(b1); b2 = wave_max(b2); h1 = wave_max(h1); h2 = wave_max(h2); lo1 = -wave_max(-lo1); lo2 = -wave_max(-lo2);
+        __syncthreads();
+        if ((tid & 63) == 0) { red[0][wv] = b1; red[1][wv] = b2; red[2][wv] = h1; red[3][wv] = h2; red[4][wv] = lo1; red[5][wv] = lo2; }
+        __syncthreads();
+        for (int i = 0; i < nw; i++) {
+            b1 = fmax(b1, red[0][i]); b2 = fmax(b2, red[1][i]); h1 = fmax(h1, red[2][i]); h2 = fmax(h2, red[3][i]);
+            lo1 = fmin(lo1, red[4][i]); lo2 = fmin(lo2, red[5][i]);
+        }
+        m1 = fmax(b1, h1); m2 = fmax(b2, h2);
+        if (!h32) break;
+        const double u1 = h1 * (1.0 + RF_F32_MARGIN), u2 = h2 * ((1.0 + RF_F32_MARGIN) * (1.0 + RF_F32_MARGIN));
+        const bool band_holds_both = u1 <= b1 && u2 <= b2;
+        const bool band_out_of_reach = lo1 >= f.water * fmax(b1, u1) && lo2 >= f.water * fmax(b2, u2);
+        if (band_holds_both) { m1 = b1; m2 = b2; }
+        if (tid == 0 && stat32 && pass == 0) atomicAdd(&stat32[2 + (chain & 63)], 1ull);      // (64 slots: one address would serialise)
+        if (band_holds_both || band_out_of_reach) break;
+        // the rare chain: its frequencies beyond the band again, in f64 (the Nyquist bin always is)
+        if (tid == 0 && stat32) atomicAdd(&stat32[0], 1ull);
+        const RfLayer* L = lc + (size_t)chain * n;
+        for (int k = f.nk + tid; k < f.n2 - 1; k += blockDim.x) {
+            cplx r21, r22;
+            rf_sweep_plain(L, n, f, k, r21, r22);
+            rr[k] = r21.re; rr[f.n2p + k] = r21.im; rr[2 * f.n2p + k] = r22.re; rr[3 * f.n2p + k] = r22.im;
+        }
+        __syncthreads();
+        h32 = false;
     }
-    m1 = wave_max(m1); m2 = wave_max(m2);
-    int wv = tid >> 6, nw = blockDim.x >> 6;
-    if ((tid & 63) == 0) { red[wv] = m1; red[4 + wv] = m2; }
-    __syncthreads();
-    m1 = red[0]; m2 = red[4];
-    for (int i = 1; i < nw; i++) { m1 = fmax(m1, red[i]); m2 = fmax(m2, red[4 + i]); }
     if (tid == 0) wmax2[chain] = m2;
     for (int k = tid; k < f.n2; k += blockDim.x) {
         cplx r21 = C(rr[k], rr[f.n2p + k]), r22 = C(rr[2 * f.n2p + k], rr[3 * f.n2p + k]);

@@ -95,4 +95,30 @@ void hs_rf_peeling_errors(int n, const double* thk, const double* rho, const dou
     for (int j = 0; j < n - 1; j++) if (fabs(ta[j] - tb[j]) / tmax > etr) etr = fabs(ta[j] - tb[j]) / tmax;
     out[0] = erow; out[1] = etr;
 }
+
+// The float32 step of pass A's sweep beyond the band (rf_row_step_f32) against the f64 sweep, one frequency:
+// out[0] = relative error of |R21|^2, out[1] = the growth exponent the kernels would compute (rf_growth_exponent),
+// out[2] = the largest exponent the float32 sweep is allowed at this layer count (rf_f32_emax).
+void hs_rf_f32_error(int n, const double* thk, const double* rho, const double* vp, const double* vs,
+                     const double* qa, const double* qb, double p, double w_re, double w_im, int rf_type, double* out)
+{
+    std::vector<RfLayer> L(n);
+    for (int j = 0; j < n; j++) rf_make_layer(L[j], thk[j], rho[j], vp[j], vs[j], qa[j], qb[j], p);
+    cplx omega = C(w_re, w_im);
+    V4 r = rf_einv_row(L[n - 1], rf_type);
+    V4f q;
+    for (int i = 0; i < 4; i++) q.v[i] = to_f32(r.v[i]);
+    for (int j = n - 2; j >= 0; j--) {
+        RfHyp H; RfA A;
+        rf_hyp(L[j], omega, H); rf_build_A(L[j], H, A);
+        r = rf_row_times_A(r, A);
+        q = rf_row_step_f32(L[j], omega, q);
+    }
+    const int c21 = (rf_type == 1) ? 0 : 1;
+    const double a = norm2(r.v[c21]);
+    const double b = (double)cf_re(q.v[c21]) * (double)cf_re(q.v[c21]) + (double)cf_im(q.v[c21]) * (double)cf_im(q.v[c21]);
+    out[0] = fabs(b / a - 1.0);
+    out[1] = rf_growth_exponent(L.data(), n, -w_im, w_re);
+    out[2] = rf_f32_emax(n);
+}
 }

@@ -237,6 +237,55 @@ def test_rf_gradient_by_row_peeling_equals_stored_rows(hip, orc, n, thk_each, rf
         assert np.array_equal(a[1], b[1]) and np.all(np.isfinite(a[1])), (p2, nt2)
 
 
+@pytest.mark.parametrize("nt,dt,rf_type", [(512, 0.1, "P"), (2048, 0.025, "P"), (1024, 0.05, "S")])
+def test_float32_sweep_beyond_the_band(hip, orc, nt, dt, rf_type):
+    """Option rf_f32_beyond_band (default on): pass A sweeps the frequencies beyond the gradient's band in float32 and
+    k_rf_mid1 proves from the exact band values that nothing else was needed -- trace, misfit and gradient equal the
+    all-f64 sweep to 1e-13 (what is left are spectrum values weighted by exp(-(w/2f0)^2) < 1e-11 with a relative error
+    of 1e-5), both within 1e-8 of the oracle.  A water level high enough to reach the band (0.5) makes the proof fail
+    where the maximum lies beyond the band: those chains are swept again in f64 (statistic rf_f32_resweeps) with the
+    same agreement.  A window much shorter than the S travel time through the stack (growth exponent beyond
+    rf_f32_emax) keeps a chain on f64 throughout."""
+    n = 30
+    rng = np.random.default_rng(nt)
+    vs0 = np.linspace(2.4, 4.6, n); thk0 = np.full(n, 2.0); thk0[-1] = 0
+    xs = np.tile(np.hstack((vs0, thk0)), (40, 1))
+    xs[:, :n] = np.sort(xs[:, :n] * (0.9 + 0.2 * rng.random((40, n))), axis=1); xs[:, n:2 * n - 1] *= 0.8 + 0.4 * rng.random((40, n - 1))
+    resweeps = {}
+    for water in (0.001, 0.5):
+        args = (0.05, nt, dt, 1.5, 5.0, water, rf_type, "freq")
+        o_rf = orc.ReceiverFunc(*args)
+        d0 = o_rf.forward(np.hstack((vs0, thk0))); o_rf.set_obsdata(d0)
+        out = {}
+        for opt in (1, 0):
+            rf = hip.ReceiverFunc(*args); rf.set_obsdata(d0)
+            ctx = rf._ensure(n)
+            ctx.set_option("rf_f32_beyond_band", opt)
+            out[opt] = rf.misfit_and_grad(xs)
+            if opt:
+                assert ctx.stat("rf_f32_chains") == len(xs)
+                resweeps[water] = ctx.stat("rf_f32_resweeps")
+            else:
+                assert ctx.stat("rf_f32_chains") == 0
+        a, b = out[1], out[0]
+        assert np.abs(a[2] - b[2]).max() <= 1e-13 * np.abs(b[2]).max()
+        assert np.abs(a[0] - b[0]).max() <= 1e-12 * np.abs(b[0]).max() and rel(a[1], b[1]) < 1e-12
+        for i in (0, 17, 39):
+            mo, go, do = o_rf.misfit_and_grad(xs[i])
+            assert rel(a[1][i], go) < 1e-8 and rel(a[2][i], do) < 1e-8 and abs(a[0][i] - mo) <= 1e-9 * mo, (water, i)
+    assert resweeps[0.001] == 0
+    if nt == 2048:
+        assert resweeps[0.5] > 0          # (the longer axis: some maxima lie beyond the band)
+    # a 6.4 s window over a 60 km stack: exponent ~10, no float32
+    rf2 = hip.ReceiverFunc(0.05, 256, 0.025, 1.5, 2.0, 0.001, rf_type, "freq"); rf2.set_obsdata(np.zeros(256))
+    c2 = rf2._ensure(n)
+    a = rf2.misfit_and_grad(xs[:8])
+    assert c2.stat("rf_f32_chains") == 0 and np.all(np.isfinite(a[1]))
+    c2.set_option("rf_f32_beyond_band", 0)
+    b = rf2.misfit_and_grad(xs[:8])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
 def test_row_peeling_closure_residual(hip, orc):
     """Option rf_peel_check / statistic rf_peel_residual: after the last layer has been peeled off the row must be the
     half-space's own.  Teleseismic slowness: ~1e-14.  Peeling FORCED (mode 2) at a slowness beyond the crustal P velocities (evanescent P

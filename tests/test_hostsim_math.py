@@ -76,6 +76,41 @@ def test_rf_row_peeling_and_commutator_density_partial(hs):
     assert worst[0] < 1e-12 and worst[1] < 1e-11, worst
 
 
+def test_rf_float32_step_stays_inside_its_margin(hs):
+    """Pass A's float32 sweep of the frequencies beyond the gradient's band (rf_row_step_f32; host build: libm instead of
+    the hardware exp2 / sin / cos): wherever the kernels would allow it -- growth exponent at most rf_f32_emax(n) -- the
+    error of |R21|^2 stays far below RF_F32_MARGIN = 1e-2, which is what k_rf_mid1 adds to the float32 maximum before it
+    lets it decide anything.  30 and 50 layers, ordered and random stacks, P and S type, slownesses up to 0.08 s/km,
+    frequencies from the band limit to the Nyquist bins of the bench shapes."""
+    import ctypes
+    H = hs["rf"] if isinstance(hs, dict) else hs.rf
+    H.hs_rf_f32_error.restype = None
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rng = np.random.default_rng(11)
+    worst = 0.0; allowed = refused = 0
+    for n, h in ((30, 2.0), (50, 1.2), (12, 5.0)):
+        for trial in range(6):
+            vs = np.linspace(2.0, 4.6, n) if trial == 0 else np.sort(1.8 + 3.0 * rng.random(n))
+            if trial >= 4:
+                vs = rng.permutation(vs)
+            thk = np.full(n, h) * (1.0 if trial == 0 else 0.6 + 0.8 * rng.random(n))
+            vp = 0.9409 + 2.0947 * vs - 0.8206 * vs ** 2 + 0.2683 * vs ** 3 - 0.0251 * vs ** 4
+            rho = 1.6612 * vp - 0.4721 * vp ** 2 + 0.0671 * vp ** 3 - 0.0043 * vp ** 4 + 0.000106 * vp ** 5
+            q = np.full(n, 9999.0)
+            for p in (0.045, 0.065, 0.08):
+                for rf_type in (1, 2):
+                    for w in (15.7, 31.4, 62.8, 125.6):
+                        for sigma in (4.0 / 51.2, 4.0 / 12.8):
+                            out = np.zeros(3)
+                            H.hs_rf_f32_error(n, dp(thk), dp(rho), dp(vp), dp(vs), dp(q), dp(q), ctypes.c_double(p),
+                                              ctypes.c_double(w), ctypes.c_double(-sigma), rf_type, dp(out))
+                            if out[1] <= out[2]:
+                                allowed += 1; worst = max(worst, out[0])
+                            else:
+                                refused += 1
+    assert allowed > 400 and refused > 0 and worst < 1e-3, (allowed, refused, worst)
+
+
 @pytest.mark.parametrize("entry", ["hs_swd_rootsearch", "hs_swd_rootsearch_split"])
 def test_root_search_state_machine(hs, orc, golden, entry):
     """Request/advance state machine (+ the split secular function of the multi-lane kernels)."""
