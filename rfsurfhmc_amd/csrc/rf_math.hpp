@@ -239,6 +239,20 @@ RFS_HD float f32_rcp(float x) {
 constexpr double RF_F32_MARGIN = 1.0e-2, RF_F32_BOUND = 16.0 * 6.0e-8;
 RFS_HD double rf_f32_emax(int n) { return 0.5 * log(RF_F32_MARGIN / (RF_F32_BOUND * (n > 1 ? n : 1))); }
 
+// k_rf_mid1's decision for a chain whose frequencies beyond the band were swept in float32.  b1 / b2: maxima of |R21|^2 and
+// |R21^2|^2 over the band (exact), lo1 / lo2: their minima over the band (exact), h1 / h2: the maxima over the other
+// frequencies as the float32 sweep gave them (true value <= (1 + RF_F32_MARGIN) x that, squared for |R21^2|^2).
+//   0: the band holds both maxima -- b1, b2 ARE the maxima over all frequencies, the water level is the all-f64 one
+//   1: no band frequency can reach a water level set by the bounds: whatever the true maxima are, fai = max(|R21|^2,
+//      water max) picks |R21|^2 at every band frequency (RFModule.f90:396-401), and so does the adjoint's fai2
+//   2: neither: the frequencies beyond the band are swept again in f64
+RFS_HD int rf_f32_decide(double water, double b1, double b2, double h1, double h2, double lo1, double lo2) {
+    const double u1 = h1 * (1.0 + RF_F32_MARGIN), u2 = h2 * ((1.0 + RF_F32_MARGIN) * (1.0 + RF_F32_MARGIN));
+    if (u1 <= b1 && u2 <= b2) return 0;
+    if (lo1 >= water * fmax(b1, u1) && lo2 >= water * fmax(b2, u2)) return 1;
+    return 2;
+}
+
 RFS_HD V4f rf_row_step_f32(const RfLayer& L, cplx omega, const V4f& r) {
     const cplx ta = omega * L.pva, tb = omega * L.pvb;
     const float sa = (ta.re > 0.0 || (ta.re == 0.0 && ta.im >= 0.0)) ? 1.0f : -1.0f;

@@ -405,12 +405,10 @@ k_rf_mid1(int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ 
         }
         m1 = fmax(b1, h1); m2 = fmax(b2, h2);
         if (!h32) break;
-        const double u1 = h1 * (1.0 + RF_F32_MARGIN), u2 = h2 * ((1.0 + RF_F32_MARGIN) * (1.0 + RF_F32_MARGIN));
-        const bool band_holds_both = u1 <= b1 && u2 <= b2;
-        const bool band_out_of_reach = lo1 >= f.water * fmax(b1, u1) && lo2 >= f.water * fmax(b2, u2);
-        if (band_holds_both) { m1 = b1; m2 = b2; }
+        const int verdict = rf_f32_decide(f.water, b1, b2, h1, h2, lo1, lo2);
+        if (verdict == 0) { m1 = b1; m2 = b2; }
         if (tid == 0 && stat32 && pass == 0) atomicAdd(&stat32[2 + (chain & 63)], 1ull);      // (64 slots: one address would serialise)
-        if (band_holds_both || band_out_of_reach) break;
+        if (verdict != 2) break;
         // the rare chain: its frequencies beyond the band again, in f64 (the Nyquist bin always is)
         if (tid == 0 && stat32) atomicAdd(&stat32[0], 1ull);
         const RfLayer* L = lc + (size_t)chain * n;

@@ -121,4 +121,10 @@ void hs_rf_f32_error(int n, const double* thk, const double* rho, const double* 
     out[1] = rf_growth_exponent(L.data(), n, -w_im, w_re);
     out[2] = rf_f32_emax(n);
 }
+
+int hs_rf_f32_decide(double water, double b1, double b2, double h1, double h2, double lo1, double lo2)
+{
+    return rf_f32_decide(water, b1, b2, h1, h2, lo1, lo2);
+}
+double hs_rf_f32_margin() { return RF_F32_MARGIN; }
 }

@@ -111,6 +111,39 @@ def test_rf_float32_step_stays_inside_its_margin(hs):
     assert allowed > 400 and refused > 0 and worst < 1e-3, (allowed, refused, worst)
 
 
+def test_rf_float32_verdict_is_a_proof(hs):
+    """rf_f32_decide (k_rf_mid1): random |R21|^2 spectra whose values beyond the band are only known to within the margin.
+    Verdict 0 must mean that the band maxima ARE the maxima over all frequencies; verdict 1 that no band frequency is
+    touched by the water level built from the TRUE maxima (neither fai nor the adjoint's fai2); everything else is swept
+    again -- and all three verdicts occur."""
+    import ctypes
+    H = hs["rf"] if isinstance(hs, dict) else hs.rf
+    H.hs_rf_f32_decide.restype = ctypes.c_int
+    H.hs_rf_f32_decide.argtypes = [ctypes.c_double] * 7
+    H.hs_rf_f32_margin.restype = ctypes.c_double
+    margin = H.hs_rf_f32_margin()
+    rng = np.random.default_rng(3)
+    seen = {0: 0, 1: 0, 2: 0}
+    for trial in range(4000):
+        nk, n2 = 128, int(rng.choice([257, 1025]))
+        spread = float(rng.choice([0.3, 1.0, 3.0, 8.0]))
+        wa = np.exp(spread * rng.standard_normal(n2)) * (1.0 + 0.5 * np.cos(np.arange(n2) * rng.uniform(0.01, 0.3)))
+        if rng.random() < 0.5:
+            wa[0] *= 1.0 + 4.0 * rng.random()                  # (the bench shapes: maximum at DC)
+        water = float(rng.choice([1e-4, 1e-3, 1e-2, 0.1, 0.5]))
+        wb = wa * wa
+        # what the float32 sweep may return: anything whose (1 + margin) multiple still covers the true value
+        ha = wa[nk:] * (1.0 + (2.0 * rng.random(n2 - nk) - 1.0) * margin / (1.0 + margin) * 0.999)
+        hb = ha * ha
+        v = H.hs_rf_f32_decide(water, wa[:nk].max(), wb[:nk].max(), ha.max(), hb.max(), wa[:nk].min(), wb[:nk].min())
+        seen[v] += 1
+        if v == 0:
+            assert wa.max() == wa[:nk].max() and wb.max() == wb[:nk].max()
+        elif v == 1:
+            assert np.all(wa[:nk] >= water * wa.max()) and np.all(wb[:nk] >= water * wb.max())
+    assert min(seen.values()) > 50, seen
+
+
 @pytest.mark.parametrize("entry", ["hs_swd_rootsearch", "hs_swd_rootsearch_split"])
 def test_root_search_state_machine(hs, orc, golden, entry):
     """Request/advance state machine (+ the split secular function of the multi-lane kernels)."""
