@@ -283,6 +283,20 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          2 = also for rfs_joint_misfit_grad[_dev]: the CALLER promises that consecutive calls with the
  *                          same nchain evaluate the same chains a small step apart (a host-side leapfrog loop).
  *                          rfs_swd_forward / rfs_swd_kernel / rfs_joint_forward never warm-start.
+ *   "swd_warm_exact"       1 (default): behind the warm start, every continued root is turned into THE REFERENCE'S root: the
+ *                          reference's nevill returns the last midpoint of a run of bisections, 0.5 .. 1e-6 c short of the sign
+ *                          change, a function of the scan cell the bracket was found in -- so each lane takes a group of
+ *                          consecutive periods of one sequence, rebuilds the reference's scan grid period by period (origin =
+ *                          the unrounded root of the period before - 1.5 dc, surfdisp96.f:272-275), steps to the cell that holds
+ *                          the continued root and runs the reference's own refinement (surfdisp96.f:568-687) inside it.  The
+ *                          hand-over between periods is sequential only inside a group; a group starts with
+ *                          "swd_exact_runup" extra periods whose only purpose is its first origin (an origin that is off
+ *                          by 1e-6 c moves the result by ~1e-9 c: two run-up periods leave nothing).  Measured (tests/
+ *                          test_gpu_warm.py, 6.9 M roots): >= 99.99 % of the roots bit-identical to the reference-semantics
+ *                          search, the rest within 1e-6 c; misfit and gradient as with "swd_warm_start" = 0.
+ *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
+ *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
+ *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 5, >= 2) and run-up periods (default 2) of the above.
  *   "swd_warm_reset"       (any value) forget the previous evaluation: the next one goes through the reference-semantics
  *                          search for every chain.  A sampler calls it where a run may be cut and resumed (a checkpoint),
  *                          so that the resumed run and the uninterrupted one evaluate the same way from there on.
@@ -327,6 +341,9 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items
  *   "swd_warm_walked_chains"    chain evaluations whose sequences walked the reference's scan grid (anomalous dispersion, or
  *                               a first-order change above 0.5 km/s: "swd_warm_wide_chains" counts the latter)
+ *   "swd_exact_secular_evals"   secular-function evaluations of the reference-root stage ("swd_warm_exact");
+ *   "swd_exact_declined_chains" chain evaluations it handed back (no sign change in the expected scan cell, a grid at the
+ *                               floor of the scan, a root the reference rejects)
  *   "swd_warm_cause_<k>"        chains handed back, by (first) cause: 4 no usable previous evaluation / forced, 5 step too
  *                               large for a first-order model, 6 no sign change inside the trust radius, 7 root above the
  *                               fastest layer, 9 / 11 another root lies between the point the reference's scan of that

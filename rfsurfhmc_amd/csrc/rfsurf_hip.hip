@@ -88,12 +88,14 @@ struct rfs_ctx {
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
     int warm_serial = 0;       // option "swd_warm_serial": warm-started steps on ONE stream (1) or SWD beside RF (0)
     int exact_final = 0;       // option "swd_exact_final": first and last evaluation of a trajectory by the full search
+    int warm_exact = 1;        // option "swd_warm_exact": behind the warm start, the reference's own refinement inside the reference's scan cell (k_swd_exact): the reference's roots
+    int exact_group = 5, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, fstat, wslope, wbetmx;
-    hipEvent_t ev_w[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, wlist3, cwarm, fstat, wslope, wbetmx;
+    hipEvent_t ev_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     bool swd_water_cur = false;           // the batch being launched holds models with a water layer on top (B1 entries)
     int warm_nitems = 0;       // (sequence, period) items of the joint configuration's evaluation
@@ -727,7 +729,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
                   c->wsgn.as<unsigned char>(), c->wneed.as<int>() + nchain + 1, c->wneed.as<int>() + 2 * nchain + 1,
                   c->wilist.as<int>(), c->wneed.as<int>() + 2 * nchain + 2, c->wlist2.as<int>(), c->wneed.as<int>() + 2 * nchain + 3,
-                  c->wslope.as<double>(), c->wbetmx.as<float>()};
+                  c->wslope.as<double>(), c->wbetmx.as<float>(), c->warm_exact ? c->cwarm.as<double>() : (double*)nullptr,
+                  c->wneed.as<int>() + 3 * nchain + 3, c->wlist3.as<int>()};
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -824,6 +827,25 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[1], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[1], 0)); }
         else TRY(launch_fallback(W.list, W.count, est));
         TRY(launch_fallback(W.list2, W.count2, 64));
+        if (c->warm_exact) {
+            // ... and from the continued roots to the reference's own: its refinement (nevill) inside its scan cell, groups of
+            // periods per lane (k_swd_exact); what a lane declines goes to the full search like the branch test's chains
+            const int G = std::max(2, c->exact_group), ru = std::max(0, c->exact_runup);
+            auto ngroups = [&](const SwdSeqs& QQ) { int g = 0; for (int q = 0; q < QQ.nseq; q++) g += (QQ.s[q].nper + G - 1) / G; return g; };
+            if (Q.nper_total > 0) {
+                const int ng = ngroups(Q);
+                hipLaunchKernelGGL((k_swd_exact<SwdRayFamily>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s,
+                                   nchain, n, Q, G, ru, ng, mdlR, c->mdlc.as<double>(), c->croot.as<double>(), W);
+            }
+            if (P.QL.nper_total > 0) {
+                const int ng = ngroups(P.QL);
+                hipLaunchKernelGGL((k_swd_exact<SwdLoveFamily>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s,
+                                   nchain, n, P.QL, G, ru, ng, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
+            }
+            HIPCHK(c, hipGetLastError());
+            if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
+            TRY(launch_fallback(W.list3, W.count3, 64));
+        }
         roots = false;
     }
     // the two families' searches are independent: outside the CU-partitioned step the Love one runs on its own stream beside
@@ -941,14 +963,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             // above has read whatever roots they had; it must have finished before these results are written)
             HIPCHK(c, hipEventRecord(c->ev_w[2], s));
             HIPCHK(c, hipStreamWaitEvent(warm_side, c->ev_w[2], 0));
-            const int* lists[2] = {c->wlist.as<int>(), c->wlist2.as<int>()};
-            const int* counts[2] = {c->wneed.as<int>() + nchain, c->wneed.as<int>() + 2 * nchain + 2};
+            const int* lists[3] = {c->wlist.as<int>(), c->wlist2.as<int>(), c->wlist3.as<int>()};
+            const int* counts[3] = {c->wneed.as<int>() + nchain, c->wneed.as<int>() + 2 * nchain + 2, c->wneed.as<int>() + 3 * nchain + 3};
 #define RFS_LAUNCH_EIGEN_LIST(LOVE, SPH, QQ, SPHP, SFL, LI)                                                          \
             hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH, true>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
                                dim3(64), 0, warm_side, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(), \
                                SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (QQ).nper_total, 0, \
                                (int*)nullptr, lists[LI], counts[LI])
-            for (int li = 0; li < 2; li++) {
+            for (int li = 0; li < (c->warm_exact ? 3 : 2); li++) {
                 if (P.QR.nper_total > 0) {
                     if (sphere) RFS_LAUNCH_EIGEN_LIST(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>(), li);
                     else RFS_LAUNCH_EIGEN_LIST(false, false, P.QR, (const double*)nullptr, c->sflag.as<int>(), li);
@@ -1002,7 +1024,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->xw, 2 * nn * sizeof(double)); ENSURE(c, c->dxT, 2 * nn * sizeof(double));
         ENSURE(c, c->crT, 2 * nn * sizeof(double));
         const size_t before = c->wvalid.cap;
-        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (3 * (size_t)nchain + 3) * sizeof(int));
+        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (3 * (size_t)nchain + 4) * sizeof(int));
+        ENSURE(c, c->wlist3, (size_t)nchain * sizeof(int));
+        ENSURE(c, c->cwarm, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
         ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, (size_t)nchain * sizeof(int));
         for (auto& e : c->ev_w) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
@@ -1167,7 +1191,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            c->mdl.as<float>(), c->mdlc.as<double>(),
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
                            early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
-                           early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 3 : (size_t)0),
+                           early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 4 : (size_t)0),
                            track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>(),
                            fpre ? *fpre : FlowPre{});      // (flow entries: the step's drift rides in this kernel)
         HIPCHK(c, hipGetLastError());
@@ -1320,7 +1344,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1442,6 +1466,18 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_warm_start must be 0, 1 or 2");
         c->warm_opt = value; c->warm_primed = false; return RFS_OK;
     }
+    if (!strcmp(name, "swd_warm_exact")) {
+        if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "swd_warm_exact must be 0 or 1");
+        c->warm_exact = value; c->warm_primed = false; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_exact_group")) {
+        if (value < 2 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [2, 4096]");
+        c->exact_group = value; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_exact_runup")) {
+        if (value < 0 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_runup must be within [0, 64]");
+        c->exact_runup = value; return RFS_OK;
+    }
     if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
     if (!strcmp(name, "swd_exact_final")) {
@@ -1503,6 +1539,8 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     else if (!strcmp(name, "swd_warm_items")) idx = 2;
     else if (!strcmp(name, "swd_warm_walked_chains")) idx = 12;
     else if (!strcmp(name, "swd_warm_wide_chains")) idx = 13;
+    else if (!strcmp(name, "swd_exact_declined_chains")) idx = 14;
+    else if (!strcmp(name, "swd_exact_secular_evals")) idx = 15;
     else if (!strncmp(name, "swd_warm_cause_", 15)) { idx = atoi(name + 15); if (idx < 4 || idx > 11) idx = -1; }
     if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
     if (!c->wstats.p) return RFS_OK;

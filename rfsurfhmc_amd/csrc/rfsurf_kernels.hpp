@@ -929,6 +929,8 @@ struct SwdWarm {
     int* wide;              // [chain] a first-order change above WARM_L1MAX somewhere: every sequence of the chain walks the grid
     double* slope;          // [item][chain] d(secular)/dc at the root as the last warm search of the item left it (0 = unknown)
     float* betmx;           // [2][chain] fastest S velocity of the Rayleigh / Love search model (k_swd_warm -> k_swd_warm_check)
+    double* cwarm;          // [item][chain] the warm-started roots as k_swd_warm left them (k_swd_exact reads them while it overwrites croot), or nullptr
+    int* count3; int* list3;             // chains handed back by k_swd_exact
 };
 
 template <class F, bool SPH>
@@ -996,6 +998,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     const bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
     if (ok) {
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
+        if (W.cwarm) W.cwarm[(size_t)e * nchain + chain] = (double)(float)ws.root;
         W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
     } else decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
     W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
@@ -1171,6 +1174,67 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         for (int off = 32; off >= 1; off >>= 1) nev += __shfl_xor(nev, off, 64);
         if (lane == 0) atomicAdd(&W.stats[1], (unsigned long long)nev);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3x the reference's own roots from the warm-started ones (ExactGroup, swd_math.hpp): lane = (group of periods of one
+// sequence, chain).  A lane walks its group period by period -- origin of the scan grid from the unrounded root of the
+// period before, cell from the warm root, the reference's nevill inside -- behind `runup` periods that only serve the
+// first origin, and overwrites croot with the float32-rounded results (surfdisp96.f:302).  Chains already on their way
+// to the full search are skipped; a lane that cannot do its job (ExactGroup's X_FAIL causes) puts its chain on list3.
+// mdl: the float32 search model (start value of the scan of a sequence's first period).
+// ---------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, const float* __restrict__ mdl,
+            const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W)
+{
+    const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    bool live = g < (size_t)ngroups * nchain;
+    const int grp = live ? (int)(g / nchain) : 0, chain = live ? (int)(g - (size_t)grp * nchain) : 0;
+    int seq = 0, gl = grp;
+    while (seq + 1 < Q.nseq && gl >= (Q.s[seq].nper + G - 1) / G) { gl -= (Q.s[seq].nper + G - 1) / G; seq++; }
+    const int nper = Q.s[seq].nper;
+    const int k0 = gl * G, k1 = min(k0 + G, nper), kr = max(0, k0 - runup);
+    live = live && k0 < nper && !W.need[chain];
+    const size_t s = (size_t)n * nchain;
+    const size_t e0 = (size_t)Q.s[seq].croot_off * nchain + chain;
+    const double* cw = W.cwarm + e0;
+    const double* tper = Q.s[seq].t; const double tscale = Q.s[seq].scale;
+    auto approx = [&](int k) { return cw[(size_t)k * nchain]; };
+    auto om = [&](int k) { return (2.0 * 3.141592653589793) / (tper[k] * tscale); };
+    const double* lc0 = mdlc + chain;
+    auto loadL = [&](int m) {
+        const double* o = lc0 + (size_t)m * 6 * nchain;
+        return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                         o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+    };
+    ExactGroup x;
+    x.phase = ExactGroup::X_DONE; x.nev = 0; x.cause = 0; x.creq = 1.0; x.omega = 1.0;
+    if (live) {
+        SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        float bmx = 0.f;
+        const double cc = (double)swd_start_value(M, bmx);
+        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om);
+    }
+    while (__any(x.active())) {
+        if (x.active()) {
+            x.advance(swd_secular_family<F>(n, loadL, x.omega, x.creq));
+            if (x.phase == ExactGroup::X_DONE) {
+                if (x.wanted()) croot[e0 + (size_t)x.k * nchain] = (double)(float)x.root();       // surfdisp96.f:302
+                x.next(approx, om);                     // (the last period: stays X_DONE)
+            }
+        }
+    }
+    if (live && x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
+        W.list3[atomicAdd(W.count3, 1)] = chain;
+        atomicAdd(&W.stats[0], 1ull);
+        atomicAdd(&W.stats[14], 1ull);
+    }
+    int nev = x.nev;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nev += __shfl_xor(nev, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[15], (unsigned long long)nev);
 }
 
 constexpr int COOP_CL = 1;                       // the consumer builds the deepest finite layer itself

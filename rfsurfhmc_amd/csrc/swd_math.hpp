@@ -864,6 +864,143 @@ struct WarmSearch {
     }
 };
 
+// ---------------------------------------------------------------------------
+// The reference's own roots, period-parallel (round 4).  A warm-started root is the converged sign change; the reference's
+// is what its nevill returns: the last midpoint of a run of bisection steps, 0.5 .. 1.0e-6 c short of the sign change
+// (surfdisp96.f:568-687) -- a function of the scan cell [c1, c1 +- dc] the bracket was found in, i.e. of the grid the scan of
+// that period walks: origin = the UNROUNDED root of the period before - 1.5 dc (:272-275), or the model's start value for a
+// sequence's first period (:257-260).  Given the right cell, nevill needs nothing else from the scan, so a lane can
+// produce the reference's root of period k bit for bit from (origin, approximate root): step the grid from the origin to
+// the cell that holds the approximate root (the same repeated additions as getsol's loop), evaluate the two edges, run the
+// reference's refinement (RootSearchT::advance from the state getsol hands it) inside.  The chain through the origins is
+// sequential, but strongly contracting: an origin that is off by delta moves the result by ~delta / 2^j (j ~ 10 bisections)
+// unless a decision of nevill flips (measured with delta = 1e-6 c: median 1.2e-9 c, 5 % of the float32 results differ;
+// with the exact origin: identical, 2 496 of 2 496).  So the periods of a sequence are cut into GROUPS; a lane takes one
+// group, sequentially, handing the unrounded root from period to period exactly as the reference does, and precedes it
+// with `runup` periods whose only purpose is the origin of the group's first period: the first run-up period takes its
+// origin from the warm root of the period before it (1e-6 c off), the next ones inherit errors of 1e-9 c, 1e-12 c, ...
+// The first group of a sequence needs none: its first origin is the model's start value.
+// The machine only REQUESTS evaluations, like RootSearchT and WarmSearch.  It declines (status X_FAIL) whatever does not
+// fit -- no sign change in the cell the approximate root lies in nor in its neighbour, a grid that would touch the lower
+// clamp of getsol (:463-467), a root the reference rejects (:483-485) -- and the caller hands the chain to the
+// reference-semantics search.
+// ---------------------------------------------------------------------------
+constexpr double EXACT_OFFSET = 0.75e-6;     // the reference's root lies 0.5 .. 1.0e-6 c below the sign change: the run-up's first origin is moved by the mean
+
+struct ExactGroup {
+    enum { X_E1, X_E2, X_E1B, X_NEV, X_DONE, X_FAIL };
+    RootSearch rs;
+    double creq, omega;                      // the pending request: secular function of period `k` at creq
+    double o, rhat, c1, c2, del1, del2s, cprev, cc, dcs;
+    int k, k0, k1, phase, dir, msteps, shifted, nev, cause;
+    float betmx;
+
+    RFS_HD bool active() const { return phase < X_DONE; }
+
+    // grid point number m of the scan from origin o (getsol's own repeated additions, surfdisp96.f:457-469)
+    RFS_HD double grid(int m) const {
+        double c = o;
+        for (int i = 0; i < m; i++) c = (dir > 0) ? c + dcs : c - dcs;
+        return c;
+    }
+
+    // Periods [kr, k1) of one sequence, results wanted for [k0, k1) (kr < k0: run-up).  cstart: the model's start value
+    // (swd_start_value), bmx: its fastest S velocity.  origin0: unrounded root of period kr - 1 as far as it is known
+    // (ignored for kr == 0).
+    template <class RootFn, class OmegaFn>
+    RFS_HD void begin(int kr, int k0_, int k1_, double cstart, float bmx, double origin0, const RootFn& approx, const OmegaFn& om) {
+        k = kr; k0 = k0_; k1 = k1_; cc = cstart; betmx = bmx; dcs = (double)0.005f;
+        cprev = origin0; nev = 0; cause = 0;
+        rs.cc = cc; rs.dc = dcs; rs.cm = cc; rs.betmx = bmx; rs.nsec = 0;
+        for (int i = 0; i < 12; i++) { rs.tab.sx(i, 0.0); rs.tab.sy(i, 0.0); }
+        start_period(approx, om);
+    }
+
+    template <class RootFn, class OmegaFn>
+    RFS_HD void start_period(const RootFn& approx, const OmegaFn& om) {
+        rhat = approx(k); omega = om(k);
+        o = (k == 0) ? cc : cprev - 1.5 * dcs;                       // surfdisp96.f:257-260 / :272-275
+        if (!(rhat > 0.0) || !(o > 0.0) || rhat == o) { phase = X_FAIL; cause = 1; return; }
+        dir = rhat > o ? +1 : -1;
+        // the cell (c1, c2] the scan from o ends in: c1 the last grid point before the root, c2 the first one beyond it
+        c1 = o; msteps = 0;
+        for (;;) {
+            c2 = dir > 0 ? c1 + dcs : c1 - dcs;
+            if (dir > 0 ? c2 >= rhat : c2 <= rhat) break;
+            c1 = c2;
+            if (++msteps > 4000) { phase = X_FAIL; cause = 2; return; }
+        }
+        // getsol's clamp at the floor of the scan (:463-467: the start value of the model) and its abort below it are the
+        // full search's business
+        if ((k > 0 && dir > 0 && o + dcs <= cc) || (dir < 0 && c2 <= cc)) { phase = X_FAIL; cause = 3; return; }
+        shifted = 0;
+        creq = c1; phase = X_E1;
+    }
+
+    RFS_HD void enter_nevill(double del2) {
+        // the state getsol is in when its scan has just evaluated c2 (RootSearchT::advance, phase PH_SCAN)
+        rs.kmax = 1; rs.k = 0; rs.retry = 0; rs.done = 0; rs.flag = 1; rs.ifirst = 0; rs.idir = dir; rs.clow = cc;
+        rs.m = 1; rs.nev = 1; rs.nctrl = 1; rs.omega = omega;
+        rs.c1 = c1; rs.del1 = del1; rs.c2 = c2; rs.creq = c2; rs.phase = RootSearch::PH_SCAN;
+        step_nevill(del2);
+    }
+
+    RFS_HD void step_nevill(double f) {
+        double res = 0.0;
+        const double om = omega;
+        auto T = [&](int) { return (2.0 * 3.141592653589793) / om; };
+        auto out = [&](int, double v) { res = v; };
+        rs.advance(f, T, out);
+        if (rs.retry) { phase = X_FAIL; cause = 5; return; }          // the reference rejects the root (above the fastest layer)
+        if (rs.done) { cprev = rs.cprev; phase = X_DONE; (void)res; return; }
+        creq = rs.creq; phase = X_NEV;
+    }
+
+    // consume f = secular(creq) of period k; afterwards either a new request is pending, or the period is finished
+    // (phase X_DONE: root() / next()), or the machine has declined
+    RFS_HD void advance(double f) {
+        nev++;
+        if (f != f) { phase = X_FAIL; cause = 6; return; }
+        if (phase == X_E1) { del1 = f; creq = c2; phase = X_E2; return; }
+        if (phase == X_E1B) { del1 = f; enter_nevill_checked(); return; }
+        if (phase == X_E2) {
+            if (diffsign(del1, f)) { del2s = f; enter_nevill(f); return; }
+            // no sign change in the cell the approximate root lies in: that root is within its own error of a grid point
+            // and the change is in the neighbouring cell -- anything else is not the situation this machine is for
+            const double tol = 4.0e-7 * fabs(rhat);
+            if (shifted) { phase = X_FAIL; cause = 4; return; }
+            shifted = 1;
+            if (fabs(rhat - c2) <= tol) {                   // one cell further: c2 becomes c1 (value known), a new c2
+                c1 = c2; del1 = f; msteps++;
+                c2 = dir > 0 ? c1 + dcs : c1 - dcs;
+                if (dir < 0 && c2 <= cc) { phase = X_FAIL; cause = 3; return; }
+                creq = c2; phase = X_E2;
+            } else if (fabs(rhat - c1) <= tol && msteps > 0) {   // one cell back: c1 becomes c2 (value known), a new c1
+                c2 = c1; del2s = del1; msteps--;
+                c1 = grid(msteps);
+                creq = c1; phase = X_E1B;
+            } else { phase = X_FAIL; cause = 4; }
+            return;
+        }
+        step_nevill(f);
+    }
+    RFS_HD void enter_nevill_checked() {
+        if (!diffsign(del1, del2s)) { phase = X_FAIL; cause = 4; return; }
+        enter_nevill(del2s);
+    }
+
+    RFS_HD double root() const { return cprev; }             // unrounded (the next period's origin); the output is (float) of it
+    RFS_HD bool wanted() const { return k >= k0; }
+    // after X_DONE: on to the next period of the group, or finished (returns false)
+    template <class RootFn, class OmegaFn>
+    RFS_HD bool next(const RootFn& approx, const OmegaFn& om) {
+        k++;
+        if (k >= k1) return false;
+        start_period(approx, om);
+        return true;
+    }
+};
+
 // The secular function of wave family F at phase velocity c, layer constants through a loader (m -> SwdLayerC):
 // the arithmetic of the lanes-per-item search (raw recurrence, power-of-two rescale every eighth layer, one final
 // normalisation), evaluated by ONE lane.

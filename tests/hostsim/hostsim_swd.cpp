@@ -344,3 +344,48 @@ extern "C" double hs_secular(int n, const float* thk, const float* vp, const flo
     SwdModel M{thk, vp, vs, rho, 1, n};
     return love ? swd_secular_love(M, omega / c, omega) : swd_secular(M, omega / c, omega);
 }
+
+// The reference's roots from approximate ones (ExactGroup, swd_math.hpp: the lane code of k_swd_exact): the nt periods of one
+// sequence in groups of `G` with `runup` run-up periods each; approx[k] = warm-started root of period k (float32-rounded,
+// as k_swd_warm leaves it).  cout[k] = float32-rounded result (0 where the group declined), status[k] = 1 / 0,
+// nev[group] = secular evaluations.  Returns the number of declined groups.
+extern "C" int hs_exact_roots(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                              const double* t, const double* approx, int love, int sphere, int G, int runup,
+                              double* cout, int* status, int* nev, int* cause)
+{
+    std::vector<float> w(4 * n);
+    const float *d = thk, *a = vp, *b = vs, *r = rho;
+    if (sphere) {
+        swd_flatten_f32(love != 0, n, thk, vp, vs, rho, 1, &w[0], &w[n], &w[2 * n], &w[3 * n], 1);
+        d = &w[0]; a = &w[n]; b = &w[2 * n]; r = &w[3 * n];
+    }
+    std::vector<SwdLayerC> LC(n);
+    for (int m = 0; m < n; m++)
+        LC[m] = SwdLayerC{(double)d[m], 1.0 / (double)a[m], 1.0 / (double)b[m], (double)b[m], (double)r[m], 1.0 / (double)r[m]};
+    auto loadL = [&](int m) { return LC[m]; };
+    SwdModel M{d, a, b, r, 1, n};
+    float bmx;
+    const double cc = (double)swd_start_value(M, bmx);
+    auto ap = [&](int k) { return approx[k]; };
+    auto om = [&](int k) { return (2.0 * 3.141592653589793) / t[k]; };
+    int nfail = 0, g = 0;
+    for (int k = 0; k < nt; k++) { cout[k] = 0.0; status[k] = 0; }
+    for (int k0 = 0; k0 < nt; k0 += G, g++) {
+        const int k1 = k0 + G < nt ? k0 + G : nt, kr = k0 - runup > 0 ? k0 - runup : 0;
+        ExactGroup x;
+        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx[kr - 1] * (1.0 - EXACT_OFFSET) : 0.0, ap, om);
+        bool fin = false;
+        while (x.active() && !fin) {
+            const double f = love ? swd_secular_family<SwdLoveFamily>(n, loadL, x.omega, x.creq)
+                                  : swd_secular_family<SwdRayFamily>(n, loadL, x.omega, x.creq);
+            x.advance(f);
+            if (x.phase == ExactGroup::X_DONE) {
+                if (x.wanted()) { cout[x.k] = (double)(float)x.root(); status[x.k] = 1; }
+                if (!x.next(ap, om)) fin = true;
+            }
+        }
+        nev[g] = x.nev; cause[g] = x.phase == ExactGroup::X_FAIL ? x.cause : 0;
+        if (x.phase == ExactGroup::X_FAIL) { nfail++; for (int k = k0; k < k1; k++) { status[k] = 0; cout[k] = 0.0; } }
+    }
+    return nfail;
+}

@@ -255,6 +255,49 @@ def test_family_form_of_the_search_rayleigh_and_love(hs, golden, nseg):
     assert nroot > 500 and nsame >= 0.99 * nroot, (nroot, nsame)
 
 
+@pytest.mark.parametrize("group,runup", [(5, 2), (8, 2), (3, 1), (40, 0)])
+def test_exact_group_search_gives_the_reference_roots(hs, golden, group, runup):
+    """ExactGroup (swd_math.hpp, the lane code of k_swd_exact): from roots that are only CONVERGED (the sign change, as the
+    warm start leaves them: 0.5 .. 1e-6 c above what the reference's nevill returns) to the reference's own roots, periods
+    in groups with run-up.  Rayleigh and Love, flat and flattened earth, the fixtures' models: the float32 results are
+    those of the sequential reference-semantics search, bit for bit (group = 40, run-up 0: one lane walks the whole
+    sequence -- the hand-over is then the reference's own and every root must be identical)."""
+    g = golden["swd_love_sphere_reference"]
+    from oracle import oracle as O
+    H = hs["swd"]
+    I = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    rng = np.random.default_rng(group * 10 + runup)
+    nroot = nsame = ndecl = 0
+    for name in sorted({k.split("/")[0] for k in g.files if k.endswith("/thk")}):
+        thk, vs, t = g[f"{name}/thk"], g[f"{name}/vs"], np.ascontiguousarray(g[f"{name}/t"])
+        vp, rho, _, _ = O.empirical_relation(vs)
+        h, a, b, r = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)) for x in (thk, vp, vs, rho)]
+        n, nt = len(h), len(t)
+        for love, wt in ((0, "Rc"), (1, "Lc")):
+            for sph in (0, 1):
+                key = f"{name}/{wt}/{sph}"
+                if f"{key}/flag" not in g.files:
+                    continue
+                c0 = np.zeros(nt)
+                if not H.hs_rootsearch_family(n, F(h), F(a), F(b), F(r), nt, P(t), P(c0), love, sph, 1):
+                    continue
+                # converged roots: the reference's + 0.5 .. 1e-6 c, float32-rounded like k_swd_warm's output
+                approx = np.ascontiguousarray((c0 * (1.0 + rng.uniform(5e-7, 1e-6, nt))).astype(np.float32).astype(np.float64))
+                cx = np.zeros(nt); st = np.zeros(nt, dtype=np.int32)
+                ng = (nt + group - 1) // group
+                nev = np.zeros(ng, dtype=np.int32); cause = np.zeros(ng, dtype=np.int32)
+                H.hs_exact_roots(n, F(h), F(a), F(b), F(r), nt, P(t), P(approx), love, sph, group, runup, P(cx), I(st), I(nev), I(cause))
+                ok = st == 1
+                ndecl += int((~ok).sum())
+                assert np.all(np.abs(cx[ok] - c0[ok]) <= 1.2e-6 * c0[ok]), key
+                nroot += int(ok.sum()); nsame += int((cx[ok] == c0[ok]).sum())
+                if runup == 0 and group >= nt:
+                    assert np.array_equal(cx[ok], c0[ok]), key
+    # (declined groups: a root within one scan step of the start value or of the fastest layer -- the full search's business)
+    assert nroot > 500 and ndecl <= 0.1 * nroot, (nroot, ndecl)
+    assert nsame >= (0.995 if runup >= 2 else 0.98) * nroot, (nroot, nsame)
+
+
 def test_fast_exp_and_sincos_accuracy(tmp_path):
     """fm_exp / fm_sincos (cplx.hpp: the transcendental functions of every layer sweep) against long double libm
     on the ranges they are used on: < 1 ulp (exp) and < 1.5 ulp (sin, cos); absolute error at multiples of pi/2."""
