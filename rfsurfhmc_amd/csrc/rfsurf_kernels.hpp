@@ -1209,13 +1209,14 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, const f
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
+    __shared__ double nevtab[24 * 64];         // Neville tables of the wavefront's lanes, one column per lane
     ExactGroup x;
     x.phase = ExactGroup::X_DONE; x.nev = 0; x.cause = 0; x.creq = 1.0; x.omega = 1.0;
     if (live) {
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         float bmx = 0.f;
         const double cc = (double)swd_start_value(M, bmx);
-        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om);
+        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om, nevtab + threadIdx.x, 64);
     }
     while (__any(x.active())) {
         if (x.active()) {

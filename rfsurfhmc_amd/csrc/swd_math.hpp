@@ -887,12 +887,145 @@ struct WarmSearch {
 // ---------------------------------------------------------------------------
 constexpr double EXACT_OFFSET = 0.75e-6;     // the reference's root lies 0.5 .. 1.0e-6 c below the sign change: the run-up's first origin is moved by the mean
 
-struct ExactGroup {
+// nevill (surfdisp96.f:568-687) inside a bracket, as a request machine of its own -- the same decisions and the same
+// arithmetic as RootSearchT::advance's refinement stages (tests/test_hostsim_math.py holds the two together bit for
+// bit) -- with LAZY evaluation: of the ~12 points nevill evaluates, most are midpoints of a run of bisections that
+// approaches the root from the FAR end of a bracket whose other end already sits on the root (|f| a few 1e-6 of the far
+// value after the first interpolation, 1e-10 after the second).  All nevill does with such a value is (a) take its sign
+// -- the far end's --, (b) test whether it is still more than 100 times the near end's (:637-641: then it bisects again)
+// and (c) hand it to the next test of the same kind.  Where the function is close to linear across the bracket -- judged
+// from the residual of the first interpolation, which is exactly its curvature -- the value is the mean of the two ends to
+// a fraction of a per cent, so the machine supplies that mean itself as long as it exceeds the near value by more than
+// 100 x LAZY_MARGIN, and asks for the true value where the decision is closer, where the point will enter an
+// interpolation (interpolated points and the ends they are built from are always true values), and whenever the bracket
+// does not look like that.  The points themselves -- midpoints of exact doubles -- do not depend on the values, so the
+// returned root is the reference's bit for bit while 7-8 of its ~15 evaluations are never made.
+constexpr double LAZY_MARGIN = 1.5;          // a supplied value decides only tests it wins by this factor (its error where it is used: < 2 %)
+constexpr double LAZY_LIN = 0.02;            // residual of the first interpolation relative to the far end: above this, no supplied values
+
+template <bool LAZY = true>
+struct CellNevillT {
+    enum { N_HALF0, N_HALF_OUT, N_HALF_B, N_NEV, N_FIX1, N_FIX2, N_DONE, N_FAIL };
+    double c1, c2, del1, del2, c3, del3v, creq, result;
+    NevTabMem tab;                           // Neville table x(1..11), y(1..11) (1-based like the Fortran): LDS on the device (set by the owner)
+    int phase, nev, m, nctrl, nsupplied;
+    bool ex1, ex2, lin;
+    float betmx;
+
+    RFS_HD bool active() const { return phase < N_DONE; }
+
+    // (c1, del1): the scan's last point before the sign change, (c2, del2) its first point behind it; both values true
+    RFS_HD void enter(double c1_, double del1_, double c2_, double del2_, float bmx) {
+        c1 = c1_; del1 = del1_; c2 = c2_; del2 = del2_; betmx = bmx;
+        ex1 = ex2 = true; lin = false; nev = 1; m = 1; nctrl = 1; nsupplied = 0; result = 0.0;
+        c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF0;                 // nevill :583-589 (half)
+    }
+
+    RFS_HD void finish() {                                                 // getsol :483-487
+        result = c3;
+        phase = (c3 > (double)betmx) ? (int)N_FAIL : (int)N_DONE;
+    }
+
+    // the part of nevill's loop body behind the bracket update: ratio tests, Neville step or bisection (:636-681)
+    RFS_HD void choose() {
+        const double pct = (double)0.01f;
+        const double ss1 = fabs(del1), ss2 = fabs(del2);
+        bool half = (pct * ss1 > ss2) || (pct * ss2 > ss1) || nev == 0;
+        if (!half) {
+            // an interpolation: every value it uses must be a true one
+            if (nev != 2 && !(ex1 && ex2)) { creq = ex1 ? c2 : c1; phase = ex1 ? (int)N_FIX2 : (int)N_FIX1; return; }
+            double xn;
+            if (nev != 2) {
+                // table rebuilt from the bracket's ends (m = 1): one step of the recurrence
+                m = 1;
+                const double denom = del2 - del1;
+                half = fabs(denom) < 1.0e-10 * fabs(del2);
+                xn = (-del1 * c2 + del2 * c1) / denom;
+                tab.sx(1, half ? c1 : xn); tab.sy(1, del1); tab.sx(2, c2); tab.sy(2, del2);
+            } else {
+                // one more point on the table (rare: two interpolations in a row)
+                tab.sx(m + 1, c3); tab.sy(m + 1, del3v);
+                const double ym1 = del3v;
+                xn = c3;
+                for (int j = m; j >= 1 && !half; j--) {
+                    const double yj = tab.gy(j), denom = ym1 - yj;
+                    if (fabs(denom) < 1.0e-10 * fabs(ym1)) half = true;
+                    else { xn = (-yj * xn + ym1 * tab.gx(j)) / denom; tab.sx(j, xn); }
+                }
+            }
+            if (!half) { c3 = xn; creq = c3; phase = N_NEV; return; }
+        }
+        c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF_B;
+    }
+
+    // one pass of nevill's loop with the TRUE value del3 of f(c3)
+    RFS_HD void step(double del3) {
+        const int ph = phase;
+        const bool looptop = ph != N_HALF_OUT;
+        nev = (ph == N_HALF0 || ph == N_HALF_B) ? 1 : (ph == N_NEV ? 2 : nev);
+        m = (ph == N_HALF_B) ? 1 : (ph == N_NEV ? (m >= 10 ? 10 : m + 1) : m);
+        nctrl = (ph == N_HALF0) ? 2 : (looptop ? nctrl + 1 : nctrl);
+        if (looptop) {
+            if (nctrl >= 100) { finish(); return; }                                  // :595
+            if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {                             // :597-607
+                nev = 0; c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF_OUT; return;
+            }
+        }
+        // the linearity of the function across the bracket, seen by the first interpolated point: its value would be zero
+        if (LAZY && ph == N_NEV && nctrl == 3) lin = fabs(del3) <= LAZY_LIN * fmax(fabs(del1), fabs(del2));
+        const double s13 = del1 - del3, s32 = del3 - del2;
+        const bool opp = diffsign(del3, del1);                                        // :608-617
+        c2 = opp ? c3 : c2; del2 = opp ? del3 : del2; ex2 = opp ? true : ex2;
+        c1 = opp ? c1 : c3; del1 = opp ? del1 : del3; ex1 = opp ? ex1 : true;
+        if (fabs(c1 - c2) <= 1.0e-6 * c1) { finish(); return; }                      // :627
+        if (diffsign(s13, s32)) nev = 0;
+        del3v = del3;
+        choose();
+    }
+
+    // may the value at the pending bisection point be supplied?  (see the struct's comment)
+    RFS_HD bool can_supply(double& v) const {
+        if (!LAZY || !lin || phase != N_HALF_B) return false;
+        const double a1 = fabs(del1), a2 = fabs(del2);
+        const bool near1 = a1 < a2;
+        if (near1 ? !ex1 : !ex2) return false;                       // the near end's value is a true one
+        v = 0.5 * (del1 + del2);
+        return fabs(v) > (100.0 * LAZY_MARGIN) * (near1 ? a1 : a2);   // (also: the sign of v is the far end's by far)
+    }
+
+    // A supplied value at a far-side bisection point: what step() does with it, and nothing else -- the point is the
+    // bracket's midpoint (inside by construction), the value lies between the ends' (no monotonicity flag, :630-634), it
+    // has the far end's sign and replaces that end, and the ratio test that follows is the one can_supply() has decided
+    // (bisect again) unless the bracket has become narrow enough to stop.
+    RFS_HD void supplied_step(double v) {
+        nev = 1; m = 1; nctrl++;
+        if (nctrl >= 100) { finish(); return; }
+        const bool near1 = fabs(del1) < fabs(del2);
+        c2 = near1 ? c3 : c2; del2 = near1 ? v : del2; ex2 = near1 ? false : ex2;
+        c1 = near1 ? c1 : c3; del1 = near1 ? del1 : v; ex1 = near1 ? ex1 : false;
+        if (fabs(c1 - c2) <= 1.0e-6 * c1) { finish(); return; }
+        c3 = 0.5 * (c1 + c2); creq = c3;                                  // (phase stays N_HALF_B)
+    }
+
+    // consume the TRUE value f of f(creq); afterwards a new request is pending or the machine is done / has failed
+    RFS_HD void advance(double f) {
+        if (phase == N_FIX1 || phase == N_FIX2) {
+            if (phase == N_FIX1) { del1 = f; ex1 = true; } else { del2 = f; ex2 = true; }
+            choose();
+        } else step(f);
+        double v;
+        while (can_supply(v)) { nsupplied++; supplied_step(v); }
+    }
+};
+using CellNevill = CellNevillT<true>;
+
+template <bool LAZY = true>
+struct ExactGroupT {
     enum { X_E1, X_E2, X_E1B, X_NEV, X_DONE, X_FAIL };
-    RootSearch rs;
+    CellNevillT<LAZY> nv;
     double creq, omega;                      // the pending request: secular function of period `k` at creq
     double o, rhat, c1, c2, del1, del2s, cprev, cc, dcs;
-    int k, k0, k1, phase, dir, msteps, shifted, nev, cause;
+    int k, k0, k1, phase, dir, msteps, shifted, nev, cause, nsupplied;
     float betmx;
 
     RFS_HD bool active() const { return phase < X_DONE; }
@@ -907,12 +1040,13 @@ struct ExactGroup {
     // Periods [kr, k1) of one sequence, results wanted for [k0, k1) (kr < k0: run-up).  cstart: the model's start value
     // (swd_start_value), bmx: its fastest S velocity.  origin0: unrounded root of period kr - 1 as far as it is known
     // (ignored for kr == 0).
+    // tab: storage of the Neville table, 24 doubles at stride `tabstride` (LDS on the device: one column per lane)
     template <class RootFn, class OmegaFn>
-    RFS_HD void begin(int kr, int k0_, int k1_, double cstart, float bmx, double origin0, const RootFn& approx, const OmegaFn& om) {
+    RFS_HD void begin(int kr, int k0_, int k1_, double cstart, float bmx, double origin0, const RootFn& approx, const OmegaFn& om,
+                      double* tab, int tabstride) {
         k = kr; k0 = k0_; k1 = k1_; cc = cstart; betmx = bmx; dcs = (double)0.005f;
-        cprev = origin0; nev = 0; cause = 0;
-        rs.cc = cc; rs.dc = dcs; rs.cm = cc; rs.betmx = bmx; rs.nsec = 0;
-        for (int i = 0; i < 12; i++) { rs.tab.sx(i, 0.0); rs.tab.sy(i, 0.0); }
+        cprev = origin0; nev = 0; cause = 0; nsupplied = 0;
+        nv.tab.base = tab; nv.tab.stride = tabstride;
         start_period(approx, om);
     }
 
@@ -938,22 +1072,15 @@ struct ExactGroup {
     }
 
     RFS_HD void enter_nevill(double del2) {
-        // the state getsol is in when its scan has just evaluated c2 (RootSearchT::advance, phase PH_SCAN)
-        rs.kmax = 1; rs.k = 0; rs.retry = 0; rs.done = 0; rs.flag = 1; rs.ifirst = 0; rs.idir = dir; rs.clow = cc;
-        rs.m = 1; rs.nev = 1; rs.nctrl = 1; rs.omega = omega;
-        rs.c1 = c1; rs.del1 = del1; rs.c2 = c2; rs.creq = c2; rs.phase = RootSearch::PH_SCAN;
-        step_nevill(del2);
+        nv.enter(c1, del1, c2, del2, betmx);
+        creq = nv.creq; phase = X_NEV;
     }
 
     RFS_HD void step_nevill(double f) {
-        double res = 0.0;
-        const double om = omega;
-        auto T = [&](int) { return (2.0 * 3.141592653589793) / om; };
-        auto out = [&](int, double v) { res = v; };
-        rs.advance(f, T, out);
-        if (rs.retry) { phase = X_FAIL; cause = 5; return; }          // the reference rejects the root (above the fastest layer)
-        if (rs.done) { cprev = rs.cprev; phase = X_DONE; (void)res; return; }
-        creq = rs.creq; phase = X_NEV;
+        nv.advance(f);
+        if (nv.phase == CellNevillT<LAZY>::N_FAIL) { phase = X_FAIL; cause = 5; return; }   // the reference rejects the root (above the fastest layer)
+        if (nv.phase == CellNevillT<LAZY>::N_DONE) { cprev = nv.result; nsupplied += nv.nsupplied; phase = X_DONE; return; }
+        creq = nv.creq;
     }
 
     // consume f = secular(creq) of period k; afterwards either a new request is pending, or the period is finished
@@ -962,9 +1089,9 @@ struct ExactGroup {
         nev++;
         if (f != f) { phase = X_FAIL; cause = 6; return; }
         if (phase == X_E1) { del1 = f; creq = c2; phase = X_E2; return; }
-        if (phase == X_E1B) { del1 = f; enter_nevill_checked(); return; }
+        if (phase == X_E1B) { del1 = f; if (!diffsign(del1, del2s)) { phase = X_FAIL; cause = 4; return; } enter_nevill(del2s); return; }
         if (phase == X_E2) {
-            if (diffsign(del1, f)) { del2s = f; enter_nevill(f); return; }
+            if (diffsign(del1, f)) { enter_nevill(f); return; }
             // no sign change in the cell the approximate root lies in: that root is within its own error of a grid point
             // and the change is in the neighbouring cell -- anything else is not the situation this machine is for
             const double tol = 4.0e-7 * fabs(rhat);
@@ -984,10 +1111,6 @@ struct ExactGroup {
         }
         step_nevill(f);
     }
-    RFS_HD void enter_nevill_checked() {
-        if (!diffsign(del1, del2s)) { phase = X_FAIL; cause = 4; return; }
-        enter_nevill(del2s);
-    }
 
     RFS_HD double root() const { return cprev; }             // unrounded (the next period's origin); the output is (float) of it
     RFS_HD bool wanted() const { return k >= k0; }
@@ -1000,6 +1123,7 @@ struct ExactGroup {
         return true;
     }
 };
+using ExactGroup = ExactGroupT<true>;
 
 // The secular function of wave family F at phase velocity c, layer constants through a loader (m -> SwdLayerC):
 // the arithmetic of the lanes-per-item search (raw recurrence, power-of-two rescale every eighth layer, one final

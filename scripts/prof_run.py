@@ -2,7 +2,7 @@
     python3 scripts/prof_run.py [config=1] [steps=10] [warm_start=1]
 The first call (start models) goes through the reference-semantics root search, the `steps` calls after it through the
 warm-started one (warm_start = 1) -- scripts/pmc_summary.py divides the counters by the calls each kernel ran in."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from rfsurfhmc_amd.model.model_rf import ReceiverFunc

@@ -348,10 +348,12 @@ extern "C" double hs_secular(int n, const float* thk, const float* vp, const flo
 // The reference's roots from approximate ones (ExactGroup, swd_math.hpp: the lane code of k_swd_exact): the nt periods of one
 // sequence in groups of `G` with `runup` run-up periods each; approx[k] = warm-started root of period k (float32-rounded,
 // as k_swd_warm leaves it).  cout[k] = float32-rounded result (0 where the group declined), status[k] = 1 / 0,
-// nev[group] = secular evaluations.  Returns the number of declined groups.
-extern "C" int hs_exact_roots(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
-                              const double* t, const double* approx, int love, int sphere, int G, int runup,
-                              double* cout, int* status, int* nev, int* cause)
+// nev[group] = secular evaluations.  lazy = 0: every value nevill asks for is evaluated (CellNevillT<false>).
+// Returns the number of declined groups.
+template <bool LAZY>
+static int exact_roots(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                       const double* t, const double* approx, int love, int sphere, int G, int runup,
+                       double* cout, int* status, int* nev, int* cause, long* nsupplied)
 {
     std::vector<float> w(4 * n);
     const float *d = thk, *a = vp, *b = vs, *r = rho;
@@ -366,26 +368,42 @@ extern "C" int hs_exact_roots(int n, const float* thk, const float* vp, const fl
     SwdModel M{d, a, b, r, 1, n};
     float bmx;
     const double cc = (double)swd_start_value(M, bmx);
-    auto ap = [&](int k) { return approx[k]; };
     auto om = [&](int k) { return (2.0 * 3.141592653589793) / t[k]; };
+    auto ap = [&](int k) { return approx[k]; };
     int nfail = 0, g = 0;
     for (int k = 0; k < nt; k++) { cout[k] = 0.0; status[k] = 0; }
     for (int k0 = 0; k0 < nt; k0 += G, g++) {
         const int k1 = k0 + G < nt ? k0 + G : nt, kr = k0 - runup > 0 ? k0 - runup : 0;
-        ExactGroup x;
-        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx[kr - 1] * (1.0 - EXACT_OFFSET) : 0.0, ap, om);
+        ExactGroupT<LAZY> x;
+        double tab[24];
+        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx[kr - 1] * (1.0 - EXACT_OFFSET) : 0.0, ap, om, tab, 1);
         bool fin = false;
         while (x.active() && !fin) {
             const double f = love ? swd_secular_family<SwdLoveFamily>(n, loadL, x.omega, x.creq)
                                   : swd_secular_family<SwdRayFamily>(n, loadL, x.omega, x.creq);
             x.advance(f);
-            if (x.phase == ExactGroup::X_DONE) {
+            if (x.phase == ExactGroupT<LAZY>::X_DONE) {
                 if (x.wanted()) { cout[x.k] = (double)(float)x.root(); status[x.k] = 1; }
                 if (!x.next(ap, om)) fin = true;
             }
         }
-        nev[g] = x.nev; cause[g] = x.phase == ExactGroup::X_FAIL ? x.cause : 0;
-        if (x.phase == ExactGroup::X_FAIL) { nfail++; for (int k = k0; k < k1; k++) { status[k] = 0; cout[k] = 0.0; } }
+        nev[g] = x.nev; cause[g] = x.phase == ExactGroupT<LAZY>::X_FAIL ? x.cause : 0;
+        if (nsupplied) *nsupplied += x.nsupplied;
+        if (x.phase == ExactGroupT<LAZY>::X_FAIL) { nfail++; for (int k = k0; k < k1; k++) { status[k] = 0; cout[k] = 0.0; } }
     }
     return nfail;
+}
+extern "C" int hs_exact_roots(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                              const double* t, const double* approx, int love, int sphere, int G, int runup,
+                              double* cout, int* status, int* nev, int* cause)
+{
+    return exact_roots<true>(n, thk, vp, vs, rho, nt, t, approx, love, sphere, G, runup, cout, status, nev, cause, nullptr);
+}
+extern "C" int hs_exact_roots2(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                               const double* t, const double* approx, int love, int sphere, int G, int runup, int lazy,
+                               double* cout, int* status, int* nev, int* cause, long* nsupplied)
+{
+    *nsupplied = 0;
+    return lazy ? exact_roots<true>(n, thk, vp, vs, rho, nt, t, approx, love, sphere, G, runup, cout, status, nev, cause, nsupplied)
+                : exact_roots<false>(n, thk, vp, vs, rho, nt, t, approx, love, sphere, G, runup, cout, status, nev, cause, nsupplied);
 }

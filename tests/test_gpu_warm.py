@@ -108,7 +108,10 @@ def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc, exact):
             r = np.abs(c_steps[s][ok] - co[ok]) / co[ok]
             worst = max(worst, float(r.max()))
             nident += int((c_steps[s][ok] == co[ok]).sum()); ntot += int(ok.sum()) * 40
-            assert r.max() <= 1.2e-6, (s, float(r.max()))
+            # converged roots lie within 1e-6 c above the reference's (+ two float32 roundings); a root of the reference-root
+            # stage that is NOT the reference's (a decision of nevill that flipped under a run-up origin 1e-9 c off) is still
+            # the end of a bracket of 1e-6 c around the sign change, like the reference's: up to 2e-6 c apart
+            assert r.max() <= (2.2e-6 if exact else 1.2e-6), (s, float(r.max()))
     # 512 chains of the last step against the oracle's joint plugin (the contract: 1e-5)
     xl, ml, gl, fl = last
     pick = np.nonzero(fl)[0][:512]

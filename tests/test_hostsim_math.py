@@ -298,6 +298,45 @@ def test_exact_group_search_gives_the_reference_roots(hs, golden, group, runup):
     assert nsame >= (0.995 if runup >= 2 else 0.98) * nroot, (nroot, nsame)
 
 
+def test_lazy_nevill_takes_the_same_path_as_the_full_one(hs):
+    """CellNevillT<true> supplies the values of far-side bisection points itself where the test they feed is won by a factor
+    of three (swd_math.hpp); CellNevillT<false> evaluates every point like the reference.  Sorted, unsorted ("wild"),
+    low-velocity-layer and thin-layer models, Rayleigh and Love, 40 periods in one sequential group: the same float32
+    roots from both, at roughly half the evaluations."""
+    import bench
+    from oracle import oracle as O
+    H = hs["swd"]
+    I = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    n, nt = 30, 40
+    t = np.ascontiguousarray(np.linspace(5, 44, nt))
+    rng = np.random.default_rng(11)
+    xs = bench.make_models(192, 123, n)
+    nroot = nev_l = nev_p = 0
+    for i, x in enumerate(xs):
+        vs, thk = x[:n].copy(), x[n:].copy()
+        if i % 4 == 1: vs = rng.permutation(vs)
+        if i % 4 == 2: vs[rng.integers(2, n - 2)] *= 0.8
+        if i % 4 == 3: thk *= 0.5
+        vp, rho, _, _ = O.empirical_relation(vs)
+        h, a, b, r = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).astype(np.float32)) for v in (thk, vp, vs, rho)]
+        for love in (0, 1):
+            c0 = np.zeros(nt)
+            if not H.hs_rootsearch_family(n, F(h), F(a), F(b), F(r), nt, P(t), P(c0), love, 0, 1):
+                continue
+            approx = np.ascontiguousarray((c0 * (1.0 + rng.uniform(5e-7, 1e-6, nt))).astype(np.float32).astype(np.float64))
+            res = []
+            for lazy in (1, 0):
+                cx = np.zeros(nt); st = np.zeros(nt, dtype=np.int32); nev = np.zeros(1, dtype=np.int32); cause = np.zeros(1, dtype=np.int32)
+                ns = ctypes.c_long(0)
+                H.hs_exact_roots2(n, F(h), F(a), F(b), F(r), nt, P(t), P(approx), love, 0, nt, 0, lazy, P(cx), I(st), I(nev), I(cause), ctypes.byref(ns))
+                res.append((cx, st, int(nev[0])))
+            (cl, sl, nl), (cp, sp, npl) = res
+            assert np.array_equal(sl, sp) and np.array_equal(cl, cp), (i, love)
+            if (sp == 1).all():
+                nroot += nt; nev_l += nl; nev_p += npl
+    assert nroot > 10000 and nev_l <= 0.62 * nev_p, (nroot, nev_l, nev_p)
+
+
 def test_fast_exp_and_sincos_accuracy(tmp_path):
     """fm_exp / fm_sincos (cplx.hpp: the transcendental functions of every layer sweep) against long double libm
     on the ranges they are used on: < 1 ulp (exp) and < 1.5 ulp (sin, cos); absolute error at multiples of pi/2."""
