@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- leapfrog-step throughput of the HIP hot path (BASELINE.json `metric`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,3,4}] [--chains C]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,3,4}] [--chains C] [--dt DT]
 
 --gpus N launches N ranks BY ITSELF (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for
 each, torch.distributed over RCCL); under `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE
@@ -10,22 +10,26 @@ already in the environment) the process is one of those ranks.  Counterpart of t
 
 Workloads (BASELINE.json `configs`; --config selects, configs[1] is the default and the headline):
   1  configs[1]: 8192 chains x 30-layer Vs+thk models per GPU, joint RF (P, nt = 512, dt = 0.1, Gaussian 1.5,
-     shift 5 s, water 1e-3, freq method) + 40 Rayleigh phase periods linspace(5, 44, 40)
+     shift 5 s, water 1e-3, freq method) + 40 Rayleigh phase periods linspace(5, 44, 40); plain HMC
+     (HamitonianMC.sample_flow, L ~ U{5..20}) at a step size tuned for an acceptance ratio within 0.65-0.9
   4  configs[4]: the same with a 2048-point RF trace (dt = 0.025 s)
-  3  configs[3]: HMCDualAveraging.sample_flow (main_DA.py), 8192 chains x 50 layers: a real sampler run with
-     per-chain dt and L = max(1, int(lambda / dt)), host accept / reject and dual averaging included
+  3  configs[3]: HMCDualAveraging.sample_flow (main_DA.py), 8192 chains x 50 layers: per-chain dt and
+     L = max(1, int(lambda / dt)), dual averaging included
 Synthetic sorted-prior models, dobs = forward(true model).
 
-A "step" = ONE LEAPFROG STEP OF EVERY CHAIN of the rank through the C ABI (rfs_flow_step: drift with mirror
-reflection, misfit + gradient evaluation, kick; pyhmc/hmc.py:164-183); state resident in HBM when the timed
-region starts.  value = leapfrog steps (= evaluations) of all ranks / max-over-ranks wall time.
-The JSON line of the default run (N = 1, configs[1]) also carries: `roofline` (the kernel group with the largest
-per-step sum), `valu_issue` (SQ_INSTS_VALU per step from the committed PMC passes against the measured time),
-`root_search` (items continued from the previous step, evaluations per item, chains handed back), `sampler_flow` (a real
-HamitonianMC run on the same chains, >= 2 s), `full_search_every_step` (the warm start off), `config4` / `config3`
-(short legs of the other single-GPU configurations, each with its own roofline) and `cpu_baseline`.  Independent
-chains shard across ranks (weak scaling, no data-path collective); the only collective is the RCCL gather of the
-per-chain misfits after the timed region (comm.Gather, main_base.py:90).
+A "step" = ONE DEVICE STEP OF THE SAMPLER: one leapfrog step of every chain through the C ABI (rfs_flow_step2: drift with
+mirror reflection, misfit + gradient evaluation, kick; accept / reject and the next trajectory's start on the device from
+draws made ahead; pyhmc/hmc.py:140-201, 228-276), state resident in HBM.  W warm-up steps (the chains' burn-in from their
+random start models) run untimed, then exactly K steps are timed.  value = leapfrog steps (= misfit+gradient evaluations) of
+chains inside a trajectory, all ranks / max-over-ranks wall time.
+The JSON line of the default run (N = 1, configs[1]) also carries: the step size and the acceptance ratio of the timed
+window, the root-search mode, `roofline` (the kernel group with the largest stand-alone time per step, its duration
+measured live over the timed region), `valu_issue` (SQ_INSTS_VALU per step from the committed PMC passes), `root_search`
+(evaluations per item, chains handed back), legs at other step sizes (`dt_sweep`: 0.002 / 0.02 / the reference's 0.1),
+with the converged instead of the reference's roots (`converged_roots`), with the history-free search at every step
+(`full_search_every_step`), rounds 1-3's headline definition (`never_ending_dt0002`), `config4` / `config3` and
+`cpu_baseline`.  Independent chains shard across ranks (weak scaling, no data-path collective); the only collective is the
+RCCL gather of the per-chain misfits after the timed region (comm.Gather, main_base.py:90).
 """
 import argparse
 import ctypes
@@ -47,6 +51,20 @@ NPER = 40
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64: 256 CUs
 METRIC = "leapfrog steps/sec (= forward+grad evals/sec) per GPU and whole node, 30-layer model"
+# param.yaml:40 runs plain HMC at dt = 0.1; SURVEY 8(d): "tune so accept ~ 0.65-0.9".  Measured on the bench's chains after
+# burn-in (scripts/dt_sweep.py, 8192 chains, L ~ U{5..20}): 0.998 at 0.002, 0.99 at 0.02, 0.95 at 0.03, 0.77 at 0.05,
+# 0.63 at 0.07, 0.44 at 0.1.
+TUNED_DT = 0.05
+DT_SWEEP = (0.002, 0.02, 0.1)
+DTYPE_TEXT = ("f64 (receiver-function row sweep beyond the Gaussian band: packed f32 where proven exact per chain, "
+              "rf_f32_beyond_band)")
+ROOT_MODE_TEXT = {
+    "reference_roots": "inside a trajectory: warm start from the previous step's roots and kernels, branch test, then the "
+                       "reference's own refinement inside its scan cell (swd_warm_start 1, swd_warm_exact 1): the reference's "
+                       "float32 roots; start models and declined chains: the reference-semantics search",
+    "converged_roots": "warm start + branch test only (swd_warm_exact 0): converged roots, within 1.1e-6 c of the reference's",
+    "full_search": "the reference-semantics sequential search at every evaluation (swd_warm_start 0)",
+}
 
 CONFIGS = {
     1: dict(idx=1, n=30, nt=512, dt=0.1, sampler=None,
@@ -102,9 +120,11 @@ def make_models(nchain, seed, n=N_LAYER):
     v = lo + (hi - lo) * rng.random((nchain, n))
     h = thk0 * (0.8 + 0.4 * rng.random((nchain, n)))
     h[:, -1] = 2.0 * rng.random(nchain)          # last thickness is a dummy in [0, 2]
-    idx = np.argsort(v, axis=1)
-    v = np.take_along_axis(v, idx, axis=1)
-    h[:, :-1] = np.take_along_axis(h, idx, axis=1)[:, :-1]
+    # hmc.py:85-93 sorts vs and carries the thicknesses along, then REJECTS a draw whose first 2n - 1 entries leave their
+    # bounds (:95-99) -- with one thickness range for every layer the accepted draws are sorted velocities over
+    # independent in-range thicknesses.  (Rounds 1-3 permuted the dummy last thickness, drawn in [0, 2], into the stack
+    # as well: about half of the start models lay outside the bounds and were mirrored back by the first drift.)
+    v = np.sort(v, axis=1)
     return np.hstack((v, h))
 
 
@@ -115,6 +135,12 @@ def _cpu_worker(args):
     plugins, one independent chain per process as the reference runs them (README.md:43-44).  Falls back to the C
     restatement where oracle/_ref is absent."""
     wid, n, nt, dt, dobs, xs, budget_s = args
+    # (the reference's Fortran writes a model dump to unit 6 whenever its root search fails -- surfdisp96.f:320-336 -- and the
+    # burned-in models of the bench do make it fail now and then: keep that out of the launcher's stdout, which carries the JSON line)
+    try:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    except OSError:
+        pass
     try:                                   # numpy is already loaded (forked): pin its BLAS pool to this one core
         from threadpoolctl import threadpool_limits
         threadpool_limits(limits=1)
@@ -274,7 +300,16 @@ def launch(args, argv):
         cfg = CONFIGS[args.config]
         side = res.pop("_cpu_inputs")
         res["cpu_baseline"] = cpu_baseline(cfg, np.array(side["xs"]), np.array(side["dobs"]))
-        res["gpu_over_cpu_node"] = res["value"] / res["cpu_baseline"]["value"]
+        g = res["value"] / res["cpu_baseline"]["value"]
+        res["gpu_over_cpu_node"] = g
+        # the two components of that ratio.  The CPU figure is the reference as written (O(n^2)
+        # propagator loop, 1 + 4 n inverse FFTs); the GPU path runs the O(n) adjoint algorithm.
+        alg = 4.6e8 / ALG_FLOPS_PER_EVAL if cfg["n"] == N_LAYER and cfg["nt"] == NT else None
+        res["cpu_baseline"]["speedup_split"] = {
+            "algorithmic": alg, "hardware_and_implementation": g / alg if alg else None,
+            "note": "algorithmic = flop count of the reference as written (4.6e8 per evaluation, SURVEY 8(d)) / the minimal O(n) "
+                    "algorithm's (2.8e7); the rest is this box's GPU against its host cores.  A CPU build of the O(n) algorithm does "
+                    "not ship (no CPU fallback in the product), so the split is by flop count, not by a second CPU measurement"}
     res.pop("_cpu_inputs", None)
     print(json.dumps(res))
 
@@ -314,7 +349,7 @@ N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs; one f64 (or any VALU) wave-instruc
 def _counters(config):
     """Per-step PMC figures of a configuration (profiles/r*_counters.json, written by scripts/pmc_summary.py from
     separate rocprofv3 --pmc passes); None where no pass was committed."""
-    for name in ("r03_counters.json",):
+    for name in ("r04_counters.json", "r03_counters.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if tj.get("chains") == 8192 and f"config{config}" in tj:
@@ -324,12 +359,12 @@ def _counters(config):
     return None
 
 
-def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, dom_live_ms_launch):
+def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, dom_live_ms_launch, dom_live_ms_step=None):
     """The figures of one timed leg: rate, per-step kernel-group times, roofline of the group with the largest per-STEP
     sum, VALU issue per group from the committed counter passes."""
     n, nt = cfg["n"], cfg["nt"]
     ab = alg_bytes_per_eval(n, nt)
-    dom_ms = ms_step[dom]
+    dom_ms = ms_step[dom] if dom_live_ms_step is None else dom_live_ms_step
     achieved = ab * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     cnt = _counters(config) if nchain == 8192 else None
     traffic = cnt[dom]["hbm_bytes"] if cnt and dom in cnt and cnt[dom]["hbm_bytes"] > 0 else None
@@ -339,8 +374,9 @@ def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, d
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_step": ab * nchain, "group_ms_per_step": dom_ms,
                      "launches_per_step": launches_step[dom], "avg_launch_ms": dom_live_ms_launch,
-                     "note": "group with the largest per-step sum of HIP-event durations; the path is FP64-VALU / "
-                             "transcendental bound (SURVEY 8(d)): see valu_issue"},
+                     "note": "kernel group with the largest stand-alone time per step; achieved = algorithmic bytes of one step "
+                             "/ its HIP-event time per step over the timed region; the path is FP64-VALU / transcendental "
+                             "bound (SURVEY 8(d)): see valu_issue"},
         "kernel_ms_per_step": ms_step, "kernel_launches_per_step": launches_step,
     }
     if cnt:
@@ -353,7 +389,7 @@ def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, d
                          "measured_ms_per_step": ms_step[k], "frac": full / ms_step[k] if ms_step[k] > 0 else None}
         rep["valu_issue"] = {"per_group": vi, "step": {"ms_at_full_issue": tot, "measured_ms_per_step": el / K * 1e3,
                                                        "frac": tot / (el / K * 1e3)},
-                             "note": "SQ_INSTS_VALU per leapfrog step (committed rocprofv3 --pmc pass, profiles/r03_pmc_config*.csv) "
+                             "note": "SQ_INSTS_VALU per leapfrog step (committed rocprofv3 --pmc passes, profiles/r0*_pmc_config*.csv) "
                                      "x 4 clocks / 1024 SIMDs / 2.4 GHz against the measured time; group times are HIP-event "
                                      "durations on two concurrent streams (they overlap, their sum exceeds the step)"}
     return rep
@@ -450,73 +486,122 @@ def flow_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, ba
     return rep, st, xs, el
 
 
-def da_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, barrier):
-    """configs[3]: a real HMCDualAveraging run on the continuous-flow schedule, K device steps timed."""
+def set_root_mode(joint, n, mode):
+    ctx = joint._ensure(n)
+    joint.set_warm_start(0 if mode == "full_search" else 1)
+    ctx.set_option("swd_warm_exact", 0 if mode == "converged_roots" else 1)
+
+
+def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, barrier, kind="hmc", dt=TUNED_DT,
+                mode="reference_roots", xs=None, groups=True):
+    """A real sampler run on the continuous-flow schedule (HamitonianMC.sample_flow / HMCDualAveraging.sample_flow): `burn`
+    device steps untimed, K timed.  kind "hmc": pyhmc/hmc.py:228-276 at step size dt, L ~ U{5..20} (param.yaml:38); "da":
+    main_DA.py's dual averaging (dt0 0.1, L0 10, target 0.65).  groups: per-kernel-group times -- every group on its own in a
+    few one-stream steps before the window (that picks the dominant group), the dominant one live over the window."""
     import torch
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
     n = cfg["n"]
+    set_root_mode(joint, n, mode)
     ctx = joint._ensure(n)
     gt = GroupTimer(ctx)
-    rs = np.random.default_rng(3 + rank)
-    xs = np.clip(x_true[None, :] * (1 + 0.02 * rs.standard_normal((nchain, 2 * n))), bounds[:, 0], bounds[:, 1])
-    xs[:, :n] = np.sort(xs[:, :n], axis=1)
-    # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
-    smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
+    if xs is None:
+        if kind == "da":
+            rs = np.random.default_rng(3 + rank)
+            xs = np.clip(x_true[None, :] * (1 + 0.02 * rs.standard_normal((nchain, 2 * n))), bounds[:, 0], bounds[:, 1])
+            xs[:, :n] = np.sort(xs[:, :n], axis=1)
+        else:
+            xs = make_models(nchain, seed=991206 + rank, n=n)      # chain c of rank r ~ reference rank r * nchain + c
+    nsamp = (burn + K) // 4 + 20                                   # more sample slots than trajectories can complete
+    if kind == "da":
+        # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
+        smp = HMCDualAveraging(joint, bounds, 0.1, 10, max(10, nsamp // 10 + 1), 0.65, 991206, nsamp, 20, myrank=rank, name="bench", outdir=None,
+                               nchains=nchain, verbose=False, store_syn=False)
+        # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
+        # given the chains different step sizes) finish in bursts; time a window behind them
+        burn = max(burn, 40)
+    else:
+        smp = HamitonianMC(joint, bounds, dt, [5, 20], 10, 991206, nsamp, 20, myrank=rank, name="bench", outdir=None,
                            nchains=nchain, verbose=False, store_syn=False)
-    # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
-    # given the chains different step sizes) finish in bursts; time a window behind them
-    nwarm = max(nwarm, 40)
     marks = {}
+    STATS = ("swd_warm_declined_chains", "swd_warm_items", "swd_warm_secular_evals", "swd_exact_secular_evals",
+             "swd_warm_walked_chains", "swd_exact_declined_chains", "flow_chain_steps")
+    nser = 4 if (groups and burn >= 12) else 0
 
     def hook(s, st):
-        if s == 1:
+        if nser and s == burn - nser - 2:
+            ctx.set_option("swd_warm_serial", 1)                   # one stream: every kernel group alone on the chip
+        if nser and s == burn - nser - 1:
             gt.on()
-        if s == nwarm:
-            marks["warm"] = gt.read()
-            marks["dom"] = int(np.argmax(marks["warm"][0]))
-            gt.on(1 << marks["dom"])
-            marks["stat0"] = (ctx.stat("swd_warm_declined_chains"), ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals"))
-            marks["fs0"] = ctx.stat("flow_chain_steps")     # chains inside a trajectory, summed over the steps = leapfrog steps done
+        if nser and s == burn - 1:
+            marks["alone"] = gt.read()
+            ctx.set_option("swd_warm_serial", 0)
+            marks["dom"] = int(np.argmax(marks["alone"][0]))
+            gt.on(1 << marks["dom"])                               # the dominant group only, measured live below
+        if s == burn:
+            marks["stat0"] = {k: ctx.stat(k) for k in STATS}
+            marks["acc0"] = tuple(int(a.sum()) for a in smp.live_counts)
             barrier()
+            if "dom" in marks:
+                gt.read()                                          # (drop the step between the two phases)
             marks["t0"] = time.perf_counter()
-        if s == nwarm + K:
+        if s == burn + K:
             ctx.check(ctx.L.rfs_synchronize(ctx.h))
             barrier()
             marks["t1"] = time.perf_counter()
-            marks["fs1"] = ctx.stat("flow_chain_steps")
-            marks["dt"] = st["dt"].clone()
-            marks["stat1"] = (ctx.stat("swd_warm_declined_chains"), ctx.stat("swd_warm_items"), ctx.stat("swd_warm_secular_evals"))
+            marks["stat1"] = {k: ctx.stat(k) for k in STATS}
+            marks["acc1"] = tuple(int(a.sum()) for a in smp.live_counts)
+            marks["dt"] = st["dt"].clone(); marks["rem"] = st["rem"].clone(); marks["x"] = st["x"].clone()
+            marks["U"] = float(st["Ucur"].median().item()); marks["fail"] = int((st["ok"] == 0).sum().item())
+            marks["misfit"] = st["Ucur"].clone()
 
-    smp.sample_flow(x_init=xs, max_steps=nwarm + K + 1, step_hook=hook)
+    smp.sample_flow(x_init=xs, max_steps=burn + K + 1, step_hook=hook)
     el = marks["t1"] - marks["t0"]
-    ms, cnt = gt.read()
-    gt.off()
-    ms_w, cnt_w = marks["warm"]
-    nw = nwarm - 1
-    ms_step = {k: ms_w[i] / nw for i, k in enumerate(gt.names)}
-    launches = {k: cnt_w[i] / nw for i, k in enumerate(gt.names)}
-    dom_id = marks["dom"]; dom = gt.names[dom_id]
-    ms_step[dom] = ms[dom_id] / K; launches[dom] = cnt[dom_id] / K
-    evals = int(marks["fs1"] - marks["fs0"])
-    rep = leg_report(cfg, config, nchain, K, el, evals, ms_step, launches, dom, ms[dom_id] / cnt[dom_id] if cnt[dom_id] else 0.0)
-    d0, i0, e0 = marks["stat0"]
-    d1, i1, e1 = marks["stat1"]
-    items = i1 - i0
+    d = {k: marks["stat1"][k] - marks["stat0"][k] for k in STATS}
+    evals = int(d["flow_chain_steps"])
+    items = max(d["swd_warm_items"], 1)
+    nacc, ntraj = marks["acc1"][0] - marks["acc0"][0], marks["acc1"][1] - marks["acc0"][1]
+    if "dom" in marks:
+        ms, cnt = gt.read()
+        gt.off()
+        ms_a, cnt_a = marks["alone"]
+        ms_step = {k: ms_a[i] / nser for i, k in enumerate(gt.names)}
+        launches = {k: cnt_a[i] / nser for i, k in enumerate(gt.names)}
+        dom_id = marks["dom"]; dom = gt.names[dom_id]
+        live_ms, live_n = ms[dom_id], cnt[dom_id]
+        rep = leg_report(cfg, config, nchain, K, el, evals, ms_step, launches, dom, live_ms / live_n if live_n else 0.0,
+                         dom_live_ms_step=live_ms / K)
+        rep["kernel_ms_note"] = (f"kernel_ms_per_step: HIP-event durations of every group in {nser} one-stream steps before the "
+                                 f"timed window (each kernel alone on the chip); roofline: '{dom}', the largest of them, by its "
+                                 "HIP events over the timed region (two streams sharing the chip)")
+    else:
+        rep = {"ms_per_step": el / K * 1e3, "value": evals / el, "unit": "evals/s", "steps": K}
     dtv = marks["dt"].cpu().numpy()
-    rep["chains_in_a_trajectory_per_step"] = evals / K
-    rep["root_search"] = {"warm_started_items_per_step": items / K, "items_per_step": nchain * NPER,
-                          "secular_evals_per_item": (e1 - e0) / max(items, 1),
-                          "chains_handed_back_to_the_full_search_per_step": (d1 - d0) / K,
-                          "handed_back_by_cause_total": {k: ctx.stat(f"swd_warm_cause_{k}") for k in range(4, 12)},
-                          "chains_walking_the_scan_grid_total": ctx.stat("swd_warm_walked_chains"),
-                          "chains_with_wide_moves_total": ctx.stat("swd_warm_wide_chains"),
-                          "warm_evaluations_total": ctx.stat("swd_warm_items") // (nchain * NPER),
-                          "adapted_dt_median": float(np.median(dtv)), "adapted_dt_max": float(dtv.max())}
-    return rep, xs, el, evals
+    rep.update({
+        "sampler": "HMCDualAveraging.sample_flow (dt0 0.1, L0 10, target_ratio 0.65)" if kind == "da" else
+                   "HamitonianMC.sample_flow (L ~ U{5..20})",
+        "dt": float(dt) if kind != "da" else None, "burn_in_steps": burn,
+        "accept_ratio": nacc / max(ntraj, 1), "trajectories_completed": ntraj,
+        "root_search_mode": mode, "chains_in_a_trajectory_per_step": evals / K,
+        "misfit_median_at_the_end": marks["U"], "root_search_failures": marks["fail"],
+        "root_search": {"warm_started_items_per_step": d["swd_warm_items"] / K, "items_per_step": nchain * NPER,
+                        "secular_evals_per_item_warm_start_and_branch_test": d["swd_warm_secular_evals"] / items,
+                        "secular_evals_per_item_reference_root_stage": d["swd_exact_secular_evals"] / items,
+                        "chains_walking_the_scan_grid_per_step": d["swd_warm_walked_chains"] / K,
+                        "chains_handed_back_to_the_full_search_per_step": d["swd_warm_declined_chains"] / K,
+                        "of_those_by_the_reference_root_stage_per_step": d["swd_exact_declined_chains"] / K}})
+    if kind == "da":
+        Lv = np.maximum(1, (10 * 0.1 / dtv).astype(int))           # L = max(1, int(lambda / dt)), lambda = L0 * dt0 (hmcda.py:307)
+        q = lambda a: [float(v) for v in np.quantile(a, [0.05, 0.5, 0.95])]
+        rep["adapted_dt_quantiles_5_50_95"] = q(dtv); rep["adapted_dt_max"] = float(dtv.max())
+        rep["L_quantiles_5_50_95"] = q(Lv)
+    return rep, xs, el, evals, marks["x"].cpu().numpy(), marks.get("misfit")
 
 
 STEP_TEXT = {
-    None: "one leapfrog step of every chain via rfs_flow_step (drift + mirror, misfit+gradient, kick)",
+    None: "one device step of HamitonianMC.sample_flow: one leapfrog step of every chain via rfs_flow_step2 (drift + mirror, "
+          "misfit+gradient, kick; accept / reject and the next trajectory's start on the device from draws the host made ahead "
+          "from every chain's MT19937 stream); value counts only chains inside a trajectory",
     "da": "one device step of HMCDualAveraging.sample_flow (accept / reject and restart on the device from draws made "
           "ahead, dual averaging on the host beside the steps); value counts only chains inside a trajectory",
 }
@@ -559,77 +644,57 @@ def run_rank(args):
     cfg = CONFIGS[args.config]
     n, nt = cfg["n"], cfg["nt"]
     nchain = args.chains
-    nwarm = max(args.warmup, 2)
-    K = args.steps
+    K, burn = args.steps, args.warmup
+    dt = args.dt if args.dt is not None else TUNED_DT
+    mode = {None: "reference_roots", 1: "reference_roots", 0: "full_search"}[args.warm_start]
+    if args.converged_roots:
+        mode = "converged_roots"
+    kind = "da" if cfg["sampler"] == "da" else "hmc"
     # --seed-rank R (single-rank jobs): run the chains rank R of a multi-rank job would run (tests)
     srank = rank if args.seed_rank is None else args.seed_rank
     joint, x_true, bounds = make_joint(cfg, local_rank)
-    if args.warm_start is not None:
-        joint.set_warm_start(args.warm_start)
     ctx = joint._ensure(n)
     extra = {}
-    if cfg["sampler"] is None:
-        rep, st, xs, el = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, K, nwarm, barrier)
-        evals_rank = nchain * K
-        misfit = st["Unew"]
-        extra["setup_steps"] = 33      # start evaluation + 32 untimed steps
-        if rank == 0 and world == 1 and not args.headline_only:
-            # ---- the reference-semantics search on every evaluation (what rounds 1 and 2 measured): the same steps with
-            # the warm start off, and the bare evaluation on a fixed x
-            joint.set_warm_start(0)
-            for _ in range(34):
-                joint.flow_step(st)                  # (the library times its CU-partition schedules on these)
-            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(K):
-                joint.flow_step(st)
-            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
-            e1 = time.perf_counter() - t1
-            extra["full_search_every_step"] = {"ms_per_step": e1 / K * 1e3, "value": nchain * K / e1, "unit": "evals/s",
-                                               "note": "rfs_set_option swd_warm_start = 0: bit-exact float32 roots of the "
-                                                       "reference's sequential search at every step"}
-            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            xfix = tt(xs)
-            for _ in range(3):
-                joint.misfit_and_grad_device(xfix)
-            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(K):
-                joint.misfit_and_grad_device(xfix)
-            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
-            extra["eval_only_ms_per_step"] = (time.perf_counter() - t1) / K * 1e3
-            joint.set_warm_start(1 if args.warm_start is None else args.warm_start)
-        if rank == 0 and not args.no_sampler_leg and not args.headline_only:
-            # beside the headline: a REAL HamitonianMC run on the same chains (continuous-flow schedule: draws from every
-            # chain's MT19937 stream, L ~ U{5..20}, accept / reject and restarts, hmc.py:228-276), K device steps timed
-            # behind 25; counts only chains inside a trajectory
-            from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
-            smp = HamitonianMC(joint, bounds, 0.002, [5, 20], 10, 991206, 100, 20, myrank=rank, name="bench", outdir=None,
-                               nchains=nchain, verbose=False, store_syn=False)
-            mk = {}
-            # (a window of >= 2 s: this is also the leg a coarse utilisation sampler can see the device busy in)
-            w2, K2 = 25, max(K, args.sustain)
-
-            def hook2(s, stt):
-                if s == w2:
-                    mk["d0"], mk["f0"] = ctx.stat("swd_warm_declined_chains"), ctx.stat("flow_chain_steps")
-                    torch.cuda.synchronize(); mk["t0"] = time.perf_counter()
-                if s == w2 + K2:
-                    ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize(); mk["t1"] = time.perf_counter()
-                    mk["d1"], mk["f1"] = ctx.stat("swd_warm_declined_chains"), ctx.stat("flow_chain_steps")
-
-            smp.sample_flow(x_init=xs, max_steps=w2 + K2 + 1, step_hook=hook2)
-            el2 = mk["t1"] - mk["t0"]
-            extra["sampler_flow"] = {
-                "value": (mk["f1"] - mk["f0"]) / el2, "unit": "evals/s", "steps": K2, "ms_per_step": el2 / K2 * 1e3,
-                "chains_in_a_trajectory_per_step": (mk["f1"] - mk["f0"]) / K2,
-                "chains_handed_back_to_the_full_search_per_step": (mk["d1"] - mk["d0"]) / K2,
-                "note": "HamitonianMC.sample_flow on the same chains (dt 0.002, L ~ U{5..20}): every chain's acceptance draw, "
-                        "next L and momentum come from its own MT19937 stream on the host, ahead of time; the device accepts / "
-                        "rejects and starts the next trajectory itself (rfs_flow_step2); books and samples are kept on the "
-                        "host beside the device steps"}
-    else:
-        rep, xs, el, evals_rank = da_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, K, nwarm, barrier)
+    rep, xs, el, evals_rank, x_end, misfit = sampler_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, K, burn,
+                                                          barrier, kind=kind, dt=dt, mode=mode)
+    if misfit is None:
         misfit = torch.zeros(nchain, dtype=torch.float64, device=dev)
+    side_legs = rank == 0 and world == 1 and kind == "hmc" and not args.headline_only
+    if side_legs:
+        # ---- the same chains, continued from where the headline left them (burned in), under other settings: short legs
+        sb, sk = min(burn, 60), min(K, 100)
+
+        def short(tag, **kw):
+            r, _, _, _, _, _ = sampler_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, sk, sb, barrier,
+                                           kind="hmc", xs=x_end, groups=False, **kw)
+            r["note"] = tag
+            return r
+
+        extra["dt_sweep"] = [short("step-size sweep: the headline's chains, burned in, continued at this step size "
+                                   "(param.yaml:40 uses 0.1)", dt=v, mode=mode) for v in DT_SWEEP]
+        if mode == "reference_roots":
+            extra["converged_roots"] = short(ROOT_MODE_TEXT["converged_roots"] + " -- misfits to ~1.4e-5, gradients to ~1e-5 "
+                                             "except on ill-conditioned chains: outside the 1e-5 contract, kept as an option",
+                                             dt=dt, mode="converged_roots")
+            extra["full_search_every_step"] = short(ROOT_MODE_TEXT["full_search"], dt=dt, mode="full_search")
+        set_root_mode(joint, n, mode)
+        # ---- rounds 1-3's headline definition, for continuity: never-ending trajectories (no accept / reject) of the random
+        # start models at dt = 0.002, the cheapest point of the step-size curve
+        r0, st0, _, _ = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, min(K, 40), 3, barrier)
+        extra["never_ending_dt0002"] = {k: r0[k] for k in ("ms_per_step", "value", "unit", "steps", "kernel_ms_per_step")}
+        extra["never_ending_dt0002"]["note"] = ("rfs_flow_step on never-ending trajectories from the random start models, dt = 0.002, "
+                                                "33 set-up steps: the definition of rounds 1-3's headline (2.57 M evals/s in round 3 "
+                                                "with converged roots; this figure: " + mode + ")")
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        xfix = tt(x_end)
+        for _ in range(3):
+            joint.misfit_and_grad_device(xfix)
+        ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            joint.misfit_and_grad_device(xfix)
+        ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+        extra["eval_only_ms_per_call"] = (time.perf_counter() - t1) / 20 * 1e3      # plugin entry: full search every call
 
     total_evals = evals_rank
     if dist is not None:
@@ -657,46 +722,53 @@ def run_rank(args):
         for ci in (4, 3):
             c2 = CONFIGS[ci]
             j2, xt2, b2 = make_joint(c2, local_rank)
-            if c2["sampler"] is None:
-                r2, _, _, _ = flow_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, max(K, 20), nwarm, barrier, setup_steps=12)
-            else:
-                r2, _, _, _ = da_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, max(K, 20), nwarm, barrier)
+            k2 = "da" if c2["sampler"] == "da" else "hmc"
+            r2, _, _, _, _, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, min(K, 100), min(burn, 150), barrier, kind=k2,
+                                            dt=dt, mode=mode)
             r2["workload"] = c2["name"]; r2["step"] = STEP_TEXT[c2["sampler"]]
             extra[f"config{ci}"] = r2
             j2._ctx.close(); j2._ctx = None
             torch.cuda.empty_cache()
 
     value = total_evals / el
-    fl = alg_flops_per_eval(n, nt)
-    flops_eval = sum(fl.values())
     res = {
         "metric": METRIC,
-        "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": burn,
         "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE_TEXT, "data": "synthetic",
         "config": {"workload": cfg["name"] if not (args.config == 1 and world * nchain == 65536) else
                    "configs[2]: 65536 chains x 30-layer joint RF+SWD, 8xMI355X independent-chain shard, RCCL gather "
                    "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
+                   "sampler": rep["sampler"], "dt": rep["dt"], "dt_note": (None if kind == "da" else
+                   f"step size {dt}: tuned for an acceptance ratio within 0.65-0.9 (SURVEY 8(d)); the reference's default 0.1 "
+                   "(param.yaml:40) gives 0.44 here -- see dt_sweep" if args.dt is None else "--dt"),
+                   "accept_ratio": rep["accept_ratio"], "L_range": [5, 20] if kind == "hmc" else None,
+                   "root_search_mode": mode, "root_search_mode_text": ROOT_MODE_TEXT[mode],
                    "step": STEP_TEXT[cfg["sampler"]],
                    "parallelism": f"independent chains x{world}" + (" -- FUNCTIONAL CHECK: all ranks share GPU 0, gloo "
                                                                     "collectives; not a measurement" if shared else ""),
                    "root_search_failures": rep.get("root_search_failures", 0)},
-        "roofline": rep["roofline"],
-        "fp64_vector": {"achieved_tflops": flops_eval * value / world / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                        "frac": flops_eval * value / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                        "alg_flops_per_eval": flops_eval,
-                        "note": "SURVEY 8(d)'s hand count of the reference's minimal algorithm (~23 secular evaluations per period "
-                                "in the root search), not a counter -- the warm-started search does ~4: see valu_issue for the "
-                                "counter view"},
-        "kernel_ms_per_step": rep["kernel_ms_per_step"], "kernel_launches_per_step": rep["kernel_launches_per_step"],
+        # scalars the driver's parser keeps
+        "dt": rep["dt"], "accept_ratio": rep["accept_ratio"], "root_search_mode": mode,
+        "roofline": rep.get("roofline"),
     }
-    for k in ("valu_issue", "root_search", "kernel_ms_note", "chains_in_a_trajectory_per_step"):
+    for k in ("kernel_ms_per_step", "kernel_launches_per_step", "valu_issue", "root_search", "kernel_ms_note",
+              "chains_in_a_trajectory_per_step", "misfit_median_at_the_end", "trajectories_completed",
+              "adapted_dt_quantiles_5_50_95", "L_quantiles_5_50_95"):
         if k in rep:
             res[k] = rep[k]
-    res.update(extra)
+    for k, v in extra.items():
+        res[k] = v
+    # the side legs' rates as top-level scalars as well
+    for k in ("converged_roots", "full_search_every_step", "never_ending_dt0002", "config3", "config4"):
+        if k in extra:
+            res[f"{k}_value"] = extra[k]["value"]
+    for r in extra.get("dt_sweep", []):
+        tag = str(r["dt"]).replace(".", "p")
+        res[f"dt_{tag}_value"] = r["value"]; res[f"dt_{tag}_accept_ratio"] = r["accept_ratio"]
     if world == 1 and not args.no_cpu_baseline and os.environ.get("RFS_BENCH_CHILD"):
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        res["_cpu_inputs"] = {"xs": xs[:max(64, ncpu)].tolist(), "dobs": joint.dobs.tolist()}
+        res["_cpu_inputs"] = {"xs": x_end[:max(64, ncpu)].tolist(), "dobs": joint.dobs.tolist()}
     print(json.dumps(res))
     sys.stdout.flush()
     if dist is not None:
@@ -706,17 +778,19 @@ def run_rank(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed device steps of the sampler")
+    ap.add_argument("--warmup", type=int, default=300, help="untimed device steps before them (the chains' burn-in)")
+    ap.add_argument("--dt", type=float, default=None, help=f"HMC step size (default {TUNED_DT}: acceptance within 0.65-0.9)")
+    ap.add_argument("--converged-roots", action="store_true", help="rfs_set_option swd_warm_exact 0 for the headline")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--chains", type=int, default=8192, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sampler-leg", action="store_true", help="skip the extra HamitonianMC.sample_flow figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU; gloo)")
     ap.add_argument("--seed-rank", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--timeout", type=float, default=1500.0, help="seconds before the launcher gives up on its ranks")
-    ap.add_argument("--sustain", type=int, default=500, help="device steps of the sampler_flow leg (a real HamitonianMC run, >= 2 s)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline leg (profiling runs)")
+    ap.add_argument("--no-sampler-leg", action="store_true", help=argparse.SUPPRESS)      # (accepted for old command lines)
+    ap.add_argument("--sustain", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] legs of the default run")
     ap.add_argument("--warm-start", type=int, default=None, choices=[0, 1], help="rfs_set_option swd_warm_start (default: library's, 1)")
     args = ap.parse_args()

@@ -297,6 +297,15 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
  *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
  *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 5, >= 2) and run-up periods (default 2) of the above.
+ *   "flow_async_handback"  rfs_flow_step / rfs_flow_step2 with the warm start on: 1 = a chain the warm start hands back to the
+ *                          reference-semantics search (a few per step on rough models: ~3 ms of dependent evaluations, during
+ *                          which every other chain would wait) sits that step out instead -- its model has drifted, it is not
+ *                          evaluated, kicked or counted (statistic flow_chain_steps); its search runs on a side stream beside
+ *                          the NEXT call, which completes the chain's step from those roots (no second drift).  Each chain
+ *                          still goes through exactly the same sequence of models, evaluations and decisions; only the
+ *                          call in which a given leapfrog step of a given chain happens moves by one.  A caller that
+ *                          counts calls (rem steps = rem calls) must look at rem / done instead.  0 (default) = every call
+ *                          completes every chain's step.  The samplers of pyhmc switch it on for sample_flow.
  *   "swd_warm_reset"       (any value) forget the previous evaluation: the next one goes through the reference-semantics
  *                          search for every chain.  A sampler calls it where a run may be cut and resumed (a checkpoint),
  *                          so that the resumed run and the uninterrupted one evaluate the same way from there on.
@@ -359,7 +368,7 @@ int rfs_get_stat(rfs_ctx* ctx, const char* name, int64_t* value);
  * duration inside a timed region enables just that one. */
 typedef enum {
     RFS_K_PREP = 0, RFS_K_RF_PASS_A, RFS_K_RF_MID, RFS_K_RF_PASS_B, RFS_K_SWD_ROOTS, RFS_K_SWD_EIGEN,
-    RFS_K_COMBINE, RFS_K_COUNT
+    RFS_K_COMBINE, RFS_K_SWD_EXACT /* the reference-root stage behind a warm start ("swd_warm_exact") */, RFS_K_COUNT
 } rfs_kernel_id;
 int rfs_enable_timing(rfs_ctx* ctx, int on);
 int rfs_kernel_ms_sum(rfs_ctx* ctx, double* ms /* [RFS_K_COUNT] */, int32_t* count /* [RFS_K_COUNT] */);

@@ -13,7 +13,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_float_p = ctypes.POINTER(ctypes.c_float)
 
 RFS_WAVE = {"Rc": 0, "Rg": 1, "Lc": 2, "Lg": 3}
-K_NAMES = ["prep", "rf_pass_a", "rf_mid", "rf_pass_b", "swd_roots", "swd_eigen", "combine"]
+K_NAMES = ["prep", "rf_pass_a", "rf_mid", "rf_pass_b", "swd_roots", "swd_eigen", "combine", "swd_exact"]
 
 
 class RfParams(ctypes.Structure):

@@ -24,6 +24,8 @@ using namespace rfs;
 #endif
 namespace {
 
+constexpr int RFS_BG_SLOTS = 8;      // sets of hand-back flags / lists (and events): background searches of that many steps may be in flight
+
 struct Buf {
     void* p = nullptr;
     size_t cap = 0;
@@ -89,6 +91,15 @@ struct rfs_ctx {
     int warm_serial = 0;       // option "swd_warm_serial": warm-started steps on ONE stream (1) or SWD beside RF (0)
     int exact_final = 0;       // option "swd_exact_final": first and last evaluation of a trajectory by the full search
     int warm_exact = 1;        // option "swd_warm_exact": behind the warm start, the reference's own refinement inside the reference's scan cell (k_swd_exact): the reference's roots
+    int flow_async = 0;        // option "flow_async_handback": in the flow entries a chain handed back to the full search sits out the step (its search runs beside the next one) instead of holding every chain
+    unsigned wpar = 0;         // slot of the hand-back lists / flags in use (RFS_BG_SLOTS sets: the searches of earlier steps still read theirs)
+    bool bg_busy[RFS_BG_SLOTS] = {};   // a background search recorded on the slot's event has not been seen complete yet
+    unsigned bg_ready = 0;     // slots whose background search was complete when the evaluation being launched started (bit mask)
+    bool flow_cur = false;     // the evaluation being launched is a flow step (rfs_flow_step2): `fpend` applies, and with flow_async its handed-back chains stay in the background
+    bool last_async = false;   // ... and did (a warm-started step with a side stream)
+    int fpend_nchain = 0;
+    Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
+    hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
     int exact_group = 5, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
@@ -721,16 +732,28 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     const float* mdlR = sphere ? c->mdlSR.as<float>() : c->mdl.as<float>();
     int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
     hipStream_t warm_side = nullptr;         // side stream carrying the full search of the chains a warm start handed back
+    bool bg_record = false;                  // this step's searches of handed-back chains stay in the background
+    if (!(warm && roots)) {
+        // whatever comes now rewrites the root buffer: every background search still under way has to be through
+        for (int i = 0; i < RFS_BG_SLOTS; i++)
+            if (c->bg_busy[i]) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_bg[i], 0)); }
+    }
     if (warm && roots) {
         // Inside a trajectory: every (period, chain) item refines the previous evaluation's root on its own (k_swd_warm);
         // the chains that cannot be continued go through the reference-semantics search right behind, on a list.
-        KTimer t(c, RFS_K_SWD_ROOTS, s);
+        KTimer* tw = new KTimer(c, RFS_K_SWD_ROOTS, s);      // (closed in front of the reference-root stage, which is a group of its own)
+        struct TwGuard { KTimer*& t; ~TwGuard() { delete t; t = nullptr; } } tw_guard{tw};
+        // (two sets of flags / lists, alternating: a background search of the step before may still be reading the other one)
+        int* wn = c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4);
+        const size_t lo = (size_t)c->wpar * nchain;
         SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
-                  c->wneed.as<int>(), c->wneed.as<int>() + nchain, c->wlist.as<int>(), c->wstats.as<unsigned long long>(),
-                  c->wsgn.as<unsigned char>(), c->wneed.as<int>() + nchain + 1, c->wneed.as<int>() + 2 * nchain + 1,
-                  c->wilist.as<int>(), c->wneed.as<int>() + 2 * nchain + 2, c->wlist2.as<int>(), c->wneed.as<int>() + 2 * nchain + 3,
+                  wn, wn + nchain, c->wlist.as<int>() + lo, c->wstats.as<unsigned long long>(),
+                  c->wsgn.as<unsigned char>(), wn + nchain + 1, wn + 2 * nchain + 1,
+                  c->wilist.as<int>(), wn + 2 * nchain + 2, c->wlist2.as<int>() + lo, wn + 2 * nchain + 3,
                   c->wslope.as<double>(), c->wbetmx.as<float>(), c->warm_exact ? c->cwarm.as<double>() : (double*)nullptr,
-                  c->wneed.as<int>() + 3 * nchain + 3, c->wlist3.as<int>()};
+                  wn + 3 * nchain + 3, c->wlist3.as<int>() + lo,
+                  (c->flow_cur && c->fpend.p && c->fpend.cap >= (size_t)nchain * sizeof(int)) ? c->fpend.as<int>() : (const int*)nullptr};
+        (void)0;
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
@@ -751,7 +774,18 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // the branch test declines behind it -- beside the eigenfunction pass of all chains; only the listed chains'
         // eigenfunctions are redone afterwards (below).
         hipStream_t sf = (kernels && c->stream_l && s != c->stream_l) ? c->stream_l : s;
+        const bool async = c->flow_cur && c->flow_async && kernels && sf != s;
+        if (async) {
+            // background form: ONE list for the three kinds of hand-back and ONE search behind the reference-root stage.  (On the
+            // same side stream as the foreground form: more streams than hardware queues -- four by default -- would put the
+            // search into the queue of the main or the surface-wave stream and serialise it with the step after all: measured.)
+            W.list2 = W.list3 = W.list; W.count2 = W.count3 = W.count;
+        }
         warm_side = sf != s ? sf : nullptr;
+        // flow entries with "flow_async_handback": the handed-back chains sit this step out (k_flow_post) and their search
+        // runs on the side stream beside the NEXT step, whose eigenfunction pass waits for it; nobody waits here
+        bg_record = async;
+        c->last_async = bg_record;
         // the first list's length of an earlier step, whenever its copy has arrived (never waited for)
         const int est = std::max(c->warm_est, 64);
         auto launch_fallback = [&](const int* list, const int* count, int estc) -> int {
@@ -790,9 +824,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             HIPCHK(c, hipGetLastError());
             return RFS_OK;
         };
-        if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[0], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[0], 0)); }
-        if (sf != s) TRY(launch_fallback(W.list, W.count, est));      // (one stream only: both lists after the branch test)
-        if (c->h_wcount && sf != s) {
+        if (sf != s && !async) { HIPCHK(c, hipEventRecord(c->ev_w[0], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[0], 0)); }
+        if (sf != s && !async) TRY(launch_fallback(W.list, W.count, est));      // (one stream only: both lists after the branch test)
+        if (c->h_wcount && sf != s && !async) {
             if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
             HIPCHK(c, hipMemcpyAsync(c->h_wcount, W.count, sizeof(int), hipMemcpyDeviceToHost, sf));
         }
@@ -824,10 +858,13 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         }
         HIPCHK(c, hipGetLastError());
         // the chains the branch test handed back (and, on one stream, those of the first list)
-        if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[1], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[1], 0)); }
+        if (async) {}
+        else if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[1], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[1], 0)); }
         else TRY(launch_fallback(W.list, W.count, est));
-        TRY(launch_fallback(W.list2, W.count2, 64));
+        if (!async) TRY(launch_fallback(W.list2, W.count2, 64));
+        delete tw; tw = nullptr;
         if (c->warm_exact) {
+            KTimer tx(c, RFS_K_SWD_EXACT, s);
             // ... and from the continued roots to the reference's own: its refinement (nevill) inside its scan cell, groups of
             // periods per lane (k_swd_exact); what a lane declines goes to the full search like the branch test's chains
             const int G = std::max(2, c->exact_group), ru = std::max(0, c->exact_runup);
@@ -844,7 +881,15 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             }
             HIPCHK(c, hipGetLastError());
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
-            TRY(launch_fallback(W.list3, W.count3, 64));
+            if (!async) TRY(launch_fallback(W.list3, W.count3, 64));
+        }
+        if (async) {
+            if (!c->warm_exact) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
+            TRY(launch_fallback(W.list, W.count, est));
+            if (c->h_wcount) {
+                if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
+                HIPCHK(c, hipMemcpyAsync(c->h_wcount, W.count, sizeof(int), hipMemcpyDeviceToHost, sf));
+            }
         }
         roots = false;
     }
@@ -958,13 +1003,20 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
 #undef RFS_LAUNCH_EIGEN2
         HIPCHK(c, hipGetLastError());
         }
+        if (bg_record) {
+            HIPCHK(c, hipEventRecord(c->ev_bg[c->wpar], warm_side));
+            c->bg_busy[c->wpar] = true;
+            warm_side = nullptr;
+        }
         if (warm_side) {
             // behind the full search of the handed-back chains: their eigenfunctions again, from their new roots (the pass
             // above has read whatever roots they had; it must have finished before these results are written)
             HIPCHK(c, hipEventRecord(c->ev_w[2], s));
             HIPCHK(c, hipStreamWaitEvent(warm_side, c->ev_w[2], 0));
-            const int* lists[3] = {c->wlist.as<int>(), c->wlist2.as<int>(), c->wlist3.as<int>()};
-            const int* counts[3] = {c->wneed.as<int>() + nchain, c->wneed.as<int>() + 2 * nchain + 2, c->wneed.as<int>() + 3 * nchain + 3};
+            const int* wn = c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4);
+            const size_t lo = (size_t)c->wpar * nchain;
+            const int* lists[3] = {c->wlist.as<int>() + lo, c->wlist2.as<int>() + lo, c->wlist3.as<int>() + lo};
+            const int* counts[3] = {wn + nchain, wn + 2 * nchain + 2, wn + 3 * nchain + 3};
 #define RFS_LAUNCH_EIGEN_LIST(LOVE, SPH, QQ, SPHP, SFL, LI)                                                          \
             hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH, true>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
                                dim3(64), 0, warm_side, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(), \
@@ -1018,18 +1070,28 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     struct ModeGuard { rfs_ctx* c; ~ModeGuard() { c->swd_mode_cur = 0; } } mode_guard{c};
     c->swd_mode_cur = c->swd_mode;
     const bool warm = track && c->warm_primed && c->warm_nchain == nchain && traj != 2;
+    c->last_async = false;
     if (track) {
         const size_t nn = (size_t)n * nchain;
         if (c->warm_nchain != nchain) c->warm_primed = false;
+        // next set of hand-back flags / lists; which background searches are through by now (never waited for, except the one
+        // whose set is needed again: RFS_BG_SLOTS steps old)
+        c->wpar = (c->wpar + 1) % RFS_BG_SLOTS;
+        if (c->bg_busy[c->wpar]) { HIPCHK(c, hipEventSynchronize(c->ev_bg[c->wpar])); c->bg_busy[c->wpar] = false; }
+        c->bg_ready = 0;
+        for (int i = 0; i < RFS_BG_SLOTS; i++) {
+            if (c->bg_busy[i] && hipEventQuery(c->ev_bg[i]) == hipSuccess) c->bg_busy[i] = false;
+            if (!c->bg_busy[i]) c->bg_ready |= 1u << i;
+        }
         ENSURE(c, c->xw, 2 * nn * sizeof(double)); ENSURE(c, c->dxT, 2 * nn * sizeof(double));
         ENSURE(c, c->crT, 2 * nn * sizeof(double));
         const size_t before = c->wvalid.cap;
-        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, (3 * (size_t)nchain + 4) * sizeof(int));
-        ENSURE(c, c->wlist3, (size_t)nchain * sizeof(int));
+        ENSURE(c, c->wvalid, (size_t)nchain * sizeof(int)); ENSURE(c, c->wneed, RFS_BG_SLOTS * (3 * (size_t)nchain + 4) * sizeof(int));
+        ENSURE(c, c->wlist3, RFS_BG_SLOTS * (size_t)nchain * sizeof(int));
         ENSURE(c, c->cwarm, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
-        ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, (size_t)nchain * sizeof(int));
+        ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, RFS_BG_SLOTS * (size_t)nchain * sizeof(int));
         for (auto& e : c->ev_w) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ENSURE(c, c->wlist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
+        ENSURE(c, c->wlist, RFS_BG_SLOTS * (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
         ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         ENSURE(c, c->wslope, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
@@ -1190,7 +1252,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            (int)c->has_rf, c->f.p, c->lc.as<RfLayer>(), c->cr.as<double>(), (int)c->has_swd,
                            c->mdl.as<float>(), c->mdlc.as<double>(),
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
-                           early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() : (int*)nullptr),
+                           early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4) : (int*)nullptr),
                            early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 4 : (size_t)0),
                            track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>(),
                            fpre ? *fpre : FlowPre{});      // (flow entries: the step's drift rides in this kernel)
@@ -1319,11 +1381,13 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream_l, hipStreamNonBlocking) == hipSuccess &&
+
               hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_lj, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < RFS_BG_SLOTS; i++) ok = hipEventCreateWithFlags(&c->ev_bg[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
     c->own_stream = true;
     hipDeviceProp_t prop;
@@ -1344,11 +1408,12 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
+    for (auto e : c->ev_bg) if (e) hipEventDestroy(e);
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -1477,6 +1542,14 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_exact_runup")) {
         if (value < 0 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_runup must be within [0, 64]");
         c->exact_runup = value; return RFS_OK;
+    }
+    if (!strcmp(name, "flow_async_handback")) {
+        if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "flow_async_handback must be 0 or 1");
+        HIPCHK(c, hipSetDevice(c->device));
+        TRY(rfs_synchronize(c));
+        c->flow_async = value; for (auto& b : c->bg_busy) b = false;
+        if (c->fpend.p) HIPCHK(c, hipMemset(c->fpend.p, 0, c->fpend.cap));
+        return RFS_OK;
     }
     if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
@@ -1964,10 +2037,21 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
     int* wforce = nullptr;
     if (c->exact_final && c->has_swd && c->warm_opt) { ENSURE(c, c->wforce, (size_t)nchain * sizeof(int)); wforce = c->wforce.as<int>(); }
-    const FlowPre fpre{minv, dt, rem, fresh, ok, bounds, x, p, fn.gsave, fn.kick, wforce};
+    // chains a step hands back to the full search may sit that step out ("flow_async_handback"): who did is kept here
+    const size_t pend_before = c->fpend.cap;
+    ENSURE(c, c->fpend, (size_t)nchain * sizeof(int));
+    if (c->fpend.cap != pend_before || c->fpend_nchain != nchain) {
+        HIPCHK(c, hipMemsetAsync(c->fpend.p, 0, c->fpend.cap, c->stream));
+        c->fpend_nchain = nchain;
+    }
+    const FlowPre fpre{minv, dt, rem, fresh, ok, bounds, x, p, fn.gsave, fn.kick, wforce, c->fpend.as<int>()};
     (void)nth;
     RfReduce rr{};
-    TRY(joint_eval(c, nchain, x, U, g, d, fl, 1, &fpre, &rr));      // (drift with mirror reflection inside k_prep_joint; RF reduction left to k_flow_post)
+    c->flow_cur = true;
+    const int rc_eval = joint_eval(c, nchain, x, U, g, d, fl, 1, &fpre, &rr);      // (drift with mirror reflection inside k_prep_joint; RF reduction left to k_flow_post)
+    c->flow_cur = false;
+    TRY(rc_eval);
+    const int* need_cur = c->last_async ? c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4) : (const int*)nullptr;
     if (next && c->has_swd && c->warm_opt && c->warm_primed && c->warm_nchain == nchain && c->xw.p) {
         // the start roots of every running trajectory, restored with the start model when it is rejected (k_flow_post)
         const int nitems = (int)(c->croot.cap / sizeof(double) / (size_t)nchain);
@@ -1982,7 +2066,8 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
         HIPCHK(c, hipMemsetAsync(c->fstat.p, 0, 64 * sizeof(unsigned long long), c->stream));
     }
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
-                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>(), rr);
+                       Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>(), rr,
+                       need_cur, c->fpend.as<int>(), (int)c->wpar + 1, c->bg_ready);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }

@@ -140,11 +140,13 @@ __device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int 
 struct FlowPre {
     const double* minv; const double* dt; const int* rem; const int* fresh; const int* ok; const double* bounds;
     double* x; double* p; const double* gsave; const int* kick; int* wforce;
+    const int* pend;        // [chain] 1: handed back to the full search in the step before and left out of it (rfs_set_option flow_async_handback): its drift has been made
 };
 __device__ __forceinline__ void flow_drift(const FlowPre& F, int chain, int i, int nx) {
     // option swd_exact_final: start and end models of a trajectory by the reference-semantics search (k_swd_warm's force)
     if (F.wforce && i == 0) F.wforce[chain] = F.fresh[chain] || F.rem[chain] == 1;
     if (F.fresh[chain] || F.rem[chain] <= 0 || !F.ok[chain]) return;
+    if (F.pend && F.pend[chain]) return;                       // this chain's evaluation of an earlier step is only completed now (or still waits for its search)
     const size_t g = (size_t)chain * nx + i;
     double pv = F.p[g];
     if (F.kick && F.kick[chain]) pv = pv - F.dt[chain] * F.gsave[g] * 0.5;      // the half kick a deferred start left open (hmc.py:164)
@@ -931,6 +933,7 @@ struct SwdWarm {
     float* betmx;           // [2][chain] fastest S velocity of the Rayleigh / Love search model (k_swd_warm -> k_swd_warm_check)
     double* cwarm;          // [item][chain] the warm-started roots as k_swd_warm left them (k_swd_exact reads them while it overwrites croot), or nullptr
     int* count3; int* list3;             // chains handed back by k_swd_exact
+    const int* pend;        // [chain] 1: the chain was handed back in the step before and its search ran in the background: croot holds its roots for THIS model
 };
 
 template <class F, bool SPH>
@@ -939,8 +942,9 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
            const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot, double* __restrict__ croot, SwdWarm W)
 {
     const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (g >= (size_t)Q.nper_total * nchain) return;
-    const int el = (int)(g / nchain), chain = (int)(g - (size_t)el * nchain);
+    // (no lane leaves before the wavefront's statistics at the end: `live` instead of early returns)
+    bool live = g < (size_t)Q.nper_total * nchain;
+    const int el = live ? (int)(g / nchain) : 0, chain = live ? (int)(g - (size_t)el * nchain) : 0;
     const int e = Q.s[0].croot_off + el;
     int seq = 0;
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
@@ -955,8 +959,11 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
             atomicAdd(&W.stats[cause], 1ull);
         }
     };
-    W.sgn[(size_t)e * nchain + chain] = 2;
-    if (!W.valid[chain] || (W.force && W.force[chain])) { decline(4); return; }
+    // a chain whose search of the step before ran in the background: nothing to do here, and nothing for the branch test
+    // or the reference-root stage either (they skip chains with a flag)
+    if (live && W.pend && W.pend[chain]) { W.need[chain] = 2; live = false; }
+    if (live) W.sgn[(size_t)e * nchain + chain] = 2;
+    if (live && (!W.valid[chain] || (W.force && W.force[chain]))) { decline(4); live = false; }
     // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
     // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
     // vtp / dtp / rtp as swd_kernel_value does
@@ -979,7 +986,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);
     }
     const double cprev = croot[(size_t)e * nchain + chain];
-    if (k == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
+    if (live && k == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
     const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
     const double* lc0 = mdlc + chain;
     auto loadL = [&](int m) {
@@ -990,19 +997,21 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     WarmSearch ws;
     ws.begin(cprev, dc, l1, W.slope[(size_t)e * nchain + chain]);
     if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
-    if (l1 > WARM_L1MAX && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
+    if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
+    if (live && l1 > WARM_L1MAX && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
     const bool refused = !ws.active();
     while (__any(ws.active())) {
         if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
     }
-    const bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
-    if (ok) {
+    const bool ok = live && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
+    if (!live) {}
+    else if (ok) {
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
         if (W.cwarm) W.cwarm[(size_t)e * nchain + chain] = (double)(float)ws.root;
         W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
     } else decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
-    W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
-    int nev = ws.nev, nok = ok ? 1 : 0;
+    if (live) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
+    int nev = live ? ws.nev : 0, nok = ok ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&W.stats[1], (unsigned long long)nev); atomicAdd(&W.stats[2], (unsigned long long)nok); }
@@ -1082,12 +1091,12 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
 // :433-479: direction from the sign at the start point against the sign below every root (del1st: the first evaluation
 // of the sequence's first period), steps of dc, abort below the start value or above the fastest layer.  The first cell
 // with a sign change must hold the continued root; otherwise the chain goes to the full search.
-template <class F, bool FIRST>      // FIRST: the first period of every sequence (a scan of ~100 cells from the start value): 64 lanes
-__global__ void __launch_bounds__(64)   // per item; otherwise the later periods (~10 cells): 16 lanes per item, four items per wavefront
+template <class F, bool FIRST>      // FIRST: the first period of every sequence (a scan of 100-700 cells from the start value): 64 lanes
+__global__ void __launch_bounds__(64)   // per item; otherwise the later periods (~2-8 cells): 8 lanes per item, eight items per wavefront
 k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc,
                 const double* __restrict__ croot, SwdWarm W)
 {
-    constexpr int LPI = FIRST ? 64 : 16, IPW = 64 / LPI;
+    constexpr int LPI = FIRST ? 64 : 8, IPW = 64 / LPI;      // (a later period's scan is ~2-8 cells long: 8 lanes per item, a second round where needed)
     const int lane = threadIdx.x & 63, sub = lane / LPI, li = lane % LPI;
     const int nsel = *W.icount;
     if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&W.stats[12], (unsigned long long)nsel);     // chains whose sequences walk the grid
@@ -1139,7 +1148,9 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         const int idir = (k == 0 || signbit(fsk) == signbit(f1st)) ? +1 : -1;
         int sprev = signbit(fsk) ? 1 : 0;                 // sign at the last point of the round before
         int nev = (walking && li < 2) ? 1 : 0;
-        constexpr int MAXR = 400 / LPI;
+        // (a first period's scan starts at the model's start value -- 0.77 x the Rayleigh velocity of the SLOWEST layer -- and may
+        // have 2.5 km/s to go on models with one slow layer: 1024 cells; later periods start 1.5 cells below the root before)
+        constexpr int MAXR = (FIRST ? 1024 : 400) / LPI;
         for (int round = 0; round < MAXR && __any(walking); round++) {
             const double c = sk + (double)idir * (double)(round * LPI + li + 1) * dcs;
             double f = 0.0;
@@ -1946,7 +1957,8 @@ struct FlowNext {
 __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, double* U,
                             double* grad, double* dsyn, int* flag, double* p, int* rem, int* fresh,
                             double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
-                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount, RfReduce rr)
+                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount, RfReduce rr,
+                            const int* need_cur, int* pend, int slot1, unsigned ready)
 {
     __shared__ double red[4];
     __shared__ int bad;
@@ -1954,7 +1966,17 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
     const int chain = blockIdx.x, tid = threadIdx.x;
     const int fr = fresh[chain], rm = rem[chain];
     if (tid == 0) done[chain] = 0;
-    if (!fr && (rm <= 0 || !ok[chain])) return;                // idle chain (block-uniform)
+    const bool idle = !fr && (rm <= 0 || !ok[chain]);
+    // A chain this step handed back to the full search (rfs_set_option flow_async_handback): its search runs in the
+    // background, beside the next step; here it is left exactly as it is -- drifted, not evaluated, not kicked -- and the
+    // next call completes the step from the search's roots (no drift, no warm start: `pend`).
+    // pend[chain] = 1 + the slot of flags / lists its search was recorded under (0: none); `ready`: the slots whose searches
+    // were complete when this call started -- a chain whose search is still running sits this call out as well.
+    const int pd = pend ? pend[chain] : 0;
+    const bool waiting = pd > 0 && !((ready >> (pd - 1)) & 1u);
+    const bool handed = !idle && !waiting && need_cur && need_cur[chain] == 1;
+    if (tid == 0 && pend) pend[chain] = handed ? slot1 : (waiting ? pd : 0);
+    if (idle || handed || waiting) return;                      // (block-uniform)
     if (tid == 0 && fcount) atomicAdd(&fcount[chain & 63], 1ull);   // statistic "flow_chain_steps" (64 slots: 8192 atomics on ONE address cost 70 us)
     if (rr.PG) rf_reduce_chain(rr, chain, U, grad, flag, dsyn, ndata);
     if (tid == 0) bad = 0;

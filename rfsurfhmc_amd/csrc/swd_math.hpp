@@ -885,6 +885,8 @@ struct WarmSearch {
 // clamp of getsol (:463-467), a root the reference rejects (:483-485) -- and the caller hands the chain to the
 // reference-semantics search.
 // ---------------------------------------------------------------------------
+constexpr double EXACT_ORIGIN_ERR = 4.0e-7;    // ... which leaves the first run-up origin within this of the reference's (relative)
+constexpr double EXACT_ORIGIN_TOL = 3.0e-9;    // origin accuracy a wanted period needs (see ExactGroupT::step_nevill): two run-up periods of a smooth secular function leave ~1e-11, roots found by bisections alone leave the 4e-7
 constexpr double EXACT_OFFSET = 0.75e-6;     // the reference's root lies 0.5 .. 1.0e-6 c below the sign change: the run-up's first origin is moved by the mean
 
 // nevill (surfdisp96.f:568-687) inside a bracket, as a request machine of its own -- the same decisions and the same
@@ -911,6 +913,12 @@ struct CellNevillT {
     int phase, nev, m, nctrl, nsupplied;
     bool ex1, ex2, lin;
     float betmx;
+    // How an error of the cell's position (the scan's origin: the root of the period before) reaches the points: the cell's
+    // edges move with it one to one, a midpoint by the mean of its two ends, an interpolated point hardly at all (the root
+    // of a smooth function does not care where it is interpolated from).  g3 at the end = the factor by which the returned
+    // root inherits the origin's error: ~2^-j after j closing bisections towards an interpolated end (1e-3 typically), 1 for
+    // a root found by bisections alone (a step-like function: crowded spectra).
+    float g1, g2, g3;
 
     RFS_HD bool active() const { return phase < N_DONE; }
 
@@ -918,6 +926,7 @@ struct CellNevillT {
     RFS_HD void enter(double c1_, double del1_, double c2_, double del2_, float bmx) {
         c1 = c1_; del1 = del1_; c2 = c2_; del2 = del2_; betmx = bmx;
         ex1 = ex2 = true; lin = false; nev = 1; m = 1; nctrl = 1; nsupplied = 0; result = 0.0;
+        g1 = g2 = 1.0f; g3 = 1.0f;
         c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF0;                 // nevill :583-589 (half)
     }
 
@@ -953,9 +962,9 @@ struct CellNevillT {
                     else { xn = (-yj * xn + ym1 * tab.gx(j)) / denom; tab.sx(j, xn); }
                 }
             }
-            if (!half) { c3 = xn; creq = c3; phase = N_NEV; return; }
+            if (!half) { c3 = xn; creq = c3; phase = N_NEV; return; }      // (g3: once its value is known, step())
         }
-        c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF_B;
+        c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF_B; g3 = 0.5f * (g1 + g2);
     }
 
     // one pass of nevill's loop with the TRUE value del3 of f(c3)
@@ -968,15 +977,22 @@ struct CellNevillT {
         if (looptop) {
             if (nctrl >= 100) { finish(); return; }                                  // :595
             if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {                             // :597-607
-                nev = 0; c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF_OUT; return;
+                nev = 0; c3 = 0.5 * (c1 + c2); creq = c3; phase = N_HALF_OUT; g3 = 0.5f * (g1 + g2); return;
             }
         }
-        // the linearity of the function across the bracket, seen by the first interpolated point: its value would be zero
-        if (LAZY && ph == N_NEV && nctrl == 3) lin = fabs(del3) <= LAZY_LIN * fmax(fabs(del1), fabs(del2));
+        if (ph == N_NEV) {
+            // the residual of an interpolated point against the ends it was built from: the nonlinearity of the function
+            // across the bracket (it would be zero).  The first one decides about supplied values (LAZY); every one says how
+            // far the point follows the ends when they move (g3): not at all where the function is linear, like a mean of
+            // the two where it is a step (both ends saturated: crowded spectra)
+            const double q = fabs(del3) / fmax(fmax(fabs(del1), fabs(del2)), 1.0e-300);
+            if (LAZY && nctrl == 3) lin = q <= LAZY_LIN;
+            g3 = fminf(1.0f, 4.0f * (float)q) * fmaxf(g1, g2);
+        }
         const double s13 = del1 - del3, s32 = del3 - del2;
         const bool opp = diffsign(del3, del1);                                        // :608-617
-        c2 = opp ? c3 : c2; del2 = opp ? del3 : del2; ex2 = opp ? true : ex2;
-        c1 = opp ? c1 : c3; del1 = opp ? del1 : del3; ex1 = opp ? ex1 : true;
+        c2 = opp ? c3 : c2; del2 = opp ? del3 : del2; ex2 = opp ? true : ex2; g2 = opp ? g3 : g2;
+        c1 = opp ? c1 : c3; del1 = opp ? del1 : del3; ex1 = opp ? ex1 : true; g1 = opp ? g1 : g3;
         if (fabs(c1 - c2) <= 1.0e-6 * c1) { finish(); return; }                      // :627
         if (diffsign(s13, s32)) nev = 0;
         del3v = del3;
@@ -1001,10 +1017,10 @@ struct CellNevillT {
         nev = 1; m = 1; nctrl++;
         if (nctrl >= 100) { finish(); return; }
         const bool near1 = fabs(del1) < fabs(del2);
-        c2 = near1 ? c3 : c2; del2 = near1 ? v : del2; ex2 = near1 ? false : ex2;
-        c1 = near1 ? c1 : c3; del1 = near1 ? del1 : v; ex1 = near1 ? ex1 : false;
+        c2 = near1 ? c3 : c2; del2 = near1 ? v : del2; ex2 = near1 ? false : ex2; g2 = near1 ? g3 : g2;
+        c1 = near1 ? c1 : c3; del1 = near1 ? del1 : v; ex1 = near1 ? ex1 : false; g1 = near1 ? g1 : g3;
         if (fabs(c1 - c2) <= 1.0e-6 * c1) { finish(); return; }
-        c3 = 0.5 * (c1 + c2); creq = c3;                                  // (phase stays N_HALF_B)
+        c3 = 0.5 * (c1 + c2); creq = c3; g3 = 0.5f * (g1 + g2);            // (phase stays N_HALF_B)
     }
 
     // consume the TRUE value f of f(creq); afterwards a new request is pending or the machine is done / has failed
@@ -1027,6 +1043,7 @@ struct ExactGroupT {
     double o, rhat, c1, c2, del1, del2s, cprev, cc, dcs;
     int k, k0, k1, phase, dir, msteps, shifted, nev, cause, nsupplied;
     float betmx;
+    float oerr;                              // relative error of the current origin, as far as the factors g3 of the periods so far tell
 
     RFS_HD bool active() const { return phase < X_DONE; }
 
@@ -1046,6 +1063,7 @@ struct ExactGroupT {
                       double* tab, int tabstride) {
         k = kr; k0 = k0_; k1 = k1_; cc = cstart; betmx = bmx; dcs = (double)0.005f;
         cprev = origin0; nev = 0; cause = 0; nsupplied = 0;
+        oerr = kr > 0 ? (float)EXACT_ORIGIN_ERR : 0.0f;                  // (a sequence's first period starts at the model's start value: exact)
         nv.tab.base = tab; nv.tab.stride = tabstride;
         start_period(approx, om);
     }
@@ -1079,7 +1097,14 @@ struct ExactGroupT {
     RFS_HD void step_nevill(double f) {
         nv.advance(f);
         if (nv.phase == CellNevillT<LAZY>::N_FAIL) { phase = X_FAIL; cause = 5; return; }   // the reference rejects the root (above the fastest layer)
-        if (nv.phase == CellNevillT<LAZY>::N_DONE) { cprev = nv.result; nsupplied += nv.nsupplied; phase = X_DONE; return; }
+        if (nv.phase == CellNevillT<LAZY>::N_DONE) {
+            // a period whose result is wanted must start from an origin that is the reference's to 3e-9 or better (its root then is
+            // the reference's float32 value but for rare cases); a run-up that did not get there -- roots found by
+            // bisections alone pass the origin's error on undiminished -- is the full search's business
+            if (k >= k0 && oerr > (float)EXACT_ORIGIN_TOL) { phase = X_FAIL; cause = 7; return; }
+            oerr *= nv.g3;
+            cprev = nv.result; nsupplied += nv.nsupplied; phase = X_DONE; return;
+        }
         creq = nv.creq;
     }
 

@@ -422,7 +422,7 @@ def with_host_threads(fn):
 
 
 def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max_steps=None, step_hook=None,
-             restart=None):
+             restart=None, async_handback=True):
     """Drive model.flow_step (rfs_flow_step) until ``active()`` is False.
 
     After every step the chains that finished a trajectory are handed to ``process_done(idx, res)`` (host side:
@@ -442,12 +442,22 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max
     device accepted / rejected and restarted; ``res`` holds Ucur, Hcur, Hnew, Unew, x [, dsyn_new] of the completed
     trajectory) and ``withdraw(idx)`` (chains that failed with a deposit outstanding: rewind their streams, they come
     through ``process_done`` next).  Such chains evaluate their new start model in the very next step instead of sitting
-    one out; the sequence of draws and decisions per chain is unchanged."""
+    one out; the sequence of draws and decisions per chain is unchanged.
+    async_handback: rfs_set_option "flow_async_handback" for the run -- a chain whose root search is handed back to the
+    reference-semantics search sits that device step out (the search runs beside the next step) instead of making every
+    chain wait for it; the chain's own sequence of models and decisions is unchanged."""
     import torch
     dev = st["x"].device
     # (events and side streams below belong to the state's device, whichever device is current in the caller)
-    with host_threads(), (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
-        return _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook, restart)
+    ctx = getattr(model, "_ctx", None)
+    if ctx is not None and dev.type == "cuda":
+        ctx.set_option("flow_async_handback", int(bool(async_handback) and os.environ.get("RFS_FLOW_ASYNC", "1") != "0"))
+    try:
+        with host_threads(), (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
+            return _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook, restart)
+    finally:
+        if ctx is not None and dev.type == "cuda":
+            ctx.set_option("flow_async_handback", 0)          # (direct callers of flow_step count on one step per call)
 
 
 def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, step_hook, restart):

@@ -135,6 +135,7 @@ class HamitonianMC:
         misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
         syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
         i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        self.live_counts = (i, ncount)          # accepted / completed trajectories per chain, as the books stand (step hooks read them)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         st = self.model.flow_state(t(x), torch.full((nc,), float(self.dt), dtype=torch.float64, device=dev),
                                    t(self.boundaries))

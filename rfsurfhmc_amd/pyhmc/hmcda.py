@@ -293,6 +293,7 @@ class HMCDualAveraging:
         dtbar = dt * 1.0
         h0 = np.full(nc, self._h0)
         i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        self.live_counts = (i, ncount)          # accepted / completed trajectories per chain, as the books stand (step hooks read them)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
         allc = list(range(nc))

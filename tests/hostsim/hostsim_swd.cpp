@@ -298,7 +298,7 @@ extern "C" int hs_warm_roots(int n, const float* thk, const float* vp, const flo
         double c1 = sk;
         for (int steps = 0;; steps++) {
             double c2 = idir > 0 ? c1 + dcs : c1 - dcs;
-            if (c2 <= cc || steps > 400) { status[k] = 2; break; }
+            if (c2 <= cc || steps > (k == 0 ? 1024 : 400)) { status[k] = 2; break; }
             const double f2 = sec(omega, c2);
             nev[k]++;
             if (diffsign(f, f2)) { if (!(fmin(c1, c2) < ck && ck < fmax(c1, c2))) status[k] = 2; break; }

@@ -191,7 +191,7 @@ def test_option_zero_is_the_history_free_search_and_failing_models_keep_their_fl
     lo, hi = tt(bounds[:, 0]), tt(bounds[:, 1])
     jw, _ = _bench_joint(2); je, _ = _bench_joint(0)
     x = tt(xs); p = tt(0.5 * rng.standard_normal(xs.shape))
-    nfail = 0
+    nfail = nroot = nsame = 0
     for s in range(8):
         mw, gw, dw, fw = jw.misfit_and_grad_device(x)
         me, ge, de, fe = je.misfit_and_grad_device(x)
@@ -201,8 +201,17 @@ def test_option_zero_is_the_history_free_search_and_failing_models_keep_their_fl
         assert torch.equal(mw[bad], me[bad]) and torch.equal(gw[bad], ge[bad]) and torch.equal(dw[bad], de[bad])
         ok = ~bad
         r = ((dw[ok][:, nt:] - de[ok][:, nt:]).abs() / de[ok][:, nt:]).max().item()
-        assert r <= 1.2e-6, (s, r)
+        # (the reference-root stage: identical roots but for a flipped decision of nevill now and then -- both values are
+        # then ends of a 1e-6 c bracket around the same sign change: 2e-6 c apart at most)
+        assert r <= 2.2e-6, (s, r)
+        nroot += int(ok.sum()) * 40; nsame += int((dw[ok][:, nt:] == de[ok][:, nt:]).sum())
         x, p = _leapfrog_move(x, p, torch.where(bad[:, None], torch.zeros_like(gw), gw), 0.002, lo, hi)
+    # (unsorted models have crowded spectra: the secular function -- normalised to a largest vector component of 1 -- is a step
+    # at the root and saturated elsewhere, and nevill's decisions there (is the midpoint's value between the ends'?  :630-634)
+    # compare numbers that differ in their last bits: the reference's own root depends on the rounding of its arithmetic.  A
+    # sequential search and a period-parallel one, or two builds of the reference, part ways on ~1 % of such roots)
+    print(f"unsorted third of the chains: {nsame} of {nroot} roots identical to the history-free search")
+    assert nsame >= 0.995 * nroot, (nsame, nroot)
     # models the reference's search FAILS on (tests/golden/swd_reference.npz "inverted_20": ierr = 1 in the compiled
     # reference) beside models it solves, moving together: same flags and failure returns at every step, and the failing
     # chains never poison their neighbours
