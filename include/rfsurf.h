@@ -173,6 +173,10 @@ int rfs_leapfrog_dev2(rfs_ctx* ctx, int nchain, const double* x0, const double* 
  * never wait for the longest one.  All arrays DEVICE, persistent between calls and owned by the caller:
  *   x, p [nchain][2n]; dt [nchain]; rem [nchain] leapfrog steps still to do (-1 = idle);
  *   fresh [nchain] = 1: the trajectory starts with this call (x = start model, p = drawn momentum, rem = L, ok = 1).
+ * One context advances one such state at a time: the warm start of the root search (roots, kernels and model of the
+ * previous evaluation) belongs to the state whose x array the previous call was given -- a call with another x array
+ * starts over from the reference-semantics search (correct, but nothing is continued), and with "flow_async_handback" on
+ * it is refused while searches of the other state are outstanding.  Two states that advance in turn want two contexts.
  * One call = ONE misfit+gradient evaluation of every chain: a fresh chain gets Ucur, Hcur, dsyn_cur and the first half
  * kick (pyhmc/hmc.py:150-164); a running chain drifts (with mirror reflection), is evaluated and kicked, rem--; when
  * rem reaches 0 its Unew, Hnew, dsyn_new are final, x holds the end model and done[chain] = 1.  ok[chain] = 0 (and

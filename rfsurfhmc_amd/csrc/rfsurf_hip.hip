@@ -98,6 +98,7 @@ struct rfs_ctx {
     bool flow_cur = false;     // the evaluation being launched is a flow step (rfs_flow_step2): `fpend` applies, and with flow_async its handed-back chains stay in the background
     bool last_async = false;   // ... and did (a warm-started step with a side stream)
     int fpend_nchain = 0;
+    const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
     int exact_group = 5, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
@@ -1071,6 +1072,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     c->swd_mode_cur = c->swd_mode;
     const bool warm = track && c->warm_primed && c->warm_nchain == nchain && traj != 2;
     c->last_async = false;
+    if (!fpre) c->flow_x = nullptr;            // (whatever this evaluation leaves behind is not a flow state's)
     if (track) {
         const size_t nn = (size_t)n * nchain;
         if (c->warm_nchain != nchain) c->warm_primed = false;
@@ -1548,6 +1550,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         HIPCHK(c, hipSetDevice(c->device));
         TRY(rfs_synchronize(c));
         c->flow_async = value; for (auto& b : c->bg_busy) b = false;
+        c->flow_x = nullptr; c->warm_primed = false;
         if (c->fpend.p) HIPCHK(c, hipMemset(c->fpend.p, 0, c->fpend.cap));
         return RFS_OK;
     }
@@ -1800,7 +1803,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
                      double sigma2, const double* dobs) {
     if (!c) return RFS_ERR_ARG;
     c->configured = false;
-    c->warm_primed = false;
+    c->warm_primed = false; c->flow_x = nullptr;
     if (nlayer < 2 || nlayer > c->max_layers || nlayer > MAXL) return fail(c, RFS_ERR_ARG, "nlayer outside [2, min(max_layers,128)]");
     int ntw[4] = {0, 0, 0, 0};
     const double* tw[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -2037,6 +2040,20 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     const double* minv = c->has_minv ? c->d_minv.as<double>() : nullptr;
     int* wforce = nullptr;
     if (c->exact_final && c->has_swd && c->warm_opt) { ENSURE(c, c->wforce, (size_t)nchain * sizeof(int)); wforce = c->wforce.as<int>(); }
+    // The previous evaluation (roots, kernels, model) and the pending flags describe ONE set of chains: the state whose x
+    // array the last flow step advanced.  Another state on the same context starts from the full search -- and with chains
+    // sitting steps out there is no way to serve two states in turn.
+    if (c->flow_x != x) {
+        if (c->flow_async && c->flow_x) {
+            bool busy = false;
+            for (bool b : c->bg_busy) busy = busy || b;
+            if (busy) return fail(c, RFS_ERR_STATE, "flow_async_handback: a context advances one flow state at a time (another x array while searches of the "
+                                                    "previous one are outstanding); use one context per state or switch the option off");
+        }
+        c->warm_primed = false;
+        if (c->fpend.p) HIPCHK(c, hipMemsetAsync(c->fpend.p, 0, c->fpend.cap, c->stream));
+        c->flow_x = x;
+    }
     // chains a step hands back to the full search may sit that step out ("flow_async_handback"): who did is kept here
     const size_t pend_before = c->fpend.cap;
     ENSURE(c, c->fpend, (size_t)nchain * sizeof(int));

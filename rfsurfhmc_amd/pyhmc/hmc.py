@@ -110,7 +110,7 @@ class HamitonianMC:
         return xres, Ures, dres, accept
 
     @with_host_threads
-    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True, async_handback=True):
         """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
         chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
         chain at its own point of its own trajectory (rfs_flow_step), and a chain that finishes a trajectory is
@@ -210,6 +210,9 @@ class HamitonianMC:
 
             @staticmethod
             def done(idx, res, accepted):
+                if sampler.trace is not None:       # (diagnostics: one record per batch of trajectories the device completed)
+                    sampler.trace.append(dict(active=[int(c) for c in idx], Hcur=res["Hcur"].copy(), Hnew=res["Hnew"].copy(),
+                                              Unew=res["Unew"].copy(), accept=np.asarray(accepted).copy()))
                 book(idx, accepted, res["Unew"], res["x"], res.get("dsyn_new"))
                 for c in idx:
                     pending.pop(int(c), None)
@@ -222,7 +225,8 @@ class HamitonianMC:
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
                                    fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
-                                   step_hook=step_hook, restart=Restart if device_restart else None)
+                                   step_hook=step_hook, restart=Restart if device_restart else None,
+                                   async_handback=async_handback)
         self.finished = not bool(np.any(i < total))
         self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written

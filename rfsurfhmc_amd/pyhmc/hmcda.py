@@ -266,7 +266,7 @@ class HMCDualAveraging:
         return misfit[0] if nc == 1 else misfit
 
     @with_host_threads
-    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True, async_handback=True):
         """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
         every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
         (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
@@ -399,7 +399,8 @@ class HMCDualAveraging:
 
         self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
                                    fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
-                                   step_hook=step_hook, restart=Restart if device_restart else None)
+                                   step_hook=step_hook, restart=Restart if device_restart else None,
+                                   async_handback=async_handback)
         self.finished = not bool(np.any(i < total))
         self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written

@@ -384,3 +384,88 @@ def test_sampler_with_and_without_the_warm_start_samples_alike(golden):
     assert relx < 1e-3 and relm < 1e-2
     assert abs(m1[:, -1].mean() - m0[:, -1].mean()) <= 0.01 * m0[:, -1].std()
     assert np.all(np.abs(x1s[:, -1].mean(0) - x0s[:, -1].mean(0)) <= 0.02 * x0s[:, -1].std(0) + 1e-12)
+
+
+def test_chains_that_sit_a_step_out_sample_the_same(golden):
+    """rfs_set_option flow_async_handback (the samplers' default): a chain whose root search is handed back to the
+    reference-semantics search sits that device step out and its search runs beside the following steps.  The same seeded
+    HamitonianMC run -- the bench's 30-layer joint problem at its step size, 512 chains from burned-in models, where a few
+    chains per step are handed back -- with the option on and off: every chain goes through the same models and decisions,
+    so the accept counts are equal and the samples agree to the last bits of the roots."""
+    import torch
+    import bench
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    n, nc = 30, 512
+    joint, t = _bench_joint(1)
+    bounds = bench.bounds_of(bench.true_model(n))
+    xs = bench.make_models(nc, 4, n)
+    ctx = joint._ensure(n)
+    # burn in (one run, then both variants start from its end models)
+    keep = {}
+    s0 = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 40, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+    s0.sample_flow(x_init=xs, max_steps=161, step_hook=lambda s, st: keep.__setitem__("x", st["x"].clone()) if s == 160 else None)
+    xb = keep["x"].cpu().numpy()
+    import os
+    MODES = (1, 0) if os.environ.get("RFS_TEST_SYNC_TWICE") != "1" else (2, 0)
+    runs = {}
+    for mode in MODES:
+        d0 = ctx.stat("swd_warm_declined_chains")
+        s = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+        # (a fixed number of device steps: on these rough models a few chains sit on a discontinuity of the reference's
+        # dispersion curve -- a mode jump -- and never accept, as they would not in the reference)
+        mis = s.sample_flow(x_init=xb, max_steps=240, async_handback=bool(mode & 1))
+        runs[mode & 1 if mode < 2 else 1] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
+                      ctx.stat("swd_warm_declined_chains") - d0)
+    (m1, x1, a1, n1, h1), (m0, x0, a0, n0, h0) = runs[1], runs[0]
+    assert h1 > 0 and h0 > 0, (h1, h0)                  # chains were handed back in both
+    # a chain that sat steps out is a few leapfrog steps behind at the cut: compare the samples both runs have
+    k = np.minimum((m1 != 0).sum(axis=1), (m0 != 0).sum(axis=1))
+    assert (np.abs(a1 - a0) <= 2).all() and (k > 3).mean() > 0.8
+    relx = relm = 0.0
+    for c in range(nc):
+        if k[c] > 0:
+            relx = max(relx, np.abs(x1[c, :k[c]] - x0[c, :k[c]]).max() / np.abs(x0[c, :k[c]]).max())
+            relm = max(relm, np.abs(m1[c, :k[c]] - m0[c, :k[c]]).max() / np.abs(m0[c, :k[c]]).max())
+    print(f"sitting out vs waiting: {h1} / {h0} chain evaluations handed back; {int(k.sum())} samples compared, "
+          f"models differ by {relx:.2e}, misfits by {relm:.2e}")
+    assert relx <= 1e-6 and relm <= 1e-5
+
+
+def test_two_flow_states_in_turn_on_one_context():
+    """The warm start belongs to the state whose x array the previous flow call advanced: two states stepped in turn on one
+    context start over from the full search at every call (nothing of the other state is continued) and get exactly the
+    numbers of the history-free evaluation."""
+    import torch
+    import bench
+    n, nc = 30, 256
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    jw, _ = _bench_joint(1); je, _ = _bench_joint(0)
+    bounds = bench.bounds_of(bench.true_model(n))
+    sts = []
+    for seed in (5, 6):
+        xs = np.clip(bench.make_models(nc, seed, n), bounds[:, 0], bounds[:, 1])
+        st = jw.flow_state(tt(xs), torch.full((nc,), 0.002, dtype=torch.float64, device=dev), tt(bounds))
+        st["p"].copy_(tt(0.5 * np.random.default_rng(seed).standard_normal(xs.shape))); st["rem"].fill_(100); st["fresh"].fill_(1)
+        sts.append(st)
+    ctx = jw._ensure(n)
+    i0 = ctx.stat("swd_warm_items")
+    for st in sts:
+        st["rem"].fill_(3)
+    for step in range(4):                        # start evaluation + 3 leapfrog steps, the two states in turn
+        for st in sts:
+            jw.flow_step(st)
+    torch.cuda.synchronize()
+    assert ctx.stat("swd_warm_items") == i0      # nothing was continued across the two states
+    for st in sts:
+        assert int((st["done"] == 1).sum()) == nc
+        m, g, d, f = je.misfit_and_grad_device(st["x"].clone())
+        okc = (f != 0) & (st["ok"] != 0)
+        assert int(okc.sum()) > nc // 2
+        assert torch.equal(st["Unew"][okc], m[okc]) and torch.equal(st["dsyn_new"][okc], d[okc])
+    # ... while one state alone is
+    sts[0]["rem"].fill_(5); sts[0]["fresh"].fill_(1); sts[0]["ok"].fill_(1)
+    for _ in range(4):
+        jw.flow_step(sts[0])
+    torch.cuda.synchronize()
+    assert ctx.stat("swd_warm_items") > i0
