@@ -69,7 +69,7 @@ ROOT_MODE_TEXT = {
 CONFIGS = {
     1: dict(idx=1, n=30, nt=512, dt=0.1, sampler=None,
             name="configs[1]: 8192 chains x 30-layer Vs+thk, joint RF(512 samples)+SWD(40 Rc periods) per GPU"),
-    4: dict(idx=4, n=30, nt=2048, dt=0.025, sampler=None,
+    4: dict(idx=4, n=30, nt=2048, dt=0.025, sampler=None, hmc_dt=0.025,      # (four times the RF samples: twice the curvature scale)
             name="configs[4]: frequency-domain RF with a 2048-point FFT, 8192 chains x 30 layers + 40 Rc periods per GPU"),
     3: dict(idx=3, n=50, nt=512, dt=0.1, sampler="da",
             name="configs[3]: main_DA.py dual averaging (HMCDualAveraging.sample_flow), 8192 chains x 50-layer model, "
@@ -407,6 +407,9 @@ def make_joint(cfg, local_rank):
     drf, dswd, flag = joint.forward(x_true)
     assert flag
     joint.set_obsdata(drf, dswd)
+    for opt, env in (("swd_exact_group", "RFS_EXACT_GROUP"), ("swd_exact_runup", "RFS_EXACT_RUNUP")):      # (experiments)
+        if os.environ.get(env):
+            joint._ensure(n).set_option(opt, int(os.environ[env]))
     return joint, x_true, bounds_of(x_true)
 
 
@@ -645,7 +648,7 @@ def run_rank(args):
     n, nt = cfg["n"], cfg["nt"]
     nchain = args.chains
     K, burn = args.steps, args.warmup
-    dt = args.dt if args.dt is not None else TUNED_DT
+    dt = args.dt if args.dt is not None else cfg.get("hmc_dt", TUNED_DT)
     mode = {None: "reference_roots", 1: "reference_roots", 0: "full_search"}[args.warm_start]
     if args.converged_roots:
         mode = "converged_roots"
@@ -723,8 +726,8 @@ def run_rank(args):
             c2 = CONFIGS[ci]
             j2, xt2, b2 = make_joint(c2, local_rank)
             k2 = "da" if c2["sampler"] == "da" else "hmc"
-            r2, _, _, _, _, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, min(K, 100), min(burn, 150), barrier, kind=k2,
-                                            dt=dt, mode=mode)
+            r2, _, _, _, _, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, min(K, 100), min(burn, 300), barrier, kind=k2,
+                                            dt=c2.get("hmc_dt", TUNED_DT), mode=mode)
             r2["workload"] = c2["name"]; r2["step"] = STEP_TEXT[c2["sampler"]]
             extra[f"config{ci}"] = r2
             j2._ctx.close(); j2._ctx = None

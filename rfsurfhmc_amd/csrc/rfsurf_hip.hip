@@ -1373,6 +1373,19 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
 
 extern "C" {
 
+// The surface-wave stream carries the step's longest dependent chain (warm start -> branch test -> reference-root stage ->
+// eigenfunctions -> combine); the receiver-function sweeps beside it have slack.  Where the device offers stream priorities
+// the surface-wave stream gets the high one, so that its wavefronts are dispatched first when both streams have work
+// (RFS_SWD_STREAM_PRIORITY=0 in the environment: plain stream, for A/B measurements).
+static bool create_swd_stream(hipStream_t* s) {
+    int lo = 0, hi = 0;
+    const char* e = getenv("RFS_SWD_STREAM_PRIORITY");
+    if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo &&
+        hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess)
+        return true;
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
+}
+
 int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     if (!out || max_chains < 1 || max_layers < 2) return RFS_ERR_ARG;
     *out = nullptr;
@@ -1381,7 +1394,7 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     rfs_ctx* c = new rfs_ctx();
     c->device = device; c->max_chains = max_chains; c->max_layers = max_layers;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+              create_swd_stream(&c->stream2) &&
               hipStreamCreateWithFlags(&c->stream_l, hipStreamNonBlocking) == hipSuccess &&
 
               hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming) == hipSuccess &&

@@ -886,7 +886,7 @@ struct WarmSearch {
 // reference-semantics search.
 // ---------------------------------------------------------------------------
 constexpr double EXACT_ORIGIN_ERR = 4.0e-7;    // ... which leaves the first run-up origin within this of the reference's (relative)
-constexpr double EXACT_ORIGIN_TOL = 3.0e-9;    // origin accuracy a wanted period needs (see ExactGroupT::step_nevill): two run-up periods of a smooth secular function leave ~1e-11, roots found by bisections alone leave the 4e-7
+constexpr double EXACT_ORIGIN_TOL = 1.0e-7;    // origin accuracy a wanted period needs (see ExactGroupT::step_nevill): two run-up periods of a smooth secular function leave ~1e-11, roots found by bisections alone leave the 4e-7
 constexpr double EXACT_OFFSET = 0.75e-6;     // the reference's root lies 0.5 .. 1.0e-6 c below the sign change: the run-up's first origin is moved by the mean
 
 // nevill (surfdisp96.f:568-687) inside a bracket, as a request machine of its own -- the same decisions and the same
@@ -1098,7 +1098,7 @@ struct ExactGroupT {
         nv.advance(f);
         if (nv.phase == CellNevillT<LAZY>::N_FAIL) { phase = X_FAIL; cause = 5; return; }   // the reference rejects the root (above the fastest layer)
         if (nv.phase == CellNevillT<LAZY>::N_DONE) {
-            // a period whose result is wanted must start from an origin that is the reference's to 3e-9 or better (its root then is
+            // a period whose result is wanted must start from an origin that is the reference's to 1e-7 or better -- in effect: unless the run-up did not contract at all -- (its root then is
             // the reference's float32 value but for rare cases); a run-up that did not get there -- roots found by
             // bisections alone pass the origin's error on undiminished -- is the full search's business
             if (k >= k0 && oerr > (float)EXACT_ORIGIN_TOL) { phase = X_FAIL; cause = 7; return; }

@@ -4,17 +4,16 @@ profiles/<tag>_pmc_config<c>.csv and the per-step, per-group figures bench.py re
 
     python3 scripts/pmc_summary.py <tag> <config> <steps> <dir_with_pass_subdirs>
 
-Each pass directory holds a *counter_collection.csv of `python3 scripts/prof_run.py <config> <steps>` (one full-search
-call + <steps> warm-started calls).  Per kernel: the sum over all dispatches divided by the number of calls it ran in
-(= per leapfrog step; a tiled shape launches a kernel several times per step).  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE
+Each pass directory holds a *counter_collection.csv of `python3 scripts/prof_run.py <config> <steps> hmc` (a sampler run
+that continues burned-in chains).  Per kernel: the sum over all dispatches divided by the device steps of the pass (the
+dispatches of k_prep_joint); "swd_roots_full_search" = the searches of the start models and of handed-back chains.  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE
 (KiB counters; gfx950 counts 64 B per 128-B request on wide coalesced reads, hence the factor 2)."""
 import csv, glob, json, os, sys
 
 GROUPS = [("k_prep", "prep"), ("k_rf_passA", "rf_pass_a"), ("k_rf_mid", "rf_mid"), ("k_rf_passB", "rf_pass_b"),
-          ("k_swd_roots_coop", "swd_roots_full_search"), ("k_swd_roots", "swd_roots"), ("k_swd_warm", "swd_roots"),
+          ("k_swd_roots", "swd_roots_full_search"), ("k_swd_warm", "swd_roots"), ("k_swd_exact", "swd_exact"),
           ("k_swd_eigen", "swd_eigen"),
-          ("k_rf_reduce", "rf_pass_b"), ("k_swd_combine", "combine")]
-FULL_ONLY = ("k_swd_roots_coop",)          # run in the first call only
+          ("k_rf_reduce", "rf_pass_b"), ("k_swd_combine", "combine"), ("k_flow_post", "combine")]
 
 
 def short(name):
@@ -35,14 +34,16 @@ def main():
     kernels = sorted({k for k, _ in tot if k.startswith("k_")})
     counters = sorted({c for _, c in tot})
 
+    # device steps of the pass = dispatches of k_prep_joint (every step launches it once)
+    nstep = max([disp.get(("k_prep_joint", c), 0) for c in counters] + [1])
+    steps = nstep
+
     def calls(k):
-        if k.startswith(FULL_ONLY):
-            return 1
-        return steps if k.startswith("k_swd_warm") or (k.startswith("k_swd_roots") and not k.startswith(FULL_ONLY)) else steps + 1
+        return nstep
     os.makedirs("profiles", exist_ok=True)
     out = os.path.join("profiles", f"{tag}_pmc_config{config}.csv")
     with open(out, "w") as fo:
-        fo.write(f"# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 scripts/prof_run.py {config} {steps}   (one pass per counter group)\n")
+        fo.write(f"# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 scripts/prof_run.py {config} {steps} hmc   (one pass per counter group)\n")
         fo.write("# per LEAPFROG STEP: sum over all dispatches of the kernel / calls it ran in; FETCH_SIZE / WRITE_SIZE in KiB as reported\n")
         fo.write("kernel,dispatches_per_step," + ",".join(counters) + "\n")
         for k in kernels:
