@@ -890,7 +890,7 @@ constexpr double EXACT_ORIGIN_TOL = 1.0e-7;    // origin accuracy a wanted perio
 constexpr double EXACT_OFFSET = 0.75e-6;     // the reference's root lies 0.5 .. 1.0e-6 c below the sign change: the run-up's first origin is moved by the mean
 
 // nevill (surfdisp96.f:568-687) inside a bracket, as a request machine of its own -- the same decisions and the same
-// arithmetic as RootSearchT::advance's refinement stages (tests/test_hostsim_math.py holds the two together bit for
+// arithmetic as RootSearchT::advance's refinement stages (a CPU test of the lane code holds the two together bit for
 // bit) -- with LAZY evaluation: of the ~12 points nevill evaluates, most are midpoints of a run of bisections that
 // approaches the root from the FAR end of a bracket whose other end already sits on the root (|f| a few 1e-6 of the far
 // value after the first interpolation, 1e-10 after the second).  All nevill does with such a value is (a) take its sign

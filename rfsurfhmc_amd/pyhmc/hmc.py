@@ -110,63 +110,59 @@ class HamitonianMC:
         return xres, Ures, dres, accept
 
     @with_host_threads
-    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True, async_handback=True):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True, async_handback=True,
+                    resume=False):
         """Same chains, same samples as sample() (each chain consumes its own RNG stream in the reference's order and
         chains never interact), scheduled as a continuous flow: every device step evaluates every chain once, each
         chain at its own point of its own trajectory (rfs_flow_step), and a chain that finishes a trajectory is
         accepted / rejected and restarted on the spot instead of waiting for the longest trajectory of the batch.
         With L drawn per chain in [Lmin, Lmax] the batch schedule spends Lmax + 1 evaluations per round and chain,
-        this one mean(L) + 2."""
+        this one mean(L) + 2.
+        ``checkpoint`` / ``checkpoint_every`` / ``mass_adapt`` (constructor) work on trajectory COUNTS, as in sample(): the
+        flow runs in segments that end when every chain has completed that many trajectories (a chain that gets there early
+        idles until the last one has: a bubble of about one trajectory per segment).  At such a barrier the state is the one
+        sample() checkpoints -- models, counters, sample slots, every chain's RNG position -- so the same file format serves
+        both schedules, ``resume=True`` continues from ``self.checkpoint`` with the samples of an uninterrupted run, and the
+        mass matrix is re-estimated from the ensemble exactly where sample() does it."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
-        if self.mass_adapt:
-            raise ValueError("mass_adapt needs the common trajectory boundaries of sample(); pass inverse_mass instead")
-        if self.checkpoint:
-            raise ValueError("checkpoint / resume is implemented for sample() only: the flow schedule has no common "
-                             "trajectory boundary to checkpoint at")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
-        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
-        self.initmodel = x.copy()
-        nx = x.shape[1]
         ndata = self.model.dobs.shape[0]
         total = nd_ + ns
-        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
-        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
-        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        if resume:
+            ck = load_checkpoint(self.checkpoint, self.rng)
+            x, i, ncount = ck["x"], ck["i"], ck["ncount"]
+            misfit, x_cache, self.initmodel = ck["misfit"], ck["x_cache"], ck["initmodel"]
+            syndata = ck["syndata"] if "syndata" in ck else None
+            self.ii = int(ck["ii"])
+            cur = int(ck["ntraj"]) if "ntraj" in ck else 0
+            if "inverse_mass" in ck:
+                self._set_inverse_mass(ck["inverse_mass"])
+            nx = x.shape[1]
+        else:
+            x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+            self.initmodel = x.copy()
+            nx = x.shape[1]
+            misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+            syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+            i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+            cur = 0
         self.live_counts = (i, ncount)          # accepted / completed trajectories per chain, as the books stand (step hooks read them)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        st = self.model.flow_state(t(x), torch.full((nc,), float(self.dt), dtype=torch.float64, device=dev),
-                                   t(self.boundaries))
-        allc = list(range(nc))
-        L = self.rng.randint(allc, self.Lrange[0], self.Lrange[1] + 1)          # hmc.py:248, then :146
-        st["p"].copy_(t(self.rng.randn(allc, nx) * self._pscale))
-        st["rem"].copy_(t(L.astype(np.int32))); st["fresh"].fill_(1)
-        def process_done(idx, res):
-            ok = res["ok"].astype(bool)
-            Hcur, Hnew, Unew, Ucur, xend = res["Hcur"], res["Hnew"], res["Unew"], res["Ucur"], res["x"]
-            dnew = res.get("dsyn_new")
-            u = np.full(len(idx), np.nan)
-            u[ok] = self.rng.rand([int(c) for c in idx[ok]])                    # hmc.py:193, skipped on failure
-            with np.errstate(over="ignore", invalid="ignore"):
-                accept = ok & (u < np.exp(-(Hnew - Hcur)))
-            book(idx, accept, Unew, xend, dnew)
-            restart = [int(c) for c in idx[i[idx] < total]]
-            if self.verbose:
-                for k, c in enumerate(idx):
-                    if i[c] % 50 == 0 or i[c] == ns - 1:
-                        Uc = Unew[k] if accept[k] else (Ucur[k] if ok[k] else np.inf)
-                        print("chain {}: {:.2%}, misfit={:.3} -- accept ratio {:.2%}".format(
-                            self.first_chain + c, i[c] / total, Uc, i[c] / ncount[c]))
-                sys.stdout.flush()
-            # every finished chain goes back to the model it keeps (accepted end point or its start model) and the
-            # unfinished ones restart: randint(L) then randn(p0), the reference's draw order (hmc.py:248, :146)
-            rs = None
-            if restart:
-                Lr = self.rng.randint(restart, self.Lrange[0], self.Lrange[1] + 1)
-                rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, rem=Lr)
-            return x[idx], rs
+        sampler = self
+        self.flow_withdrawn = 0                     # early draws taken back because the trajectory failed after all
+        self.flow_steps = 0
+        every = self.checkpoint_every if self.checkpoint else 0
+        points = sorted(self.mass_adapt) if self.mass_adapt else []
+
+        def next_barrier(c):
+            """Smallest trajectory count > c at which every chain has to stand still (checkpoint, mass adaptation)."""
+            cand = [p for p in points if p > c]
+            if every:
+                cand.append((c // every + 1) * every)
+            return min(cand) if cand else None
 
         def book(idx, accept, Unew, xend, dnew):
             """One completed trajectory per chain of idx: keep the accepted end points, fill the sample slots."""
@@ -175,58 +171,111 @@ class HamitonianMC:
                 x[ca] = xend[accept]
                 keep = i[ca] >= nd_
                 if np.any(keep):
-                    ck, slot = ca[keep], i[ca][keep] - nd_
-                    misfit[ck, slot] = Unew[accept][keep]
-                    x_cache[ck, slot] = xend[accept][keep]
+                    ck_, slot = ca[keep], i[ca][keep] - nd_
+                    misfit[ck_, slot] = Unew[accept][keep]
+                    x_cache[ck_, slot] = xend[accept][keep]
                     if syndata is not None:
-                        syndata[ck, slot] = dnew[accept][keep]
+                        syndata[ck_, slot] = dnew[accept][keep]
                 i[ca] += 1; self.ii += len(ca)
             ncount[idx] += 1
 
-        # Restarts on the device (rfs_flow_step2): neither the acceptance draw nor the next L and momentum depend on the
-        # trajectory (hmc.py:193, 248, 146), so they are drawn -- in that order, from the chain's own stream -- while the
-        # trajectory still runs, and the device accepts / rejects and starts over by itself.  The one exception is the
-        # reference's failure paths, which skip the acceptance draw (hmc.py:156,173,177,179): the streams are
-        # snapshotted before the early draws and rewound for a chain that fails.
-        sampler = self
-        self.flow_withdrawn = 0                     # early draws taken back because the trajectory failed after all
-        pending = {}                                # chain -> snapshot its early draws can be undone with
+        capped = False
+        while np.any(i < total) and not capped:
+            if cur in points:                       # as sample(): the ensemble's variance, before trajectory number `cur`
+                self._set_inverse_mass(ensemble_inverse_mass(x))
+            target = next_barrier(cur)              # None: no barrier ahead, the segment runs to the end
+            lim = np.inf if target is None else target
+            live = np.nonzero(i < total)[0]
+            st = self.model.flow_state(t(x), torch.full((nc,), float(self.dt), dtype=torch.float64, device=dev),
+                                       t(self.boundaries))
+            livel = [int(c) for c in live]
+            L = np.zeros(nc, dtype=np.int64)
+            L[live] = self.rng.randint(livel, self.Lrange[0], self.Lrange[1] + 1)  # hmc.py:248, then :146
+            p0 = np.zeros((nc, nx)); p0[live] = self.rng.randn(livel, nx) * self._pscale
+            st["p"].copy_(t(p0))
+            rem0 = np.where(i < total, L, -1).astype(np.int32)
+            st["rem"].copy_(t(rem0)); st["fresh"].copy_(t((i < total).astype(np.int32)))
+            pending = {}                            # chain -> snapshot its early draws can be undone with
 
-        class Restart:
-            rem0 = L
+            def process_done(idx, res):
+                ok = res["ok"].astype(bool)
+                Hcur, Hnew, Unew, Ucur, xend = res["Hcur"], res["Hnew"], res["Unew"], res["Ucur"], res["x"]
+                dnew = res.get("dsyn_new")
+                u = np.full(len(idx), np.nan)
+                u[ok] = self.rng.rand([int(c) for c in idx[ok]])                    # hmc.py:193, skipped on failure
+                with np.errstate(over="ignore", invalid="ignore"):
+                    accept = ok & (u < np.exp(-(Hnew - Hcur)))
+                book(idx, accept, Unew, xend, dnew)
+                restart = [int(c) for c in idx[(i[idx] < total) & (ncount[idx] < lim)]]
+                if self.verbose:
+                    for k, c in enumerate(idx):
+                        if i[c] % 50 == 0 or i[c] == ns - 1:
+                            Uc = Unew[k] if accept[k] else (Ucur[k] if ok[k] else np.inf)
+                            print("chain {}: {:.2%}, misfit={:.3} -- accept ratio {:.2%}".format(
+                                self.first_chain + c, i[c] / total, Uc, i[c] / ncount[c]))
+                    sys.stdout.flush()
+                # every finished chain goes back to the model it keeps (accepted end point or its start model) and the
+                # unfinished ones restart: randint(L) then randn(p0), the reference's draw order (hmc.py:248, :146)
+                rs = None
+                if restart:
+                    Lr = self.rng.randint(restart, self.Lrange[0], self.Lrange[1] + 1)
+                    rs = dict(idx=restart, p=self.rng.randn(restart, nx) * self._pscale, rem=Lr)
+                return x[idx], rs
 
-            @staticmethod
-            def predraw(cands):
-                sel = cands[i[cands] + 1 < total]   # needs another trajectory whatever the decision
-                if len(sel) == 0:
-                    return sel, None, None, None
-                snap = sampler.rng.snapshot(sel)
-                for c in sel:
-                    pending[int(c)] = snap
-                cl = [int(c) for c in sel]
-                u = sampler.rng.rand(cl)
-                Ln = sampler.rng.randint(cl, sampler.Lrange[0], sampler.Lrange[1] + 1)
-                return sel, u, sampler.rng.randn(cl, nx) * sampler._pscale, Ln
+            # Restarts on the device (rfs_flow_step2): neither the acceptance draw nor the next L and momentum depend on the
+            # trajectory (hmc.py:193, 248, 146), so they are drawn -- in that order, from the chain's own stream -- while the
+            # trajectory still runs, and the device accepts / rejects and starts over by itself.  The one exception is the
+            # reference's failure paths, which skip the acceptance draw (hmc.py:156,173,177,179): the streams are
+            # snapshotted before the early draws and rewound for a chain that fails.
+            class Restart:
+                rem0 = np.where(i < total, L, 1 << 30)      # (idle chains: never "about to complete")
 
-            @staticmethod
-            def done(idx, res, accepted):
-                if sampler.trace is not None:       # (diagnostics: one record per batch of trajectories the device completed)
-                    sampler.trace.append(dict(active=[int(c) for c in idx], Hcur=res["Hcur"].copy(), Hnew=res["Hnew"].copy(),
-                                              Unew=res["Unew"].copy(), accept=np.asarray(accepted).copy()))
-                book(idx, accepted, res["Unew"], res["x"], res.get("dsyn_new"))
-                for c in idx:
-                    pending.pop(int(c), None)
+                @staticmethod
+                def predraw(cands):
+                    # needs another trajectory whatever the decision, and on this side of the barrier
+                    sel = cands[(i[cands] + 1 < total) & (ncount[cands] + 1 < lim)]
+                    if len(sel) == 0:
+                        return sel, None, None, None
+                    snap = sampler.rng.snapshot(sel)
+                    for c in sel:
+                        pending[int(c)] = snap
+                    cl = [int(c) for c in sel]
+                    u = sampler.rng.rand(cl)
+                    Ln = sampler.rng.randint(cl, sampler.Lrange[0], sampler.Lrange[1] + 1)
+                    return sel, u, sampler.rng.randn(cl, nx) * sampler._pscale, Ln
 
-            @staticmethod
-            def withdraw(idx):
-                sampler.flow_withdrawn += len(idx)
-                for c in idx:
-                    sampler.rng.restore(pending.pop(int(c)), [int(c)])
+                @staticmethod
+                def done(idx, res, accepted):
+                    if sampler.trace is not None:       # (diagnostics: one record per batch of trajectories the device completed)
+                        sampler.trace.append(dict(active=[int(c) for c in idx], Hcur=res["Hcur"].copy(), Hnew=res["Hnew"].copy(),
+                                                  Unew=res["Unew"].copy(), accept=np.asarray(accepted).copy()))
+                    book(idx, accepted, res["Unew"], res["x"], res.get("dsyn_new"))
+                    for c in idx:
+                        pending.pop(int(c), None)
 
-        self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
-                                   fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
-                                   step_hook=step_hook, restart=Restart if device_restart else None,
-                                   async_handback=async_handback)
+                @staticmethod
+                def withdraw(idx):
+                    sampler.flow_withdrawn += len(idx)
+                    for c in idx:
+                        sampler.rng.restore(pending.pop(int(c)), [int(c)])
+
+            left = None if max_steps is None else max_steps - self.flow_steps
+            base = self.flow_steps
+            hook = None if step_hook is None else (lambda s_, st_, _b=base: step_hook(_b + s_, st_))
+            nst = run_flow(self.model, st, process_done, lambda: bool(np.any((i < total) & (ncount < lim))),
+                           fetch_syn=syndata is not None, pipeline=pipeline, max_steps=left,
+                           step_hook=hook, restart=Restart if device_restart else None,
+                           async_handback=async_handback)
+            self.flow_steps += nst
+            capped = max_steps is not None and self.flow_steps >= max_steps
+            if capped and np.any((i < total) & (ncount < lim)):
+                break                                   # stopped inside a segment: no barrier state to keep
+            if target is not None:
+                cur = target
+                if every and cur % every == 0 and np.any(i < total):
+                    self._save_checkpoint(x, np.zeros(nc), i, ncount, misfit, x_cache, syndata, cur)
+            else:
+                break
         self.finished = not bool(np.any(i < total))
         self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written

@@ -266,141 +266,183 @@ class HMCDualAveraging:
         return misfit[0] if nc == 1 else misfit
 
     @with_host_threads
-    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True, async_handback=True):
+    def sample_flow(self, x_init=None, pipeline=True, max_steps=None, step_hook=None, device_restart=True, async_handback=True,
+                    resume=False):
         """Same chains and samples as sample(), on the continuous-flow schedule (rfs_flow_step): with dual averaging
         every chain has its own step size and therefore its own trajectory length L = max(1, int(lambda / dt))
         (hmcda.py:307); here no chain waits for the longest one.  Per chain the RNG stream is consumed in the reference's
-        order (momentum at the start of a trajectory, the acceptance draw at its end)."""
+        order (momentum at the start of a trajectory, the acceptance draw at its end).
+        ``checkpoint`` / ``checkpoint_every`` / ``mass_adapt`` / ``resume``: as HamitonianMC.sample_flow -- segments that end
+        at trajectory counts, sample()'s checkpoint format (with dt, dtbar and the dual-averaging statistic per chain)."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
-        if self.mass_adapt:
-            raise ValueError("mass_adapt needs the common trajectory boundaries of sample(); pass inverse_mass instead")
-        if self.checkpoint:
-            raise ValueError("checkpoint / resume is implemented for sample() only: the flow schedule has no common "
-                             "trajectory boundary to checkpoint at")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
-        x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
-        self.initmodel = x.copy()
-        nx = x.shape[1]
         ndata = self.model.dobs.shape[0]
         mu = np.log(10 * self.dt)
         total = nd_ + ns
-        misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
-        syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
-        dt = self._find_initial_dt(self.dt, x)
-        dtbar = dt * 1.0
-        h0 = np.full(nc, self._h0)
-        i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+        if resume:
+            ck = load_checkpoint(self.checkpoint, self.rng)
+            x, i, ncount = ck["x"], ck["i"], ck["ncount"]
+            misfit, x_cache, self.initmodel = ck["misfit"], ck["x_cache"], ck["initmodel"]
+            syndata = ck["syndata"] if "syndata" in ck else None
+            dt, dtbar, h0 = ck["dt"], ck["dtbar"], ck["h0"]
+            self.ii = int(ck["ii"])
+            cur = int(ck["ntraj"]) if "ntraj" in ck else 0
+            if "inverse_mass" in ck:
+                self._set_inverse_mass(ck["inverse_mass"])
+            nx = x.shape[1]
+        else:
+            x = initial_models(self.rng, self.boundaries) if x_init is None else np.array(x_init, dtype=float)
+            self.initmodel = x.copy()
+            nx = x.shape[1]
+            misfit = np.zeros((nc, ns)); x_cache = np.zeros((nc, ns, nx))
+            syndata = np.zeros((nc, ns, ndata)) if self.store_syn else None
+            dt = self._find_initial_dt(self.dt, x)
+            dtbar = dt * 1.0
+            h0 = np.full(nc, self._h0)
+            i = np.zeros(nc, dtype=int); ncount = np.zeros(nc, dtype=int)
+            cur = 0
         self.live_counts = (i, ncount)          # accepted / completed trajectories per chain, as the books stand (step hooks read them)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
-        allc = list(range(nc))
-        st["p"].copy_(t(self.rng.randn(allc, nx) * self._pscale))
-        st["rem"].copy_(t(self._traj_len(dt)))
-        st["fresh"].fill_(1)
-        pending = {}                                # chain -> (u, p) drawn ahead of time for it (restarts on the device)
-
-        def books(idx, ok, Hcur, Hnew, Unew, xend, dnew, u, acc=None):
-            """One completed trajectory per chain of idx: accept / reject (acc given: the device's decision with the same
-            u), sample slots, dual averaging of the step size (hmcda.py:329-345)."""
-            Unew = np.where(ok, Unew, np.inf)
-            with np.errstate(over="ignore", invalid="ignore"):
-                alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
-            if acc is None:
-                acc = u < alpha
-            # accepted end points (vectorised over the finished chains; one sample slot per chain and trajectory)
-            ca = idx[acc]
-            if len(ca):
-                x[ca] = xend[acc]
-                keep = i[ca] >= nd_
-                if np.any(keep):
-                    ck, slot = ca[keep], i[ca][keep] - nd_
-                    misfit[ck, slot] = Unew[acc][keep]
-                    x_cache[ck, slot] = xend[acc][keep]
-                    if syndata is not None:
-                        okk = ok[acc][keep]
-                        syndata[ck, slot] = np.where(okk[:, None], dnew[acc][keep], self.model.dobs[None, :])
-                i[ca] += 1; self.ii += len(ca)
-            adapt = ncount[idx] < nd_
-            m = ncount[idx] + 1.0
-            fac = 1.0 / (m + self._t0)
-            h_new = (1 - fac) * h0[idx] + fac * (self.delta - alpha)
-            logdt = mu - np.sqrt(m) / self._gamma * h_new
-            fac2 = m ** (-self._kappa)
-            dtbar_new = np.exp(fac2 * logdt + (1 - fac2) * np.log(dtbar[idx]))
-            h0[idx] = np.where(adapt, h_new, h0[idx])
-            dt[idx] = np.where(adapt, np.exp(logdt), dtbar[idx])
-            dtbar[idx] = np.where(adapt, dtbar_new, dtbar[idx])
-            ncount[idx] += 1
-            if self.verbose:
-                for k, c in enumerate(idx):
-                    if i[c] % 50 == 0 or i[c] == ns - 1:
-                        print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
-                            self.first_chain + c, i[c] / total, dt[c], Unew[k], i[c] / ncount[c]))
-                sys.stdout.flush()
-
-        def process_done(idx, res):
-            ok = res["ok"].astype(bool)
-            # acceptance draws (every iteration, hmcda.py:311): a chain that had its draws made early but failed -- the
-            # device leaves those to the host -- uses exactly those, the others draw now
-            early = np.array([int(c) in pending for c in idx], dtype=bool)
-            u = np.empty(len(idx))
-            if early.any():
-                u[early] = [pending[int(c)][0] for c in idx[early]]
-            if (~early).any():
-                u[~early] = self.rng.rand([int(c) for c in idx[~early]])
-            books(idx, ok, res["Hcur"], res["Hnew"], res["Unew"], res["x"], res.get("dsyn_new"), u)
-            restart = [int(c) for c in idx if i[c] < total]
-            rs = None
-            if restart:
-                fresh_p = [c for c in restart if c not in pending]
-                drawn = dict(zip(fresh_p, self.rng.randn(fresh_p, nx) * self._pscale)) if fresh_p else {}
-                pr = np.stack([pending[c][1] if c in pending else drawn[c] for c in restart])
-                rs = dict(idx=restart, p=pr, dt=dt[restart], rem=self._traj_len(dt[restart]))
-            for c in idx:
-                pending.pop(int(c), None)
-            return x[idx], rs
-
-        # Restarts on the device, deferred form (rfs_flow_step2 with gsave / kick): the acceptance draw and the next
-        # momentum never depend on the trajectory (hmcda.py:311, :236) and are drawn one step ahead; the next step size
-        # does (dual averaging), so the device accepts / rejects, starts the chain on its new momentum and evaluates the
-        # start model at once, while the first half kick waits one call for dt and L from the host.
         sampler = self
+        self.flow_steps = 0
+        every = self.checkpoint_every if self.checkpoint else 0
+        points = sorted(self.mass_adapt) if self.mass_adapt else []
 
-        class Restart:
-            rem0 = self._traj_len(dt)
-            deferred = True
+        def next_barrier(c):
+            cand = [p for p in points if p > c]
+            if every:
+                cand.append((c // every + 1) * every)
+            return min(cand) if cand else None
 
-            @staticmethod
-            def predraw(cands):
-                sel = cands[i[cands] + 1 < total]
-                if len(sel) == 0:
-                    return sel, None, None, None
-                cl = [int(c) for c in sel]
-                u = sampler.rng.rand(cl)
-                pn = sampler.rng.randn(cl, nx) * sampler._pscale
-                for k, c in enumerate(cl):
-                    pending[c] = (u[k], pn[k])
-                return sel, u, pn, None
+        capped = False
+        while np.any(i < total) and not capped:
+          if cur in points:                         # as sample(): dual averaging then re-tunes dt (burn-in)
+              self._set_inverse_mass(ensemble_inverse_mass(x))
+          target = next_barrier(cur)
+          lim = np.inf if target is None else target
+          live0 = i < total
+          st = self.model.flow_state(t(x), t(dt.astype(np.float64)), t(self.boundaries))
+          livel = [int(c) for c in np.nonzero(live0)[0]]
+          p0 = np.zeros((nc, nx)); p0[live0] = self.rng.randn(livel, nx) * self._pscale
+          st["p"].copy_(t(p0))
+          st["rem"].copy_(t(np.where(live0, self._traj_len(dt), -1).astype(np.int32)))
+          st["fresh"].copy_(t(live0.astype(np.int32)))
+          pending = {}                                # chain -> (u, p) drawn ahead of time for it (restarts on the device)
 
-            @staticmethod
-            def done(idx, res, accepted):
-                ok = np.ones(len(idx), dtype=bool)
-                books(idx, ok, res["Hcur"], res["Hnew"], res["Unew"], res["x"], res.get("dsyn_new"), None, acc=accepted)
-                for c in idx:
-                    pending.pop(int(c), None)
-                return dict(dt=dt[idx], rem=sampler._traj_len(dt[idx]))
+          def books(idx, ok, Hcur, Hnew, Unew, xend, dnew, u, acc=None):
+              """One completed trajectory per chain of idx: accept / reject (acc given: the device's decision with the same
+              u), sample slots, dual averaging of the step size (hmcda.py:329-345)."""
+              Unew = np.where(ok, Unew, np.inf)
+              with np.errstate(over="ignore", invalid="ignore"):
+                  alpha = np.where(ok, np.minimum(1.0, np.exp(-(Hnew - Hcur))), 0.0)
+              if acc is None:
+                  acc = u < alpha
+              # accepted end points (vectorised over the finished chains; one sample slot per chain and trajectory)
+              ca = idx[acc]
+              if len(ca):
+                  x[ca] = xend[acc]
+                  keep = i[ca] >= nd_
+                  if np.any(keep):
+                      ck, slot = ca[keep], i[ca][keep] - nd_
+                      misfit[ck, slot] = Unew[acc][keep]
+                      x_cache[ck, slot] = xend[acc][keep]
+                      if syndata is not None:
+                          okk = ok[acc][keep]
+                          syndata[ck, slot] = np.where(okk[:, None], dnew[acc][keep], self.model.dobs[None, :])
+                  i[ca] += 1; self.ii += len(ca)
+              adapt = ncount[idx] < nd_
+              m = ncount[idx] + 1.0
+              fac = 1.0 / (m + self._t0)
+              h_new = (1 - fac) * h0[idx] + fac * (self.delta - alpha)
+              logdt = mu - np.sqrt(m) / self._gamma * h_new
+              fac2 = m ** (-self._kappa)
+              dtbar_new = np.exp(fac2 * logdt + (1 - fac2) * np.log(dtbar[idx]))
+              h0[idx] = np.where(adapt, h_new, h0[idx])
+              dt[idx] = np.where(adapt, np.exp(logdt), dtbar[idx])
+              dtbar[idx] = np.where(adapt, dtbar_new, dtbar[idx])
+              ncount[idx] += 1
+              if self.verbose:
+                  for k, c in enumerate(idx):
+                      if i[c] % 50 == 0 or i[c] == ns - 1:
+                          print("chain {}: {:.2%}, dt = {:.3},  misfit={:.3} -- accept ratio {:.2%}".format(
+                              self.first_chain + c, i[c] / total, dt[c], Unew[k], i[c] / ncount[c]))
+                  sys.stdout.flush()
 
-            @staticmethod
-            def withdraw(idx):                      # nothing to rewind: process_done uses the early draws
-                pass
+          def process_done(idx, res):
+              ok = res["ok"].astype(bool)
+              # acceptance draws (every iteration, hmcda.py:311): a chain that had its draws made early but failed -- the
+              # device leaves those to the host -- uses exactly those, the others draw now
+              early = np.array([int(c) in pending for c in idx], dtype=bool)
+              u = np.empty(len(idx))
+              if early.any():
+                  u[early] = [pending[int(c)][0] for c in idx[early]]
+              if (~early).any():
+                  u[~early] = self.rng.rand([int(c) for c in idx[~early]])
+              books(idx, ok, res["Hcur"], res["Hnew"], res["Unew"], res["x"], res.get("dsyn_new"), u)
+              restart = [int(c) for c in idx if i[c] < total and ncount[c] < lim]
+              rs = None
+              if restart:
+                  fresh_p = [c for c in restart if c not in pending]
+                  drawn = dict(zip(fresh_p, self.rng.randn(fresh_p, nx) * self._pscale)) if fresh_p else {}
+                  pr = np.stack([pending[c][1] if c in pending else drawn[c] for c in restart])
+                  rs = dict(idx=restart, p=pr, dt=dt[restart], rem=self._traj_len(dt[restart]))
+              for c in idx:
+                  pending.pop(int(c), None)
+              return x[idx], rs
 
-        self.flow_steps = run_flow(self.model, st, process_done, lambda: bool(np.any(i < total)),
-                                   fetch_syn=syndata is not None, pipeline=pipeline, max_steps=max_steps,
-                                   step_hook=step_hook, restart=Restart if device_restart else None,
-                                   async_handback=async_handback)
+          # Restarts on the device, deferred form (rfs_flow_step2 with gsave / kick): the acceptance draw and the next
+          # momentum never depend on the trajectory (hmcda.py:311, :236) and are drawn one step ahead; the next step size
+          # does (dual averaging), so the device accepts / rejects, starts the chain on its new momentum and evaluates the
+          # start model at once, while the first half kick waits one call for dt and L from the host.
+          sampler = self
+
+          class Restart:
+              rem0 = np.where(live0, self._traj_len(dt), 1 << 30)
+              deferred = True
+
+              @staticmethod
+              def predraw(cands):
+                  sel = cands[(i[cands] + 1 < total) & (ncount[cands] + 1 < lim)]
+                  if len(sel) == 0:
+                      return sel, None, None, None
+                  cl = [int(c) for c in sel]
+                  u = sampler.rng.rand(cl)
+                  pn = sampler.rng.randn(cl, nx) * sampler._pscale
+                  for k, c in enumerate(cl):
+                      pending[c] = (u[k], pn[k])
+                  return sel, u, pn, None
+
+              @staticmethod
+              def done(idx, res, accepted):
+                  ok = np.ones(len(idx), dtype=bool)
+                  books(idx, ok, res["Hcur"], res["Hnew"], res["Unew"], res["x"], res.get("dsyn_new"), None, acc=accepted)
+                  for c in idx:
+                      pending.pop(int(c), None)
+                  return dict(dt=dt[idx], rem=sampler._traj_len(dt[idx]))
+
+              @staticmethod
+              def withdraw(idx):                      # nothing to rewind: process_done uses the early draws
+                  pass
+
+          left = None if max_steps is None else max_steps - self.flow_steps
+          base = self.flow_steps
+          hook = None if step_hook is None else (lambda s_, st_, _b=base: step_hook(_b + s_, st_))
+          nst = run_flow(self.model, st, process_done, lambda: bool(np.any((i < total) & (ncount < lim))),
+                         fetch_syn=syndata is not None, pipeline=pipeline, max_steps=left,
+                         step_hook=hook, restart=Restart if device_restart else None,
+                         async_handback=async_handback)
+          self.flow_steps += nst
+          capped = max_steps is not None and self.flow_steps >= max_steps
+          if capped and np.any((i < total) & (ncount < lim)):
+              break                                     # stopped inside a segment: no barrier state to keep
+          if target is None:
+              break
+          cur = target
+          if every and cur % every == 0 and np.any(i < total):
+              self._save_checkpoint(x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0, cur)
         self.finished = not bool(np.any(i < total))
         self.naccepted, self.ntrajectories = i.copy(), ncount.copy()
         if not self.finished:                    # stopped by max_steps: nothing is written

@@ -79,3 +79,50 @@ def test_device_run_resumed_from_a_checkpoint_is_bit_identical(kind, warm, tmp_p
     assert {"initmodel", "obs", "mean/model", "mean/syn", "model", "syn"} <= set(za)
     for k in za:
         assert np.array_equal(za[k], zb[k]), k
+
+
+@pytest.mark.parametrize("warm", [0, 1])
+@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
+def test_flow_schedule_resumed_from_a_checkpoint_is_bit_identical(kind, warm, tmp_path):
+    """sample_flow with a checkpoint: the flow runs in segments that end when every chain has completed
+    ``checkpoint_every`` more trajectories; the state at such a barrier is sample()'s (same file format).  A run cut
+    inside a later segment and continued by fresh objects from the last barrier equals the uninterrupted one bit for bit --
+    and, the schedules being equivalent, the batch schedule's run as well (compared with the warm start off: inside a
+    trajectory the batch schedule's steps and the flow's continue different evaluations)."""
+    b = _bounds()
+    x0 = np.hstack((VS, THK))[None, :] * (1 + 0.03 * np.random.default_rng(5).standard_normal((64, 2 * N)))
+    x0 = np.clip(x0, b[:, 0], b[:, 1]); x0[:, :N] = np.sort(x0[:, :N], axis=1)
+    ckf = str(tmp_path / "full.npz")
+    full = _sampler(kind, tmp_path / "a", warm_start=warm, checkpoint=ckf, checkpoint_every=2)
+    mis_full = full.sample_flow(x_init=x0)
+    assert full.finished and np.isfinite(mis_full).all()
+    ck = str(tmp_path / "state.npz")
+    part = _sampler(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2, warm_start=warm)
+    # stop a few device steps into the third segment (two barriers behind)
+    seen = {}
+    part.sample_flow(x_init=x0, max_steps=10 ** 6, step_hook=lambda s_, st: seen.setdefault("n", 0))
+    assert part.finished                               # (establish the step count of the whole run ...)
+    nsteps = part.flow_steps
+    os.remove(ck)
+    part = _sampler(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=2, warm_start=warm)
+    part.sample_flow(x_init=x0, max_steps=int(0.55 * nsteps))      # (... and cut a second run in the middle)
+    assert not part.finished and os.path.exists(ck)
+    del part
+    rest = _sampler(kind, tmp_path / "b", checkpoint=ck, warm_start=warm, checkpoint_every=2)   # fresh plugin + rfs_ctx + sampler
+    mis = rest.sample_flow(resume=True)
+    assert rest.finished
+    assert np.array_equal(mis, mis_full)
+    assert np.array_equal(rest.x_cache, full.x_cache) and np.array_equal(rest.syndata, full.syndata)
+    assert np.array_equal(rest.xmean, full.xmean) and np.array_equal(rest.synmean, full.synmean)
+    if warm == 0:
+        batch = _sampler(kind, tmp_path / "c", warm_start=0)
+        mb = batch.sample(x_init=x0)
+        assert np.array_equal(mb, mis_full) and np.array_equal(batch.x_cache, full.x_cache)
+        # ... and a checkpoint written by one schedule is continued by the other
+        ck2 = str(tmp_path / "mixed.npz")
+        p2 = _sampler(kind, tmp_path / "d", checkpoint=ck2, checkpoint_every=2, warm_start=0)
+        p2.sample(x_init=x0, max_trajectories=4)
+        assert not p2.finished
+        r2 = _sampler(kind, tmp_path / "d", checkpoint=ck2, checkpoint_every=2, warm_start=0)
+        m2 = r2.sample_flow(resume=True)
+        assert r2.finished and np.array_equal(m2, mis_full) and np.array_equal(r2.x_cache, full.x_cache)

@@ -284,6 +284,18 @@ def test_ensemble_mass_adaptation_on_the_device(golden):
     d = HMCDualAveraging(_joint(g), bounds, 0.02, 4, 2, 0.65, 991206, 4, 3, mass_adapt=[0, 2], **kw)
     md = d.sample(x_init=x)
     assert np.all(np.isfinite(md)) and d.inverse_mass is not None and np.all(d.dt_final > 0)
+    # the flow schedule adapts at the same trajectory counts (its segments end there): same estimate, same samples as the
+    # batch schedule (full search at every step: the two schedules then evaluate identically)
+    af = HamitonianMC(_joint(g, warm=0), bounds, 0.02, [3, 6], 2, 991206, 4, 2, mass_adapt=[0, 1], **kw)
+    maf = af.sample_flow(x_init=x)
+    ab = HamitonianMC(_joint(g, warm=0), bounds, 0.02, [3, 6], 2, 991206, 4, 2, mass_adapt=[0, 1], **kw)
+    mab = ab.sample(x_init=x)
+    assert np.array_equal(maf, mab) and np.array_equal(af.x_cache, ab.x_cache) and np.array_equal(af.inverse_mass, ab.inverse_mass)
+    df = HMCDualAveraging(_joint(g, warm=0), bounds, 0.02, 4, 2, 0.65, 991206, 4, 3, mass_adapt=[0, 2], **kw)
+    mdf = df.sample_flow(x_init=x)
+    db = HMCDualAveraging(_joint(g, warm=0), bounds, 0.02, 4, 2, 0.65, 991206, 4, 3, mass_adapt=[0, 2], **kw)
+    mdb = db.sample(x_init=x)
+    assert np.array_equal(mdf, mdb) and np.array_equal(df.dt_final, db.dt_final) and np.array_equal(df.inverse_mass, db.inverse_mass)
 
 
 def test_flow_step2_accepts_rejects_and_restarts_like_the_host(golden):

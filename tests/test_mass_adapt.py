@@ -115,13 +115,6 @@ def test_resume_carries_the_adapted_mass(kind, tmp_path):
     assert np.array_equal(rest.x_cache, full.x_cache)
 
 
-@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
-def test_flow_schedule_refuses_mass_adapt(kind, tmp_path):
-    smp = _make(kind, tmp_path, nchains=4, mass_adapt=[0])
-    with pytest.raises(ValueError, match="mass_adapt"):
-        smp.sample_flow(x_init=np.zeros((4, 6)))
-
-
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

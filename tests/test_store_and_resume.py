@@ -282,3 +282,32 @@ def test_device_restarts_with_failing_trajectories_keep_the_reference_draw_order
     assert runs["flow_dev"][3].flow_steps < runs["flow_host"][3].flow_steps
     if kind == "hmc":
         assert runs["flow_dev"][3].flow_withdrawn > 0 and runs["flow_dev_sync"][3].flow_withdrawn > 0  # the rewind was exercised
+
+
+@pytest.mark.parametrize("kind", ["hmc", "hmcda"])
+def test_flow_schedule_checkpoints_at_trajectory_counts(kind, tmp_path):
+    """sample_flow with checkpoint_every: segments that end when every chain has completed that many more trajectories.
+    The uninterrupted flow run, a run cut inside a later segment and resumed from its last barrier, the batch schedule,
+    and a checkpoint written by one schedule and continued by the other: the same samples, bit for bit."""
+    x0 = np.random.default_rng(2).normal(size=(5, 6))
+    ref = _make(kind, tmp_path / "r"); mr = ref.sample(x_init=x0)
+    full = _make(kind, tmp_path / "a", checkpoint=str(tmp_path / "a.npz"), checkpoint_every=3)
+    mf = full.sample_flow(x_init=x0)
+    assert full.finished and np.array_equal(mf, mr) and np.array_equal(full.x_cache, ref.x_cache)
+    ck = str(tmp_path / "b.npz")
+    part = _make(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=3)
+    part.sample_flow(x_init=x0, max_steps=int(0.6 * full.flow_steps))
+    assert not part.finished and os.path.exists(ck)
+    rest = _make(kind, tmp_path / "b", checkpoint=ck, checkpoint_every=3)
+    mres = rest.sample_flow(resume=True)
+    assert rest.finished and np.array_equal(mres, mr) and np.array_equal(rest.x_cache, ref.x_cache)
+    ck2 = str(tmp_path / "c.npz")
+    p2 = _make(kind, tmp_path / "c", checkpoint=ck2, checkpoint_every=3)
+    p2.sample(x_init=x0, max_trajectories=6)
+    assert not p2.finished
+    r2 = _make(kind, tmp_path / "c", checkpoint=ck2, checkpoint_every=3)
+    m2 = r2.sample_flow(resume=True)
+    assert r2.finished and np.array_equal(m2, mr)
+    r3 = _make(kind, tmp_path / "b2", checkpoint=ck, checkpoint_every=3)
+    m3 = r3.sample(resume=True)                   # ... and the flow's checkpoint by the batch schedule
+    assert r3.finished and np.array_equal(m3, mr)
