@@ -268,6 +268,11 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          between the limits of "rf_band_floor_digits" (default 8) and "rf_band_limit_digits" the band
  *                          ends there, so that no wavefront runs mostly idle (nt = 512, dt = 0.1, f0 = 1.5: 128 bins instead
  *                          of 150; measured difference to the unlimited gradient 8e-16).  0 = never move the limit down.
+ *                          Worst case: a dropped frequency carries at most 10^-floor x the weight of the strongest one, so
+ *                          the gradient's RELATIVE error is bounded by (dropped bins) x 10^-floor -- reached only where the
+ *                          water level clamps the spectrum beyond the band (a water level of order 0.1 with a small f0); the
+ *                          8e-16 / 1e-13 figures are those of spectra the water level does not clamp.  The same floor
+ *                          bounds the weight of the float32-swept bins in the forward trace ("rf_f32_beyond_band").
  *   "swd_warm_start"       the root search inside a trajectory.  The reference searches every model from scratch, period
  *                          after period (surfdisp96.f:257-316: ~23 secular evaluations per period, each period starting
  *                          from the root before it).  Inside a leapfrog trajectory the model of step s is the model of
@@ -311,8 +316,10 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          counts calls (rem steps = rem calls) must look at rem / done instead.  0 (default) = every call
  *                          completes every chain's step.  The samplers of pyhmc switch it on for sample_flow.
  *   "swd_warm_reset"       (any value) forget the previous evaluation: the next one goes through the reference-semantics
- *                          search for every chain.  A sampler calls it where a run may be cut and resumed (a checkpoint),
- *                          so that the resumed run and the uninterrupted one evaluate the same way from there on.
+ *                          search for every chain.  The samplers of pyhmc call it whenever they write a checkpoint, so
+ *                          that a resumed run and the uninterrupted one evaluate the same way from there on (their own
+ *                          schedules start every trajectory batch / flow segment from the full search anyway; a caller's
+ *                          host-side leapfrog loop with swd_warm_start = 2 needs the call).
  *   "swd_warm_serial"      1: a warm-started step runs on ONE stream (every kernel alone on the chip: clean per-kernel
  *                          durations for profiling); 0 (default): the surface-wave kernels on a second stream beside the
  *                          receiver-function sweeps (~5 % faster).  Results are identical.

@@ -167,7 +167,7 @@ RFS_HD V4 rf_row_times_A(const V4& r, const RfA& A) {   // r' = r . A
     return o;
 }
 
-// How much the layer matrices of a chain can grow: sum over the finite layers of h (sigma |Im p_beta| + w_max (|Re p_alpha| +
+// How much the layer matrices of a chain can grow: sum over the finite layers of h (sigma (|Im p_alpha| + |Im p_beta|) + w_max (|Re p_alpha| +
 // |Re p_beta|)) -- the exponent of exp(+- nu h) at the band's highest frequency (nu = omega p_v, omega = w - i sigma: the
 // damping acts on the propagating S leg, the larger one; a post-critical leg is evanescent in full).  Peeling a row off with A^-1 loses exp(2 x this) of relative accuracy, so a chain peels only below
 // RF_PEEL_EMAX (1e-16 e^{10} = 2e-12; a soak of 600 random configurations: gradients within 4e-11 of the stored-row sweep at 6); deeper / slower stacks, shorter windows (sigma = 4 / window) or post-critical
@@ -175,7 +175,8 @@ RFS_HD V4 rf_row_times_A(const V4& r, const RfA& A) {   // r' = r . A
 constexpr double RF_PEEL_EMAX = 5.0;
 RFS_HD double rf_growth_exponent(const RfLayer* L, int n, double sigma, double wmax) {
     double e = 0.0;
-    for (int j = 0; j < n - 1; j++) e += L[j].h * (sigma * fabs(L[j].pvb.im) + wmax * (fabs(L[j].pva.re) + fabs(L[j].pvb.re)));
+    for (int j = 0; j < n - 1; j++)
+        e += L[j].h * (sigma * (fabs(L[j].pvb.im) + fabs(L[j].pva.im)) + wmax * (fabs(L[j].pva.re) + fabs(L[j].pvb.re)));
     return e;
 }
 

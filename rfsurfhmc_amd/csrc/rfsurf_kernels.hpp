@@ -114,7 +114,7 @@ __device__ __forceinline__ double wave_max(double v) {
 __device__ __forceinline__ double rf_growth_exponent_wave(const RfLayer* __restrict__ L, int n, double sigma, double wmax) {
     double e = 0.0;
     for (int j = threadIdx.x & 63; j < n - 1; j += 64)
-        e += L[j].h * (sigma * fabs(L[j].pvb.im) + wmax * (fabs(L[j].pva.re) + fabs(L[j].pvb.re)));
+        e += L[j].h * (sigma * (fabs(L[j].pvb.im) + fabs(L[j].pva.im)) + wmax * (fabs(L[j].pva.re) + fabs(L[j].pvb.re)));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off, 64);
     return e;
@@ -342,6 +342,16 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
         for (int i = 0; i < 4; i++) rd.v[i] = C((double)cf_re(r.v[i]), (double)cf_im(r.v[i]));
         cplx r21, r22;
         rf_r21_r22(f, rd, r21, r22);
+        // (rf_r21_r22 scrubs NaN to 0 like the reference, RFModule.f90:662-667 -- for a FLOAT32 result that would understate the
+        // maxima k_rf_mid1 builds its proof on: an overflowed or undefined float32 value goes on as +inf instead, the
+        // verdict is then "sweep again in f64" and the f64 sweep decides what the reference's scrub sees)
+        bool finite32 = true;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float a = cf_re(r.v[i]), b = cf_im(r.v[i]);
+            finite32 = finite32 && (a - a == 0.0f) && (b - b == 0.0f);
+        }
+        if (!finite32) r21 = C(__longlong_as_double(0x7ff0000000000000LL), 0.0);
         o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
         return;
     }
@@ -1064,7 +1074,8 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
     // sequence walks the grid as well.
     if (!irregular && sg <= 1 && sk > 0.0 && sk < ck) {
         const double gup = sk + (floor((ck - sk) / dcs) + 1.0) * dcs;
-        if (gup > (double)W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain]) { W.wide[chain] = 1; irregular = true; }
+        // (no write to `wide` here: other items of the chain read it in this very launch; the walk reads `irr` instead)
+        if (gup > (double)W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain]) irregular = true;
     }
     if (irregular) {                                                 // -> k_swd_warm_walk, one 16-lane group per item
         if (atomicExch(&W.irr[chain], 1) == 0) W.ilist[atomicAdd(W.icount, 1)] = chain;
@@ -1121,7 +1132,7 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
         bool irregular = false;
         for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
-        irregular = irregular || W.wide[chain] != 0;
+        irregular = irregular || W.wide[chain] != 0 || W.irr[chain] != 0;      // (irr: set by the branch test, launch before this one)
         live = live && irregular && !W.need[chain];
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};

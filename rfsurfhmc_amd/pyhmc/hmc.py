@@ -372,6 +372,8 @@ class HamitonianMC:
         return misfit[0] if nc == 1 else misfit
 
     def _save_checkpoint(self, x, U, i, ncount, misfit, x_cache, syndata, ntraj):
+        if hasattr(self.model, "reset_warm_start"):      # the run may be cut here: what follows starts from the full search, as a resumed run would
+            self.model.reset_warm_start()
         save_checkpoint(self.checkpoint, self.rng, x=x, U=U, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,
                         syndata=syndata, initmodel=self.initmodel, ii=self.ii, ntraj=ntraj,
                         inverse_mass=self.inverse_mass)

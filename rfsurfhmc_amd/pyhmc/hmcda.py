@@ -451,6 +451,8 @@ class HMCDualAveraging:
         return self._finish(misfit, x_cache, syndata, i, ncount, dt)
 
     def _save_checkpoint(self, x, i, ncount, misfit, x_cache, syndata, dt, dtbar, h0, ntraj):
+        if hasattr(self.model, "reset_warm_start"):      # the run may be cut here: what follows starts from the full search, as a resumed run would
+            self.model.reset_warm_start()
         save_checkpoint(self.checkpoint, self.rng, x=x, i=i, ncount=ncount, misfit=misfit, x_cache=x_cache,
                         syndata=syndata, initmodel=self.initmodel, ii=self.ii, dt=dt, dtbar=dtbar, h0=h0, ntraj=ntraj,
                         inverse_mass=self.inverse_mass)

@@ -50,6 +50,32 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
         assert np.array_equal(np.load(dump1), g[rk * 256:(rk + 1) * 256]), rk
 
 
+def test_bench_two_ranks_on_two_gpus_over_rccl(tmp_path):
+    """Where the box has two GPUs: the same two-rank job with one rank per device and backend "nccl" (RCCL) -- the process
+    group, the barriers and max-over-ranks timing, and gather_misfits on DEVICE tensors.  Skipped on a one-GPU box (the
+    builder's; the driver's multi-GPU node runs it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    args = ["--chains", "256", "--steps", "2", "--warmup", "2", "--no-cpu-baseline"]
+    dump2 = str(tmp_path / "two.npy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=_env({"RFS_BENCH_DUMP": dump2}))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["chains_per_gpu"] == 256 and d["scaling"] == "weak"
+    assert "FUNCTIONAL CHECK" not in d["config"]["parallelism"]
+    g = np.load(dump2)
+    assert g.shape == (512,) and np.isfinite(g).all() and (g > 0).all()
+    for rk in (0, 1):                                                  # rank r's block = the single-rank job of its chains
+        dump1 = str(tmp_path / f"one{rk}.npy")
+        r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--seed-rank", str(rk),
+                             "--headline-only"] + args, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                            env=_env({"RFS_BENCH_DUMP": dump1}))
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        assert np.array_equal(np.load(dump1), g[rk * 256:(rk + 1) * 256]), rk
+
+
 def test_example_driver_two_ranks_share_the_gpu(tmp_path):
     """examples/main_hmc.py (the role of main_base.py) under torch.distributed.run with two ranks on GPU 0: rank 0
     broadcasts the observed data, every rank samples its own chains, rank 0 gathers [total_chains, nsamples]."""

@@ -305,3 +305,32 @@ def test_row_peeling_closure_residual(hip, orc):
         res[p] = ctx.stat("rf_peel_residual") * 1e-18
     assert 0 < res[0.06] < 1e-12, res
     assert res[0.22] > 100 * res[0.06], res
+
+
+def test_band_limit_where_the_water_level_clamps_the_spectrum(hip, orc):
+    """The band limit's stated worst case (include/rfsurf.h, rf_band_floor_digits): a large water level (0.1) with a low
+    Gaussian (f0 = 0.6) clamps the spectrum over most of the axis, so the frequencies the adjoint sweep drops are not
+    negligible against the kept ones by their |R21|^2, only by their Gaussian weight: the gradient with the default limits
+    (13 / 8 digits) against the unlimited sum and against the oracle -- within the floor's bound (bins x 1e-8), far inside
+    the 1e-5 contract."""
+    n, nt, dt = 30, 512, 0.1
+    rng = np.random.default_rng(9)
+    vs0 = np.linspace(2.4, 4.6, n); thk0 = np.full(n, 2.0); thk0[-1] = 0
+    xs = np.tile(np.hstack((vs0, thk0)), (24, 1))
+    xs[:, :n] = np.sort(xs[:, :n] * (0.9 + 0.2 * rng.random((24, n))), axis=1); xs[:, n:2 * n - 1] *= 0.8 + 0.4 * rng.random((24, n - 1))
+    args = (0.05, nt, dt, 0.6, 5.0, 0.1, "P", "freq")
+    o_rf = orc.ReceiverFunc(*args)
+    d0 = o_rf.forward(np.hstack((vs0, thk0))); o_rf.set_obsdata(d0)
+    out = {}
+    for digits in (13, 0):
+        rf = hip.ReceiverFunc(*args); rf.set_obsdata(d0)
+        rf._ensure(n).set_option("rf_band_limit_digits", digits)
+        out[digits] = rf.misfit_and_grad(xs)
+    a, b = out[13], out[0]
+    assert rel(a[2], b[2]) < 1e-9 and np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(b[0]).max()
+    worst = max(rel(a[1][i], b[1][i]) for i in range(len(xs)))
+    print(f"band limit under a clamping water level: gradient differs from the unlimited sum by {worst:.2e}")
+    assert worst <= 257 * 1e-8
+    for i in (0, 11, 23):
+        mo, go, do = o_rf.misfit_and_grad(xs[i])
+        assert rel(a[1][i], go) < 1e-5 and rel(a[2][i], do) < 1e-8 and abs(a[0][i] - mo) <= 1e-8 * mo
