@@ -58,6 +58,8 @@ struct rfs_ctx {
     // user/main stream; SWD search stream; CU-partitioned pair (search on one half of the chip, RF on the other)
     hipStream_t stream = nullptr, stream2 = nullptr, stream2m = nullptr, stream3 = nullptr;
     hipStream_t stream_l = nullptr;     // Love root search beside the Rayleigh one (unpartitioned steps)
+    hipStream_t stream_w = nullptr;     // the grid walk of irregular sequences beside the reference-root stage (background form of the flow entries)
+    hipEvent_t ev_wk[2] = {nullptr, nullptr};
     hipEvent_t ev_lf = nullptr, ev_lj = nullptr;
     bool own_stream = false;
     int early_eigen = -1;      // periods whose eigenfunction kernels run early on the RF half: -1 automatic, 0 off
@@ -101,7 +103,7 @@ struct rfs_ctx {
     const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
-    int exact_group = 5, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
+    int exact_group = 3, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
@@ -734,6 +736,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     int* sflagL = c->sflag.as<int>() + (size_t)P.QR.nseq * nchain;
     hipStream_t warm_side = nullptr;         // side stream carrying the full search of the chains a warm start handed back
     bool bg_record = false;                  // this step's searches of handed-back chains stay in the background
+    bool walk_join = false;                  // the grid walk ran on its own stream: this stream joins it behind the eigenfunction pass
     if (!(warm && roots)) {
         // whatever comes now rewrites the root buffer: every background search still under way has to be through
         for (int i = 0; i < RFS_BG_SLOTS; i++)
@@ -841,22 +844,28 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // ... sequences with anomalous dispersion: the reference's scan grid itself -- 64 lanes per item for the first period
         // of a sequence (a scan of ~100 cells), 16 for the others (grids: sized for a share of the chains, the number of
         // irregular ones is only known on the device -- the blocks stride)
+        // (background form with a stream to spare: the walk runs BESIDE the reference-root stage -- that stage does not need its
+        // verdicts, a chain the walk declines afterwards just sits the step out like any other -- and the search of the
+        // handed-back chains and the end of the step wait for both)
+        hipStream_t sw = (async && c->stream_w && c->warm_exact) ? c->stream_w : s;
+        if (sw != s) { HIPCHK(c, hipEventRecord(c->ev_wk[0], s)); HIPCHK(c, hipStreamWaitEvent(sw, c->ev_wk[0], 0)); }
         {
             const int gw = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 4 + 15) / 16)));
             const int g1 = std::max(64, std::min(2048, nchain / 4));
             if (Q.nper_total > 0) {
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, true>), dim3(g1), dim3(64), 0, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, true>), dim3(g1), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                    c->croot.as<double>(), W);
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, false>), dim3(gw), dim3(64), 0, s, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                    c->croot.as<double>(), W);
             }
             if (P.QL.nper_total > 0) {
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, true>), dim3(g1), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, true>), dim3(g1), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
                                    c->mdlcL.as<double>(), c->croot.as<double>(), W);
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, false>), dim3(gw), dim3(64), 0, s, nchain, n, P.QL, c->mdlL.as<float>(),
+                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
                                    c->mdlcL.as<double>(), c->croot.as<double>(), W);
             }
         }
+        if (sw != s) HIPCHK(c, hipEventRecord(c->ev_wk[1], sw));
         HIPCHK(c, hipGetLastError());
         // the chains the branch test handed back (and, on one stream, those of the first list)
         if (async) {}
@@ -884,8 +893,10 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
             if (!async) TRY(launch_fallback(W.list3, W.count3, 64));
         }
+        walk_join = sw != s;
         if (async) {
             if (!c->warm_exact) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
+            if (walk_join) HIPCHK(c, hipStreamWaitEvent(sf, c->ev_wk[1], 0));
             TRY(launch_fallback(W.list, W.count, est));
             if (c->h_wcount) {
                 if (*c->h_wcount >= 0) c->warm_est = *c->h_wcount;
@@ -1004,6 +1015,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
 #undef RFS_LAUNCH_EIGEN2
         HIPCHK(c, hipGetLastError());
         }
+        if (walk_join) HIPCHK(c, hipStreamWaitEvent(s, c->ev_wk[1], 0));      // (the caller joins this stream: k_flow_post needs the walk's verdicts)
         if (bg_record) {
             HIPCHK(c, hipEventRecord(c->ev_bg[c->wpar], warm_side));
             c->bg_busy[c->wpar] = true;
@@ -1403,6 +1415,12 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < RFS_BG_SLOTS; i++) ok = hipEventCreateWithFlags(&c->ev_bg[i], hipEventDisableTiming) == hipSuccess;
+    // (RFS_WALK_STREAM=0 in the environment: the walk stays on the surface-wave stream -- A/B measurements.  Measured at the bench's
+    // configuration with the default four hardware queues: 7.05 -> 6.47 ms per step; with GPU_MAX_HW_QUEUES = 6 / 8: 6.8)
+    if (ok && !(getenv("RFS_WALK_STREAM") && atoi(getenv("RFS_WALK_STREAM")) == 0))
+        ok = hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_wk[0], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_wk[1], hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
     c->own_stream = true;
     hipDeviceProp_t prop;
@@ -1429,6 +1447,8 @@ void rfs_destroy(rfs_ctx* c) {
     if (c->h_scount) hipHostFree(c->h_scount);
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
     for (auto e : c->ev_bg) if (e) hipEventDestroy(e);
+    for (auto e : c->ev_wk) if (e) hipEventDestroy(e);
+    if (c->stream_w) hipStreamDestroy(c->stream_w);
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -1458,6 +1478,7 @@ int rfs_synchronize(rfs_ctx* c) {
     if (!c) return RFS_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->stream_l) HIPCHK(c, hipStreamSynchronize(c->stream_l));
+    if (c->stream_w) HIPCHK(c, hipStreamSynchronize(c->stream_w));
     if (c->stream2m) HIPCHK(c, hipStreamSynchronize(c->stream2m));
     if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     HIPCHK(c, hipStreamSynchronize(c->stream));
