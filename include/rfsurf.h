@@ -343,6 +343,10 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          frequency can reach a water level set by 1.01 x the float32 maxima; otherwise that chain's
  *                          frequencies are swept again in f64 (rfs_get_stat "rf_f32_resweeps").  Trace, misfit and gradient
  *                          equal the all-f64 sweep to a few 1e-13.  0 = f64 for every frequency.
+ *   "rf_mid_fused"         1 (default): the middle section of the frequency-domain gradient -- water level, spectrum, inverse FFT,
+ *                          trace, residual, misfit, forward FFT of the weighted residual -- runs as ONE kernel with a chain's 4 KB
+ *                          in LDS (FFT lengths 16 .. 4096) instead of two kernels around two rocFFT calls; same numbers to
+ *                          rounding (1e-15).  librf's entries, the forward-only calls and the time domain always use rocFFT.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.

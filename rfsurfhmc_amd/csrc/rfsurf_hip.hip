@@ -119,6 +119,9 @@ struct rfs_ctx {
     Buf slist, scount;                    // chains of a peeling evaluation that kept stored rows (k_rf_passA -> k_rf_passB<., false>)
     int* h_scount = nullptr; int* d_hscount = nullptr; int stored_est = -1; unsigned speel_eval = 0;   // their number in an earlier evaluation (host-mapped word the device writes; -1 = unknown); evaluation parity of the two counters
     Buf RT, rstat;                        // final rows of pass A (row peeling, k_rf_passB<., true>); closure residual of the peeling
+    int rf_mid_fused = 1;                 // option "rf_mid_fused": the middle section of the frequency-domain gradient in one kernel (k_rf_mid_fused) instead of k_rf_mid1 / rocFFT / k_rf_mid2 / rocFFT
+    Buf twid; int twid_nft = 0;           // exp(-2 pi i j / nft), j <= nft / 2
+    Buf gtab, etab; double mid_tab_key[6] = {0, 0, 0, 0, 0, 0};   // chain-independent factors of the fused middle section (k_rf_mid_tables)
     int rf_f32 = RFS_F32_DEFAULT;                       // option "rf_f32_beyond_band": pass A sweeps the frequencies beyond the gradient's band in float32 where that is provably enough
     Buf hi32, stat32;                     // [chain] pass A's choice; [66] chains swept again in f64 by k_rf_mid1, chains swept in float32 (64 slots)
     int rf_peel_check = 0;                // option "rf_peel_check": pass B records the closure residual (statistic rf_peel_residual)
@@ -362,6 +365,45 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
 // (mrf: per-chain RF misfits of the whole batch, written at [c0, c0 + nchain); every other buffer is tile-local)
 int launch_mid(rfs_ctx* c, int nchain, int n, const RfFreq& f, const double* dobs, int ndata, double* dsyn,
                bool adjoint, size_t c0 = 0, size_t nchain_total = 0) {
+    if (adjoint && dobs && c->rf_mid_fused && f.method == RFS_RF_FREQ && f.nft >= 16 && f.nft <= 4096) {
+        // the gradient's middle section in one kernel, one chain per block, in LDS (k_rf_mid_fused)
+        if (c->twid_nft != f.nft) {
+            std::vector<cplx> tw((size_t)f.nft / 2 + 1);
+            for (size_t j = 0; j < tw.size(); j++) {
+                const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)f.nft;
+                tw[j] = C((double)cosl(a), (double)sinl(a));
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            ENSURE(c, c->twid, tw.size() * sizeof(cplx));
+            HIPCHK(c, hipMemcpy(c->twid.p, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice));
+            c->twid_nft = f.nft;
+            c->mid_tab_key[0] = 0.0;
+        }
+        const double key[6] = {(double)f.nft, f.dt, f.f0, f.t0, f.sigma, (double)f.nt};
+        if (std::memcmp(key, c->mid_tab_key, sizeof(key)) != 0) {
+            ENSURE(c, c->gtab, (size_t)f.n2 * sizeof(cplx)); ENSURE(c, c->etab, (size_t)std::max(f.nt, 1) * sizeof(double));
+            const int nthr = std::max(f.n2, f.nt);
+            hipLaunchKernelGGL(k_rf_mid_tables, dim3((nthr + 255) / 256), dim3(256), 0, c->stream, f, c->gtab.as<cplx>(), c->etab.as<double>());
+            HIPCHK(c, hipGetLastError());
+            std::memcpy(c->mid_tab_key, key, sizeof(key));
+        }
+        ENSURE(c, c->wmax2, (size_t)nchain * sizeof(double));
+        ENSURE(c, c->mrf, std::max((size_t)nchain, nchain_total) * sizeof(double));
+        ENSURE(c, c->W, (size_t)nchain * f.n2 * sizeof(cplx));
+        const int* hi = nullptr; unsigned long long* st = nullptr;
+        if (rf_f32_on(c, f)) {
+            if (!c->stat32.p) { ENSURE(c, c->stat32, 66 * sizeof(unsigned long long)); HIPCHK(c, hipMemsetAsync(c->stat32.p, 0, 66 * sizeof(unsigned long long), c->stream)); }
+            hi = c->hi32.as<int>(); st = c->stat32.as<unsigned long long>();
+        }
+        int logN = 0;
+        while ((1 << (logN + 1)) < f.nft) logN++;
+        const size_t lds = ((size_t)f.nft / 2 + 1) * sizeof(cplx);
+        hipLaunchKernelGGL(k_rf_mid_fused, dim3(nchain), dim3(128), lds, c->stream, n, f, logN, c->lc.as<RfLayer>() + c0 * n,
+                           c->RR.as<double>(), c->wmax2.as<double>(), c->twid.as<cplx>(), c->gtab.as<cplx>(), c->etab.as<double>(), dobs, ndata, dsyn,
+                           c->mrf.as<double>() + c0, c->W.as<cplx>(), hi, st);
+        HIPCHK(c, hipGetLastError());
+        return RFS_OK;
+    }
     // rocFFT plans are per batch size; varying chain counts (length-sorted trajectories) are rounded up to a
     // multiple of 256 so that a handful of cached plans serve them all (the padding transforms stale data)
     const size_t nb = nchain > 256 ? ((size_t)nchain + 255) / 256 * 256 : (size_t)nchain;
@@ -1441,7 +1483,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1539,6 +1581,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value, c->rf_band_floor); }
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
+    }
+    if (!strcmp(name, "rf_mid_fused")) {
+        if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "rf_mid_fused must be 0 or 1");
+        c->rf_mid_fused = value; return RFS_OK;
     }
     if (!strcmp(name, "rf_f32_beyond_band")) {
         if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "rf_f32_beyond_band must be 0 or 1");

@@ -382,21 +382,14 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
 // 411-413) and the RF spectrum S = conj(R21) R22 G e^{-i w t0} / fai (:401), with the
 // imaginary parts of DC / Nyquist zeroed (FFTW's c2r ignores them, rocFFT must not see them).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_rf_mid1(int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR, double* __restrict__ wmax2,
-          cplx* __restrict__ spec, const int* __restrict__ hi32, unsigned long long* __restrict__ stat32)
+// the first half of k_rf_mid1 (water-level maxima; float32 verdict and re-sweep), shared by the fused kernel
+__device__ __forceinline__ void rf_mid_maxima(int n, const RfFreq& f, const RfLayer* __restrict__ lc, double* __restrict__ rr, int chain,
+                                              const int* __restrict__ hi32, unsigned long long* __restrict__ stat32,
+                                              double (*red)[4], double& m1, double& m2)
 {
-    __shared__ double red[6][4];
-    int chain = blockIdx.x, tid = threadIdx.x;
-    double* rr = RR + (size_t)chain * 4 * f.n2p;
-    const int wv = tid >> 6, nw = blockDim.x >> 6;
-    // Pass A swept this chain's frequencies beyond the band in float32 (h32): the maxima are taken apart -- band values are
-    // exact, the others carry a relative error below RF_F32_MARGIN.  Where the band holds both maxima, or no band
-    // frequency can reach a water level set by (1 + margin) x the others' maxima, every number that reaches the results
-    // with a weight above exp(-(w_nk/2f0)^2) is what the all-f64 sweep gives; otherwise the block sweeps those
-    // frequencies again in f64 (statistic rf_f32_resweeps) and nothing of the float32 pass is left.
+    const int tid = threadIdx.x, wv = tid >> 6, nw = blockDim.x >> 6;
     bool h32 = hi32 && hi32[chain] != 0;
-    double m1 = 0.0, m2 = 0.0;
+    m1 = 0.0; m2 = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         double b1 = 0.0, b2 = 0.0, h1 = 0.0, h2 = 0.0, lo1 = 1.0e300, lo2 = 1.0e300;
         for (int k = tid; k < f.n2; k += blockDim.x) {
@@ -432,6 +425,22 @@ k_rf_mid1(int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ 
         __syncthreads();
         h32 = false;
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_rf_mid1(int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR, double* __restrict__ wmax2,
+          cplx* __restrict__ spec, const int* __restrict__ hi32, unsigned long long* __restrict__ stat32)
+{
+    __shared__ double red[6][4];
+    int chain = blockIdx.x, tid = threadIdx.x;
+    double* rr = RR + (size_t)chain * 4 * f.n2p;
+    // Pass A swept this chain's frequencies beyond the band in float32 (hi32): the maxima are taken apart -- band values are
+    // exact, the others carry a relative error below RF_F32_MARGIN.  Where the band holds both maxima, or no band
+    // frequency can reach a water level set by (1 + margin) x the others' maxima, every number that reaches the results
+    // with a weight above exp(-(w_nk/2f0)^2) is what the all-f64 sweep gives; otherwise the block sweeps those
+    // frequencies again in f64 (statistic rf_f32_resweeps) and nothing of the float32 pass is left (rf_mid_maxima).
+    double m1, m2;
+    rf_mid_maxima(n, f, lc, rr, chain, hi32, stat32, red, m1, m2);
     if (tid == 0) wmax2[chain] = m2;
     for (int k = tid; k < f.n2; k += blockDim.x) {
         cplx r21 = C(rr[k], rr[f.n2p + k]), r22 = C(rr[2 * f.n2p + k], rr[3 * f.n2p + k]);
@@ -443,6 +452,132 @@ k_rf_mid1(int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ 
         cplx S = (conj(r21) * r22) * (g / fai) * C(c, -s);
         if (k == 0 || k == f.n2 - 1) S.im = 0.0;
         spec[(size_t)chain * f.n2 + k] = S;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 fused (round 4): the whole middle section of the frequency-domain gradient for one chain per block, in LDS --
+// water level -> spectrum (k_rf_mid1) -> inverse real FFT -> rf(t), residual, misfit, weighted residual (k_rf_mid2) ->
+// forward real FFT -> W_k for the adjoint sweep.  One launch and 4 KB of LDS per chain instead of five launches (two of
+// them rocFFT's) that each wait for wave slots beside the surface-wave kernels: 1.35 -> ~0.4 ms of the RF stream inside a
+// step (0.12 ms of kernel time either way).  rocFFT keeps librf's entries (B1), the forward-only calls and the time domain.
+// The real transforms of length M = nft ride on a complex radix-2 FFT of length N = M / 2 (tw[j] = exp(-2 pi i j / M),
+// j <= N: one table per nft, made on the host):
+//   c2r  Z_k = (S_k + conj S_{N-k}) + i conj(tw_k) (S_k - conj S_{N-k}), z = N-point inverse FFT (unnormalised), x[2t] + i x[2t+1] = z_t
+//   r2c  z_t = x[2t] + i x[2t+1], Z = N-point FFT, X_k = (Z_k + conj Z_{N-k}) / 2 - (i / 2) tw_k (Z_k - conj Z_{N-k}),  Z_N = Z_0
+// -- the values rocFFT's c2r / r2c give (unnormalised, e^{-} forward) to rounding (2e-16 relative against numpy).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_fft_pow2(cplx* __restrict__ z, int N, int logN, const cplx* __restrict__ tw, int M, bool inverse)
+{
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int i = tid; i < N; i += nth) {                      // bit reversal
+        const int r = (int)(__brev((unsigned)i) >> (32 - logN));
+        if (i < r) { const cplx a = z[i]; z[i] = z[r]; z[r] = a; }
+    }
+    __syncthreads();
+    for (int st = 1; st <= logN; st++) {
+        const int len = 1 << st, half = len >> 1, step = M / len;
+        for (int b = tid; b < (N >> 1); b += nth) {
+            const int grp = b / half, j = b - grp * half;
+            const int i0 = grp * len + j, i1 = i0 + half;
+            cplx w = tw[j * step];                              // exp(-2 pi i j / len)
+            if (inverse) w = conj(w);
+            const cplx t = w * z[i1], u = z[i0];
+            z[i0] = u + t; z[i1] = u - t;
+        }
+        __syncthreads();
+    }
+}
+
+// gtab[k] = exp(-(w_k / 2 f0)^2) exp(-i w_k t0), etab[t] = exp(sigma (t dt - t0)) / dt: the chain-independent factors, made once
+// per configuration (k_rf_mid_tables)
+__global__ void k_rf_mid_tables(RfFreq f, cplx* __restrict__ gtab, double* __restrict__ etab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < f.n2) {
+        const double w = rf_wk(f, i);
+        const double g = exp(-((w / 2 / f.f0) * (w / 2 / f.f0)));
+        double s, c; sincos(w * f.t0, &s, &c);
+        gtab[i] = C(g * c, -g * s);
+    }
+    if (i < f.nt) etab[i] = exp(f.sigma * (-f.t0 + i * f.dt)) / f.dt;
+}
+
+__global__ void __launch_bounds__(128)
+k_rf_mid_fused(int n, RfFreq f, int logN, const RfLayer* __restrict__ lc, double* __restrict__ RR, double* __restrict__ wmax2,
+               const cplx* __restrict__ tw, const cplx* __restrict__ gtab, const double* __restrict__ etab,
+               const double* __restrict__ dobs, int ndata, double* __restrict__ dsyn,
+               double* __restrict__ misfit_rf, cplx* __restrict__ Wout, const int* __restrict__ hi32,
+               unsigned long long* __restrict__ stat32)
+{
+    extern __shared__ double lds_mid[];
+    __shared__ double red[6][4];
+    cplx* z = (cplx*)lds_mid;                                 // N + 1 complex numbers
+    const int chain = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int M = f.nft, N = M >> 1;
+    double* rr = RR + (size_t)chain * 4 * f.n2p;
+    double m1, m2;
+    rf_mid_maxima(n, f, lc, rr, chain, hi32, stat32, red, m1, m2);
+    if (tid == 0) wmax2[chain] = m2;
+    // spectrum (RFModule.f90:393-401), Im of the DC and Nyquist bins dropped as FFTW's c2r does
+    for (int k = tid; k <= N; k += nth) {
+        cplx r21 = C(rr[k], rr[f.n2p + k]), r22 = C(rr[2 * f.n2p + k], rr[3 * f.n2p + k]);
+        double wa = (r21 * conj(r21)).re;
+        double fai = fmax(wa, f.water * m1);
+        cplx S = (conj(r21) * r22) * (1.0 / fai) * gtab[k];
+        if (k == 0 || k == N) S.im = 0.0;
+        z[k] = S;
+    }
+    __syncthreads();
+    // c2r: pairs (k, N - k) in place
+    for (int k = tid; k <= (N >> 1); k += nth) {
+        const int kb = N - k;
+        const cplx a = z[k], b = z[kb];
+        const cplx ac = conj(a), bc = conj(b);
+        const cplx zk = (a + bc) + mul_i(conj(tw[k]) * (a - bc));
+        const cplx zb = (b + ac) + mul_i(conj(tw[kb]) * (b - ac));
+        z[k] = zk;
+        if (kb != k && kb < N) z[kb] = zb;
+    }
+    __syncthreads();
+    lds_fft_pow2(z, N, logN, tw, M, true);
+    // rf(t) = x(t) / nft / dt * exp(sigma (t dt - t0)) (:404-407), residual, misfit, weighted residual -- packed for the r2c
+    double acc = 0.0;
+    for (int t2 = tid; t2 < N; t2 += nth) {
+        const cplx v = z[t2];
+        double wv[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int t = 2 * t2 + q;
+            const double x = q ? v.im : v.re;
+            wv[q] = 0.0;
+            if (t < f.nt) {
+                const double e = etab[t];                      // exp(sigma (t dt - t0)) / dt
+                const double rf = x / f.nft * e;
+                if (dsyn) dsyn[(size_t)chain * ndata + t] = rf;
+                const double r = rf - dobs[t];
+                acc += r * r;
+                wv[q] = r * e;
+            }
+        }
+        z[t2] = C(wv[0], wv[1]);
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) red[0][tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0 && misfit_rf) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(nth >> 6); i++) s += red[0][i];
+        misfit_rf[chain] = 0.5 * s;
+    }
+    lds_fft_pow2(z, N, logN, tw, M, false);
+    // r2c post-processing -> W_k, k = 0 .. N
+    cplx* W = Wout + (size_t)chain * f.n2;
+    for (int k = tid; k <= N; k += nth) {
+        const cplx a = z[k == N ? 0 : k], b = conj(z[(N - k) == N ? 0 : (N - k)]);
+        const cplx x = (a + b) * 0.5 - mul_i(tw[k] * (a - b)) * 0.5;
+        W[k] = x;
     }
 }
 

@@ -334,3 +334,30 @@ def test_band_limit_where_the_water_level_clamps_the_spectrum(hip, orc):
     for i in (0, 11, 23):
         mo, go, do = o_rf.misfit_and_grad(xs[i])
         assert rel(a[1][i], go) < 1e-5 and rel(a[2][i], do) < 1e-8 and abs(a[0][i] - mo) <= 1e-8 * mo
+
+
+@pytest.mark.parametrize("nt,dt", [(512, 0.1), (2048, 0.025), (125, 0.4), (20, 1.0), (4000, 0.0125)])
+def test_fused_middle_section_equals_the_rocfft_path(hip, orc, nt, dt):
+    """Option rf_mid_fused (default on): spectrum -> inverse real FFT -> trace, residual, misfit -> forward real FFT in one
+    kernel, a chain's transform in LDS (radix-2 on the packed half-length complex sequence), against the same section
+    with rocFFT's c2r / r2c around k_rf_mid1 / k_rf_mid2: trace, misfit and gradient to rounding, and both against the
+    oracle.  FFT lengths 32 .. 4096."""
+    n = 12
+    rng = np.random.default_rng(nt)
+    vs0 = np.linspace(2.6, 4.5, n); thk0 = np.full(n, 4.0); thk0[-1] = 0
+    xs = np.tile(np.hstack((vs0, thk0)), (33, 1))
+    xs[:, :n] = np.sort(xs[:, :n] * (0.9 + 0.2 * rng.random((33, n))), axis=1); xs[:, n:2 * n - 1] *= 0.8 + 0.4 * rng.random((33, n - 1))
+    args = (0.05, nt, dt, 1.5, 5.0, 0.001, "P", "freq")
+    o_rf = orc.ReceiverFunc(*args)
+    d0 = o_rf.forward(np.hstack((vs0, thk0))); o_rf.set_obsdata(d0)
+    out = {}
+    for opt in (1, 0):
+        rf = hip.ReceiverFunc(*args); rf.set_obsdata(d0)
+        rf._ensure(n).set_option("rf_mid_fused", opt)
+        out[opt] = rf.misfit_and_grad(xs)
+    a, b = out[1], out[0]
+    assert np.abs(a[2] - b[2]).max() <= 1e-13 * np.abs(b[2]).max()
+    assert np.abs(a[0] - b[0]).max() <= 1e-12 * np.abs(b[0]).max() and rel(a[1], b[1]) < 1e-12
+    for i in (0, 16, 32):
+        mo, go, do = o_rf.misfit_and_grad(xs[i])
+        assert rel(a[1][i], go) < 1e-8 and rel(a[2][i], do) < 1e-8 and abs(a[0][i] - mo) <= 1e-9 * mo
