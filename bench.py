@@ -407,7 +407,7 @@ def make_joint(cfg, local_rank):
     drf, dswd, flag = joint.forward(x_true)
     assert flag
     joint.set_obsdata(drf, dswd)
-    for opt, env in (("swd_exact_group", "RFS_EXACT_GROUP"), ("swd_exact_runup", "RFS_EXACT_RUNUP"), ("rf_mid_fused", "RFS_MID_FUSED")):      # (experiments)
+    for opt, env in (("swd_exact_group", "RFS_EXACT_GROUP"), ("swd_exact_runup", "RFS_EXACT_RUNUP"), ("rf_mid_fused", "RFS_MID_FUSED"), ("swd_walk_dense", "RFS_WALK_DENSE")):      # (experiments)
         if os.environ.get(env):
             joint._ensure(n).set_option(opt, int(os.environ[env]))
     return joint, x_true, bounds_of(x_true)

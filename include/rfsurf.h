@@ -347,6 +347,10 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          trace, residual, misfit, forward FFT of the weighted residual -- runs as ONE kernel with a chain's 4 KB
  *                          in LDS (FFT lengths 16 .. 4096) instead of two kernels around two rocFFT calls; same numbers to
  *                          rounding (1e-15).  librf's entries, the forward-only calls and the time domain always use rocFFT.
+ *   "swd_walk_dense"       1 (default): the grid walk of a walking sequence's later periods evaluates exactly the points the
+ *                          reference's scan passes on its way to the continued root (their number follows from the root),
+ *                          dealt densely to the lanes; 0: 8 lanes per item evaluate rounds of 8 grid points speculatively.
+ *                          Same verdicts, about half the evaluations.
  *   "swd_exact_final"      1: with the warm start on, the start model and the end model of every trajectory (the two
  *                          evaluations the accept / reject decision and the stored sample come from) still go through the
  *                          reference-semantics search.  0 (default) = off.

@@ -108,7 +108,7 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, wlist3, cwarm, fstat, wslope, wbetmx;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, wlist3, cwarm, fstat, wslope, wbetmx, wsg1;
     hipEvent_t ev_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     bool swd_water_cur = false;           // the batch being launched holds models with a water layer on top (B1 entries)
@@ -119,6 +119,7 @@ struct rfs_ctx {
     Buf slist, scount;                    // chains of a peeling evaluation that kept stored rows (k_rf_passA -> k_rf_passB<., false>)
     int* h_scount = nullptr; int* d_hscount = nullptr; int stored_est = -1; unsigned speel_eval = 0;   // their number in an earlier evaluation (host-mapped word the device writes; -1 = unknown); evaluation parity of the two counters
     Buf RT, rstat;                        // final rows of pass A (row peeling, k_rf_passB<., true>); closure residual of the peeling
+    int walk_dense = 1;                   // option "swd_walk_dense": the later periods' grid walk packed densely (k_swd_warm_walk_dense) instead of 8 speculative lanes per item
     int rf_mid_fused = 1;                 // option "rf_mid_fused": the middle section of the frequency-domain gradient in one kernel (k_rf_mid_fused) instead of k_rf_mid1 / rocFFT / k_rf_mid2 / rocFFT
     Buf twid; int twid_nft = 0;           // exp(-2 pi i j / nft), j <= nft / 2
     Buf gtab, etab; double mid_tab_key[6] = {0, 0, 0, 0, 0, 0};   // chain-independent factors of the fused middle section (k_rf_mid_tables)
@@ -798,7 +799,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wilist.as<int>(), wn + 2 * nchain + 2, c->wlist2.as<int>() + lo, wn + 2 * nchain + 3,
                   c->wslope.as<double>(), c->wbetmx.as<float>(), c->warm_exact ? c->cwarm.as<double>() : (double*)nullptr,
                   wn + 3 * nchain + 3, c->wlist3.as<int>() + lo,
-                  (c->flow_cur && c->fpend.p && c->fpend.cap >= (size_t)nchain * sizeof(int)) ? c->fpend.as<int>() : (const int*)nullptr};
+                  (c->flow_cur && c->fpend.p && c->fpend.cap >= (size_t)nchain * sizeof(int)) ? c->fpend.as<int>() : (const int*)nullptr,
+                  c->wsg1.as<unsigned char>()};
         (void)0;
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
@@ -894,17 +896,22 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         {
             const int gw = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 4 + 15) / 16)));
             const int g1 = std::max(64, std::min(2048, nchain / 4));
+            const int gd = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 2 + 63) / 64)));   // 64 items per block and trip
             if (Q.nper_total > 0) {
                 hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, true>), dim3(g1), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                    c->croot.as<double>(), W);
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
-                                   c->croot.as<double>(), W);
+                if (c->walk_dense) hipLaunchKernelGGL((k_swd_warm_walk_dense<SwdRayFamily>), dim3(gd), dim3(64), 0, sw, nchain, n, Q, mdlR,
+                                                      c->mdlc.as<double>(), c->croot.as<double>(), W);
+                else hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
+                                        c->croot.as<double>(), W);
             }
             if (P.QL.nper_total > 0) {
                 hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, true>), dim3(g1), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
                                    c->mdlcL.as<double>(), c->croot.as<double>(), W);
-                hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
-                                   c->mdlcL.as<double>(), c->croot.as<double>(), W);
+                if (c->walk_dense) hipLaunchKernelGGL((k_swd_warm_walk_dense<SwdLoveFamily>), dim3(gd), dim3(64), 0, sw, nchain, n, P.QL,
+                                                      c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
+                else hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
+                                        c->mdlcL.as<double>(), c->croot.as<double>(), W);
             }
         }
         if (sw != s) HIPCHK(c, hipEventRecord(c->ev_wk[1], sw));
@@ -1151,7 +1158,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         ENSURE(c, c->wslope, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
-        ENSURE(c, c->wbetmx, (size_t)2 * nchain * sizeof(float));
+        ENSURE(c, c->wbetmx, (size_t)2 * nchain * sizeof(float)); ENSURE(c, c->wsg1, (size_t)8 * nchain);
         // slopes of the secular function belong to roots a warm search found: an evaluation by the full search leaves none
         if (!warm) HIPCHK(c, hipMemsetAsync(c->wslope.p, 0, c->wslope.cap, c->stream));
         if (c->wvalid.cap != before) {
@@ -1483,7 +1490,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->slist, &c->scount, &c->hi32, &c->stat32};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1581,6 +1588,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value, c->rf_band_floor); }
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
+    }
+    if (!strcmp(name, "swd_walk_dense")) {
+        if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "swd_walk_dense must be 0 or 1");
+        c->walk_dense = value; return RFS_OK;
     }
     if (!strcmp(name, "rf_mid_fused")) {
         if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "rf_mid_fused must be 0 or 1");

@@ -251,6 +251,40 @@ def test_option_zero_is_the_history_free_search_and_failing_models_keep_their_fl
     assert torch.equal(st["Unew"][okc], m[okc]) and torch.equal(st["dsyn_new"][okc], d[okc])
 
 
+def test_dense_grid_walk_gives_the_speculative_walk_s_verdicts():
+    """Option swd_walk_dense: the later periods of walking sequences evaluate exactly the grid points up to the continued
+    root, densely packed -- the same verdicts as rounds of 8 speculative lanes per item: two plugins on the same models
+    (2048 chains, half of them unsorted, 10 steps at a sampler's step size) hand back the same number of chains for the
+    same causes at every step and return identical numbers, with fewer evaluations."""
+    import torch
+    import bench
+    n, nt, nchain = 30, 512, 2048
+    dev = torch.device("cuda")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(23)
+    bounds = bench.bounds_of(bench.true_model(n))
+    xs = np.clip(bench.make_models(nchain, 5, n), bounds[:, 0], bounds[:, 1])
+    for i in np.nonzero(rng.random(nchain) < 0.5)[0]:
+        xs[i, :n] = rng.permutation(xs[i, :n])
+    lo, hi = tt(bounds[:, 0]), tt(bounds[:, 1])
+    jd, _ = _bench_joint(2); js, _ = _bench_joint(2)
+    cd, cs = jd._ensure(n), js._ensure(n)
+    cd.set_option("swd_walk_dense", 1); cs.set_option("swd_walk_dense", 0)
+    x = tt(xs); p = tt(0.5 * rng.standard_normal(xs.shape))
+    names = ("swd_warm_declined_chains", "swd_warm_walked_chains", "swd_exact_declined_chains", "swd_warm_items")
+    for s in range(11):
+        md, gd, dd, fd = jd.misfit_and_grad_device(x)
+        ms, gs, ds, fs = js.misfit_and_grad_device(x)
+        assert torch.equal(fd, fs) and torch.equal(md, ms) and torch.equal(gd, gs) and torch.equal(dd, ds), s
+        assert [cd.stat(k) for k in names] == [cs.stat(k) for k in names], (s, [cd.stat(k) for k in names], [cs.stat(k) for k in names])
+        x, p = _leapfrog_move(x, p, torch.zeros_like(gd), 0.03, lo, hi)
+    walked, items = cd.stat("swd_warm_walked_chains"), cd.stat("swd_warm_items")
+    ed, es = cd.stat("swd_warm_secular_evals"), cs.stat("swd_warm_secular_evals")
+    print(f"{walked} chain evaluations walked the grid, {cd.stat('swd_warm_declined_chains')} handed back; warm-start + branch-test "
+          f"evaluations per item: dense {ed / items:.2f}, speculative {es / items:.2f}")
+    assert walked >= 2000 and ed < 0.85 * es
+
+
 def test_exact_final_gives_reference_roots_at_the_end_model():
     """swd_exact_final = 1: the steps inside a trajectory are warm-started, the evaluation of its END model goes through
     the reference-semantics search: the synthetics stored for that model are bit for bit those of a plain evaluation."""
