@@ -305,7 +305,7 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          search, the rest within 1e-6 c; misfit and gradient as with "swd_warm_start" = 0.
  *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
  *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
- *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 3, >= 2: measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; with fewer most groups are handed back) of the above.
+ *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2: measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; with fewer most groups are handed back) of the above.
  *   "flow_async_handback"  rfs_flow_step / rfs_flow_step2 with the warm start on: 1 = a chain the warm start hands back to the
  *                          reference-semantics search (a few per step on rough models: ~3 ms of dependent evaluations, during
  *                          which every other chain would wait) sits that step out instead -- its model has drifted, it is not

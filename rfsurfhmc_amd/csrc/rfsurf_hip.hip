@@ -103,7 +103,7 @@ struct rfs_ctx {
     const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
-    int exact_group = 3, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
+    int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)

@@ -421,6 +421,17 @@ def with_host_threads(fn):
     return wrapped
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    import torch
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max_steps=None, step_hook=None,
              restart=None, async_handback=True):
     """Drive model.flow_step (rfs_flow_step) until ``active()`` is False.
@@ -498,7 +509,10 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
     # launched first, the side stream waits for the event recorded behind step s and gathers the finished chains' rows
     # (those chains idle in step s+1, so nothing writes them; the done flags alternate between two buffers because
     # every step clears its own).  The device then never waits for the host between steps.
-    side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and pipeline) else None
+    # (ONE side stream per device and process: torch deals its pool streams round-robin, and a stream that lands on the
+    # hardware queue of the library's background-search stream has its small copies queue behind 4 ms searches -- a second
+    # or third run in a process was then twice as slow as the first: measured, 5.8 vs 11.5 ms per step)
+    side = _side_stream(dev) if (dev.type == "cuda" and pipeline) else None
     dbuf = [st["done"], torch.zeros_like(st["done"])]
     marks = []                                   # (done buffer, event, step index) of the steps not fetched yet
     if restart is not None and not hasattr(model, "flow_restart_state"):
