@@ -1287,37 +1287,42 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         };
         bool bad = live && (sg > 1 || !(sk > 0.0) || sk == ck);
         bool walking = live && !bad;
-        // round 0: lane 0 of the group evaluates the start point, lane 1 the sign below every root (del1st)
+        // round 0: lane 0 of the group evaluates the start point, lane 1 the sign below every root (del1st).  A sequence's first
+        // period (FIRST) has both in one -- its start point IS the sequence's first evaluation and the scan goes up -- and takes
+        // it as point 0 of its first round of grid points instead of a round of its own
+        constexpr int OFF = FIRST ? 0 : 1;                // index of a round's first point
         double f0 = 0.0;
-        if (walking && li < 2) f0 = swd_secular_family<F>(n, loadL, li == 0 ? omega : om0, li == 0 ? sk : cc);
+        if (!FIRST && walking && li < 2) f0 = swd_secular_family<F>(n, loadL, li == 0 ? omega : om0, li == 0 ? sk : cc);
         const int gbase = sub * LPI;
         const double fsk = __shfl(f0, gbase, 64), f1st = __shfl(f0, gbase + 1, 64);
-        if (FIRST && walking && li == 0 && W.sg1) W.sg1[(size_t)((F::LOVE ? 4 : 0) + seq) * nchain + chain] = signbit(f1st) ? 1 : 0;
-        const int idir = (k == 0 || signbit(fsk) == signbit(f1st)) ? +1 : -1;
+        const int idir = (FIRST || k == 0 || signbit(fsk) == signbit(f1st)) ? +1 : -1;
         int sprev = signbit(fsk) ? 1 : 0;                 // sign at the last point of the round before
-        int nev = (walking && li < 2) ? 1 : 0;
+        int nev = (!FIRST && walking && li < 2) ? 1 : 0;
         // (a first period's scan starts at the model's start value -- 0.77 x the Rayleigh velocity of the SLOWEST layer -- and may
         // have 2.5 km/s to go on models with one slow layer: 1024 cells; later periods start 1.5 cells below the root before)
         constexpr int MAXR = (FIRST ? 1024 : 400) / LPI;
         for (int round = 0; round < MAXR && __any(walking); round++) {
-            const double c = sk + (double)idir * (double)(round * LPI + li + 1) * dcs;
+            const int pidx = round * LPI + li + OFF;                       // 0: the start point itself (FIRST only)
+            const double c = pidx == 0 ? sk : sk + (double)idir * (double)pidx * dcs;
             double f = 0.0;
-            if (walking) { f = swd_secular_family<F>(n, loadL, omega, c > 1.0e-3 ? c : 1.0e-3); nev++; }
+            if (walking) { f = swd_secular_family<F>(n, loadL, omega, (pidx == 0 || c > 1.0e-3) ? c : 1.0e-3); nev++; }
             const int sgn_me = signbit(f) ? 1 : 0;
             int sgn_before = __shfl_up(sgn_me, 1, LPI);
-            if (li == 0) sgn_before = sprev;
+            if (li == 0) sgn_before = (FIRST && round == 0) ? sgn_me : sprev;
+            if (FIRST && round == 0 && walking && li == 0 && W.sg1)            // del1st, for the later periods' dense walk
+                W.sg1[(size_t)((F::LOVE ? 4 : 0) + seq) * nchain + chain] = (unsigned char)sgn_me;
             // per lane: does the scan END at this point?  a sign change against the point before, or one of getsol's limits
             // once the scan has moved here without one (:463-479; the clamp at clow is handed back to the full search)
-            const bool clampd = c <= cc;                                   // getsol would clamp here instead of evaluating
-            const bool change = sgn_me != sgn_before && !clampd;
-            const bool limit = clampd || c >= (double)bmx + dcs;
+            const bool clampd = pidx > 0 && c <= cc;                       // getsol would clamp here instead of evaluating
+            const bool change = pidx > 0 && sgn_me != sgn_before && !clampd;
+            const bool limit = clampd || (pidx > 0 && c >= (double)bmx + dcs);
             const unsigned long long gmask = LPI == 64 ? ~0ull : (((1ull << (LPI & 63)) - 1ull) << gbase);
             const unsigned long long mend = __ballot(walking && (change || limit)) & gmask;
             const unsigned long long mchange = __ballot(walking && change) & gmask;
             if (walking && mend) {
                 const int first = __ffsll((long long)mend) - 1 - gbase;   // the group's first ending point
                 const bool by_change = ((mchange >> (gbase + first)) & 1ull) != 0;
-                const double cend = sk + (double)idir * (double)(round * LPI + first + 1) * dcs, cbefore = cend - (double)idir * dcs;
+                const double cend = sk + (double)idir * (double)(round * LPI + first + OFF) * dcs, cbefore = cend - (double)idir * dcs;
                 bad = !by_change || !(fmin(cbefore, cend) < ck && ck < fmax(cbefore, cend));
                 walking = false;
             }
