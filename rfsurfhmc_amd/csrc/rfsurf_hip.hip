@@ -891,7 +891,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // (background form with a stream to spare: the walk runs BESIDE the reference-root stage -- that stage does not need its
         // verdicts, a chain the walk declines afterwards just sits the step out like any other -- and the search of the
         // handed-back chains and the end of the step wait for both)
-        hipStream_t sw = (async && c->stream_w && c->warm_exact) ? c->stream_w : s;
+        hipStream_t sw = (async && c->stream_w) ? c->stream_w : s;      // (without the reference-root stage: beside the eigenfunction pass)
         if (sw != s) { HIPCHK(c, hipEventRecord(c->ev_wk[0], s)); HIPCHK(c, hipStreamWaitEvent(sw, c->ev_wk[0], 0)); }
         {
             const int gw = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 4 + 15) / 16)));
