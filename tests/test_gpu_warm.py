@@ -353,11 +353,10 @@ def test_love_group_and_sphere_blocks_are_continued_too(orc):
 
 @pytest.mark.parametrize("kind", ["hmc", "da"])
 def test_reference_sampler_traces_with_the_warm_start_on(kind, golden):
-    """The reference's own sampler traces (tests/golden/sampler_hybrid.npz) with the warm start on: same initial models, L
-    draws and accept decisions; states, step sizes and misfits at the tolerance the warm start keeps -- the reference's
-    roots stop up to 1e-6 c short of the sign change (surfdisp96.f:627), a residual of order 1e-2 turns that into ~1e-5
-    of a misfit, and the traces were made with dt = 0.1 (tests/test_gpu_samplers.py holds them to 1e-6 / 1e-5 with the
-    history-free search)."""
+    """The reference's own sampler traces (tests/golden/sampler_hybrid.npz) with the warm start on (default: with the
+    reference-root stage behind it): same initial models, L draws and accept decisions; states, step sizes and misfits at
+    the tolerances tests/test_gpu_samplers.py holds the history-free search to (1e-6 / 1e-5) -- the steps inside a
+    trajectory now return the reference's own roots."""
     from test_gpu_samplers import _joint
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
@@ -372,10 +371,9 @@ def test_reference_sampler_traces_with_the_warm_start_on(kind, golden):
             seq = [(tr, tr["active"].index(c)) for tr in s.trace if c in tr["active"]]
             assert np.array_equal(np.array([tr["L"][k] for tr, k in seq]), g[f"{tag}/L"])
             assert np.array_equal(np.array([tr["accept"][k] for tr, k in seq]), g[f"{tag}/accept"])
-            # (trajectories of 5..20 steps of dt = 0.1 amplify a 1e-6 difference of the synthetics by ~1e2)
-            assert rel(np.array([tr["xres"][k] for tr, k in seq]), g[f"{tag}/x"]) < 1e-4
-            assert rel(np.array([tr["Ures"][k] for tr, k in seq]), g[f"{tag}/U"]) < 1e-3
-            assert rel(mis[c], g[f"{tag}/misfit"]) < 1e-3
+            assert rel(np.array([tr["xres"][k] for tr, k in seq]), g[f"{tag}/x"]) < 1e-6
+            assert rel(np.array([tr["Ures"][k] for tr, k in seq]), g[f"{tag}/U"]) < 1e-5
+            assert rel(mis[c], g[f"{tag}/misfit"]) < 1e-5
     else:
         s = HMCDualAveraging(joint, g["bounds"], 0.1, 10, 2, 0.65, 991206, 6, 3, myrank=0, name="t", outdir=None,
                              nchains=1, verbose=False)
@@ -383,18 +381,16 @@ def test_reference_sampler_traces_with_the_warm_start_on(kind, golden):
         mis = s.sample()
         assert np.array_equal(np.array([tr["L"][0] for tr in s.trace]), g["da_r0/L"])
         # (dual averaging feeds every acceptance ratio back into the next step size: differences compound)
-        assert rel(np.array([tr["dt"][0] for tr in s.trace]), g["da_r0/dt"]) < 1e-4
-        assert rel(np.array([tr["xend"][0] for tr in s.trace]), g["da_r0/x"]) < 1e-4
-        assert rel(mis, g["da_r0/misfit"]) < 1e-3
+        assert rel(np.array([tr["dt"][0] for tr in s.trace]), g["da_r0/dt"]) < 1e-6
+        assert rel(np.array([tr["xend"][0] for tr in s.trace]), g["da_r0/x"]) < 1e-6
+        assert rel(mis, g["da_r0/misfit"]) < 1e-5
 
 
 def test_sampler_with_and_without_the_warm_start_samples_alike(golden):
     """End to end: the same seeded HamitonianMC run (256 chains, the 7-layer joint problem of the reference's traces) with
-    the warm start on and off.  Every chain consumes the same random numbers in both; the roots differ by <= 1.1e-6 c, so
-    the trajectories differ at that level and, barring a draw that lands within that margin of its acceptance threshold,
-    the chains take the same decisions: almost all chains end with the same accept counts and samples equal to ~1e-4,
-    and the ensemble statistics a user looks at (mean misfit, per-parameter means of the final samples) agree far inside
-    their sampling error."""
+    the warm start on (reference-root stage included: the default) and off.  Every chain consumes the same random numbers
+    in both and the steps inside a trajectory return the reference's roots, so every chain takes the same decisions and
+    the samples agree to the few roots in 1e5 that end on a neighbouring float32 (1e-6 of a sample at most)."""
     from test_gpu_samplers import _joint
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     g = golden["sampler_hybrid"]
@@ -410,12 +406,12 @@ def test_sampler_with_and_without_the_warm_start_samples_alike(golden):
         runs[warm] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted))
     (m0, x0s, a0), (m1, x1s, a1) = runs[0], runs[1]
     same = a0 == a1
-    assert same.mean() >= 0.95, same.mean()
+    assert same.all(), same.mean()
     relx = np.abs(x1s[same] - x0s[same]).max() / np.abs(x0s[same]).max()
     relm = np.abs(m1[same] - m0[same]).max() / np.abs(m0[same]).max()
     print(f"warm vs full-search sampler: {same.mean():.1%} of the chains with identical accept counts; on those samples differ "
           f"by {relx:.2e}, misfits by {relm:.2e}; ensemble mean misfit {m0[:, -1].mean():.6f} vs {m1[:, -1].mean():.6f}")
-    assert relx < 1e-3 and relm < 1e-2
+    assert relx < 1e-6 and relm < 1e-5
     assert abs(m1[:, -1].mean() - m0[:, -1].mean()) <= 0.01 * m0[:, -1].std()
     assert np.all(np.abs(x1s[:, -1].mean(0) - x0s[:, -1].mean(0)) <= 0.02 * x0s[:, -1].std(0) + 1e-12)
 
