@@ -222,6 +222,17 @@ int rfs_flow_step2(rfs_ctx* ctx, int nchain, double* x, double* p, const double*
                    const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                    double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next);
 
+/* What the caller does to the chains that go through the host between two flow steps -- pyhmc/hmc.py:228-276's loop body
+ * for a chain whose trajectory ended in a failed evaluation (no acceptance draw: the reference returns early, :154-180), or
+ * every finished chain of a run without rfs_flow_next -- in one launch on the context's stream instead of a dozen small
+ * copies and scatters between two steps.  All pointers DEVICE: idx1 [n1] chains whose row of x becomes xkeep [n1][2*nlayer]
+ * (the model the chain keeps); idx2 [n2] chains that start another trajectory: p <- pnew [n2][2*nlayer], rem <- remnew [n2],
+ * dt <- dtnew [n2] (NULL: unchanged), fresh = ok = 1; idx3 [n3] chains whose deposit (rfs_flow_next.have) is withdrawn.
+ * x, p, rem, dt, fresh, ok: the arrays of rfs_flow_step; nxt_have: rfs_flow_next.have or NULL (n3 = 0). */
+int rfs_flow_restart(rfs_ctx* ctx, int nchain, int n1, const int32_t* idx1, const double* xkeep, int n2, const int32_t* idx2,
+                     const double* pnew, const int32_t* remnew, const double* dtnew, int n3, const int32_t* idx3,
+                     double* x, double* p, int32_t* rem, double* dt, int32_t* fresh, int32_t* ok, int32_t* nxt_have);
+
 /* Diagonal inverse mass matrix of the leapfrog entries above (rfs_leapfrog_dev / dev2, rfs_flow_step): drift
  * x += dt * minv * p, kinetic energy p.minv.p / 2; the caller draws p ~ N(0, M).  minv: HOST [2*nlayer], NULL =
  * identity (the reference's `invert_Mass`, pyhmc/hmc.py:48).  Reset by rfs_joint_setup. */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "rfs_leapfrog_dev2": (_i, [_vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp] + [_vp] * 8),
     "rfs_flow_step": (_i, [_vp, _i] + [_vp] * 14),
     "rfs_flow_step2": (_i, [_vp, _i] + [_vp] * 14 + [ctypes.POINTER(FlowNext)]),
+    "rfs_flow_restart": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp] + [_vp] * 7),
     "rfs_set_inverse_mass": (_i, [_vp, _vp]),
     "rfs_ndata": (_i, [_vp]),
     "rfs_set_option": (_i, [_vp, ctypes.c_char_p, _i]),

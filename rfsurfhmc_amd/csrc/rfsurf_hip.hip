@@ -2180,6 +2180,24 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     return RFS_OK;
 }
 
+int rfs_flow_restart(rfs_ctx* c, int nchain, int n1, const int32_t* idx1, const double* xkeep, int n2, const int32_t* idx2,
+                     const double* pnew, const int32_t* remnew, const double* dtnew, int n3, const int32_t* idx3,
+                     double* x, double* p, int32_t* rem, double* dt, int32_t* fresh, int32_t* ok, int32_t* nxt_have) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (n1 < 0 || n2 < 0 || n3 < 0 || n1 > nchain || n2 > nchain || n3 > nchain) return fail(c, RFS_ERR_ARG, "list lengths must be within [0, nchain]");
+    if ((n1 && (!idx1 || !xkeep || !x)) || (n2 && (!idx2 || !pnew || !remnew || !p || !rem || !fresh || !ok)) ||
+        (n2 && dtnew && !dt) || (n3 && (!idx3 || !nxt_have)))
+        return fail(c, RFS_ERR_ARG, "null argument");
+    if (n1 + n2 + n3 == 0) return RFS_OK;
+    const int nx = 2 * c->n;
+    hipLaunchKernelGGL(k_flow_restart, dim3(n1 + n2 + n3), dim3(64), 0, c->stream, nx, n1, n2, n3, idx1, xkeep, idx2, pnew, remnew,
+                       dtnew, idx3, x, p, rem, dt, fresh, ok, nxt_have);
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
 int rfs_flow_step(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                   double* dsyn_new, int32_t* ok, int32_t* done) {

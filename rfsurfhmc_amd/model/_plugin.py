@@ -194,6 +194,22 @@ class FusedPlugin:
         else:
             ctx.check(ctx.L.rfs_flow_step(ctx.h, nchain, *args))
 
+    def flow_restart(self, st, buf, n1, o_idx1, o_xkeep, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3):
+        """rfs_flow_restart on the state ``st``: the lists and rows live in ONE device byte buffer ``buf`` (a uint8 CUDA
+        tensor the caller copied up in one piece) at the given byte offsets (None: absent)."""
+        import torch
+        x = st["x"]
+        nchain, nx = x.shape
+        ctx = self._ensure(nx // 2)
+        ctx.check(ctx.L.rfs_set_stream(ctx.h, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        base = buf.data_ptr()
+        P = lambda off: None if off is None else base + off
+        nh = st.get("nxt_have")
+        ctx.check(ctx.L.rfs_flow_restart(ctx.h, nchain, n1, P(o_idx1), P(o_xkeep), n2, P(o_idx2), P(o_p), P(o_rem), P(o_dt),
+                                         n3, P(o_idx3), st["x"].data_ptr(), st["p"].data_ptr(), st["rem"].data_ptr(),
+                                         st["dt"].data_ptr(), st["fresh"].data_ptr(), st["ok"].data_ptr(),
+                                         nh.data_ptr() if nh is not None else None))
+
     def flow_restart_state(self, st, want_dsyn=False, deferred=False):
         """Adds to a flow state the arrays of rfs_flow_next: deposits for the next trajectory (nxt_have / nxt_u / nxt_p /
         nxt_rem), the start model of the running one (xstart) and the parked results of the last completed one (res_x,

@@ -560,6 +560,48 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
             st["fresh"].index_fill_(0, rs, 1)
             st["ok"].index_fill_(0, rs, 1)
 
+    # The same in ONE copy and ONE launch (rfs_flow_restart) where the model offers it: a dozen small copies and scatters on
+    # the main stream between two steps cost the device 0.3 ms of every step in which some chain goes through the host
+    # (a failed evaluation ends a trajectory without an acceptance draw: a few chains in most steps of a real run)
+    fused = dev.type == "cuda" and hasattr(model, "flow_restart")
+    stage = [[None, None] for _ in range(8)]      # rotating pinned byte buffers: [tensor, event behind its last copy]
+    stage_next = [0]
+
+    def apply_fused(idx, xkeep, rs_, wd):
+        parts, off = [], 0
+
+        def put(a, dtype):
+            nonlocal off
+            a = np.ascontiguousarray(a, dtype=dtype)
+            o = off
+            parts.append((o, a))
+            off = (o + a.nbytes + 7) & ~7
+            return o
+
+        n1 = len(idx)
+        o_idx1 = put(idx, np.int32); o_xk = put(xkeep, np.float64)
+        n2 = 0; o_idx2 = o_p = o_rem = o_dt = None
+        if rs_ is not None and len(rs_["idx"]):
+            n2 = len(rs_["idx"])
+            o_idx2 = put(rs_["idx"], np.int32); o_p = put(rs_["p"], np.float64); o_rem = put(rs_["rem"], np.int32)
+            if rs_.get("dt") is not None:
+                o_dt = put(rs_["dt"], np.float64)
+        n3 = len(wd)
+        o_idx3 = put(wd, np.int32) if n3 else None
+        slot = stage[stage_next[0]]; stage_next[0] = (stage_next[0] + 1) % len(stage)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < off:
+            slot[0] = torch.empty(max(off, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        h = slot[0].numpy()
+        for o, a in parts:
+            h[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        d = slot[0][:off].to(dev, non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        model.flow_restart(st, d, n1, o_idx1, o_xk, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3)
+
     steps = 0
 
     deposited = []                               # events behind deposits made on the side stream
@@ -590,16 +632,23 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         if uploaded:
             uploaded.pop().synchronize()         # bounds how far the host runs ahead (the staging buffers guard themselves, t())
         if len(idx1):
+            wd = idx1[:0]
             if restart is not None:
                 wd = idx1[has_dep[idx1]]
                 if len(wd):                      # failed with a deposit outstanding: take it back before anything is drawn
                     restart.withdraw(wd)
                     has_dep[wd] = False
-                    st["nxt_have"].index_fill_(0, t(wd), 0)
-                    if side is not None:         # a deposit made later on the side stream must land behind this fill
-                        wev = torch.cuda.Event(); wev.record(); side.wait_event(wev)
+                    if not fused:
+                        st["nxt_have"].index_fill_(0, t(wd), 0)
+                        if side is not None:     # a deposit made later on the side stream must land behind this fill
+                            wev = torch.cuda.Event(); wev.record(); side.wait_event(wev)
             xkeep, rs_ = process_done(idx1, res1)
-            apply(idx1, xkeep, rs_)              # stream-ordered after the step launched above
+            if fused:
+                apply_fused(idx1, xkeep, rs_, wd)            # stream-ordered after the step launched above
+                if len(wd) and side is not None:
+                    wev = torch.cuda.Event(); wev.record(); side.wait_event(wev)
+            else:
+                apply(idx1, xkeep, rs_)
             if restart is not None:
                 finish[idx1] = -1
                 if rs_ is not None and len(rs_["idx"]):              # fresh in the step launched next

@@ -499,3 +499,53 @@ def test_two_flow_states_in_turn_on_one_context():
         jw.flow_step(sts[0])
     torch.cuda.synchronize()
     assert ctx.stat("swd_warm_items") > i0
+
+
+def test_host_path_restart_in_one_launch_equals_the_scatters():
+    """rfs_flow_restart (what run_flow does to chains that go through the host between two steps, in one launch) against
+    the dozen torch scatters it replaces: same state afterwards, with and without new step sizes / withdrawn deposits;
+    refusals for lists longer than the batch."""
+    import torch
+    import bench
+    from rfsurfhmc_amd._lib import RfsError
+    n, nchain = 30, 512
+    joint, _ = _bench_joint(1)
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(3)
+    bounds = bench.bounds_of(bench.true_model(n))
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    st = joint.flow_state(tt(bench.make_models(nchain, 1, n)), torch.full((nchain,), 0.01, dtype=torch.float64, device=dev), tt(bounds))
+    joint.flow_restart_state(st)
+    st["nxt_have"].fill_(1)
+    for with_dt, n3 in ((False, 0), (True, 7)):
+        idx1 = np.sort(rng.choice(nchain, 40, replace=False)).astype(np.int32)
+        idx2 = idx1[rng.random(40) < 0.7]
+        idx3 = idx1[:n3]
+        xk = rng.standard_normal((len(idx1), 2 * n)); pn = rng.standard_normal((len(idx2), 2 * n))
+        rem = rng.integers(5, 21, len(idx2)).astype(np.int32); dtn = rng.random(len(idx2))
+        ref = {k: st[k].clone() for k in ("x", "p", "rem", "dt", "fresh", "ok", "nxt_have")}
+        ref["x"].index_copy_(0, tt(idx1.astype(np.int64)), tt(xk))
+        i2 = tt(idx2.astype(np.int64))
+        ref["p"].index_copy_(0, i2, tt(pn)); ref["rem"].index_copy_(0, i2, tt(rem))
+        if with_dt:
+            ref["dt"].index_copy_(0, i2, tt(dtn))
+        ref["fresh"].index_fill_(0, i2, 1); ref["ok"].index_fill_(0, i2, 1)
+        if n3:
+            ref["nxt_have"].index_fill_(0, tt(idx3.astype(np.int64)), 0)
+        # one byte buffer, 8-byte aligned pieces
+        parts, off, offs = [], 0, []
+        for a in (idx1, xk, idx2, pn, rem, dtn, idx3):
+            a = np.ascontiguousarray(a); offs.append(off); parts.append(a); off = (off + a.nbytes + 7) & ~7
+        h = np.zeros(off, dtype=np.uint8)
+        for o, a in zip(offs, parts):
+            h[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        buf = tt(h)
+        st["ok"].zero_()
+        ref["ok"].zero_(); ref["ok"].index_fill_(0, i2, 1)
+        joint.flow_restart(st, buf, len(idx1), offs[0], offs[1], len(idx2), offs[2], offs[3], offs[4], offs[5] if with_dt else None,
+                           n3, offs[6] if n3 else None)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(st[k], ref[k]), (with_dt, k)
+    with pytest.raises(RfsError):
+        joint.flow_restart(st, buf, nchain + 1, 0, 0, 0, None, None, None, None, 0, None)
