@@ -227,7 +227,9 @@ int rfs_flow_step2(rfs_ctx* ctx, int nchain, double* x, double* p, const double*
  * every finished chain of a run without rfs_flow_next -- in one launch on the context's stream instead of a dozen small
  * copies and scatters between two steps.  All pointers DEVICE: idx1 [n1] chains whose row of x becomes xkeep [n1][2*nlayer]
  * (the model the chain keeps); idx2 [n2] chains that start another trajectory: p <- pnew [n2][2*nlayer], rem <- remnew [n2],
- * dt <- dtnew [n2] (NULL: unchanged), fresh = ok = 1; idx3 [n3] chains whose deposit (rfs_flow_next.have) is withdrawn.
+ * dt <- dtnew [n2] (NULL: unchanged), fresh = ok = 1 -- or, with pnew NULL, chains the device has already restarted whose
+ * length and step size follow a call late (rfs_flow_next.rem == NULL, pyhmc/hmcda.py:280-369): rem and dt only;
+ * idx3 [n3] chains whose deposit (rfs_flow_next.have) is withdrawn.
  * x, p, rem, dt, fresh, ok: the arrays of rfs_flow_step; nxt_have: rfs_flow_next.have or NULL (n3 = 0). */
 int rfs_flow_restart(rfs_ctx* ctx, int nchain, int n1, const int32_t* idx1, const double* xkeep, int n2, const int32_t* idx2,
                      const double* pnew, const int32_t* remnew, const double* dtnew, int n3, const int32_t* idx3,

@@ -2187,7 +2187,7 @@ int rfs_flow_restart(rfs_ctx* c, int nchain, int n1, const int32_t* idx1, const 
     if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
     TRY(check_batch(c, nchain, c->n));
     if (n1 < 0 || n2 < 0 || n3 < 0 || n1 > nchain || n2 > nchain || n3 > nchain) return fail(c, RFS_ERR_ARG, "list lengths must be within [0, nchain]");
-    if ((n1 && (!idx1 || !xkeep || !x)) || (n2 && (!idx2 || !pnew || !remnew || !p || !rem || !fresh || !ok)) ||
+    if ((n1 && (!idx1 || !xkeep || !x)) || (n2 && (!idx2 || !remnew || !rem)) || (n2 && pnew && (!p || !fresh || !ok)) ||
         (n2 && dtnew && !dt) || (n3 && (!idx3 || !nxt_have)))
         return fail(c, RFS_ERR_ARG, "null argument");
     if (n1 + n2 + n3 == 0) return RFS_OK;

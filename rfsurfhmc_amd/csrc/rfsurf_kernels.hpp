@@ -2346,7 +2346,8 @@ __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, c
 
 // rfs_flow_restart: what the caller does to the chains that go through the host between two flow steps (a trajectory that
 // ended in a failed evaluation, a run without device-side restarts), in ONE launch: row idx1[i] of x <- xkeep[i]; for the
-// chains idx2 that start another trajectory p <- pnew, rem <- L, dt (optional), fresh = ok = 1; deposits of idx3 withdrawn.
+// chains idx2 that start another trajectory p <- pnew, rem <- L, dt (optional), fresh = ok = 1 (pnew == nullptr: chains already
+// under way whose length and step size follow late -- rem and dt only); deposits of idx3 withdrawn.
 // block = one listed chain.
 __global__ void k_flow_restart(int nx, int n1, int n2, int n3, const int* __restrict__ idx1, const double* __restrict__ xkeep,
                                const int* __restrict__ idx2, const double* __restrict__ pnew, const int* __restrict__ remnew,
@@ -2361,8 +2362,8 @@ __global__ void k_flow_restart(int nx, int n1, int n2, int n3, const int* __rest
     } else if (b < n1 + n2) {
         const int r = b - n1, c = idx2[r];
         const size_t o = (size_t)c * nx, i = (size_t)r * nx;
-        for (int j = threadIdx.x; j < nx; j += blockDim.x) p[o + j] = pnew[i + j];
-        if (threadIdx.x == 0) { rem[c] = remnew[r]; if (dtnew) dt[c] = dtnew[r]; fresh[c] = 1; ok[c] = 1; }
+        if (pnew) for (int j = threadIdx.x; j < nx; j += blockDim.x) p[o + j] = pnew[i + j];
+        if (threadIdx.x == 0) { rem[c] = remnew[r]; if (dtnew) dt[c] = dtnew[r]; if (pnew) { fresh[c] = 1; ok[c] = 1; } }
     } else if (b < n1 + n2 + n3) {
         if (threadIdx.x == 0 && nxt_have) nxt_have[idx3[b - n1 - n2]] = 0;
     }

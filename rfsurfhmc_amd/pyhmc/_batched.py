@@ -579,11 +579,15 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
             return o
 
         n1 = len(idx)
-        o_idx1 = put(idx, np.int32); o_xk = put(xkeep, np.float64)
+        o_idx1 = o_xk = None
+        if n1:
+            o_idx1 = put(idx, np.int32); o_xk = put(xkeep, np.float64)
         n2 = 0; o_idx2 = o_p = o_rem = o_dt = None
         if rs_ is not None and len(rs_["idx"]):
             n2 = len(rs_["idx"])
-            o_idx2 = put(rs_["idx"], np.int32); o_p = put(rs_["p"], np.float64); o_rem = put(rs_["rem"], np.int32)
+            o_idx2 = put(rs_["idx"], np.int32); o_rem = put(rs_["rem"], np.int32)
+            if rs_.get("p") is not None:         # (absent: lengths and step sizes of chains already under way)
+                o_p = put(rs_["p"], np.float64)
             if rs_.get("dt") is not None:
                 o_dt = put(rs_["dt"], np.float64)
         n3 = len(wd)
@@ -655,10 +659,13 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                     finish[np.asarray(rs_["idx"])] = steps + np.asarray(rs_["rem"], dtype=np.int64)
         if len(idx2):
             late = restart.done(idx2, res2, acc2)
-            if late is not None:                 # deferred form: the new step sizes and lengths, needed from step s + 2 on
+            if late is not None and fused:       # deferred form: the new step sizes and lengths, needed from step s + 2 on
+                apply_fused(idx2[:0], None, dict(idx=idx2, rem=late["rem"], dt=late["dt"]), idx2[:0])
+            elif late is not None:
                 ts = t(idx2)
                 st["dt"].index_copy_(0, ts, t(np.asarray(late["dt"], dtype=np.float64)))
                 st["rem"].index_copy_(0, ts, t(np.asarray(late["rem"], dtype=np.int32)))
+            if late is not None:
                 dep_rem[idx2] = late["rem"]
             finish[idx2] = s + 1 + dep_rem[idx2]                     # fresh in step s + 1, already under way
             has_dep[idx2] = False

@@ -547,5 +547,12 @@ def test_host_path_restart_in_one_launch_equals_the_scatters():
         torch.cuda.synchronize()
         for k in ref:
             assert torch.equal(st[k], ref[k]), (with_dt, k)
+    # lengths and step sizes only (chains the device has restarted already: no momentum, fresh / ok untouched)
+    before = {k: st[k].clone() for k in ("x", "p", "fresh", "ok", "nxt_have")}
+    joint.flow_restart(st, buf, 0, None, None, len(idx2), offs[2], None, offs[4], offs[5], 0, None)
+    torch.cuda.synchronize()
+    for k in before:
+        assert torch.equal(st[k], before[k]), k
+    assert torch.equal(st["rem"][i2], tt(rem)) and torch.equal(st["dt"][i2], tt(dtn))
     with pytest.raises(RfsError):
         joint.flow_restart(st, buf, nchain + 1, 0, 0, 0, None, None, None, None, 0, None)
