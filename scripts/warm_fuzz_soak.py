@@ -1,0 +1,80 @@
+"""Soak of tests/test_gpu_fuzz.py::test_random_configuration_warm_started_against_the_full_search for many more seeds, with
+the statistics the test does not keep: how many phase-velocity roots of the default path (warm start + reference-root stage)
+are bit-identical to the history-free search's, the worst deviation, misfit / gradient differences.
+usage: python3 scripts/warm_fuzz_soak.py first last"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+from rfsurfhmc_amd.model.model_rf import ReceiverFunc
+from rfsurfhmc_amd.model.model_surf import SurfWD
+from rfsurfhmc_amd.model.model_rf_swd_vs_thk import Joint_RF_SWD
+a, b = int(sys.argv[1]), int(sys.argv[2])
+tot = dict(roots=0, same=0, groots=0, gsame=0, evals=0)
+worst = dict(c=0.0, u=0.0, m=0.0, g=0.0)
+bad = []
+t0 = time.time()
+dev = torch.device("cuda")
+for seed in range(a, b):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(2, 26))
+    thk = 1.0 + 5.0 * rng.random(n); thk[-1] = 0.0
+    vs = np.sort(2.4 + 2.2 * rng.random(n))
+    x0 = np.hstack((vs, thk))
+    nper = int(rng.integers(1, 14))
+    t = np.sort(4.0 + 36.0 * rng.random(nper))
+    names = [k for k in ("tRc", "tRg", "tLc", "tLg") if rng.random() < 0.5] or ["tRg"]
+    blocks = {k: t for k in names}
+    sphere = bool(rng.random() < 0.4)
+    with_rf = rng.random() < 0.6
+    kw = dict(sphere=sphere, reference_periods=False, **blocks)
+    rfargs = (0.045, int(rng.integers(40, 160)), 0.2, 1.5, 4.0, 0.001, "P", "time" if rng.random() < 0.3 else "freq")
+
+    def make(warm):
+        s = SurfWD(**kw)
+        j = Joint_RF_SWD(1.0, 1.3, ReceiverFunc(*rfargs), s) if with_rf else s
+        j.set_warm_start(warm)
+        return j
+    try:
+        jw, je = make(2), make(0)
+        d0 = je.forward(x0)
+        if with_rf:
+            jw.set_obsdata(d0[0], d0[1] * 1.01); je.set_obsdata(d0[0], d0[1] * 1.01); nt = rfargs[1]
+        else:
+            jw.set_obsdata(d0[0] * 1.01); je.set_obsdata(d0[0] * 1.01); nt = 0
+        nchain = int(rng.choice([1, 3, 37, 64, 130]))
+        xs = np.tile(x0, (nchain, 1)) * (1 + 0.02 * rng.standard_normal((nchain, 2 * n)))
+        xs[:, :n] = np.sort(xs[:, :n], axis=1); xs[:, -1] = 0.0
+        x = torch.from_numpy(xs).to(dev); p = torch.from_numpy(0.5 * rng.standard_normal(xs.shape)).to(dev)
+        lo, hi = torch.from_numpy(0.7 * xs.min(0)).to(dev), torch.from_numpy(1.3 * xs.max(0) + 1e-9).to(dev)
+        order = [k for k in ("tRc", "tRg", "tLc", "tLg") if k in blocks]
+        for s in range(5):
+            mw, gw, dw, fw = jw.misfit_and_grad_device(x)
+            me, ge, de, fe = je.misfit_and_grad_device(x)
+            assert torch.equal(fw, fe), "flags"
+            ok = fe != 0
+            for bi, name in enumerate(order):
+                a_, b_ = dw[ok][:, nt + bi * nper: nt + (bi + 1) * nper], de[ok][:, nt + bi * nper: nt + (bi + 1) * nper]
+                if not a_.numel():
+                    continue
+                r = float(((a_ - b_).abs() / b_.abs()).max())
+                if name in ("tRc", "tLc"):
+                    tot["roots"] += a_.numel(); tot["same"] += int((a_ == b_).sum()); worst["c"] = max(worst["c"], r)
+                    assert r <= 2.2e-6, (name, r)
+                else:
+                    tot["groots"] += a_.numel(); tot["gsame"] += int((a_ == b_).sum()); worst["u"] = max(worst["u"], r)
+                    assert r <= 4e-4, (name, r)
+            if ok.any():
+                worst["m"] = max(worst["m"], float(((mw[ok] - me[ok]).abs() / me[ok].abs().clamp_min(1e-300)).max()))
+                worst["g"] = max(worst["g"], float(((gw[ok] - ge[ok]).abs().amax(dim=1) / ge[ok].abs().amax(dim=1).clamp_min(1e-300)).max()))
+            g = torch.where(ok[:, None], gw, torch.zeros_like(gw))
+            p = p - 0.003 * g
+            x = x + 0.003 * p
+            for _ in range(3):
+                over, under = x > hi, x < lo
+                x = torch.where(over, 2 * hi - x, x); x = torch.where(under, 2 * lo - x, x)
+                p = torch.where(over | under, -p, p)
+    except Exception as e:
+        bad.append(seed); print("seed", seed, (n, names, sphere, with_rf), "FAILED:", repr(e)[:200], flush=True)
+print(f"seeds {a}..{b - 1}: failures {bad}; phase roots {tot['roots']}, bit-identical {tot['same']} ({tot['same'] / max(tot['roots'], 1):.4%}), worst {worst['c']:.2e} c; "
+      f"group values {tot['groots']}, bit-identical {tot['gsame']} ({tot['gsame'] / max(tot['groots'], 1):.4%}), worst {worst['u']:.2e}; "
+      f"misfit worst {worst['m']:.2e}, gradient worst {worst['g']:.2e}; {time.time() - t0:.0f} s")
