@@ -19,8 +19,9 @@ Synthetic sorted-prior models, dobs = forward(true model).
 
 A "step" = ONE DEVICE STEP OF THE SAMPLER: one leapfrog step of every chain through the C ABI (rfs_flow_step2: drift with
 mirror reflection, misfit + gradient evaluation, kick; accept / reject and the next trajectory's start on the device from
-draws made ahead; pyhmc/hmc.py:140-201, 228-276), state resident in HBM.  W warm-up steps (the chains' burn-in from their
-random start models) run untimed, then exactly K steps are timed.  value = leapfrog steps (= misfit+gradient evaluations) of
+draws made ahead; pyhmc/hmc.py:140-201, 228-276), state resident in HBM.  Set-up (untimed, like building a model): the chains
+are burned in from their random start models for BURN_IN - W device steps; then W warm-up steps run untimed, then exactly K
+steps are timed (W >= BURN_IN: the warm-up is the burn-in).  value = leapfrog steps (= misfit+gradient evaluations) of
 chains inside a trajectory, all ranks / max-over-ranks wall time.
 The JSON line of the default run (N = 1, configs[1]) also carries: the step size and the acceptance ratio of the timed
 window, the root-search mode, `roofline` (the kernel group with the largest stand-alone time per step, its duration
@@ -56,6 +57,9 @@ METRIC = "leapfrog steps/sec (= forward+grad evals/sec) per GPU and whole node, 
 # 0.63 at 0.07, 0.44 at 0.1.
 TUNED_DT = 0.05
 DT_SWEEP = (0.002, 0.02, 0.1)
+BURN_IN = 300           # device steps before the timed window (set-up + warm-up): the chains' burn-in -- acceptance and the share of
+                        # chains with anomalous dispersion are stationary by then (scripts/dt_sweep.py)
+SIDE_BURN, SIDE_K = 60, 100      # the side legs (they continue burned-in chains): untimed / timed device steps
 DTYPE_TEXT = ("f64 (receiver-function row sweep beyond the Gaussian band: packed f32 where proven exact per chain, "
               "rf_f32_beyond_band)")
 ROOT_MODE_TEXT = {
@@ -647,7 +651,8 @@ def run_rank(args):
     cfg = CONFIGS[args.config]
     n, nt = cfg["n"], cfg["nt"]
     nchain = args.chains
-    K, burn = args.steps, args.warmup
+    K, W = args.steps, args.warmup
+    burn = max(W, BURN_IN)                       # set-up steps (burn-in) + the W warm-up steps
     dt = args.dt if args.dt is not None else cfg.get("hmc_dt", TUNED_DT)
     mode = {None: "reference_roots", 1: "reference_roots", 0: "full_search"}[args.warm_start]
     if args.converged_roots:
@@ -665,7 +670,7 @@ def run_rank(args):
     side_legs = rank == 0 and world == 1 and kind == "hmc" and not args.headline_only
     if side_legs:
         # ---- the same chains, continued from where the headline left them (burned in), under other settings: short legs
-        sb, sk = min(burn, 60), min(K, 100)
+        sb, sk = SIDE_BURN, SIDE_K
 
         def short(tag, **kw):
             r, _, _, _, _, _ = sampler_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, sk, sb, barrier,
@@ -683,7 +688,7 @@ def run_rank(args):
         set_root_mode(joint, n, mode)
         # ---- rounds 1-3's headline definition, for continuity: never-ending trajectories (no accept / reject) of the random
         # start models at dt = 0.002, the cheapest point of the step-size curve
-        r0, st0, _, _ = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, min(K, 40), 3, barrier)
+        r0, st0, _, _ = flow_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, 40, 3, barrier)
         extra["never_ending_dt0002"] = {k: r0[k] for k in ("ms_per_step", "value", "unit", "steps", "kernel_ms_per_step")}
         extra["never_ending_dt0002"]["note"] = ("rfs_flow_step on never-ending trajectories from the random start models, dt = 0.002, "
                                                 "33 set-up steps: the definition of rounds 1-3's headline (2.57 M evals/s in round 3 "
@@ -726,7 +731,7 @@ def run_rank(args):
             c2 = CONFIGS[ci]
             j2, xt2, b2 = make_joint(c2, local_rank)
             k2 = "da" if c2["sampler"] == "da" else "hmc"
-            r2, _, _, _, _, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, min(K, 100), min(burn, 300), barrier, kind=k2,
+            r2, _, _, _, _, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, SIDE_K, BURN_IN, barrier, kind=k2,
                                             dt=c2.get("hmc_dt", TUNED_DT), mode=mode)
             r2["workload"] = c2["name"]; r2["step"] = STEP_TEXT[c2["sampler"]]
             extra[f"config{ci}"] = r2
@@ -736,12 +741,14 @@ def run_rank(args):
     value = total_evals / el
     res = {
         "metric": METRIC,
-        "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": burn,
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE_TEXT, "data": "synthetic",
         "config": {"workload": cfg["name"] if not (args.config == 1 and world * nchain == 65536) else
                    "configs[2]: 65536 chains x 30-layer joint RF+SWD, 8xMI355X independent-chain shard, RCCL gather "
                    "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
+                   "set_up_steps": burn - W, "set_up_note": f"untimed set-up: the chains are burned in for {burn - W} device steps "
+                   f"from their random start models before the {W} warm-up steps (burn-in = {burn} steps in all)",
                    "sampler": rep["sampler"], "dt": rep["dt"], "dt_note": (None if kind == "da" else
                    f"step size {dt}: tuned for an acceptance ratio within 0.65-0.9 (SURVEY 8(d)); the reference's default 0.1 "
                    "(param.yaml:40) gives 0.44 here -- see dt_sweep" if args.dt is None else "--dt"),
@@ -782,7 +789,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed device steps of the sampler")
-    ap.add_argument("--warmup", type=int, default=300, help="untimed device steps before them (the chains' burn-in)")
+    ap.add_argument("--warmup", type=int, default=300, help=f"untimed warm-up steps before them; the chains are burned in for max(0, {BURN_IN} - W) set-up steps before that")
     ap.add_argument("--dt", type=float, default=None, help=f"HMC step size (default {TUNED_DT}: acceptance within 0.65-0.9)")
     ap.add_argument("--converged-roots", action="store_true", help="rfs_set_option swd_warm_exact 0 for the headline")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
