@@ -23,6 +23,9 @@ def _env(extra):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "RFS_BENCH_CHILD"):
         e.pop(k, None)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the checks below compare the chains' state at a given DEVICE step across jobs: with hand-backs in the background a chain
+    # that sits steps out is at another point of the same trajectory there, depending on when its search finished
+    e["RFS_FLOW_ASYNC"] = "0"
     e.update(extra)
     return e
 
