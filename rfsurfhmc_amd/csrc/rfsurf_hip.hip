@@ -104,6 +104,7 @@ struct rfs_ctx {
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
+    bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
@@ -1039,13 +1040,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         ENSURE(c, c->cds, ntot * 6 * n * sizeof(double));
         ENSURE(c, c->krn, ntot * 4 * n * sizeof(double));
         ENSURE(c, c->ugr, 3 * ntot * sizeof(double));      // U and the two kernel scale slots of every item (swd_krn)
+        const double* crT_arg = c->krn_ruled ? c->crT.as<double>() : (const double*)nullptr;       // chain-ruled storage (swd_eigen_lane)
         {   // (timed group: the launches of this stream only -- the wait for the side stream below is not kernel time)
         KTimer t(c, eigen_mode == 1 ? -1 : RFS_K_SWD_EIGEN, s);     // the early launch hides behind the search: not timed
 #define RFS_LAUNCH_EIGEN2(LOVE, SPH, WAT, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                          \
         hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH, false, WAT>), dim3((unsigned)(((size_t)(EL1) * nchain + 63) / 64)), \
                            dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(),     \
                            SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (int)(EL1), EARLY, EDONE, \
-                           (const int*)nullptr, (const int*)nullptr)
+                           (const int*)nullptr, (const int*)nullptr, crT_arg)
 #define RFS_LAUNCH_EIGEN(LOVE, SPH, QQ, SPHP, SFL, EL1, EARLY, EDONE)                                                \
         do { if (c->swd_water_cur) RFS_LAUNCH_EIGEN2(LOVE, SPH, true, QQ, SPHP, SFL, EL1, EARLY, EDONE);              \
              else RFS_LAUNCH_EIGEN2(LOVE, SPH, false, QQ, SPHP, SFL, EL1, EARLY, EDONE); } while (0)
@@ -1083,7 +1085,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             hipLaunchKernelGGL((k_swd_eigen<LOVE, SPH, true>), dim3((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64)), \
                                dim3(64), 0, warm_side, nchain, n, QQ, ntot, c->mdl.as<float>(), SPHP, c->croot.as<double>(), \
                                SFL, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(), 0, (QQ).nper_total, 0, \
-                               (int*)nullptr, lists[LI], counts[LI])
+                               (int*)nullptr, lists[LI], counts[LI], crT_arg)
             for (int li = 0; li < (c->warm_exact ? 3 : 2); li++) {
                 if (P.QR.nper_total > 0) {
                     if (sphere) RFS_LAUNCH_EIGEN_LIST(false, true, P.QR, c->sphR.as<double>(), c->sflag.as<int>(), li);
@@ -1129,8 +1131,10 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
     // track: keep the model / roots / kernels of this evaluation for the next one; warm: use those of the previous one
     // (higher modes: always the reference-semantics search -- the warm start's branch test is the fundamental's)
     const bool track = c->has_swd && c->swd_mode == 0 && (c->warm_opt == 2 || (c->warm_opt == 1 && traj));
-    struct ModeGuard { rfs_ctx* c; ~ModeGuard() { c->swd_mode_cur = 0; } } mode_guard{c};
+    struct ModeGuard { rfs_ctx* c; ~ModeGuard() { c->swd_mode_cur = 0; c->krn_ruled = false; } } mode_guard{c};
     c->swd_mode_cur = c->swd_mode;
+    c->krn_ruled = c->has_swd;                 // k_swd_combine and the warm start read the chain-ruled storage
+    if (c->has_swd) ENSURE(c, c->crT, 2 * (size_t)n * nchain * sizeof(double));
     const bool warm = track && c->warm_primed && c->warm_nchain == nchain && traj != 2;
     c->last_async = false;
     if (!fpre) c->flow_x = nullptr;            // (whatever this evaluation leaves behind is not a flow state's)
@@ -1317,7 +1321,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            early_items > 0 ? c->croot.as<double>() : (double*)nullptr, early_items > 0 ? ntot : (size_t)0,
                            early_items > 0 ? c->edone.as<int>() : (warm ? c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4) : (int*)nullptr),
                            early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 4 : (size_t)0),
-                           track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(), c->crT.as<double>(),
+                           track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(),
+                           c->has_swd ? c->crT.as<double>() : (double*)nullptr,
                            fpre ? *fpre : FlowPre{});      // (flow entries: the step's drift rides in this kernel)
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));

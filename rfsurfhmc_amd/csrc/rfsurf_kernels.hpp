@@ -189,6 +189,8 @@ __global__ void k_prep_joint(int nchain, int n, const double* x /* may be fpre.x
         dxT[(size_t)j * nchain + chain] = vs - w[j];
         dxT[(size_t)(n + j) * nchain + chain] = thk - w[n + j];
         w[j] = vs; w[n + j] = thk;
+    }
+    if (crT) {     // chain-rule factors, chain-minor: the eigenfunction pass stores d c / d vs with them (k_swd_eigen)
         crT[(size_t)j * nchain + chain] = dadb;
         crT[(size_t)(n + j) * nchain + chain] = drda * dadb;
     }
@@ -1119,13 +1121,11 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     float betmx = -1.e20f;
     for (int m = n - 1; m >= 0; m--) {
         const size_t lm = (size_t)m * nchain;
-        double ka = kr0[lm] * ksc, kb = kr0[s + lm] * ksc, kr = kr0[2 * s + lm] * ksc, kh = kr0[3 * s + lm] * kfac;
+        // (chain-ruled storage: slot 0 = d c / d vs of the previous model, its flattening factors inside; slot 1 = the interface partial)
+        const double gv = kr0[lm] * ksc;
+        double kh = kr0[s + lm] * kfac;
         if (fabs(kh) < 1.0e-38) kh = 0.0;
-        if (SPH) {
-            const double vtp = sph[4 * s + lm + chain], dtp = sph[5 * s + lm + chain], rtp = sph[6 * s + lm + chain];
-            ka *= vtp; kb *= vtp; kr *= rtp; kh *= dtp;
-        }
-        const double gv = kb + ka * W.crT[lm + chain] + kr * W.crT[s + lm + chain];
+        if (SPH) kh *= sph[5 * s + lm + chain];
         const double t1 = gv * W.dxT[lm + chain], t2 = suf * W.dxT[s + lm + chain];
         dc += t1 + t2; l1 += fabs(t1) + fabs(t2);
         suf += kh;
@@ -1706,19 +1706,29 @@ k_swd_roots_coop(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl,
 // WATER: the top layer may be a fluid (vs = 0).  Rayleigh: the fluid branches of sregn96 (swd_math.hpp).  Love: slegn96
 // reads array elements it never assigned for such a model (uu(1), exl(1): slegn96.f90:211-222 after :417) and the
 // compiled reference returns NaN kernels and NaN group velocities -- so does this (phase velocities are the search's).
+// crt != nullptr (the chain's column of crT: dadb, drda dadb per layer): the kernels are stored CHAIN-RULED -- slot 0 = d c / d vs
+// = kb + ka dadb + kr drda dadb (model_surf.py:184; sphf: the flattened model's vtp / rtp factors inside), slot 1 = the
+// interface partial -- which is all the joint evaluation and the warm start read: half the stores here and half the loads
+// there.  crt == nullptr: the four raw classes (B1: libsurf.adjoint_kernel returns them).
 template <bool LOVE, bool WATER, class Mdl>
 __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, size_t ntot, double t, double cp,
                                                double* __restrict__ sc, double* __restrict__ ko,
-                                               double* __restrict__ uout)
+                                               double* __restrict__ uout, const double* __restrict__ crt,
+                                               const double* __restrict__ sphf)
 {
     const size_t s = (size_t)n * nchain;
+    auto put = [&](int m, double da, double db, double dr, double dh) {
+        const size_t lm = (size_t)m * nchain;
+        if (crt) {
+            if (sphf) { const double vtp = sphf[4 * s + lm], rtp = sphf[6 * s + lm]; da *= vtp; db *= vtp; dr *= rtp; }
+            ko[lm] = db + da * crt[lm] + dr * crt[s + lm];
+            ko[s + lm] = dh;
+        } else { ko[lm] = da; ko[s + lm] = db; ko[2 * s + lm] = dr; ko[3 * s + lm] = dh; }
+    };
     const double omega = 2.0 * SR_PI32 / t, wvno = omega / cp;
     if (LOVE && WATER && M.B(0) <= 0.0) {
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-        for (int m = 0; m < n; m++) {
-            ko[0 * s + (size_t)m * nchain] = 0.0; ko[1 * s + (size_t)m * nchain] = qnan;
-            ko[2 * s + (size_t)m * nchain] = qnan; ko[3 * s + (size_t)m * nchain] = qnan;
-        }
+        for (int m = 0; m < n; m++) put(m, 0.0, qnan, qnan, qnan);
         *uout = qnan; uout[ntot] = 1.0; uout[2 * ntot] = 1.0;
         return;
     }
@@ -1732,10 +1742,7 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
                 const double* o = sc + (size_t)m * 6 * ntot;
                 uu = o[0]; tt = o[ntot]; exl = o[2 * ntot];
             },
-            [&](int m, double db, double dr, double dh) {
-                ko[0 * s + (size_t)m * nchain] = 0.0; ko[1 * s + (size_t)m * nchain] = db;
-                ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
-            });
+            [&](int m, double db, double dr, double dh) { put(m, 0.0, db, dr, dh); });
         // the kernels stay as emitted: their common factors -- 1 / I1, and `fac` of the interface terms with its flush
         // (slegn96.f90:598-602) -- go to the item's two scale slots and are applied by whoever reads krn (swd_krn)
         uout[ntot] = 1.0 / R.sumi1; uout[2 * ntot] = R.fac;
@@ -1754,10 +1761,7 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
             for (int i = 0; i < 5; i++) cd[i] = o[(size_t)i * ntot];
             exe = o[(size_t)5 * ntot];
         };
-        auto emit = [&](int m, double da, double db, double dr, double dh) {
-            ko[0 * s + (size_t)m * nchain] = da; ko[1 * s + (size_t)m * nchain] = db;
-            ko[2 * s + (size_t)m * nchain] = dr; ko[3 * s + (size_t)m * nchain] = dh;
-        };
+        auto emit = [&](int m, double da, double db, double dr, double dh) { put(m, da, db, dr, dh); };
         SrTotals R = sr_down_energy<WATER>(M, omega, wvno, load, emit);
         // (1 / (U I0) of energy :1181-1186 and `fac` of getdcdh with its flush :1529-1531: the item's scale slots, swd_krn)
         uout[ntot] = 1.0 / (R.ugr * R.sumi0); uout[2 * ntot] = R.fac;
@@ -1780,7 +1784,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
             const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
             double* __restrict__ krn, double* __restrict__ ugr, int el0, int el1, int early, int* __restrict__ edone,
-            const int* __restrict__ list, const int* __restrict__ count)
+            const int* __restrict__ list, const int* __restrict__ count, const double* __restrict__ crT)
 {
     // list != nullptr: only the *count chains named there (the chains a warm-started search handed back to the full
     // search, whose roots have just been rewritten); the grid is sized for every chain
@@ -1809,10 +1813,10 @@ k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__
     double* ko = krn + (size_t)e * 4 * s + chain;       // [e][q][m][chain]
     if (SPH) {
         SwdModelD M{sph + chain, sph + s + chain, sph + 2 * s + chain, sph + 3 * s + chain, nchain, n};
-        swd_eigen_lane<LOVE, WATER>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
+        swd_eigen_lane<LOVE, WATER>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi, crT ? crT + chain : nullptr, sph + chain);
     } else {
         SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
-        swd_eigen_lane<LOVE, WATER>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi);
+        swd_eigen_lane<LOVE, WATER>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi, crT ? crT + chain : nullptr, (const double*)nullptr);
     }
     if (early && (threadIdx.x & 63) == 0) edone[widx] = 1;
 }
@@ -1846,17 +1850,21 @@ __device__ __forceinline__ double swd_data_value(const SwdRows& R, const SwdBlk&
 // One kernel value of item e as the eigenfunction pass defines it: the emitted per-layer factor times the item's scale
 // (slot 0: alpha, beta, rho; slot 1: interface, flushed below 1e-38 as the reference does).  ugr: [3][item][chain] = U and
 // the two scale slots; s = n * nchain, lm = m * nchain + chain.
+// RULED: the chain-ruled storage (swd_eigen_lane): q = 0 d c / d vs, q = 1 the interface partial.
+template <bool RULED = false>
 __device__ __forceinline__ double swd_krn(const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot,
                                           int e, int q, size_t s, size_t lm, int nchain, int chain)
 {
+    const bool iface = RULED ? q == 1 : q == 3;
     const double v = krn[((size_t)e * 4 + q) * s + lm];
-    const double sc = ugr[(size_t)(q == 3 ? 2 : 1) * ntot + (size_t)e * nchain + chain];
+    const double sc = ugr[(size_t)(iface ? 2 : 1) * ntot + (size_t)e * nchain + chain];
     const double r = v * sc;
-    return (q == 3 && fabs(r) < 1.0e-38) ? 0.0 : r;
+    return (iface && fabs(r) < 1.0e-38) ? 0.0 : r;
 }
 
-// kernel q (0 alpha, 1 beta, 2 rho, 3 interface) of row k of block B at layer m
-template <bool SPH>
+// kernel q (0 alpha, 1 beta, 2 rho, 3 interface; RULED: 0 vs, 1 interface -- the flattening factors of the vs kernel are
+// inside it already) of row k of block B at layer m
+template <bool SPH, bool RULED = false>
 __device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBlk& B, int k, int q, int m, int chain,
                                                    int nchain, int n, const double* __restrict__ krn,
                                                    const double* __restrict__ croot, const double* __restrict__ ugr)
@@ -1865,9 +1873,10 @@ __device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBl
     const bool love = B.type >= 2;
     const int e0 = B.off + k;
     const size_t ntot = (size_t)R.nitems * nchain;
-    const double k0 = swd_krn(krn, ugr, ntot, e0, q, s, lm, nchain, chain);
+    const double k0 = swd_krn<RULED>(krn, ugr, ntot, e0, q, s, lm, nchain, chain);
     double fac = 1.0;
-    if (SPH) fac = (love ? R.sphL : R.sphR)[(size_t)((q < 2) ? 4 : (q == 2 ? 6 : 5)) * s + lm];
+    if (SPH && RULED) { if (q == 1) fac = (love ? R.sphL : R.sphR)[(size_t)5 * s + lm]; }
+    else if (SPH) fac = (love ? R.sphL : R.sphR)[(size_t)((q < 2) ? 4 : (q == 2 ? 6 : 5)) * s + lm];
     if (!(B.type & 1)) {
         if (!SPH) return k0;
         double tm = sr_tm(love, croot[(size_t)e0 * nchain + chain], 2.0 * SR_PI32 / B.t[k]);
@@ -1877,8 +1886,8 @@ __device__ __forceinline__ double swd_kernel_value(const SwdRows& R, const SwdBl
     const double t = B.t[k], t1 = t * (1.0 + 0.05), t2 = t * (1.0 - 0.05);
     const double cg = ugr[(size_t)e0 * nchain + chain], cp = croot[(size_t)e0 * nchain + chain];
     const double uc1 = cg / cp;
-    const double k1 = swd_krn(krn, ugr, ntot, e1, q, s, lm, nchain, chain);
-    const double k2 = swd_krn(krn, ugr, ntot, e2, q, s, lm, nchain, chain);
+    const double k1 = swd_krn<RULED>(krn, ugr, ntot, e1, q, s, lm, nchain, chain);
+    const double k2 = swd_krn<RULED>(krn, ugr, ntot, e2, q, s, lm, nchain, chain);
     const double du = uc1 * (2.0 - uc1) * k2 - uc1 * uc1 * t * (k2 - k1) / (t2 - t1);
     if (!SPH) return du;
     const double omega = 2.0 * SR_PI32 / t, tm = sr_tm(love, cp, omega), tm1 = sr_tm1(love, omega, tm);
@@ -2001,7 +2010,6 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
         __syncthreads();
     }
     for (int j = slot; j < n; j += NS) {
-        double dadb = cr[((size_t)chain * 2) * n + j], drdadb = cr[((size_t)chain * 2 + 1) * n + j];
         double gs = 0.0, hj = 0.0;
         const size_t lm = (size_t)j * nchain + chain;
         if (ok) {
@@ -2018,20 +2026,19 @@ k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const d
                         if (j == slot && slot == 0 && inb && dsyn) dsyn[(size_t)chain * ndata + nt + row] = d;
                     }
                     if (j == slot && slot == 0) m_swd += r * r;
+                    // (krn: the chain-ruled storage of the eigenfunction pass -- d c / d vs = kb + ka dadb + kr drda dadb of
+                    // model_surf.py:184 formed where the kernels were, and the interface partial)
                     if (plain) {
                         const double* kq = krn + (size_t)(B.off + k) * 4 * s + lm;
-                        const double ka = kq[0], kb = kq[s], kr = kq[2 * s];
-                        double kh = kq[3 * s] * rc[(size_t)(2 * nswd + row) * 32 + tx];
+                        double kh = kq[s] * rc[(size_t)(2 * nswd + row) * 32 + tx];
                         if (fabs(kh) < 1.0e-38) kh = 0.0;
-                        gs += rc[(size_t)(nswd + row) * 32 + tx] * (kb + ka * dadb + kr * drdadb);
+                        gs += rc[(size_t)(nswd + row) * 32 + tx] * kq[0];
                         hj += r * kh;
                         continue;
                     }
-                    double ka = swd_kernel_value<SPH>(R, B, k, 0, j, chain, nchain, n, krn, croot, ugr);
-                    double kb = swd_kernel_value<SPH>(R, B, k, 1, j, chain, nchain, n, krn, croot, ugr);
-                    double kr = swd_kernel_value<SPH>(R, B, k, 2, j, chain, nchain, n, krn, croot, ugr);
-                    double kh = swd_kernel_value<SPH>(R, B, k, 3, j, chain, nchain, n, krn, croot, ugr);
-                    gs += r * (kb + ka * dadb + kr * drdadb);                    // model_surf.py:184
+                    const double gv = swd_kernel_value<SPH, true>(R, B, k, 0, j, chain, nchain, n, krn, croot, ugr);
+                    const double kh = swd_kernel_value<SPH, true>(R, B, k, 1, j, chain, nchain, n, krn, croot, ugr);
+                    gs += r * gv;
                     hj += r * kh;
                 }
             }
