@@ -15,7 +15,9 @@
 //   PG       [chain][npart][4][n]        per-wave partial gradient sums (deterministic reduce)
 //   croot    [seq][nper][chain]          phase velocities per root-search sequence
 //   cds      [n][6][item]                compound up-sweep scratch of the eigenfunction pass
-//   krn      [item-class][4][n][chain]   kernels d(c)/d(alpha,beta,rho,interface) before their per-item scales (swd_krn)
+//   krn      [item-class][4][n][chain]   kernels before their per-item scales (swd_krn): slots 0-1 = d(c)/d(vs), interface partial
+//                                        (chain-ruled storage: joint evaluation, warm start), or the four raw classes
+//                                        d(c)/d(alpha,beta,rho,interface) (B1)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rf_math.hpp"
