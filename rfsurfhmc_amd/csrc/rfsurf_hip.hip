@@ -794,7 +794,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // (two sets of flags / lists, alternating: a background search of the step before may still be reading the other one)
         int* wn = c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4);
         const size_t lo = (size_t)c->wpar * nchain;
-        SwdWarm W{c->dxT.as<double>(), c->crT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
+        SwdWarm W{c->dxT.as<double>(), c->wvalid.as<int>(), c->exact_final ? c->wforce.as<int>() : (const int*)nullptr,
                   wn, wn + nchain, c->wlist.as<int>() + lo, c->wstats.as<unsigned long long>(),
                   c->wsgn.as<unsigned char>(), wn + nchain + 1, wn + 2 * nchain + 1,
                   c->wilist.as<int>(), wn + 2 * nchain + 2, c->wlist2.as<int>() + lo, wn + 2 * nchain + 3,
@@ -1340,7 +1340,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         const size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
 #define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
         hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 4), lds_c,      /* 256-thread blocks: they slip into wave slots the RF sweep frees, a 1024-thread block waits for a whole CU */                             \
-                           st, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(), c->cr.as<double>(),                \
+                           st, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(),                                    \
                            c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),          \
                            P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                      \
                            track ? c->wvalid.as<int>() : (int*)nullptr, rowc, first)

@@ -1068,7 +1068,6 @@ k_swd_roots_split(int nchain, int n, int G, SwdSeqs Q, const float* __restrict__
 // ---------------------------------------------------------------------------------------
 struct SwdWarm {
     const double* dxT;      // [2n][chain] model change since the previous evaluation (vs, thk)
-    const double* crT;      // [2][n][chain] chain-rule factors dadb, drda * dadb
     const int* valid;       // [chain] the previous evaluation of this chain succeeded
     const int* force;       // [chain] the caller wants the reference-semantics search this time (or nullptr)
     int* need;              // [chain] out: 1 = goes to the reference-semantics search
@@ -1970,7 +1969,7 @@ k_rf_reduce(int nchain, RfReduce R, double* __restrict__ misfit, double* __restr
 template <bool SPH>
 __global__ void __launch_bounds__(1024)
 k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const double* __restrict__ misfit_rf,
-              const double* __restrict__ cr, const double* __restrict__ krn, const double* __restrict__ croot,
+              const double* __restrict__ krn, const double* __restrict__ croot,
               const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
               const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
               double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid, int rowc, int first)
