@@ -1493,7 +1493,7 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, const f
     }
     while (__any(x.active())) {
         if (x.active()) {
-            x.advance(swd_secular_family<F>(n, loadL, x.omega, x.creq));
+            x.advance(swd_secular_family<F, true>(n, loadL, x.omega, x.creq));      // (DUAL: this kernel is short of wavefronts)
             if (x.phase == ExactGroup::X_DONE) {
                 if (x.wanted()) croot[e0 + (size_t)x.k * nchain] = (double)(float)x.root();       // surfdisp96.f:302
                 x.next(approx, om);                     // (the last period: stays X_DONE)

@@ -256,14 +256,62 @@ RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, doub
     }
 }
 
+// swd_trig_split for the P and the S wavenumber of one layer AT ONCE: the same numbers, but the two square roots and the two
+// exponentials -- long chains of dependent f64 operations each -- stand side by side in one branch-free block, so that a
+// wavefront that has its SIMD nearly to itself (k_swd_exact: 1.25 per SIMD) overlaps them; sine and cosine only where some lane
+// of the wavefront is oscillatory in that wave type (P: hardly ever below the P velocities), an exponential only where some lane
+// is evanescent.
+RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
+                            double& pex, double& cosp, double& w, double& x, double& eha,
+                            double& sex, double& cosq, double& y, double& z, double& ehb) {
+    const double va = (wvno + xka) * fabs(wvno - xka), vb = (wvno + xkb) * fabs(wvno - xkb);
+    const bool osca = wvno < xka, oscb = wvno < xkb;
+    const double ira = rsqrt_p(va), irb = rsqrt_p(vb);
+    const double ra = va * ira, rb = vb * irb, pa = ra * dpth, pb = rb * dpth;
+    double ea = 1.0, eb = 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool needa = __any(!osca), needb = __any(!oscb);       // (an exponential no lane of the wavefront uses is not computed)
+#else
+    const bool needa = !osca, needb = !oscb;
+#endif
+    if (needa && needb) { ea = fm_exp(-pa); eb = fm_exp(-pb); }
+    else if (needa) ea = fm_exp(-pa);
+    else if (needb) eb = fm_exp(-pb);
+    const double faca = (pa < 16.0) ? ea * ea : 0.0, facb = (pb < 16.0) ? eb * eb : 0.0;
+    double csa = (1.0 + faca) * 0.5, sna = (1.0 - faca) * 0.5, csb = (1.0 + facb) * 0.5, snb = (1.0 - facb) * 0.5;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__any(osca))
+#endif
+    { double sn, cs; fm_sincos(pa, &sn, &cs); csa = osca ? cs : csa; sna = osca ? sn : sna; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__any(oscb))
+#endif
+    { double sn, cs; fm_sincos(pb, &sn, &cs); csb = oscb ? cs : csb; snb = oscb ? sn : snb; }
+    eha = osca ? 1.0 : ea; ehb = oscb ? 1.0 : eb;
+    cosp = csa; w = sna * ira; x = (osca ? -ra : ra) * sna; pex = osca ? 0.0 : pa;
+    cosq = csb; y = snb * irb; z = (oscb ? -rb : rb) * snb; sex = oscb ? 0.0 : pb;
+    const bool dega = (wvno == xka), degb = (wvno == xkb);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__any(dega || degb))
+#endif
+    {
+        if (dega) { cosp = 1.0; w = dpth; x = 0.0; pex = 0.0; eha = 1.0; }
+        if (degb) { cosq = 1.0; y = dpth; z = 0.0; sex = 0.0; ehb = 1.0; }
+    }
+}
+
+template <bool DUAL = false>
 RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega,
                               double ent[SWD_NENT]) {
     double xka = omega * L.ia, xkb = omega * L.ib;
     double t = L.b * iomega;
     double gammk = 2.0 * t * t, gam = gammk * wvno2;
     double pex, sex, cosp, w, x, cosq, y, z, eha, ehb;
-    swd_trig_split(wvno, xka, L.d, pex, cosp, w, x, eha);
-    swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z, ehb);
+    if (DUAL) swd_trig_split2(wvno, xka, xkb, L.d, pex, cosp, w, x, eha, sex, cosq, y, z, ehb);
+    else {
+        swd_trig_split(wvno, xka, L.d, pex, cosp, w, x, eha);
+        swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z, ehb);
+    }
     double exa = pex + sex;
     double a0 = (exa < 60.0) ? eha * ehb : 0.0;
     double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
@@ -351,7 +399,11 @@ struct SwdRayFamily {
     static constexpr int NENT = SWD_NENT, NV = 5;
     static constexpr bool LOVE = false;
     static RFS_HD void entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent) {
-        swd_layer_entries(L, wvno, wvno2, omega, iomega, ent);
+        swd_layer_entries<false>(L, wvno, wvno2, omega, iomega, ent);
+    }
+    // the same numbers with the two wave types' functions side by side (swd_trig_split2): for kernels short of wavefronts
+    static RFS_HD void entries_dual(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent) {
+        swd_layer_entries<true>(L, wvno, wvno2, omega, iomega, ent);
     }
     static RFS_HD void halfspace(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* e) {
         swd_halfspace_e(L, wvno, wvno2, omega, iomega, e);
@@ -369,6 +421,9 @@ struct SwdLoveFamily {
         ent[0] = cosq;
         ent[1] = (L.rho * L.b * L.b) * z;                     // mu z
         ent[2] = y * (L.irho * L.ib * L.ib);                  // y / mu
+    }
+    static RFS_HD void entries_dual(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent) {
+        entries(L, wvno, wvno2, omega, iomega, ent);
     }
     static RFS_HD void halfspace(const SwdLayerC& L, double wvno, double, double omega, double, double* e) {
         const double xkb = omega * L.ib;
@@ -1153,7 +1208,7 @@ using ExactGroup = ExactGroupT<true>;
 // The secular function of wave family F at phase velocity c, layer constants through a loader (m -> SwdLayerC):
 // the arithmetic of the lanes-per-item search (raw recurrence, power-of-two rescale every eighth layer, one final
 // normalisation), evaluated by ONE lane.
-template <class F, class LoadL>
+template <class F, bool DUAL = false, class LoadL>
 RFS_HD double swd_secular_family(int n, const LoadL& loadL, double omega_raw, double c) {
     const double omega = omega_raw < 1.0e-4 ? 1.0e-4 : omega_raw, iomega = 1.0 / omega;
     const double wvno = omega_raw / c, wvno2 = wvno * wvno, tt = -2.0 * wvno2;
@@ -1163,7 +1218,8 @@ RFS_HD double swd_secular_family(int n, const LoadL& loadL, double omega_raw, do
     for (int m = n - 2; m >= 0; m--) {
         const SwdLayerC Ln = loadL(m > 0 ? m - 1 : 0);      // next layer's constants on their way during this layer's math
         double ent[F::NENT];
-        F::entries(L, wvno, wvno2, omega, iomega, ent);
+        if (DUAL) F::entries_dual(L, wvno, wvno2, omega, iomega, ent);
+        else F::entries(L, wvno, wvno2, omega, iomega, ent);
         F::apply(e, ent, tt);
         if ((m & 7) == 0) swd_rescale_pow2_n<F::NV>(e);
         L = Ln;
