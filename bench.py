@@ -59,6 +59,7 @@ TUNED_DT = 0.05
 DT_SWEEP = (0.002, 0.02, 0.1)
 BURN_IN = 300           # device steps before the timed window (set-up + warm-up): the chains' burn-in -- acceptance and the share of
                         # chains with anomalous dispersion are stationary by then (scripts/dt_sweep.py)
+SUSTAIN_K = 100         # --steps below this: a second timed window of this many steps follows the contract's K (reported beside it)
 SIDE_BURN, SIDE_K = 60, 100      # the side legs (they continue burned-in chains): untimed / timed device steps
 DTYPE_TEXT = ("f64 (receiver-function row sweep beyond the Gaussian band: packed f32 where proven exact per chain, "
               "rf_f32_beyond_band)")
@@ -98,6 +99,87 @@ def alg_flops_per_eval(n, nt):
 
 ALG_BYTES_PER_EVAL = alg_bytes_per_eval(N_LAYER, NT)
 ALG_FLOPS_PER_EVAL = sum(alg_flops_per_eval(N_LAYER, NT).values())
+
+
+# ------------------------------------------------------------------------------------------ the line the driver parses
+LINE_LIMIT = 6000       # bytes: the driver keeps 8 KB of stdout; round 4's 21 KB line was cut and never parsed
+DETAIL_FILE = "bench_detail.json"
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step",
+              "group_ms_per_step", "launches_per_step", "avg_launch_ms")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "evals_per_s_per_core", "cpu_model", "shapes")
+_CONFIG_KEYS = ("workload", "chains_per_gpu", "nlayer", "nt", "nper", "dt", "accept_ratio", "L_range", "sampler",
+                "root_search_mode", "set_up_steps", "parallelism", "root_search_failures")
+
+
+def _rnd(v, sig=7):
+    """Floats to `sig` significant digits (the line is read by people and a parser, not fed back into arithmetic)."""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}") if np.isfinite(v) else None
+    if isinstance(v, dict):
+        return {k: _rnd(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_rnd(x, sig) for x in v]
+    return v
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def headline_line(res):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline` and scalars only -- every nested leg, per-group
+    table and prose note stays in bench_detail.json.  Always < LINE_LIMIT bytes."""
+    out = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data"):
+        if k in res:
+            out[k] = res[k]
+    cfg = res.get("config") or {}
+    out["config"] = {k: _clip(cfg[k], 160) for k in _CONFIG_KEYS if k in cfg}
+    if res.get("roofline"):
+        out["roofline"] = {k: res["roofline"][k] for k in _ROOF_KEYS if k in res["roofline"]}
+    if res.get("cpu_baseline"):
+        cb = res["cpu_baseline"]
+        out["cpu_baseline"] = {k: (_clip(cb[k], 200) if k != "shapes" else cb[k]) for k in _CPU_KEYS if k in cb}
+    vi = (res.get("valu_issue") or {}).get("step")
+    if vi:
+        out["valu_issue_frac"] = vi.get("frac")
+    rs = res.get("root_search") or {}
+    for k, short in (("secular_evals_per_item_warm_start_and_branch_test", "evals_per_item_warm"),
+                     ("secular_evals_per_item_reference_root_stage", "evals_per_item_exact"),
+                     ("chains_handed_back_to_the_full_search_per_step", "handed_back_per_step")):
+        if k in rs:
+            out[short] = rs[k]
+    for k, v in res.items():                       # every top-level scalar rides along (dt, accept_ratio, *_value, ...)
+        if k not in out and not k.startswith("_") and isinstance(v, (int, float, bool, type(None))):
+            out[k] = v
+        elif k not in out and isinstance(v, str) and len(v) <= 40:
+            out[k] = v
+    out["detail"] = DETAIL_FILE
+    out = _rnd(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                    # never again: drop the optional scalars before the contract's keys
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail")
+        line = json.dumps({k: out[k] for k in keep if k in out}, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def emit(res):
+    """bench_detail.json (everything) beside bench.py -- and under gpurun_out/ where that exists -- then the headline line
+    as the LAST line of stdout."""
+    res = {k: v for k, v in res.items() if not k.startswith("_")}
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if not res.get("dry_run") else ():
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    json.dump(res, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {d}/{DETAIL_FILE}: {e}", file=sys.stderr)
+    sys.stderr.flush()
+    print(headline_line(res))
+    sys.stdout.flush()
 
 
 def true_model(n=N_LAYER):
@@ -315,7 +397,7 @@ def launch(args, argv):
                     "algorithm's (2.8e7); the rest is this box's GPU against its host cores.  A CPU build of the O(n) algorithm does "
                     "not ship (no CPU fallback in the product), so the split is by flop count, not by a second CPU measurement"}
     res.pop("_cpu_inputs", None)
-    print(json.dumps(res))
+    emit(res)
 
 
 # ------------------------------------------------------------------------------------------ one rank
@@ -500,9 +582,10 @@ def set_root_mode(joint, n, mode):
 
 
 def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, barrier, kind="hmc", dt=TUNED_DT,
-                mode="reference_roots", xs=None, groups=True):
+                mode="reference_roots", xs=None, groups=True, K2=0):
     """A real sampler run on the continuous-flow schedule (HamitonianMC.sample_flow / HMCDualAveraging.sample_flow): `burn`
-    device steps untimed, K timed.  kind "hmc": pyhmc/hmc.py:228-276 at step size dt, L ~ U{5..20} (param.yaml:38); "da":
+    device steps untimed, K timed (then, K2 > 0: a second timed window of K2 steps straight behind it -- the driver's K = 20 is a
+    0.1 s window that starts from a drained device and ends waiting for the background searches).  kind "hmc": pyhmc/hmc.py:228-276 at step size dt, L ~ U{5..20} (param.yaml:38); "da":
     main_DA.py's dual averaging (dt0 0.1, L0 10, target 0.65).  groups: per-kernel-group times -- every group on its own in a
     few one-stream steps before the window (that picks the dominant group), the dominant one live over the window."""
     import torch
@@ -519,7 +602,7 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
             xs[:, :n] = np.sort(xs[:, :n], axis=1)
         else:
             xs = make_models(nchain, seed=991206 + rank, n=n)      # chain c of rank r ~ reference rank r * nchain + c
-    nsamp = (burn + K) // 4 + 20                                   # more sample slots than trajectories can complete
+    nsamp = (burn + K + K2) // 4 + 20                                   # more sample slots than trajectories can complete
     if kind == "da":
         # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
         smp = HMCDualAveraging(joint, bounds, 0.1, 10, max(10, nsamp // 10 + 1), 0.65, 991206, nsamp, 20, myrank=rank, name="bench", outdir=None,
@@ -561,8 +644,14 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
             marks["dt"] = st["dt"].clone(); marks["rem"] = st["rem"].clone(); marks["x"] = st["x"].clone()
             marks["U"] = float(st["Ucur"].median().item()); marks["fail"] = int((st["ok"] == 0).sum().item())
             marks["misfit"] = st["Ucur"].clone()
+            marks["t1b"] = time.perf_counter()
+        if K2 and s == burn + K + K2:
+            ctx.check(ctx.L.rfs_synchronize(ctx.h))
+            barrier()
+            marks["t2"] = time.perf_counter()
+            marks["stat2"] = ctx.stat("flow_chain_steps")
 
-    smp.sample_flow(x_init=xs, max_steps=burn + K + 1, step_hook=hook)
+    smp.sample_flow(x_init=xs, max_steps=burn + K + K2 + 1, step_hook=hook)
     el = marks["t1"] - marks["t0"]
     d = {k: marks["stat1"][k] - marks["stat0"][k] for k in STATS}
     evals = int(d["flow_chain_steps"])
@@ -597,6 +686,10 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
                         "chains_walking_the_scan_grid_per_step": d["swd_warm_walked_chains"] / K,
                         "chains_handed_back_to_the_full_search_per_step": d["swd_warm_declined_chains"] / K,
                         "of_those_by_the_reference_root_stage_per_step": d["swd_exact_declined_chains"] / K}})
+    if K2:
+        el2 = marks["t2"] - marks["t1b"]
+        rep["sustained"] = {"steps": K2, "ms_per_step": el2 / K2 * 1e3,
+                            "value": (marks["stat2"] - marks["stat1"]["flow_chain_steps"]) / el2, "unit": "evals/s"}
     if kind == "da":
         Lv = np.maximum(1, (10 * 0.1 / dtv).astype(int))           # L = max(1, int(lambda / dt)), lambda = L0 * dt0 (hmcda.py:307)
         q = lambda a: [float(v) for v in np.quantile(a, [0.05, 0.5, 0.95])]
@@ -664,7 +757,8 @@ def run_rank(args):
     ctx = joint._ensure(n)
     extra = {}
     rep, xs, el, evals_rank, x_end, misfit = sampler_leg(cfg, args.config, joint, x_true, bounds, nchain, srank, dev, K, burn,
-                                                          barrier, kind=kind, dt=dt, mode=mode)
+                                                          barrier, kind=kind, dt=dt, mode=mode,
+                                                          K2=(SUSTAIN_K if K < SUSTAIN_K else 0))
     if misfit is None:
         misfit = torch.zeros(nchain, dtype=torch.float64, device=dev)
     side_legs = rank == 0 and world == 1 and kind == "hmc" and not args.headline_only
@@ -705,11 +799,15 @@ def run_rank(args):
         extra["eval_only_ms_per_call"] = (time.perf_counter() - t1) / 20 * 1e3      # plugin entry: full search every call
 
     total_evals = evals_rank
+    sus = rep.get("sustained")
+    sus_el = sus["ms_per_step"] * sus["steps"] * 1e-3 if sus else 0.0
+    sus_evals = sus["value"] * sus_el if sus else 0.0
     if dist is not None:
-        red = torch.tensor([el, float(evals_rank)], dtype=torch.float64, device=cdev)
-        tmax = red[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = red[1:].clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        el, total_evals = float(tmax.item()), float(tsum.item())
+        red = torch.tensor([el, sus_el, float(evals_rank), sus_evals], dtype=torch.float64, device=cdev)
+        tmax = red[:2].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = red[2:].clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        el, total_evals = float(tmax[0].item()), float(tsum[0].item())
+        sus_el, sus_evals = float(tmax[1].item()), float(tsum[1].item())
         # the path's only collective: gather the per-chain misfits on rank 0 (after the timed region)
         from rfsurfhmc_amd.chains import gather_misfits
         gathered = gather_misfits(misfit.to(cdev))
@@ -743,7 +841,7 @@ def run_rank(args):
         "metric": METRIC,
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": DTYPE_TEXT, "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "dtype_note": DTYPE_TEXT, "data": "synthetic",
         "config": {"workload": cfg["name"] if not (args.config == 1 and world * nchain == 65536) else
                    "configs[2]: 65536 chains x 30-layer joint RF+SWD, 8xMI355X independent-chain shard, RCCL gather "
                    "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
@@ -767,6 +865,10 @@ def run_rank(args):
               "adapted_dt_quantiles_5_50_95", "L_quantiles_5_50_95"):
         if k in rep:
             res[k] = rep[k]
+    if sus:
+        # (--steps below SUSTAIN_K: the contract's K-step window is `value`; the longer window right behind it rides along)
+        res["sustained_steps"] = sus["steps"]; res["sustained_ms_per_step"] = sus_el / sus["steps"] * 1e3
+        res["sustained_value"] = sus_evals / sus_el
     for k, v in extra.items():
         res[k] = v
     # the side legs' rates as top-level scalars as well
@@ -779,8 +881,11 @@ def run_rank(args):
     if world == 1 and not args.no_cpu_baseline and os.environ.get("RFS_BENCH_CHILD"):
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         res["_cpu_inputs"] = {"xs": x_end[:max(64, ncpu)].tolist(), "dobs": joint.dobs.tolist()}
-    print(json.dumps(res))
-    sys.stdout.flush()
+    if os.environ.get("RFS_BENCH_CHILD"):
+        print(json.dumps(res))                       # to the launching process (a pipe), which adds the CPU baseline and emits
+        sys.stdout.flush()
+    else:
+        emit(res)                                    # a rank of torch.distributed.run: the line itself
     if dist is not None:
         dist.destroy_process_group()
 
