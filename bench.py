@@ -59,6 +59,8 @@ TUNED_DT = 0.05
 DT_SWEEP = (0.002, 0.02, 0.1)
 BURN_IN = 300           # device steps before the timed window (set-up + warm-up): the chains' burn-in -- acceptance and the share of
                         # chains with anomalous dispersion are stationary by then (scripts/dt_sweep.py)
+DA_ADAPT_CAP = 2600     # device steps the configs[3] leg waits for 95 % of its chains to finish adapting (then it times anyway and says so)
+DA_NDRAWS = 6           # adapting trajectories per chain in the configs[3] leg (the reference's param.yaml: 200)
 SUSTAIN_K = 100         # --steps below this: a second timed window of this many steps follows the contract's K (reported beside it)
 SIDE_BURN, SIDE_K = 60, 100      # the side legs (they continue burned-in chains): untimed / timed device steps
 DTYPE_TEXT = ("f64 (receiver-function row sweep beyond the Gaussian band: packed f32 where proven exact per chain, "
@@ -219,8 +221,9 @@ def _cpu_worker(args):
     """One host core: the reference's own compiled sources (oracle/_ref: libsurf complete; RF propagator / partials
     core from RFModule.f90 + numpy irfft for the 15-line tail) driven by the oracle's numpy restatement of the
     plugins, one independent chain per process as the reference runs them (README.md:43-44).  Falls back to the C
-    restatement where oracle/_ref is absent."""
-    wid, n, nt, dt, dobs, xs, budget_s = args
+    restatement where oracle/_ref is absent.  shape "joint": Joint_RF_SWD (configs[1] / [3] / [4]); "swd0": configs[0]'s
+    SWD-only plugin (36 Rc + 36 Rg periods)."""
+    wid, shape, n, nt, dt, dobs, xs, budget_s = args
     # (the reference's Fortran writes a model dump to unit 6 whenever its root search fails -- surfdisp96.f:320-336 -- and the
     # burned-in models of the bench do make it fail now and then: keep that out of the launcher's stdout, which carries the JSON line)
     try:
@@ -237,19 +240,24 @@ def _cpu_worker(args):
     except Exception:
         pass
     from oracle import oracle as O
-    t = np.linspace(5, 44, NPER)
     if O.ref_available():
         kind, swd_lib, rf_lib = "reference", O.ref_libsurf(), O.RefRFCore()
     else:
         kind, swd_lib, rf_lib = "port", O.libsurf, O.librf
-    joint = O.Joint_RF_SWD(1.0, 1.0, O.ReceiverFunc(RAY_P, nt, dt, GAUSS, TSHIFT, WATER, "P", "freq", lib=rf_lib),
-                           O.SurfWD(tRc=t, lib=swd_lib))
-    joint.set_obsdata(dobs[:nt], dobs[nt:])
-    joint.misfit_and_grad(xs[0])                     # first call: library loading, page faults
+    if shape == "swd0":
+        t0p = np.arange(5., 41.)
+        model = O.SurfWD(tRc=t0p, tRg=t0p, lib=swd_lib)
+        model.set_obsdata(dobs)
+    else:
+        t = np.linspace(5, 44, NPER)
+        model = O.Joint_RF_SWD(1.0, 1.0, O.ReceiverFunc(RAY_P, nt, dt, GAUSS, TSHIFT, WATER, "P", "freq", lib=rf_lib),
+                               O.SurfWD(tRc=t, lib=swd_lib))
+        model.set_obsdata(dobs[:nt], dobs[nt:])
+    model.misfit_and_grad(xs[0])                     # first call: library loading, page faults
     k = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        joint.misfit_and_grad(xs[(wid + k) % len(xs)])
+        model.misfit_and_grad(xs[(wid + k) % len(xs)])
         k += 1
     return kind, k, time.perf_counter() - t0
 
@@ -291,11 +299,20 @@ def _host_cpus():
     return allowed, (len(cores) if cores else len(allowed)), model
 
 
-def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
+def _cpu_pool_rate(ncores, shape, n, nt, dt, dobs, xs, budget_s):
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    sample = xs[:max(64, ncores)]
+    with ctx.Pool(ncores) as pool:
+        res = pool.map(_cpu_worker, [(w, shape, n, nt, dt, dobs, sample, budget_s) for w in range(ncores)])
+    return res[0][0], float(sum(k / el for _, k, el in res)), int(sum(k for _, k, _ in res))
+
+
+def cpu_baseline(cfg, xs, dobs, budget_s=15.0, others=None):
     """Reference CPU path on ALL host cores: one independent process per physical core (the reference's only
     parallelism: one chain per MPI rank), same models as the GPU run; runs in the launching process, which never
-    initialised the GPU, after the GPU ranks have finished."""
-    import multiprocessing as mp
+    initialised the GPU, after the GPU ranks have finished.  others: {"config3": dict(n, nt, dt, xs, dobs), ...} -- the
+    other configurations' shapes, a few seconds each, reported under "shapes"."""
     from oracle import oracle as O
     O.build(ref=False)
     allowed, nphys, model = _host_cpus()
@@ -303,25 +320,32 @@ def cpu_baseline(cfg, xs, dobs, budget_s=15.0):
     # one process per core the container can actually run: its physical cores, capped by the cgroup's CPU quota (more
     # processes than that only time-share the same cores)
     ncores = max(1, min(nphys, int(quota)) if quota else nphys)
-    ctx = mp.get_context("fork")
-    sample = xs[:max(64, ncores)]
-    with ctx.Pool(ncores) as pool:
-        res = pool.map(_cpu_worker, [(w, cfg["n"], cfg["nt"], cfg["dt"], dobs, sample, budget_s) for w in range(ncores)])
-    kind = res[0][0]
-    rates = [k / el for _, k, el in res]
-    total = float(sum(rates))
-    return {"value": total, "unit": "evals/s", "cores": ncores, "physical_cores_visible": nphys,
-            "logical_cpus": len(allowed), "cpu_quota_cores": quota, "cpu_model": model,
-            "evals_per_s_per_core": total / ncores,
-            "kind": kind,
-            "kind_detail": ("reference (RF tail numpy): oracle/_ref = the reference's own sources, compiled in the BUILD "
-                            "container by oracle/Makefile and shipped to this box as binaries -- libsurf complete, RF "
-                            "propagator/partials core of RFModule.f90; the 15-line RF tail (water level, Gaussian, irfft, "
-                            "e^{sigma t}) is numpy because FFTW3 is absent from the image" if kind == "reference"
-                            else "port: the C restatement oracle/liboracle.so"),
-            "sample": f"{sum(k for _, k, _ in res)} joint misfit+grad evaluations of the bench's own {cfg['n']}-layer "
-                      f"models (nt = {cfg['nt']}, {NPER} Rc periods), {ncores} independent processes (one per core the "
-                      f"container may use) for {budget_s:.0f} s each"}
+    kind, total, nev = _cpu_pool_rate(ncores, "joint", cfg["n"], cfg["nt"], cfg["dt"], dobs, xs, budget_s)
+    out = {"value": total, "unit": "evals/s", "cores": ncores, "physical_cores_visible": nphys,
+           "logical_cpus": len(allowed), "cpu_quota_cores": quota, "cpu_model": model,
+           "evals_per_s_per_core": total / ncores,
+           "kind": kind,
+           "kind_detail": ("reference (RF tail numpy): oracle/_ref = the reference's own sources, compiled in the BUILD "
+                           "container by oracle/Makefile and shipped to this box as binaries -- libsurf complete, RF "
+                           "propagator/partials core of RFModule.f90; the 15-line RF tail (water level, Gaussian, irfft, "
+                           "e^{sigma t}) is numpy because FFTW3 is absent from the image" if kind == "reference"
+                           else "port: the C restatement oracle/liboracle.so"),
+           "sample": f"{nev} joint misfit+grad evaluations of the bench's own {cfg['n']}-layer "
+                     f"models (nt = {cfg['nt']}, {NPER} Rc periods), {ncores} independent processes (one per core the "
+                     f"container may use) for {budget_s:.0f} s each"}
+    shapes = {}
+    for tag, o in (others or {}).items():
+        try:
+            nc = 1 if o.get("shape") == "swd0" else ncores          # configs[0] is ONE chain on one core (param.yaml, mpi4py n = 1)
+            _, rate, ne = _cpu_pool_rate(nc, o.get("shape", "joint"), o["n"], o["nt"], o["dt"], np.array(o["dobs"]), np.array(o["xs"]),
+                                         o.get("budget_s", 5.0))
+            shapes[tag] = {"value": rate, "cores": nc, "evals": ne}
+        except Exception as e:                                        # (a side figure must not cost the line)
+            shapes[tag] = {"value": None, "error": str(e)[:200]}
+    if shapes:
+        out["shapes"] = {k: (None if v["value"] is None else float(f"{v['value']:.5g}")) for k, v in shapes.items()}
+        out["shapes_detail"] = shapes
+    return out
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -385,7 +409,10 @@ def launch(args, argv):
     if n == 1 and not args.no_cpu_baseline and not args.dry_run:
         cfg = CONFIGS[args.config]
         side = res.pop("_cpu_inputs")
-        res["cpu_baseline"] = cpu_baseline(cfg, np.array(side["xs"]), np.array(side["dobs"]))
+        res["cpu_baseline"] = cpu_baseline(cfg, np.array(side["xs"]), np.array(side["dobs"]), others=side.get("others"))
+        for tag, v in (res["cpu_baseline"].get("shapes") or {}).items():
+            if v and isinstance(res.get(f"{tag}_value"), (int, float)):
+                res[f"{tag}_gpu_over_cpu"] = res[f"{tag}_value"] / v
         g = res["value"] / res["cpu_baseline"]["value"]
         res["gpu_over_cpu_node"] = g
         # the two components of that ratio.  The CPU figure is the reference as written (O(n^2)
@@ -544,7 +571,7 @@ def flow_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, nwarm, ba
     nw = max(nwarm - 1, 1)
     ms_step = {k: ms_w[i] / nw for i, k in enumerate(gt.names)}
     launches = {k: cnt_w[i] / nw for i, k in enumerate(gt.names)}
-    dom_id = int(np.argmax([ms_step[k] for k in gt.names]))
+    dom_id = int(np.argmax([ms_step[k] if k != "flow_step" else 0.0 for k in gt.names]))
     gt.on(1 << dom_id)                                             # the dominant group only, measured live below
     d0 = ctx.stat("swd_warm_declined_chains"); i0 = ctx.stat("swd_warm_items"); e0 = ctx.stat("swd_warm_secular_evals")
     barrier()
@@ -582,12 +609,14 @@ def set_root_mode(joint, n, mode):
 
 
 def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, barrier, kind="hmc", dt=TUNED_DT,
-                mode="reference_roots", xs=None, groups=True, K2=0):
+                mode="reference_roots", xs=None, groups=True, K2=0, adapt_cap=0):
     """A real sampler run on the continuous-flow schedule (HamitonianMC.sample_flow / HMCDualAveraging.sample_flow): `burn`
     device steps untimed, K timed (then, K2 > 0: a second timed window of K2 steps straight behind it -- the driver's K = 20 is a
     0.1 s window that starts from a drained device and ends waiting for the background searches).  kind "hmc": pyhmc/hmc.py:228-276 at step size dt, L ~ U{5..20} (param.yaml:38); "da":
     main_DA.py's dual averaging (dt0 0.1, L0 10, target 0.65).  groups: per-kernel-group times -- every group on its own in a
-    few one-stream steps before the window (that picks the dominant group), the dominant one live over the window."""
+    few one-stream steps before the window (that picks the dominant group), the dominant one live over the window.
+    adapt_cap > 0 (kind "da"): the window starts once 95 % of the chains have completed their `ndraws` adapting trajectories
+    (hmcda.py:329-345: the step size is then frozen at dtbar) -- or after adapt_cap device steps, whichever comes first."""
     import torch
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     from rfsurfhmc_amd.pyhmc.hmcda import HMCDualAveraging
@@ -605,8 +634,11 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
     nsamp = (burn + K + K2) // 4 + 20                                   # more sample slots than trajectories can complete
     if kind == "da":
         # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
-        smp = HMCDualAveraging(joint, bounds, 0.1, 10, max(10, nsamp // 10 + 1), 0.65, 991206, nsamp, 20, myrank=rank, name="bench", outdir=None,
-                               nchains=nchain, verbose=False, store_syn=False)
+        # (the leg cannot afford param.yaml's 200 adapting trajectories of ~1 time unit each: DA_NDRAWS of them, the sample
+        # count sized so that ndraws >= 0.1 nsamples holds, hmcda.py:57-60)
+        nsamp = min(max(nsamp, 40), 10 * DA_NDRAWS) if adapt_cap else nsamp
+        smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, nsamp, DA_NDRAWS if adapt_cap else 20, myrank=rank,
+                               name="bench", outdir=None, nchains=nchain, verbose=False, store_syn=False)
         # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
         # given the chains different step sizes) finish in bursts; time a window behind them
         burn = max(burn, 40)
@@ -618,7 +650,19 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
              "swd_warm_walked_chains", "swd_exact_declined_chains", "flow_chain_steps")
     nser = 4 if (groups and burn >= 12) else 0
 
+    class _StopLeg(Exception):
+        pass
+
+    sched = {"burn": None if (adapt_cap and kind == "da") else burn}
+
     def hook(s, st):
+        burn = sched["burn"]
+        if burn is None:                                           # dual averaging still adapting: look every 16 steps
+            if s >= 40 and s % 16 == 0:
+                share = float(np.mean(smp.live_counts[1] >= smp.ndraws))
+                if share >= 0.95 or s >= adapt_cap:
+                    sched["burn"] = s + nser + 3; marks["adapted_share"] = share
+            return
         if nser and s == burn - nser - 2:
             ctx.set_option("swd_warm_serial", 1)                   # one stream: every kernel group alone on the chip
         if nser and s == burn - nser - 1:
@@ -626,7 +670,9 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
         if nser and s == burn - 1:
             marks["alone"] = gt.read()
             ctx.set_option("swd_warm_serial", 0)
-            marks["dom"] = int(np.argmax(marks["alone"][0]))
+            alone = np.array(marks["alone"][0], dtype=float)
+            alone[[i for i, k in enumerate(gt.names) if k == "flow_step"]] = 0.0      # (the whole step's span is not a kernel group)
+            marks["dom"] = int(np.argmax(alone))
             gt.on(1 << marks["dom"])                               # the dominant group only, measured live below
         if s == burn:
             marks["stat0"] = {k: ctx.stat(k) for k in STATS}
@@ -644,22 +690,30 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
             marks["dt"] = st["dt"].clone(); marks["rem"] = st["rem"].clone(); marks["x"] = st["x"].clone()
             marks["U"] = float(st["Ucur"].median().item()); marks["fail"] = int((st["ok"] == 0).sum().item())
             marks["misfit"] = st["Ucur"].clone()
+            if "dom" in marks:
+                marks["live"] = gt.read(); gt.off()             # the dominant group's HIP events over exactly the K timed steps
             marks["t1b"] = time.perf_counter()
+            if not K2:
+                raise _StopLeg
         if K2 and s == burn + K + K2:
             ctx.check(ctx.L.rfs_synchronize(ctx.h))
             barrier()
             marks["t2"] = time.perf_counter()
             marks["stat2"] = ctx.stat("flow_chain_steps")
+            raise _StopLeg
 
-    smp.sample_flow(x_init=xs, max_steps=burn + K + K2 + 1, step_hook=hook)
+    try:                                                           # (the hook ends the run once its last time stamp is taken)
+        smp.sample_flow(x_init=xs, max_steps=(adapt_cap + 64 if sched["burn"] is None else burn) + K + K2 + 16, step_hook=hook)
+    except _StopLeg:
+        ctx.check(ctx.L.rfs_synchronize(ctx.h))
+    burn = sched["burn"]
     el = marks["t1"] - marks["t0"]
     d = {k: marks["stat1"][k] - marks["stat0"][k] for k in STATS}
     evals = int(d["flow_chain_steps"])
     items = max(d["swd_warm_items"], 1)
     nacc, ntraj = marks["acc1"][0] - marks["acc0"][0], marks["acc1"][1] - marks["acc0"][1]
     if "dom" in marks:
-        ms, cnt = gt.read()
-        gt.off()
+        ms, cnt = marks["live"]
         ms_a, cnt_a = marks["alone"]
         ms_step = {k: ms_a[i] / nser for i, k in enumerate(gt.names)}
         launches = {k: cnt_a[i] / nser for i, k in enumerate(gt.names)}
@@ -691,11 +745,67 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
         rep["sustained"] = {"steps": K2, "ms_per_step": el2 / K2 * 1e3,
                             "value": (marks["stat2"] - marks["stat1"]["flow_chain_steps"]) / el2, "unit": "evals/s"}
     if kind == "da":
+        rep["L_cap"] = int(smp.L_cap); rep["trajectory_lengths_clamped_to_L_cap"] = int(getattr(smp, "n_L_clamped", 0))
+        rep["adapting_trajectories_per_chain"] = int(smp.ndraws)
+        if "adapted_share" in marks:
+            rep["share_of_chains_past_adaptation_at_window_start"] = marks["adapted_share"]
         Lv = np.maximum(1, (10 * 0.1 / dtv).astype(int))           # L = max(1, int(lambda / dt)), lambda = L0 * dt0 (hmcda.py:307)
         q = lambda a: [float(v) for v in np.quantile(a, [0.05, 0.5, 0.95])]
         rep["adapted_dt_quantiles_5_50_95"] = q(dtv); rep["adapted_dt_max"] = float(dtv.max())
         rep["L_quantiles_5_50_95"] = q(Lv)
     return rep, xs, el, evals, marks["x"].cpu().numpy(), marks.get("misfit")
+
+
+def config0_leg(local_rank, dev, K=300, burn=40):
+    """configs[0], the reference's param.yaml as it ships: ONE chain, the SWD-only plugin (model/model_surf.py), 10 layers,
+    36 Rc + 36 Rg periods 5 .. 40 s (param.yaml:16-21), plain HMC at dt 0.1, L ~ U{5..20} (:36-40) -- the case the reference
+    runs as `mpiexec -n 1`.  One chain is a latency measurement: evaluations per second of that single chain, ms per
+    evaluation.  Returns (report, inputs of the CPU leg at this shape)."""
+    import torch
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
+    t = np.arange(5., 41.)
+    x0 = np.hstack((vs, thk))
+    m = SurfWD(tRc=t, tRg=t, device=local_rank)
+    d, flag = m.forward(x0)
+    assert flag
+    m.set_obsdata(d)
+    bounds = bounds_of(x0)
+    smp = HamitonianMC(m, bounds, 0.1, [5, 20], 10, 991206, 800, 200, myrank=0, name="bench0", outdir=None, nchains=1,
+                       verbose=False, store_syn=False)
+    ctx = m._ensure(10)
+    marks = {}
+
+    class _Stop(Exception):
+        pass
+
+    def hook(s, st):
+        if s == burn:
+            torch.cuda.synchronize(); marks["e0"] = ctx.stat("flow_chain_steps"); marks["a0"] = tuple(int(a.sum()) for a in smp.live_counts)
+            marks["t0"] = time.perf_counter()
+        if s == burn + K:
+            ctx.check(ctx.L.rfs_synchronize(ctx.h)); torch.cuda.synchronize()
+            marks["t1"] = time.perf_counter(); marks["e1"] = ctx.stat("flow_chain_steps")
+            marks["a1"] = tuple(int(a.sum()) for a in smp.live_counts)
+            raise _Stop
+
+    try:
+        smp.sample_flow(max_steps=burn + K + 8, step_hook=hook)
+    except _Stop:
+        pass
+    el, ev = marks["t1"] - marks["t0"], marks["e1"] - marks["e0"]
+    ntraj = marks["a1"][1] - marks["a0"][1]
+    rep = {"workload": "configs[0]: param.yaml default -- 1 chain, 10-layer Vs model, SWD-only plugin (36 Rc + 36 Rg periods), "
+                       "HamitonianMC dt 0.1, L ~ U{5..20}", "value": ev / el, "unit": "evals/s", "ms_per_eval": el / max(ev, 1) * 1e3,
+           "device_steps": K, "evaluations": int(ev), "accept_ratio": (marks["a1"][0] - marks["a0"][0]) / max(ntraj, 1),
+           "note": "one chain = one wavefront's worth of work per kernel: a latency figure, set by the length of the dependent "
+                   "chain of one evaluation (three root searches + eigenfunction passes per group-velocity period)"}
+    rng = np.random.default_rng(5)
+    xs = np.clip(x0[None, :] * (1 + 0.02 * rng.standard_normal((16, 20))), bounds[:, 0], bounds[:, 1])
+    xs[:, :10] = np.sort(xs[:, :10], axis=1)
+    m._ctx.close(); m._ctx = None
+    return rep, {"shape": "swd0", "n": 10, "nt": 0, "dt": 0.0, "xs": xs.tolist(), "dobs": np.asarray(d).tolist(), "budget_s": 4.0}
 
 
 STEP_TEXT = {
@@ -822,6 +932,7 @@ def run_rank(args):
         return
 
     # ---- the other single-GPU configurations of BASELINE.json, as short legs of the default run
+    cpu_others = {}
     if world == 1 and args.config == 1 and nchain == 8192 and not args.headline_only and not args.no_other_configs:
         joint._ctx.close(); joint._ctx = None; joint._cfg = None
         torch.cuda.empty_cache()
@@ -829,12 +940,18 @@ def run_rank(args):
             c2 = CONFIGS[ci]
             j2, xt2, b2 = make_joint(c2, local_rank)
             k2 = "da" if c2["sampler"] == "da" else "hmc"
-            r2, _, _, _, _, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, SIDE_K, BURN_IN, barrier, kind=k2,
-                                            dt=c2.get("hmc_dt", TUNED_DT), mode=mode)
+            r2, _, _, _, xe2, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, SIDE_K, BURN_IN, barrier, kind=k2,
+                                              dt=c2.get("hmc_dt", TUNED_DT), mode=mode, adapt_cap=DA_ADAPT_CAP if k2 == "da" else 0)
             r2["workload"] = c2["name"]; r2["step"] = STEP_TEXT[c2["sampler"]]
             extra[f"config{ci}"] = r2
+            cpu_others[f"config{ci}"] = {"shape": "joint", "n": c2["n"], "nt": c2["nt"], "dt": c2["dt"], "xs": xe2[:64].tolist(),
+                                         "dobs": j2.dobs.tolist(), "budget_s": 5.0}
             j2._ctx.close(); j2._ctx = None
             torch.cuda.empty_cache()
+        try:
+            extra["config0"], cpu_others["config0"] = config0_leg(local_rank, dev)
+        except Exception as e:                       # (a side leg must not cost the line)
+            extra["config0"] = {"value": None, "error": repr(e)[:300]}
 
     value = total_evals / el
     res = {
@@ -872,15 +989,19 @@ def run_rank(args):
     for k, v in extra.items():
         res[k] = v
     # the side legs' rates as top-level scalars as well
-    for k in ("converged_roots", "full_search_every_step", "never_ending_dt0002", "config3", "config4"):
+    for k in ("converged_roots", "full_search_every_step", "never_ending_dt0002", "config3", "config4", "config0"):
         if k in extra:
             res[f"{k}_value"] = extra[k]["value"]
+    if "config0" in extra and extra["config0"].get("ms_per_eval"):
+        res["config0_ms_per_eval"] = extra["config0"]["ms_per_eval"]
+    if "config3" in extra:
+        res["config3_accept_ratio"] = extra["config3"].get("accept_ratio")
     for r in extra.get("dt_sweep", []):
         tag = str(r["dt"]).replace(".", "p")
         res[f"dt_{tag}_value"] = r["value"]; res[f"dt_{tag}_accept_ratio"] = r["accept_ratio"]
     if world == 1 and not args.no_cpu_baseline and os.environ.get("RFS_BENCH_CHILD"):
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        res["_cpu_inputs"] = {"xs": x_end[:max(64, ncpu)].tolist(), "dobs": joint.dobs.tolist()}
+        res["_cpu_inputs"] = {"xs": x_end[:max(64, ncpu)].tolist(), "dobs": joint.dobs.tolist(), "others": cpu_others}
     if os.environ.get("RFS_BENCH_CHILD"):
         print(json.dumps(res))                       # to the launching process (a pipe), which adds the CPU baseline and emits
         sys.stdout.flush()

@@ -400,10 +400,16 @@ int rfs_get_stat(rfs_ctx* ctx, const char* name, int64_t* value);
  * duration inside a timed region enables just that one. */
 typedef enum {
     RFS_K_PREP = 0, RFS_K_RF_PASS_A, RFS_K_RF_MID, RFS_K_RF_PASS_B, RFS_K_SWD_ROOTS, RFS_K_SWD_EIGEN,
-    RFS_K_COMBINE, RFS_K_SWD_EXACT /* the reference-root stage behind a warm start ("swd_warm_exact") */, RFS_K_COUNT
+    RFS_K_COMBINE, RFS_K_SWD_EXACT /* the reference-root stage behind a warm start ("swd_warm_exact") */,
+    RFS_K_FLOW_STEP /* one whole rfs_flow_step / rfs_flow_step2 call on the caller's stream: first launch .. behind the kick */, RFS_K_COUNT
 } rfs_kernel_id;
 int rfs_enable_timing(rfs_ctx* ctx, int on);
 int rfs_kernel_ms_sum(rfs_ctx* ctx, double* ms /* [RFS_K_COUNT] */, int32_t* count /* [RFS_K_COUNT] */);
+/* Where in a flow step each group runs, without a profiler attached: for every group the SUMS over the event pairs gathered
+ * since timing was switched on of (group start - step start) and (group end - step start) in ms, step start = the first
+ * launch of the rfs_flow_step2 call the pair belongs to (RFS_K_FLOW_STEP must be in the mask), and the number of pairs.
+ * Synchronises; does not reset (rfs_kernel_ms_sum does).  Diagnostics: profiles/r05_step_timeline_events.txt. */
+int rfs_kernel_timeline(rfs_ctx* ctx, double* start_ms /* [RFS_K_COUNT] */, double* end_ms /* [RFS_K_COUNT] */, int32_t* count /* [RFS_K_COUNT] */);
 
 #ifdef __cplusplus
 }

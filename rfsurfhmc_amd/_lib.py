@@ -13,7 +13,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_float_p = ctypes.POINTER(ctypes.c_float)
 
 RFS_WAVE = {"Rc": 0, "Rg": 1, "Lc": 2, "Lg": 3}
-K_NAMES = ["prep", "rf_pass_a", "rf_mid", "rf_pass_b", "swd_roots", "swd_eigen", "combine", "swd_exact"]
+K_NAMES = ["prep", "rf_pass_a", "rf_mid", "rf_pass_b", "swd_roots", "swd_eigen", "combine", "swd_exact", "flow_step"]
 
 
 class RfParams(ctypes.Structure):
@@ -67,7 +67,9 @@ SIGNATURES = {
     "rfs_get_stat": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "rfs_enable_timing": (_i, [_vp, _i]),
     "rfs_kernel_ms_sum": (_i, [_vp, _vp, _vp]),
+    "rfs_kernel_timeline": (_i, [_vp, _vp, _vp, _vp]),
 }
+_DIAGNOSTIC = {"rfs_kernel_timeline"}      # (absent from older builds loaded through RFSURF_LIB for A/B runs)
 
 _LIB = None
 
@@ -88,6 +90,8 @@ def load() -> ctypes.CDLL:
             pass
         L = ctypes.CDLL(LIBPATH)
         for name, (res, args) in SIGNATURES.items():
+            if name in _DIAGNOSTIC and not hasattr(L, name) and os.environ.get("RFSURF_LIB"):
+                continue
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -101,6 +101,9 @@ struct rfs_ctx {
     bool last_async = false;   // ... and did (a warm-started step with a side stream)
     int fpend_nchain = 0;
     const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
+    bool warm_widen = true;    // option "swd_warm_widen": the warm search may bracket beyond its trust radius (the grid walk then vouches)
+    bool flow_skip_idle = true;   // option "flow_skip_idle": idle chains of a flow step are neither continued nor handed back
+    const int *f_rem = nullptr, *f_fresh = nullptr, *f_ok = nullptr;   // the flow state's arrays during a flow step (k_swd_warm: idle chains)
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
@@ -139,6 +142,8 @@ struct rfs_ctx {
     unsigned timing_mask = ~0u;     // groups that get event pairs while timing is on (bit = rfs_kernel_id)
     std::vector<hipEvent_t> tev[RFS_K_COUNT];
     size_t tused[RFS_K_COUNT] = {};
+    std::vector<hipEvent_t> tref[RFS_K_COUNT];   // per event pair: the start event of the flow step it belongs to (rfs_kernel_timeline), or nullptr
+    hipEvent_t cur_step_ev = nullptr;
 };
 
 namespace {
@@ -236,7 +241,12 @@ struct KTimer {   // brackets a group of launches with HIP events on the stream 
         auto& pool = c->tev[id];
         size_t& u = c->tused[id];
         while (pool.size() < u + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pool.push_back(e); }
-        hipEventRecord(pool[u], s); e1 = pool[u + 1]; u += 2;
+        hipEventRecord(pool[u], s); e1 = pool[u + 1];
+        if (id == RFS_K_FLOW_STEP) c->cur_step_ev = pool[u];
+        auto& ref = c->tref[id];
+        if (ref.size() < u / 2 + 1) ref.resize(u / 2 + 1);
+        ref[u / 2] = c->cur_step_ev;
+        u += 2;
     }
     ~KTimer() { if (e1) hipEventRecord(e1, s); }
 };
@@ -352,13 +362,11 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     int* scn = sc ? c->scount.as<int>() + ((c->speel_eval + 1) & 1) : nullptr;
     const RfLayer* lc = c->lc.as<RfLayer>() + c0 * n;
     const int bs = rf_block_of(f, 128);
-    dim3 grid(nchain, rf_chunks_of(f, bs));          // chain = fast index (XCD balance, see k_rf_passA)
+    dim3 grid(nchain, rf_chunks_of(f, bs) + 1);      // chain = fast index (XCD balance); row 0 = the Nyquist bin (see k_rf_passA)
     RfFreq fa = f;
     int* hi = nullptr;
     if (rf_f32_on(c, f)) { fa.e32max = rf_f32_emax(n); ENSURE(c, c->hi32, (size_t)nchain * sizeof(int)); hi = c->hi32.as<int>(); }
-    hipLaunchKernelGGL(k_rf_passA<false>, grid, dim3(bs), 0, c->stream, nchain, n, fa, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn, hi);
-    hipLaunchKernelGGL(k_rf_passA<true>, dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, fa, lc,
-                       c->RR.as<double>(), Rs, RT, sl, sc, (int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_rf_passA, grid, dim3(bs), 0, c->stream, nchain, n, fa, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn, hi);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -801,7 +809,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wslope.as<double>(), c->wbetmx.as<float>(), c->warm_exact ? c->cwarm.as<double>() : (double*)nullptr,
                   wn + 3 * nchain + 3, c->wlist3.as<int>() + lo,
                   (c->flow_cur && c->fpend.p && c->fpend.cap >= (size_t)nchain * sizeof(int)) ? c->fpend.as<int>() : (const int*)nullptr,
-                  c->wsg1.as<unsigned char>()};
+                  c->wsg1.as<unsigned char>(),
+                  (c->flow_cur && c->flow_skip_idle) ? c->f_rem : (const int*)nullptr, c->f_fresh, c->f_ok,
+                  c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0};
         (void)0;
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
@@ -1562,6 +1572,23 @@ int rfs_kernel_ms_sum(rfs_ctx* c, double* ms, int32_t* count) {
     return RFS_OK;
 }
 
+int rfs_kernel_timeline(rfs_ctx* c, double* start_ms, double* end_ms, int32_t* count) {
+    if (!c || !start_ms || !end_ms || !count) return RFS_ERR_ARG;
+    TRY(rfs_synchronize(c));
+    for (int i = 0; i < RFS_K_COUNT; i++) {
+        double a = 0.0, b = 0.0; int nn = 0;
+        for (size_t k = 0; k + 1 < c->tused[i]; k += 2) {
+            hipEvent_t ref = k / 2 < c->tref[i].size() ? c->tref[i][k / 2] : nullptr;
+            float t0 = 0.f, t1 = 0.f;
+            if (!ref) continue;
+            if (hipEventElapsedTime(&t0, ref, c->tev[i][k]) != hipSuccess || hipEventElapsedTime(&t1, ref, c->tev[i][k + 1]) != hipSuccess) continue;
+            a += t0; b += t1; nn++;
+        }
+        start_ms[i] = a; end_ms[i] = b; count[i] = nn;
+    }
+    return RFS_OK;
+}
+
 int rfs_ndata(const rfs_ctx* c) { return c ? c->ndata : 0; }
 
 
@@ -1651,6 +1678,8 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         return RFS_OK;
     }
     if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
+    if (!strcmp(name, "swd_warm_widen")) { c->warm_widen = value != 0; return RFS_OK; }
+    if (!strcmp(name, "flow_skip_idle")) { c->flow_skip_idle = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
     if (!strcmp(name, "swd_exact_final")) {
         c->exact_final = value != 0;
@@ -2160,9 +2189,11 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
     const FlowPre fpre{minv, dt, rem, fresh, ok, bounds, x, p, fn.gsave, fn.kick, wforce, c->fpend.as<int>()};
     (void)nth;
     RfReduce rr{};
-    c->flow_cur = true;
+    KTimer tstep(c, RFS_K_FLOW_STEP, c->stream);      // the whole step on the caller's stream: first launch .. behind k_flow_post
+    struct StepEvGuard { rfs_ctx* c; ~StepEvGuard() { c->cur_step_ev = nullptr; } } step_ev_guard{c};
+    c->flow_cur = true; c->f_rem = rem; c->f_fresh = fresh; c->f_ok = ok;
     const int rc_eval = joint_eval(c, nchain, x, U, g, d, fl, 1, &fpre, &rr);      // (drift with mirror reflection inside k_prep_joint; RF reduction left to k_flow_post)
-    c->flow_cur = false;
+    c->flow_cur = false; c->f_rem = c->f_fresh = c->f_ok = nullptr;
     TRY(rc_eval);
     const int* need_cur = c->last_async ? c->wneed.as<int>() + (size_t)c->wpar * (3 * (size_t)nchain + 4) : (const int*)nullptr;
     if (next && c->has_swd && c->warm_opt && c->warm_primed && c->warm_nchain == nchain && c->xw.p) {

@@ -300,11 +300,13 @@ __device__ __forceinline__ void rf_sweep_plain(const RfLayer* __restrict__ L, in
     rf_r21_r22(f, r, r21, r22);
 }
 
+// TAIL: the Nyquist bin, lane = chain; otherwise lane = frequency k of chunk `cy` of ONE chain (block-uniform: its layer
+// constants come through scalar loads).  Both are rows of one grid (k_rf_passA below).
 template <bool TAIL>
-__global__ void __launch_bounds__(256)
-k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
-           double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
-           int* __restrict__ scount_next, int* __restrict__ hi32)
+__device__ __forceinline__ void
+rf_passA_rows(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
+              double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
+              int* __restrict__ scount_next, int* __restrict__ hi32, const int cy)
 {
     int chain, k;
     bool live = true;
@@ -314,7 +316,7 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
     } else {
         // grid = (chain, chunk of frequencies): workgroups go round-robin over the 8 XCDs by their linear index, so the chain
         // must be the fast index -- with the chunk there, each XCD would get ONE kind of chunk (all f64 band chunks on one XCD)
-        chain = blockIdx.x; k = blockIdx.y * blockDim.x + threadIdx.x;
+        chain = blockIdx.x; k = cy * blockDim.x + threadIdx.x;
         if (k >= f.n2 - 1) { live = false; k = f.n2 - 2; }      // (kept until the wave-wide sums below are done)
     }
     const RfLayer* L = lc + (size_t)chain * n;
@@ -328,11 +330,11 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
     bool c32 = false;
     if (!TAIL && f.e32max > 0.0 && f.nk < f.n2) {
         c32 = rf_growth_exponent_wave(L, n, f.sigma, rf_wk(f, f.n2 - 1)) <= f.e32max;
-        if (hi32 && blockIdx.y == 0 && threadIdx.x == 0) hi32[chain] = c32 ? 1 : 0;
+        if (hi32 && cy == 0 && threadIdx.x == 0) hi32[chain] = c32 ? 1 : 0;
     }
     // (the chains that keep stored rows, for pass B's launch over them: normally none)
-    if (!TAIL && RT && store && slist && blockIdx.y == 0 && threadIdx.x == 0) slist[atomicAdd(scount, 1)] = chain;
-    if (!TAIL && scount_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scount_next = 0;   // the NEXT evaluation's counter
+    if (!TAIL && RT && store && slist && cy == 0 && threadIdx.x == 0) slist[atomicAdd(scount, 1)] = chain;
+    if (!TAIL && scount_next && blockIdx.x == 0 && cy == 0 && threadIdx.x == 0) *scount_next = 0;   // the NEXT evaluation's counter
     if (!live) return;
     double* o = RR + (size_t)chain * 4 * n2p + k;
     if (!TAIL && c32 && k - (int)(threadIdx.x & 63) >= f.nk) {          // a whole wavefront beyond the band
@@ -380,6 +382,22 @@ k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* 
     cplx r21, r22;
     rf_r21_r22(f, r, r21, r22);
     o[0] = r21.re; o[n2p] = r21.im; o[2 * n2p] = r22.re; o[3 * n2p] = r22.im;
+}
+// One launch for all frequencies: grid = (chain, 1 + chunks).  Row 0 holds the Nyquist bin (lane = chain: its first
+// ceil(nchain / blockDim) blocks work, the rest leave at once) -- dispatched FIRST, so its one-wavefront-per-64-chains sweep
+// runs beside the bulk instead of as a launch of its own behind it (0.11 ms alone, 0.3-0.4 ms in the shared step:
+// profiles/r04_step_timeline.txt); rows 1 .. chunks: chunk y - 1 of chain x.
+__global__ void __launch_bounds__(256)
+k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
+           double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
+           int* __restrict__ scount_next, int* __restrict__ hi32)
+{
+    if (blockIdx.y == 0) {                       // (block-uniform)
+        if ((size_t)blockIdx.x * blockDim.x >= (size_t)nchain) return;
+        rf_passA_rows<true>(nchain, n, f, lc, RR, Rs, RT, slist, scount, nullptr, nullptr, 0);
+    } else {
+        rf_passA_rows<false>(nchain, n, f, lc, RR, Rs, RT, slist, scount, scount_next, hi32, (int)blockIdx.y - 1);
+    }
 }
 // ---------------------------------------------------------------------------------------
 // K2 mid 1: per chain -- water level (max over all frequencies, RFModule.f90:396-398,
@@ -1083,6 +1101,14 @@ struct SwdWarm {
     int* count3; int* list3;             // chains handed back by k_swd_exact
     const int* pend;        // [chain] 1: the chain was handed back in the step before and its search ran in the background: croot holds its roots for THIS model
     unsigned char* sg1;     // [2][4][chain] sign bit of the sequence's first evaluation (del1st), left by the first-period walk for the dense walk of the later periods
+    // flow entries: the chains' trajectory state as the step found it (nullptr elsewhere).  An IDLE chain -- waiting for the host
+    // after a trajectory, or failed -- has not moved and nothing reads its evaluation (k_flow_post): it is neither continued nor
+    // handed back (a failed chain has no valid previous evaluation and would go to the full search at every step it waits --
+    // the slowest searches there are, for nothing; and in the background form nothing would order such a search against the
+    // step that evaluates the chain's NEXT start model)
+    const int* f_rem; const int* f_fresh; const int* f_ok;
+    const double* walk_roots;   // [item][chain] what the grid walks take for the continued roots: cwarm beside k_swd_exact (which overwrites croot meanwhile), else croot
+    int widen;              // option "swd_warm_widen": 1 = the search may go on beyond the trust radius (WarmSearch::wide)
 };
 
 template <class F, bool SPH>
@@ -1111,6 +1137,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     // a chain whose search of the step before ran in the background: nothing to do here, and nothing for the branch test
     // or the reference-root stage either (they skip chains with a flag)
     if (live && W.pend && W.pend[chain]) { W.need[chain] = 2; live = false; }
+    if (live && W.f_rem && !W.f_fresh[chain] && (W.f_rem[chain] <= 0 || !W.f_ok[chain])) { W.need[chain] = 2; live = false; }    // idle
     if (live) W.sgn[(size_t)e * nchain + chain] = 2;
     if (live && (!W.valid[chain] || (W.force && W.force[chain]))) { decline(4); live = false; }
     // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
@@ -1143,6 +1170,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     };
     WarmSearch ws;
     ws.begin(cprev, dc, l1, W.slope[(size_t)e * nchain + chain]);
+    ws.may_widen = W.widen != 0;
     if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
     if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
     if (live && l1 > WARM_L1MAX && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
@@ -1151,6 +1179,8 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
     }
     const bool ok = live && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
+    // a root found beyond the trust radius: the grid walk has the word (statistic 13 counts the chains, as for large moves)
+    if (ok && ws.wide && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
     if (!live) {}
     else if (ok) {
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
@@ -1266,7 +1296,7 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
             live = live && k > 0;
         }
         const int e = Q.s[seq].croot_off + k;
-        const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
+        const double* cq = W.walk_roots + (size_t)Q.s[seq].croot_off * nchain + chain;
         bool irregular = false;
         for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
         irregular = irregular || W.wide[chain] != 0 || W.irr[chain] != 0;      // (irr: set by the branch test, launch before this one)
@@ -1276,7 +1306,7 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         float bmx = 0.f;
         const double cc = (double)swd_start_value(M, bmx);
         const int sg = W.sgn[(size_t)e * nchain + chain];
-        const double ck = croot[(size_t)e * nchain + chain];
+        const double ck = W.walk_roots[(size_t)e * nchain + chain];
         const double sk = (k == 0) ? cc : cq[(size_t)(k - 1) * nchain] - 1.5 * dcs;
         const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
         const double om0 = (2.0 * 3.141592653589793) / (Q.s[seq].t[0] * Q.s[seq].scale);
@@ -1373,13 +1403,13 @@ k_swd_warm_walk_dense(int nchain, int n, SwdSeqs Q, const float* __restrict__ md
         const int k = e0 - Q.s[seq].croot_off;
         live = live && k > 0 && W.irr[chain] != 0 && !W.need[chain];
         const int e = Q.s[seq].croot_off + k;
-        const double* cq = croot + (size_t)Q.s[seq].croot_off * nchain + chain;
+        const double* cq = W.walk_roots + (size_t)Q.s[seq].croot_off * nchain + chain;
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         float bmx = 0.f;
         const double cc = (double)swd_start_value(M, bmx);
         const int sg = W.sgn[(size_t)e * nchain + chain];
-        const double ck = croot[(size_t)e * nchain + chain];
+        const double ck = W.walk_roots[(size_t)e * nchain + chain];
         const double sk = cq[(size_t)(k > 0 ? k - 1 : 0) * nchain] - 1.5 * dcs;
         bool bad = live && (sg > 1 || !(sk > 0.0) || sk == ck || !(ck == ck));
         const int dir = ck > sk ? +1 : -1;
@@ -1765,9 +1795,19 @@ __device__ __forceinline__ void swd_eigen_lane(const Mdl& M, int n, int nchain, 
         auto emit = [&](int m, double da, double db, double dr, double dh) { put(m, da, db, dr, dh); };
         SrTotals R = sr_down_energy<WATER>(M, omega, wvno, load, emit);
         // (1 / (U I0) of energy :1181-1186 and `fac` of getdcdh with its flush :1529-1531: the item's scale slots, swd_krn)
-        uout[ntot] = 1.0 / (R.ugr * R.sumi0); uout[2 * ntot] = R.fac;
+        double sc1 = 1.0 / (R.ugr * R.sumi0), sc2 = R.fac;
         double u = R.ugr;
         if (fabs(u) < 1.0e-36) u = 0.0;                                             // :1703
+        // A phase velocity that EQUALS a layer's P or S velocity (both are float32 values: about one (period, chain) item of a
+        // bench step) makes that layer's vertical wavenumber exactly zero, and sregn96 divides by it (evalg :719-758, intijr):
+        // the reference returns NaN for U and for every kernel of the period -- checked on the compiled reference for every
+        // layer incl. the half-space, P and S alike; one float32 step away everything is finite (tests/test_gpu_edges.py) --
+        // and its samplers end the trajectory there (hmc.py:177-179).  The sweeps here take the root of a real number and
+        // come out finite, so the reference's result is restored by hand: NaN scales turn every kernel of the item into NaN.
+        bool hit = false;
+        for (int m = 0; m < n; m++) hit = hit || cp == M.A(m) || cp == M.B(m);
+        if (hit) { const double qnan = __longlong_as_double(0x7ff8000000000000LL); sc1 = qnan; sc2 = qnan; u = qnan; }
+        uout[ntot] = sc1; uout[2 * ntot] = sc2;
         *uout = u;
     }
 }

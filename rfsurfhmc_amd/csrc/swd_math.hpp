@@ -629,7 +629,7 @@ struct RootSearchT {
         double a1 = c1, a2 = c2; int id = idir;
         for (int i = 0; i < j; i++) {
             a1 = a2;
-            if (a1 < cm || a1 >= ((double)betmx + dc)) return false;
+            if (!(a1 >= cm && a1 < ((double)betmx + dc))) return false;
             const double c2n = (id > 0) ? a1 + dc : a1 - dc;
             const bool clamp = c2n <= clow;
             if (clamp) { id = +1; a1 = clow; }
@@ -660,7 +660,9 @@ struct RootSearchT {
         del2 = pC ? del : del2;
         c1 = cont ? c2 : c1;
         del1 = (pS || cont) ? del : del1;
-        const bool sfail = cont && (c1 < cm || c1 >= ((double)betmx + dc));
+        // (the limits as the reference states them, getsol :477-479, negated so that a NaN scan point -- a model with NaN
+        // velocities: a sampler that carried a NaN gradient into its next drift -- ends the scan as well instead of walking on for ever)
+        const bool sfail = cont && !(c1 >= cm && c1 < ((double)betmx + dc));
         const bool st_scan = pS || (cont && !sfail);
         bool st_fail = sfail, st_half = chg, st_newperiod = false;
         bool return_after = false;                                          // (MODES: the next request is already set up)
@@ -808,6 +810,16 @@ constexpr double WARM_L1MAX = 0.5;           // km/s: beyond this first-order ch
                                              // the chain's sequences walk the reference's scan grid (k_swd_warm_walk) like irregular ones
 constexpr double WARM_L1WIDE = 2.0;          // km/s: and beyond this the model is not "the previous one, moved" at all
 constexpr int WARM_MAXIT = 12;
+// Round 5: beyond the trust radius.  Where no sign change lies within R of the first-order prediction (the root has left the
+// first-order model's reach, or two modes have come close: 32 of the 53 chains a bench step handed back), the bracket keeps
+// widening up to WARM_RWIDE x R, at most WARM_RWIDE_ABS km/s -- whatever root that finds, the first-order model does not vouch
+// for it, so the lane reports `wide` and every sequence of the chain walks the reference's scan grid (k_swd_warm_walk): the
+// walk alone decides whether the reference's scan would stop in that root's cell.
+constexpr double WARM_RWIDE = 16.0;
+constexpr double WARM_RWIDE_ABS = 0.1;
+// ... and a bracket that false position has not closed in WARM_MAXIT steps (the normalised secular function is a step
+// between crowded modes: +-1 either side) is closed by bisection
+constexpr int WARM_MAXBIS = 48;
 
 
 constexpr double WARM_OVER = 0.25;           // Newton start: overshoot of the step, so that the second point lands beyond the root
@@ -820,6 +832,8 @@ struct WarmSearch {
     enum { W_A, W_B, W_X, W_REF, W_N0, W_N1, W_DONE, W_FAIL };
     double cpred, eps, R, a, fa, b, fb, creq, root, slope, f0, mlast;
     int phase, it, side, second, lastside, nev, ntry;
+    bool wide;            // the bracket was found beyond the trust radius: the caller makes the chain's sequences walk the grid
+    bool may_widen;       // allowed to look there at all (rfs_set_option "swd_warm_widen"; begin() sets it)
 
     RFS_HD bool active() const { return phase < W_DONE; }
 
@@ -831,7 +845,7 @@ struct WarmSearch {
         cpred = cprev + dc;
         R = WARM_R0 * cpred + WARM_R1 * l1;
         nev = 0; it = 0; side = 0; second = 0; lastside = -1; root = 0.0; slope = 0.0; f0 = 0.0; ntry = 0; mlast = 0.0;
-        fa = fb = 0.0;
+        fa = fb = 0.0; wide = false; may_widen = true;
         eps = WARM_EPS0 * cpred + WARM_EPS1 * l1;
         a = cpred - eps; b = cpred + eps; creq = a;
         phase = W_A;
@@ -896,13 +910,21 @@ struct WarmSearch {
             if (!diffsign(f, fa)) { a = c3; fa = f; if (lastside == 0) fb *= 0.5; lastside = 0; }    // Illinois rule
             else { b = c3; fb = f; if (lastside == 1) fa *= 0.5; lastside = 1; }
             const double c4 = a - fa * (b - a) / (fb - fa);
-            if (fabs(c4 - c3) <= WARM_TOL * fabs(c4)) { root = c4; phase = W_DONE; }
-            else if (++it >= WARM_MAXIT || !(c4 >= a && c4 <= b)) phase = W_FAIL;
+            if (it >= WARM_MAXIT) {                // bisection from here on (the signs of fa / fb are all that is used)
+                if (b - a <= 2.0 * WARM_TOL * b) { root = 0.5 * (a + b); phase = W_DONE; }
+                else if (++it >= WARM_MAXIT + WARM_MAXBIS) phase = W_FAIL;
+                else creq = 0.5 * (a + b);
+            }
+            else if (fabs(c4 - c3) <= WARM_TOL * fabs(c4)) { root = c4; phase = W_DONE; }
+            else if (!(c4 >= a && c4 <= b)) phase = W_FAIL;
+            else if (++it >= WARM_MAXIT) creq = 0.5 * (a + b);
             else creq = c4;
         }
         if (widen) {
-            if (eps >= R) { phase = W_FAIL; return; }
-            eps = fmin(4.0 * eps, R);
+            const double Rw = may_widen ? fmin(WARM_RWIDE * R, fmax(R, WARM_RWIDE_ABS)) : R;
+            if (eps >= Rw) { phase = W_FAIL; return; }
+            if (eps >= R) wide = true;             // beyond the first-order model's word
+            eps = eps < R ? fmin(4.0 * eps, R) : fmin(4.0 * eps, Rw);
             side = (fabs(fa) <= fabs(fb)) ? 0 : 1;           // the side the function is closer to zero on goes first
             creq = side == 0 ? cpred - eps : cpred + eps;
             phase = (creq > 0.0) ? (int)W_X : (int)W_FAIL;

@@ -424,6 +424,9 @@ def with_host_threads(fn):
 _SIDE_STREAMS = {}
 
 
+LEGACY_TAIL = os.environ.get("RFS_FLOW_LEGACY_TAIL") == "1"      # (A/B runs: round 4's staging copy + immediate wait between two steps)
+
+
 def _side_stream(dev):
     import torch
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
@@ -600,15 +603,19 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         h = slot[0].numpy()
         for o, a in parts:
             h[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
-        d = slot[0][:off].to(dev, non_blocking=True)
+        # The launch reads the lists STRAIGHT FROM THE PINNED BUFFER: pinned host memory is mapped into the device's address
+        # space at the same address, a few KB over the link cost the kernel less than the separate copy kernel in front of
+        # it did (0.05 ms on the main stream between two steps: profiles/r04_step_timeline.txt)
         if slot[1] is None:
             slot[1] = torch.cuda.Event()
-        slot[1].record(torch.cuda.current_stream(dev))
-        model.flow_restart(st, d, n1, o_idx1, o_xk, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3)
+        src = slot[0] if not LEGACY_TAIL else slot[0][:off].to(dev, non_blocking=True)
+        model.flow_restart(st, src, n1, o_idx1, o_xk, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3)
+        slot[1].record(torch.cuda.current_stream(dev))            # the buffer is free again once the launch has run
 
     steps = 0
 
     deposited = []                               # events behind deposits made on the side stream
+    withdrawn = []                               # events behind rfs_flow_restart launches that withdrew deposits
 
     def step():
         nonlocal steps
@@ -650,7 +657,15 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
             if fused:
                 apply_fused(idx1, xkeep, rs_, wd)            # stream-ordered after the step launched above
                 if len(wd) and side is not None:
-                    wev = torch.cuda.Event(); wev.record(); side.wait_event(wev)
+                    # A deposit made LATER for a withdrawn chain must land behind this launch (it clears the chain's `have`).
+                    # Such a chain restarts with a trajectory of its own first: nothing is deposited for it before the
+                    # iteration after next -- so the side stream takes the dependency at the NEXT iteration's deposits, when
+                    # the launch has long run.  (Waiting here made this iteration's deposits, and with them the next step's
+                    # first kernel, wait for a launch that sits behind the whole step under way: 0.17 ms of idle device
+                    # between two steps, profiles/r04_step_timeline.txt.)
+                    wev = torch.cuda.Event(); wev.record(); withdrawn.append((steps, wev))
+                    if LEGACY_TAIL:
+                        side.wait_event(withdrawn.pop()[1])
             else:
                 apply(idx1, xkeep, rs_)
             if restart is not None:
@@ -673,6 +688,8 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
             cand = np.nonzero((finish == steps) & ~has_dep)[0]       # they complete in the step launched next
             if len(cand):
                 sel, u, pn, rem = restart.predraw(cand)
+                while withdrawn and withdrawn[0][0] < steps and side is not None:    # (earlier iterations' launches: see above)
+                    side.wait_event(withdrawn.pop(0)[1])
                 if len(sel):
                     # on the side stream, beside the step that is running: these chains are in mid-trajectory there and the
                     # device looks at a deposit only in the step that completes one; the next launch waits for the event

@@ -130,7 +130,10 @@ class HMCDualAveraging:
             ediff = -(Hnew - Hcur)
             if it == 0:
                 a = 2.0 * (ediff > np.log(0.5)) - 1.0
-            stop = live & (ediff < np.log(0.5))
+            # (a non-finite energy -- the reference's sregn96 returns NaN kernels where a root equals a layer velocity -- never
+            # satisfies the reference's test (:209) and its loop would carry NaN models into the next evaluation; such a
+            # chain stops here and keeps the step size it has)
+            stop = live & ((ediff < np.log(0.5)) | ~np.isfinite(ediff))
             go = live & ~stop
             pcur = np.where(go[:, None], pcur - 0.5 * dt[:, None] * grad, pcur)
             Hcur = np.where(go, Hnew, Hcur)

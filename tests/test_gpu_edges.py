@@ -375,3 +375,40 @@ def test_b1_rf_entry_tiles_any_number_of_chains():
     assert np.array_equal(rf[sub], rf2)
     rf3, kl3 = librf.kernel_all(thk[:40000], rho[:40000], vp[:40000], vs[:40000], q[:40000], q[:40000], *args)
     assert np.array_equal(rf3, rf[:40000]) and np.array_equal(kl3[sub[:80]], kl2[:80])
+
+
+def test_root_that_equals_a_layer_velocity_gives_the_references_nan(orc, golden):
+    """A float32 phase velocity that EQUALS a layer's float32 S velocity (about one (period, chain) item per bench step): the
+    reference's sregn96 divides by that layer's vertical wavenumber and returns NaN kernels for the period (fixture written by
+    the compiled reference); its samplers then end the trajectory (hmc.py:177-179).  B1 returns the same NaN pattern, the
+    joint plugin a NaN gradient with flag True -- and one float32 step away everything is finite again."""
+    from rfsurfhmc_amd.model.lib import libsurf
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    g = golden["exact_equality_reference"]
+    x, t = g["x"], g["t"]
+    n = len(x) // 2
+    vs, thk = x[:n], x[n:]
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    c, ka, kb, kr, kh, flag = libsurf.adjoint_kernel(thk, vp, vs, rho, t, "Rc")
+    assert flag and np.array_equal(c, g["c"])
+    row = int(g["nan_row"][0])
+    for mine, ref in ((ka, g["ka"]), (kb, g["kb"]), (kr, g["kr"]), (kh, g["kh"])):
+        assert np.array_equal(np.isnan(mine), np.isnan(ref)), (np.argwhere(np.isnan(mine) != np.isnan(ref))[:5])
+        ok = np.isfinite(ref)
+        assert np.abs(mine[ok] - ref[ok]).max() <= 2e-6 * np.abs(ref[ok]).max()
+    m = SurfWD(tRc=t)
+    d, f = m.forward(x)
+    m.set_obsdata(d * 1.01)
+    mis, grad, dsyn, fl = m.misfit_and_grad(x)
+    assert fl and np.isfinite(mis) and np.isfinite(dsyn).all() and np.isnan(grad[:n]).all()
+    # group velocities: the three passes of sregnpu; the period's U and kernels are NaN, the others finite
+    u, ua, ub, ur, uh, fu = libsurf.adjoint_kernel(thk, vp, vs, rho, t[row:row + 1], "Rg")
+    uo, uao, ubo, uro, uho, fo = orc.libsurf.adjoint_kernel(thk, vp, vs, rho, t[row:row + 1], "Rg")
+    assert fu == fo and np.array_equal(np.isnan(u), np.isnan(uo)) and np.array_equal(np.isnan(ub), np.isnan(ubo))
+    x2 = x.copy(); x2[20] = float(np.nextafter(np.float32(x[20]), np.float32(10.0)))      # the layer one float32 step faster
+    vp2, rho2, _, _ = orc.empirical_relation(x2[:n])
+    c2, ka2, kb2, kr2, kh2, f2 = libsurf.adjoint_kernel(x2[n:], vp2, x2[:n], rho2, t, "Rc")
+    co, kao, kbo, kro, kho, fo2 = orc.libsurf.adjoint_kernel(x2[n:], vp2, x2[:n], rho2, t, "Rc")
+    assert f2 and fo2 and np.isfinite(kb2).all() == np.isfinite(kbo).all()
+    if np.isfinite(kbo).all():
+        assert np.abs(kb2 - kbo).max() <= 2e-6 * np.abs(kbo).max()

@@ -228,3 +228,24 @@ def test_surfwd_plugin_with_love_blocks_and_sphere(orc, golden):
             assert rel(dsyn, g[f"{key}/dsyn"]) < 1e-9
             assert abs(mf - float(g[f"{key}/misfit"])) <= 1e-8 * float(g[f"{key}/misfit"])
             assert rel(grad, g[f"{key}/grad"]) < 1e-7
+
+
+def test_exact_equality_of_root_and_layer_velocity_gives_nan_kernels(orc, golden):
+    """tests/golden/exact_equality_reference.npz (compiled reference): a phase velocity that equals a layer's float32 S velocity
+    makes sregn96 divide by a zero vertical wavenumber -- every kernel of that period is NaN, the flag stays True.  The
+    restatement must do the same (sregn96.f90:652-829, 1203-1323)."""
+    g = golden["exact_equality_reference"]
+    x, t = g["x"], g["t"]
+    n = len(x) // 2
+    vs, thk = x[:n], x[n:]
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    c, ka, kb, kr, kh, flag = orc.libsurf.adjoint_kernel(thk, vp, vs, rho, t, "Rc")
+    assert flag and bool(g["flag"])
+    assert np.array_equal(c, g["c"])
+    row = int(g["nan_row"][0])
+    assert c[row] == float(np.float32(vs[20]))
+    for mine, ref in ((ka, g["ka"]), (kb, g["kb"]), (kr, g["kr"]), (kh, g["kh"])):
+        assert np.array_equal(np.isnan(mine), np.isnan(ref))
+        assert np.isnan(mine[row, :-1]).all()
+        ok = np.isfinite(ref)
+        assert np.abs(mine[ok] - ref[ok]).max() <= 2e-11 * np.abs(ref[ok]).max()
