@@ -520,6 +520,8 @@ def make_joint(cfg, local_rank):
     drf, dswd, flag = joint.forward(x_true)
     assert flag
     joint.set_obsdata(drf, dswd)
+    for kv in filter(None, os.environ.get("RFS_OPTS", "").split(",")):      # (experiments: "name=value,...")
+        k_, v_ = kv.split("="); joint._ensure(n).set_option(k_, int(v_))
     for opt, env in (("swd_exact_group", "RFS_EXACT_GROUP"), ("swd_exact_runup", "RFS_EXACT_RUNUP"), ("rf_mid_fused", "RFS_MID_FUSED"), ("swd_walk_dense", "RFS_WALK_DENSE")):      # (experiments)
         if os.environ.get(env):
             joint._ensure(n).set_option(opt, int(os.environ[env]))
@@ -889,6 +891,13 @@ def run_rank(args):
                                              "except on ill-conditioned chains: outside the 1e-5 contract, kept as an option",
                                              dt=dt, mode="converged_roots")
             extra["full_search_every_step"] = short(ROOT_MODE_TEXT["full_search"], dt=dt, mode="full_search")
+            # one run-up period per group of the reference-root stage, origins accepted to 5e-7 c (include/rfsurf.h,
+            # "swd_exact_origin_tol_e9"): a sixth of that stage's evaluations less; roots 99.997 % bit-identical, but the gradient
+            # of ~0.4 % of burned-in chains 1.0-1.2e-5 off the reference's (tests/test_gpu_flow_parity.py with RFS_OPTS): an option
+            ctx.set_option("swd_exact_runup", 1); ctx.set_option("swd_exact_origin_tol_e9", 500)
+            extra["one_runup_period"] = short("swd_exact_runup 1, swd_exact_origin_tol_e9 500: faster, gradients of ~0.4 % of the chains "
+                                              "just outside 1e-5", dt=dt, mode=mode)
+            ctx.set_option("swd_exact_runup", 2); ctx.set_option("swd_exact_origin_tol_e9", 100)
         set_root_mode(joint, n, mode)
         # ---- rounds 1-3's headline definition, for continuity: never-ending trajectories (no accept / reject) of the random
         # start models at dt = 0.002, the cheapest point of the step-size curve
@@ -989,7 +998,7 @@ def run_rank(args):
     for k, v in extra.items():
         res[k] = v
     # the side legs' rates as top-level scalars as well
-    for k in ("converged_roots", "full_search_every_step", "never_ending_dt0002", "config3", "config4", "config0"):
+    for k in ("converged_roots", "full_search_every_step", "one_runup_period", "never_ending_dt0002", "config3", "config4", "config0"):
         if k in extra:
             res[f"{k}_value"] = extra[k]["value"]
     if "config0" in extra and extra["config0"].get("ms_per_eval"):

@@ -328,6 +328,23 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          call in which a given leapfrog step of a given chain happens moves by one.  A caller that
  *                          counts calls (rem steps = rem calls) must look at rem / done instead.  0 (default) = every call
  *                          completes every chain's step.  The samplers of pyhmc switch it on for sample_flow.
+ *   "swd_exact_origin_tol_e9"  how far (in units of 1e-9 c, default 100) the origin of a wanted period's scan grid may be from the
+ *                          reference's, as tracked through the run-up periods, before its group is handed back.  The defaults
+ *                          (two run-up periods, 1e-7 c) reproduce the reference's float32 roots (>= 99.99 %).  "swd_exact_runup" 1
+ *                          with 500 here is a FASTER, LOOSER setting: a sixth of the stage's evaluations less (5.35 -> 5.10 ms
+ *                          per step at 8192 chains), the few groups whose single run-up period was closed by bisections alone
+ *                          keep an origin 4e-7 c off -- roots still 99.997 % bit-identical on smooth models, misfit within
+ *                          3e-6, but the gradient of ~0.4 % of burned-in chains then misses the reference's by 1.0 - 1.2e-5.
+ *   "swd_warm_widen"       1 (default): a warm search that finds no sign change within its trust radius (the root has left the
+ *                          first-order model's reach: 32 chains per step of a burned-in 8192-chain population) keeps widening its
+ *                          bracket, out to 16 x the radius or 0.1 km/s; an item whose first-order change exceeds 2 km/s (kernels
+ *                          blown up next to an osculation point) looks around its previous root the same way.  Whatever root is
+ *                          found there is not taken on the first-order model's word: every sequence of such a chain walks the
+ *                          reference's scan grid, and the walk decides (-> the full search otherwise).  0: such chains go to the
+ *                          full search at once (round 4's behaviour: 54 instead of 39 chains per step handed back).
+ *   "flow_skip_idle"       1 (default): in the flow entries a chain that is idle in a step -- waiting for the caller after a
+ *                          trajectory, or failed -- is neither continued nor handed back (nothing reads its evaluation, and a
+ *                          failed chain would go to the full search at every step it waits).  0: round 4's behaviour.
  *   "swd_warm_reset"       (any value) forget the previous evaluation: the next one goes through the reference-semantics
  *                          search for every chain.  The samplers of pyhmc call it whenever they write a checkpoint, so
  *                          that a resumed run and the uninterrupted one evaluate the same way from there on (their own
@@ -385,6 +402,11 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *   "swd_exact_secular_evals"   secular-function evaluations of the reference-root stage ("swd_warm_exact");
  *   "swd_exact_declined_chains" chain evaluations it handed back (no sign change in the expected scan cell, a grid at the
  *                               floor of the scan, a root the reference rejects)
+ *   "swd_exact_cause_<k>"       ... by cause: 1 no usable approximate root / origin, 2 root too far from the origin, 3 the grid touches
+ *                               the floor of the scan, 4 no sign change in the root's cell nor in its neighbour, 5 root above the
+ *                               fastest layer, 6 NaN, 7 the run-up left the origin short of "swd_exact_origin_tol_e9"
+ *   "swd_warm_fail_no_change" / "swd_warm_fail_other"   (period, chain) items whose warm search failed: no sign change out to
+ *                               the widest bracket / anything else
  *   "swd_warm_cause_<k>"        chains handed back, by (first) cause: 4 no usable previous evaluation / forced, 5 step too
  *                               large for a first-order model, 6 no sign change inside the trust radius, 7 root above the
  *                               fastest layer, 9 / 11 another root lies between the point the reference's scan of that

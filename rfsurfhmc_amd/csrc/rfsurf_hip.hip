@@ -106,6 +106,7 @@ struct rfs_ctx {
     const int *f_rem = nullptr, *f_fresh = nullptr, *f_ok = nullptr;   // the flow state's arrays during a flow step (k_swd_warm: idle chains)
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
+    float exact_origin_tol = (float)EXACT_ORIGIN_TOL;   // option "swd_exact_origin_tol_e9"
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
@@ -942,12 +943,12 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             if (Q.nper_total > 0) {
                 const int ng = ngroups(Q);
                 hipLaunchKernelGGL((k_swd_exact<SwdRayFamily>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s,
-                                   nchain, n, Q, G, ru, ng, mdlR, c->mdlc.as<double>(), c->croot.as<double>(), W);
+                                   nchain, n, Q, G, ru, ng, c->exact_origin_tol, mdlR, c->mdlc.as<double>(), c->croot.as<double>(), W);
             }
             if (P.QL.nper_total > 0) {
                 const int ng = ngroups(P.QL);
                 hipLaunchKernelGGL((k_swd_exact<SwdLoveFamily>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s,
-                                   nchain, n, P.QL, G, ru, ng, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
+                                   nchain, n, P.QL, G, ru, ng, c->exact_origin_tol, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
             }
             HIPCHK(c, hipGetLastError());
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
@@ -1169,7 +1170,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, RFS_BG_SLOTS * (size_t)nchain * sizeof(int));
         for (auto& e : c->ev_w) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ENSURE(c, c->wlist, RFS_BG_SLOTS * (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
-        ENSURE(c, c->wstats, 16 * sizeof(unsigned long long));
+        ENSURE(c, c->wstats, 32 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         ENSURE(c, c->wslope, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
         ENSURE(c, c->wbetmx, (size_t)2 * nchain * sizeof(float)); ENSURE(c, c->wsg1, (size_t)8 * nchain);
@@ -1664,6 +1665,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 2 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [2, 4096]");
         c->exact_group = value; return RFS_OK;
     }
+    if (!strcmp(name, "swd_exact_origin_tol_e9")) {
+        if (value < 0 || value > 2000) return fail(c, RFS_ERR_ARG, "swd_exact_origin_tol_e9 must be within [0, 2000] (units of 1e-9 c)");
+        c->exact_origin_tol = (float)(value * 1.0e-9); return RFS_OK;
+    }
     if (!strcmp(name, "swd_exact_runup")) {
         if (value < 0 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_runup must be within [0, 64]");
         c->exact_runup = value; return RFS_OK;
@@ -1743,11 +1748,14 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     else if (!strcmp(name, "swd_exact_declined_chains")) idx = 14;
     else if (!strcmp(name, "swd_exact_secular_evals")) idx = 15;
     else if (!strncmp(name, "swd_warm_cause_", 15)) { idx = atoi(name + 15); if (idx < 4 || idx > 11) idx = -1; }
+    else if (!strcmp(name, "swd_warm_fail_no_change")) idx = 24;
+    else if (!strcmp(name, "swd_warm_fail_other")) idx = 25;
+    else if (!strncmp(name, "swd_exact_cause_", 16)) { idx = atoi(name + 16); idx = (idx < 1 || idx > 7) ? -1 : 16 + idx; }
     if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
     if (!c->wstats.p) return RFS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     TRY(rfs_synchronize(c));
-    unsigned long long v[16];
+    unsigned long long v[32];
     HIPCHK(c, hipMemcpy(v, c->wstats.p, sizeof(v), hipMemcpyDeviceToHost));
     *value = (int64_t)v[idx];
     return RFS_OK;

@@ -387,7 +387,7 @@ rf_passA_rows(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc
 // ceil(nchain / blockDim) blocks work, the rest leave at once) -- dispatched FIRST, so its one-wavefront-per-64-chains sweep
 // runs beside the bulk instead of as a launch of its own behind it (0.11 ms alone, 0.3-0.4 ms in the shared step:
 // profiles/r04_step_timeline.txt); rows 1 .. chunks: chunk y - 1 of chain x.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))      // (the bulk rows need 85 VGPRs; the Nyquist row's per-lane layer constants would cost the whole kernel a wavefront per SIMD)
 k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
            double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
            int* __restrict__ scount_next, int* __restrict__ hi32)
@@ -1112,7 +1112,7 @@ struct SwdWarm {
 };
 
 template <class F, bool SPH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))          // (round 5's bisection / wide-bracket paths took it to 171 VGPRs: three wavefronts per SIMD end at 168)
 k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const double* __restrict__ sph,
            const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot, double* __restrict__ croot, SwdWarm W)
 {
@@ -1170,23 +1170,27 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     };
     WarmSearch ws;
     ws.begin(cprev, dc, l1, W.slope[(size_t)e * nchain + chain]);
-    ws.may_widen = W.widen != 0;
-    if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
+    if (W.widen && cprev > 0.0 && (!(dc == dc) || !(l1 <= WARM_L1WIDE))) ws.begin_wide(cprev);
+    else if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
     if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
-    if (live && l1 > WARM_L1MAX && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
+    if (live && !(l1 <= WARM_L1MAX) && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
     const bool refused = !ws.active();
     while (__any(ws.active())) {
-        if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq));
+        if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq), W.widen != 0);
     }
     const bool ok = live && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
     // a root found beyond the trust radius: the grid walk has the word (statistic 13 counts the chains, as for large moves)
-    if (ok && ws.wide && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
+    if (ok && ws.wide() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
     if (!live) {}
     else if (ok) {
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
         if (W.cwarm) W.cwarm[(size_t)e * nchain + chain] = (double)(float)ws.root;
         W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
-    } else decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
+    } else {
+        decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
+        // (diagnostics: why a search failed -- 24: no sign change out to the widest bracket, 25: anything else)
+        if (!refused && ws.phase != WarmSearch::W_DONE) atomicAdd(&W.stats[ws.eps >= fmin(WARM_RWIDE * ws.R, fmax(ws.R, WARM_RWIDE_ABS)) ? 24 : 25], 1ull);
+    }
     if (live) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
     int nev = live ? ws.nev : 0, nok = ok ? 1 : 0;
 #pragma unroll
@@ -1489,7 +1493,7 @@ k_swd_warm_walk_dense(int nchain, int n, SwdSeqs Q, const float* __restrict__ md
 // ---------------------------------------------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(64)
-k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, const float* __restrict__ mdl,
+k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float origin_tol, const float* __restrict__ mdl,
             const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W)
 {
     const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -1519,7 +1523,7 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, const f
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         float bmx = 0.f;
         const double cc = (double)swd_start_value(M, bmx);
-        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om, nevtab + threadIdx.x, 64);
+        x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om, nevtab + threadIdx.x, 64, origin_tol);
     }
     while (__any(x.active())) {
         if (x.active()) {
@@ -1534,6 +1538,7 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, const f
         W.list3[atomicAdd(W.count3, 1)] = chain;
         atomicAdd(&W.stats[0], 1ull);
         atomicAdd(&W.stats[14], 1ull);
+        if (x.cause >= 1 && x.cause <= 7) atomicAdd(&W.stats[16 + x.cause], 1ull);       // "swd_exact_cause_<k>" (ExactGroup's X_FAIL causes)
     }
     int nev = x.nev;
 #pragma unroll

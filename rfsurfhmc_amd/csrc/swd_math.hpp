@@ -832,8 +832,9 @@ struct WarmSearch {
     enum { W_A, W_B, W_X, W_REF, W_N0, W_N1, W_DONE, W_FAIL };
     double cpred, eps, R, a, fa, b, fb, creq, root, slope, f0, mlast;
     int phase, it, side, second, lastside, nev, ntry;
-    bool wide;            // the bracket was found beyond the trust radius: the caller makes the chain's sequences walk the grid
-    bool may_widen;       // allowed to look there at all (rfs_set_option "swd_warm_widen"; begin() sets it)
+    // the bracket was found beyond the trust radius: the caller makes the chain's sequences walk the grid
+    // (no state of its own -- the kernel sits at the edge of three wavefronts per SIMD: eps only ever exceeds R out there)
+    RFS_HD bool wide() const { return eps > R; }
 
     RFS_HD bool active() const { return phase < W_DONE; }
 
@@ -845,13 +846,26 @@ struct WarmSearch {
         cpred = cprev + dc;
         R = WARM_R0 * cpred + WARM_R1 * l1;
         nev = 0; it = 0; side = 0; second = 0; lastside = -1; root = 0.0; slope = 0.0; f0 = 0.0; ntry = 0; mlast = 0.0;
-        fa = fb = 0.0; wide = false; may_widen = true;
+        fa = fb = 0.0;
         eps = WARM_EPS0 * cpred + WARM_EPS1 * l1;
         a = cpred - eps; b = cpred + eps; creq = a;
         phase = W_A;
         // not a continuation of the previous model (or no previous root at all): leave it to the full search
         if (!(cprev > 0.0) || !(l1 <= WARM_L1WIDE) || !(a > 0.0)) phase = W_FAIL;
+        // ... unless the search may go beyond the trust radius anyway (begin_wide below)
         else if (slope0 != 0.0 && slope0 == slope0 && l1 <= WARM_L1MAX) { slope = slope0; creq = cpred; phase = W_N0; }
+    }
+
+    // A first-order change beyond WARM_L1WIDE (kernels blown up next to an osculation point: 11 chains of a bench step) says
+    // nothing about where the root went -- but the root itself has usually moved little.  With the wide search allowed, such
+    // an item looks around the PREVIOUS root instead, out to WARM_RWIDE_ABS; the caller marks the chain wide (its l1 is
+    // beyond WARM_L1MAX), so the grid walk decides whether what is found is the reference's root.
+    RFS_HD void begin_wide(double cprev) {
+        const double l1w = WARM_RWIDE_ABS / WARM_RWIDE;
+        cpred = cprev; R = WARM_R0 * cpred + WARM_R1 * l1w; eps = WARM_EPS0 * cpred + WARM_EPS1 * l1w;
+        slope = 0.0;
+        start_bracket();
+        if (!(cprev > 0.0) || !(a > 0.0)) phase = W_FAIL;
     }
 
     RFS_HD void start_bracket() { a = cpred - eps; b = cpred + eps; creq = a; phase = W_A; }
@@ -862,7 +876,8 @@ struct WarmSearch {
         creq = c3; phase = W_REF; lastside = -1;
     }
 
-    RFS_HD void advance(double f) {
+    // may_widen: allowed to look beyond the trust radius at all (rfs_set_option "swd_warm_widen")
+    RFS_HD void advance(double f, const bool may_widen = true) {
         nev++;
         if (f != f) { phase = W_FAIL; return; }
         bool widen = false;
@@ -923,8 +938,7 @@ struct WarmSearch {
         if (widen) {
             const double Rw = may_widen ? fmin(WARM_RWIDE * R, fmax(R, WARM_RWIDE_ABS)) : R;
             if (eps >= Rw) { phase = W_FAIL; return; }
-            if (eps >= R) wide = true;             // beyond the first-order model's word
-            eps = eps < R ? fmin(4.0 * eps, R) : fmin(4.0 * eps, Rw);
+            eps = eps < R ? fmin(4.0 * eps, R) : fmin(4.0 * eps, Rw);      // (beyond R: not on the first-order model's word any more, wide())
             side = (fabs(fa) <= fabs(fb)) ? 0 : 1;           // the side the function is closer to zero on goes first
             creq = side == 0 ? cpred - eps : cpred + eps;
             phase = (creq > 0.0) ? (int)W_X : (int)W_FAIL;
@@ -1112,6 +1126,7 @@ struct ExactGroupT {
     int k, k0, k1, phase, dir, msteps, shifted, nev, cause, nsupplied;
     float betmx;
     float oerr;                              // relative error of the current origin, as far as the factors g3 of the periods so far tell
+    float otol;                              // ... and what a wanted period accepts (EXACT_ORIGIN_TOL; rfs_set_option "swd_exact_origin_tol_e9")
 
     RFS_HD bool active() const { return phase < X_DONE; }
 
@@ -1128,7 +1143,8 @@ struct ExactGroupT {
     // tab: storage of the Neville table, 24 doubles at stride `tabstride` (LDS on the device: one column per lane)
     template <class RootFn, class OmegaFn>
     RFS_HD void begin(int kr, int k0_, int k1_, double cstart, float bmx, double origin0, const RootFn& approx, const OmegaFn& om,
-                      double* tab, int tabstride) {
+                      double* tab, int tabstride, float origin_tol = (float)EXACT_ORIGIN_TOL) {
+        otol = origin_tol;
         k = kr; k0 = k0_; k1 = k1_; cc = cstart; betmx = bmx; dcs = (double)0.005f;
         cprev = origin0; nev = 0; cause = 0; nsupplied = 0;
         oerr = kr > 0 ? (float)EXACT_ORIGIN_ERR : 0.0f;                  // (a sequence's first period starts at the model's start value: exact)
@@ -1169,7 +1185,7 @@ struct ExactGroupT {
             // a period whose result is wanted must start from an origin that is the reference's to 1e-7 or better -- in effect: unless the run-up did not contract at all -- (its root then is
             // the reference's float32 value but for rare cases); a run-up that did not get there -- roots found by
             // bisections alone pass the origin's error on undiminished -- is the full search's business
-            if (k >= k0 && oerr > (float)EXACT_ORIGIN_TOL) { phase = X_FAIL; cause = 7; return; }
+            if (k >= k0 && oerr > otol) { phase = X_FAIL; cause = 7; return; }
             oerr *= nv.g3;
             cprev = nv.result; nsupplied += nv.nsupplied; phase = X_DONE; return;
         }

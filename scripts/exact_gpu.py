@@ -28,6 +28,8 @@ ap, _ = _bench_joint(2, n=n)
 cx = ex._ensure(n); ca = ap._ensure(n)
 cx.set_option("swd_warm_exact", 1); cx.set_option("swd_exact_group", G); cx.set_option("swd_exact_runup", RU)
 ca.set_option("swd_warm_exact", 0)
+if os.environ.get("EXACT_TOL_E9"):
+    cx.set_option("swd_exact_origin_tol_e9", int(os.environ["EXACT_TOL_E9"]))
 x = tt(np.clip(bench.make_models(nchain, 991206, n), bounds[:, 0], bounds[:, 1]))
 p = tt(0.5 * np.random.default_rng(7).standard_normal((nchain, 2 * n)))
 tot = dict(roots=0, ident=0, ident_approx=0)

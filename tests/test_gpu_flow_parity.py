@@ -15,6 +15,8 @@ model/model_rf_swd_vs_thk.py:66-86, surfdisp96.f:568-687):
 Three shapes: configs[1] (8192 chains x 30 layers, dt 0.05, 200 steps of burn-in), configs[3] (HMCDualAveraging.sample_flow,
 50 layers, per-chain dt), configs[4] (nt = 2048).  The asserts carry the measured numbers (tolerance of the contract: 1e-5).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -34,6 +36,8 @@ def _joint(n, nt, dt_rf):
     drf, dswd, flag = j.forward(bench.true_model(n))
     assert flag
     j.set_obsdata(drf, dswd)
+    for kv in filter(None, os.environ.get("RFS_OPTS", "").split(",")):      # (experiments: "name=value,..."; unset in the suite)
+        k_, v_ = kv.split("="); j._ensure(n).set_option(k_, int(v_))
     return j, t
 
 

@@ -464,6 +464,50 @@ def test_chains_that_sit_a_step_out_sample_the_same(golden):
     assert relx <= 1e-6 and relm <= 1e-5
 
 
+def test_wide_brackets_and_skipped_idle_chains_sample_the_same():
+    """Round 5: a warm search that finds no sign change within its trust radius keeps widening (the grid walk vouches for
+    what it finds, "swd_warm_widen"), and chains that are idle in a flow step are neither continued nor handed back
+    ("flow_skip_idle").  Both change only WHO evaluates a chain -- the period-parallel stages or the sequential search --
+    never the roots: the same seeded sampler run from burned-in models with both options on and both off (round 4's
+    behaviour; blocking hand-backs, so that device steps line up) accepts the same trajectories and stores the same
+    samples; fewer chains go to the full search with them on."""
+    import bench
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    n, nc = 30, 1024
+    joint, t = _bench_joint(1)
+    bounds = bench.bounds_of(bench.true_model(n))
+    ctx = joint._ensure(n)
+    keep = {}
+    s0 = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 40, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+    s0.sample_flow(x_init=bench.make_models(nc, 4, n), max_steps=161,
+                   step_hook=lambda s, st: keep.__setitem__("x", st["x"].clone()) if s == 160 else None)
+    xb = keep["x"].cpu().numpy()
+    runs = {}
+    for on in (1, 0):
+        ctx.set_option("swd_warm_widen", on); ctx.set_option("flow_skip_idle", on)
+        d0 = ctx.stat("swd_warm_declined_chains"); w0 = ctx.stat("swd_warm_wide_chains")
+        s = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+        mis = s.sample_flow(x_init=xb, max_steps=160, async_handback=False)
+        runs[on] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
+                    ctx.stat("swd_warm_declined_chains") - d0, ctx.stat("swd_warm_wide_chains") - w0)
+    ctx.set_option("swd_warm_widen", 1); ctx.set_option("flow_skip_idle", 1)
+    (m1, x1, a1, n1, h1, w1), (m0, x0, a0, n0, h0, w0_) = runs[1], runs[0]
+    assert np.array_equal(n1, n0)                        # blocking hand-backs: every chain completed the same trajectories
+    same = a1 == a0
+    k = np.minimum((m1 != 0).sum(axis=1), (m0 != 0).sum(axis=1))
+    relx = relm = 0.0
+    for c in np.nonzero(same)[0]:
+        if k[c] > 0:
+            relx = max(relx, np.abs(x1[c, :k[c]] - x0[c, :k[c]]).max() / np.abs(x0[c, :k[c]]).max())
+            relm = max(relm, np.abs(m1[c, :k[c]] - m0[c, :k[c]]).max() / np.abs(m0[c, :k[c]]).max())
+    print(f"options on / off: {h1} / {h0} chain evaluations handed back, {w1} / {w0_} chains walked the grid for a wide bracket; "
+          f"{int(same.sum())} of {nc} chains with identical accept counts, {int(k[same].sum())} samples compared: "
+          f"models differ by {relx:.2e}, misfits by {relm:.2e}")
+    assert h1 < h0 and w1 > w0_
+    # (a root off by a float32 step can flip an acceptance whose draw lies within 1e-7 of the threshold: not more than a chain or two)
+    assert same.mean() >= 0.995 and relx <= 1e-6 and relm <= 1e-5
+
+
 def test_two_flow_states_in_turn_on_one_context():
     """The warm start belongs to the state whose x array the previous flow call advanced: two states stepped in turn on one
     context start over from the full search at every call (nothing of the other state is continued) and get exactly the
