@@ -283,126 +283,6 @@ RFS_HD V4f rf_row_step_f32(const RfLayer& L, cplx omega, const V4f& r) {
     return o;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// float32 form of the COLUMN sweep (pass B with row peeling) for the upper part of the Gaussian band (round 5).  A
-// frequency's contribution to the gradient carries G = exp(-(w / 2 f0)^2); the band's second wavefront (bins 64 .. 127 at
-// a 51.2 s window, f0 = 1.5) starts at G = 1.05e-3 and holds 2.3e-4 of the band's total weight, so a relative error of
-// 1e-4 in its terms moves the gradient by ~3e-8 -- against a contract of 1e-5 (RfFreq::k32, option "rf_f32_band_digits_x10").
-// Same formulas as rf_hyp / rf_peel-and-advance / rf_layer_partials above, on the packed-f32 VALU; phases reduced in f64.
-// ---------------------------------------------------------------------------------------------------------------
-struct RfHypF { cplxf ca, cb, xa, ya, xb, yb; float sa, sb; };
-
-RFS_HD void rf_hyp_f32(const RfLayer& L, cplx omega, RfHypF& H) {
-    const cplx ta = omega * L.pva, tb = omega * L.pvb;
-    H.sa = (ta.re > 0.0 || (ta.re == 0.0 && ta.im >= 0.0)) ? 1.0f : -1.0f;
-    H.sb = (tb.re > 0.0 || (tb.re == 0.0 && tb.im >= 0.0)) ? 1.0f : -1.0f;
-    double pa = (L.h * ta.im) * 0.15915494309189535, pb = (L.h * tb.im) * 0.15915494309189535;
-    pa -= floor(pa); pb -= floor(pb);
-    float s1, c1, s2, c2;
-    f32_sincos_rev((float)pa, &s1, &c1); f32_sincos_rev((float)pb, &s2, &c2);
-    const float e1 = f32_exp((float)(L.h * ta.re)), e2 = f32_exp((float)(L.h * tb.re));
-    const float i1 = f32_rcp(e1), i2 = f32_rcp(e2);
-    const float ch1 = 0.5f * (e1 + i1), sh1 = 0.5f * (e1 - i1), ch2 = 0.5f * (e2 + i2), sh2 = 0.5f * (e2 - i2);
-    H.ca = cf_pmul(ch1, sh1, c1, s1); H.cb = cf_pmul(ch2, sh2, c2, s2);
-    const cplxf sha = H.sa * cf_pmul(sh1, ch1, c1, s1), shb = H.sb * cf_pmul(sh2, ch2, c2, s2);
-    H.xa = L.fva * sha; H.ya = sha * L.fiva; H.xb = L.fvb * shb; H.yb = shb * L.fivb;
-}
-
-// rb = r . A^-1 and ya = A . y in one pass over the distinct entries of A (see rf_row_times_Ainv / rf_A_times_col)
-RFS_HD void rf_peel_and_advance_f32(const RfLayer& L, const RfHypF& H, const V4f& r, const V4f& y, V4f& rb, V4f& ya) {
-    const cplxf g1 = L.fg1, g1sq = L.fg1sq, im2 = L.fim2, m2 = L.fm2;
-    const cplxf dc = H.ca - H.cb, dci = dc * im2;
-    cplxf e;
-    e = cmsub(H.ca, g1, H.cb);                     // a11 (= a44)
-    rb.v[0] = r.v[0] * e;  rb.v[3] = r.v[3] * e;  ya.v[0] = e * y.v[0];  ya.v[3] = e * y.v[3];
-    e = cmsub(H.cb, g1, H.ca);                     // a22 (= a33)
-    rb.v[1] = r.v[1] * e;  rb.v[2] = r.v[2] * e;  ya.v[1] = e * y.v[1];  ya.v[2] = e * y.v[2];
-    e = cmadd(-H.xb, g1, H.ya);                    // a12 (= -a34); sinh-type: opposite sign in A^-1
-    rb.v[1] = cmsub(rb.v[1], r.v[0], e);  rb.v[3] = cmadd(rb.v[3], r.v[2], e);  ya.v[0] = cmadd(ya.v[0], e, y.v[1]);  ya.v[2] = cmsub(ya.v[2], e, y.v[3]);
-    e = cmadd(-H.xa, g1, H.yb);                    // a21 (= -a43); sinh-type
-    rb.v[0] = cmsub(rb.v[0], r.v[1], e);  rb.v[2] = cmadd(rb.v[2], r.v[3], e);  ya.v[1] = cmadd(ya.v[1], e, y.v[0]);  ya.v[3] = cmsub(ya.v[3], e, y.v[2]);
-    // a13 = -dci, a24 = dci (cosh-type)
-    rb.v[2] = cmsub(rb.v[2], r.v[0], dci);  rb.v[3] = cmadd(rb.v[3], r.v[1], dci);  ya.v[0] = cmsub(ya.v[0], dci, y.v[2]);  ya.v[1] = cmadd(ya.v[1], dci, y.v[3]);
-    e = (H.xb - H.ya) * im2;                       // a14; sinh-type
-    rb.v[3] = cmsub(rb.v[3], r.v[0], e);  ya.v[0] = cmadd(ya.v[0], e, y.v[3]);
-    e = (H.xa - H.yb) * im2;                       // a23; sinh-type
-    rb.v[2] = cmsub(rb.v[2], r.v[1], e);  ya.v[1] = cmadd(ya.v[1], e, y.v[2]);
-    e = L.fm2g1 * dc;                              // a31 (= -a42); cosh-type
-    rb.v[0] = cmadd(rb.v[0], r.v[2], e);  rb.v[1] = cmsub(rb.v[1], r.v[3], e);  ya.v[2] = cmadd(ya.v[2], e, y.v[0]);  ya.v[3] = cmsub(ya.v[3], e, y.v[1]);
-    e = m2 * cmadd(-H.xb, g1sq, H.ya);             // a32; sinh-type
-    rb.v[1] = cmsub(rb.v[1], r.v[2], e);  ya.v[2] = cmadd(ya.v[2], e, y.v[1]);
-    e = m2 * cmadd(-H.xa, g1sq, H.yb);             // a41; sinh-type
-    rb.v[0] = cmsub(rb.v[0], r.v[3], e);  ya.v[3] = cmadd(ya.v[3], e, y.v[0]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) { rb.v[i] = L.fgam * rb.v[i]; ya.v[i] = L.fgam * ya.v[i]; }
-}
-
-// Re(r . dA/dm . y) for [rho, vp, vs, thk] (rf_layer_partials + rf_rho_partial): ra = the row above the layer (= r A),
-// r = the row below, y = the column above, yb = the column below (= A y)
-RFS_HD void rf_layer_partials_f32(const RfLayer& L, const RfHypF& H, cplx kd, const V4f& ra, const V4f& r, const V4f& y,
-                                  const V4f& yb_, float T[4]) {
-    const cplxf g = L.fgam, g1 = L.fg1, g1sq = L.fg1sq, g2 = to_f32(L.gam2), g3 = to_f32(L.gam3);
-    const cplxf im2 = L.fim2, m2 = L.fm2;
-    const cplxf ca = H.ca, cb = H.cb, xa = H.xa, ya = H.ya, xb = H.xb, yb = H.yb;
-    const cplxf k = to_f32(kd), kh = (float)L.h * k;
-    const cplxf dc = ca - cb;
-    // density: the commutator form (rf_rho_partial)
-    T[0] = (cf_re(ra.v[0] * y.v[0]) + cf_re(ra.v[1] * y.v[1]) - cf_re(r.v[0] * yb_.v[0]) - cf_re(r.v[1] * yb_.v[1])) / (float)L.rho;
-    const cplxf c11 = cmadd(r.v[0] * y.v[0], r.v[3], y.v[3]);
-    const cplxf c22 = cmadd(r.v[1] * y.v[1], r.v[2], y.v[2]);
-    const cplxf c12 = cmsub(r.v[0] * y.v[1], r.v[2], y.v[3]);
-    const cplxf c21 = cmsub(r.v[1] * y.v[0], r.v[3], y.v[2]);
-    const cplxf i13 = im2 * cmsub(r.v[0] * y.v[2], r.v[1], y.v[3]);
-    const cplxf i14 = im2 * (r.v[0] * y.v[3]);
-    const cplxf i23 = im2 * (r.v[1] * y.v[2]);
-    const cplxf m31 = m2 * cmsub(r.v[2] * y.v[0], r.v[3], y.v[1]);
-    const cplxf m32 = m2 * (r.v[2] * y.v[1]);
-    const cplxf m41 = m2 * (r.v[3] * y.v[0]);
-    {   // vp (:829-844)
-        const cplxf ga = g2 * to_f32(L.ia);
-        const cplxf khca = kh * ca;
-        cplxf t = ((kh * ya) * ga) * (c11 - i13 + g1 * (m31 - c22));
-        t = cmadd(t, ((khca - ya) * ga) * to_f32(L.iva2), g1 * c12 - i14 + g1sq * m32);
-        t = cmadd(t, (khca + ya) * ga, i23 - c21 - m41);
-        T[1] = cf_re(to_f32(L.sca) * t);
-    }
-    {   // vs (:811-826)
-        const cplxf khyb = kh * yb, khcb = kh * cb;
-        const cplxf e1 = khcb + yb, e2 = khcb - yb;
-        const cplxf gdc = g * dc, g1khyb = g1 * khyb, g1g3 = g1 * g3;
-        const cplxf two_g = 2.0f * g;
-        cplxf t = (gdc - g1khyb) * c11;
-        t = cmadd(t, g * (ya - xb) - e1, c12);
-        t = cmadd(t, khyb - gdc, c22);
-        t = cmadd(t, khyb, i13);
-        t = cmadd(t, e1, i14);
-        t = cmsub(t, e2 * (g * g3), i23);
-        t = cmadd(t, (two_g - cf(1.0f, 0.0f)) * dc - g1khyb, m31);
-        t = cmadd(t, two_g * cmadd(-xb, g1, ya) - e1, m32);
-        cplxf u = ((yb - xa) + g1g3 * e2) * c21;
-        u = cmadd(u, 2.0f * (g1 * yb) - 2.0f * xa + (g1 * g1g3) * e2, m41);
-        t = cmadd(t, g, u);
-        T[2] = cf_re((to_f32(L.scb) * (2.0f * to_f32(L.ib))) * t);
-    }
-    {   // thickness (:858-874)
-        const cplxf va2 = L.fva * L.fva, vb2 = L.fvb * L.fvb;
-        const cplxf na = (H.sa * k) * va2, nb = (H.sb * k) * vb2;
-        const cplxf kca = k * ca, kcb = k * cb, nbcb = nb * cb, naca = na * ca;
-        const cplxf kdx = (xa - xb) * k;
-        cplxf t = ((xa - g1 * xb) * k) * c11;
-        t = cmadd(t, g1 * kca - nbcb, c12);
-        t = cmsub(t, kdx, i13);
-        t = cmadd(t, nbcb - kca, i14);
-        t = cmadd(t, g1 * kcb - naca, c21);
-        t = cmadd(t, (xb - g1 * xa) * k, c22);
-        t = cmadd(t, naca - kcb, i23);
-        t = cmadd(t, g1 * kdx, m31);
-        t = cmadd(t, g1sq * kca - nbcb, m32);
-        t = cmadd(t, g1sq * kcb - naca, m41);
-        T[3] = cf_re(g * t);
-    }
-}
-
 // Row `rf_type` of the half-space matrix E^-1 (RFModule.f90:903-920).
 RFS_HD V4 rf_einv_row(const RfLayer& L, int rf_type) {
     V4 r;

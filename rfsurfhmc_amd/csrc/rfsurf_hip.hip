@@ -87,7 +87,6 @@ struct rfs_ctx {
     Buf d_minv; bool has_minv = false;                              // diagonal inverse mass of the leapfrog kernels
     // warm start of the root search inside trajectories (k_swd_warm): roots / kernels / model of the previous evaluation
     int rf_peel = -1;          // option "rf_row_peeling": pass B peels the layers off pass A's final row instead of reading stored rows: -1 / 1 = for the chains whose growth exponent allows it (decided on the device), 0 = never, 2 = always (diagnostics)
-    int rf_f32_band_x10 = 29;  // option "rf_f32_band_digits_x10": the column sweep takes the band's bins whose Gaussian weight is below 10^-(value / 10) in float32 (0 = none)
     int rf_band_digits = 13;   // option "rf_band_limit_digits": adjoint band limit at 1e-digits * water (0 = off)
     int rf_band_floor = 8;     // option "rf_band_floor_digits": the limit may move down to a multiple of 64 bins, never below this
     int warm_opt = 1;          // option "swd_warm_start": 0 off, 1 trajectory entries, 2 also the plugin entries
@@ -336,17 +335,6 @@ void set_band_limit(RfFreq& f, int digits, int floor_digits) {
     }
     if (nk < f.n2) { f.nk = std::max(nk, 1); f.nkp = (f.nk + 15) / 16 * 16; }
 }
-// the band's float32 part in the column sweep: from the first multiple of 64 bins on whose Gaussian weight is below
-// 10^-(x10 / 10) (default 2.9: 1.26e-3 -- at a 51.2 s window and f0 = 1.5 bin 64 carries 1.05e-3); 0 = none
-void set_f32_band(RfFreq& f, int x10) {
-    f.k32 = 0;
-    if (x10 <= 0 || f.method != RFS_RF_FREQ || !(f.f0 > 0.0) || f.nk >= f.n2) return;
-    const double thr = std::pow(10.0, -0.1 * x10), dw = 2.0 * 3.14159265358979323846 / (f.nft * f.dt);
-    for (int m = 64; m < f.nk; m += 64) {
-        const double a = m * dw / (2.0 * f.f0);
-        if (std::exp(-a * a) <= thr) { f.k32 = m; return; }
-    }
-}
 
 constexpr int RF_MAX_CHAINS_PER_LAUNCH = 32768;      // the RF sweeps use one grid row per chain (gridDim.y <= 65535)
 
@@ -478,21 +466,20 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0, 
         }
         if (*c->h_scount >= 0) c->stored_est = *c->h_scount;
         hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
-                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe,
-                           (rf_f32_on(c, f) && f.k32 > 0) ? c->hi32.as<int>() : (const int*)nullptr);
+                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
         const int gy = c->stored_est < 0 ? nchain : std::max(8, std::min(nchain, c->stored_est + c->stored_est / 8));
         hipLaunchKernelGGL((k_rf_passB<false, false>), dim3(rf_chunks_b(f), gy), dim3(bs), 0, c->stream, nchain, n, f, lc,
                            c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr,
-                           c->slist.as<int>(), c->scount.as<int>() + (c->speel_eval & 1), c->d_hscount, (const int*)nullptr);
+                           c->slist.as<int>(), c->scount.as<int>() + (c->speel_eval & 1), c->d_hscount);
     } else {
         hipLaunchKernelGGL((k_rf_passB<false, false>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
-                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe, (const int*)nullptr);
+                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
     }
     if (f.nk >= f.n2) {     // the Nyquist bin, lane = chain (no band limit: it is the first bin to go)
         if (peel) hipLaunchKernelGGL((k_rf_passB<true, true>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                                     c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe, (const int*)nullptr);
+                                     c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
         hipLaunchKernelGGL((k_rf_passB<true, false>), dim3((nchain + 63) / 64), dim3(64), 0, c->stream, nchain, n, f, lc,
-                           c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe, (const int*)nullptr);
+                           c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
     }
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
@@ -1628,16 +1615,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 1) return fail(c, RFS_ERR_ARG, "rf_scratch_budget_mb must be positive");
         c->rf_scratch_budget = (size_t)value << 20; return RFS_OK;
     }
-    if (!strcmp(name, "rf_f32_band_digits_x10")) {
-        if (value < 0 || value > 3000) return fail(c, RFS_ERR_ARG, "rf_f32_band_digits_x10 must be within [0, 3000]");
-        c->rf_f32_band_x10 = value;
-        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_f32_band(c->f, value); }
-        return RFS_OK;
-    }
     if (!strcmp(name, "rf_band_limit_digits")) {
         if (value < 0 || value > 300) return fail(c, RFS_ERR_ARG, "rf_band_limit_digits must be within [0, 300]");
         c->rf_band_digits = value;
-        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value, c->rf_band_floor); set_f32_band(c->f, c->rf_f32_band_x10); }
+        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, value, c->rf_band_floor); }
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
     }
@@ -1668,7 +1649,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "rf_band_floor_digits")) {
         if (value < 0 || value > 300) return fail(c, RFS_ERR_ARG, "rf_band_floor_digits must be within [0, 300]");
         c->rf_band_floor = value;
-        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, c->rf_band_digits, value); set_f32_band(c->f, c->rf_f32_band_x10); }
+        if (c->configured && c->has_rf) { HIPCHK(c, hipSetDevice(c->device)); TRY(rfs_synchronize(c)); set_band_limit(c->f, c->rf_band_digits, value); }
         for (auto& kv : c->calib) kv.second.stage = -1;
         return RFS_OK;
     }
@@ -1980,7 +1961,7 @@ int rfs_joint_setup2(rfs_ctx* c, int nlayer, const rfs_rf_params* rf, const rfs_
     c->sphere = sphere;
     c->has_minv = false;
     int nt = 0;
-    if (rf) { c->f = make_freq(*rf, 0); set_band_limit(c->f, c->rf_band_digits, c->rf_band_floor); set_f32_band(c->f, c->rf_f32_band_x10); nt = rf->nt; }
+    if (rf) { c->f = make_freq(*rf, 0); set_band_limit(c->f, c->rf_band_digits, c->rf_band_floor); nt = rf->nt; }
     c->ndata = nt + nswd;
     // wt = (sigma1/sigma2)^2 n1/n2, model_rf_swd_vs_thk.py:79
     c->wt = c->has_swd && c->has_rf ? (sigma1 / sigma2) * (sigma1 / sigma2) * nt / (double)nswd : 1.0;

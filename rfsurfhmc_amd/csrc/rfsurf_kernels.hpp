@@ -39,8 +39,6 @@ struct RfFreq {             // frequency axis + RF scalars shared by the RF kern
     double peel_emax;       // growth exponent up to which a chain's rows are rebuilt by peeling (rf_growth_exponent; 0 = never)
     double e32max;          // growth exponent (at the Nyquist frequency) up to which pass A sweeps a chain's frequencies beyond
                             // the band in float32 (rf_row_step_f32, rf_f32_emax; 0 = never)
-    int k32;                // first bin (a multiple of 64) of the band's float32 part in the column sweep (pass B with row peeling:
-                            // rf_layer_partials_f32): the Gaussian weight is below 10^-(rf_f32_band_digits_x10 / 10) from there on; 0 = none
 };
 
 __device__ __forceinline__ double rf_wk(const RfFreq& f, int k) {
@@ -666,11 +664,11 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
 // for the chains whose growth exponent allows it; the others read their stored rows (Rs).  With RT given both
 // instantiations are launched and each takes its own chains (a block = one chain: the other kind leaves at once).
 template <bool TAIL, bool INV = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))      // 256 VGPRs, 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
+__global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
 k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
            const double* __restrict__ Rs, const double* __restrict__ RT, const cplx* __restrict__ W,
            const double* __restrict__ wmax2, int npart, double* __restrict__ PG, unsigned* __restrict__ peel_resid,
-           const int* __restrict__ slist, const int* __restrict__ scount, int* __restrict__ est_out, const int* __restrict__ hi32)
+           const int* __restrict__ slist, const int* __restrict__ scount, int* __restrict__ est_out)
 {
   // slist (stored-row launch beside a peeling one): the blocks' y index strides over the chains pass A listed
   const int nsel = (!TAIL && slist) ? *scount : 1;
@@ -704,50 +702,6 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
     if (INV) {
 #pragma unroll
         for (int i = 0; i < 4; i++) r.v[i] = C(rs[(2 * i) * nkp], rs[(2 * i + 1) * nkp]);
-    }
-    // The band's float32 part (RfFreq::k32; a whole wavefront, a chain pass A found tame enough for float32 -- hi32): the same
-    // sweep on the packed-f32 VALU.  Its frequencies carry a Gaussian weight below ~1e-3 (2e-4 of the band's total).
-    if (!TAIL && INV && f.k32 > 0 && hi32 && k - lane >= f.k32 && hi32[chain]) {
-        V4f rf, yf;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { rf.v[i] = to_f32(r.v[i]); yf.v[i] = to_f32(y.v[i]); }
-        for (int j = 0; j < n; j++) {
-            double v4[4];
-            if (j < n - 1) {
-                RfHypF H;
-                rf_hyp_f32(L[j], omega, H);
-                V4f rb, yb;
-                rf_peel_and_advance_f32(L[j], H, rf, yf, rb, yb);
-                float T[4];
-                rf_layer_partials_f32(L[j], H, kk, rf, rb, yf, yb, T);
-                rf = rb; yf = yb;
-#pragma unroll
-                for (int ip = 0; ip < 4; ip++) v4[ip] = (double)T[ip];
-            } else {
-                V4 y64; cplx T64[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) y64.v[i] = C((double)cf_re(yf.v[i]), (double)cf_im(yf.v[i]));
-                rf_half_partials(L[j], omega, f.rf_type, y64, T64);
-#pragma unroll
-                for (int ip = 0; ip < 4; ip++) v4[ip] = T64[ip].re;
-            }
-#pragma unroll
-            for (int ip = 0; ip < 4; ip++) if (v4[ip] != v4[ip]) v4[ip] = 0.0;        // NaN scrub (:698-703)
-            double t4[4];
-            wave_sum4_uniform(v4, t4);
-#pragma unroll
-            for (int ip = 0; ip < 4; ip++)
-                if (lane == (j & 63)) acc[ip][j >> 6] = t4[ip];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            const int j = s2 * 64 + lane;
-            if (j < n) {
-#pragma unroll
-                for (int ip = 0; ip < 4; ip++) pg[(size_t)ip * n + j] = acc[ip][s2];
-            }
-        }
-        continue;
     }
     for (int j = 0; j < n; j++) {
         cplx T[4];
