@@ -462,7 +462,7 @@ N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs; one f64 (or any VALU) wave-instruc
 def _counters(config):
     """Per-step PMC figures of a configuration (profiles/r*_counters.json, written by scripts/pmc_summary.py from
     separate rocprofv3 --pmc passes); None where no pass was committed."""
-    for name in ("r04_counters.json", "r03_counters.json"):
+    for name in ("r05_counters.json", "r04_counters.json", "r03_counters.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if tj.get("chains") == 8192 and f"config{config}" in tj:

@@ -6,7 +6,7 @@ profiles/<tag>_pmc_config<c>.csv and the per-step, per-group figures bench.py re
 
 Each pass directory holds a *counter_collection.csv of `python3 scripts/prof_run.py <config> <steps> hmc` (a sampler run
 that continues burned-in chains).  Per kernel: the sum over all dispatches divided by the device steps of the pass (the
-dispatches of k_prep_joint); "swd_roots_full_search" = the searches of the start models and of handed-back chains.  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE
+dispatches of k_flow_post); "swd_roots_full_search" = the searches of the start models and of handed-back chains.  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE
 (KiB counters; gfx950 counts 64 B per 128-B request on wide coalesced reads, hence the factor 2)."""
 import csv, glob, json, os, sys
 
@@ -34,8 +34,11 @@ def main():
     kernels = sorted({k for k, _ in tot if k.startswith("k_")})
     counters = sorted({c for _, c in tot})
 
-    # device steps of the pass = dispatches of k_prep_joint (every step launches it once)
-    nstep = max([disp.get(("k_prep_joint", c), 0) for c in counters] + [1])
+    # device steps of the pass = dispatches of k_flow_post (one per flow step; k_prep_joint also runs in the plain evaluations of
+    # HMCDualAveraging._find_initial_dt, which are not steps -- ADVICE r04); passes without a flow step fall back to k_prep_joint
+    nstep = max([disp.get(("k_flow_post", c), 0) for c in counters] + [0])
+    if nstep == 0:
+        nstep = max([disp.get(("k_prep_joint", c), 0) for c in counters] + [1])
     steps = nstep
 
     def calls(k):

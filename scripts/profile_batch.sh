@@ -1,12 +1,12 @@
 #!/bin/bash
-# Profile batch of a round (run on the GPU box from the repo root):  bash scripts/profile_batch.sh r04
+# Profile batch of a round (run on the GPU box from the repo root):  bash scripts/profile_batch.sh r05
 #   gpurun_out/<tag>_bench.json      the bench line (with cpu_baseline)
 #   gpurun_out/<tag>_stats/          rocprofv3 --kernel-trace --stats of the bench command (the rank process itself:
 #                                    WORLD_SIZE=1 in the environment makes bench.py run as rank 0 without spawning a child --
 #                                    a process that the profiler's library has attached to the GPU must not start another)
 #   gpurun_out/<tag>_pmc/c<config>/g<i>/  one rocprofv3 --pmc pass per counter group and configuration (scripts/prof_run.py)
 # Afterwards (anywhere):  python3 scripts/pmc_summary.py <tag> <config> 0 gpurun_out/<tag>_pmc/c<config> ; copy the stats csv to profiles/.
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 root=$PWD
 mkdir -p gpurun_out
