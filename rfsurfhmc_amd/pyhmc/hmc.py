@@ -123,9 +123,16 @@ class HamitonianMC:
         idles until the last one has: a bubble of about one trajectory per segment).  At such a barrier the state is the one
         sample() checkpoints -- models, counters, sample slots, every chain's RNG position -- so the same file format serves
         both schedules, ``resume=True`` continues from ``self.checkpoint`` with the samples of an uninterrupted run, and the
-        mass matrix is re-estimated from the ensemble exactly where sample() does it."""
+        mass matrix is re-estimated from the ensemble exactly where sample() does it.  Where the write policy differs from
+        sample(): a checkpoint is written only at a barrier with chains still unfinished (sample() also writes one whenever it
+        stops early); `checkpoint` without `checkpoint_every` is refused."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.checkpoint and not self.checkpoint_every and not resume:
+            # sample() writes a checkpoint whenever it stops unfinished; the flow has states a run can continue from only at its
+            # barriers (every chain at the same trajectory count), so without an interval there would never be a file
+            raise ValueError("sample_flow: `checkpoint` needs `checkpoint_every` > 0 (checkpoints are written at barriers: every "
+                             "chain at the same trajectory count; a run cut by max_steps inside a segment writes none)")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()

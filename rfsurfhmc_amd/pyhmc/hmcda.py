@@ -117,14 +117,22 @@ class HMCDualAveraging:
         U, grad, _, flag = self.model.misfit_and_grad(xcur)
         Hcur = U + 0.5 * np.sum(pcur * pcur * mi, axis=1)
         a = np.zeros(nc)
+        # A chain whose evaluation fails here, or comes back with a NaN gradient (the reference's sregn96 where a root equals a
+        # layer velocity: about one chain in 8192 per evaluation), keeps dt0.  The reference -- one chain per process -- exits on
+        # the failed flag (:196-198) and would carry a NaN gradient into its next model; a batch does not give up 8191 chains
+        # for one, and says so.
+        live = flag & np.isfinite(U) & np.isfinite(grad).all(axis=1)
+        nbad = int((~live).sum())
+        grad = np.where(live[:, None], grad, 0.0)
         pcur = pcur - 0.5 * dt[:, None] * grad
-        live = np.ones(nc, dtype=bool)
         for it in range(20):
             xn, pn = _mirror(xcur + dt[:, None] * (pcur * mi), pcur, self.boundaries)
             xcur = np.where(live[:, None], xn, xcur); pcur = np.where(live[:, None], pn, pcur)
             U, grad, _, flag = self.model.misfit_and_grad(xcur)
-            if np.any(live & ~flag):
-                raise RuntimeError("error in chain %d!" % (self.first_chain + int(np.nonzero(live & ~flag)[0][0])))
+            failed = live & ~flag
+            if np.any(failed):
+                nbad += int(failed.sum()); live = live & flag
+            grad = np.where(live[:, None], grad, 0.0)
             pcur = np.where(live[:, None], pcur - 0.5 * dt[:, None] * grad, pcur)
             Hnew = U + 0.5 * np.sum(pcur * pcur * mi, axis=1)
             ediff = -(Hnew - Hcur)
@@ -141,6 +149,9 @@ class HMCDualAveraging:
             live = go
             if not live.any():
                 break
+        if nbad:
+            print(f"HMCDualAveraging._find_initial_dt: {nbad} chain(s) with a failed or non-finite evaluation keep their step size "
+                  f"(the reference exits there: 'error in chain')", file=sys.stderr)
         if self.verbose:
             for c in range(nc):
                 print(f"chain {self.first_chain + c}: change dt from {dt0} to {dt[c]}")
@@ -279,6 +290,8 @@ class HMCDualAveraging:
         at trajectory counts, sample()'s checkpoint format (with dt, dtbar and the dual-averaging statistic per chain)."""
         import torch
         nc, ns, nd_ = self.nchains, self.nsamples, self.ndraws
+        if self.checkpoint and not self.checkpoint_every and not resume:      # (as HamitonianMC.sample_flow)
+            raise ValueError("sample_flow: `checkpoint` needs `checkpoint_every` > 0 (checkpoints are written at barriers)")
         if self.inverse_mass is not None:
             self.model.set_inverse_mass(self.inverse_mass)
         dev = self._device()
@@ -331,7 +344,10 @@ class HMCDualAveraging:
           livel = [int(c) for c in np.nonzero(live0)[0]]
           p0 = np.zeros((nc, nx)); p0[live0] = self.rng.randn(livel, nx) * self._pscale
           st["p"].copy_(t(p0))
-          st["rem"].copy_(t(np.where(live0, self._traj_len(dt), -1).astype(np.int32)))
+          # (one call per segment, for the live chains only: _traj_len counts the lengths it clamps to L_cap, and that count is
+          # part of the results -- ADVICE r04)
+          L0 = np.zeros(nc, dtype=np.int64); L0[live0] = self._traj_len(dt[live0])
+          st["rem"].copy_(t(np.where(live0, L0, -1).astype(np.int32)))
           st["fresh"].copy_(t(live0.astype(np.int32)))
           pending = {}                                # chain -> (u, p) drawn ahead of time for it (restarts on the device)
 
@@ -403,7 +419,7 @@ class HMCDualAveraging:
           sampler = self
 
           class Restart:
-              rem0 = np.where(live0, self._traj_len(dt), 1 << 30)
+              rem0 = np.where(live0, L0, 1 << 30)
               deferred = True
 
               @staticmethod

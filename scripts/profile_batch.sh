@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 root=$PWD
 mkdir -p gpurun_out
 timeout 1500 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+cp bench_detail.json gpurun_out/${tag}_bench_detail.json        # (the profiled run below writes its own)
 export WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -- python3 $root/bench.py --gpus 1 --no-cpu-baseline --headline-only > $root/gpurun_out/${tag}_stats_bench.json 2> /dev/null )
 unset WORLD_SIZE RANK LOCAL_RANK
