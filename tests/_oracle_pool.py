@@ -42,6 +42,8 @@ def _roots_worker(args):
     O = _orc()
     c = np.zeros((len(xs), len(t))); ok = np.zeros(len(xs), dtype=bool)
     for i, x in enumerate(xs):
+        if not np.isfinite(x).all():             # (the restated scan never ends on a NaN model, like the reference's)
+            continue
         vs, thk = x[:n], x[n:]
         vp, rho, _, _ = O.empirical_relation(vs)
         c[i], ok[i] = O.libsurf.forward(thk, vp, vs, rho, t, "Rc")

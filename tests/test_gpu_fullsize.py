@@ -144,6 +144,7 @@ def test_early_eigenfunction_launch_changes_nothing():
                                                  "P", "freq"), SurfWD(tRc=t))
     drf, dswd, flag = joint.forward(bench.true_model())
     joint.set_obsdata(drf, dswd)
+    from _refnan import same
     x = torch.from_numpy(bench.make_models(8192, 7)).cuda()
     ctx = joint._ensure(bench.N_LAYER)
     ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", 0))
@@ -156,7 +157,7 @@ def test_early_eigenfunction_launch_changes_nothing():
                 out = joint.misfit_and_grad_device(x)
                 torch.cuda.synchronize()
                 for a, b in zip(out, ref):
-                    assert torch.equal(a, b), (k, rep)
+                    assert same(a, b), (k, rep)        # (NaN == NaN: the reference's NaN kernels, tests/_refnan.py)
     finally:
         ctx.check(ctx.L.rfs_set_option(ctx.h, b"early_eigen_periods", -1))
 
@@ -335,12 +336,15 @@ def test_65536_chains_on_one_device_within_the_scratch_budget():
     free0 = torch.cuda.mem_get_info()[0]
     out = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(xs).cuda())]
     used_gb = (free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30
-    assert out[3].all() and np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
+    from _refnan import check_nan_gradients, same
+    # (a handful of the 65 536 chains have a root that equals a layer velocity: the reference's NaN kernels, nowhere else)
+    nanrow = check_nan_gradients(xs, out[1], out[2][:, bench.NT:], bench.N_LAYER, "65536 chains")
+    assert out[3].all() and np.isfinite(out[0]).all() and np.isfinite(out[1][~nanrow]).all()
     assert used_gb < 20.0, used_gb                       # untiled: 33 GB of Rs alone
     sub = np.r_[0:64, 30000:30064, 65472:65536]
     ref = [o.cpu().numpy() for o in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[sub])).cuda())]
     for a, b in zip(out, ref):
-        assert np.array_equal(a[sub], b)
+        assert same(a[sub], b)
 
 
 def test_schedule_calibration_never_changes_a_result():

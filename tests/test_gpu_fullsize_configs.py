@@ -40,11 +40,13 @@ def test_full_batch_is_sane(full):
     cfg, joint, xs, (mis, grad, dsyn, flag), t, _ = full
     n, nt = cfg["n"], cfg["nt"]
     assert mis.shape == (8192,) and grad.shape == (8192, 2 * n) and dsyn.shape == (8192, nt + 40)
-    assert flag.all() and np.isfinite(mis).all() and np.isfinite(grad).all() and np.isfinite(dsyn).all()
+    from _refnan import check_nan_gradients
+    nanrow = check_nan_gradients(xs, grad, dsyn[:, nt:], n, cfg["name"])         # the reference's NaN kernels, nowhere else
+    assert flag.all() and np.isfinite(mis).all() and np.isfinite(grad[~nanrow]).all() and np.isfinite(dsyn).all()
     c = dsyn[:, nt:]
     assert np.all(c > 1.0) and np.all(c < 5.0)
     assert np.array_equal(c, c.astype(np.float32).astype(np.float64))      # float32-rounded roots (surfdisp96.f:302)
-    assert np.all(grad[:, 2 * n - 1] == 0.0)                               # the half-space thickness is a dummy
+    assert np.all(grad[~nanrow, 2 * n - 1] == 0.0)                         # the half-space thickness is a dummy
 
 
 def test_batch_invariance_and_permutation(full):
@@ -52,10 +54,11 @@ def test_batch_invariance_and_permutation(full):
     cfg, joint, xs, (mis, grad, dsyn, flag), t, _ = full
     sub = np.r_[0:64, 4000:4064, 8128:8192]
     o = [a.cpu().numpy() for a in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[sub])).cuda())]
-    assert np.array_equal(o[0], mis[sub]) and np.array_equal(o[1], grad[sub]) and np.array_equal(o[2], dsyn[sub])
+    from _refnan import same
+    assert same(o[0], mis[sub]) and same(o[1], grad[sub]) and same(o[2], dsyn[sub])
     perm = np.random.default_rng(0).permutation(8192)
     o = [a.cpu().numpy() for a in joint.misfit_and_grad_device(torch.from_numpy(np.ascontiguousarray(xs[perm])).cuda())]
-    assert np.array_equal(o[0], mis[perm]) and np.array_equal(o[1], grad[perm]) and np.array_equal(o[3], flag[perm])
+    assert same(o[0], mis[perm]) and same(o[1], grad[perm]) and same(o[3], flag[perm])
 
 
 def test_256_chains_against_the_oracle(full, orc):

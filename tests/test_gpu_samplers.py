@@ -369,6 +369,15 @@ def test_flow_with_device_restarts_at_scale_equals_the_synchronous_host_path(kin
         # (dual averaging lets a chain whose first trajectories are rejected shrink dt, hence lengthen L = lambda / dt: capped)
         return HMCDualAveraging(_joint(g), g["bounds"], 0.05, 10, 2, 0.65, 991206, 3, 12, myrank=0, name="t", outdir=None,
                                 nchains=nc, verbose=False, L_cap=30)
+    # A start model with a root that equals a layer velocity has the reference's NaN gradient (tests/_refnan.py: here the
+    # 1.05 T support root of a group-velocity period of chain 1703 -- the compiled reference returns NaN for it too): every
+    # trajectory from it fails at its first step, in the reference as here, and the chain never finishes.  (The root sits ON
+    # the layer velocity -- a sign change of the secular function where its formulas switch from oscillatory to evanescent -- and
+    # follows it when the model is moved.)  Such chains start from a neighbour's model instead.
+    _, g0, _, _ = mk().model.misfit_and_grad(x0)
+    stuck = ~np.isfinite(g0).all(axis=1)
+    assert stuck.sum() <= 2 and not stuck[0]
+    x0[stuck] = x0[0]
     a = mk(); ma = a.sample_flow(x_init=x0, pipeline=False, device_restart=False, max_steps=6000)   # (bounded: never hangs)
     b = mk(); mb = b.sample_flow(x_init=x0, max_steps=6000)
     assert a.finished and b.finished, (a.flow_steps, b.flow_steps)

@@ -46,6 +46,10 @@ def _bench_joint(warm, n=30, nt=512, dt=0.1, exact=None, **swd):
 def _leapfrog_move(x, p, g, dt, lo, hi):
     """One leapfrog step with unit mass and mirror reflection (pyhmc/hmc.py:121-137,166-183), on torch tensors."""
     import torch
+    # (a chain whose root equals a layer velocity comes back with the reference's NaN gradient -- tests/_refnan.py; the
+    # reference's sampler ends the trajectory there, this bare loop lets the chain coast: a NaN model would hang the oracle's
+    # restatement of the scan as it hangs the reference's)
+    g = torch.nan_to_num(g, nan=0.0)
     p = p - dt * g
     x = x + dt * p
     for _ in range(4):
@@ -81,7 +85,14 @@ def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc, exact):
         m, g, d, f = joint.misfit_and_grad_device(x)
         m0, g0, d0, f0 = full.misfit_and_grad_device(x)
         assert torch.equal(f, f0), s
-        okd = f0 != 0
+        # (the reference's NaN kernels where a root equals a layer velocity -- tests/_refnan.py -- in both evaluations or in
+        # neither, unless the two roots differ by their last float32 step: at most a chain or two of the 8192)
+        nan_w, nan_f = ~torch.isfinite(g).all(dim=1), ~torch.isfinite(g0).all(dim=1)
+        # (converged roots -- exact = 0 -- are the sign changes themselves: where the sign change IS a layer velocity, the place
+        # the secular function's formulas switch, they land on it far more often than the reference's nevill value, which
+        # stops short of it)
+        assert int((nan_w != nan_f).sum()) <= (2 if exact else 400) and int(nan_f.sum()) <= 8, (s, int(nan_w.sum()), int(nan_f.sum()))
+        okd = (f0 != 0) & ~nan_w & ~nan_f
         mrel.append(((m[okd] - m0[okd]).abs() / m0[okd].abs()).cpu().numpy())
         grel.append(((g[okd] - g0[okd]).abs().amax(dim=1) / g0[okd].abs().amax(dim=1)).cpu().numpy())
         xs_steps.append(x.cpu().numpy()); c_steps.append(d[:, nt:].cpu().numpy()); f_steps.append(f.cpu().numpy() != 0)
@@ -114,7 +125,7 @@ def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc, exact):
             assert r.max() <= (2.2e-6 if exact else 1.2e-6), (s, float(r.max()))
     # 512 chains of the last step against the oracle's joint plugin (the contract: 1e-5)
     xl, ml, gl, fl = last
-    pick = np.nonzero(fl)[0][:512]
+    pick = np.nonzero(fl & np.isfinite(gl).all(axis=1))[0][:512]
     rfpar = (bench.RAY_P, nt, 0.1, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
     res = joint_batch(xl[pick], rfpar, t, joint.dobs[:nt], joint.dobs[nt:])
     om = np.array([r[0] for r in res]); og = np.array([r[1] for r in res]); of = np.array([r[3] for r in res])
@@ -256,6 +267,7 @@ def test_dense_grid_walk_gives_the_speculative_walk_s_verdicts():
     root, densely packed -- the same verdicts as rounds of 8 speculative lanes per item: two plugins on the same models
     (2048 chains, half of them unsorted, 10 steps at a sampler's step size) hand back the same number of chains for the
     same causes at every step and return identical numbers, with fewer evaluations."""
+    from _refnan import same
     import torch
     import bench
     n, nt, nchain = 30, 512, 2048
@@ -275,7 +287,7 @@ def test_dense_grid_walk_gives_the_speculative_walk_s_verdicts():
     for s in range(11):
         md, gd, dd, fd = jd.misfit_and_grad_device(x)
         ms, gs, ds, fs = js.misfit_and_grad_device(x)
-        assert torch.equal(fd, fs) and torch.equal(md, ms) and torch.equal(gd, gs) and torch.equal(dd, ds), s
+        assert torch.equal(fd, fs) and torch.equal(md, ms) and same(gd, gs) and torch.equal(dd, ds), s      # (NaN == NaN: tests/_refnan.py)
         assert [cd.stat(k) for k in names] == [cs.stat(k) for k in names], (s, [cd.stat(k) for k in names], [cs.stat(k) for k in names])
         x, p = _leapfrog_move(x, p, torch.zeros_like(gd), 0.03, lo, hi)
     walked, items = cd.stat("swd_warm_walked_chains"), cd.stat("swd_warm_items")
@@ -307,7 +319,9 @@ def test_exact_final_gives_reference_roots_at_the_end_model():
     items = ctx.stat("swd_warm_items")
     assert items >= 0.9 * (L - 1) * nchain * 40                     # the inner steps were warm-started
     m, g, d, f = je.misfit_and_grad_device(st["x"].clone())
-    assert torch.equal(st["dsyn_new"], d) and torch.equal(st["Unew"], m)
+    okc = st["ok"] != 0               # (a trajectory that met the reference's NaN gradient on its way has ended there: tests/_refnan.py)
+    assert int((~okc).sum()) <= 2
+    assert torch.equal(st["dsyn_new"][okc], d[okc]) and torch.equal(st["Unew"][okc], m[okc])
 
 
 def test_love_group_and_sphere_blocks_are_continued_too(orc):
