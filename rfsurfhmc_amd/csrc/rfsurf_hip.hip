@@ -101,6 +101,8 @@ struct rfs_ctx {
     bool last_async = false;   // ... and did (a warm-started step with a side stream)
     int fpend_nchain = 0;
     const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
+    bool warm_feedback = true;   // option "swd_warm_feedback": last step's prediction error corrects this step's prediction (SwdWarm::ferr)
+    Buf wferr;
     bool warm_widen = true;    // option "swd_warm_widen": the warm search may bracket beyond its trust radius (the grid walk then vouches)
     bool flow_skip_idle = true;   // option "flow_skip_idle": idle chains of a flow step are neither continued nor handed back
     const int *f_rem = nullptr, *f_fresh = nullptr, *f_ok = nullptr;   // the flow state's arrays during a flow step (k_swd_warm: idle chains)
@@ -812,7 +814,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   (c->flow_cur && c->fpend.p && c->fpend.cap >= (size_t)nchain * sizeof(int)) ? c->fpend.as<int>() : (const int*)nullptr,
                   c->wsg1.as<unsigned char>(),
                   (c->flow_cur && c->flow_skip_idle) ? c->f_rem : (const int*)nullptr, c->f_fresh, c->f_ok,
-                  c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0};
+                  c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0,
+                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr};
         (void)0;
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
@@ -1174,6 +1177,8 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         ENSURE(c, c->wslope, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
         ENSURE(c, c->wbetmx, (size_t)2 * nchain * sizeof(float)); ENSURE(c, c->wsg1, (size_t)8 * nchain);
+        ENSURE(c, c->wferr, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
+        if (!warm) HIPCHK(c, hipMemsetAsync(c->wferr.p, 0, c->wferr.cap, c->stream));      // (an evaluation by the full search leaves nothing to carry over)
         // slopes of the secular function belong to roots a warm search found: an evaluation by the full search leaves none
         if (!warm) HIPCHK(c, hipMemsetAsync(c->wslope.p, 0, c->wslope.cap, c->stream));
         if (c->wvalid.cap != before) {
@@ -1506,7 +1511,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1684,6 +1689,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     }
     if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_widen")) { c->warm_widen = value != 0; return RFS_OK; }
+    if (!strcmp(name, "swd_warm_feedback")) { c->warm_feedback = value != 0; return RFS_OK; }
     if (!strcmp(name, "flow_skip_idle")) { c->flow_skip_idle = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
     if (!strcmp(name, "swd_exact_final")) {

@@ -1109,6 +1109,11 @@ struct SwdWarm {
     const int* f_rem; const int* f_fresh; const int* f_ok;
     const double* walk_roots;   // [item][chain] what the grid walks take for the continued roots: cwarm beside k_swd_exact (which overwrites croot meanwhile), else croot
     int widen;              // option "swd_warm_widen": 1 = the search may go on beyond the trust radius (WarmSearch::wide)
+    // Error feedback of the predictor (round 5, option "swd_warm_feedback"): what the first-order prediction missed by at the
+    // previous step -- root - (previous root + G . dx), the second-order term of the root along the trajectory -- is added to
+    // this step's prediction: inside a trajectory consecutive moves dt M^-1 p are nearly equal, and so are their second-order
+    // terms.  [item][chain]; zero where there is nothing to carry over (a trajectory that starts with this step, a failed search).
+    double* ferr;
 };
 
 template <class F, bool SPH>
@@ -1169,15 +1174,27 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
     WarmSearch ws;
-    ws.begin(cprev, dc, l1, W.slope[(size_t)e * nchain + chain]);
+    // (a correction larger than the first-order terms themselves is not a second-order term: ignored)
+    double fb = (W.ferr && live) ? W.ferr[(size_t)e * nchain + chain] : 0.0;
+    if (!(fabs(fb) <= l1)) fb = 0.0;
+    ws.begin(cprev, dc + fb, l1, W.slope[(size_t)e * nchain + chain]);
     if (W.widen && cprev > 0.0 && (!(dc == dc) || !(l1 <= WARM_L1WIDE))) ws.begin_wide(cprev);
     else if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
     if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
     if (live && !(l1 <= WARM_L1MAX) && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
     const bool refused = !ws.active();
-    while (__any(ws.active())) {
-        if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq), W.widen != 0);
+    int nev_first = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        while (__any(ws.active())) {
+            if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq), W.widen != 0);
+        }
+        // a search that failed from a corrected prediction starts over from the plain first-order one (the correction is a
+        // guess: where the trajectory has just turned, or next to another mode, it points the wrong way)
+        const bool again = attempt == 0 && live && !refused && fb != 0.0 && ws.phase == WarmSearch::W_FAIL;
+        if (!__any(again)) break;
+        if (again) { nev_first = ws.nev; fb = 0.0; ws.begin(cprev, dc, l1, 0.0); }
     }
+    ws.nev += nev_first;
     const bool ok = live && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
     // a root found beyond the trust radius: the grid walk has the word (statistic 13 counts the chains, as for large moves)
     if (ok && ws.wide() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
@@ -1192,6 +1209,11 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (!refused && ws.phase != WarmSearch::W_DONE) atomicAdd(&W.stats[ws.eps >= fmin(WARM_RWIDE * ws.R, fmax(ws.R, WARM_RWIDE_ABS)) ? 24 : 25], 1ull);
     }
     if (live) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
+    if (live && W.ferr) {
+        // a trajectory that starts with this step has not moved (and its next move has a new momentum): nothing to carry over
+        const bool fresh = W.f_fresh && W.f_fresh[chain];
+        W.ferr[(size_t)e * nchain + chain] = (ok && !fresh && dc == dc) ? ws.root - (cprev + dc) : 0.0;
+    }
     int nev = live ? ws.nev : 0, nok = ok ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }

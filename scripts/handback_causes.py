@@ -7,7 +7,7 @@ cfg = bench.CONFIGS[1]
 dev = torch.device("cuda:0")
 joint, x_true, bounds = bench.make_joint(cfg, 0)
 ctx = joint._ensure(cfg["n"])
-names = [f"swd_warm_cause_{i}" for i in range(4, 12)] + [f"swd_exact_cause_{i}" for i in range(1, 8)] + ["swd_warm_fail_no_change", "swd_warm_fail_other", "swd_warm_wide_chains", "swd_exact_secular_evals", "swd_warm_items"] + ["swd_warm_declined_chains", "swd_exact_declined_chains", "swd_warm_walked_chains", "flow_chain_steps"]
+names = [f"swd_warm_cause_{i}" for i in range(4, 12)] + [f"swd_exact_cause_{i}" for i in range(1, 8)] + ["swd_warm_fail_no_change", "swd_warm_fail_other", "swd_warm_wide_chains", "swd_exact_secular_evals", "swd_warm_items", "swd_warm_secular_evals"] + ["swd_warm_declined_chains", "swd_exact_declined_chains", "swd_warm_walked_chains", "flow_chain_steps"]
 snap = {}
 orig = bench.sampler_leg
 import time
