@@ -1355,7 +1355,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         const int rowc = ((size_t)(n + 3 * R.nswd) * 32 * sizeof(double) <= 56 * 1024) ? 1 : 0;
         const size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
 #define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
-        hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 4), lds_c,      /* 256-thread blocks: they slip into wave slots the RF sweep frees, a 1024-thread block waits for a whole CU */                             \
+        hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 8), lds_c,      /* 512-thread blocks = 16 layer slots per chain (round 5: 5.29 -> 5.24 ms per step against 256 threads; 1024 the same, 128 slower: 5.38); same sums in the same order */                             \
                            st, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(),                                    \
                            c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),          \
                            P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                      \
