@@ -56,17 +56,28 @@ for seed in range(a, b):
                 a_, b_ = dw[ok][:, nt + bi * nper: nt + (bi + 1) * nper], de[ok][:, nt + bi * nper: nt + (bi + 1) * nper]
                 if not a_.numel():
                     continue
-                r = float(((a_ - b_).abs() / b_.abs()).max())
+                # (a group velocity whose central root equals a layer velocity is NaN in the reference: in both or in neither)
+                fin = torch.isfinite(a_) & torch.isfinite(b_)
+                assert bool((torch.isfinite(a_) == torch.isfinite(b_)).all()), (name, "NaN pattern")
+                tot["nan_values"] = tot.get("nan_values", 0) + int((~fin).sum())
+                if not fin.any():
+                    continue
+                r = float(((a_[fin] - b_[fin]).abs() / b_[fin].abs()).max())
                 if name in ("tRc", "tLc"):
                     tot["roots"] += a_.numel(); tot["same"] += int((a_ == b_).sum()); worst["c"] = max(worst["c"], r)
                     assert r <= 2.2e-6, (name, r)
                 else:
                     tot["groots"] += a_.numel(); tot["gsame"] += int((a_ == b_).sum()); worst["u"] = max(worst["u"], r)
                     assert r <= 4e-4, (name, r)
-            if ok.any():
-                worst["m"] = max(worst["m"], float(((mw[ok] - me[ok]).abs() / me[ok].abs().clamp_min(1e-300)).max()))
-                worst["g"] = max(worst["g"], float(((gw[ok] - ge[ok]).abs().amax(dim=1) / ge[ok].abs().amax(dim=1).clamp_min(1e-300)).max()))
-            g = torch.where(ok[:, None], gw, torch.zeros_like(gw))
+            # (the reference's NaN kernels where a root equals a layer velocity: in both evaluations or -- a root one float32 step
+            # apart -- in one; counted, left out of the gradient comparison, and the chain coasts)
+            nanw, nane = ~torch.isfinite(gw).all(dim=1), ~torch.isfinite(ge).all(dim=1)
+            tot["nan_rows"] = tot.get("nan_rows", 0) + int((nanw | nane).sum()); tot["nan_differ"] = tot.get("nan_differ", 0) + int((nanw != nane).sum())
+            okg = ok & ~nanw & ~nane
+            if okg.any():
+                worst["m"] = max(worst["m"], float(((mw[okg] - me[okg]).abs() / me[okg].abs().clamp_min(1e-300)).max()))
+                worst["g"] = max(worst["g"], float(((gw[okg] - ge[okg]).abs().amax(dim=1) / ge[okg].abs().amax(dim=1).clamp_min(1e-300)).max()))
+            g = torch.where(okg[:, None], gw, torch.zeros_like(gw))
             p = p - 0.003 * g
             x = x + 0.003 * p
             for _ in range(3):
@@ -77,4 +88,5 @@ for seed in range(a, b):
         bad.append(seed); print("seed", seed, (n, names, sphere, with_rf), "FAILED:", repr(e)[:200], flush=True)
 print(f"seeds {a}..{b - 1}: failures {bad}; phase roots {tot['roots']}, bit-identical {tot['same']} ({tot['same'] / max(tot['roots'], 1):.4%}), worst {worst['c']:.2e} c; "
       f"group values {tot['groots']}, bit-identical {tot['gsame']} ({tot['gsame'] / max(tot['groots'], 1):.4%}), worst {worst['u']:.2e}; "
-      f"misfit worst {worst['m']:.2e}, gradient worst {worst['g']:.2e}; {time.time() - t0:.0f} s")
+      f"misfit worst {worst['m']:.2e}, gradient worst {worst['g']:.2e}; rows with the reference's NaN gradient {tot.get('nan_rows', 0)} "
+      f"(in one evaluation only: {tot.get('nan_differ', 0)}); {time.time() - t0:.0f} s")
