@@ -141,21 +141,22 @@ def _report(tag, out):
         json.dump(allr, open(path, "w"), indent=1)
 
 
-def test_configs1_sampler_step_at_dt_005_on_burned_in_chains(orc):
+@pytest.mark.parametrize("s0", [200, 350])
+def test_configs1_sampler_step_at_dt_005_on_burned_in_chains(orc, s0):
     """configs[1], the bench's headline run itself: 8192 chains, HamitonianMC.sample_flow at dt 0.05, stopped at device
-    step 200; 512 completed + 512 mid-trajectory chains of that step against the oracle."""
+    step 200 (350: behind the bench's burn-in); 512 completed + 512 mid-trajectory chains of that step against the oracle."""
     import bench
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
-    n, nt, nchain, s0 = 30, 512, 8192, 200
+    n, nt, nchain = 30, 512, 8192
     joint, t = _joint(n, nt, 0.1)
     bounds = bench.bounds_of(bench.true_model(n))
-    smp = HamitonianMC(joint, bounds, bench.TUNED_DT, [5, 20], 10, 991206, 80, 20, myrank=0, name="parity", outdir=None,
+    smp = HamitonianMC(joint, bounds, bench.TUNED_DT, [5, 20], 10, 991206, 120, 20, myrank=0, name="parity", outdir=None,
                        nchains=nchain, verbose=False, store_syn=False)
     b, a = _capture(smp, bench.make_models(nchain, 991206, n), s0)
     ctx = joint._ensure(n)
     assert ctx.stat("swd_exact_secular_evals") > 0 and ctx.stat("swd_warm_items") > 0.9 * s0 * nchain * 40     # the measured mode ran
     rfpar = (bench.RAY_P, nt, 0.1, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
-    r = _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, 512, "configs[1] dt 0.05 step 200")
+    r = _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, 512, f"configs[1] dt 0.05 step {s0}")
     assert r["unsorted_share"] > 0.2                      # burned in: velocity inversions are the rule, not the exception
     assert r["rf_trace_max"] <= 1e-9
     # measured (round 5, two boxes): roots <= 9.4e-7 c, 99.8-99.9 % of them bit-identical; misfit max 2.7e-6, p99 1.1e-6;

@@ -138,7 +138,10 @@ def test_every_root_of_20_step_trajectories_of_the_bench_chains(orc, exact):
           f"vs the oracle (512 chains): misfit max {omr.max():.2e}, gradient max {ogr.max():.2e} p99 {np.quantile(ogr, 0.99):.2e}")
     if exact:
         assert nident >= 0.9999 * ntot, (nident, ntot)
-        assert mrel.max() <= 1e-6 and grel.max() <= 1e-6, (mrel.max(), grel.max())
+        # (round 5's default -- one run-up period, origins to 5e-7 c -- leaves 5e-5 of the roots one float32 step off the
+        # sequential search's: measured 99.9954 % identical, misfit within 1.9e-7, gradient within 2.0e-6 of it; round 4's two
+        # run-up periods: 99.998 %, 5e-8, 6e-8)
+        assert mrel.max() <= 1e-6 and grel.max() <= 5e-6, (mrel.max(), grel.max())
         assert omr.max() <= 2e-6 and ogr.max() <= 1e-5, (omr.max(), ogr.max())
     else:
         # converged roots, 0.5 .. 1e-6 c above the reference's: a misfit built on residuals of ~0.3 km/s moves by ~1.4e-5;
