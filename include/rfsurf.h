@@ -336,7 +336,7 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          population: misfit max 2.9e-6, none above 1e-5; gradient 6 chains above 1e-5 (max 1.3e-5) -- round 4's
  *                          setting ("swd_exact_runup" 2, 100 here): 3.6e-6, none; 4 chains (max 2.2e-5): the same ill-conditioned
  *                          chains either way; roots 99.997 % bit-identical to the sequential search on smooth models.  A sixth of
- *                          the stage's evaluations less: 5.27 -> 4.85 ms per step at 8192 chains.
+ *                          the stage's evaluations less: 5.26 -> 5.08 ms per step at 8192 chains (same-box A/B).
  *   "swd_warm_widen"       1 (default): a warm search that finds no sign change within its trust radius (the root has left the
  *                          first-order model's reach: 32 chains per step of a burned-in 8192-chain population) keeps widening its
  *                          bracket, out to 16 x the radius or 0.1 km/s; an item whose first-order change exceeds 2 km/s (kernels

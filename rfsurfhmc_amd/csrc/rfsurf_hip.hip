@@ -111,7 +111,7 @@ struct rfs_ctx {
     // Round 5: ONE run-up period, origins accepted to 5e-7 c.  Over 3 072 + 3 072 burned-in bench chains against the oracle
     // (scripts/flow_parity_stats.py) this setting and round 4's (two run-up periods, 1e-7 c) are indistinguishable -- misfit
     // max 2.9e-6 / 3.6e-6, none above 1e-5; gradient 6 / 4 chains above 1e-5 (max 1.3e-5 / 2.2e-5: the ill-conditioned chains
-    // either setting has) -- and the stage does a sixth less work: 5.27 -> 4.85 ms per step.
+    // either setting has) -- and the stage does a sixth less work: 5.26 -> 5.08 ms per step (same-box A/B).
     float exact_origin_tol = 5.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL = 1e-7: round 4's)
     int exact_group = 4, exact_runup = 1;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
