@@ -905,6 +905,11 @@ def run_rank(args):
             extra["two_runup_periods"] = short("swd_exact_runup 2, swd_exact_origin_tol_e9 100: round 4's setting of the reference-root stage",
                                                dt=dt, mode=mode)
             ctx.set_option("swd_exact_runup", 1); ctx.set_option("swd_exact_origin_tol_e9", 500)
+            # ... and the headline's own setting by the side legs' protocol, straight after it: a side leg continues chains that
+            # have been through ~1 000 more steps than the headline's window and times a shorter window, so its rate compares with
+            # THIS figure, not with `value`
+            extra["headline_again"] = short("the headline's setting, measured like a side leg (for the side legs' ratios)",
+                                            dt=dt, mode=mode)
         set_root_mode(joint, n, mode)
         # ---- rounds 1-3's headline definition, for continuity: never-ending trajectories (no accept / reject) of the random
         # start models at dt = 0.002, the cheapest point of the step-size curve
@@ -1012,7 +1017,7 @@ def run_rank(args):
     for k, v in extra.items():
         res[k] = v
     # the side legs' rates as top-level scalars as well
-    for k in ("converged_roots", "full_search_every_step", "two_runup_periods", "never_ending_dt0002", "config3", "config4", "config0"):
+    for k in ("converged_roots", "full_search_every_step", "two_runup_periods", "headline_again", "never_ending_dt0002", "config3", "config4", "config0"):
         if k in extra:
             res[f"{k}_value"] = extra[k]["value"]
     if "config0" in extra and extra["config0"].get("ms_per_eval"):
