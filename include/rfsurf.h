@@ -417,6 +417,9 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *                               fastest layer, 6 NaN, 7 the run-up left the origin short of "swd_exact_origin_tol_e9"
  *   "swd_warm_fail_no_change" / "swd_warm_fail_other"   (period, chain) items whose warm search failed: no sign change out to
  *                               the widest bracket / anything else
+ *   "swd_warm_search_evals" / "swd_warm_search_evals_slowest_lane" / "swd_warm_search_lanes"   divergence of the warm search
+ *                               (k_swd_warm): evaluations of all lanes, of each wavefront's slowest lane (x 64 = what the
+ *                               wavefronts execute), lanes that searched
  *   "swd_warm_cause_<k>"        chains handed back, by (first) cause: 4 no usable previous evaluation / forced, 5 step too
  *                               large for a first-order model, 6 no sign change inside the trust radius, 7 root above the
  *                               fastest layer, 9 / 11 another root lies between the point the reference's scan of that

@@ -101,6 +101,7 @@ struct rfs_ctx {
     bool last_async = false;   // ... and did (a warm-started step with a side stream)
     int fpend_nchain = 0;
     const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
+    int warm_budgets = 302;      // option "swd_warm_round_budgets": evaluations a lane may spend in round 1 / 2 / 3 of k_swd_warm (b1 + 100 b2 + 10000 b3; the last round has no limit); 0: one round
     bool warm_feedback = true;   // option "swd_warm_feedback": last step's prediction error corrects this step's prediction (SwdWarm::ferr)
     Buf wferr;
     bool warm_widen = true;    // option "swd_warm_widen": the warm search may bracket beyond its trust radius (the grid walk then vouches)
@@ -119,7 +120,7 @@ struct rfs_ctx {
     int warm_nchain = 0;
     int warm_est = 0;          // chains the last steps handed back to the full search (sizes the next fallback launch)
     int* h_wcount = nullptr;   // pinned mirror of the device-side count, copied back asynchronously (never waited for)
-    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, wlist3, cwarm, fstat, wslope, wbetmx, wsg1;
+    Buf xw, dxT, crT, wvalid, wneed, wlist, wforce, wstats, wsgn, crs, craw, wilist, wlist2, wlist3, cwarm, fstat, wslope, wbetmx, wsg1, wspA, wspB, wspc;
     hipEvent_t ev_w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // hand-overs between the SWD stream and its side stream (warm start)
     int swd_mode = 0, swd_mode_cur = 0;   // libsurf's `mode` of the joint configuration / of the evaluation being launched
     bool swd_water_cur = false;           // the batch being launched holds models with a water layer on top (B1 entries)
@@ -821,18 +822,55 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0,
                   c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr};
         (void)0;
+// Rounds (WarmSpill, rfsurf_kernels.hpp): budgets b1, b2, b3 and a last round without one; the unfinished searches of a round
+        // are packed into a list for the next.  The lists' lengths are only known on the device: the later rounds' grids are sized for
+        // what the bench's chains need several times over, and their blocks stride.
+        const int wb1 = c->warm_budgets % 100, wb2 = (c->warm_budgets / 100) % 100, wb3 = (c->warm_budgets / 10000) % 100;
+        const bool rounds = wb1 > 0;
+        const size_t items_max = (size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain;
+        const int spcap = rounds ? (int)std::min<size_t>(std::max<size_t>(4096, items_max / 2), (size_t)1 << 30) : 1;
+        const size_t spbytes = (size_t)spcap * (WARM_SPILL_ND + 2) * 8;
+        ENSURE(c, c->wspA, spbytes); ENSURE(c, c->wspB, spbytes); ENSURE(c, c->wspc, 8 * sizeof(int));
+        auto spill = [&](Buf& bf, int ci) {
+            double* d = bf.as<double>();
+            return WarmSpill{d, (unsigned long long*)(d + (size_t)WARM_SPILL_ND * spcap), (unsigned long long*)(d + (size_t)(WARM_SPILL_ND + 1) * spcap),
+                             c->wspc.as<int>() + ci, spcap};
+        };
+        const int NOLIM = 0x7fffffff;
+#define RFS_LAUNCH_WARM1(FAM, SPHB, FIRSTB, GRID, QQ, MDLC, SPHP, IN, OUT, BUD, RND)                                   \
+        hipLaunchKernelGGL((k_swd_warm<FAM, SPHB, FIRSTB>), GRID, dim3(64), 0, s, nchain, n, QQ, MDLC, SPHP,             \
+                           c->krn.as<double>(), c->ugr.as<double>(), (size_t)P.nitems * nchain, c->croot.as<double>(), W, \
+                           IN, OUT, BUD, RND)
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
-            dim3 grid((unsigned)(((size_t)(QQ).nper_total * nchain + 63) / 64));                                      \
-            if (sphere) hipLaunchKernelGGL((k_swd_warm<FAM, true>), grid, dim3(64), 0, s, nchain, n, QQ, MDLC, SPHP,   \
-                                           c->krn.as<double>(), c->ugr.as<double>(), (size_t)P.nitems * nchain,       \
-                                           c->croot.as<double>(), W);                                                 \
-            else hipLaunchKernelGGL((k_swd_warm<FAM, false>), grid, dim3(64), 0, s, nchain, n, QQ, MDLC,              \
-                                    (const double*)nullptr, c->krn.as<double>(), c->ugr.as<double>(),                 \
-                                    (size_t)P.nitems * nchain, c->croot.as<double>(), W);                             \
+            const size_t nit = (size_t)(QQ).nper_total * nchain;                                                      \
+            dim3 grid((unsigned)((nit + 63) / 64));                                                                   \
+            const double* sp_ = sphere ? (SPHP) : (const double*)nullptr;                                             \
+            WarmSpill none{nullptr, nullptr, nullptr, c->wspc.as<int>() + 3, 0};                                      \
+            if (!rounds) {                                                                                            \
+                if (sphere) RFS_LAUNCH_WARM1(FAM, true, true, grid, QQ, MDLC, sp_, none, none, NOLIM, -1);            \
+                else RFS_LAUNCH_WARM1(FAM, false, true, grid, QQ, MDLC, sp_, none, none, NOLIM, -1);                  \
+                break;                                                                                                \
+            }                                                                                                         \
+            HIPCHK(c, hipMemsetAsync(c->wspc.p, 0, 8 * sizeof(int), s));                                              \
+            WarmSpill A0 = spill(c->wspA, 0), B1 = spill(c->wspB, 1), A2 = spill(c->wspA, 2);                         \
+            const unsigned gw = (unsigned)((nit + 63) / 64);                                                          \
+            dim3 g2(std::max(64u, gw / 3)), g3(std::max(32u, gw / 8)), g4(std::max(16u, gw / 24));                    \
+            if (sphere) {                                                                                             \
+                RFS_LAUNCH_WARM1(FAM, true, true, grid, QQ, MDLC, sp_, none, A0, wb1, 0);                             \
+                if (wb2 > 0) RFS_LAUNCH_WARM1(FAM, true, false, g2, QQ, MDLC, sp_, A0, B1, wb2, 1);                    \
+                if (wb2 > 0 && wb3 > 0) RFS_LAUNCH_WARM1(FAM, true, false, g3, QQ, MDLC, sp_, B1, A2, wb3, 2);         \
+                RFS_LAUNCH_WARM1(FAM, true, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
+            } else {                                                                                                  \
+                RFS_LAUNCH_WARM1(FAM, false, true, grid, QQ, MDLC, sp_, none, A0, wb1, 0);                            \
+                if (wb2 > 0) RFS_LAUNCH_WARM1(FAM, false, false, g2, QQ, MDLC, sp_, A0, B1, wb2, 1);                   \
+                if (wb2 > 0 && wb3 > 0) RFS_LAUNCH_WARM1(FAM, false, false, g3, QQ, MDLC, sp_, B1, A2, wb3, 2);        \
+                RFS_LAUNCH_WARM1(FAM, false, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
+            }                                                                                                         \
         } while (0)
         if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
         if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
+#undef RFS_LAUNCH_WARM1
 #undef RFS_LAUNCH_WARM
         HIPCHK(c, hipGetLastError());
         // The hand-back lists are nearly always empty, and when one is not, the full search of even ONE chain takes ~3 ms
@@ -1496,6 +1534,9 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
              hipEventCreateWithFlags(&c->ev_wk[0], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_wk[1], hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
+    // (RFS_WARM_ROUND_BUDGETS in the environment: the start value of option "swd_warm_round_budgets" -- for A/B runs of
+    // scripts that build their contexts themselves)
+    if (const char* e = getenv("RFS_WARM_ROUND_BUDGETS")) { const int v = atoi(e); if (v >= 0 && v <= 999999) c->warm_budgets = v; }
     c->own_stream = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return RFS_ERR_HIP; }
@@ -1515,7 +1556,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1694,6 +1735,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_widen")) { c->warm_widen = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_feedback")) { c->warm_feedback = value != 0; return RFS_OK; }
+    if (!strcmp(name, "swd_warm_round_budgets")) {
+        if (value < 0 || value > 999999) return fail(c, RFS_ERR_ARG, "swd_warm_round_budgets must be b1 + 100 b2 + 10000 b3 with 0 <= b < 100");
+        c->warm_budgets = (int)value; return RFS_OK;
+    }
     if (!strcmp(name, "flow_skip_idle")) { c->flow_skip_idle = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_reset")) { c->warm_primed = false; return RFS_OK; }      // next evaluation: full search
     if (!strcmp(name, "swd_exact_final")) {
@@ -1760,6 +1805,10 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     else if (!strncmp(name, "swd_warm_cause_", 15)) { idx = atoi(name + 15); if (idx < 4 || idx > 11) idx = -1; }
     else if (!strcmp(name, "swd_warm_fail_no_change")) idx = 24;
     else if (!strcmp(name, "swd_warm_fail_other")) idx = 25;
+    else if (!strcmp(name, "swd_warm_search_evals")) idx = 26;
+    else if (!strcmp(name, "swd_warm_search_evals_slowest_lane")) idx = 27;
+    else if (!strcmp(name, "swd_warm_search_lanes")) idx = 28;
+    else if (!strncmp(name, "swd_warm_passed_on_", 19)) { idx = atoi(name + 19); idx = (idx < 1 || idx > 3) ? -1 : 28 + idx; }
     else if (!strncmp(name, "swd_exact_cause_", 16)) { idx = atoi(name + 16); idx = (idx < 1 || idx > 7) ? -1 : 16 + idx; }
     if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
     if (!c->wstats.p) return RFS_OK;

@@ -1116,14 +1116,35 @@ struct SwdWarm {
     double* ferr;
 };
 
-template <class F, bool SPH>
+// Searches a round of k_swd_warm did not finish within its budget of evaluations: [field][slot], slot = position in the round's
+// list.  A wavefront executes what its SLOWEST lane needs, and the searches are very uneven -- 2 evaluations where the Newton start
+// brackets the root at once (most items), 3-6 through a bracket, 20-60 through a widened bracket and bisection (a few per
+// thousand): measured on the bench's chains, 2.56 evaluations per lane but 7.98 executed per lane.  So the search runs in ROUNDS:
+// every lane gets a budget; what is unfinished then is written out densely (wavefront-aggregated slots) and the next round picks
+// it up 64 unfinished searches to a wavefront.  A lane's sequence of evaluations does not depend on who shares its wavefront:
+// the results are the single-round kernel's bit for bit.
+struct WarmSpill {
+    double* d;                    // [WARM_SPILL_ND][cap]
+    unsigned long long* bits;     // [cap] the machine's small integers, packed
+    unsigned long long* item;     // [cap] the lane's global item index (~0: not a slot)
+    int* count;                   // slots handed out (may exceed cap: the lanes beyond finish in place)
+    int cap;
+};
+constexpr int WARM_SPILL_ND = 17;
+
+template <class F, bool SPH, bool FIRST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))          // (round 5's bisection / wide-bracket paths took it to 171 VGPRs: three wavefronts per SIMD end at 168)
 k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const double* __restrict__ sph,
-           const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot, double* __restrict__ croot, SwdWarm W)
+           const double* __restrict__ krn, const double* __restrict__ ugr, size_t ntot, double* __restrict__ croot, SwdWarm W,
+           WarmSpill in, WarmSpill out, int budget, int round)
 {
-    const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const int nin = FIRST ? 0 : min(*in.count, in.cap);
+  for (size_t base = (size_t)blockIdx.x * 64; FIRST ? base == (size_t)blockIdx.x * 64 : base < (size_t)nin; base += (size_t)gridDim.x * 64) {
+    const size_t slot = base + threadIdx.x;
+    size_t g = slot;
     // (no lane leaves before the wavefront's statistics at the end: `live` instead of early returns)
-    bool live = g < (size_t)Q.nper_total * nchain;
+    bool live = FIRST ? g < (size_t)Q.nper_total * nchain : slot < (size_t)nin;
+    if (!FIRST) { g = live ? (size_t)in.item[slot] : 0; live = live && g != ~0ull; if (!live) g = 0; }
     const int el = live ? (int)(g / nchain) : 0, chain = live ? (int)(g - (size_t)el * nchain) : 0;
     const int e = Q.s[0].croot_off + el;
     int seq = 0;
@@ -1139,33 +1160,59 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
             atomicAdd(&W.stats[cause], 1ull);
         }
     };
-    // a chain whose search of the step before ran in the background: nothing to do here, and nothing for the branch test
-    // or the reference-root stage either (they skip chains with a flag)
-    if (live && W.pend && W.pend[chain]) { W.need[chain] = 2; live = false; }
-    if (live && W.f_rem && !W.f_fresh[chain] && (W.f_rem[chain] <= 0 || !W.f_ok[chain])) { W.need[chain] = 2; live = false; }    // idle
-    if (live) W.sgn[(size_t)e * nchain + chain] = 2;
-    if (live && (!W.valid[chain] || (W.force && W.force[chain]))) { decline(4); live = false; }
-    // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
-    // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
-    // vtp / dtp / rtp as swd_kernel_value does
-    const double* kr0 = krn + (size_t)e * 4 * s + chain;
-    const double ksc = ugr[ntot + (size_t)e * nchain + chain], kfac = ugr[2 * ntot + (size_t)e * nchain + chain];    // swd_krn's scales
-    double dc = 0.0, l1 = 0.0, suf = 0.0;
+    WarmSearch ws;
+    double cprev = 0.0, dc = 0.0, l1 = 0.0, fb = 0.0;
     float betmx = -1.e20f;
-    for (int m = n - 1; m >= 0; m--) {
-        const size_t lm = (size_t)m * nchain;
-        // (chain-ruled storage: slot 0 = d c / d vs of the previous model, its flattening factors inside; slot 1 = the interface partial)
-        const double gv = kr0[lm] * ksc;
-        double kh = kr0[s + lm] * kfac;
-        if (fabs(kh) < 1.0e-38) kh = 0.0;
-        if (SPH) kh *= sph[5 * s + lm + chain];
-        const double t1 = gv * W.dxT[lm + chain], t2 = suf * W.dxT[s + lm + chain];
-        dc += t1 + t2; l1 += fabs(t1) + fabs(t2);
-        suf += kh;
-        betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);
+    bool refused = false;
+    int nev_first = 0, attempt = 0;
+    if (FIRST) {
+        // a chain whose search of the step before ran in the background: nothing to do here, and nothing for the branch test
+        // or the reference-root stage either (they skip chains with a flag)
+        if (live && W.pend && W.pend[chain]) { W.need[chain] = 2; live = false; }
+        if (live && W.f_rem && !W.f_fresh[chain] && (W.f_rem[chain] <= 0 || !W.f_ok[chain])) { W.need[chain] = 2; live = false; }    // idle
+        if (live) W.sgn[(size_t)e * nchain + chain] = 2;
+        if (live && (!W.valid[chain] || (W.force && W.force[chain]))) { decline(4); live = false; }
+        // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
+        // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
+        // vtp / dtp / rtp as swd_kernel_value does
+        const double* kr0 = krn + (size_t)e * 4 * s + chain;
+        const double ksc = ugr[ntot + (size_t)e * nchain + chain], kfac = ugr[2 * ntot + (size_t)e * nchain + chain];    // swd_krn's scales
+        double suf = 0.0;
+        for (int m = n - 1; m >= 0; m--) {
+            const size_t lm = (size_t)m * nchain;
+            // (chain-ruled storage: slot 0 = d c / d vs of the previous model, its flattening factors inside; slot 1 = the interface partial)
+            const double gv = kr0[lm] * ksc;
+            double kh = kr0[s + lm] * kfac;
+            if (fabs(kh) < 1.0e-38) kh = 0.0;
+            if (SPH) kh *= sph[5 * s + lm + chain];
+            const double t1 = gv * W.dxT[lm + chain], t2 = suf * W.dxT[s + lm + chain];
+            dc += t1 + t2; l1 += fabs(t1) + fabs(t2);
+            suf += kh;
+            betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);
+        }
+        cprev = croot[(size_t)e * nchain + chain];
+        if (live && k == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
+        // (a correction larger than the first-order terms themselves is not a second-order term: ignored)
+        fb = (W.ferr && live) ? W.ferr[(size_t)e * nchain + chain] : 0.0;
+        if (!(fabs(fb) <= l1)) fb = 0.0;
+        ws.begin(cprev, dc + fb, l1, W.slope[(size_t)e * nchain + chain]);
+        if (W.widen && cprev > 0.0 && (!(dc == dc) || !(l1 <= WARM_L1WIDE))) ws.begin_wide(cprev);
+        else if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
+        if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
+        if (live && !(l1 <= WARM_L1MAX) && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
+        refused = !ws.active();
+    } else {
+        const size_t sl = live ? slot : 0, cp = (size_t)in.cap;
+        const double* D = in.d + sl;
+        ws.cpred = D[0]; ws.eps = D[cp]; ws.R = D[2 * cp]; ws.a = D[3 * cp]; ws.fa = D[4 * cp]; ws.b = D[5 * cp]; ws.fb = D[6 * cp];
+        ws.creq = D[7 * cp]; ws.root = D[8 * cp]; ws.slope = D[9 * cp]; ws.f0 = D[10 * cp]; ws.mlast = D[11 * cp];
+        cprev = D[12 * cp]; dc = D[13 * cp]; l1 = D[14 * cp]; fb = D[15 * cp]; betmx = (float)D[16 * cp];
+        const unsigned long long bt = in.bits[sl];
+        ws.phase = (int)(bt & 7); ws.it = (int)((bt >> 3) & 127); ws.side = (int)((bt >> 10) & 1); ws.second = (int)((bt >> 11) & 1);
+        ws.lastside = (int)((bt >> 12) & 3) - 1; ws.ntry = (int)((bt >> 14) & 3); attempt = (int)((bt >> 16) & 1);
+        ws.nev = (int)((bt >> 20) & 4095); nev_first = (int)((bt >> 32) & 4095);
+        if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
     }
-    const double cprev = croot[(size_t)e * nchain + chain];
-    if (live && k == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
     const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
     const double* lc0 = mdlc + chain;
     auto loadL = [&](int m) {
@@ -1173,32 +1220,55 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
                          o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
     };
-    WarmSearch ws;
-    // (a correction larger than the first-order terms themselves is not a second-order term: ignored)
-    double fb = (W.ferr && live) ? W.ferr[(size_t)e * nchain + chain] : 0.0;
-    if (!(fabs(fb) <= l1)) fb = 0.0;
-    ws.begin(cprev, dc + fb, l1, W.slope[(size_t)e * nchain + chain]);
-    if (W.widen && cprev > 0.0 && (!(dc == dc) || !(l1 <= WARM_L1WIDE))) ws.begin_wide(cprev);
-    else if (!(dc == dc) || !(l1 == l1)) ws.phase = WarmSearch::W_FAIL;
-    if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
-    if (live && !(l1 <= WARM_L1MAX) && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
-    const bool refused = !ws.active();
-    int nev_first = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        while (__any(ws.active())) {
-            if (ws.active()) ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq), W.widen != 0);
+    int used = 0, left = budget;
+    bool spilled = false;
+    for (;;) {
+        while (__any(ws.active() && left > 0)) {
+            if (ws.active() && left > 0) {
+                ws.advance(swd_secular_family<F>(n, loadL, omega, ws.creq), W.widen != 0);
+                used++; left--;
+                // a search that failed from a corrected prediction starts over from the plain first-order one (the correction is a
+                // guess: where the trajectory has just turned, or next to another mode, it points the wrong way)
+                if (attempt == 0 && live && !refused && fb != 0.0 && ws.phase == WarmSearch::W_FAIL) {
+                    nev_first = ws.nev; fb = 0.0; attempt = 1; ws.begin(cprev, dc, l1, 0.0);
+                }
+            }
         }
-        // a search that failed from a corrected prediction starts over from the plain first-order one (the correction is a
-        // guess: where the trajectory has just turned, or next to another mode, it points the wrong way)
-        const bool again = attempt == 0 && live && !refused && fb != 0.0 && ws.phase == WarmSearch::W_FAIL;
-        if (!__any(again)) break;
-        if (again) { nev_first = ws.nev; fb = 0.0; ws.begin(cprev, dc, l1, 0.0); }
+        // out of budget: the unfinished searches of this wavefront go to the next round, densely
+        const bool unfinished = ws.active();
+        const unsigned long long um = __ballot(unfinished);
+        if (um == 0ull) break;
+        int sbase = 0;
+        const int nun = __popcll(um);
+        if ((threadIdx.x & 63) == 0) sbase = atomicAdd(out.count, nun);
+        sbase = __shfl(sbase, 0, 64);
+        if (sbase + nun > out.cap) {
+            // no room: the slots handed out stay empty, the searches finish here
+            if (unfinished) { const int sl = sbase + __popcll(um & ((1ull << (threadIdx.x & 63)) - 1ull)); if (sl < out.cap) out.item[sl] = ~0ull; }
+            left = 0x7fffffff;
+            continue;
+        }
+        if (unfinished) {
+            const size_t sl = (size_t)sbase + __popcll(um & ((1ull << (threadIdx.x & 63)) - 1ull)), cp = (size_t)out.cap;
+            double* D = out.d + sl;
+            D[0] = ws.cpred; D[cp] = ws.eps; D[2 * cp] = ws.R; D[3 * cp] = ws.a; D[4 * cp] = ws.fa; D[5 * cp] = ws.b; D[6 * cp] = ws.fb;
+            D[7 * cp] = ws.creq; D[8 * cp] = ws.root; D[9 * cp] = ws.slope; D[10 * cp] = ws.f0; D[11 * cp] = ws.mlast;
+            D[12 * cp] = cprev; D[13 * cp] = dc; D[14 * cp] = l1; D[15 * cp] = fb; D[16 * cp] = (double)betmx;
+            out.bits[sl] = (unsigned long long)(ws.phase & 7) | ((unsigned long long)(ws.it & 127) << 3) | ((unsigned long long)(ws.side & 1) << 10) |
+                           ((unsigned long long)(ws.second & 1) << 11) | ((unsigned long long)((ws.lastside + 1) & 3) << 12) |
+                           ((unsigned long long)(ws.ntry & 3) << 14) | ((unsigned long long)(attempt & 1) << 16) |
+                           ((unsigned long long)(ws.nev & 4095) << 20) | ((unsigned long long)(nev_first & 4095) << 32);
+            out.item[sl] = (unsigned long long)g;
+            spilled = true;
+        }
+        break;
     }
+    const bool fin = live && !spilled;
     ws.nev += nev_first;
-    const bool ok = live && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
+    const bool ok = fin && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
     // a root found beyond the trust radius: the grid walk has the word (statistic 13 counts the chains, as for large moves)
     if (ok && ws.wide() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
-    if (!live) {}
+    if (!fin) {}
     else if (ok) {
         croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
         if (W.cwarm) W.cwarm[(size_t)e * nchain + chain] = (double)(float)ws.root;
@@ -1208,16 +1278,27 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         // (diagnostics: why a search failed -- 24: no sign change out to the widest bracket, 25: anything else)
         if (!refused && ws.phase != WarmSearch::W_DONE) atomicAdd(&W.stats[ws.eps >= fmin(WARM_RWIDE * ws.R, fmax(ws.R, WARM_RWIDE_ABS)) ? 24 : 25], 1ull);
     }
-    if (live) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
-    if (live && W.ferr) {
+    if (fin) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
+    if (fin && W.ferr) {
         // a trajectory that starts with this step has not moved (and its next move has a new momentum): nothing to carry over
         const bool fresh = W.f_fresh && W.f_fresh[chain];
         W.ferr[(size_t)e * nchain + chain] = (ok && !fresh && dc == dc) ? ws.root - (cprev + dc) : 0.0;
     }
-    int nev = live ? ws.nev : 0, nok = ok ? 1 : 0;
+    int nev = fin ? ws.nev : 0, nok = ok ? 1 : 0, nmax = used, nlive = fin ? 1 : 0, nsp = spilled ? 1 : 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&W.stats[1], (unsigned long long)nev); atomicAdd(&W.stats[2], (unsigned long long)nok); }
+    for (int off = 32; off >= 1; off >>= 1) {
+        nev += __shfl_xor(nev, off, 64); nok += __shfl_xor(nok, off, 64);
+        nmax = max(nmax, __shfl_xor(nmax, off, 64)); nlive += __shfl_xor(nlive, off, 64); nsp += __shfl_xor(nsp, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&W.stats[1], (unsigned long long)nev); atomicAdd(&W.stats[2], (unsigned long long)nok);
+        // divergence of the search: evaluations of the lanes that finished here (26), of this wavefront's slowest lane in this
+        // round (27: what the wavefront executes is 64 x this), lanes that searched (28), searches passed on by round 1 / 2 / 3 (29-31)
+        atomicAdd(&W.stats[26], (unsigned long long)nev); atomicAdd(&W.stats[27], (unsigned long long)nmax);
+        atomicAdd(&W.stats[28], (unsigned long long)nlive);
+        if (nsp && round >= 0 && round < 3) atomicAdd(&W.stats[29 + round], (unsigned long long)nsp);
+    }
+  }
 }
 
 // The branch test of the warm start (WarmSearch, swd_math.hpp): one secular evaluation per item at the point the

@@ -525,6 +525,43 @@ def test_wide_brackets_and_skipped_idle_chains_sample_the_same():
     assert same.mean() >= 0.995 and relx <= 1e-6 and relm <= 1e-5
 
 
+def test_warm_search_in_rounds_is_the_one_round_search_bit_for_bit():
+    """Round 5: k_swd_warm runs in rounds -- a budget of evaluations per lane, the unfinished searches packed densely for the
+    next round ("swd_warm_round_budgets": a wavefront executes what its slowest lane needs, and the searches are very uneven).
+    Which wavefront a search finishes in changes none of its evaluations: the same seeded sampler run from burned-in models
+    in one round, in the default three and in four rounds with tiny budgets gives identical samples, misfits and counters."""
+    import bench
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    n, nc = 30, 1024
+    joint, t = _bench_joint(1)
+    bounds = bench.bounds_of(bench.true_model(n))
+    ctx = joint._ensure(n)
+    keep = {}
+    s0 = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 40, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+    s0.sample_flow(x_init=bench.make_models(nc, 4, n), max_steps=121,
+                   step_hook=lambda s, st: keep.__setitem__("x", st["x"].clone()) if s == 120 else None)
+    xb = keep["x"].cpu().numpy()
+    runs = {}
+    try:
+        for budgets in (0, 302, 10101):
+            ctx.set_option("swd_warm_round_budgets", budgets)
+            names = ("swd_warm_declined_chains", "swd_warm_secular_evals", "swd_warm_items", "swd_exact_secular_evals")
+            c0 = [ctx.stat(k) for k in names]
+            p1 = ctx.stat("swd_warm_passed_on_1")
+            s = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+            mis = s.sample_flow(x_init=xb, max_steps=100, async_handback=False)
+            runs[budgets] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
+                             [ctx.stat(k) - v for k, v in zip(names, c0)], ctx.stat("swd_warm_passed_on_1") - p1)
+    finally:
+        ctx.set_option("swd_warm_round_budgets", 302)
+    ref = runs[0]
+    assert ref[5] == 0 and runs[302][5] > 0 and runs[10101][5] > runs[302][5]         # (the rounds did take place)
+    for budgets in (302, 10101):
+        r = runs[budgets]
+        assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), budgets
+        assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]) and r[4] == ref[4], (budgets, r[4], ref[4])
+
+
 def test_two_flow_states_in_turn_on_one_context():
     """The warm start belongs to the state whose x array the previous flow call advanced: two states stepped in turn on one
     context start over from the full search at every call (nothing of the other state is continued) and get exactly the
