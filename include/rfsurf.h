@@ -352,6 +352,20 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          changes (the roots are the same sign changes); 0.6 evaluations per item less and a third fewer
  *                          hand-backs (39 -> 29 chains per step at 8192 chains: the second attempt also rescues searches that
  *                          failed before).  0 = off.
+ *   "swd_warm_round_budgets"  303 (default) = b1 + 100 b2 + 10000 b3: the warm search runs in ROUNDS.  A wavefront executes what its
+ *                          slowest lane needs, and the searches are very uneven (2 evaluations where the Newton start brackets
+ *                          the root at once, 3-6 through a bracket, 20-60 through a widened bracket and bisection: 2.56
+ *                          evaluations per lane, 7.98 executed per lane in one round).  Every lane gets b1 evaluations; the
+ *                          searches that are unfinished then are packed densely into a list and get b2 more in a second launch
+ *                          (b3: a third), and a last round without a limit finishes the rest.  A lane's sequence of
+ *                          evaluations does not depend on who shares its wavefront: results are bit for bit those of one
+ *                          round (0).  5.06 -> 4.95 ms per step at 8192 chains with (2, 3); with the cooperative last round
+ *                          and (3, 3): 4.62.
+ *   "swd_warm_last_round_coop"  1 (default): the last round -- a few per cent of the items, and the stage ends with its slowest
+ *                          search -- with 16 lanes per search: each lane builds the layer entries of every 16th layer, every
+ *                          lane runs the short vector recurrence (the arithmetic of the single lane's evaluation, operation for
+ *                          operation: same roots bit for bit, a third of the time per evaluation).  Models of up to 65 layers;
+ *                          0 or deeper models: one lane per search.
  *   "flow_skip_idle"       1 (default): in the flow entries a chain that is idle in a step -- waiting for the caller after a
  *                          trajectory, or failed -- is neither continued nor handed back (nothing reads its evaluation, and a
  *                          failed chain would go to the full search at every step it waits).  0: round 4's behaviour.
@@ -417,6 +431,7 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *                               fastest layer, 6 NaN, 7 the run-up left the origin short of "swd_exact_origin_tol_e9"
  *   "swd_warm_fail_no_change" / "swd_warm_fail_other"   (period, chain) items whose warm search failed: no sign change out to
  *                               the widest bracket / anything else
+ *   "swd_warm_passed_on_<r>"    searches round r = 1, 2, 3 of the warm search passed on to the next round
  *   "swd_warm_search_evals" / "swd_warm_search_evals_slowest_lane" / "swd_warm_search_lanes"   divergence of the warm search
  *                               (k_swd_warm): evaluations of all lanes, of each wavefront's slowest lane (x 64 = what the
  *                               wavefronts execute), lanes that searched

@@ -101,7 +101,8 @@ struct rfs_ctx {
     bool last_async = false;   // ... and did (a warm-started step with a side stream)
     int fpend_nchain = 0;
     const double* flow_x = nullptr;   // the state a flow step last advanced (its x array): what the warm start and `fpend` describe
-    int warm_budgets = 302;      // option "swd_warm_round_budgets": evaluations a lane may spend in round 1 / 2 / 3 of k_swd_warm (b1 + 100 b2 + 10000 b3; the last round has no limit); 0: one round
+    bool warm_coop = true;       // option "swd_warm_last_round_coop": 16 lanes per search in the last round of k_swd_warm (k_swd_warm_coop)
+    int warm_budgets = 303;      // option "swd_warm_round_budgets": evaluations a lane may spend in round 1 / 2 / 3 of k_swd_warm (b1 + 100 b2 + 10000 b3; the last round has no limit); 0: one round
     bool warm_feedback = true;   // option "swd_warm_feedback": last step's prediction error corrects this step's prediction (SwdWarm::ferr)
     Buf wferr;
     bool warm_widen = true;    // option "swd_warm_widen": the warm search may bracket beyond its trust radius (the grid walk then vouches)
@@ -841,6 +842,15 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         hipLaunchKernelGGL((k_swd_warm<FAM, SPHB, FIRSTB>), GRID, dim3(64), 0, s, nchain, n, QQ, MDLC, SPHP,             \
                            c->krn.as<double>(), c->ugr.as<double>(), (size_t)P.nitems * nchain, c->croot.as<double>(), W, \
                            IN, OUT, BUD, RND)
+        // the last round with 16 lanes per search (k_swd_warm_coop): its grid strides as well -- 4 searches per wavefront
+        const bool coop_last = rounds && c->warm_coop && n >= 3 && n - 1 <= 64;
+#define RFS_LAUNCH_WARMC(FAM, QQ, MDLC, IN)                                                                            \
+        do {                                                                                                          \
+            const size_t ldsb = (size_t)4 * ((size_t)(n - 1) * FAM::NENT + FAM::NV) * sizeof(double);                 \
+            const unsigned gc = (unsigned)std::min<size_t>(((size_t)(QQ).nper_total * nchain + 3) / 4, (size_t)8192); \
+            hipLaunchKernelGGL((k_swd_warm_coop<FAM>), dim3(std::max(64u, gc)), dim3(64), ldsb, s, nchain, n, QQ, MDLC, \
+                               c->croot.as<double>(), W, IN);                                                         \
+        } while (0)
 #define RFS_LAUNCH_WARM(FAM, QQ, MDLC, SPHP)                                                                          \
         do {                                                                                                          \
             const size_t nit = (size_t)(QQ).nper_total * nchain;                                                      \
@@ -860,17 +870,20 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                 RFS_LAUNCH_WARM1(FAM, true, true, grid, QQ, MDLC, sp_, none, A0, wb1, 0);                             \
                 if (wb2 > 0) RFS_LAUNCH_WARM1(FAM, true, false, g2, QQ, MDLC, sp_, A0, B1, wb2, 1);                    \
                 if (wb2 > 0 && wb3 > 0) RFS_LAUNCH_WARM1(FAM, true, false, g3, QQ, MDLC, sp_, B1, A2, wb3, 2);         \
-                RFS_LAUNCH_WARM1(FAM, true, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
+                if (coop_last) RFS_LAUNCH_WARMC(FAM, QQ, MDLC, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0));                             \
+                else RFS_LAUNCH_WARM1(FAM, true, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
             } else {                                                                                                  \
                 RFS_LAUNCH_WARM1(FAM, false, true, grid, QQ, MDLC, sp_, none, A0, wb1, 0);                            \
                 if (wb2 > 0) RFS_LAUNCH_WARM1(FAM, false, false, g2, QQ, MDLC, sp_, A0, B1, wb2, 1);                   \
                 if (wb2 > 0 && wb3 > 0) RFS_LAUNCH_WARM1(FAM, false, false, g3, QQ, MDLC, sp_, B1, A2, wb3, 2);        \
-                RFS_LAUNCH_WARM1(FAM, false, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
+                if (coop_last) RFS_LAUNCH_WARMC(FAM, QQ, MDLC, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0));                             \
+                else RFS_LAUNCH_WARM1(FAM, false, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
             }                                                                                                         \
         } while (0)
         if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
         if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
 #undef RFS_LAUNCH_WARM1
+#undef RFS_LAUNCH_WARMC
 #undef RFS_LAUNCH_WARM
         HIPCHK(c, hipGetLastError());
         // The hand-back lists are nearly always empty, and when one is not, the full search of even ONE chain takes ~3 ms
@@ -1735,6 +1748,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_warm_serial")) { c->warm_serial = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_widen")) { c->warm_widen = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_feedback")) { c->warm_feedback = value != 0; return RFS_OK; }
+    if (!strcmp(name, "swd_warm_last_round_coop")) { c->warm_coop = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_round_budgets")) {
         if (value < 0 || value > 999999) return fail(c, RFS_ERR_ARG, "swd_warm_round_budgets must be b1 + 100 b2 + 10000 b3 with 0 <= b < 100");
         c->warm_budgets = (int)value; return RFS_OK;

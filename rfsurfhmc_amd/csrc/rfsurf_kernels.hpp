@@ -1132,6 +1132,54 @@ struct WarmSpill {
 };
 constexpr int WARM_SPILL_ND = 17;
 
+// What a finished warm search leaves behind (k_swd_warm, k_swd_warm_coop): the root rounded to float32 like the reference's, the
+// sign below it for the branch test, its slope and the predictor's miss for the next step -- or the chain on the hand-back list.
+// cause: 4 no usable previous evaluation / forced, 5 step too large for a first-order model, 6 no sign change inside the trust
+// radius or no convergence, 7 root above the fastest layer  (statistics only)
+__device__ __forceinline__ void swd_warm_decline(const SwdWarm& W, int chain, int cause) {
+    if (atomicExch(&W.need[chain], 1) == 0) {
+        W.list[atomicAdd(W.count, 1)] = chain;
+        atomicAdd(&W.stats[0], 1ull);
+        atomicAdd(&W.stats[cause], 1ull);
+    }
+}
+__device__ __forceinline__ bool swd_warm_finish(const WarmSearch& ws, bool fin, bool refused, float betmx, int e, int chain, int nchain,
+                                                double cprev, double dc, double* __restrict__ croot, const SwdWarm& W) {
+    const bool ok = fin && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
+    // a root found beyond the trust radius: the grid walk has the word (statistic 13 counts the chains, as for large moves)
+    if (ok && ws.wide() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
+    if (!fin) {}
+    else if (ok) {
+        croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
+        if (W.cwarm) W.cwarm[(size_t)e * nchain + chain] = (double)(float)ws.root;
+        W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
+    } else {
+        swd_warm_decline(W, chain, refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
+        // (diagnostics: why a search failed -- 24: no sign change out to the widest bracket, 25: anything else)
+        if (!refused && ws.phase != WarmSearch::W_DONE) atomicAdd(&W.stats[ws.eps >= fmin(WARM_RWIDE * ws.R, fmax(ws.R, WARM_RWIDE_ABS)) ? 24 : 25], 1ull);
+    }
+    if (fin) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
+    if (fin && W.ferr) {
+        // a trajectory that starts with this step has not moved (and its next move has a new momentum): nothing to carry over
+        const bool fresh = W.f_fresh && W.f_fresh[chain];
+        W.ferr[(size_t)e * nchain + chain] = (ok && !fresh && dc == dc) ? ws.root - (cprev + dc) : 0.0;
+    }
+    return ok;
+}
+// a search's state out of / into a WarmSpill slot
+__device__ __forceinline__ void swd_warm_load(const WarmSpill& in, size_t sl, WarmSearch& ws, double& cprev, double& dc, double& l1, double& fb,
+                                              float& betmx, int& attempt, int& nev_first) {
+    const size_t cp = (size_t)in.cap;
+    const double* D = in.d + sl;
+    ws.cpred = D[0]; ws.eps = D[cp]; ws.R = D[2 * cp]; ws.a = D[3 * cp]; ws.fa = D[4 * cp]; ws.b = D[5 * cp]; ws.fb = D[6 * cp];
+    ws.creq = D[7 * cp]; ws.root = D[8 * cp]; ws.slope = D[9 * cp]; ws.f0 = D[10 * cp]; ws.mlast = D[11 * cp];
+    cprev = D[12 * cp]; dc = D[13 * cp]; l1 = D[14 * cp]; fb = D[15 * cp]; betmx = (float)D[16 * cp];
+    const unsigned long long bt = in.bits[sl];
+    ws.phase = (int)(bt & 7); ws.it = (int)((bt >> 3) & 127); ws.side = (int)((bt >> 10) & 1); ws.second = (int)((bt >> 11) & 1);
+    ws.lastside = (int)((bt >> 12) & 3) - 1; ws.ntry = (int)((bt >> 14) & 3); attempt = (int)((bt >> 16) & 1);
+    ws.nev = (int)((bt >> 20) & 4095); nev_first = (int)((bt >> 32) & 4095);
+}
+
 template <class F, bool SPH, bool FIRST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))          // (round 5's bisection / wide-bracket paths took it to 171 VGPRs: three wavefronts per SIMD end at 168)
 k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const double* __restrict__ sph,
@@ -1151,15 +1199,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
     const int k = e - Q.s[seq].croot_off;
     const size_t s = (size_t)n * nchain;
-    // cause: 4 no usable previous evaluation / forced, 5 step too large for a first-order model, 6 no sign change inside
-    // the trust radius or no convergence, 7 root above the fastest layer  (statistics only)
-    auto decline = [&](int cause) {
-        if (atomicExch(&W.need[chain], 1) == 0) {
-            W.list[atomicAdd(W.count, 1)] = chain;
-            atomicAdd(&W.stats[0], 1ull);
-            atomicAdd(&W.stats[cause], 1ull);
-        }
-    };
+    auto decline = [&](int cause) { swd_warm_decline(W, chain, cause); };
     WarmSearch ws;
     double cprev = 0.0, dc = 0.0, l1 = 0.0, fb = 0.0;
     float betmx = -1.e20f;
@@ -1202,15 +1242,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (live && !(l1 <= WARM_L1MAX) && ws.active() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
         refused = !ws.active();
     } else {
-        const size_t sl = live ? slot : 0, cp = (size_t)in.cap;
-        const double* D = in.d + sl;
-        ws.cpred = D[0]; ws.eps = D[cp]; ws.R = D[2 * cp]; ws.a = D[3 * cp]; ws.fa = D[4 * cp]; ws.b = D[5 * cp]; ws.fb = D[6 * cp];
-        ws.creq = D[7 * cp]; ws.root = D[8 * cp]; ws.slope = D[9 * cp]; ws.f0 = D[10 * cp]; ws.mlast = D[11 * cp];
-        cprev = D[12 * cp]; dc = D[13 * cp]; l1 = D[14 * cp]; fb = D[15 * cp]; betmx = (float)D[16 * cp];
-        const unsigned long long bt = in.bits[sl];
-        ws.phase = (int)(bt & 7); ws.it = (int)((bt >> 3) & 127); ws.side = (int)((bt >> 10) & 1); ws.second = (int)((bt >> 11) & 1);
-        ws.lastside = (int)((bt >> 12) & 3) - 1; ws.ntry = (int)((bt >> 14) & 3); attempt = (int)((bt >> 16) & 1);
-        ws.nev = (int)((bt >> 20) & 4095); nev_first = (int)((bt >> 32) & 4095);
+        swd_warm_load(in, live ? slot : 0, ws, cprev, dc, l1, fb, betmx, attempt, nev_first);
         if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
     }
     const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
@@ -1265,25 +1297,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
     }
     const bool fin = live && !spilled;
     ws.nev += nev_first;
-    const bool ok = fin && ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);      // getsol :483-485
-    // a root found beyond the trust radius: the grid walk has the word (statistic 13 counts the chains, as for large moves)
-    if (ok && ws.wide() && atomicExch(&W.wide[chain], 1) == 0) atomicAdd(&W.stats[13], 1ull);
-    if (!fin) {}
-    else if (ok) {
-        croot[(size_t)e * nchain + chain] = (double)(float)ws.root;                    // surfdisp96.f:302
-        if (W.cwarm) W.cwarm[(size_t)e * nchain + chain] = (double)(float)ws.root;
-        W.sgn[(size_t)e * nchain + chain] = signbit(ws.fa) ? 1 : 0;                    // (a, fa): the bracket's lower end
-    } else {
-        decline(refused ? 5 : (ws.phase == WarmSearch::W_DONE ? 7 : 6));
-        // (diagnostics: why a search failed -- 24: no sign change out to the widest bracket, 25: anything else)
-        if (!refused && ws.phase != WarmSearch::W_DONE) atomicAdd(&W.stats[ws.eps >= fmin(WARM_RWIDE * ws.R, fmax(ws.R, WARM_RWIDE_ABS)) ? 24 : 25], 1ull);
-    }
-    if (fin) W.slope[(size_t)e * nchain + chain] = ok ? ws.slope : 0.0;
-    if (fin && W.ferr) {
-        // a trajectory that starts with this step has not moved (and its next move has a new momentum): nothing to carry over
-        const bool fresh = W.f_fresh && W.f_fresh[chain];
-        W.ferr[(size_t)e * nchain + chain] = (ok && !fresh && dc == dc) ? ws.root - (cprev + dc) : 0.0;
-    }
+    const bool ok = swd_warm_finish(ws, fin, refused, betmx, e, chain, nchain, cprev, dc, croot, W);
     int nev = fin ? ws.nev : 0, nok = ok ? 1 : 0, nmax = used, nlive = fin ? 1 : 0, nsp = spilled ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -1299,6 +1313,112 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (nsp && round >= 0 && round < 3) atomicAdd(&W.stats[29 + round], (unsigned long long)nsp);
     }
   }
+}
+
+// The LAST round of the warm search (what two budgets have not finished: a few per cent of the items, with 5 to 60 evaluations
+// still to go -- and the stage ends with its slowest search): G = 16 lanes per search.  Every lane of a group runs the same
+// machine on the same numbers (identical inputs -> identical states, as in k_swd_roots_split); per evaluation lane j builds the
+// vector-independent numbers of layers j, j + 16, ... into LDS, then every lane runs the short vector recurrence over them.
+// The arithmetic is swd_secular_family's operation for operation (that function IS this evaluation done by one lane), so the
+// roots are the single-lane search's bit for bit -- in a third of the time per evaluation.  n - 1 <= 64 layers.
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_warm_coop(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, WarmSpill in)
+{
+    constexpr int G = 16, NG = 64 / G, LPL = 4, NENT = F::NENT, NV = F::NV;
+    extern __shared__ double coop_lds[];         // per group: entries [m][NENT], then the half-space vector [NV]
+    const int lane = threadIdx.x & 63, grp = lane / G, lg = lane - grp * G;
+    double* const ent_g = coop_lds + (size_t)grp * ((size_t)(n - 1) * NENT + NV);
+    double* const hs_g = ent_g + (size_t)(n - 1) * NENT;
+    const int nin = min(*in.count, in.cap);
+    for (int blk = blockIdx.x; blk * NG < nin; blk += gridDim.x) {
+        const int slot = blk * NG + grp;
+        bool live = slot < nin;
+        size_t g = live ? (size_t)in.item[slot] : 0;
+        live = live && g != ~0ull;
+        if (!live) g = 0;
+        const int el = (int)(g / nchain), chain = (int)(g - (size_t)el * nchain);
+        const int e = Q.s[0].croot_off + el;
+        int seq = 0;
+        while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
+        const int k = e - Q.s[seq].croot_off;
+        WarmSearch ws;
+        double cprev = 0.0, dc = 0.0, l1 = 0.0, fb = 0.0;
+        float betmx = -1.e20f;
+        int nev_first = 0, attempt = 0;
+        swd_warm_load(in, live ? (size_t)slot : 0, ws, cprev, dc, l1, fb, betmx, attempt, nev_first);
+        if (!live) { ws.phase = WarmSearch::W_FAIL; ws.nev = 0; }
+        const double omega_raw = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
+        const double omega = omega_raw < 1.0e-4 ? 1.0e-4 : omega_raw, iomega = 1.0 / omega;
+        const double* lc0 = mdlc + chain;
+        auto loadL = [&](int m) {
+            const double* o = lc0 + (size_t)m * 6 * nchain;
+            return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                             o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+        };
+        const SwdLayerC Lhalf = loadL(n - 1);
+        SwdLayerC Lmine[LPL];                    // this lane's layers lg, lg + G, ... stay in registers
+#pragma unroll
+        for (int q = 0; q < LPL; q++) { const int m = lg + q * G; Lmine[q] = loadL(m < n - 1 ? m : n - 2); }
+        int used = 0;
+        while (__any(ws.active())) {
+            const bool act = ws.active();
+            const double wvno = omega_raw / ws.creq, wvno2 = wvno * wvno, tt = -2.0 * wvno2;
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < LPL; q++) {
+                    const int m = lg + q * G;
+                    if (m < n - 1) {
+                        double ent[NENT];
+                        F::entries(Lmine[q], wvno, wvno2, omega, iomega, ent);
+#pragma unroll
+                        for (int i = 0; i < NENT; i++) ent_g[m * NENT + i] = ent[i];
+                    }
+                }
+                if (lg == G - 1) {
+                    double eh[NV];
+                    F::halfspace(Lhalf, wvno, wvno2, omega, iomega, eh);
+#pragma unroll
+                    for (int j = 0; j < NV; j++) hs_g[j] = eh[j];
+                }
+            }
+            __syncthreads();
+            double delta = 0.0;
+            if (act) {
+                double ev[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) ev[j] = hs_g[j];
+                const double* pe = ent_g + (size_t)(n - 2) * NENT;
+                for (int m = n - 2; m >= 0; m--, pe -= NENT) {
+                    double cur[NENT];
+#pragma unroll
+                    for (int i = 0; i < NENT; i++) cur[i] = pe[i];
+                    F::apply(ev, cur, tt);
+                    if ((m & 7) == 0) swd_rescale_pow2_n<NV>(ev);
+                }
+                delta = swd_finish_n<NV>(ev);
+            }
+            __syncthreads();
+            if (act) {
+                ws.advance(delta, W.widen != 0);
+                used++;
+                if (attempt == 0 && live && fb != 0.0 && ws.phase == WarmSearch::W_FAIL) {
+                    nev_first = ws.nev; fb = 0.0; attempt = 1; ws.begin(cprev, dc, l1, 0.0);
+                }
+            }
+        }
+        const bool fin = live && lg == 0;            // one lane of the group writes
+        ws.nev += nev_first;
+        const bool ok = swd_warm_finish(ws, fin, false, betmx, e, chain, nchain, cprev, dc, croot, W);
+        if (fin) {
+            atomicAdd(&W.stats[1], (unsigned long long)ws.nev); atomicAdd(&W.stats[2], ok ? 1ull : 0ull);
+            atomicAdd(&W.stats[26], (unsigned long long)ws.nev); atomicAdd(&W.stats[28], 1ull);
+        }
+        int nmax = used;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+        if (lane == 0) atomicAdd(&W.stats[27], (unsigned long long)nmax);      // (per wavefront, as in k_swd_warm: 4 searches here, not 64)
+    }
 }
 
 // The branch test of the warm start (WarmSearch, swd_math.hpp): one secular evaluation per item at the point the

@@ -528,8 +528,10 @@ def test_wide_brackets_and_skipped_idle_chains_sample_the_same():
 def test_warm_search_in_rounds_is_the_one_round_search_bit_for_bit():
     """Round 5: k_swd_warm runs in rounds -- a budget of evaluations per lane, the unfinished searches packed densely for the
     next round ("swd_warm_round_budgets": a wavefront executes what its slowest lane needs, and the searches are very uneven).
-    Which wavefront a search finishes in changes none of its evaluations: the same seeded sampler run from burned-in models
-    in one round, in the default three and in four rounds with tiny budgets gives identical samples, misfits and counters."""
+    Which wavefront a search finishes in changes none of its evaluations, and neither does the last round's 16 lanes per
+    search (k_swd_warm_coop: the single lane's arithmetic, shared out): the same seeded sampler run from burned-in models in
+    one round, in the default three with and without the cooperative last round, and in four rounds with tiny budgets (which
+    overflow their lists) gives identical samples, misfits and counters."""
     import bench
     from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
     n, nc = 30, 1024
@@ -543,20 +545,20 @@ def test_warm_search_in_rounds_is_the_one_round_search_bit_for_bit():
     xb = keep["x"].cpu().numpy()
     runs = {}
     try:
-        for budgets in (0, 302, 10101):
-            ctx.set_option("swd_warm_round_budgets", budgets)
+        for budgets, coop in ((0, 1), (302, 1), (302, 0), (10101, 1), (303, 1), (4, 1), (5, 0)):
+            ctx.set_option("swd_warm_round_budgets", budgets); ctx.set_option("swd_warm_last_round_coop", coop)
             names = ("swd_warm_declined_chains", "swd_warm_secular_evals", "swd_warm_items", "swd_exact_secular_evals")
             c0 = [ctx.stat(k) for k in names]
             p1 = ctx.stat("swd_warm_passed_on_1")
             s = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
             mis = s.sample_flow(x_init=xb, max_steps=100, async_handback=False)
-            runs[budgets] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
+            runs[(budgets, coop)] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
                              [ctx.stat(k) - v for k, v in zip(names, c0)], ctx.stat("swd_warm_passed_on_1") - p1)
     finally:
-        ctx.set_option("swd_warm_round_budgets", 302)
-    ref = runs[0]
-    assert ref[5] == 0 and runs[302][5] > 0 and runs[10101][5] > runs[302][5]         # (the rounds did take place)
-    for budgets in (302, 10101):
+        ctx.set_option("swd_warm_round_budgets", 303); ctx.set_option("swd_warm_last_round_coop", 1)
+    ref = runs[(0, 1)]
+    assert ref[5] == 0 and runs[(302, 1)][5] > 0 and runs[(10101, 1)][5] > runs[(302, 1)][5]         # (the rounds did take place)
+    for budgets in ((302, 1), (302, 0), (10101, 1), (303, 1), (4, 1), (5, 0)):
         r = runs[budgets]
         assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), budgets
         assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]) and r[4] == ref[4], (budgets, r[4], ref[4])
