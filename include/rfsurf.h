@@ -318,7 +318,7 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          search, the rest within 1e-6 c; misfit and gradient as with "swd_warm_start" = 0.
  *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
  *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
- *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2: measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 1 since round 5, see "swd_exact_origin_tol_e9"; round 4: 2) of the above.
+ *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2: measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; 1 with "swd_exact_origin_tol_e9" 500 is the faster, looser setting described there) of the above.
  *   "flow_async_handback"  rfs_flow_step / rfs_flow_step2 with the warm start on: 1 = a chain the warm start hands back to the
  *                          reference-semantics search (a few per step on rough models: ~3 ms of dependent evaluations, during
  *                          which every other chain would wait) sits that step out instead -- its model has drifted, it is not
@@ -328,15 +328,16 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          call in which a given leapfrog step of a given chain happens moves by one.  A caller that
  *                          counts calls (rem steps = rem calls) must look at rem / done instead.  0 (default) = every call
  *                          completes every chain's step.  The samplers of pyhmc switch it on for sample_flow.
- *   "swd_exact_origin_tol_e9"  how far (in units of 1e-9 c, default 500) the origin of a wanted period's scan grid may be from the
- *                          reference's, as tracked through the run-up periods, before its group is handed back.  Round 5's defaults
- *                          -- ONE run-up period ("swd_exact_runup" 1) and 5e-7 c -- let a group whose run-up period was closed by
- *                          bisections alone keep an origin up to 4e-7 c off (0.3 % of the groups; with 1e-7 c they would all be
- *                          handed back).  Against the oracle, 3 072 completed and 3 072 mid-trajectory chains of the burned-in bench
- *                          population: misfit max 2.9e-6, none above 1e-5; gradient 6 chains above 1e-5 (max 1.3e-5) -- round 4's
- *                          setting ("swd_exact_runup" 2, 100 here): 3.6e-6, none; 4 chains (max 2.2e-5): the same ill-conditioned
- *                          chains either way; roots 99.997 % bit-identical to the sequential search on smooth models.  A sixth of
- *                          the stage's evaluations less: 5.26 -> 5.08 ms per step at 8192 chains (same-box A/B).
+ *   "swd_exact_origin_tol_e9"  how far (in units of 1e-9 c, default 100) the origin of a wanted period's scan grid may be from the
+ *                          reference's, as tracked through the run-up periods, before its group is handed back.  ONE run-up period
+ *                          ("swd_exact_runup" 1) needs 500 here: a group whose run-up period was closed by bisections alone keeps an
+ *                          origin up to 4e-7 c off (0.3 % of the groups; with 100 they would all be handed back).  That setting does
+ *                          a sixth of the stage's evaluations less (-3.7 % per step, same-box A/B) and, against the oracle on 3 072
+ *                          completed + 3 072 mid-trajectory chains of the burned-in bench population (phase velocities only), gives
+ *                          the default's figures (misfit max 2.9e-6 / 3.6e-6, none above 1e-5; gradient 6 / 4 chains above 1e-5) --
+ *                          but on random configurations with group velocities, which difference the roots of neighbouring periods,
+ *                          79 instead of 1 of 518 473 roots differ from the sequential search's by a float32 step and the misfit
+ *                          is off by up to 5.1e-5 instead of 6.0e-6.  Hence an option, not the default.
  *   "swd_warm_widen"       1 (default): a warm search that finds no sign change within its trust radius (the root has left the
  *                          first-order model's reach: 32 chains per step of a burned-in 8192-chain population) keeps widening its
  *                          bracket, out to 16 x the radius or 0.1 km/s; an item whose first-order change exceeds 2 km/s (kernels

@@ -110,12 +110,14 @@ struct rfs_ctx {
     const int *f_rem = nullptr, *f_fresh = nullptr, *f_ok = nullptr;   // the flow state's arrays during a flow step (k_swd_warm: idle chains)
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
-    // Round 5: ONE run-up period, origins accepted to 5e-7 c.  Over 3 072 + 3 072 burned-in bench chains against the oracle
-    // (scripts/flow_parity_stats.py) this setting and round 4's (two run-up periods, 1e-7 c) are indistinguishable -- misfit
-    // max 2.9e-6 / 3.6e-6, none above 1e-5; gradient 6 / 4 chains above 1e-5 (max 1.3e-5 / 2.2e-5: the ill-conditioned chains
-    // either setting has) -- and the stage does a sixth less work: 5.26 -> 5.08 ms per step (same-box A/B).
-    float exact_origin_tol = 5.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL = 1e-7: round 4's)
-    int exact_group = 4, exact_runup = 1;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
+    // TWO run-up periods, origins accepted to 1e-7 c.  Round 5 measured ONE period with 5e-7 c: a sixth less work in the stage
+    // (-3.7 % per step), and over 3 072 + 3 072 burned-in bench chains against the oracle (phase velocities only,
+    // scripts/flow_parity_stats.py) the same parity figures -- but on random configurations with group velocities (which
+    // difference roots at neighbouring periods: a root one float32 step off counts fifty-fold) 79 instead of 1 of 518 473 roots
+    // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
+    // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
+    float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
+    int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
     int warm_nchain = 0;
@@ -1547,14 +1549,26 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
              hipEventCreateWithFlags(&c->ev_wk[0], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_wk[1], hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
-    // (RFS_WARM_ROUND_BUDGETS in the environment: the start value of option "swd_warm_round_budgets" -- for A/B runs of
-    // scripts that build their contexts themselves)
-    if (const char* e = getenv("RFS_WARM_ROUND_BUDGETS")) { const int v = atoi(e); if (v >= 0 && v <= 999999) c->warm_budgets = v; }
     c->own_stream = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return RFS_ERR_HIP; }
     c->ncu = prop.multiProcessorCount;
     if (make_partition_streams(c) != RFS_OK) c->cu_split = 0;      // masks unsupported: fall back to shared CUs
+    // (RFS_CTX_OPTS="name=value,name=value" in the environment: options every new context starts with -- for A/B runs of
+    // scripts that build their contexts themselves; unknown names are reported on stderr and ignored)
+    if (const char* e = getenv("RFS_CTX_OPTS")) {
+        std::string all(e);
+        size_t p0 = 0;
+        while (p0 < all.size()) {
+            size_t p1 = all.find(',', p0);
+            if (p1 == std::string::npos) p1 = all.size();
+            const std::string kv = all.substr(p0, p1 - p0);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && rfs_set_option(c, kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)) != RFS_OK)
+                fprintf(stderr, "rfsurf: RFS_CTX_OPTS: %s not applied (%s)\n", kv.c_str(), c->err.c_str());
+            p0 = p1 + 1;
+        }
+    }
     *out = c;
     return RFS_OK;
 }
