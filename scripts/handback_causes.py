@@ -26,5 +26,5 @@ print("ms/step", rep["ms_per_step"])
 print({k: (snap[1][k] - snap[0][k]) / K for k in names})
 d = {k: (snap[1][k] - snap[0][k]) / K for k in names}
 if d["swd_warm_search_lanes"]:
-    print("warm search: %.2f evaluations per lane, %.2f executed per lane (the wavefront's slowest lane x 64)" % (d["swd_warm_search_evals"] / d["swd_warm_search_lanes", "swd_warm_passed_on_1", "swd_warm_passed_on_2", "swd_warm_passed_on_3"], 64 * d["swd_warm_search_evals_slowest_lane"] / d["swd_warm_search_lanes", "swd_warm_passed_on_1", "swd_warm_passed_on_2", "swd_warm_passed_on_3"]))
+    print("warm search: %.2f evaluations per lane, %.2f executed per lane (the wavefront's slowest lane x 64)" % (d["swd_warm_search_evals"] / d["swd_warm_search_lanes"], 64 * d["swd_warm_search_evals_slowest_lane"] / d["swd_warm_search_lanes"]))
 print("causes: 4 no valid previous evaluation / forced, 5 refused (move too large), 6 warm search failed, 7 root above the fastest layer; 8 / 10 degenerate start point (later / first period), 9 / 11 branch test (later / first period)")
