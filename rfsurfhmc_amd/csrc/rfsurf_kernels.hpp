@@ -1174,10 +1174,7 @@ __device__ __forceinline__ void swd_warm_load(const WarmSpill& in, size_t sl, Wa
     ws.cpred = D[0]; ws.eps = D[cp]; ws.R = D[2 * cp]; ws.a = D[3 * cp]; ws.fa = D[4 * cp]; ws.b = D[5 * cp]; ws.fb = D[6 * cp];
     ws.creq = D[7 * cp]; ws.root = D[8 * cp]; ws.slope = D[9 * cp]; ws.f0 = D[10 * cp]; ws.mlast = D[11 * cp];
     cprev = D[12 * cp]; dc = D[13 * cp]; l1 = D[14 * cp]; fb = D[15 * cp]; betmx = (float)D[16 * cp];
-    const unsigned long long bt = in.bits[sl];
-    ws.phase = (int)(bt & 7); ws.it = (int)((bt >> 3) & 127); ws.side = (int)((bt >> 10) & 1); ws.second = (int)((bt >> 11) & 1);
-    ws.lastside = (int)((bt >> 12) & 3) - 1; ws.ntry = (int)((bt >> 14) & 3); attempt = (int)((bt >> 16) & 1);
-    ws.nev = (int)((bt >> 20) & 4095); nev_first = (int)((bt >> 32) & 4095);
+    ws.unpack_small(in.bits[sl], attempt, nev_first);
 }
 
 template <class F, bool SPH, bool FIRST>
@@ -1286,10 +1283,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
             D[0] = ws.cpred; D[cp] = ws.eps; D[2 * cp] = ws.R; D[3 * cp] = ws.a; D[4 * cp] = ws.fa; D[5 * cp] = ws.b; D[6 * cp] = ws.fb;
             D[7 * cp] = ws.creq; D[8 * cp] = ws.root; D[9 * cp] = ws.slope; D[10 * cp] = ws.f0; D[11 * cp] = ws.mlast;
             D[12 * cp] = cprev; D[13 * cp] = dc; D[14 * cp] = l1; D[15 * cp] = fb; D[16 * cp] = (double)betmx;
-            out.bits[sl] = (unsigned long long)(ws.phase & 7) | ((unsigned long long)(ws.it & 127) << 3) | ((unsigned long long)(ws.side & 1) << 10) |
-                           ((unsigned long long)(ws.second & 1) << 11) | ((unsigned long long)((ws.lastside + 1) & 3) << 12) |
-                           ((unsigned long long)(ws.ntry & 3) << 14) | ((unsigned long long)(attempt & 1) << 16) |
-                           ((unsigned long long)(ws.nev & 4095) << 20) | ((unsigned long long)(nev_first & 4095) << 32);
+            out.bits[sl] = ws.pack_small(attempt, nev_first);
             out.item[sl] = (unsigned long long)g;
             spilled = true;
         }

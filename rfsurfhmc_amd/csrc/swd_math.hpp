@@ -838,6 +838,20 @@ struct WarmSearch {
 
     RFS_HD bool active() const { return phase < W_DONE; }
 
+    // The machine's small integers (+ the caller's attempt flag and the evaluations of its first attempt) in one word, and
+    // back: a search that moves to another lane between two evaluations (k_swd_warm's rounds) carries its 12 doubles and this.
+    RFS_HD unsigned long long pack_small(int attempt, int nev_first) const {
+        return (unsigned long long)(phase & 7) | ((unsigned long long)(it & 127) << 3) | ((unsigned long long)(side & 1) << 10) |
+               ((unsigned long long)(second & 1) << 11) | ((unsigned long long)((lastside + 1) & 3) << 12) |
+               ((unsigned long long)(ntry & 3) << 14) | ((unsigned long long)(attempt & 1) << 16) |
+               ((unsigned long long)(nev & 4095) << 20) | ((unsigned long long)(nev_first & 4095) << 32);
+    }
+    RFS_HD void unpack_small(unsigned long long bt, int& attempt, int& nev_first) {
+        phase = (int)(bt & 7); it = (int)((bt >> 3) & 127); side = (int)((bt >> 10) & 1); second = (int)((bt >> 11) & 1);
+        lastside = (int)((bt >> 12) & 3) - 1; ntry = (int)((bt >> 14) & 3); attempt = (int)((bt >> 16) & 1);
+        nev = (int)((bt >> 20) & 4095); nev_first = (int)((bt >> 32) & 4095);
+    }
+
     // cprev: root of the previous model; dc: first-order change; l1: sum of |first-order terms|; slope0: d(secular)/dc at
     // the previous model's root as its own search left it (0 = unknown).  With a slope the search starts with a Newton
     // step from the prediction, overshot by WARM_OVER: two evaluations bracket the root within a fraction of the

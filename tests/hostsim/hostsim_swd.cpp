@@ -1,6 +1,7 @@
 // tests/hostsim/hostsim_swd.cpp -- TEST HARNESS ONLY (never shipped, never a fallback).
 // Host build of rfsurfhmc_amd/csrc/swd_math.hpp for CPU-side checks against the oracle.
 #include <vector>
+#include <cstring>
 #include "../../rfsurfhmc_amd/csrc/swd_math.hpp"
 
 using namespace rfs;
@@ -236,6 +237,46 @@ double hs_eigen_general(int n, const float* thk, const float* vp, const float* v
     dcdh[n - 1] = 0.0;
     return u;
 }
+}
+
+// A warm search that changes lanes every `budget` evaluations, as in k_swd_warm's rounds: its 12 doubles and the packed word
+// (WarmSearch::pack_small) are all that travels; the receiving machine starts from garbage.  cout / nev / status as
+// hs_warm_roots; the caller compares them with the uninterrupted search.  Returns the number of hand-overs made.
+extern "C" int hs_warm_roots_handover(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                                      const double* t, const double* cprev, const double* dc, const double* l1, int budget,
+                                      double* cout, int* nev, int* status)
+{
+    std::vector<SwdLayerC> LC(n);
+    float betmx = -1.e20f;
+    for (int m = 0; m < n; m++) {
+        LC[m] = SwdLayerC{(double)thk[m], 1.0 / (double)vp[m], 1.0 / (double)vs[m], (double)vs[m], (double)rho[m], 1.0 / (double)rho[m]};
+        if (vs[m] > betmx) betmx = vs[m];
+    }
+    auto loadL = [&](int m) { return LC[m]; };
+    int moves = 0;
+    for (int k = 0; k < nt; k++) {
+        const double omega = (2.0 * 3.141592653589793) / t[k];
+        WarmSearch ws;
+        ws.begin(cprev[k], dc[k], l1[k]);
+        int left = budget, attempt = 0, nev_first = 0;
+        while (ws.active()) {
+            ws.advance(swd_secular_family<SwdRayFamily>(n, loadL, omega, ws.creq));
+            if (--left == 0 && ws.active()) {
+                const double d[12] = {ws.cpred, ws.eps, ws.R, ws.a, ws.fa, ws.b, ws.fb, ws.creq, ws.root, ws.slope, ws.f0, ws.mlast};
+                const unsigned long long bits = ws.pack_small(attempt, nev_first);
+                WarmSearch w2;
+                memset((void*)&w2, 0xA5, sizeof(w2));
+                w2.cpred = d[0]; w2.eps = d[1]; w2.R = d[2]; w2.a = d[3]; w2.fa = d[4]; w2.b = d[5]; w2.fb = d[6];
+                w2.creq = d[7]; w2.root = d[8]; w2.slope = d[9]; w2.f0 = d[10]; w2.mlast = d[11];
+                w2.unpack_small(bits, attempt, nev_first);
+                ws = w2; left = budget; moves++;
+            }
+        }
+        const bool ok = ws.phase == WarmSearch::W_DONE && !(ws.root > (double)betmx);
+        cout[k] = ok ? (double)(float)ws.root : 0.0;
+        nev[k] = ws.nev; status[k] = ok ? 1 : 0;
+    }
+    return moves;
 }
 
 // Warm-started refinement (WarmSearch + swd_secular_family: the lane code of k_swd_warm) for the nt periods of one

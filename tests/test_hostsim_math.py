@@ -337,6 +337,45 @@ def test_lazy_nevill_takes_the_same_path_as_the_full_one(hs):
     assert nroot > 10000 and nev_l <= 0.62 * nev_p, (nroot, nev_l, nev_p)
 
 
+@pytest.mark.parametrize("budget", [1, 2, 3])
+def test_warm_search_handed_from_lane_to_lane(hs, budget):
+    """k_swd_warm runs in rounds: a search that has used its budget of evaluations is written out (12 doubles + the word of
+    WarmSearch::pack_small) and picked up by a lane of the next launch.  The lane code on the host: searches from good,
+    poor and hopeless predictions (Newton start, bracket, widened bracket, bisection, failure), handed over every `budget`
+    evaluations into a machine that starts from garbage, end where the uninterrupted search ends -- root, evaluation count
+    and verdict."""
+    H = hs["swd"]
+    I = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    from oracle import oracle as O
+    rng = np.random.default_rng(11 + budget)
+    nroots = nmoves = nlong = 0
+    for trial in range(12):
+        n = int(rng.integers(4, 16))
+        thk = 2.0 + 6.0 * rng.random(n); thk[-1] = 0.0
+        vs = np.sort(2.6 + 1.9 * rng.random(n))
+        if trial % 3 == 2:
+            vs[1:-1] = rng.permutation(vs[1:-1])                     # velocity inversions: crowded spectra
+        vp, rho, _, _ = O.empirical_relation(vs)
+        h, a, b, r = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)) for x in (thk, vp, vs, rho)]
+        t = np.ascontiguousarray(np.sort(5.0 + 30.0 * rng.random(12)))
+        nt = len(t)
+        c0 = np.zeros(nt)
+        if not H.hs_rootsearch_family(n, F(h), F(a), F(b), F(r), nt, P(t), P(c0), 0, 0, 1):
+            continue
+        # predictions: the root moved by up to 0.1 %, 1 % or 5 %, with a first-order estimate that is right, off, or useless
+        move = c0 * rng.choice([1e-3, 1e-2, 5e-2], nt) * rng.uniform(-1, 1, nt)
+        cprev = np.ascontiguousarray(c0 - move)
+        dc = np.ascontiguousarray(move * rng.choice([1.0, 0.7, -0.5], nt))
+        l1 = np.ascontiguousarray(np.abs(move) * rng.uniform(1.0, 3.0, nt))
+        c1 = np.zeros(nt); n1 = np.zeros(nt, dtype=np.int32); s1 = np.zeros(nt, dtype=np.int32)
+        c2 = np.zeros(nt); n2 = np.zeros(nt, dtype=np.int32); s2 = np.zeros(nt, dtype=np.int32)
+        H.hs_warm_roots_handover(n, F(h), F(a), F(b), F(r), nt, P(t), P(cprev), P(dc), P(l1), 1 << 30, P(c1), I(n1), I(s1))
+        nmoves += H.hs_warm_roots_handover(n, F(h), F(a), F(b), F(r), nt, P(t), P(cprev), P(dc), P(l1), budget, P(c2), I(n2), I(s2))
+        assert np.array_equal(c1, c2) and np.array_equal(n1, n2) and np.array_equal(s1, s2), trial
+        nroots += int(s1.sum()); nlong += int((n1 > 8).sum())
+    assert nroots > 60 and nmoves > 100 and nlong > 5, (nroots, nmoves, nlong)
+
+
 def test_fast_exp_and_sincos_accuracy(tmp_path):
     """fm_exp / fm_sincos (cplx.hpp: the transcendental functions of every layer sweep) against long double libm
     on the ranges they are used on: < 1 ulp (exp) and < 1.5 ulp (sin, cos); absolute error at multiples of pi/2."""
