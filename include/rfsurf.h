@@ -434,8 +434,10 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *                               the widest bracket / anything else
  *   "swd_warm_passed_on_<r>"    searches round r = 1, 2, 3 of the warm search passed on to the next round
  *   "swd_warm_search_evals" / "swd_warm_search_evals_slowest_lane" / "swd_warm_search_lanes"   divergence of the warm search
- *                               (k_swd_warm): evaluations of all lanes, of each wavefront's slowest lane (x 64 = what the
- *                               wavefronts execute), lanes that searched
+ *                               (k_swd_warm): evaluations of all searches, of each wavefront's slowest search summed over
+ *                               the rounds' wavefronts (what the wavefronts execute; a wavefront of the cooperative last round
+ *                               holds 4 searches, the others 64), searches made.  One round: 2.56 evaluations per search needed,
+ *                               40 400 wavefront-evaluations executed per step of 8192 chains; in rounds: 23 300
  *   "swd_warm_cause_<k>"        chains handed back, by (first) cause: 4 no usable previous evaluation / forced, 5 step too
  *                               large for a first-order model, 6 no sign change inside the trust radius, 7 root above the
  *                               fastest layer, 9 / 11 another root lies between the point the reference's scan of that
