@@ -59,14 +59,14 @@ TUNED_DT = 0.05
 DT_SWEEP = (0.002, 0.02, 0.1)
 BURN_IN = 300           # device steps before the timed window (set-up + warm-up): the chains' burn-in -- acceptance and the share of
                         # chains with anomalous dispersion are stationary by then (scripts/dt_sweep.py)
-# configs[3]: where to time dual averaging.  VERDICT r04 asked for a window behind the adapting trajectories (acceptance ~ target).
-# Measured (round 5, 8192 chains x 50 layers, RFS_DA_NDRAWS / RFS_DA_ADAPT_CAP): with 6 adapting trajectories 95 % of the chains are
-# through after 215 steps, but dual averaging has not converged (dt median 0.095, acceptance 0.27); with 25 (50) of them the step
-# sizes collapse to a median of 2e-4 (L = 5 000: clamped to L_cap = 1 000 at 29 000 trajectory starts) and after 4 000 device steps
-# 5 % (0.05 %) of the chains are through (acceptance 0.43 / 0.56 on the way).  The reference's scheme on this noise-free 50-layer
-# problem has no stationary regime a bench leg can reach: the leg times the adaptation itself, from step 300, as round 4 did, and
-# says how many chains were through.
-DA_ADAPT_CAP = int(os.environ.get("RFS_DA_ADAPT_CAP", "300"))      # device steps the configs[3] leg waits for 95 % of its chains to finish adapting (then it times anyway and says so)
+# configs[3]: where to time dual averaging.  The reference adapts the step size for `ndraws` trajectories and samples at the frozen
+# dtbar afterwards (hmcda.py:329-345): the leg's window lies BEHIND the adaptation of (nearly) every chain.  On this noise-free
+# 50-layer problem dual averaging drives the step sizes down to a few 1e-3 (a trajectory of fixed length lambda = L0 dt0 = 1 leaves
+# the region where the root search succeeds whatever its step size, and every failure counts as alpha = 0), so a trajectory is
+# 300-1000 device steps and DA_NDRAWS of them take ~10 000 steps: they run untimed, for at most DA_ADAPT_CAP device steps or
+# DA_ADAPT_BUDGET_S seconds (the driver allows the bench 1 800 s), and the leg says what share of the chains was through.
+DA_ADAPT_CAP = int(os.environ.get("RFS_DA_ADAPT_CAP", "60000"))     # device steps the configs[3] leg waits for 95 % of its chains to finish adapting (then it times anyway and says so)
+DA_ADAPT_BUDGET_S = float(os.environ.get("RFS_DA_ADAPT_BUDGET_S", "420"))   # ... or this many seconds
 DA_NDRAWS = int(os.environ.get("RFS_DA_NDRAWS", "20"))          # adapting trajectories per chain in the configs[3] leg (the reference's param.yaml: 200)
 SUSTAIN_K = 100         # --steps below this: a second timed window of this many steps follows the contract's K (reported beside it)
 SIDE_BURN, SIDE_K = 60, 100      # the side legs (they continue burned-in chains): untimed / timed device steps
@@ -89,6 +89,10 @@ CONFIGS = {
             name="configs[3]: main_DA.py dual averaging (HMCDualAveraging.sample_flow), 8192 chains x 50-layer model, "
                  "joint RF(512)+SWD(40 Rc) per GPU, per-chain dt and L"),
 }
+# SURVEY 8(d), Config 2's secondary run: configs[1] plus 40 Rayleigh GROUP periods (tRg = tRc): three root searches and three
+# eigenfunction passes per group period (surfdisp.cpp:235-256, sregn96.f90:1747-1888) -- the costliest SWD shape
+CONFIG1_RG = dict(CONFIGS[1], rg=True, idx="1rg",
+                  name="configs[1] + 40 Rg periods (tRg = tRc = linspace(5, 44, 40)): 8192 chains x 30 layers, joint RF(512)+SWD(40 Rc + 40 Rg)")
 # backwards-compatible module constants (scripts/ import them): the headline shape
 N_LAYER, NT, DT = 30, 512, 0.1
 
@@ -117,7 +121,7 @@ _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", 
               "group_ms_per_step", "launches_per_step", "avg_launch_ms")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "evals_per_s_per_core", "cpu_model", "shapes")
 _CONFIG_KEYS = ("workload", "chains_per_gpu", "nlayer", "nt", "nper", "dt", "accept_ratio", "L_range", "sampler",
-                "root_search_mode", "set_up_steps", "parallelism", "root_search_failures")
+                "root_search_mode", "set_up_steps", "parallelism", "root_search_failures", "rf_f32_bins_share")
 
 
 def _rnd(v, sig=7):
@@ -147,6 +151,8 @@ def headline_line(res):
     out["config"] = {k: _clip(cfg[k], 160) for k in _CONFIG_KEYS if k in cfg}
     if res.get("roofline"):
         out["roofline"] = {k: res["roofline"][k] for k in _ROOF_KEYS if k in res["roofline"]}
+    if res.get("roofline_fp64"):
+        out["roofline_fp64"] = res["roofline_fp64"]
     if res.get("cpu_baseline"):
         cb = res["cpu_baseline"]
         out["cpu_baseline"] = {k: (_clip(cb[k], 200) if k != "shapes" else cb[k]) for k in _CPU_KEYS if k in cb}
@@ -169,7 +175,7 @@ def headline_line(res):
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                    # never again: drop the optional scalars before the contract's keys
         keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail")
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_fp64", "cpu_baseline", "detail")
         line = json.dumps({k: out[k] for k in keep if k in out}, separators=(",", ":"))
     assert len(line) < LINE_LIMIT, len(line)
     return line
@@ -469,7 +475,7 @@ N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs; one f64 (or any VALU) wave-instruc
 def _counters(config):
     """Per-step PMC figures of a configuration (profiles/r*_counters.json, written by scripts/pmc_summary.py from
     separate rocprofv3 --pmc passes); None where no pass was committed."""
-    for name in ("r05_counters.json", "r04_counters.json", "r03_counters.json"):
+    for name in ("r06_counters.json", "r05_counters.json", "r04_counters.json", "r03_counters.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if tj.get("chains") == 8192 and f"config{config}" in tj:
@@ -483,7 +489,7 @@ def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, d
     """The figures of one timed leg: rate, per-step kernel-group times, roofline of the group with the largest per-STEP
     sum, VALU issue per group from the committed counter passes."""
     n, nt = cfg["n"], cfg["nt"]
-    ab = alg_bytes_per_eval(n, nt)
+    ab = alg_bytes_per_eval(n, nt, NPER * (2 if cfg.get("rg") else 1))
     dom_ms = ms_step[dom] if dom_live_ms_step is None else dom_live_ms_step
     achieved = ab * nchain / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     cnt = _counters(config) if nchain == 8192 else None
@@ -512,6 +518,19 @@ def leg_report(cfg, config, nchain, K, el, evals, ms_step, launches_step, dom, d
                              "note": "SQ_INSTS_VALU per leapfrog step (committed rocprofv3 --pmc passes, profiles/r0*_pmc_config*.csv) "
                                      "x 4 clocks / 1024 SIMDs / 2.4 GHz against the measured time; group times are HIP-event "
                                      "durations on two concurrent streams (they overlap, their sum exceeds the step)"}
+    if cnt and any(v.get("fp64_flops", 0) > 0 for v in cnt.values()):
+        # FP64 vector roofline from counters (the roofline that binds): SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 per
+        # leapfrog step of the committed --pmc passes, FMA = 2 flops, the others 1, x 64 lanes per wave-instruction (an upper
+        # estimate where lanes are masked off), against the step time measured HERE
+        fl = {k: v["fp64_flops"] for k, v in cnt.items() if v.get("fp64_flops", 0) > 0}
+        tot = float(sum(fl.values()))
+        step_s = el / K
+        rep["roofline_fp64"] = {"bound": "fp64_valu", "achieved_tflops": tot / step_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tot / step_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                "fp64_flops_per_step": tot, "fp64_flops_per_eval": tot / nchain,
+                                "per_group_flops_per_step": fl,
+                                "note": "flops per step from the committed counter passes (same workload, 8192 chains) / this run's "
+                                        "measured step time; counts every lane of a wave-instruction"}
     return rep
 
 
@@ -522,7 +541,7 @@ def make_joint(cfg, local_rank):
     n, nt = cfg["n"], cfg["nt"]
     t = np.linspace(5, 44, NPER)
     joint = Joint_RF_SWD(1.0, 1.0, ReceiverFunc(RAY_P, nt, cfg["dt"], GAUSS, TSHIFT, WATER, "P", "freq", device=local_rank),
-                         SurfWD(tRc=t, device=local_rank))
+                         SurfWD(tRc=t, tRg=t if cfg.get("rg") else None, device=local_rank))
     x_true = true_model(n)
     drf, dswd, flag = joint.forward(x_true)
     assert flag
@@ -618,7 +637,7 @@ def set_root_mode(joint, n, mode):
 
 
 def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, barrier, kind="hmc", dt=TUNED_DT,
-                mode="reference_roots", xs=None, groups=True, K2=0, adapt_cap=0):
+                mode="reference_roots", xs=None, groups=True, K2=0, adapt_cap=0, nper_items=NPER):
     """A real sampler run on the continuous-flow schedule (HamitonianMC.sample_flow / HMCDualAveraging.sample_flow): `burn`
     device steps untimed, K timed (then, K2 > 0: a second timed window of K2 steps straight behind it -- the driver's K = 20 is a
     0.1 s window that starts from a drained device and ends waiting for the background searches).  kind "hmc": pyhmc/hmc.py:228-276 at step size dt, L ~ U{5..20} (param.yaml:38); "da":
@@ -645,7 +664,7 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
         # hmc block of the reference's param.yaml: dt 0.1, L0 10, target_ratio 0.65, seed 991206 (main_DA.py:79)
         # (the leg cannot afford param.yaml's 200 adapting trajectories of ~1 time unit each: DA_NDRAWS of them, the sample
         # count sized so that ndraws >= 0.1 nsamples holds, hmcda.py:57-60)
-        nsamp = min(max(nsamp, 2 * DA_NDRAWS), 10 * DA_NDRAWS) if adapt_cap else nsamp
+        nsamp = 10 * DA_NDRAWS if adapt_cap else nsamp
         smp = HMCDualAveraging(joint, bounds, 0.1, 10, 10, 0.65, 991206, nsamp, DA_NDRAWS if adapt_cap else 20, myrank=rank,
                                name="bench", outdir=None, nchains=nchain, verbose=False, store_syn=False)
         # every chain starts its first trajectory at the same step: the first ~3 trajectories (until dual averaging has
@@ -666,11 +685,14 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
 
     def hook(s, st):
         burn = sched["burn"]
-        if burn is None:                                           # dual averaging still adapting: look every 16 steps
-            if s >= 40 and s % 16 == 0:
+        if burn is None:                                           # dual averaging still adapting: look every 64 steps
+            if s == 0:
+                marks["adapt_t0"] = time.perf_counter()
+            if s >= 40 and s % 64 == 0:
                 share = float(np.mean(smp.live_counts[1] >= smp.ndraws))
-                if share >= 0.95 or s >= adapt_cap:
+                if share >= 0.95 or s >= adapt_cap or time.perf_counter() - marks["adapt_t0"] > DA_ADAPT_BUDGET_S:
                     sched["burn"] = s + nser + 3; marks["adapted_share"] = share
+                    marks["adapt_s"] = time.perf_counter() - marks["adapt_t0"]
             return
         if nser and s == burn - nser - 2:
             ctx.set_option("swd_warm_serial", 1)                   # one stream: every kernel group alone on the chip
@@ -712,7 +734,7 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
             raise _StopLeg
 
     try:                                                           # (the hook ends the run once its last time stamp is taken)
-        smp.sample_flow(x_init=xs, max_steps=(adapt_cap + 64 if sched["burn"] is None else burn) + K + K2 + 16, step_hook=hook)
+        smp.sample_flow(x_init=xs, max_steps=(adapt_cap + 128 if sched["burn"] is None else burn) + K + K2 + 16, step_hook=hook)
     except _StopLeg:
         ctx.check(ctx.L.rfs_synchronize(ctx.h))
     burn = sched["burn"]
@@ -743,7 +765,7 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
         "accept_ratio": nacc / max(ntraj, 1), "trajectories_completed": ntraj,
         "root_search_mode": mode, "chains_in_a_trajectory_per_step": evals / K,
         "misfit_median_at_the_end": marks["U"], "root_search_failures": marks["fail"],
-        "root_search": {"warm_started_items_per_step": d["swd_warm_items"] / K, "items_per_step": nchain * NPER,
+        "root_search": {"warm_started_items_per_step": d["swd_warm_items"] / K, "items_per_step": nchain * nper_items,
                         "secular_evals_per_item_warm_start_and_branch_test": d["swd_warm_secular_evals"] / items,
                         "secular_evals_per_item_reference_root_stage": d["swd_exact_secular_evals"] / items,
                         "chains_walking_the_scan_grid_per_step": d["swd_warm_walked_chains"] / K,
@@ -758,6 +780,12 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
         rep["adapting_trajectories_per_chain"] = int(smp.ndraws)
         if "adapted_share" in marks:
             rep["share_of_chains_past_adaptation_at_window_start"] = marks["adapted_share"]
+            rep["adaptation_seconds_untimed"] = marks.get("adapt_s")
+        # a length clamped to L_cap stands for int(lambda / dt) steps of the reference (hmcda.py:307, no cap there): the rate in
+        # leapfrog steps is the same either way -- what the clamp changes is how many steps a trajectory is, not how fast one is
+        Lw = np.maximum(1.0, np.floor(10 * 0.1 / dtv))
+        rep["L_unclamped_mean"] = float(Lw.mean()); rep["L_clamped_mean"] = float(np.minimum(Lw, smp.L_cap).mean())
+        rep["share_of_chains_above_L_cap"] = float((Lw > smp.L_cap).mean())
         Lv = np.maximum(1, (10 * 0.1 / dtv).astype(int))           # L = max(1, int(lambda / dt)), lambda = L0 * dt0 (hmcda.py:307)
         q = lambda a: [float(v) for v in np.quantile(a, [0.05, 0.5, 0.95])]
         rep["adapted_dt_quantiles_5_50_95"] = q(dtv); rep["adapted_dt_max"] = float(dtv.max())
@@ -881,6 +909,8 @@ def run_rank(args):
                                                           adapt_cap=DA_ADAPT_CAP if kind == "da" else 0)
     if misfit is None:
         misfit = torch.zeros(nchain, dtype=torch.float64, device=dev)
+    f32_chains = ctx.stat("rf_f32_chains")       # chain evaluations whose frequencies beyond the band were swept in float32
+    f32_share = (1.0 - ctx.stat("rf_band_bins") / max(ctx.stat("rf_bins"), 1)) if f32_chains > 0 else 0.0
     side_legs = rank == 0 and world == 1 and kind == "hmc" and not args.headline_only
     if side_legs:
         # ---- the same chains, continued from where the headline left them (burned in), under other settings: short legs
@@ -910,6 +940,12 @@ def run_rank(args):
             # THIS figure, not with `value`
             extra["headline_again"] = short("the headline's setting, measured like a side leg (for the side legs' ratios)",
                                             dt=dt, mode=mode)
+            # ... and with EVERY frequency of the receiver-function row sweep in f64 (the reference's own arithmetic type
+            # throughout): the headline's pass A takes the bins beyond the Gaussian band in packed float32 where a per-chain
+            # proof allows it -- same trace, misfit and gradient to 3e-13 (tests/test_gpu_parity.py), fewer instructions
+            ctx.set_option("rf_f32_beyond_band", 0)
+            extra["all_f64"] = short("rf_f32_beyond_band 0: every frequency in f64; compares with headline_again", dt=dt, mode=mode)
+            ctx.set_option("rf_f32_beyond_band", 1)
         set_root_mode(joint, n, mode)
         # ---- rounds 1-3's headline definition, for continuity: never-ending trajectories (no accept / reject) of the random
         # start models at dt = 0.002, the cheapest point of the step-size curve
@@ -957,18 +993,20 @@ def run_rank(args):
     if world == 1 and args.config == 1 and nchain == 8192 and not args.headline_only and not args.no_other_configs:
         joint._ctx.close(); joint._ctx = None; joint._cfg = None
         torch.cuda.empty_cache()
-        for ci in (4, 3):
-            c2 = CONFIGS[ci]
+        for ci in ("1_rg", 4, 3):
+            c2 = CONFIG1_RG if ci == "1_rg" else CONFIGS[ci]
             j2 = None
             try:                                     # (a side leg must not cost the line)
                 j2, xt2, b2 = make_joint(c2, local_rank)
                 k2 = "da" if c2["sampler"] == "da" else "hmc"
                 r2, _, _, _, xe2, _ = sampler_leg(c2, ci, j2, xt2, b2, 8192, rank, dev, SIDE_K, BURN_IN, barrier, kind=k2,
-                                                  dt=c2.get("hmc_dt", TUNED_DT), mode=mode, adapt_cap=DA_ADAPT_CAP if k2 == "da" else 0)
+                                                  dt=c2.get("hmc_dt", TUNED_DT), mode=mode, adapt_cap=DA_ADAPT_CAP if k2 == "da" else 0,
+                                                  nper_items=NPER * (4 if c2.get("rg") else 1))
                 r2["workload"] = c2["name"]; r2["step"] = STEP_TEXT[c2["sampler"]]
                 extra[f"config{ci}"] = r2
-                cpu_others[f"config{ci}"] = {"shape": "joint", "n": c2["n"], "nt": c2["nt"], "dt": c2["dt"], "xs": xe2[:64].tolist(),
-                                             "dobs": j2.dobs.tolist(), "budget_s": 5.0}
+                if ci != "1_rg":
+                    cpu_others[f"config{ci}"] = {"shape": "joint", "n": c2["n"], "nt": c2["nt"], "dt": c2["dt"], "xs": xe2[:64].tolist(),
+                                                 "dobs": j2.dobs.tolist(), "budget_s": 5.0}
             except Exception as e:
                 extra[f"config{ci}"] = {"value": None, "error": repr(e)[:300]}
                 print(f"bench.py: the configs[{ci}] leg failed: {e!r}", file=sys.stderr)
@@ -985,7 +1023,8 @@ def run_rank(args):
         "metric": METRIC,
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "dtype_note": DTYPE_TEXT, "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64 (+f32 beyond band)" if f32_chains > 0 else "f64", "dtype_note": DTYPE_TEXT,
+        "data": "synthetic",
         "config": {"workload": cfg["name"] if not (args.config == 1 and world * nchain == 65536) else
                    "configs[2]: 65536 chains x 30-layer joint RF+SWD, 8xMI355X independent-chain shard, RCCL gather "
                    "(= configs[1]'s 8192 chains on each GPU)", "chains_per_gpu": nchain, "nlayer": n, "nt": nt, "nper": NPER,
@@ -999,11 +1038,14 @@ def run_rank(args):
                    "step": STEP_TEXT[cfg["sampler"]],
                    "parallelism": f"independent chains x{world}" + (" -- FUNCTIONAL CHECK: all ranks share GPU 0, gloo "
                                                                     "collectives; not a measurement" if shared else ""),
-                   "root_search_failures": rep.get("root_search_failures", 0)},
+                   "root_search_failures": rep.get("root_search_failures", 0),
+                   "rf_f32_bins_share": f32_share},
         # scalars the driver's parser keeps
         "dt": rep["dt"], "accept_ratio": rep["accept_ratio"], "root_search_mode": mode,
         "roofline": rep.get("roofline"),
     }
+    if rep.get("roofline_fp64"):
+        res["roofline_fp64"] = {k: rep["roofline_fp64"][k] for k in ("bound", "achieved_tflops", "peak", "unit", "frac", "fp64_flops_per_eval")}
     for k in ("kernel_ms_per_step", "kernel_launches_per_step", "valu_issue", "root_search", "kernel_ms_note",
               "chains_in_a_trajectory_per_step", "misfit_median_at_the_end", "trajectories_completed",
               "adapted_dt_quantiles_5_50_95", "adapted_dt_max", "L_quantiles_5_50_95", "L_cap", "trajectory_lengths_clamped_to_L_cap",
@@ -1017,13 +1059,17 @@ def run_rank(args):
     for k, v in extra.items():
         res[k] = v
     # the side legs' rates as top-level scalars as well
-    for k in ("converged_roots", "full_search_every_step", "one_runup_period", "headline_again", "never_ending_dt0002", "config3", "config4", "config0"):
+    for k in ("converged_roots", "full_search_every_step", "one_runup_period", "headline_again", "all_f64", "never_ending_dt0002", "config3",
+              "config4", "config0", "config1_rg"):
         if k in extra:
             res[f"{k}_value"] = extra[k]["value"]
     if "config0" in extra and extra["config0"].get("ms_per_eval"):
         res["config0_ms_per_eval"] = extra["config0"]["ms_per_eval"]
     if "config3" in extra:
         res["config3_accept_ratio"] = extra["config3"].get("accept_ratio")
+        res["config3_adapted_share"] = extra["config3"].get("share_of_chains_past_adaptation_at_window_start")
+    if "config1_rg" in extra:
+        res["config1_rg_accept_ratio"] = extra["config1_rg"].get("accept_ratio")
     for r in extra.get("dt_sweep", []):
         tag = str(r["dt"]).replace(".", "p")
         res[f"dt_{tag}_value"] = r["value"]; res[f"dt_{tag}_accept_ratio"] = r["accept_ratio"]

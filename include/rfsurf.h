@@ -419,6 +419,8 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *                               -- waiting for the host, or failed -- do not count): the evaluations a sampler used
  *   "rf_f32_chains"             chain evaluations whose frequencies beyond the band were swept in float32; "rf_f32_resweeps":
  *                               those of them swept again in f64 (see "rf_f32_beyond_band")
+ *   "rf_band_bins" / "rf_bins"  frequencies inside the band of the fused gradient ("rf_band_limit_digits"; the rest is what
+ *                               "rf_f32_beyond_band" sweeps in float32) / all frequencies n2 of the joint configuration
  *   "swd_warm_declined_chains"  chain evaluations the warm start handed back to the reference-semantics search
  *   "swd_warm_items"            (period, chain) items the warm start refined
  *   "swd_warm_secular_evals"    secular-function evaluations it spent on all items
@@ -444,6 +446,11 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *                               period (/ of a sequence's first period) starts from and the continued root, 8 / 10
  *                               degenerate start point */
 int rfs_get_stat(rfs_ctx* ctx, const char* name, int64_t* value);
+/* Diagnostics: the roots of the LAST evaluation of the joint configuration as they lie in the context's persistent root
+ * buffer -- one value per (sequence, period) item in the order Rc, [Rg pass at T, 1.05 T, 0.95 T], Lc, ... (the float32
+ * values the reference stores, surfdisp96.f:302; for a flow step: of every chain that was evaluated in it).
+ * *nitems = items per chain (also with croots == NULL); croots: HOST [nchain][*nitems].  Synchronises. */
+int rfs_last_roots(rfs_ctx* ctx, int nchain, int32_t* nitems, double* croots);
 /* Kernel groups of one rfs_joint_misfit_grad_dev call.  With timing enabled every group of every
  * call is bracketed by its own pair of HIP events recorded on the stream the kernels run on
  * (the root search / eigenfunction groups run on the context's second stream); nothing

@@ -498,6 +498,28 @@ def ref_libsurf():
     return mod
 
 
+def ref_libsurf_variant(kind: str):
+    """The reference's libsurf at another optimisation setting (oracle/Makefile `ref_variants`): "O2" = the pin above,
+    "O0", "native" (-O3 -march=native: the reference's own Release flags, CMakeLists.txt:16-34).  Not an oracle -- used by
+    oracle/make_golden.py --ill-conditioned and scripts/ref_selfdiff.py to measure the reference against itself.
+    ONE variant per process: the interpreter keeps one extension module per name (a second `libsurf` comes back as the
+    first), so callers that compare builds run each in a process of its own."""
+    import sysconfig
+    if kind == "O2":
+        return ref_libsurf()
+    path = os.path.join(_HERE, "_ref", kind, "libsurf" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not built (make -C oracle ref_variants)")
+    if "libsurf_ref_loaded" in globals() and globals()["libsurf_ref_loaded"] != path:
+        raise RuntimeError("one build of the reference's libsurf per process")
+    globals()["libsurf_ref_loaded"] = path
+    spec = importlib.util.spec_from_file_location("libsurf", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert os.path.samefile(mod.__file__, path), mod.__file__
+    return mod
+
+
 class RefRFCore:
     """Compiled reference RF core (RFModule.f90 procedures) behind oracle/ref_probe.c.
 

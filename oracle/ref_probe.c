@@ -13,6 +13,8 @@
  * cal_E_inv_par (:924-987) -- through their flang module-procedure symbols
  * (_QMrfmoduleP<name>, Fortran ABI: every argument by reference, explicit-shape
  * arrays as bare pointers, column-major).
+ * Round 6: refprobe_gauss_filter reaches deconit.f90:15-32 (`gauss_filter`), the one routine of the
+ * time-domain path besides nextpow2 that calls neither rfft nor irfft.
  */
 #include <complex.h>
 
@@ -35,6 +37,7 @@ extern void _QMrfmodulePcal_e_inv(const zc *omega, const double *ray_p,
 extern void _QMrfmodulePcal_e_inv_par(const zc *omega, const double *ray_p,
     const zc *alpha, const zc *beta, const double *rho, zc *e, const int *ipars);
 extern void nextpow2_(const int *n, int *nout);
+extern void gauss_filter_(const int *nt, const double *dt, const double *f0, double *gauss);
 
 /* omega = (w_re, w_im); alpha/beta complex[nlayer] interleaved (re,im).
  * R21_m/R22_m come back Fortran-shaped (nlayer, 4): index [ipar*nlayer + layer]. */
@@ -86,4 +89,10 @@ int refprobe_nextpow2(int n)
     int out = 0;
     nextpow2_(&n, &out);
     return out;
+}
+
+/* deconit.f90:15-32: gauss[nt/2 + 1] = exp(-0.25 (2 pi_f32 f / f0)^2), f = i / (nt dt) */
+void refprobe_gauss_filter(int nt, double dt, double f0, double *gauss)
+{
+    gauss_filter_(&nt, &dt, &f0, gauss);
 }

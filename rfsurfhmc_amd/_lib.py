@@ -65,11 +65,12 @@ SIGNATURES = {
     "rfs_ndata": (_i, [_vp]),
     "rfs_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "rfs_get_stat": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "rfs_last_roots": (_i, [_vp, _i, c_int32_p, _vp]),
     "rfs_enable_timing": (_i, [_vp, _i]),
     "rfs_kernel_ms_sum": (_i, [_vp, _vp, _vp]),
     "rfs_kernel_timeline": (_i, [_vp, _vp, _vp, _vp]),
 }
-_DIAGNOSTIC = {"rfs_kernel_timeline"}      # (absent from older builds loaded through RFSURF_LIB for A/B runs)
+_DIAGNOSTIC = {"rfs_kernel_timeline", "rfs_last_roots"}      # (absent from older builds loaded through RFSURF_LIB for A/B runs)
 
 _LIB = None
 
@@ -127,6 +128,14 @@ class Context:
         v = ctypes.c_int64(0)
         self.check(self.L.rfs_get_stat(self.h, name.encode(), ctypes.byref(v)))
         return int(v.value)
+
+    def last_roots(self, nchain: int) -> np.ndarray:
+        """[nchain][items] roots of the last evaluation (rfs_last_roots: diagnostics)."""
+        ni = ctypes.c_int32(0)
+        self.check(self.L.rfs_last_roots(self.h, int(nchain), ctypes.byref(ni), None))
+        out = np.zeros((int(nchain), int(ni.value)))
+        self.check(self.L.rfs_last_roots(self.h, int(nchain), ctypes.byref(ni), hptr(out)))
+        return out
 
     def close(self):
         if getattr(self, "h", None):

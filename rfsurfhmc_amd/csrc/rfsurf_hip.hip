@@ -1804,6 +1804,10 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
         *value = (q > 9.0e0f) ? INT64_MAX : (int64_t)((double)q * 1.0e18);
         return RFS_OK;
     }
+    if (!strcmp(name, "rf_band_bins") || !strcmp(name, "rf_bins")) {       // frequencies inside the gradient's band / all of them (n2)
+        *value = c->has_rf ? (!strcmp(name, "rf_bins") ? c->f.n2 : std::min(c->f.nk, c->f.n2)) : 0;
+        return RFS_OK;
+    }
     if (!strcmp(name, "rf_f32_chains") || !strcmp(name, "rf_f32_resweeps")) {    // (chain, evaluation) pairs swept in float32 beyond the band / swept again in f64
         if (!c->stat32.p) return RFS_OK;
         HIPCHK(c, hipSetDevice(c->device));
@@ -1845,6 +1849,25 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     unsigned long long v[32];
     HIPCHK(c, hipMemcpy(v, c->wstats.p, sizeof(v), hipMemcpyDeviceToHost));
     *value = (int64_t)v[idx];
+    return RFS_OK;
+}
+
+// The roots (phase velocities, float32 values as the reference stores them) of the LAST evaluation, as they lie in the
+// persistent root buffer: diagnostics for parity tests that want to know which chains of a flow step hold a root that is
+// not the sequential search's.  c: HOST [nchain][nitems]; returns the number of items through *nitems.
+int rfs_last_roots(rfs_ctx* c, int nchain, int32_t* nitems, double* croots) {
+    if (!c || !nitems) return RFS_ERR_ARG;
+    *nitems = c->warm_nitems;
+    if (!croots) return RFS_OK;
+    if (!c->configured || !c->croot.p || c->warm_nitems <= 0 || nchain != c->warm_nchain ||
+        c->croot.cap < (size_t)c->warm_nitems * nchain * sizeof(double))
+        return fail(c, RFS_ERR_STATE, "rfs_last_roots: no evaluation of that many chains yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(rfs_synchronize(c));
+    std::vector<double> tmp((size_t)c->warm_nitems * nchain);
+    HIPCHK(c, hipMemcpy(tmp.data(), c->croot.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int e = 0; e < c->warm_nitems; e++)
+        for (int k = 0; k < nchain; k++) croots[(size_t)k * c->warm_nitems + e] = tmp[(size_t)e * nchain + k];
     return RFS_OK;
 }
 

@@ -66,6 +66,11 @@ def main():
                     g["hbm_bytes"] += (2 * tot[(k, "FETCH_SIZE")] + tot[(k, "WRITE_SIZE")]) * 1024.0 / calls(k)
                 if (k, "SQ_INSTS_VALU") in tot:
                     g["valu_insts"] += tot[(k, "SQ_INSTS_VALU")] / calls(k)
+                # FP64 vector flops (round 6): wave-instructions by class, FMA = 2 flops, ADD / MUL / TRANS = 1, x 64 lanes
+                f64 = [tot.get((k, "SQ_INSTS_VALU_" + cls + "_F64")) for cls in ("ADD", "MUL", "FMA", "TRANS")]
+                if all(v is not None for v in f64):
+                    g["fp64_flops"] = g.get("fp64_flops", 0.0) + (f64[0] + f64[1] + 2 * f64[2] + f64[3]) * 64.0 / calls(k)
+                    g["fp64_wave_insts"] = g.get("fp64_wave_insts", 0.0) + sum(f64) / calls(k)
                 break
     J[f"config{config}"] = sec
     json.dump(J, open(jpath, "w"), indent=1)

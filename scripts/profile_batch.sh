@@ -6,7 +6,7 @@
 #                                    a process that the profiler's library has attached to the GPU must not start another)
 #   gpurun_out/<tag>_pmc/c<config>/g<i>/  one rocprofv3 --pmc pass per counter group and configuration (scripts/prof_run.py)
 # Afterwards (anywhere):  python3 scripts/pmc_summary.py <tag> <config> 0 gpurun_out/<tag>_pmc/c<config> ; copy the stats csv to profiles/.
-tag=${1:-r05}
+tag=${1:-r06}
 export TMPDIR=/tmp
 root=$PWD
 mkdir -p gpurun_out
@@ -20,7 +20,7 @@ rm -f $(find gpurun_out/${tag}_stats -name "*kernel_trace.csv")
 for cfg in 1 3 4; do
   timeout 600 python3 scripts/prof_run.py $cfg 10 hmc > gpurun_out/${tag}_burn_c$cfg.log 2>&1      # burn-in, kept in gpurun_out/burned_c<cfg>.npy
   i=0
-  for g in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"; do
+  for g in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"; do
     i=$((i+1))
     ( cd $root && timeout 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc/c$cfg/g$i -- python3 scripts/prof_run.py $cfg 40 hmc > gpurun_out/${tag}_pmc_c${cfg}_g$i.log 2>&1 )
   done

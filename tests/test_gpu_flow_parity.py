@@ -41,8 +41,9 @@ def _joint(n, nt, dt_rf):
     return j, t
 
 
-def _capture(smp, xs, s0):
-    """Run smp.sample_flow for s0 + 1 device steps; returns the state right before and right after device step s0."""
+def _capture(smp, xs, s0, roots_of=None):
+    """Run smp.sample_flow for s0 + 1 device steps; returns the state right before and right after device step s0.
+    roots_of: () -> [chain][item] roots of the last evaluation (rfs_last_roots), read right behind device step s0."""
     import torch
     cap = {}
 
@@ -56,11 +57,16 @@ def _capture(smp, xs, s0):
             cap["a"] = {k: st[k].clone() for k in KEYS}
             for k in ("done", "res_x", "res_val", "res_dsyn"):         # (st["done"] still names step s0's buffer here)
                 cap["a"][k] = st[k].clone()
+            if roots_of is not None:
+                cap["roots"] = roots_of()
 
     smp.sample_flow(x_init=xs, max_steps=s0 + 2, step_hook=hook)
     torch.cuda.synchronize()
     to = lambda d: {k: (v.cpu().numpy() if v is not None else None) for k, v in d.items()}
-    return to(cap["b"]), to(cap["a"])
+    b, a = to(cap["b"]), to(cap["a"])
+    if roots_of is not None:
+        a["roots"] = cap["roots"]
+    return b, a
 
 
 def _device_gradients(b, a, bounds):
@@ -121,6 +127,23 @@ def _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, nmax, tag):
                misfit_max=float(mrel.max()), misfit_p99=float(np.quantile(mrel, 0.99)), misfit_share_above_1e5=float((mrel > 1e-5).mean()),
                grad_max=float(grel.max()), grad_p99=float(np.quantile(grel, 0.99)), grad_share_above_1e5=float((grel > 1e-5).mean()),
                roots_max=float(crel.max()), roots_identical=nident / nroot, rf_trace_max=float(rrel.max()))
+    if a.get("roots") is not None:
+        # The two classes of the 1e-5 claim: a mid-trajectory chain whose roots of this very step are ALL the
+        # oracle's bit for bit, and a chain that holds a root which is not (one end of the reference's own 1e-6 c bracket
+        # instead of the other: what the reference does to itself between two builds, tests/golden/ill_conditioned_reference.npz)
+        cdev = a["roots"][idx]
+        corc = np.array([r[2][nt:] for r in rm_])
+        same = (cdev == corc).all(axis=1)
+        out.update(n_mid_same_roots=int(same.sum()), n_mid_other_root=int((~same).sum()),
+                   grad_max_same_roots=float(grel[same].max()) if same.any() else 0.0,
+                   grad_max_other_root=float(grel[~same].max()) if (~same).any() else 0.0,
+                   grad_above_1e5_same_roots=int((grel[same] > 1e-5).sum()), grad_above_1e5_other_root=int((grel[~same] > 1e-5).sum()))
+        keep = (~same) | (grel > 5e-6)
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if keep.any() and os.path.isdir(d):      # the models for a look on the CPU (oracle/make_golden.py --ill-conditioned)
+            name = "r06_other_root_" + "".join(ch if ch.isalnum() else "_" for ch in tag) + ".npz"
+            np.savez(os.path.join(d, name), x=xm[keep], g_dev=gm[keep], g_orc=og[keep], c_dev=cdev[keep], c_orc=corc[keep],
+                     grel=grel[keep], chain=idx[keep])
     _report(tag, out)
     return out
 
@@ -132,7 +155,7 @@ def _report(tag, out):
     print(f"{tag}: " + ", ".join(f"{k} {v:.3g}" if isinstance(v, float) else f"{k} {v}" for k, v in out.items()))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
-        path = os.path.join(d, "r05_flow_parity.json")
+        path = os.path.join(d, "r06_flow_parity.json")
         try:
             allr = json.load(open(path))
         except Exception:
@@ -152,7 +175,7 @@ def test_configs1_sampler_step_at_dt_005_on_burned_in_chains(orc, s0):
     bounds = bench.bounds_of(bench.true_model(n))
     smp = HamitonianMC(joint, bounds, bench.TUNED_DT, [5, 20], 10, 991206, 120, 20, myrank=0, name="parity", outdir=None,
                        nchains=nchain, verbose=False, store_syn=False)
-    b, a = _capture(smp, bench.make_models(nchain, 991206, n), s0)
+    b, a = _capture(smp, bench.make_models(nchain, 991206, n), s0, roots_of=lambda: joint._ensure(n).last_roots(nchain))
     ctx = joint._ensure(n)
     assert ctx.stat("swd_exact_secular_evals") > 0 and ctx.stat("swd_warm_items") > 0.9 * s0 * nchain * 40     # the measured mode ran
     rfpar = (bench.RAY_P, nt, 0.1, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
@@ -180,7 +203,7 @@ def test_configs3_dual_averaging_50_layers(orc):
     xs[:, :n] = np.sort(xs[:, :n], axis=1)
     smp = HMCDualAveraging(joint, bounds, 0.1, 10, 20, 0.65, 991206, 100, 20, myrank=0, name="parity", outdir=None,
                            nchains=nchain, verbose=False, store_syn=False)
-    b, a = _capture(smp, xs, s0)
+    b, a = _capture(smp, xs, s0, roots_of=lambda: joint._ensure(n).last_roots(nchain))
     ctx = joint._ensure(n)
     assert ctx.stat("swd_exact_secular_evals") > 0
     rfpar = (bench.RAY_P, nt, 0.1, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
@@ -225,7 +248,7 @@ def test_configs4_trace_of_2048_samples(orc):
     bounds = bench.bounds_of(bench.true_model(n))
     smp = HamitonianMC(joint, bounds, bench.CONFIGS[4]["hmc_dt"], [5, 20], 10, 991206, 60, 20, myrank=0, name="parity",
                        outdir=None, nchains=nchain, verbose=False, store_syn=False)
-    b, a = _capture(smp, bench.make_models(nchain, 991206, n), s0)
+    b, a = _capture(smp, bench.make_models(nchain, 991206, n), s0, roots_of=lambda: joint._ensure(n).last_roots(nchain))
     ctx = joint._ensure(n)
     assert ctx.stat("swd_exact_secular_evals") > 0
     rfpar = (bench.RAY_P, nt, 0.025, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")

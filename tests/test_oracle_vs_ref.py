@@ -62,3 +62,16 @@ def test_rf_routines_vs_compiled_reference(orc):
                 assert np.all(A[1] == 0) and np.all(B[1] == 0) and np.all(A[3] == 0) and np.all(B[3] == 0)
             else:
                 assert rel(B, A) < 1e-12
+
+
+def test_gauss_filter_vs_compiled_reference(orc):
+    """deconit.f90:15-32, the one routine of the time-domain path (besides nextpow2) that calls neither rfft nor irfft:
+    the compiled reference against the numpy restatement.  Everything else of deconit.f90 ends in FFTW3 (absent from the
+    image): the time-domain path stays "parity unpinned" (DESIGN section 6)."""
+    R = O.RefRFCore().L
+    for nt, dt, f0 in ((128, 0.4, 1.5), (512, 0.1, 1.5), (2048, 0.025, 2.5), (64, 0.2, 0.6), (6, 1.0, 1.0)):
+        g = np.zeros(nt // 2 + 1)
+        R.refprobe_gauss_filter(ctypes.c_int(nt), ctypes.c_double(dt), ctypes.c_double(f0),
+                                g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        g0 = O.gauss_filter(nt, dt, f0)
+        assert g[0] == 1.0 and np.abs(g - g0).max() <= 4e-16, float(np.abs(g - g0).max())
