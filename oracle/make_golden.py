@@ -30,9 +30,10 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 
 
-def import_reference():
-    """Import the reference Python with model.lib.{libsurf,librf} injected."""
-    ref_surf = orc.ref_libsurf()
+def import_reference(kind="O2"):
+    """Import the reference Python with model.lib.{libsurf,librf} injected.  kind: which build of the reference's libsurf
+    ("O2" = the oracle's pin; "O0" / "native": oracle/Makefile ref_variants -- one build per process)."""
+    ref_surf = orc.ref_libsurf_variant(kind)
     ref_rf = orc.RefRFCore()
     pkg = types.ModuleType("model")
     pkg.__path__ = [os.path.join(REF, "model")]
@@ -455,8 +456,90 @@ def gen_rf_full(M):
     print("rf_trace_reference.npz:", len(g), "arrays (complete reference librf)")
 
 
+# ---- the reference against itself on ill-conditioned chains (round 6; VERDICT r05 "Next 1") --------------------------------
+BENCH_T = np.linspace(5, 44, 40)
+
+
+def _ill_worker(args):
+    """One build of the reference's libsurf (a process of its own) under the reference's own Python plugins
+    (model/model_surf.py, model/model_rf_swd_vs_thk.py): SWD-only and joint misfit_and_grad of every model."""
+    kind, xs, dobs, nt, dt = args
+    _, _, m_surf, m_rf, m_joint = import_reference(kind)
+    swd = m_surf.SurfWD(tRc=BENCH_T, tRg=None, tLc=None, tLg=None)
+    rf = m_rf.ReceiverFunc(RAY_P, nt, dt, GAUSS, TSHIFT, WATER, "P", "freq")
+    joint = m_joint.Joint_RF_SWD(1.0, 1.0, rf, swd)
+    joint.set_obsdata(dobs[:nt], dobs[nt:])
+    out = []
+    for x in xs:
+        ms, gs, ds, fs = swd.misfit_and_grad(x)
+        mj, gj, dj, fj = joint.misfit_and_grad(x)
+        out.append((float(ms), np.asarray(gs), np.asarray(ds), bool(fs), float(mj), np.asarray(gj), bool(fj)))
+    return out
+
+
+def gen_ill_conditioned(files):
+    """tests/golden/ill_conditioned_reference.npz: burned-in chains of the bench's sampler run (configs[1], dumped by
+    tests/test_gpu_flow_parity.py on the GPU box: gpurun_out/r06_other_root_*.npz) on which the device holds a root that is
+    not the -O2 reference's -- evaluated by THREE builds of the reference's own src/SWD (flang -O2, -O0, -O3 -march=native =
+    the reference's Release flags) under the reference's own plugins.  Shows by how much the reference differs from ITSELF
+    there.  The RF half of the joint values is the usual hybrid (compiled RFModule.f90 core + numpy irfft)."""
+    import multiprocessing as mp
+    d = [np.load(f) for f in files]
+    x = np.vstack([q["x"] for q in d]); g_dev = np.vstack([q["g_dev"] for q in d]); c_dev = np.vstack([q["c_dev"] for q in d])
+    grel_dev = np.concatenate([q["grel"] for q in d])
+    n, nt, dt = x.shape[1] // 2, 512, 0.1
+    thk = np.full(n, 60.0 / n); thk[-1] = 0.0
+    x_true = np.hstack((np.linspace(2.8, 4.6, n), thk))                  # bench.true_model
+    _, _, m_surf, m_rf, m_joint = import_reference("O2")
+    jt = m_joint.Joint_RF_SWD(1.0, 1.0, m_rf.ReceiverFunc(RAY_P, nt, dt, GAUSS, TSHIFT, WATER, "P", "freq"),
+                              m_surf.SurfWD(tRc=BENCH_T, tRg=None, tLc=None, tLg=None))
+    drf, dswd, flag = jt.forward(x_true)
+    dobs = np.hstack((drf, dswd))
+    kinds = ("O2", "O0", "native")
+    nproc = max(1, len(os.sched_getaffinity(0)))
+    parts = [q for q in np.array_split(np.arange(len(x)), max(1, nproc // len(kinds)) * 2) if len(q)]
+    jobs = [(k, x[q], dobs, nt, dt) for k in kinds for q in parts]
+    with mp.get_context("spawn").Pool(nproc, maxtasksperchild=1) as pool:
+        out = pool.map(_ill_worker, jobs, chunksize=1)
+    res = {k: [] for k in kinds}
+    for (k, *_), r in zip(jobs, out):
+        res[k] += r
+    ok = np.array([all(res[k][i][3] and res[k][i][6] for k in kinds) for i in range(len(x))])
+    G = {k: np.array([r[5] for r in res[k]]) for k in kinds}
+    rel = lambda a, b: np.abs(a - b).max(axis=1) / np.abs(b).max(axis=1)
+    self_native, self_O0 = rel(G["native"], G["O2"]), rel(G["O0"], G["O2"])
+    # keep: every chain on which the device or another build of the reference is more than 5e-6 from the -O2 build, and a
+    # seeded sample of the rest
+    keep = ok & ((grel_dev > 5e-6) | (self_native > 5e-6) | (self_O0 > 5e-6))
+    rest = np.nonzero(ok & ~keep)[0]
+    keep[np.random.default_rng(6).choice(rest, size=min(len(rest), 32), replace=False)] = True
+    sel = np.nonzero(keep)[0]
+    g = {"x": x[sel], "dobs": dobs, "t": BENCH_T, "nt": np.array(nt), "dt": np.array(dt),
+         "device_joint_grad": g_dev[sel], "device_roots": c_dev[sel],
+         "n_chains_evaluated": np.array(len(x)), "n_mid_trajectory_chains_compared": np.array(12288)}
+    for k in kinds:
+        g[f"{k}/swd_misfit"] = np.array([res[k][i][0] for i in sel])
+        g[f"{k}/swd_grad"] = np.array([res[k][i][1] for i in sel])
+        g[f"{k}/roots"] = np.array([res[k][i][2] for i in sel])
+        g[f"{k}/joint_misfit_hybrid"] = np.array([res[k][i][4] for i in sel])
+        g[f"{k}/joint_grad_hybrid"] = G[k][sel]
+    # the statistics over ALL evaluated chains (the fixture keeps a subset)
+    cO2 = np.array([r[2] for r in res["O2"]])
+    for k, sd in (("native", self_native), ("O0", self_O0)):
+        ck = np.array([r[2] for r in res[k]])
+        g[f"stats/{k}_vs_O2"] = np.array([int(ok.sum()), int(((ck != cO2).any(axis=1) & ok).sum()), float(sd[ok].max()),
+                                          int((sd[ok] > 1e-5).sum()), int((sd[ok] > 1e-6).sum())])
+    g["stats/device_vs_O2"] = np.array([int(ok.sum()), int(ok.sum()), float(grel_dev[ok].max()), int((grel_dev[ok] > 1e-5).sum()),
+                                        int((grel_dev[ok] > 1e-6).sum())])
+    np.savez_compressed(os.path.join(OUT, "ill_conditioned_reference.npz"), **g)
+    print("ill_conditioned_reference.npz:", len(sel), "of", len(x), "chains;",
+          {k: g[k].tolist() for k in g if k.startswith("stats/")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--ill-conditioned" in sys.argv:      # (round 6) python3 oracle/make_golden.py --ill-conditioned gpurun_out/r06_other_root_*.npz
+        return gen_ill_conditioned([a for a in sys.argv[1:] if a.endswith(".npz")])
     ref_surf, ref_rf, m_surf, m_rf, m_joint = import_reference()
     M = models()
     if "--modes-only" in sys.argv:           # (added in round 3: leaves the other fixture files as they are)

@@ -132,6 +132,34 @@ class _LibSurf:
         return c, ka, kb, kr, kh, ierr != 1
 
 
+def rayleigh_kernels_at_roots(thk, vp, vs, rho, period, c):
+    """The reference's eigenfunction pass (sregn96, sregn96.f90:1637-1745, through orc_sregn96) at GIVEN phase velocities c
+    instead of the ones its own root search would find: (dcda, dcdb, dcdr, dcdh) [nper][n] as _SurfKernel fills them for "Rc"
+    (surfdisp.cpp:223-227).  Parity tests use it to separate what a root's value does to the kernels from everything else."""
+    (h, a, b, r), t = _LibSurf._prep(thk, vp, vs, rho, period)
+    n, nt = len(h), len(t)
+    c = np.ascontiguousarray(np.asarray(c, dtype=np.float64))
+    ka, kb, kr, kh = (np.zeros((nt, n)) for _ in range(4))
+    L = lib()
+    cg = ctypes.c_double(0.0)
+    dummy = np.zeros(n)
+    for k in range(nt):
+        L.orc_sregn96(_f(h), _f(a), _f(b), _f(r), ctypes.c_int(n), ctypes.c_double(t[k]), ctypes.c_double(c[k]),
+                      ctypes.byref(cg), _d(dummy), _d(dummy), _d(dummy), _d(dummy), _d(ka[k]), _d(kb[k]), _d(kh[k]), _d(kr[k]))
+    return ka, kb, kr, kh
+
+
+def swd_misfit_and_grad_at_roots(x, period, c, dobs):
+    """SurfWD.misfit_and_grad (model/model_surf.py:155-228) for an Rc-only plugin with the roots GIVEN (see above)."""
+    n = len(x) // 2
+    vs, thk = x[:n], x[n:]
+    vp, rho, dadb, drda = empirical_relation(vs)
+    ka, kb, kr, kh = rayleigh_kernels_at_roots(thk, vp, vs, rho, period, c)
+    kernel = kb + ka * dadb + kr * drda * dadb
+    r = np.asarray(c, dtype=np.float64) - dobs
+    return 0.5 * np.sum(r**2), np.hstack((r @ kernel, r @ kh))
+
+
 def _rf_type(rf_type, time_shift):
     if rf_type in ("P", "p"):
         return 1, time_shift

@@ -102,6 +102,40 @@ RFS_HD void fm_sincos(double x, double* sn, double* cs) {
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// The same sine / cosine with the twelve polynomial coefficients handed in by the caller, who holds them in VECTOR registers
+// (fm_vc_load, once per kernel): a kernel whose layer loop keeps more 64-bit constants alive than the scalar register file
+// takes (k_swd_exact: two exponentials and two sine / cosine pairs side by side) otherwise re-reads the spilled ones with
+// v_readlane in every layer -- 24 of 361 vector instructions.  Same operations in the same order: same numbers bit for bit.
+struct FmVC { double s[6], c[6]; };
+RFS_HD FmVC fm_vc_load() {
+    FmVC k;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        k.s[i] = FM_SIN_C[i]; k.c[i] = FM_COS_C[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(k.s[i]));      // (opaque to the compiler from here on: stays in vector registers)
+        asm volatile("" : "+v"(k.c[i]));
+#endif
+    }
+    return k;
+}
+RFS_HD void fm_sincos_vc(double x, const FmVC& k, double* sn, double* cs) {
+    const double n = rint(x * FM_RED_C[3]);
+    double r = ::fma(-n, FM_RED_C[4], x);
+    r = ::fma(-n, FM_RED_C[5], r);
+    r = ::fma(-n, -1.49738490485916983294e-33, r);
+    const double z = r * r;
+    double ps = k.s[0], pc = k.c[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++) { ps = ::fma(ps, z, k.s[i]); pc = ::fma(pc, z, k.c[i]); }
+    const double s0 = ::fma(ps * z, r, r);
+    const double c0 = ::fma(pc * z, z, ::fma(-0.5, z, 1.0));
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 struct cplx {
     double re, im;
 };

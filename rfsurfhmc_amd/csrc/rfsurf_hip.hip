@@ -831,7 +831,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         const int wb1 = c->warm_budgets % 100, wb2 = (c->warm_budgets / 100) % 100, wb3 = (c->warm_budgets / 10000) % 100;
         const bool rounds = wb1 > 0;
         const size_t items_max = (size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain;
-        const int spcap = rounds ? (int)std::min<size_t>(std::max<size_t>(4096, items_max / 2), (size_t)1 << 30) : 1;
+        // (measured need: a few per cent of the items; a list that overflows is not an error -- the searches it cannot take finish
+        // in place, test_warm_search_in_rounds_... runs that path -- so a quarter of the items is plenty: 152 B a slot, two lists)
+        const int spcap = rounds ? (int)std::min<size_t>(std::max<size_t>(4096, items_max / 4), (size_t)1 << 30) : 1;
         const size_t spbytes = (size_t)spcap * (WARM_SPILL_ND + 2) * 8;
         ENSURE(c, c->wspA, spbytes); ENSURE(c, c->wspB, spbytes); ENSURE(c, c->wspc, 8 * sizeof(int));
         auto spill = [&](Buf& bf, int ci) {
@@ -1557,17 +1559,25 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     // (RFS_CTX_OPTS="name=value,name=value" in the environment: options every new context starts with -- for A/B runs of
     // scripts that build their contexts themselves; unknown names are reported on stderr and ignored)
     if (const char* e = getenv("RFS_CTX_OPTS")) {
-        std::string all(e);
+        std::string all(e), applied;
         size_t p0 = 0;
         while (p0 < all.size()) {
             size_t p1 = all.find(',', p0);
             if (p1 == std::string::npos) p1 = all.size();
             const std::string kv = all.substr(p0, p1 - p0);
             const size_t eq = kv.find('=');
-            if (eq != std::string::npos && rfs_set_option(c, kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)) != RFS_OK)
+            char* endp = nullptr;
+            const long v = eq != std::string::npos ? strtol(kv.c_str() + eq + 1, &endp, 10) : 0;
+            if (kv.empty()) {}
+            else if (eq == std::string::npos || eq == 0 || endp == kv.c_str() + eq + 1 || *endp != '\0')
+                fprintf(stderr, "rfsurf: RFS_CTX_OPTS: malformed entry '%s' (want name=integer) -- ignored\n", kv.c_str());
+            else if (rfs_set_option(c, kv.substr(0, eq).c_str(), (int)v) != RFS_OK)
                 fprintf(stderr, "rfsurf: RFS_CTX_OPTS: %s not applied (%s)\n", kv.c_str(), c->err.c_str());
+            else applied += (applied.empty() ? "" : ", ") + kv;
             p0 = p1 + 1;
         }
+        // (these settings move parity-relevant behaviour: never silently)
+        if (!applied.empty()) fprintf(stderr, "rfsurf: RFS_CTX_OPTS applied to a new context: %s\n", applied.c_str());
     }
     *out = c;
     return RFS_OK;
@@ -1765,6 +1775,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_warm_last_round_coop")) { c->warm_coop = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_warm_round_budgets")) {
         if (value < 0 || value > 999999) return fail(c, RFS_ERR_ARG, "swd_warm_round_budgets must be b1 + 100 b2 + 10000 b3 with 0 <= b < 100");
+        // a later round without the one before it never runs (the launches chain b1 -> b2 -> b3): say so instead of dropping it
+        const int b1 = value % 100, b2 = (value / 100) % 100, b3 = (value / 10000) % 100;
+        if ((b1 == 0 && (b2 > 0 || b3 > 0)) || (b2 == 0 && b3 > 0))
+            return fail(c, RFS_ERR_ARG, "swd_warm_round_budgets: a round needs the one before it (b1 = 0 with b2 > 0, or b2 = 0 with b3 > 0)");
         c->warm_budgets = (int)value; return RFS_OK;
     }
     if (!strcmp(name, "flow_skip_idle")) { c->flow_skip_idle = value != 0; return RFS_OK; }

@@ -1736,6 +1736,7 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float o
     __shared__ double nevtab[24 * 64];         // Neville tables of the wavefront's lanes, one column per lane
     ExactGroup x;
     x.phase = ExactGroup::X_DONE; x.nev = 0; x.cause = 0; x.creq = 1.0; x.omega = 1.0;
+    const FmVC vc = fm_vc_load();          // sine / cosine coefficients in vector registers for the whole kernel (cplx.hpp)
     if (live) {
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         float bmx = 0.f;
@@ -1744,7 +1745,7 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float o
     }
     while (__any(x.active())) {
         if (x.active()) {
-            x.advance(swd_secular_family<F, true>(n, loadL, x.omega, x.creq));      // (DUAL: this kernel is short of wavefronts)
+            x.advance(swd_secular_family<F, true>(n, loadL, x.omega, x.creq, &vc));      // (DUAL: this kernel is short of wavefronts)
             if (x.phase == ExactGroup::X_DONE) {
                 if (x.wanted()) croot[e0 + (size_t)x.k * nchain] = (double)(float)x.root();       // surfdisp96.f:302
                 x.next(approx, om);                     // (the last period: stays X_DONE)

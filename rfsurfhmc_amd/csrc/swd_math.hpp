@@ -264,7 +264,7 @@ RFS_HD void swd_trig_split(double wvno, double xk, double dpth, double& ex, doub
 // velocities below the P velocities hardly ever need it.)
 RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
                             double& pex, double& cosp, double& w, double& x, double& eha,
-                            double& sex, double& cosq, double& y, double& z, double& ehb) {
+                            double& sex, double& cosq, double& y, double& z, double& ehb, const FmVC* vc = nullptr) {
     const double va = (wvno + xka) * fabs(wvno - xka), vb = (wvno + xkb) * fabs(wvno - xkb);
     const bool osca = wvno < xka, oscb = wvno < xkb;
     const double ira = rsqrt_p(va), irb = rsqrt_p(vb);
@@ -276,8 +276,8 @@ RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__any(osca))
 #endif
-    { double sn, cs; fm_sincos(pa, &sn, &cs); csa = osca ? cs : csa; sna = osca ? sn : sna; }
-    { double sn, cs; fm_sincos(pb, &sn, &cs); csb = oscb ? cs : csb; snb = oscb ? sn : snb; }
+    { double sn, cs; if (vc) fm_sincos_vc(pa, *vc, &sn, &cs); else fm_sincos(pa, &sn, &cs); csa = osca ? cs : csa; sna = osca ? sn : sna; }
+    { double sn, cs; if (vc) fm_sincos_vc(pb, *vc, &sn, &cs); else fm_sincos(pb, &sn, &cs); csb = oscb ? cs : csb; snb = oscb ? sn : snb; }
     eha = osca ? 1.0 : ea; ehb = oscb ? 1.0 : eb;
     cosp = csa; w = sna * ira; x = (osca ? -ra : ra) * sna; pex = osca ? 0.0 : pa;
     cosq = csb; y = snb * irb; z = (oscb ? -rb : rb) * snb; sex = oscb ? 0.0 : pb;
@@ -293,12 +293,12 @@ RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
 
 template <bool DUAL = false>
 RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega,
-                              double ent[SWD_NENT]) {
+                              double ent[SWD_NENT], const FmVC* vc = nullptr) {
     double xka = omega * L.ia, xkb = omega * L.ib;
     double t = L.b * iomega;
     double gammk = 2.0 * t * t, gam = gammk * wvno2;
     double pex, sex, cosp, w, x, cosq, y, z, eha, ehb;
-    if (DUAL) swd_trig_split2(wvno, xka, xkb, L.d, pex, cosp, w, x, eha, sex, cosq, y, z, ehb);
+    if (DUAL) swd_trig_split2(wvno, xka, xkb, L.d, pex, cosp, w, x, eha, sex, cosq, y, z, ehb, vc);
     else {
         swd_trig_split(wvno, xka, L.d, pex, cosp, w, x, eha);
         swd_trig_split(wvno, xkb, L.d, sex, cosq, y, z, ehb);
@@ -393,8 +393,9 @@ struct SwdRayFamily {
         swd_layer_entries<false>(L, wvno, wvno2, omega, iomega, ent);
     }
     // the same numbers with the two wave types' functions side by side (swd_trig_split2): for kernels short of wavefronts
-    static RFS_HD void entries_dual(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent) {
-        swd_layer_entries<true>(L, wvno, wvno2, omega, iomega, ent);
+    static RFS_HD void entries_dual(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent,
+                                    const FmVC* vc = nullptr) {
+        swd_layer_entries<true>(L, wvno, wvno2, omega, iomega, ent, vc);
     }
     static RFS_HD void halfspace(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* e) {
         swd_halfspace_e(L, wvno, wvno2, omega, iomega, e);
@@ -413,7 +414,8 @@ struct SwdLoveFamily {
         ent[1] = (L.rho * L.b * L.b) * z;                     // mu z
         ent[2] = y * (L.irho * L.ib * L.ib);                  // y / mu
     }
-    static RFS_HD void entries_dual(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent) {
+    static RFS_HD void entries_dual(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double* ent,
+                                    const FmVC* = nullptr) {
         entries(L, wvno, wvno2, omega, iomega, ent);
     }
     static RFS_HD void halfspace(const SwdLayerC& L, double wvno, double, double omega, double, double* e) {
@@ -1252,20 +1254,27 @@ using ExactGroup = ExactGroupT<true>;
 // the arithmetic of the lanes-per-item search (raw recurrence, power-of-two rescale every eighth layer, one final
 // normalisation), evaluated by ONE lane.
 template <class F, bool DUAL = false, class LoadL>
-RFS_HD double swd_secular_family(int n, const LoadL& loadL, double omega_raw, double c) {
+RFS_HD double swd_secular_family(int n, const LoadL& loadL, double omega_raw, double c, const FmVC* vc = nullptr) {
     const double omega = omega_raw < 1.0e-4 ? 1.0e-4 : omega_raw, iomega = 1.0 / omega;
     const double wvno = omega_raw / c, wvno2 = wvno * wvno, tt = -2.0 * wvno2;
     double e[F::NV];
     F::halfspace(loadL(n - 1), wvno, wvno2, omega, iomega, e);
-    SwdLayerC L = loadL(n - 2 >= 0 ? n - 2 : 0);
-    for (int m = n - 2; m >= 0; m--) {
-        const SwdLayerC Ln = loadL(m > 0 ? m - 1 : 0);      // next layer's constants on their way during this layer's math
+    // two layers per trip, their constants in two sets of registers that are loaded in turn (the next layer's are on their way
+    // during this layer's arithmetic): a single rotating set costs six register copies per layer
+    SwdLayerC La = loadL(n - 2 >= 0 ? n - 2 : 0);
+    auto layer = [&](const SwdLayerC& L, int m) {
         double ent[F::NENT];
-        if (DUAL) F::entries_dual(L, wvno, wvno2, omega, iomega, ent);
+        if (DUAL) F::entries_dual(L, wvno, wvno2, omega, iomega, ent, vc);
         else F::entries(L, wvno, wvno2, omega, iomega, ent);
         F::apply(e, ent, tt);
         if ((m & 7) == 0) swd_rescale_pow2_n<F::NV>(e);
-        L = Ln;
+    };
+    for (int m = n - 2; m >= 0; m -= 2) {
+        const SwdLayerC Lb = loadL(m > 0 ? m - 1 : 0);
+        layer(La, m);
+        if (m == 0) break;
+        La = loadL(m > 1 ? m - 2 : 0);
+        layer(Lb, m - 1);
     }
     return swd_finish_n<F::NV>(e);
 }

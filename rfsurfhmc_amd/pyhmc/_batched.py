@@ -422,6 +422,7 @@ def with_host_threads(fn):
 
 
 _SIDE_STREAMS = {}
+ASYNC_MIN_CHAINS = int(os.environ.get("RFS_ASYNC_MIN_CHAINS", "64"))      # populations below this keep hand-backs in the foreground (run_flow)
 
 
 LEGACY_TAIL = os.environ.get("RFS_FLOW_LEGACY_TAIL") == "1"      # (A/B runs: round 4's staging copy + immediate wait between two steps)
@@ -464,6 +465,11 @@ def run_flow(model, st, process_done, active, fetch_syn=True, pipeline=True, max
     dev = st["x"].device
     # (events and side streams below belong to the state's device, whichever device is current in the caller)
     ctx = getattr(model, "_ctx", None)
+    # (a handful of chains: a chain that sits steps out while its search runs in the background leaves the device with
+    # nothing to do -- every such step still costs its dozen launches, 0.75 ms for ONE chain -- so small populations take
+    # the search in the foreground: configs[0], one chain at dt 0.1, 3.2 -> 1.8 ms per evaluation)
+    if st["x"].shape[0] < ASYNC_MIN_CHAINS:
+        async_handback = False
     if ctx is not None and dev.type == "cuda":
         ctx.set_option("flow_async_handback", int(bool(async_handback) and os.environ.get("RFS_FLOW_ASYNC", "1") != "0"))
     try:

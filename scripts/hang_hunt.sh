@@ -1,5 +1,5 @@
 #!/bin/bash
-# The two tests next to which one suite run stopped (EXPERIMENTS.md, round 5), N times each in fresh processes, with the
+# The two tests next to which one suite run stopped (EXPERIMENTS.md, "One run of the GPU suite stopped making progress"), N times each in fresh processes, with the
 # watchdog thread at 90 s: a hang prints every thread's stack.
 mkdir -p gpurun_out
 n=0

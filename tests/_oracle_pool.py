@@ -50,6 +50,31 @@ def _roots_worker(args):
     return c, ok
 
 
+def _at_roots_worker(args):
+    xs, cs, rfpar, t, drf, dswd = args
+    O = _orc()
+    ro = O.ReceiverFunc(*rfpar)
+    ro.set_obsdata(drf)
+    wt = len(drf) / len(dswd)                    # model_rf_swd_vs_thk.py:79, sigma1 = sigma2
+    out = []
+    for x, c in zip(xs, cs):
+        mr, gr, dr = ro.misfit_and_grad(x)
+        ms, gs = O.swd_misfit_and_grad_at_roots(x, t, c, dswd)
+        out.append(gr + wt * gs)
+    return out
+
+
+def joint_grad_at_roots_batch(xs, cs, rfpar, t, drf, dswd):
+    """Joint gradients with the oracle's eigenfunction pass evaluated at GIVEN Rc roots cs[i] (oracle.swd_misfit_and_grad_at_roots)."""
+    if len(xs) == 0:
+        return np.zeros((0, xs.shape[1]))
+    p = nproc()
+    parts = [q for q in np.array_split(np.arange(len(xs)), p * 2) if len(q)]
+    with _ctx().Pool(p) as pool:
+        res = pool.map(_at_roots_worker, [(xs[q], cs[q], rfpar, t, drf, dswd) for q in parts])
+    return np.array([r for part in res for r in part])
+
+
 def nproc():
     return max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 

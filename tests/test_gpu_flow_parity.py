@@ -20,7 +20,9 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (the longest tests of the suite: their own limit, so that the global 600 s of pytest.ini -- whose watchdog ends the whole run --
+# does not cut a healthy run on a slower box)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
 KEYS = ("x", "p", "rem", "fresh", "dt", "ok")
 
@@ -115,7 +117,6 @@ def _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, nmax, tag):
     og = np.array([r[1] for r in rm_])
     badrow = ~(np.isfinite(og).all(axis=1) & np.isfinite(gm).all(axis=1))
     if badrow.any():                             # keep the models for a look on the CPU
-        import os
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         if os.path.isdir(d):
             np.savez(os.path.join(d, "r05_nonfinite_" + tag.split()[0].replace("[", "").replace("]", "") + ".npz"), x=xm[badrow], g_dev=gm[badrow], g_orc=og[badrow])
@@ -127,7 +128,16 @@ def _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, nmax, tag):
                misfit_max=float(mrel.max()), misfit_p99=float(np.quantile(mrel, 0.99)), misfit_share_above_1e5=float((mrel > 1e-5).mean()),
                grad_max=float(grel.max()), grad_p99=float(np.quantile(grel, 0.99)), grad_share_above_1e5=float((grel > 1e-5).mean()),
                roots_max=float(crel.max()), roots_identical=nident / nroot, rf_trace_max=float(rrel.max()))
-    if a.get("roots") is not None:
+    _classes(out, a, idx, xm, gm, og, rm_, grel, rfpar, t, joint, nt, tag)
+    _report(tag, out)
+    return out
+
+
+def _classes(out, a, idx, xm, gm, og, rm_, grel, rfpar, t, joint, nt, tag):
+    """Adds the per-class figures (see _the_two_classes) to `out`; dumps the chains that hold another root."""
+    if a.get("roots") is None:
+        return
+    if True:
         # The two classes of the 1e-5 claim (DESIGN section 6): a mid-trajectory chain whose roots of this very step are ALL the
         # oracle's bit for bit, and a chain that holds a root which is not (one end of the reference's own 1e-6 c bracket
         # instead of the other: what the reference does to itself between two builds, tests/golden/ill_conditioned_reference.npz)
@@ -138,20 +148,25 @@ def _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, nmax, tag):
                    grad_max_same_roots=float(grel[same].max()) if same.any() else 0.0,
                    grad_max_other_root=float(grel[~same].max()) if (~same).any() else 0.0,
                    grad_above_1e5_same_roots=int((grel[same] > 1e-5).sum()), grad_above_1e5_other_root=int((grel[~same] > 1e-5).sum()))
+        # ... and for the second class: the device's gradient against the reference's eigenfunction pass AT THE DEVICE'S ROOTS --
+        # what is left once the choice between the two ends of the bracket is taken out
+        from _oracle_pool import joint_grad_at_roots_batch
+        oth = np.nonzero(~same)[0]
+        g_at = joint_grad_at_roots_batch(xm[oth], cdev[oth], rfpar, t, joint.dobs[:nt], joint.dobs[nt:])
+        at_rel = np.abs(gm[oth] - g_at).max(axis=1) / np.abs(g_at).max(axis=1) if len(oth) else np.zeros(0)
+        out.update(grad_max_at_device_roots=float(at_rel.max()) if len(oth) else 0.0,
+                   other_root_max_distance=float((np.abs(cdev[oth] - corc[oth]) / corc[oth]).max()) if len(oth) else 0.0)
         keep = (~same) | (grel > 5e-6)
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         if keep.any() and os.path.isdir(d):      # the models for a look on the CPU (oracle/make_golden.py --ill-conditioned)
             name = "r06_other_root_" + "".join(ch if ch.isalnum() else "_" for ch in tag) + ".npz"
             np.savez(os.path.join(d, name), x=xm[keep], g_dev=gm[keep], g_orc=og[keep], c_dev=cdev[keep], c_orc=corc[keep],
                      grel=grel[keep], chain=idx[keep])
-    _report(tag, out)
-    return out
 
 
 def _report(tag, out):
     """Print the figures and keep them (gpurun_out/r05_flow_parity.json on the GPU box: DESIGN section 6 quotes them)."""
     import json
-    import os
     print(f"{tag}: " + ", ".join(f"{k} {v:.3g}" if isinstance(v, float) else f"{k} {v}" for k, v in out.items()))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
@@ -182,11 +197,26 @@ def test_configs1_sampler_step_at_dt_005_on_burned_in_chains(orc, s0):
     r = _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, 512, f"configs[1] dt 0.05 step {s0}")
     assert r["unsorted_share"] > 0.2                      # burned in: velocity inversions are the rule, not the exception
     assert r["rf_trace_max"] <= 1e-9
-    # measured (round 5, two boxes): roots <= 9.4e-7 c, 99.8-99.9 % of them bit-identical; misfit max 2.7e-6, p99 1.1e-6;
-    # gradient max 7.2e-6, p99 2.3e-6; nothing above the contract's 1e-5
-    assert r["roots_max"] <= 2.2e-6 and r["roots_identical"] >= 0.995
+    assert r["roots_max"] <= 1.2e-6 and r["roots_identical"] >= 0.995
     assert r["misfit_max"] <= 1e-5 and r["misfit_p99"] <= 3e-6 and r["misfit_share_above_1e5"] == 0.0
-    assert r["grad_max"] <= 3e-5 and r["grad_p99"] <= 1e-5 and r["grad_share_above_1e5"] <= 0.005
+    _the_two_classes(r)
+
+
+def _the_two_classes(r, min_same=0.9):
+    """The 1e-5 contract, class by class (measured over 12 288 mid-trajectory chains of four device steps:
+    11 629 with the oracle's roots -- gradient within 2.3e-8 --, 659 with another root, 25 of those above 1e-5, max 2.2e-5).
+      * a chain whose roots of this step are ALL the oracle's bit for bit: gradient within 1e-6.  No exceptions.
+      * a chain that holds another root: every root within the reference's own refinement tolerance of the oracle's (1e-6 c,
+        surfdisp96.f:627, + float32 rounding), the gradient equal to the reference's eigenfunction pass AT those roots (1e-8:
+        no exceptions), and against the -O2 build's gradient inside the scatter of the reference's own builds on such chains
+        (tests/golden/ill_conditioned_reference.npz: -O3 -march=native against -O2 up to 1.9e-5; tests/test_ill_conditioned.py)."""
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ill_conditioned_reference.npz"))
+    self_max = float(fix["stats/native_vs_O2"][2])            # the reference against itself on this class of chains
+    assert r["n_mid_same_roots"] >= min_same * r["n_mid"]
+    assert r["grad_above_1e5_same_roots"] == 0 and r["grad_max_same_roots"] <= 1e-6
+    assert r["other_root_max_distance"] <= 1.2e-6
+    assert r["grad_max_at_device_roots"] <= 1e-8
+    assert r["grad_max_other_root"] <= 1.5 * self_max and r["grad_p99"] <= 1e-5
 
 
 def test_configs3_dual_averaging_50_layers(orc):
@@ -209,9 +239,9 @@ def test_configs3_dual_averaging_50_layers(orc):
     rfpar = (bench.RAY_P, nt, 0.1, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
     # (the step sizes dual averaging settles on are small and the trajectories long: few chains complete in one given step)
     r = _against_the_oracle_loose_end(b, a, bounds, joint, t, rfpar, nt, 256, "configs[3] DA n = 50 step 150")
-    assert r["rf_trace_max"] <= 1e-9 and r["roots_max"] <= 2.2e-6
+    assert r["rf_trace_max"] <= 1e-9 and r["roots_max"] <= 1.2e-6
     assert r["misfit_max"] <= 1e-5
-    assert r["grad_max"] <= 3e-5 and r["grad_p99"] <= 1e-5
+    _the_two_classes(r)
 
 
 def _against_the_oracle_loose_end(b, a, bounds, joint, t, rfpar, nt, nmax, tag):
@@ -234,6 +264,7 @@ def _against_the_oracle_loose_end(b, a, bounds, joint, t, rfpar, nt, nmax, tag):
     og = np.array([r[1] for r in rm_])
     grel = np.abs(gm - og).max(axis=1) / np.abs(og).max(axis=1)
     out.update(grad_max=float(grel.max()), grad_p99=float(np.quantile(grel, 0.99)), grad_share_above_1e5=float((grel > 1e-5).mean()))
+    _classes(out, a, idx, xm, gm, og, rm_, grel, rfpar, t, joint, nt, tag)
     _report(tag, out)
     return out
 
@@ -253,6 +284,7 @@ def test_configs4_trace_of_2048_samples(orc):
     assert ctx.stat("swd_exact_secular_evals") > 0
     rfpar = (bench.RAY_P, nt, 0.025, bench.GAUSS, bench.TSHIFT, bench.WATER, "P", "freq")
     r = _against_the_oracle(b, a, bounds, joint, t, rfpar, nt, 256, "configs[4] nt 2048 step 120")
-    assert r["rf_trace_max"] <= 1e-9 and r["roots_max"] <= 2.2e-6
-    assert r["misfit_max"] <= 3e-5 and r["misfit_p99"] <= 1e-5
-    assert r["grad_max"] <= 3e-5 and r["grad_p99"] <= 1e-5
+    assert r["rf_trace_max"] <= 1e-9 and r["roots_max"] <= 1.2e-6
+    # (nt = 2048: the RF half of the misfit is four times as many samples, measured misfit max 6.7e-7)
+    assert r["misfit_max"] <= 1e-5 and r["misfit_p99"] <= 3e-6
+    _the_two_classes(r)

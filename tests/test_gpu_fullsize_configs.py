@@ -5,7 +5,9 @@ the sampler itself: a dual-averaging flow run with per-chain dt and L whose chai
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (the longest tests of the suite: their own limit, so that the global 600 s of pytest.ini -- whose watchdog ends the whole run --
+# does not cut a healthy run on a slower box)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
 
 def rel(a, b):

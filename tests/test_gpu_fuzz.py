@@ -4,7 +4,9 @@ goes through rfs_joint_setup2 + rfs_joint_misfit_grad with a small batch."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (the longest tests of the suite: their own limit, so that the global 600 s of pytest.ini -- whose watchdog ends the whole run --
+# does not cut a healthy run on a slower box)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
 
 def rel(a, b):

@@ -19,7 +19,9 @@ turns the converged roots into the reference's roots.  What is checked here:
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (the longest tests of the suite: their own limit, so that the global 600 s of pytest.ini -- whose watchdog ends the whole run --
+# does not cut a healthy run on a slower box)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
 
 def rel(a, b):
@@ -557,7 +559,8 @@ def test_warm_search_in_rounds_is_the_one_round_search_bit_for_bit():
     finally:
         ctx.set_option("swd_warm_round_budgets", 303); ctx.set_option("swd_warm_last_round_coop", 1)
     ref = runs[(0, 1)]
-    assert ref[5] == 0 and runs[(302, 1)][5] > 0 and runs[(10101, 1)][5] > runs[(302, 1)][5]         # (the rounds did take place)
+    # (the rounds did take place; budgets of one evaluation overflow the lists -- a quarter of the items -- so their count is capped)
+    assert ref[5] == 0 and runs[(302, 1)][5] > 0 and runs[(10101, 1)][5] > 0
     for budgets in ((302, 1), (302, 0), (10101, 1), (303, 1), (4, 1), (5, 0)):
         r = runs[budgets]
         assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), budgets
