@@ -711,8 +711,9 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
             barrier()
             if "dom" in marks:
                 gt.read()                                          # (drop the step between the two phases)
-            marks["t0"] = time.perf_counter()
+            marks["t0"] = time.perf_counter(); marks["cpu0"] = time.process_time()
         if s == burn + K:
+            marks["cpu1"] = time.process_time()
             ctx.check(ctx.L.rfs_synchronize(ctx.h))
             barrier()
             marks["t1"] = time.perf_counter()
@@ -765,6 +766,9 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
         "accept_ratio": nacc / max(ntraj, 1), "trajectories_completed": ntraj,
         "root_search_mode": mode, "chains_in_a_trajectory_per_step": evals / K,
         "misfit_median_at_the_end": marks["U"], "root_search_failures": marks["fail"],
+        # CPU time of this rank's process (all its threads) per device step over the timed window: what 8 ranks on one node's
+        # host cores have to find room for (a rank is one Python thread + the HIP runtime's helpers)
+        "host_cpu_ms_per_step": (marks["cpu1"] - marks["cpu0"]) / K * 1e3,
         "root_search": {"warm_started_items_per_step": d["swd_warm_items"] / K, "items_per_step": nchain * nper_items,
                         "secular_evals_per_item_warm_start_and_branch_test": d["swd_warm_secular_evals"] / items,
                         "secular_evals_per_item_reference_root_stage": d["swd_exact_secular_evals"] / items,
@@ -1046,7 +1050,7 @@ def run_rank(args):
     }
     if rep.get("roofline_fp64"):
         res["roofline_fp64"] = {k: rep["roofline_fp64"][k] for k in ("bound", "achieved_tflops", "peak", "unit", "frac", "fp64_flops_per_eval")}
-    for k in ("kernel_ms_per_step", "kernel_launches_per_step", "valu_issue", "root_search", "kernel_ms_note",
+    for k in ("kernel_ms_per_step", "kernel_launches_per_step", "valu_issue", "root_search", "kernel_ms_note", "host_cpu_ms_per_step",
               "chains_in_a_trajectory_per_step", "misfit_median_at_the_end", "trajectories_completed",
               "adapted_dt_quantiles_5_50_95", "adapted_dt_max", "L_quantiles_5_50_95", "L_cap", "trajectory_lengths_clamped_to_L_cap",
               "adapting_trajectories_per_chain", "share_of_chains_past_adaptation_at_window_start", "burn_in_steps"):

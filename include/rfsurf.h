@@ -222,11 +222,47 @@ int rfs_flow_step2(rfs_ctx* ctx, int nchain, double* x, double* p, const double*
                    const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                    double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next);
 
+/* rfs_flow_step2 that also hands the caller's books what they need of every chain that COMPLETED a trajectory in the call, packed
+ * densely into memory the host can read -- instead of the caller copying the done flags down, building index lists, copying them
+ * up and gathering rows (pyhmc's loop: a dozen small copies and index kernels per step; with this, none).
+ *   records->buf: memory the DEVICE can write and the HOST can read: pinned host memory (hipHostMalloc / a torch tensor with
+ *   pin_memory=True: mapped into the device's address space at the same address), zero-filled by the caller, used as a RING of
+ *   `cap` records (cap >= 2 nchain) of stride 8 + 2 nlayer (+ ndata with want_dsyn) float64 each:
+ *     [0] chain, [1] done code (1: waits for the caller, as in rfs_flow_step; 2 / 3: rejected / accepted and restarted on the
+ *     device from its deposit), [2] ok, [3] Ucur, [4] Hcur, [5] Hnew, [6] Unew, [7] `stamp` of the call that wrote the record,
+ *     [8 ..) the end model, [8 + 2 nlayer ..) its synthetics.  For done codes 2 / 3 these are the values rfs_flow_next parks in
+ *     res_val / res_x / res_dsyn.
+ *   Record number k since the last `reset` lies in slot k % cap.  The caller gives every call its own non-zero stamp, keeps a
+ *   read cursor and -- behind an event recorded after the call -- takes records while their [7] equals that call's stamp (what
+ *   follows is a stale record of an earlier lap or one of the NEXT call, which may already be running: cap >= 2 nchain keeps
+ *   the call being read and the one under way apart).  The order of a call's records is not defined (sort by chain).
+ *   reset != 0: the ring starts over at slot 0 with this call (first call of a run).  records == NULL: rfs_flow_step2. */
+typedef struct rfs_flow_records {
+    void* buf;
+    uint64_t bytes;     /* size of buf: >= 8 * cap * stride */
+    int32_t cap;        /* slots of the ring */
+    int32_t want_dsyn;  /* != 0: every record carries the ndata synthetics as well */
+    double stamp;       /* non-zero, different from the stamps of the two calls before */
+    int32_t reset;
+} rfs_flow_records;
+int rfs_flow_step3(rfs_ctx* ctx, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                   double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next, const rfs_flow_records* records);
+/* The deposits of rfs_flow_next for n chains in ONE launch on `hip_stream` (NULL: the context's stream): for i < n, chain idx[i]
+ * gets u[i], pnew[i][2 nlayer], remnew[i] (NULL in the deferred form) and have = 1 -- what pyhmc/hmc.py:246-258 draws for the
+ * trajectory after the one that is running.  idx / u / pnew / remnew: device memory, or pinned host memory mapped into the device
+ * (a few KB read over the link cost less than a copy in front of the launch; above ~64 KB copy first).  The caller orders the
+ * launch before the call in which the chains complete (an event on hip_stream that the calls' stream waits for). */
+int rfs_flow_deposit(rfs_ctx* ctx, void* hip_stream, int nchain, int n, const int32_t* idx, const double* u, const double* pnew,
+                     const int32_t* remnew, const rfs_flow_next* next);
+
 /* What the caller does to the chains that go through the host between two flow steps -- pyhmc/hmc.py:228-276's loop body
  * for a chain whose trajectory ended in a failed evaluation (no acceptance draw: the reference returns early, :154-180), or
  * every finished chain of a run without rfs_flow_next -- in one launch on the context's stream instead of a dozen small
  * copies and scatters between two steps.  All pointers DEVICE: idx1 [n1] chains whose row of x becomes xkeep [n1][2*nlayer]
  * (the model the chain keeps); idx2 [n2] chains that start another trajectory: p <- pnew [n2][2*nlayer], rem <- remnew [n2],
+ * (DEVICE, or pinned host memory mapped into the device: the launch then reads the lists over the link -- right for a few KB,
+ * above ~64 KB copy them to the device first)
  * dt <- dtnew [n2] (NULL: unchanged), fresh = ok = 1 -- or, with pnew NULL, chains the device has already restarted whose
  * length and step size follow a call late (rfs_flow_next.rem == NULL, pyhmc/hmcda.py:280-369): rem and dt only;
  * idx3 [n3] chains whose deposit (rfs_flow_next.have) is withdrawn.

@@ -33,6 +33,11 @@ class FlowNext(ctypes.Structure):      # rfs_flow_next (include/rfsurf.h): devic
                                                "kick")]
 
 
+class FlowRecords(ctypes.Structure):   # rfs_flow_records
+    _fields_ = [("buf", ctypes.c_void_p), ("bytes", ctypes.c_uint64), ("cap", ctypes.c_int32), ("want_dsyn", ctypes.c_int32),
+                ("stamp", ctypes.c_double), ("reset", ctypes.c_int32)]
+
+
 class RfsError(RuntimeError):
     pass
 
@@ -60,6 +65,8 @@ SIGNATURES = {
     "rfs_leapfrog_dev2": (_i, [_vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp] + [_vp] * 8),
     "rfs_flow_step": (_i, [_vp, _i] + [_vp] * 14),
     "rfs_flow_step2": (_i, [_vp, _i] + [_vp] * 14 + [ctypes.POINTER(FlowNext)]),
+    "rfs_flow_step3": (_i, [_vp, _i] + [_vp] * 14 + [ctypes.POINTER(FlowNext), ctypes.POINTER(FlowRecords)]),
+    "rfs_flow_deposit": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(FlowNext)]),
     "rfs_flow_restart": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp] + [_vp] * 7),
     "rfs_set_inverse_mass": (_i, [_vp, _vp]),
     "rfs_ndata": (_i, [_vp]),
@@ -70,7 +77,7 @@ SIGNATURES = {
     "rfs_kernel_ms_sum": (_i, [_vp, _vp, _vp]),
     "rfs_kernel_timeline": (_i, [_vp, _vp, _vp, _vp]),
 }
-_DIAGNOSTIC = {"rfs_kernel_timeline", "rfs_last_roots"}      # (absent from older builds loaded through RFSURF_LIB for A/B runs)
+_DIAGNOSTIC = {"rfs_kernel_timeline", "rfs_last_roots", "rfs_flow_step3", "rfs_flow_deposit"}      # (absent from older builds loaded through RFSURF_LIB for A/B runs)
 
 _LIB = None
 

@@ -108,6 +108,7 @@ struct rfs_ctx {
     bool warm_widen = true;    // option "swd_warm_widen": the warm search may bracket beyond its trust radius (the grid walk then vouches)
     bool flow_skip_idle = true;   // option "flow_skip_idle": idle chains of a flow step are neither continued nor handed back
     const int *f_rem = nullptr, *f_fresh = nullptr, *f_ok = nullptr;   // the flow state's arrays during a flow step (k_swd_warm: idle chains)
+    Buf frec;                  // the device word of rfs_flow_records: records handed out so far (k_flow_post; a ring, never reset between steps)
     Buf fpend;                 // [chain] 1: handed back in the previous flow step (k_flow_post) -- no drift, no warm start this time: its roots are the background search's
     hipEvent_t ev_bg[RFS_BG_SLOTS] = {};
     // TWO run-up periods, origins accepted to 1e-7 c.  Round 5 measured ONE period with 5e-7 c: a sixth less work in the stage
@@ -1593,7 +1594,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -2272,6 +2273,12 @@ int rfs_set_inverse_mass(rfs_ctx* c, const double* minv) {
 int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
                    const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                    double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next) {
+    return rfs_flow_step3(c, nchain, x, p, dt, rem, fresh, bounds, Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, next, nullptr);
+}
+
+int rfs_flow_step3(rfs_ctx* c, int nchain, double* x, double* p, const double* dt, int32_t* rem, int32_t* fresh,
+                   const double* bounds, double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                   double* dsyn_new, int32_t* ok, int32_t* done, const rfs_flow_next* next, const rfs_flow_records* records) {
     if (!c) return RFS_ERR_ARG;
     if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
     TRY(check_batch(c, nchain, c->n));
@@ -2341,9 +2348,21 @@ int rfs_flow_step2(rfs_ctx* c, int nchain, double* x, double* p, const double* d
         ENSURE(c, c->fstat, 64 * sizeof(unsigned long long));
         HIPCHK(c, hipMemsetAsync(c->fstat.p, 0, 64 * sizeof(unsigned long long), c->stream));
     }
+    FlowRec frec{nullptr, nullptr, 0, 0, 0, 0.0};
+    if (records && records->buf) {
+        const int stride = 8 + nx + (records->want_dsyn ? nd : 0);
+        if (records->cap < 2 * nchain || records->bytes < (uint64_t)records->cap * stride * sizeof(double))
+            return fail(c, RFS_ERR_ARG, "rfs_flow_records: a ring of cap >= 2 nchain records of 8 + 2 nlayer [+ ndata] doubles");
+        if (!(records->stamp != 0.0)) return fail(c, RFS_ERR_ARG, "rfs_flow_records: stamp must not be 0 (what an empty slot holds)");
+        if (!c->frec.p || records->reset) {
+            ENSURE(c, c->frec, sizeof(unsigned long long));
+            HIPCHK(c, hipMemsetAsync(c->frec.p, 0, sizeof(unsigned long long), c->stream));
+        }
+        frec = FlowRec{(double*)records->buf, c->frec.as<unsigned long long>(), records->cap, stride, records->want_dsyn ? 1 : 0, records->stamp};
+    }
     hipLaunchKernelGGL(k_flow_post, dim3(nchain), dim3(64), 0, c->stream, nchain, nx, nd, minv, dt, x, U, g, d, fl, p, rem, fresh,
                        Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new, ok, done, fn, c->fstat.as<unsigned long long>(), rr,
-                       need_cur, c->fpend.as<int>(), (int)c->wpar + 1, c->bg_ready);
+                       need_cur, c->fpend.as<int>(), (int)c->wpar + 1, c->bg_ready, frec);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -2362,6 +2381,22 @@ int rfs_flow_restart(rfs_ctx* c, int nchain, int n1, const int32_t* idx1, const 
     const int nx = 2 * c->n;
     hipLaunchKernelGGL(k_flow_restart, dim3(n1 + n2 + n3), dim3(64), 0, c->stream, nx, n1, n2, n3, idx1, xkeep, idx2, pnew, remnew,
                        dtnew, idx3, x, p, rem, dt, fresh, ok, nxt_have);
+    HIPCHK(c, hipGetLastError());
+    return RFS_OK;
+}
+
+int rfs_flow_deposit(rfs_ctx* c, void* hip_stream, int nchain, int n, const int32_t* idx, const double* u, const double* pnew,
+                     const int32_t* remnew, const rfs_flow_next* next) {
+    if (!c) return RFS_ERR_ARG;
+    if (!c->configured) return fail(c, RFS_ERR_STATE, "rfs_joint_setup has not been called");
+    TRY(check_batch(c, nchain, c->n));
+    if (n < 0 || n > nchain) return fail(c, RFS_ERR_ARG, "list length must be within [0, nchain]");
+    if (n == 0) return RFS_OK;
+    if (!idx || !u || !pnew || !next || !next->have || !next->u || !next->p || (remnew && !next->rem))
+        return fail(c, RFS_ERR_ARG, "null argument");
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipLaunchKernelGGL(k_flow_deposit, dim3(n), dim3(64), 0, st, 2 * c->n, n, idx, u, pnew, remnew, next->have,
+                       const_cast<double*>(next->u), const_cast<double*>(next->p), const_cast<int*>(next->rem));
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }

@@ -2485,8 +2485,62 @@ struct FlowNext {
     // continues from "the same model" instead of from the end model a whole trajectory away
     double* croot; double* crs; double* xw; int nitems;
 };
+// Records of the chains that completed a trajectory in a flow step (rfs_flow_records, include/rfsurf.h): what the caller's books
+// need of every such chain, packed densely into a RING in memory the HOST can read (pinned, mapped into the device): the device
+// writes a few hundred records of (8 + 2n [+ ndata]) doubles per step over the link, and the host reads them behind the step's
+// event instead of copying flags down, indices up and gathered rows down again (a dozen copies and index kernels per step).
+//   rec[0] chain, [1] done code (1 waits for the caller, 2 rejected / 3 accepted and restarted on the device), [2] ok,
+//   [3] Ucur, [4] Hcur, [5] Hnew, [6] Unew, [7] the call's stamp, [8 .. 8 + nx) end model, then the synthetics if asked for
+// A slot is the next value of ONE device counter that only ever goes up (modulo the ring): only the chains that completed take
+// one (~8 % of the blocks), nothing is reset between steps and no block has to know that it is the last -- a per-step count
+// published by the step's last block cost 8192 atomics on one address, 70 us at the very end of every step.
+struct FlowRec {
+    double* buf;            // [cap][stride]
+    unsigned long long* count;
+    int cap, stride, want_dsyn;
+    double stamp;
+};
+__device__ __forceinline__ void flow_post_body(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, double* U,
+                            double* grad, double* dsyn, int* flag, double* p, int* rem, int* fresh,
+                            double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount, RfReduce rr,
+                            const int* need_cur, int* pend, int slot1, unsigned ready);
 // rr.PG != nullptr: the RF reduction of this chain's evaluation is still open (joint_eval left it to this kernel)
 __global__ void k_flow_post(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, double* U,
+                            double* grad, double* dsyn, int* flag, double* p, int* rem, int* fresh,
+                            double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
+                            double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount, RfReduce rr,
+                            const int* need_cur, int* pend, int slot1, unsigned ready, FlowRec rec)
+{
+    flow_post_body(nchain, nx, ndata, minv, dt, x, U, grad, dsyn, flag, p, rem, fresh, Ucur, Hcur, Unew, Hnew, dsyn_cur, dsyn_new,
+                   ok, done, nx_, fcount, rr, need_cur, pend, slot1, ready);
+    if (!rec.buf) return;
+    __shared__ unsigned long long s_slot;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    __syncthreads();                                            // (the body's stores of this block are complete)
+    const int dn = ((volatile int*)done)[chain];
+    if (dn == 0) return;                                        // (block-uniform)
+    if (tid == 0) s_slot = atomicAdd(rec.count, 1ull);
+    __syncthreads();
+    double* r = rec.buf + (size_t)(s_slot % (unsigned long long)rec.cap) * rec.stride;
+    const bool parked = dn >= 2;                                // restarted on the device: the results wait in res_*
+    const double* xs = parked ? nx_.res_x + (size_t)chain * nx : x + (size_t)chain * nx;
+    for (int i = tid; i < nx; i += blockDim.x) r[8 + i] = xs[i];
+    if (rec.want_dsyn) {
+        // (a restarted chain's synthetics at the end model: the evaluation's own row, which k_flow_post parks in res_dsyn)
+        const double* ds = parked ? dsyn + (size_t)chain * ndata : dsyn_new + (size_t)chain * ndata;
+        for (int i = tid; i < ndata; i += blockDim.x) r[8 + nx + i] = ds[i];
+    }
+    if (tid == 0) {
+        const double* rv = nx_.res_val + (size_t)chain * 4;
+        r[0] = (double)chain; r[1] = (double)dn; r[2] = parked ? 1.0 : (double)((volatile int*)ok)[chain];
+        r[3] = parked ? rv[0] : ((volatile double*)Ucur)[chain]; r[4] = parked ? rv[1] : ((volatile double*)Hcur)[chain];
+        r[5] = parked ? rv[2] : ((volatile double*)Hnew)[chain]; r[6] = parked ? rv[3] : ((volatile double*)Unew)[chain];
+        r[7] = rec.stamp;
+    }
+}
+
+__device__ __forceinline__ void flow_post_body(int nchain, int nx, int ndata, const double* minv, const double* dt, double* x, double* U,
                             double* grad, double* dsyn, int* flag, double* p, int* rem, int* fresh,
                             double* Ucur, double* Hcur, double* Unew, double* Hnew, double* dsyn_cur,
                             double* dsyn_new, int* ok, int* done, FlowNext nx_, unsigned long long* fcount, RfReduce rr,
@@ -2638,6 +2692,22 @@ __global__ void k_flow_restart(int nx, int n1, int n2, int n3, const int* __rest
     } else if (b < n1 + n2 + n3) {
         if (threadIdx.x == 0 && nxt_have) nxt_have[idx3[b - n1 - n2]] = 0;
     }
+}
+
+// rfs_flow_deposit: the deposits of rfs_flow_next for the listed chains in one launch (block = one listed chain): the
+// acceptance draw, the next trajectory's momentum and length, then the flag.
+__global__ void k_flow_deposit(int nx, int n, const int* __restrict__ idx, const double* __restrict__ u, const double* __restrict__ pn,
+                               const int* __restrict__ remn, int* __restrict__ have, double* __restrict__ nu, double* __restrict__ np_,
+                               int* __restrict__ nrem)
+{
+    const int b = blockIdx.x;
+    if (b >= n) return;
+    const int c = idx[b];
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) np_[(size_t)c * nx + j] = pn[(size_t)b * nx + j];
+    if (threadIdx.x == 0) { nu[c] = u[b]; if (remn && nrem) nrem[c] = remn[b]; }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) have[c] = 1;
 }
 
 }  // namespace rfs

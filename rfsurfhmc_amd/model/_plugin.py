@@ -186,17 +186,44 @@ class FusedPlugin:
         ctx.check(ctx.L.rfs_set_stream(ctx.h, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         args = [st[k].data_ptr() for k in ("x", "p", "dt", "rem", "fresh", "bounds", "Ucur", "Hcur", "Unew", "Hnew",
                                            "dsyn_cur", "dsyn_new", "ok", "done")]
-        if "nxt_have" in st:        # restarts on the device (rfs_flow_step2), state from flow_restart_state()
-            from .._lib import FlowNext
-            nxt = FlowNext(*[st[k].data_ptr() if st.get(k) is not None else None for k in
-                             ("nxt_have", "nxt_u", "nxt_p", "nxt_rem", "xstart", "res_x", "res_val", "res_dsyn", "gsave", "kick")])
+        nxt = self._flow_next(st)
+        if st.get("rec") is not None and hasattr(ctx.L, "rfs_flow_step3"):
+            # records of the chains that complete a trajectory in this call, straight into the caller's pinned buffer
+            # (rfs_flow_records): st["rec"] = (pinned float64 tensor used as a ring, its slots, want_dsyn, this call's stamp, reset)
+            from .._lib import FlowRecords
+            buf, cap, want, stamp, reset = st["rec"]
+            rec = FlowRecords(buf.data_ptr(), buf.numel() * buf.element_size(), int(cap), int(bool(want)), float(stamp), int(bool(reset)))
+            ctx.check(ctx.L.rfs_flow_step3(ctx.h, nchain, *args, ctypes.byref(nxt) if nxt is not None else None, ctypes.byref(rec)))
+        elif nxt is not None:       # restarts on the device (rfs_flow_step2), state from flow_restart_state()
             ctx.check(ctx.L.rfs_flow_step2(ctx.h, nchain, *args, ctypes.byref(nxt)))
         else:
             ctx.check(ctx.L.rfs_flow_step(ctx.h, nchain, *args))
 
+    @staticmethod
+    def _flow_next(st):
+        if "nxt_have" not in st:
+            return None
+        from .._lib import FlowNext
+        return FlowNext(*[st[k].data_ptr() if st.get(k) is not None else None for k in
+                          ("nxt_have", "nxt_u", "nxt_p", "nxt_rem", "xstart", "res_x", "res_val", "res_dsyn", "gsave", "kick")])
+
+    def flow_deposit(self, st, stream, buf, n, o_idx, o_u, o_p, o_rem):
+        """rfs_flow_deposit on the state ``st``: the n listed chains' acceptance draws, next momenta and lengths (o_rem None:
+        deferred form) out of ONE byte buffer ``buf`` -- device memory, or pinned host memory the launch reads over the link --
+        at the given byte offsets, in one launch on ``stream`` (a torch stream)."""
+        nchain, nx = st["x"].shape
+        ctx = self._ensure(nx // 2)
+        base = buf.data_ptr()
+        P = lambda off: None if off is None else base + off
+        nxt = self._flow_next(st)
+        ctx.check(ctx.L.rfs_flow_deposit(ctx.h, ctypes.c_void_p(stream.cuda_stream), nchain, int(n), P(o_idx), P(o_u), P(o_p), P(o_rem),
+                                         ctypes.byref(nxt)))
+
     def flow_restart(self, st, buf, n1, o_idx1, o_xkeep, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3):
-        """rfs_flow_restart on the state ``st``: the lists and rows live in ONE device byte buffer ``buf`` (a uint8 CUDA
-        tensor the caller copied up in one piece) at the given byte offsets (None: absent)."""
+        """rfs_flow_restart on the state ``st``: the lists and rows live in ONE byte buffer ``buf`` at the given byte offsets
+        (None: absent) -- a uint8 CUDA tensor the caller copied up in one piece, or a PINNED host tensor, which the launch
+        reads over the link (pinned host memory is mapped into the device's address space: right for a few KB; the caller
+        copies anything above ~64 KB to the device first)."""
         import torch
         x = st["x"]
         nchain, nx = x.shape

@@ -533,10 +533,46 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         has_dep = np.zeros(nchain_all, dtype=bool)                    # deposit outstanding
         dep_rem = np.zeros(nchain_all, dtype=np.int64)                # length of the deposited trajectory
 
+    # Records (rfs_flow_step3, round 6): the device packs what the books need of every chain that completed a trajectory into a
+    # pinned buffer the host reads behind the step's event -- no copy of the flags down, no index lists up, no gathers: the
+    # per-step fetch costs the device nothing (before: 7-15 copies and 2-8 index kernels per step on the side stream)
+    nx_ = st["x"].shape[1]
+    use_rec = (dev.type == "cuda" and hasattr(model, "flow_deposit") and os.environ.get("RFS_FLOW_RECORDS", "1") != "0"
+               and hasattr(getattr(getattr(model, "_ctx", None), "L", None), "rfs_flow_step3"))
+    if use_rec:
+        rstride = 8 + nx_ + (st["dsyn_new"].shape[1] if fetch_syn else 0)
+        rcap = 3 * nchain_all                     # a ring: the step being read, the one under way, and slack
+        ring = torch.zeros(rcap * rstride, dtype=torch.float64, pin_memory=True)
+        ring_h = ring.numpy().reshape(rcap, rstride)
+        rd = [0]                                  # read cursor: records consumed since the ring started
+
     def fetch():
         """-> (s, idx1, res1, idx2, res2, acc2): step index; chains that finished and wait for the host (done = 1) with
         their rows; chains the device restarted (done = 2 / 3) with the parked results and the accept flags."""
-        done, ev, s = marks.pop(0)
+        done, ev, s, rb = marks.pop(0)
+        if rb is not None:
+            ev.synchronize()                      # the step is through: its records are complete
+            stamp = float(s + 1)
+            # this step's records: from the cursor on, as long as they carry its stamp (then comes a stale slot or one of the
+            # step that is running now)
+            k0 = rd[0] % rcap
+            st7 = np.concatenate((ring_h[k0:, 7], ring_h[:k0, 7]))[:nchain_all + 1]
+            nrec = int(np.argmax(st7 != stamp)) if (st7 != stamp).any() else len(st7)
+            assert nrec <= nchain_all, nrec
+            sl = (k0 + np.arange(nrec)) % rcap
+            rd[0] += nrec
+            R = ring_h[sl]                                          # (a copy: the slots are rewritten a lap later)
+            R = R[np.argsort(R[:, 0], kind="stable")]
+            chain, code = R[:, 0].astype(np.int64), R[:, 1].astype(np.int64)
+            out = []
+            for m in (code == 1, code >= 2):
+                r = R[m]
+                res = dict(ok=r[:, 2].astype(np.int32), Ucur=r[:, 3].copy(), Hcur=r[:, 4].copy(), Hnew=r[:, 5].copy(),
+                           Unew=r[:, 6].copy(), x=r[:, 8:8 + nx_].copy()) if len(r) else None
+                if res is not None and fetch_syn:
+                    res["dsyn_new"] = r[:, 8 + nx_:].copy()
+                out.append((chain[m], res))
+            return s, out[0][0], out[0][1], out[1][0], out[1][1], code[code >= 2] == 3
         if side is not None:
             side.wait_event(ev)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -576,46 +612,56 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
     stage = [[None, None] for _ in range(8)]      # rotating pinned byte buffers: [tensor, event behind its last copy]
     stage_next = [0]
 
-    def apply_fused(idx, xkeep, rs_, wd):
-        parts, off = [], 0
+    ZERO_COPY_MAX = 1 << 16                       # bytes a launch reads straight from pinned memory; above: one async copy first
+
+    def staged(parts_of):
+        """Pack host arrays into ONE pinned byte buffer.  parts_of(put) calls put(array, dtype) -> byte offset for each.
+        Returns (slot, source tensor for the launch): the pinned buffer itself when the lists are small (pinned host memory is
+        mapped into the device's address space at the same address: a few KB over the link cost a kernel less than a copy
+        kernel in front of it did, profiles/r04_step_timeline.txt), a device copy of it (ONE async copy on the current
+        stream) above ZERO_COPY_MAX -- restart=None runs put every finished chain's row through here, MBs at 8192 chains."""
+        parts, off = [], [0]
 
         def put(a, dtype):
-            nonlocal off
             a = np.ascontiguousarray(a, dtype=dtype)
-            o = off
+            o = off[0]
             parts.append((o, a))
-            off = (o + a.nbytes + 7) & ~7
+            off[0] = (o + a.nbytes + 7) & ~7
             return o
 
-        n1 = len(idx)
-        o_idx1 = o_xk = None
-        if n1:
-            o_idx1 = put(idx, np.int32); o_xk = put(xkeep, np.float64)
-        n2 = 0; o_idx2 = o_p = o_rem = o_dt = None
-        if rs_ is not None and len(rs_["idx"]):
-            n2 = len(rs_["idx"])
-            o_idx2 = put(rs_["idx"], np.int32); o_rem = put(rs_["rem"], np.int32)
-            if rs_.get("p") is not None:         # (absent: lengths and step sizes of chains already under way)
-                o_p = put(rs_["p"], np.float64)
-            if rs_.get("dt") is not None:
-                o_dt = put(rs_["dt"], np.float64)
-        n3 = len(wd)
-        o_idx3 = put(wd, np.int32) if n3 else None
+        offs = parts_of(put)
         slot = stage[stage_next[0]]; stage_next[0] = (stage_next[0] + 1) % len(stage)
         if slot[1] is not None:
-            slot[1].synchronize()
-        if slot[0] is None or slot[0].numel() < off:
-            slot[0] = torch.empty(max(off, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            slot[1].synchronize()                 # the launch / copy that last read this buffer has run
+        if slot[0] is None or slot[0].numel() < off[0]:
+            slot[0] = torch.empty(max(off[0], 1 << 16), dtype=torch.uint8, pin_memory=True)
         h = slot[0].numpy()
         for o, a in parts:
             h[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
-        # The launch reads the lists STRAIGHT FROM THE PINNED BUFFER: pinned host memory is mapped into the device's address
-        # space at the same address, a few KB over the link cost the kernel less than the separate copy kernel in front of
-        # it did (0.05 ms on the main stream between two steps: profiles/r04_step_timeline.txt)
         if slot[1] is None:
             slot[1] = torch.cuda.Event()
-        src = slot[0] if not LEGACY_TAIL else slot[0][:off].to(dev, non_blocking=True)
-        model.flow_restart(st, src, n1, o_idx1, o_xk, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3)
+        src = slot[0] if (off[0] <= ZERO_COPY_MAX and not LEGACY_TAIL) else slot[0][:off[0]].to(dev, non_blocking=True)
+        return slot, src, offs
+
+    def apply_fused(idx, xkeep, rs_, wd):
+        def parts_of(put):
+            n1 = len(idx)
+            o_idx1 = o_xk = None
+            if n1:
+                o_idx1 = put(idx, np.int32); o_xk = put(xkeep, np.float64)
+            n2 = 0; o_idx2 = o_p = o_rem = o_dt = None
+            if rs_ is not None and len(rs_["idx"]):
+                n2 = len(rs_["idx"])
+                o_idx2 = put(rs_["idx"], np.int32); o_rem = put(rs_["rem"], np.int32)
+                if rs_.get("p") is not None:         # (absent: lengths and step sizes of chains already under way)
+                    o_p = put(rs_["p"], np.float64)
+                if rs_.get("dt") is not None:
+                    o_dt = put(rs_["dt"], np.float64)
+            n3 = len(wd)
+            o_idx3 = put(wd, np.int32) if n3 else None
+            return n1, o_idx1, o_xk, n2, o_idx2, o_p, o_rem, o_dt, n3, o_idx3
+        slot, src, offs = staged(parts_of)
+        model.flow_restart(st, src, *offs)
         slot[1].record(torch.cuda.current_stream(dev))            # the buffer is free again once the launch has run
 
     steps = 0
@@ -630,11 +676,13 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         if step_hook is not None:
             step_hook(steps, st)
         st["done"] = dbuf[steps % 2]
+        rb = ring if use_rec else None
+        st["rec"] = (ring, rcap, fetch_syn, float(steps + 1), steps == 0) if use_rec else None
         model.flow_step(st); steps += 1
         ev = None
-        if side is not None:
+        if side is not None or use_rec:
             ev = torch.cuda.Event(); ev.record()
-        marks.append((st["done"], ev, steps - 1))
+        marks.append((st["done"], ev, steps - 1, rb))
 
     capped = lambda: max_steps is not None and steps >= max_steps
     step()
@@ -669,7 +717,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                     # the launch has long run.  (Waiting here made this iteration's deposits, and with them the next step's
                     # first kernel, wait for a launch that sits behind the whole step under way: 0.17 ms of idle device
                     # between two steps, profiles/r04_step_timeline.txt.)
-                    wev = torch.cuda.Event(); wev.record(); withdrawn.append((steps, wev))
+                    wev = torch.cuda.Event(); wev.record(); withdrawn.append((steps, wev, np.asarray(wd)))
                     if LEGACY_TAIL:
                         side.wait_event(withdrawn.pop()[1])
             else:
@@ -694,9 +742,24 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
             cand = np.nonzero((finish == steps) & ~has_dep)[0]       # they complete in the step launched next
             if len(cand):
                 sel, u, pn, rem = restart.predraw(cand)
-                while withdrawn and withdrawn[0][0] < steps and side is not None:    # (earlier iterations' launches: see above)
+                # (earlier iterations' withdrawing launches: see above.  A launch of THIS iteration is only waited for if it
+                # withdrew one of the chains deposited now -- which the callers' schedules rule out, a withdrawn chain runs a
+                # whole trajectory first; the check makes that an enforced invariant instead of a silent race on nxt_have)
+                while withdrawn and side is not None and (withdrawn[0][0] < steps or np.isin(sel, withdrawn[0][2]).any()):
                     side.wait_event(withdrawn.pop(0)[1])
-                if len(sel):
+                if len(sel) and use_rec:
+                    # ONE launch on the side stream (rfs_flow_deposit), its lists read from pinned memory or copied up in one piece
+                    sd = side if side is not None else torch.cuda.current_stream(dev)
+                    with torch.cuda.stream(sd):
+                        def parts_of(put):
+                            return (len(sel), put(sel, np.int32), put(u, np.float64), put(pn, np.float64),
+                                    put(rem, np.int32) if rem is not None else None)
+                        slot, src, offs = staged(parts_of)
+                        model.flow_deposit(st, sd, src, *offs)
+                        slot[1].record(sd)
+                        if side is not None:
+                            ev = torch.cuda.Event(); ev.record(); deposited.append(ev)
+                elif len(sel):
                     # on the side stream, beside the step that is running: these chains are in mid-trajectory there and the
                     # device looks at a deposit only in the step that completes one; the next launch waits for the event
                     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -708,6 +771,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                         st["nxt_have"].index_fill_(0, ts, 1)
                         if side is not None:
                             ev = torch.cuda.Event(); ev.record(); deposited.append(ev)
+                if len(sel):
                     has_dep[sel] = True
                     if rem is not None:
                         dep_rem[sel] = rem
