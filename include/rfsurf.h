@@ -354,7 +354,13 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          search, the rest within 1e-6 c; misfit and gradient as with "swd_warm_start" = 0.
  *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
  *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
- *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2: measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; 1 with "swd_exact_origin_tol_e9" 500 is the faster, looser setting described there) of the above.
+ *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2 -- 1 only with 16 lanes per group, "swd_exact_coop": measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; 1 with "swd_exact_origin_tol_e9" 500 is the faster, looser setting described there) of the above.
+ *   "swd_exact_coop"       1 (default): batches of up to 8192 (group, chain) pairs run the reference-root stage with 16 lanes per
+ *                          group -- each lane builds the layer entries of every 16th layer, every lane runs the short vector
+ *                          recurrence: the single lane's arithmetic operation for operation, the same roots bit for bit, a third
+ *                          of the time per evaluation: a stage as long as one lane's ~40 dependent evaluations whatever the
+ *                          batch size is what a small batch spends most of its step in.  0 = a lane per
+ *                          group always, 2 = 16 lanes per group always (tests).  Models of up to 65 layers.
  *   "flow_async_handback"  rfs_flow_step / rfs_flow_step2 with the warm start on: 1 = a chain the warm start hands back to the
  *                          reference-semantics search (a few per step on rough models: ~3 ms of dependent evaluations, during
  *                          which every other chain would wait) sits that step out instead -- its model has drifted, it is not

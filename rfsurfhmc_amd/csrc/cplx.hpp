@@ -10,6 +10,16 @@
 #define RFS_HD inline
 #endif
 
+// Arithmetic that several kernels must reproduce bit for bit (the layer entries and the vector recurrence of the secular
+// functions: a lane per item, 16 lanes per item, producer / consumer blocks) spells out its fused multiply-adds and switches the
+// compiler's own contraction off: which of the two products of a * b - c * d the compiler fuses depends on the code around the
+// expression (use counts, hoisting), and two kernels built from the same source line then differ in the last bit.
+#if defined(__clang__)
+#define RFS_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define RFS_NO_CONTRACT
+#endif
+
 namespace rfs {
 
 // reciprocal square root: v_rsq_f64 + refinement on the device, 1/sqrt on the host harness

@@ -24,6 +24,7 @@ using namespace rfs;
 #endif
 namespace {
 
+constexpr int EXACT_COOP_MAX = 8192;   // (group, chain) pairs of the reference-root stage up to which a group takes 16 lanes (k_swd_exact_coop): ~1 500 wavefronts hold 6 000 groups at once
 constexpr int RFS_BG_SLOTS = 8;      // sets of hand-back flags / lists (and events): background searches of that many steps may be in flight
 
 struct Buf {
@@ -118,6 +119,7 @@ struct rfs_ctx {
     // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
     // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
+    int exact_coop = 1;        // option "swd_exact_coop": 0 never, 1 (default) 16 lanes per group for small batches (k_swd_exact_coop), 2 always (tests)
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
@@ -1001,18 +1003,34 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             KTimer tx(c, RFS_K_SWD_EXACT, s);
             // ... and from the continued roots to the reference's own: its refinement (nevill) inside its scan cell, groups of
             // periods per lane (k_swd_exact); what a lane declines goes to the full search like the branch test's chains
-            const int G = std::max(2, c->exact_group), ru = std::max(0, c->exact_runup);
-            auto ngroups = [&](const SwdSeqs& QQ) { int g = 0; for (int q = 0; q < QQ.nseq; q++) g += (QQ.s[q].nper + G - 1) / G; return g; };
-            if (Q.nper_total > 0) {
-                const int ng = ngroups(Q);
-                hipLaunchKernelGGL((k_swd_exact<SwdRayFamily>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s,
-                                   nchain, n, Q, G, ru, ng, c->exact_origin_tol, mdlR, c->mdlc.as<double>(), c->croot.as<double>(), W);
-            }
-            if (P.QL.nper_total > 0) {
-                const int ng = ngroups(P.QL);
-                hipLaunchKernelGGL((k_swd_exact<SwdLoveFamily>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s,
-                                   nchain, n, P.QL, G, ru, ng, c->exact_origin_tol, c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
-            }
+            int G = std::max(1, c->exact_group);
+            const int ru = std::max(0, c->exact_runup);
+            auto ngroups = [&](const SwdSeqs& QQ, int g_) { int g = 0; for (int q = 0; q < QQ.nseq; q++) g += (QQ.s[q].nper + g_ - 1) / g_; return g; };
+            // Small batches (round 6): a lane per group leaves the chip empty and the stage as long as ever -- its length is one
+            // lane's ~40 dependent evaluations, whatever the number of lanes.  Up to EXACT_COOP_MAX groups take 16 lanes each
+            // (k_swd_exact_coop: a third of the time per evaluation, bit-identical).
+            const int np_max = std::max(Q.nper_total, P.QL.nper_total);
+            bool coop = c->exact_coop != 0 && n >= 3 && n - 1 <= 64 &&
+                        (c->exact_coop > 1 || (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain <= (size_t)EXACT_COOP_MAX);
+            // (shorter groups for very small batches were tried and lose: every group has its own run-up, and a run-up that does
+            // not contract hands the chain to the sequential search -- ONE chain of configs[0]: 27 -> 96 of 299 evaluations)
+            if (!coop) G = std::max(2, G);
+#define RFS_LAUNCH_EXACT(FAM, QQ, MDL, MDLC)                                                                            \
+            do {                                                                                                       \
+                const int ng = ngroups(QQ, G);                                                                          \
+                if (coop) {                                                                                             \
+                    const size_t ldsb = (size_t)4 * ((size_t)(n - 1) * FAM::NENT + FAM::NV) * sizeof(double);           \
+                    const unsigned gx = (unsigned)std::min<size_t>(((size_t)ng * nchain + 3) / 4, (size_t)4096);        \
+                    hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(std::max(1u, gx)), dim3(64), ldsb, s, nchain, n, QQ, G, ru, ng, \
+                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr); \
+                } else {                                                                                                \
+                    hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
+                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W);  \
+                }                                                                                                       \
+            } while (0)
+            if (Q.nper_total > 0) RFS_LAUNCH_EXACT(SwdRayFamily, Q, mdlR, c->mdlc.as<double>());
+            if (P.QL.nper_total > 0) RFS_LAUNCH_EXACT(SwdLoveFamily, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>());
+#undef RFS_LAUNCH_EXACT
             HIPCHK(c, hipGetLastError());
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
             if (!async) TRY(launch_fallback(W.list3, W.count3, 64));
@@ -1750,8 +1768,12 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         c->warm_exact = value; c->warm_primed = false; return RFS_OK;
     }
     if (!strcmp(name, "swd_exact_group")) {
-        if (value < 2 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [2, 4096]");
-        c->exact_group = value; return RFS_OK;
+        if (value < 1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [1, 4096]");
+        c->exact_group = value; return RFS_OK;      // (1: the 16-lane form only; a lane per group takes >= 2)
+    }
+    if (!strcmp(name, "swd_exact_coop")) {
+        if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_exact_coop must be 0, 1 or 2");
+        c->exact_coop = value; return RFS_OK;
     }
     if (!strcmp(name, "swd_exact_origin_tol_e9")) {
         if (value < 0 || value > 2000) return fail(c, RFS_ERR_ARG, "swd_exact_origin_tol_e9 must be within [0, 2000] (units of 1e-9 c)");
@@ -1842,7 +1864,8 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
         for (int i = 0; i < 64; i++) *value += (int64_t)v[i];
         return RFS_OK;
     }
-    if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
+    if (!strncmp(name, "wstat_", 6)) { idx = atoi(name + 6); if (idx < 0 || idx > 31) idx = -1; }      // (raw slot: debug builds)
+    else if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
     else if (!strcmp(name, "swd_warm_secular_evals")) idx = 1;
     else if (!strcmp(name, "swd_warm_items")) idx = 2;
     else if (!strcmp(name, "swd_warm_walked_chains")) idx = 12;

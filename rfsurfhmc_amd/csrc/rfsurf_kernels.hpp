@@ -1764,6 +1764,127 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float o
     if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[15], (unsigned long long)nev);
 }
 
+// The same stage with LG = 16 lanes per group (round 6), for the batches that leave the chip mostly empty (a few hundred chains;
+// ONE chain for configs[0]): every lane of a group runs the same machine on the same numbers, per evaluation lane j builds the
+// vector-independent numbers of layers j, j + 16, ... into LDS and every lane runs the short vector recurrence over them -- as
+// k_swd_warm_coop does for the warm search.  The arithmetic is swd_secular_family<F, true>'s operation for operation (entries of a
+// layer, then the raw recurrence top-down with its rescales), so the roots are k_swd_exact's bit for bit, in a third of the time
+// per evaluation.  glist / gcount: the groups to do (nullptr: all ngroups * nchain of them); the blocks stride.  n - 1 <= 64.
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float origin_tol, const float* __restrict__ mdl,
+                 const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, const int* __restrict__ glist,
+                 const int* __restrict__ gcount)
+{
+    constexpr int LG = 16, NG = 64 / LG, LPL = 4, NENT = F::NENT, NV = F::NV;
+    extern __shared__ double xcoop_lds[];        // per group: entries [m][NENT], then the half-space vector [NV]
+    __shared__ double nevtab[24 * 64];           // Neville tables, one column per lane (the lanes of a group hold identical ones)
+    const int lane = threadIdx.x & 63, grp_l = lane / LG, lg = lane - grp_l * LG;
+    double* const ent_g = xcoop_lds + (size_t)grp_l * ((size_t)(n - 1) * NENT + NV);
+    double* const hs_g = ent_g + (size_t)(n - 1) * NENT;
+    const size_t total = glist ? (size_t)*gcount : (size_t)ngroups * nchain;
+    const FmVC vc = fm_vc_load();
+    for (size_t blk = blockIdx.x; blk * NG < total; blk += gridDim.x) {
+        const size_t slot = blk * NG + grp_l;
+        bool live = slot < total;
+        const size_t g = live ? (glist ? (size_t)glist[slot] : slot) : 0;
+        const int grp = (int)(g / nchain), chain = (int)(g - (size_t)grp * nchain);
+        int seq = 0, gl = grp;
+        while (seq + 1 < Q.nseq && gl >= (Q.s[seq].nper + G - 1) / G) { gl -= (Q.s[seq].nper + G - 1) / G; seq++; }
+        const int nper = Q.s[seq].nper;
+        const int k0 = gl * G, k1 = min(k0 + G, nper), kr = max(0, k0 - runup);
+        live = live && k0 < nper && !W.need[chain];
+        const size_t s = (size_t)n * nchain;
+        const size_t e0 = (size_t)Q.s[seq].croot_off * nchain + chain;
+        const double* cw = W.cwarm + e0;
+        const double* tper = Q.s[seq].t; const double tscale = Q.s[seq].scale;
+        auto approx = [&](int k) { return cw[(size_t)k * nchain]; };
+        auto om = [&](int k) { return (2.0 * 3.141592653589793) / (tper[k] * tscale); };
+        const double* lc0 = mdlc + chain;
+        auto loadL = [&](int m) {
+            const double* o = lc0 + (size_t)m * 6 * nchain;
+            return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                             o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+        };
+        ExactGroup x;
+        x.phase = ExactGroup::X_DONE; x.nev = 0; x.cause = 0; x.creq = 1.0; x.omega = 1.0;
+        if (live) {
+            SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+            float bmx = 0.f;
+            const double cc = (double)swd_start_value(M, bmx);
+            x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om, nevtab + threadIdx.x, 64, origin_tol);
+        }
+        const SwdLayerC Lhalf = loadL(n - 1);
+        SwdLayerC Lmine[LPL];                    // this lane's layers lg, lg + LG, ... stay in registers
+#pragma unroll
+        for (int q = 0; q < LPL; q++) { const int m = lg + q * LG; Lmine[q] = loadL(m < n - 1 ? m : n - 2); }
+        while (__any(x.active())) {
+            const bool act = x.active();
+            const double omega_raw = x.omega;
+            const double omega = omega_raw < 1.0e-4 ? 1.0e-4 : omega_raw, iomega = 1.0 / omega;
+            const double wvno = omega_raw / x.creq, wvno2 = wvno * wvno, tt = -2.0 * wvno2;
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < LPL; q++) {
+                    const int m = lg + q * LG;
+                    if (m < n - 1) {
+                        double ent[NENT];
+                        F::entries_dual(Lmine[q], wvno, wvno2, omega, iomega, ent, &vc);
+#pragma unroll
+                        for (int i = 0; i < NENT; i++) ent_g[m * NENT + i] = ent[i];
+                    }
+                }
+                if (lg == LG - 1) {
+                    double eh[NV];
+                    F::halfspace(Lhalf, wvno, wvno2, omega, iomega, eh);
+#pragma unroll
+                    for (int j = 0; j < NV; j++) hs_g[j] = eh[j];
+                }
+            }
+            __syncthreads();
+            double delta = 0.0;
+            if (act) {
+                double ev[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) ev[j] = hs_g[j];
+                const double* pe = ent_g + (size_t)(n - 2) * NENT;
+                for (int m = n - 2; m >= 0; m--, pe -= NENT) {
+                    double cur[NENT];
+#pragma unroll
+                    for (int i = 0; i < NENT; i++) cur[i] = pe[i];
+                    F::apply(ev, cur, tt);
+                    if ((m & 7) == 0) swd_rescale_pow2_n<NV>(ev);
+                }
+                delta = swd_finish_n<NV>(ev);
+            }
+            __syncthreads();
+#ifdef RFS_DEBUG_COOP
+            if (act && lg == 0) {        // (debug builds: the cooperative evaluation against the single lane's, value by value)
+                const double d1 = swd_secular_family<F, true>(n, loadL, x.omega, x.creq, &vc);
+                atomicAdd(&W.stats[16], 1ull);
+                if (d1 != delta) atomicAdd(&W.stats[3], 1ull);
+            }
+#endif
+            if (act) {
+                x.advance(delta);
+                if (x.phase == ExactGroup::X_DONE) {
+                    if (x.wanted() && lg == 0) croot[e0 + (size_t)x.k * nchain] = (double)(float)x.root();       // surfdisp96.f:302
+                    x.next(approx, om);
+                }
+            }
+        }
+        if (live && lg == 0) {
+            if (x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
+                W.list3[atomicAdd(W.count3, 1)] = chain;
+                atomicAdd(&W.stats[0], 1ull);
+                atomicAdd(&W.stats[14], 1ull);
+                if (x.cause >= 1 && x.cause <= 7) atomicAdd(&W.stats[16 + x.cause], 1ull);
+            }
+            atomicAdd(&W.stats[15], (unsigned long long)x.nev);
+        }
+    }
+}
+
 constexpr int COOP_CL = 1;                       // the consumer builds the deepest finite layer itself
 // periods of a search sequence as tables in LDS: omega_k = 2 pi / T_k and 1 / max(omega_k, 1e-4), divided once per block
 // instead of once per (lane, period) inside the consumer's serial phase

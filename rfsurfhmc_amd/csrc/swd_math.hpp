@@ -294,6 +294,7 @@ RFS_HD void swd_trig_split2(double wvno, double xka, double xkb, double dpth,
 template <bool DUAL = false>
 RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega,
                               double ent[SWD_NENT], const FmVC* vc = nullptr) {
+    RFS_NO_CONTRACT
     double xka = omega * L.ia, xkb = omega * L.ib;
     double t = L.b * iomega;
     double gammk = 2.0 * t * t, gam = gammk * wvno2;
@@ -309,35 +310,50 @@ RFS_HD void swd_layer_entries(const SwdLayerC& L, double wvno, double wvno2, dou
     double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
     double gamm1 = gam - 1.0, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1;
     double gm1sq = gamm1 * gamm1, rho = L.rho, ir = L.irho, rho2 = rho * rho, ir2 = ir * ir, a0pq = a0 - cpcq;
-    double c11 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - wvno2 * gm1sq * wy;
+    // (every fused multiply-add written out, see RFS_NO_CONTRACT: left to right through the reference's expressions, dnka)
+    double c11 = ::fma(-(2.0 * gmgm1), a0pq, cpcq);                                 // cpcq - 2 gmgm1 a0pq - gmgmk xz - wvno2 gm1sq wy
+    c11 = ::fma(-gmgmk, xz, c11);
+    c11 = ::fma(-(wvno2 * gm1sq), wy, c11);
     ent[0] = c11;
-    ent[1] = (wvno2 * cpy - cqx) * ir;                                              // c12
-    ent[2] = -(twgm1 * a0pq + gammk * xz + wvno2 * gamm1 * wy) * ir;                // c13
-    ent[3] = (cpz - wvno2 * cqw) * ir;                                              // c14
-    ent[4] = -(2.0 * wvno2 * a0pq + xz + wvno2 * wvno2 * wy) * ir2;                 // c15
-    ent[5] = (gmgmk * cpz - gm1sq * cqw) * rho;                                     // c21
+    ent[1] = ::fma(wvno2, cpy, -cqx) * ir;                                          // c12
+    double s13 = twgm1 * a0pq;                                                      // c13 = -(twgm1 a0pq + gammk xz + wvno2 gamm1 wy) / rho
+    s13 = ::fma(gammk, xz, s13);
+    s13 = ::fma(wvno2 * gamm1, wy, s13);
+    ent[2] = -s13 * ir;
+    ent[3] = ::fma(-wvno2, cqw, cpz) * ir;                                          // c14
+    double s15 = ::fma(2.0 * wvno2, a0pq, xz);                                      // c15 = -(2 wvno2 a0pq + xz + wvno2^2 wy) / rho^2
+    s15 = ::fma(wvno2 * wvno2, wy, s15);
+    ent[4] = -s15 * ir2;
+    ent[5] = ::fma(gmgmk, cpz, -(gm1sq * cqw)) * rho;                               // c21
     ent[6] = cpcq;                                                                  // c22
-    ent[7] = gammk * cpz - gamm1 * cqw;                                             // c23
+    ent[7] = ::fma(gammk, cpz, -(gamm1 * cqw));                                     // c23
     ent[8] = -wz;                                                                   // c24
-    ent[9] = (gm1sq * cpy - gmgmk * cqx) * rho;                                     // c41
+    ent[9] = ::fma(gm1sq, cpy, -(gmgmk * cqx)) * rho;                               // c41
     ent[10] = -xy;                                                                  // c42
-    ent[11] = gamm1 * cpy - gammk * cqx;                                            // c43
-    ent[12] = -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;          // c51
-    ent[13] = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) * rho;    // c53
-    ent[14] = a0 + 2.0 * (cpcq - c11);                                              // c33
+    ent[11] = ::fma(gamm1, cpy, -(gammk * cqx));                                    // c43
+    double s51 = ((2.0 * gmgmk) * gm1sq) * a0pq;                                    // c51 = -(2 gmgmk gm1sq a0pq + gmgmk^2 xz + gm1sq^2 wy) rho^2
+    s51 = ::fma(gmgmk * gmgmk, xz, s51);
+    s51 = ::fma(gm1sq * gm1sq, wy, s51);
+    ent[12] = -s51 * rho2;
+    double s53 = ((gammk * gamm1) * twgm1) * a0pq;                                  // c53 = -(gammk gamm1 twgm1 a0pq + gam gammk^2 xz + gamm1 gm1sq wy) rho
+    s53 = ::fma((gam * gammk) * gammk, xz, s53);
+    s53 = ::fma(gamm1 * gm1sq, wy, s53);
+    ent[13] = -s53 * rho;
+    ent[14] = ::fma(2.0, cpcq - c11, a0);                                           // c33
 }
 
 RFS_HD void swd_halfspace_e(const SwdLayerC& L, double wvno, double wvno2, double omega, double iomega, double e[5]) {
+    RFS_NO_CONTRACT
     double xka = omega * L.ia, xkb = omega * L.ib;
     double ra = sqrt((wvno + xka) * fabs(wvno - xka));
     double rb = sqrt((wvno + xkb) * fabs(wvno - xkb));
     double t = L.b * iomega;
     double gammk = 2.0 * t * t, gam = gammk * wvno2, gamm1 = gam - 1.0, rho1 = L.rho;
-    e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+    e[0] = (rho1 * rho1) * ::fma(-((gam * gammk) * ra), rb, gamm1 * gamm1);
     e[1] = -rho1 * ra;
-    e[2] = rho1 * (gamm1 - gammk * ra * rb);
+    e[2] = rho1 * ::fma(-(gammk * ra), rb, gamm1);
     e[3] = rho1 * rb;
-    e[4] = wvno2 - ra * rb;
+    e[4] = ::fma(-ra, rb, wvno2);
 }
 
 RFS_HD void swd_apply_layer(double e[5], const double c[SWD_NENT], double tt /* -2 wvno^2 */) {
@@ -359,12 +375,13 @@ RFS_HD void swd_apply_layer(double e[5], const double c[SWD_NENT], double tt /* 
 // therefore drops the max/reciprocal chain from every layer (25 FMAs remain); an exact power-of-two
 // rescale every few layers keeps the range, and swd_finish applies the one normalisation that matters.
 RFS_HD void swd_apply_layer_raw(double e[5], const double c[SWD_NENT], double tt /* -2 wvno^2 */) {
-    double e2t = e[2] * tt;
-    double n0 = e[0] * c[0] + e[1] * c[5] + e2t * c[13] + e[3] * c[9] + e[4] * c[12];
-    double n1 = e[0] * c[1] + e[1] * c[6] + e2t * c[11] + e[3] * c[10] + e[4] * c[9];
-    double n2 = e[0] * c[2] + e[1] * c[7] + e[2] * c[14] + e[3] * c[11] + e[4] * c[13];
-    double n3 = e[0] * c[3] + e[1] * c[8] + e2t * c[7] + e[3] * c[6] + e[4] * c[5];
-    double n4 = e[0] * c[4] + e[1] * c[3] + e2t * c[2] + e[3] * c[1] + e[4] * c[0];
+    RFS_NO_CONTRACT
+    const double e2t = e[2] * tt;
+    const double n0 = ::fma(e[4], c[12], ::fma(e[3], c[9], ::fma(e2t, c[13], ::fma(e[1], c[5], e[0] * c[0]))));
+    const double n1 = ::fma(e[4], c[9], ::fma(e[3], c[10], ::fma(e2t, c[11], ::fma(e[1], c[6], e[0] * c[1]))));
+    const double n2 = ::fma(e[4], c[13], ::fma(e[3], c[11], ::fma(e[2], c[14], ::fma(e[1], c[7], e[0] * c[2]))));
+    const double n3 = ::fma(e[4], c[5], ::fma(e[3], c[6], ::fma(e2t, c[7], ::fma(e[1], c[8], e[0] * c[3]))));
+    const double n4 = ::fma(e[4], c[0], ::fma(e[3], c[1], ::fma(e2t, c[2], ::fma(e[1], c[3], e[0] * c[4]))));
     e[0] = n0; e[1] = n1; e[2] = n2; e[3] = n3; e[4] = n4;
 }
 RFS_HD void swd_rescale_pow2(double e[5]) {
@@ -424,7 +441,8 @@ struct SwdLoveFamily {
         e[1] = L.ib * L.ib;
     }
     static RFS_HD void apply(double* e, const double* c, double) {
-        const double n0 = e[0] * c[0] + e[1] * c[1], n1 = e[0] * c[2] + e[1] * c[0];
+        RFS_NO_CONTRACT
+        const double n0 = ::fma(e[1], c[1], e[0] * c[0]), n1 = ::fma(e[1], c[0], e[0] * c[2]);
         e[0] = n0; e[1] = n1;
     }
     static RFS_HD void rescale(double* e) {

@@ -567,6 +567,61 @@ def test_warm_search_in_rounds_is_the_one_round_search_bit_for_bit():
         assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]) and r[4] == ref[4], (budgets, r[4], ref[4])
 
 
+def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_bit_for_bit():
+    """Round 6: k_swd_exact_coop (16 lanes per group of periods: every lane builds the entries of every 16th layer, all run the
+    short recurrence) against k_swd_exact (a lane per group) -- the same seeded sampler run from burned-in models, with the
+    form forced on ("swd_exact_coop" 2) and off (0), stores identical samples, misfits and counters (joint problem of the
+    bench, 512 chains; and the SWD-only problem of configs[0] with group velocities, 16 chains)."""
+    import bench
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    n, nc = 30, 512
+    joint, t = _bench_joint(1)
+    bounds = bench.bounds_of(bench.true_model(n))
+    ctx = joint._ensure(n)
+    keep = {}
+    s0 = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 40, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+    s0.sample_flow(x_init=bench.make_models(nc, 4, n), max_steps=121,
+                   step_hook=lambda s, st: keep.__setitem__("x", st["x"].clone()) if s == 120 else None)
+    xb = keep["x"].cpu().numpy()
+
+    def runs_of(model, ctx, bounds, x_init, nchains, dt):
+        out = {}
+        try:
+            for coop in (0, 2):
+                ctx.set_option("swd_exact_coop", coop)
+                names = ("swd_warm_declined_chains", "swd_exact_declined_chains", "swd_exact_secular_evals", "swd_warm_items")
+                c0 = [ctx.stat(k) for k in names]
+                s = HamitonianMC(model, bounds, dt, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nchains, verbose=False)
+                mis = s.sample_flow(x_init=x_init, max_steps=80, async_handback=False)
+                out[coop] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
+                             [ctx.stat(k) - v for k, v in zip(names, c0)])
+        finally:
+            ctx.set_option("swd_exact_coop", 1)
+        return out
+
+    r = runs_of(joint, ctx, bounds, xb, nc, 0.05)
+    assert r[0][4][2] > 0                                                # the stage ran
+    for i in range(4):
+        assert np.array_equal(r[0][i], r[2][i]), i
+    assert r[0][4] == r[2][4], (r[0][4], r[2][4])
+    # configs[0]'s plugin: 10 layers, 36 Rc + 36 Rg periods (four sequences per chain)
+    thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
+    tt = np.arange(5., 41.)
+    x0 = np.hstack((vs, thk))
+    m = SurfWD(tRc=tt, tRg=tt, device=0)
+    d, flag = m.forward(x0); assert flag
+    m.set_obsdata(d)
+    b0 = bench.bounds_of(x0)
+    rng = np.random.default_rng(2)
+    xs = np.clip(x0[None, :] * (1 + 0.02 * rng.standard_normal((16, 20))), b0[:, 0], b0[:, 1])
+    r = runs_of(m, m._ensure(10), b0, xs, 16, 0.03)
+    assert r[0][4][2] > 0
+    for i in range(4):
+        assert np.array_equal(r[0][i], r[2][i]), i
+    assert r[0][4] == r[2][4], (r[0][4], r[2][4])
+
+
 def test_two_flow_states_in_turn_on_one_context():
     """The warm start belongs to the state whose x array the previous flow call advanced: two states stepped in turn on one
     context start over from the full search at every call (nothing of the other state is continued) and get exactly the
