@@ -604,7 +604,7 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
     assert r[0][4][2] > 0                                                # the stage ran
     for i in range(4):
         assert np.array_equal(r[0][i], r[2][i]), i
-    assert r[0][4] == r[2][4], (r[0][4], r[2][4])
+    _same_counters(r[0][4], r[2][4])
     # configs[0]'s plugin: 10 layers, 36 Rc + 36 Rg periods (four sequences per chain)
     thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
     tt = np.arange(5., 41.)
@@ -619,7 +619,14 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
     assert r[0][4][2] > 0
     for i in range(4):
         assert np.array_equal(r[0][i], r[2][i]), i
-    assert r[0][4] == r[2][4], (r[0][4], r[2][4])
+    _same_counters(r[0][4], r[2][4])
+
+
+def _same_counters(a, b):
+    """Hand-backs and items identical; the stage's evaluation count may differ by the few groups that find their chain already
+    handed back by a sister group when they start (which group of a chain runs first is a matter of scheduling)."""
+    assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3], (a, b)
+    assert abs(a[2] - b[2]) <= 1e-3 * a[2], (a, b)
 
 
 def test_two_flow_states_in_turn_on_one_context():
