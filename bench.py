@@ -675,7 +675,8 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
                            nchains=nchain, verbose=False, store_syn=False)
     marks = {}
     STATS = ("swd_warm_declined_chains", "swd_warm_items", "swd_warm_secular_evals", "swd_exact_secular_evals",
-             "swd_warm_walked_chains", "swd_exact_declined_chains", "flow_chain_steps")
+             "swd_warm_walked_chains", "swd_exact_declined_chains", "flow_chain_steps", "swd_exact_evals_slowest_lane",
+             "swd_exact_wavefronts")
     nser = 4 if (groups and burn >= 12) else 0
 
     class _StopLeg(Exception):
@@ -774,7 +775,10 @@ def sampler_leg(cfg, config, joint, x_true, bounds, nchain, rank, dev, K, burn, 
                         "secular_evals_per_item_reference_root_stage": d["swd_exact_secular_evals"] / items,
                         "chains_walking_the_scan_grid_per_step": d["swd_warm_walked_chains"] / K,
                         "chains_handed_back_to_the_full_search_per_step": d["swd_warm_declined_chains"] / K,
-                        "of_those_by_the_reference_root_stage_per_step": d["swd_exact_declined_chains"] / K}})
+                        "of_those_by_the_reference_root_stage_per_step": d["swd_exact_declined_chains"] / K,
+                        # the reference-root stage's wavefronts execute what their slowest lane needs: evaluations needed / executed
+                        "reference_root_stage_lane_efficiency": d["swd_exact_secular_evals"] / max(64.0 * d["swd_exact_evals_slowest_lane"], 1.0),
+                        "reference_root_stage_evals_of_the_slowest_lane_per_wavefront": d["swd_exact_evals_slowest_lane"] / max(d["swd_exact_wavefronts"], 1)}})
     if K2:
         el2 = marks["t2"] - marks["t1b"]
         rep["sustained"] = {"steps": K2, "ms_per_step": el2 / K2 * 1e3,

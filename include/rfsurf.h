@@ -355,6 +355,13 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
  *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
  *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2 -- 1 only with 16 lanes per group, "swd_exact_coop": measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; 1 with "swd_exact_origin_tol_e9" 500 is the faster, looser setting described there) of the above.
+ *   "swd_exact_budget"     44 (default): the reference-root stage of big batches runs in two launches.  Its wavefronts execute what
+ *                          their slowest lane needs (47 evaluations where the lanes need 38.5 on average: the lazy nevill's
+ *                          count varies from period to period), and the stage ends with its slowest wavefront.  Every lane gets
+ *                          this many evaluations; the groups that are unfinished then (6 % at 44) have their machines saved --
+ *                          in the middle of a period if need be -- and are continued by k_swd_exact_coop, 16 lanes per group.
+ *                          The same evaluations in the same order: the same roots bit for bit (test_gpu_warm.py).  4.71 -> 4.64 ms
+ *                          per step at 8192 chains (40: 4.69, 48: 4.68, 36: 5.10 -- too many groups passed on).  0: one launch.
  *   "swd_exact_coop"       1 (default): batches of up to 8192 (group, chain) pairs run the reference-root stage with 16 lanes per
  *                          group -- each lane builds the layer entries of every 16th layer, every lane runs the short vector
  *                          recurrence: the single lane's arithmetic operation for operation, the same roots bit for bit, a third
@@ -469,6 +476,8 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *   "swd_warm_walked_chains"    chain evaluations whose sequences walked the reference's scan grid (anomalous dispersion, or
  *                               a first-order change above 0.5 km/s: "swd_warm_wide_chains" counts the latter)
  *   "swd_exact_secular_evals"   secular-function evaluations of the reference-root stage ("swd_warm_exact");
+ *   "swd_exact_evals_slowest_lane" / "swd_exact_wavefronts"   divergence of that stage (k_swd_exact): evaluations of each
+ *                               wavefront's slowest lane, summed (a wavefront executes 64 x that), and wavefronts run
  *   "swd_exact_declined_chains" chain evaluations it handed back (no sign change in the expected scan cell, a grid at the
  *                               floor of the scan, a root the reference rejects)
  *   "swd_exact_cause_<k>"       ... by cause: 1 no usable approximate root / origin, 2 root too far from the origin, 3 the grid touches

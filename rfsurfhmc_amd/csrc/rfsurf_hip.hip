@@ -119,6 +119,8 @@ struct rfs_ctx {
     // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
     // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
+    int exact_budget = 44;     // option "swd_exact_budget": evaluations a lane of k_swd_exact may spend before its group goes on to the 16-lane launch (0: one round)
+    Buf xsp, xspc;             // ... the saved machines of those groups (ExactSpill) and their counts (Rayleigh, Love)
     int exact_coop = 1;        // option "swd_exact_coop": 0 never, 1 (default) 16 lanes per group for small batches (k_swd_exact_coop), 2 always (tests)
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
@@ -1015,21 +1017,38 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             // (shorter groups for very small batches were tried and lose: every group has its own run-up, and a run-up that does
             // not contract hands the chain to the sequential search -- ONE chain of configs[0]: 27 -> 96 of 299 evaluations)
             if (!coop) G = std::max(2, G);
-#define RFS_LAUNCH_EXACT(FAM, QQ, MDL, MDLC)                                                                            \
+            // big batches in rounds ("swd_exact_budget"): a budget of evaluations per lane, the unfinished groups continued with 16
+            // lanes each.  Lists of a quarter of the groups; one that overflows is not an error (those groups finish in place).
+            const int budget = (!coop && c->exact_budget > 0 && n - 1 <= 64) ? c->exact_budget : 0;
+            const size_t xcap = budget ? std::max<size_t>(4096, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 4) : 1;
+            if (budget) {
+                ENSURE(c, c->xsp, xcap * (EXACT_SPILL_ND + 1) * sizeof(double)); ENSURE(c, c->xspc, 2 * sizeof(int));
+                HIPCHK(c, hipMemsetAsync(c->xspc.p, 0, 2 * sizeof(int), s));
+            }
+#define RFS_LAUNCH_EXACT(FAM, QQ, MDL, MDLC, CI)                                                                        \
             do {                                                                                                       \
                 const int ng = ngroups(QQ, G);                                                                          \
+                const size_t ldsb = (size_t)4 * ((size_t)(n - 1) * FAM::NENT + FAM::NV) * sizeof(double);               \
+                ExactSpill none{nullptr, nullptr, c->xspc.p ? c->xspc.as<int>() + (CI) : (int*)nullptr, 0};            \
                 if (coop) {                                                                                             \
-                    const size_t ldsb = (size_t)4 * ((size_t)(n - 1) * FAM::NENT + FAM::NV) * sizeof(double);           \
                     const unsigned gx = (unsigned)std::min<size_t>(((size_t)ng * nchain + 3) / 4, (size_t)4096);        \
                     hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(std::max(1u, gx)), dim3(64), ldsb, s, nchain, n, QQ, G, ru, ng, \
-                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr); \
+                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, none); \
+                } else if (budget) {                                                                                    \
+                    double* xd = c->xsp.as<double>();                                                                   \
+                    ExactSpill sp{xd, (unsigned long long*)(xd + (size_t)EXACT_SPILL_ND * xcap), c->xspc.as<int>() + (CI), (int)xcap}; \
+                    hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
+                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, sp, budget); \
+                    const unsigned gx = (unsigned)std::min<size_t>((xcap + 3) / 4, (size_t)4096);                       \
+                    hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(gx), dim3(64), ldsb, s, nchain, n, QQ, G, ru, ng,    \
+                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, sp); \
                 } else {                                                                                                \
                     hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
-                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W);  \
+                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, none, 0x7fffffff); \
                 }                                                                                                       \
             } while (0)
-            if (Q.nper_total > 0) RFS_LAUNCH_EXACT(SwdRayFamily, Q, mdlR, c->mdlc.as<double>());
-            if (P.QL.nper_total > 0) RFS_LAUNCH_EXACT(SwdLoveFamily, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>());
+            if (Q.nper_total > 0) RFS_LAUNCH_EXACT(SwdRayFamily, Q, mdlR, c->mdlc.as<double>(), 0);
+            if (P.QL.nper_total > 0) RFS_LAUNCH_EXACT(SwdLoveFamily, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), 1);
 #undef RFS_LAUNCH_EXACT
             HIPCHK(c, hipGetLastError());
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
@@ -1612,7 +1631,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1771,6 +1790,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [1, 4096]");
         c->exact_group = value; return RFS_OK;      // (1: the 16-lane form only; a lane per group takes >= 2)
     }
+    if (!strcmp(name, "swd_exact_budget")) {
+        if (value < 0 || value > 100000) return fail(c, RFS_ERR_ARG, "swd_exact_budget must be within [0, 100000]");
+        c->exact_budget = value; return RFS_OK;
+    }
     if (!strcmp(name, "swd_exact_coop")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_exact_coop must be 0, 1 or 2");
         c->exact_coop = value; return RFS_OK;
@@ -1872,6 +1895,8 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     else if (!strcmp(name, "swd_warm_wide_chains")) idx = 13;
     else if (!strcmp(name, "swd_exact_declined_chains")) idx = 14;
     else if (!strcmp(name, "swd_exact_secular_evals")) idx = 15;
+    else if (!strcmp(name, "swd_exact_evals_slowest_lane")) idx = 3;
+    else if (!strcmp(name, "swd_exact_wavefronts")) idx = 16;
     else if (!strncmp(name, "swd_warm_cause_", 15)) { idx = atoi(name + 15); if (idx < 4 || idx > 11) idx = -1; }
     else if (!strcmp(name, "swd_warm_fail_no_change")) idx = 24;
     else if (!strcmp(name, "swd_warm_fail_other")) idx = 25;

@@ -1708,10 +1708,21 @@ k_swd_warm_walk_dense(int nchain, int n, SwdSeqs Q, const float* __restrict__ md
 // to the full search are skipped; a lane that cannot do its job (ExactGroup's X_FAIL causes) puts its chain on list3.
 // mdl: the float32 search model (start value of the scan of a sequence's first period).
 // ---------------------------------------------------------------------------------------
+// In rounds (round 6): a wavefront executes what its slowest lane needs -- 47 evaluations where the lanes need 38.5 on average, and
+// the stage ends with its slowest wavefront.  With a budget every lane gets that many evaluations; the groups that are unfinished
+// then (ExactGroupT::save: the whole machine, in the middle of a period if need be) go to a second launch, k_swd_exact_coop with
+// 16 lanes per group.  A machine's sequence of evaluations does not depend on where it runs: the same roots bit for bit.
+struct ExactSpill {
+    double* d;                    // [EXACT_SPILL_ND][cap]
+    unsigned long long* item;     // [cap] the group's global index grp * nchain + chain (~0: not a slot)
+    int* count;                   // slots handed out (may exceed cap: the lanes beyond finish in place)
+    int cap;
+};
+
 template <class F>
 __global__ void __launch_bounds__(64)
 k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float origin_tol, const float* __restrict__ mdl,
-            const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W)
+            const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, ExactSpill out, int budget)
 {
     const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
     bool live = g < (size_t)ngroups * nchain;
@@ -1743,25 +1754,55 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float o
         const double cc = (double)swd_start_value(M, bmx);
         x.begin(kr, k0, k1, cc, bmx, kr > 0 ? approx(kr - 1) * (1.0 - EXACT_OFFSET) : 0.0, approx, om, nevtab + threadIdx.x, 64, origin_tol);
     }
-    while (__any(x.active())) {
-        if (x.active()) {
-            x.advance(swd_secular_family<F, true>(n, loadL, x.omega, x.creq, &vc));      // (DUAL: this kernel is short of wavefronts)
-            if (x.phase == ExactGroup::X_DONE) {
-                if (x.wanted()) croot[e0 + (size_t)x.k * nchain] = (double)(float)x.root();       // surfdisp96.f:302
-                x.next(approx, om);                     // (the last period: stays X_DONE)
+    int left = budget, used = 0;
+    bool spilled = false;
+    for (;;) {
+        while (__any(x.active() && left > 0)) {
+            if (x.active() && left > 0) {
+                x.advance(swd_secular_family<F, true>(n, loadL, x.omega, x.creq, &vc));      // (DUAL: this kernel is short of wavefronts)
+                left--; used++;
+                if (x.phase == ExactGroup::X_DONE) {
+                    if (x.wanted()) croot[e0 + (size_t)x.k * nchain] = (double)(float)x.root();       // surfdisp96.f:302
+                    x.next(approx, om);                     // (the last period: stays X_DONE)
+                }
             }
         }
+        // out of budget: the unfinished groups of this wavefront go to the second launch, densely
+        const bool unfinished = x.active();
+        const unsigned long long um = __ballot(unfinished);
+        if (um == 0ull) break;
+        int sbase = 0;
+        const int nun = __popcll(um);
+        if ((threadIdx.x & 63) == 0) sbase = atomicAdd(out.count, nun);
+        sbase = __shfl(sbase, 0, 64);
+        if (sbase + nun > out.cap) {
+            // no room: the slots handed out stay empty, the groups finish here
+            if (unfinished) { const int sl = sbase + __popcll(um & ((1ull << (threadIdx.x & 63)) - 1ull)); if (sl < out.cap) out.item[sl] = ~0ull; }
+            left = 0x7fffffff;
+            continue;
+        }
+        if (unfinished) {
+            const size_t sl = (size_t)sbase + __popcll(um & ((1ull << (threadIdx.x & 63)) - 1ull));
+            x.save(out.d + sl, (size_t)out.cap);
+            out.item[sl] = (unsigned long long)g;
+            spilled = true;
+        }
+        break;
     }
-    if (live && x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
+    if (live && !spilled && x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
         W.list3[atomicAdd(W.count3, 1)] = chain;
         atomicAdd(&W.stats[0], 1ull);
         atomicAdd(&W.stats[14], 1ull);
         if (x.cause >= 1 && x.cause <= 7) atomicAdd(&W.stats[16 + x.cause], 1ull);       // "swd_exact_cause_<k>" (ExactGroup's X_FAIL causes)
     }
-    int nev = x.nev;
+    int nev = spilled ? 0 : x.nev, nmax = used;         // (a group passed on is counted where it finishes)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) nev += __shfl_xor(nev, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&W.stats[15], (unsigned long long)nev);
+    for (int off = 32; off >= 1; off >>= 1) { nev += __shfl_xor(nev, off, 64); nmax = max(nmax, __shfl_xor(nmax, off, 64)); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&W.stats[15], (unsigned long long)nev);
+        // divergence of the stage: evaluations of each wavefront's slowest lane (what the wavefront executes is 64 x this), wavefronts
+        atomicAdd(&W.stats[3], (unsigned long long)nmax); atomicAdd(&W.stats[16], 1ull);
+    }
 }
 
 // The same stage with LG = 16 lanes per group (round 6), for the batches that leave the chip mostly empty (a few hundred chains;
@@ -1774,7 +1815,7 @@ template <class F>
 __global__ void __launch_bounds__(64)
 k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float origin_tol, const float* __restrict__ mdl,
                  const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, const int* __restrict__ glist,
-                 const int* __restrict__ gcount)
+                 const int* __restrict__ gcount, ExactSpill in)
 {
     constexpr int LG = 16, NG = 64 / LG, LPL = 4, NENT = F::NENT, NV = F::NV;
     extern __shared__ double xcoop_lds[];        // per group: entries [m][NENT], then the half-space vector [NV]
@@ -1782,18 +1823,20 @@ k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, fl
     const int lane = threadIdx.x & 63, grp_l = lane / LG, lg = lane - grp_l * LG;
     double* const ent_g = xcoop_lds + (size_t)grp_l * ((size_t)(n - 1) * NENT + NV);
     double* const hs_g = ent_g + (size_t)(n - 1) * NENT;
-    const size_t total = glist ? (size_t)*gcount : (size_t)ngroups * nchain;
+    // in.d != nullptr: the groups a first launch of k_swd_exact left unfinished, continued from their saved machines
+    const size_t total = in.d ? (size_t)min(*in.count, in.cap) : (glist ? (size_t)*gcount : (size_t)ngroups * nchain);
     const FmVC vc = fm_vc_load();
     for (size_t blk = blockIdx.x; blk * NG < total; blk += gridDim.x) {
         const size_t slot = blk * NG + grp_l;
         bool live = slot < total;
-        const size_t g = live ? (glist ? (size_t)glist[slot] : slot) : 0;
+        size_t g = live ? (in.d ? (size_t)in.item[slot] : (glist ? (size_t)glist[slot] : slot)) : 0;
+        if (in.d && g == ~0ull) { live = false; g = 0; }
         const int grp = (int)(g / nchain), chain = (int)(g - (size_t)grp * nchain);
         int seq = 0, gl = grp;
         while (seq + 1 < Q.nseq && gl >= (Q.s[seq].nper + G - 1) / G) { gl -= (Q.s[seq].nper + G - 1) / G; seq++; }
         const int nper = Q.s[seq].nper;
         const int k0 = gl * G, k1 = min(k0 + G, nper), kr = max(0, k0 - runup);
-        live = live && k0 < nper && !W.need[chain];
+        live = live && k0 < nper && (in.d || !W.need[chain]);       // (a saved machine is finished whatever its chain's fate: its count)
         const size_t s = (size_t)n * nchain;
         const size_t e0 = (size_t)Q.s[seq].croot_off * nchain + chain;
         const double* cw = W.cwarm + e0;
@@ -1808,7 +1851,9 @@ k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, fl
         };
         ExactGroup x;
         x.phase = ExactGroup::X_DONE; x.nev = 0; x.cause = 0; x.creq = 1.0; x.omega = 1.0;
-        if (live) {
+        x.nv.tab.base = nevtab + threadIdx.x; x.nv.tab.stride = 64;
+        if (live && in.d) x.load(in.d + slot, (size_t)in.cap, nevtab + threadIdx.x, 64);
+        else if (live) {
             SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
             float bmx = 0.f;
             const double cc = (double)swd_start_value(M, bmx);
@@ -1858,13 +1903,6 @@ k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, fl
                 delta = swd_finish_n<NV>(ev);
             }
             __syncthreads();
-#ifdef RFS_DEBUG_COOP
-            if (act && lg == 0) {        // (debug builds: the cooperative evaluation against the single lane's, value by value)
-                const double d1 = swd_secular_family<F, true>(n, loadL, x.omega, x.creq, &vc);
-                atomicAdd(&W.stats[16], 1ull);
-                if (d1 != delta) atomicAdd(&W.stats[3], 1ull);
-            }
-#endif
             if (act) {
                 x.advance(delta);
                 if (x.phase == ExactGroup::X_DONE) {

@@ -1003,6 +1003,7 @@ struct WarmSearch {
 // ---------------------------------------------------------------------------
 constexpr double EXACT_ORIGIN_ERR = 4.0e-7;    // ... which leaves the first run-up origin within this of the reference's (relative)
 constexpr double EXACT_ORIGIN_TOL = 1.0e-7;    // origin accuracy a wanted period needs (see ExactGroupT::step_nevill): two run-up periods of a smooth secular function leave ~1e-11, roots found by bisections alone leave the 4e-7
+constexpr int EXACT_SPILL_ND = 68;           // doubles of ExactGroupT::save / load
 constexpr double EXACT_OFFSET = 0.75e-6;     // the reference's root lies 0.5 .. 1.0e-6 c below the sign change: the run-up's first origin is moved by the mean
 
 // nevill (surfdisp96.f:568-687) inside a bracket, as a request machine of its own -- the same decisions and the same
@@ -1253,6 +1254,38 @@ struct ExactGroupT {
             return;
         }
         step_nevill(f);
+    }
+
+    // The whole machine out of / into EXACT_SPILL_ND doubles at stride cp (k_swd_exact in rounds: a lane that has used up its
+    // budget of evaluations hands its group on, in the middle of a period if need be).  Integers, flags and float32 values
+    // travel as doubles (exact); the Neville table goes along.  load() installs `tab` as the table's storage.
+    RFS_HD void save(double* D, size_t cp) const {
+        int f = 0;
+        auto put = [&](double v) { D[(size_t)f * cp] = v; f++; };
+        put(nv.c1); put(nv.c2); put(nv.del1); put(nv.del2); put(nv.c3); put(nv.del3v); put(nv.creq); put(nv.result);
+        put((double)nv.phase); put((double)nv.nev); put((double)nv.m); put((double)nv.nctrl); put((double)nv.nsupplied);
+        put(nv.ex1 ? 1.0 : 0.0); put(nv.ex2 ? 1.0 : 0.0); put(nv.lin ? 1.0 : 0.0);
+        put((double)nv.betmx); put((double)nv.g1); put((double)nv.g2); put((double)nv.g3);
+        for (int i = 0; i < 24; i++) put(nv.tab.base[i * nv.tab.stride]);
+        put(creq); put(omega); put(o); put(rhat); put(c1); put(c2); put(del1); put(del2s); put(cprev); put(cc); put(dcs);
+        put((double)k); put((double)k0); put((double)k1); put((double)phase); put((double)dir); put((double)msteps);
+        put((double)shifted); put((double)nev); put((double)cause); put((double)nsupplied);
+        put((double)betmx); put((double)oerr); put((double)otol);
+    }
+    RFS_HD void load(const double* D, size_t cp, double* tab, int tabstride) {
+        int f = 0;
+        auto get = [&]() { const double v = D[(size_t)f * cp]; f++; return v; };
+        nv.c1 = get(); nv.c2 = get(); nv.del1 = get(); nv.del2 = get(); nv.c3 = get(); nv.del3v = get(); nv.creq = get(); nv.result = get();
+        nv.phase = (int)get(); nv.nev = (int)get(); nv.m = (int)get(); nv.nctrl = (int)get(); nv.nsupplied = (int)get();
+        nv.ex1 = get() != 0.0; nv.ex2 = get() != 0.0; nv.lin = get() != 0.0;
+        nv.betmx = (float)get(); nv.g1 = (float)get(); nv.g2 = (float)get(); nv.g3 = (float)get();
+        nv.tab.base = tab; nv.tab.stride = tabstride;
+        for (int i = 0; i < 24; i++) tab[i * tabstride] = get();
+        creq = get(); omega = get(); o = get(); rhat = get(); c1 = get(); c2 = get(); del1 = get(); del2s = get(); cprev = get();
+        cc = get(); dcs = get();
+        k = (int)get(); k0 = (int)get(); k1 = (int)get(); phase = (int)get(); dir = (int)get(); msteps = (int)get();
+        shifted = (int)get(); nev = (int)get(); cause = (int)get(); nsupplied = (int)get();
+        betmx = (float)get(); oerr = (float)get(); otol = (float)get();
     }
 
     RFS_HD double root() const { return cprev; }             // unrounded (the next period's origin); the output is (float) of it

@@ -422,6 +422,24 @@ def with_host_threads(fn):
 
 
 _SIDE_STREAMS = {}
+# How the HOST waits for an event.  A rank runs one step ahead of the device and waits for most of every step; the runtime's
+# synchronize calls spin -- measured on the GPU boxes (ROCm 7.2): Event.synchronize() keeps the calling thread at 100 % of a
+# core, with or without the blocking-sync flag, and a helper thread of the runtime beside it: 2.0 cores per rank, 9.1 ms of CPU
+# per 4.65 ms step (bench.py: host_cpu_ms_per_step), which eight ranks on a node's 16-CPU quota do not have.  Polling
+# Event.query() between short sleeps costs 0.002 s of CPU where the spin costs 0.143 s.  RFS_HOST_SPIN=1: the runtime's wait.
+HOST_WAIT_BLOCKS = False
+HOST_WAIT_POLLS = os.environ.get("RFS_HOST_SPIN", "0") != "1"
+HOST_POLL_SLEEP = 5.0e-5
+
+
+def host_wait(ev):
+    """Wait for a torch.cuda.Event on the host without spinning (see HOST_WAIT_POLLS)."""
+    if HOST_WAIT_POLLS:
+        import time
+        while not ev.query():
+            time.sleep(HOST_POLL_SLEEP)
+    else:
+        ev.synchronize()
 ASYNC_MIN_CHAINS = int(os.environ.get("RFS_ASYNC_MIN_CHAINS", "64"))      # populations below this keep hand-backs in the foreground (run_flow)
 
 
@@ -505,12 +523,12 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         pinned[key][1] = (nxt + 1) % len(bufs)
         slot = bufs[nxt]
         if slot[1] is not None:
-            slot[1].synchronize()                 # the copy that last read this buffer has finished
+            host_wait(slot[1])                    # the copy that last read this buffer has finished
         h = slot[0][: a.shape[0]]
         h.copy_(src)
         out = h.to(dev, non_blocking=True)
         if slot[1] is None:
-            slot[1] = torch.cuda.Event()
+            slot[1] = torch.cuda.Event(blocking=HOST_WAIT_BLOCKS)
         slot[1].record(torch.cuda.current_stream(dev))
         return out
 
@@ -551,7 +569,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         their rows; chains the device restarted (done = 2 / 3) with the parked results and the accept flags."""
         done, ev, s, rb = marks.pop(0)
         if rb is not None:
-            ev.synchronize()                      # the step is through: its records are complete
+            host_wait(ev)                         # the step is through: its records are complete
             stamp = float(s + 1)
             # this step's records: from the cursor on, as long as they carry its stamp (then comes a stale slot or one of the
             # step that is running now)
@@ -632,14 +650,14 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         offs = parts_of(put)
         slot = stage[stage_next[0]]; stage_next[0] = (stage_next[0] + 1) % len(stage)
         if slot[1] is not None:
-            slot[1].synchronize()                 # the launch / copy that last read this buffer has run
+            host_wait(slot[1])                    # the launch / copy that last read this buffer has run
         if slot[0] is None or slot[0].numel() < off[0]:
             slot[0] = torch.empty(max(off[0], 1 << 16), dtype=torch.uint8, pin_memory=True)
         h = slot[0].numpy()
         for o, a in parts:
             h[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
         if slot[1] is None:
-            slot[1] = torch.cuda.Event()
+            slot[1] = torch.cuda.Event(blocking=HOST_WAIT_BLOCKS)
         src = slot[0] if (off[0] <= ZERO_COPY_MAX and not LEGACY_TAIL) else slot[0][:off[0]].to(dev, non_blocking=True)
         return slot, src, offs
 
@@ -681,7 +699,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         model.flow_step(st); steps += 1
         ev = None
         if side is not None or use_rec:
-            ev = torch.cuda.Event(); ev.record()
+            ev = torch.cuda.Event(blocking=HOST_WAIT_BLOCKS); ev.record()
         marks.append((st["done"], ev, steps - 1, rb))
 
     capped = lambda: max_steps is not None and steps >= max_steps
@@ -695,7 +713,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
         if pipeline and more and not early:
             step()                               # the chains that wait for the host idle in this step (rem = -1, fresh = 0)
         if uploaded:
-            uploaded.pop().synchronize()         # bounds how far the host runs ahead (the staging buffers guard themselves, t())
+            host_wait(uploaded.pop())            # bounds how far the host runs ahead (the staging buffers guard themselves, t())
         if len(idx1):
             wd = idx1[:0]
             if restart is not None:
@@ -776,7 +794,7 @@ def _run_flow(model, st, process_done, active, fetch_syn, pipeline, max_steps, s
                     if rem is not None:
                         dep_rem[sel] = rem
         if dev.type == "cuda":
-            ev = torch.cuda.Event(); ev.record(); uploaded.append(ev)
+            ev = torch.cuda.Event(blocking=HOST_WAIT_BLOCKS); ev.record(); uploaded.append(ev)
         if not active() or capped():
             break
         if not pipeline:

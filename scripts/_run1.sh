@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 1700 python3 -m pytest tests -x -q -m gpu > gpurun_out/r06_gpu_suite.txt 2>&1; tail -6 gpurun_out/r06_gpu_suite.txt
-bash scripts/ab_bench.sh 2 "RFSURF_LIB=$PWD/ab/librfsurf_base6.so,RFS_FLOW_RECORDS=0" "-" > gpurun_out/r06_ab_all.txt 2>&1
-cat gpurun_out/r06_ab_all.txt
+timeout 300 python3 scripts/host_cpu_threads.py 2>&1 | tail -5
+for v in 1 0; do RFS_HOST_SPIN=$v timeout 300 python3 bench.py --headline-only --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('spin $v', d['ms_per_step'], d['value'], 'host cpu ms/step', d.get('host_cpu_ms_per_step'))"; done

@@ -605,6 +605,22 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
     for i in range(4):
         assert np.array_equal(r[0][i], r[2][i]), i
     _same_counters(r[0][4], r[2][4])
+    # ... and in ROUNDS ("swd_exact_budget"): a lane per group with a budget of evaluations, the unfinished groups' machines
+    # saved in the middle of whatever they were doing and continued by the 16-lane kernel -- budgets that pass on a few per
+    # cent of the groups, most of them, and (5) every one, the last also overflowing the list
+    try:
+        ctx.set_option("swd_exact_coop", 0)
+        rb = {}
+        for budget in (0, 44, 30, 5):
+            ctx.set_option("swd_exact_budget", budget)
+            s = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+            mis = s.sample_flow(x_init=xb, max_steps=80, async_handback=False)
+            rb[budget] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories))
+    finally:
+        ctx.set_option("swd_exact_budget", 0); ctx.set_option("swd_exact_coop", 1)
+    for budget in (0, 44, 30, 5):
+        for i in range(4):
+            assert np.array_equal(rb[budget][i], r[0][i]), (budget, i)
     # configs[0]'s plugin: 10 layers, 36 Rc + 36 Rg periods (four sequences per chain)
     thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
     tt = np.arange(5., 41.)
