@@ -116,21 +116,34 @@ struct RfHyp {            // per (layer, frequency): cosh and the four scaled si
 };
 
 // nu*h = s*omega*pva*h with s chosen so that nu is the principal square root.
-RFS_HD void rf_hyp(const RfLayer& L, cplx omega, RfHyp& H) {
+// In two halves: the transcendental part -- e^{Re}, cos / sin of the imaginary part for the P and the S leg, six numbers -- and
+// everything that follows from it.  The row sweep (pass A) can leave the six numbers of every (layer, band frequency) in HBM
+// for the column sweep (pass B), which then skips two exponentials and two sine / cosine pairs per layer ("rf_store_hyp").
+struct RfHypB { double e1, c1, s1, e2, c2, s2; };
+RFS_HD void rf_hyp_base(const RfLayer& L, cplx omega, RfHypB& B) {
+    cplx ta = omega * L.pva, tb = omega * L.pvb;
+    B.e1 = fm_exp(L.h * ta.re); B.e2 = fm_exp(L.h * tb.re);
+    fm_sincos(L.h * ta.im, &B.s1, &B.c1);
+    fm_sincos(L.h * tb.im, &B.s2, &B.c2);
+}
+RFS_HD void rf_hyp_from(const RfLayer& L, cplx omega, const RfHypB& B, RfHyp& H) {
     cplx ta = omega * L.pva, tb = omega * L.pvb;
     H.sa = (ta.re > 0.0 || (ta.re == 0.0 && ta.im >= 0.0)) ? 1.0 : -1.0;
     H.sb = (tb.re > 0.0 || (tb.re == 0.0 && tb.im >= 0.0)) ? 1.0 : -1.0;
     // cosh / sinh of the complex arguments from ONE exp, one reciprocal and one sincos each:
     // e^{a+ib} = e^a (c + i s), e^{-(a+ib)} = e^{-a} (c - i s)  ->  cosh = (ch c, sh s), sinh = (sh c, ch s)
-    double e1 = fm_exp(L.h * ta.re), s1, c1, e2 = fm_exp(L.h * tb.re), s2, c2;
-    fm_sincos(L.h * ta.im, &s1, &c1);
-    fm_sincos(L.h * tb.im, &s2, &c2);
+    const double e1 = B.e1, s1 = B.s1, c1 = B.c1, e2 = B.e2, s2 = B.s2, c2 = B.c2;
     double i1 = rcp_p(e1), i2 = rcp_p(e2);
     double ch1 = 0.5 * (e1 + i1), sh1 = 0.5 * (e1 - i1), ch2 = 0.5 * (e2 + i2), sh2 = 0.5 * (e2 - i2);
     H.ca = cplx{ch1 * c1, sh1 * s1}; H.cb = cplx{ch2 * c2, sh2 * s2};
     cplx sha = H.sa * cplx{sh1 * c1, ch1 * s1}, shb = H.sb * cplx{sh2 * c2, ch2 * s2};
     H.xa = L.va * sha; H.ya = sha * L.iva;
     H.xb = L.vb * shb; H.yb = shb * L.ivb;
+}
+RFS_HD void rf_hyp(const RfLayer& L, cplx omega, RfHyp& H) {
+    RfHypB B;
+    rf_hyp_base(L, omega, B);
+    rf_hyp_from(L, omega, B, H);
 }
 
 struct V4 { cplx v[4]; };

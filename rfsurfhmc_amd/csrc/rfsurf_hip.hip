@@ -121,6 +121,8 @@ struct rfs_ctx {
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
     int exact_budget = 44;     // option "swd_exact_budget": evaluations a lane of k_swd_exact may spend before its group goes on to the 16-lane launch (0: one round)
     Buf xsp, xspc;             // ... the saved machines of those groups (ExactSpill) and their counts (Rayleigh, Love)
+    int exact_redo_runup = 0;  // option "swd_exact_redo_runup": > "swd_exact_runup": a group whose run-up did not contract is done again with this many run-up periods (k_swd_exact_coop over a list) instead of handing its chain back; 0 = hand back
+    Buf xredo;                 // ... the lists of those groups
     int exact_coop = 1;        // option "swd_exact_coop": 0 never, 1 (default) 16 lanes per group for small batches (k_swd_exact_coop), 2 always (tests)
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
@@ -145,6 +147,8 @@ struct rfs_ctx {
     Buf gtab, etab; double mid_tab_key[6] = {0, 0, 0, 0, 0, 0};   // chain-independent factors of the fused middle section (k_rf_mid_tables)
     int rf_f32 = RFS_F32_DEFAULT;                       // option "rf_f32_beyond_band": pass A sweeps the frequencies beyond the gradient's band in float32 where that is provably enough
     Buf hi32, stat32;                     // [chain] pass A's choice; [66] chains swept again in f64 by k_rf_mid1, chains swept in float32 (64 slots)
+    int rf_store_hyp = 0;                 // (measured, round 6: 4.73-4.81 -> 4.90-4.97 ms per step -- 110 instructions per layer of pass B saved, 2.9 GB of HBM traffic per step and their latency added: off) option "rf_store_hyp": pass A leaves exp / cos / sin of every (layer, band frequency) for pass B (row peeling only)
+    Buf Hs; double* Hs_cur = nullptr;     // [chain][layer][6][nkp]; what the pass A of the evaluation being launched wrote (nullptr: nothing)
     int rf_peel_check = 0;                // option "rf_peel_check": pass B records the closure residual (statistic rf_peel_residual)
     Buf x, misfit, grad, dsyn, flag, lc, cr, mdl, RR, Rs, spec, tser, wres, W, wmax2, PG, mrf, croot, sflag, edone,
         cds, krn, ugr, b1a, b1b, b1c, b1d, b1e, b1f, b1g, specp, tserp, klbuf, bt;
@@ -382,7 +386,13 @@ int launch_passA(rfs_ctx* c, int nchain, int n, const RfFreq& f, bool scratch, s
     RfFreq fa = f;
     int* hi = nullptr;
     if (rf_f32_on(c, f)) { fa.e32max = rf_f32_emax(n); ENSURE(c, c->hi32, (size_t)nchain * sizeof(int)); hi = c->hi32.as<int>(); }
-    hipLaunchKernelGGL(k_rf_passA, grid, dim3(bs), 0, c->stream, nchain, n, fa, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn, hi);
+    // "rf_store_hyp": with row peeling pass A leaves the six transcendental numbers of every (layer, band frequency) for pass B
+    // (1.5 GB at 8192 chains x 29 layers x 128 frequencies), as long as that fits the scratch budget
+    double* Hs = nullptr;
+    const size_t hsb = (size_t)nchain * (n - 1) * 6 * f.nkp * sizeof(double);
+    if (RT && c->rf_store_hyp && f.nk < f.n2 && hsb <= c->rf_scratch_budget) { ENSURE(c, c->Hs, hsb); Hs = c->Hs.as<double>(); }
+    c->Hs_cur = Hs;
+    hipLaunchKernelGGL(k_rf_passA, grid, dim3(bs), 0, c->stream, nchain, n, fa, lc, c->RR.as<double>(), Rs, RT, sl, sc, scn, hi, Hs);
     HIPCHK(c, hipGetLastError());
     return RFS_OK;
 }
@@ -480,8 +490,12 @@ int launch_passB(rfs_ctx* c, int nchain, int n, const RfFreq& f, size_t c0 = 0, 
             HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_hscount, c->h_scount, 0));
         }
         if (*c->h_scount >= 0) c->stored_est = *c->h_scount;
-        hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
-                           c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe);
+        if (c->Hs_cur)
+            hipLaunchKernelGGL((k_rf_passB<false, true, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
+                               c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe, (const double*)c->Hs_cur);
+        else
+            hipLaunchKernelGGL((k_rf_passB<false, true>), grid, dim3(bs), 0, c->stream, nchain, n, f, lc, c->RR.as<double>(), rows, rt,
+                               c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr, nol, nol, noe, (const double*)nullptr);
         const int gy = c->stored_est < 0 ? nchain : std::max(8, std::min(nchain, c->stored_est + c->stored_est / 8));
         hipLaunchKernelGGL((k_rf_passB<false, false>), dim3(rf_chunks_b(f), gy), dim3(bs), 0, c->stream, nchain, n, f, lc,
                            c->RR.as<double>(), rows, rt, c->W.as<cplx>(), c->wmax2.as<double>(), npart, c->PG.as<double>(), pr,
@@ -1022,29 +1036,42 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             const int budget = (!coop && c->exact_budget > 0 && n - 1 <= 64) ? c->exact_budget : 0;
             const size_t xcap = budget ? std::max<size_t>(4096, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 4) : 1;
             if (budget) {
-                ENSURE(c, c->xsp, xcap * (EXACT_SPILL_ND + 1) * sizeof(double)); ENSURE(c, c->xspc, 2 * sizeof(int));
-                HIPCHK(c, hipMemsetAsync(c->xspc.p, 0, 2 * sizeof(int), s));
+                ENSURE(c, c->xsp, xcap * (EXACT_SPILL_ND + 1) * sizeof(double));
             }
+            // groups whose run-up did not contract: done again with a longer one ("swd_exact_redo_runup") instead of handing
+            // their chain to the sequential search
+            const int ru2 = c->exact_redo_runup > ru ? c->exact_redo_runup : 0;
+            const size_t rcap = ru2 ? std::max<size_t>(1024, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 8) : 1;
+            ENSURE(c, c->xspc, 4 * sizeof(int));
+            if (ru2) ENSURE(c, c->xredo, 2 * rcap * sizeof(int));
+            HIPCHK(c, hipMemsetAsync(c->xspc.p, 0, 4 * sizeof(int), s));
 #define RFS_LAUNCH_EXACT(FAM, QQ, MDL, MDLC, CI)                                                                        \
             do {                                                                                                       \
                 const int ng = ngroups(QQ, G);                                                                          \
                 const size_t ldsb = (size_t)4 * ((size_t)(n - 1) * FAM::NENT + FAM::NV) * sizeof(double);               \
-                ExactSpill none{nullptr, nullptr, c->xspc.p ? c->xspc.as<int>() + (CI) : (int*)nullptr, 0};            \
+                const ExactSpill none{nullptr, nullptr, c->xspc.as<int>() + (CI), 0};                                   \
+                const ExactRedo noredo{nullptr, nullptr, 0};                                                            \
+                const ExactRedo rd = ru2 ? ExactRedo{c->xredo.as<int>() + (size_t)(CI) * rcap, c->xspc.as<int>() + 2 + (CI), (int)rcap} : noredo; \
                 if (coop) {                                                                                             \
                     const unsigned gx = (unsigned)std::min<size_t>(((size_t)ng * nchain + 3) / 4, (size_t)4096);        \
                     hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(std::max(1u, gx)), dim3(64), ldsb, s, nchain, n, QQ, G, ru, ng, \
-                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, none); \
+                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, none, rd); \
                 } else if (budget) {                                                                                    \
                     double* xd = c->xsp.as<double>();                                                                   \
                     ExactSpill sp{xd, (unsigned long long*)(xd + (size_t)EXACT_SPILL_ND * xcap), c->xspc.as<int>() + (CI), (int)xcap}; \
                     hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
-                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, sp, budget); \
+                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, sp, budget, rd); \
                     const unsigned gx = (unsigned)std::min<size_t>((xcap + 3) / 4, (size_t)4096);                       \
                     hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(gx), dim3(64), ldsb, s, nchain, n, QQ, G, ru, ng,    \
-                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, sp); \
+                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, sp, rd); \
                 } else {                                                                                                \
                     hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
-                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, none, 0x7fffffff); \
+                                       nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, none, 0x7fffffff, rd); \
+                }                                                                                                       \
+                if (ru2) {                                                                                              \
+                    const unsigned gr = (unsigned)std::min<size_t>((rcap + 3) / 4, (size_t)1024);                       \
+                    hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(gr), dim3(64), ldsb, s, nchain, n, QQ, G, ru2, ng,   \
+                                       c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)rd.list, (const int*)rd.count, none, noredo); \
                 }                                                                                                       \
             } while (0)
             if (Q.nper_total > 0) RFS_LAUNCH_EXACT(SwdRayFamily, Q, mdlR, c->mdlc.as<double>(), 0);
@@ -1631,7 +1658,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc, &c->xredo, &c->Hs};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1789,6 +1816,11 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_exact_group")) {
         if (value < 1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [1, 4096]");
         c->exact_group = value; return RFS_OK;      // (1: the 16-lane form only; a lane per group takes >= 2)
+    }
+    if (!strcmp(name, "rf_store_hyp")) { c->rf_store_hyp = value != 0; return RFS_OK; }
+    if (!strcmp(name, "swd_exact_redo_runup")) {
+        if (value < 0 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_redo_runup must be within [0, 64]");
+        c->exact_redo_runup = value; return RFS_OK;
     }
     if (!strcmp(name, "swd_exact_budget")) {
         if (value < 0 || value > 100000) return fail(c, RFS_ERR_ARG, "swd_exact_budget must be within [0, 100000]");

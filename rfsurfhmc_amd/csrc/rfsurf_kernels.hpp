@@ -306,7 +306,7 @@ template <bool TAIL>
 __device__ __forceinline__ void
 rf_passA_rows(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
               double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
-              int* __restrict__ scount_next, int* __restrict__ hi32, const int cy)
+              int* __restrict__ scount_next, int* __restrict__ hi32, const int cy, double* __restrict__ Hs = nullptr)
 {
     int chain, k;
     bool live = true;
@@ -363,14 +363,21 @@ rf_passA_rows(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc
     }
     V4 r = rf_einv_row(L[n - 1], f.rf_type);
     double* rs = (store && k < f.nk) ? Rs + ((size_t)chain * (n - 1)) * 8 * nkp + k : nullptr;
+    // the transcendental numbers of every (layer, band frequency) for pass B (rf_hyp_base; [chain][layer][6][nkp])
+    double* hs = (!TAIL && Hs && !store && k < f.nk) ? Hs + ((size_t)chain * (n - 1)) * 6 * nkp + k : nullptr;
     for (int j = n - 2; j >= 0; j--) {
         if (rs) {
             double* q = rs + (size_t)j * 8 * nkp;
 #pragma unroll
             for (int i = 0; i < 4; i++) { q[(2 * i) * nkp] = r.v[i].re; q[(2 * i + 1) * nkp] = r.v[i].im; }
         }
-        RfHyp H; RfA A;
-        rf_hyp(L[j], omega, H);
+        RfHyp H; RfA A; RfHypB B;
+        rf_hyp_base(L[j], omega, B);
+        if (hs) {
+            double* q = hs + (size_t)j * 6 * nkp;
+            q[0] = B.e1; q[nkp] = B.c1; q[2 * nkp] = B.s1; q[3 * nkp] = B.e2; q[4 * nkp] = B.c2; q[5 * nkp] = B.s2;
+        }
+        rf_hyp_from(L[j], omega, B, H);
         rf_build_A(L[j], H, A);
         r = rf_row_times_A(r, A);
     }
@@ -390,13 +397,13 @@ rf_passA_rows(int nchain, int n, const RfFreq& f, const RfLayer* __restrict__ lc
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))      // (the bulk rows need 85 VGPRs; the Nyquist row's per-lane layer constants would cost the whole kernel a wavefront per SIMD)
 k_rf_passA(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, double* __restrict__ RR,
            double* __restrict__ Rs, double* __restrict__ RT, int* __restrict__ slist, int* __restrict__ scount,
-           int* __restrict__ scount_next, int* __restrict__ hi32)
+           int* __restrict__ scount_next, int* __restrict__ hi32, double* __restrict__ Hs)
 {
     if (blockIdx.y == 0) {                       // (block-uniform)
         if ((size_t)blockIdx.x * blockDim.x >= (size_t)nchain) return;
         rf_passA_rows<true>(nchain, n, f, lc, RR, Rs, RT, slist, scount, nullptr, nullptr, 0);
     } else {
-        rf_passA_rows<false>(nchain, n, f, lc, RR, Rs, RT, slist, scount, scount_next, hi32, (int)blockIdx.y - 1);
+        rf_passA_rows<false>(nchain, n, f, lc, RR, Rs, RT, slist, scount, scount_next, hi32, (int)blockIdx.y - 1, Hs);
     }
 }
 // ---------------------------------------------------------------------------------------
@@ -663,12 +670,13 @@ __device__ __forceinline__ V4 rf_adjoint_seed(const RfFreq& f, int k, cplx r21, 
 // INV: the row of layer j is the row of layer j-1 times A_j^-1, starting from pass A's final row (RT: [chain][8][nkp]) --
 // for the chains whose growth exponent allows it; the others read their stored rows (Rs).  With RT given both
 // instantiations are launched and each takes its own chains (a block = one chain: the other kind leaves at once).
-template <bool TAIL, bool INV = false>
+template <bool TAIL, bool INV = false, bool HST = false>      // HST: pass A stored exp / cos / sin of every (layer, frequency) (INV, not TAIL)
 __global__ void __launch_bounds__(256)      // 238 VGPRs -> 2 waves/SIMD; forcing 3 or 4 (spills) measured no faster
 k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const double* __restrict__ RR,
            const double* __restrict__ Rs, const double* __restrict__ RT, const cplx* __restrict__ W,
            const double* __restrict__ wmax2, int npart, double* __restrict__ PG, unsigned* __restrict__ peel_resid,
-           const int* __restrict__ slist, const int* __restrict__ scount, int* __restrict__ est_out)
+           const int* __restrict__ slist, const int* __restrict__ scount, int* __restrict__ est_out,
+           const double* __restrict__ Hs = nullptr)
 {
   // slist (stored-row launch beside a peeling one): the blocks' y index strides over the chains pass A listed
   const int nsel = (!TAIL && slist) ? *scount : 1;
@@ -703,11 +711,16 @@ k_rf_passB(int nchain, int n, RfFreq f, const RfLayer* __restrict__ lc, const do
 #pragma unroll
         for (int i = 0; i < 4; i++) r.v[i] = C(rs[(2 * i) * nkp], rs[(2 * i + 1) * nkp]);
     }
+    const double* hs = HST ? Hs + ((size_t)chain * (n - 1)) * 6 * nkp + k : nullptr;
     for (int j = 0; j < n; j++) {
         cplx T[4];
         if (j < n - 1) {
             RfHyp H; RfA A;
-            rf_hyp(L[j], omega, H);
+            if (HST) {                             // pass A left the exponentials, cosines and sines of this (layer, frequency)
+                const double* q = hs + (size_t)j * 6 * nkp;
+                const RfHypB B{q[0], q[nkp], q[2 * nkp], q[3 * nkp], q[4 * nkp], q[5 * nkp]};
+                rf_hyp_from(L[j], omega, B, H);
+            } else rf_hyp(L[j], omega, H);
             if (INV) {
                 rf_build_A(L[j], H, A);
                 const V4 ra = r;                                  // the row above this layer (= r A)
@@ -1719,10 +1732,22 @@ struct ExactSpill {
     int cap;
 };
 
+// Groups whose run-up did not bring their first origin within the tolerance (ExactGroup's cause 7: a run-up period whose root
+// was closed by bisections alone passes the origin's error on undiminished) -- with ONE run-up period 0.3 % of the groups.  They
+// are not handed to the sequential search but listed here and done again with a longer run-up (k_swd_exact_coop over the list).
+struct ExactRedo { int* list; int* count; int cap; };
+__device__ __forceinline__ bool swd_exact_redo(const ExactRedo& R, size_t g) {
+    if (!R.list) return false;
+    const int sl = atomicAdd(R.count, 1);
+    if (sl >= R.cap) return false;               // no room: the chain goes to the sequential search after all
+    R.list[sl] = (int)g;
+    return true;
+}
+
 template <class F>
 __global__ void __launch_bounds__(64)
 k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float origin_tol, const float* __restrict__ mdl,
-            const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, ExactSpill out, int budget)
+            const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, ExactSpill out, int budget, ExactRedo redo)
 {
     const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
     bool live = g < (size_t)ngroups * nchain;
@@ -1789,7 +1814,8 @@ k_swd_exact(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float o
         }
         break;
     }
-    if (live && !spilled && x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
+    if (live && !spilled && x.phase == ExactGroup::X_FAIL && x.cause == 7 && swd_exact_redo(redo, g)) {}
+    else if (live && !spilled && x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
         W.list3[atomicAdd(W.count3, 1)] = chain;
         atomicAdd(&W.stats[0], 1ull);
         atomicAdd(&W.stats[14], 1ull);
@@ -1815,7 +1841,7 @@ template <class F>
 __global__ void __launch_bounds__(64)
 k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, float origin_tol, const float* __restrict__ mdl,
                  const double* __restrict__ mdlc, double* __restrict__ croot, SwdWarm W, const int* __restrict__ glist,
-                 const int* __restrict__ gcount, ExactSpill in)
+                 const int* __restrict__ gcount, ExactSpill in, ExactRedo redo)
 {
     constexpr int LG = 16, NG = 64 / LG, LPL = 4, NENT = F::NENT, NV = F::NV;
     extern __shared__ double xcoop_lds[];        // per group: entries [m][NENT], then the half-space vector [NV]
@@ -1912,7 +1938,8 @@ k_swd_exact_coop(int nchain, int n, SwdSeqs Q, int G, int runup, int ngroups, fl
             }
         }
         if (live && lg == 0) {
-            if (x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
+            if (x.phase == ExactGroup::X_FAIL && x.cause == 7 && swd_exact_redo(redo, g)) {}
+            else if (x.phase == ExactGroup::X_FAIL && atomicExch(&W.need[chain], 1) == 0) {
                 W.list3[atomicAdd(W.count3, 1)] = chain;
                 atomicAdd(&W.stats[0], 1ull);
                 atomicAdd(&W.stats[14], 1ull);

@@ -1,5 +1,4 @@
 export TMPDIR=/tmp
-timeout 300 python3 scripts/host_cpu_threads.py 2>&1 | tail -5
-for v in 1 0; do RFS_HOST_SPIN=$v timeout 300 python3 bench.py --headline-only --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('spin $v', d['ms_per_step'], d['value'], 'host cpu ms/step', d.get('host_cpu_ms_per_step'))"; done
+mkdir -p gpurun_out
+bash scripts/ab_bench.sh 2 "RFS_OPTS=rf_store_hyp=0" "-" > gpurun_out/r06_ab_hst.txt 2>&1; cat gpurun_out/r06_ab_hst.txt
+timeout 1200 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_configs.py -x -q -m gpu > gpurun_out/r06_rf_tests.txt 2>&1; tail -4 gpurun_out/r06_rf_tests.txt

@@ -16,6 +16,9 @@ export WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -- python3 $root/bench.py --gpus 1 --no-cpu-baseline --headline-only > $root/gpurun_out/${tag}_stats_bench.json 2> /dev/null )
 unset WORLD_SIZE RANK LOCAL_RANK
 python3 scripts/step_timeline.py $(find gpurun_out/${tag}_stats -name "*kernel_trace.csv") 5 > gpurun_out/${tag}_step_timeline.txt
+cp $(find gpurun_out/${tag}_stats -name "*kernel_stats.csv") gpurun_out/${tag}_bench_kernel_stats.csv
+timeout 300 python3 scripts/event_timeline.py 100 > gpurun_out/${tag}_step_timeline_events.txt 2>&1
+timeout 300 python3 scripts/host_cpu_threads.py > gpurun_out/${tag}_host_cpu_threads.txt 2>&1
 rm -f $(find gpurun_out/${tag}_stats -name "*kernel_trace.csv")
 for cfg in 1 3 4; do
   timeout 600 python3 scripts/prof_run.py $cfg 10 hmc > gpurun_out/${tag}_burn_c$cfg.log 2>&1      # burn-in, kept in gpurun_out/burned_c<cfg>.npy
