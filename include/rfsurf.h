@@ -355,6 +355,18 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          0: keep the converged roots (within 1.1e-6 c of the reference's, misfits to ~1.4e-5, gradients to
  *                          ~1e-5 except on ill-conditioned chains): 2-3 times cheaper in the root search.
  *   "swd_exact_group" / "swd_exact_runup"   periods per lane (default 4, >= 2 -- 1 only with 16 lanes per group, "swd_exact_coop": measured best at 8192 chains x 40 periods -- fewer make more lanes and more run-up work, more make the kernel's dependent chain longer) and run-up periods (default 2; 1 with "swd_exact_origin_tol_e9" 500 is the faster, looser setting described there) of the above.
+ *   "swd_walk_window"      2 (default): which periods of a sequence with anomalous dispersion walk the reference's scan grid for the
+ *                          branch test.  -1 = all of them (rounds 3-5: 540 evaluations per such sequence and step, 2.0 M of
+ *                          the step's 6.3 M -- the first period alone scans 100-700 cells from the model's start value); W >= 0 =
+ *                          the periods within W of an anomalous pair (c(j) <= c(j-1) - 1.5 dc: the pair itself, W periods
+ *                          before and after); the others take the test of a sequence with normal dispersion -- one evaluation
+ *                          at the point their scan starts from.  A chain marked wide ("swd_warm_widen") and a sequence that
+ *                          walks for a root next to the fastest layer still walk whole.  Measured at 8192 chains: 9.6 -> 6.7
+ *                          evaluations per item in the warm stage, 4.75 -> 4.54 ms per step (same box; W = 0 / 1 / 4: 4.65 / 4.63 /
+ *                          4.56), 29 -> 27 chains per step handed back.  Against the oracle (the sampler run stopped at ten
+ *                          device steps, 53 360 mid-trajectory chains + 5 967 end models with W = 2): every root within the
+ *                          reference's own 1e-6 c bracket of the oracle's, 94.5 % of the chains with all 40 roots bit-identical
+ *                          -- the figures of -1 (profiles/r06_flow_parity_stats*.txt).
  *   "swd_exact_budget"     44 (default): the reference-root stage of big batches runs in two launches.  Its wavefronts execute what
  *                          their slowest lane needs (47 evaluations where the lanes need 38.5 on average: the lazy nevill's
  *                          count varies from period to period), and the stage ends with its slowest wavefront.  Every lane gets

@@ -119,6 +119,7 @@ struct rfs_ctx {
     // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
     // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
+    int walk_window = 2;       // option "swd_walk_window": periods around an anomalous one that walk the reference's grid (-1: the whole sequence)
     int exact_budget = 44;     // option "swd_exact_budget": evaluations a lane of k_swd_exact may spend before its group goes on to the 16-lane launch (0: one round)
     Buf xsp, xspc;             // ... the saved machines of those groups (ExactSpill) and their counts (Rayleigh, Love)
     int exact_redo_runup = 0;  // option "swd_exact_redo_runup": > "swd_exact_runup": a group whose run-up did not contract is done again with this many run-up periods (k_swd_exact_coop over a list) instead of handing its chain back; 0 = hand back
@@ -842,7 +843,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wsg1.as<unsigned char>(),
                   (c->flow_cur && c->flow_skip_idle) ? c->f_rem : (const int*)nullptr, c->f_fresh, c->f_ok,
                   c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0,
-                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr};
+                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr, c->walk_window};
         (void)0;
 // Rounds (WarmSpill, rfsurf_kernels.hpp): budgets b1, b2, b3 and a last round without one; the unfinished searches of a round
         // are packed into a list for the next.  The lists' lengths are only known on the device: the later rounds' grids are sized for
@@ -1816,6 +1817,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_exact_group")) {
         if (value < 1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [1, 4096]");
         c->exact_group = value; return RFS_OK;      // (1: the 16-lane form only; a lane per group takes >= 2)
+    }
+    if (!strcmp(name, "swd_walk_window")) {
+        if (value < -1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_walk_window must be -1 or within [0, 4096]");
+        c->walk_window = value; return RFS_OK;
     }
     if (!strcmp(name, "rf_store_hyp")) { c->rf_store_hyp = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_exact_redo_runup")) {

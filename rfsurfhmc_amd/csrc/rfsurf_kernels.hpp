@@ -1127,7 +1127,19 @@ struct SwdWarm {
     // this step's prediction: inside a trajectory consecutive moves dt M^-1 p are nearly equal, and so are their second-order
     // terms.  [item][chain]; zero where there is nothing to carry over (a trajectory that starts with this step, a failed search).
     double* ferr;
+    // "swd_walk_window" (round 6): < 0 = every period of a sequence with anomalous dispersion somewhere walks the reference's grid;
+    // W >= 0 = only the periods within W of an anomalous one (the pair j - 1, j with c(j) <= c(j - 1) - 1.5 dc counts for both)
+    // do, the others take the regular sequences' test -- one evaluation at the point their scan starts from
+    int walk_window;
 };
+// is period k of a sequence (roots cq, stride nchain) within `win` periods of an anomalous pair?
+__device__ __forceinline__ bool swd_walk_near(const double* cq, size_t nchain, int nper, int k, int win, double dcs) {
+    if (win < 0) return true;
+    const int j0 = max(1, k - win), j1 = min(nper - 1, k + win + 1);
+    bool near = false;
+    for (int j = j0; j <= j1; j++) near = near || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+    return near;
+}
 
 // Searches a round of k_swd_warm did not finish within its budget of evaluations: [field][slot], slot = position in the round's
 // list.  A wavefront executes what its SLOWEST lane needs, and the searches are very uneven -- 2 evaluations where the Newton start
@@ -1473,17 +1485,25 @@ k_swd_warm_check(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, co
     // secular function no longer changes sign there (the half-space term is taken by its absolute value, surfdisp96.f:744,
     // :815): a root within dc of that velocity -- Love waves at long periods -- is found or missed by the grid.  Such a
     // sequence walks the grid as well.
+    bool forced = false;
     if (!irregular && sg <= 1 && sk > 0.0 && sk < ck) {
         const double gup = sk + (floor((ck - sk) / dcs) + 1.0) * dcs;
         // (no write to `wide` here: other items of the chain read it in this very launch; the walk reads `irr` instead)
-        if (gup > (double)W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain]) irregular = true;
+        if (gup > (double)W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain]) { irregular = true; forced = true; }
     }
-    if (irregular) {                                                 // -> k_swd_warm_walk, one 16-lane group per item
+    // (a chain marked wide, or a root next to the fastest layer: the whole sequence walks, whatever the window)
+    const bool local = irregular && W.walk_window >= 0 && !W.wide[chain] && !forced &&
+                       !swd_walk_near(cq, (size_t)nchain, Q.s[seq].nper, k, W.walk_window, dcs) && sk > 0.0 && sk < ck;
+    if (irregular && !local) {                                       // -> k_swd_warm_walk, one 16-lane group per item
         if (atomicExch(&W.irr[chain], 1) == 0) W.ilist[atomicAdd(W.icount, 1)] = chain;
         return;
     }
+    if (local && cc == 0.0 && k == 0) cc = (double)swd_start_value(M, bmx);
     const bool order = sg > 1 || !(sk > 0.0) || sk == ck;
     const double f = swd_secular_family<F>(n, loadL, omega, order ? ck : sk);
+    // (the sign of the sequence's first evaluation, del1st, which the dense walk of its later periods asks for: written by the
+    // first period's own walk -- or here, where the first period does not walk)
+    if (local && k == 0 && W.sg1) W.sg1[(size_t)((F::LOVE ? 4 : 0) + seq) * nchain + chain] = (unsigned char)(signbit(f) ? 1 : 0);
     int nev = 1;
     const bool bad = order || !(sk < ck) || (signbit(f) ? 1 : 0) != sg;
     if (bad && atomicExch(&W.need[chain], 1) == 0) {
@@ -1533,8 +1553,11 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         const double* cq = W.walk_roots + (size_t)Q.s[seq].croot_off * nchain + chain;
         bool irregular = false;
         for (int j = 1; j < Q.s[seq].nper; j++) irregular = irregular || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+        // (with a window: only the periods next to an anomalous pair -- unless the chain is wide, or the sequence is not anomalous
+        // at all and walks for another reason, a root next to the fastest layer: then every period does)
+        const bool whole = W.wide[chain] != 0 || !irregular;
         irregular = irregular || W.wide[chain] != 0 || W.irr[chain] != 0;      // (irr: set by the branch test, launch before this one)
-        live = live && irregular && !W.need[chain];
+        live = live && irregular && !W.need[chain] && (whole || swd_walk_near(cq, (size_t)nchain, Q.s[seq].nper, k, W.walk_window, dcs));
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         float bmx = 0.f;
@@ -1638,6 +1661,11 @@ k_swd_warm_walk_dense(int nchain, int n, SwdSeqs Q, const float* __restrict__ md
         live = live && k > 0 && W.irr[chain] != 0 && !W.need[chain];
         const int e = Q.s[seq].croot_off + k;
         const double* cq = W.walk_roots + (size_t)Q.s[seq].croot_off * nchain + chain;
+        if (live && W.walk_window >= 0 && !W.wide[chain]) {
+            bool anom = false;                                         // (as k_swd_warm_walk: a sequence without an anomalous pair walks whole)
+            for (int j = 1; j < Q.s[seq].nper; j++) anom = anom || (cq[(size_t)(j - 1) * nchain] - 1.5 * dcs >= cq[(size_t)j * nchain]);
+            live = !anom || swd_walk_near(cq, (size_t)nchain, Q.s[seq].nper, k, W.walk_window, dcs);
+        }
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
         float bmx = 0.f;

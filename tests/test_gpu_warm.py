@@ -287,6 +287,7 @@ def test_dense_grid_walk_gives_the_speculative_walk_s_verdicts():
     jd, _ = _bench_joint(2); js, _ = _bench_joint(2)
     cd, cs = jd._ensure(n), js._ensure(n)
     cd.set_option("swd_walk_dense", 1); cs.set_option("swd_walk_dense", 0)
+    cd.set_option("swd_walk_window", -1); cs.set_option("swd_walk_window", -1)      # (every period of a walking sequence: the comparison's subject)
     x = tt(xs); p = tt(0.5 * rng.standard_normal(xs.shape))
     names = ("swd_warm_declined_chains", "swd_warm_walked_chains", "swd_exact_declined_chains", "swd_warm_items")
     for s in range(11):
