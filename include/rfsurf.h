@@ -374,6 +374,17 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          in the middle of a period if need be -- and are continued by k_swd_exact_coop, 16 lanes per group.
  *                          The same evaluations in the same order: the same roots bit for bit (test_gpu_warm.py).  4.71 -> 4.64 ms
  *                          per step at 8192 chains (40: 4.69, 48: 4.68, 36: 5.10 -- too many groups passed on).  0: one launch.
+ *   "swd_exact_overlap"    1: in the background form of the flow entries the second launch of the above runs on the walk stream BESIDE
+ *                          the eigenfunction pass of all items, and the periods of the groups it finishes get their
+ *                          eigenfunctions again afterwards (k_swd_eigen_groups).  Same results; measured slower (4.55 -> 4.67 ms:
+ *                          the launch starves beside the pass and the RF sweeps).  0 (default): one after the other.
+ *   "swd_exact_redo_runup" r > "swd_exact_runup": a group whose run-up did not bring its first origin within the tolerance is not
+ *                          handed to the sequential search but done again with r run-up periods (16 lanes per group).  With ONE
+ *                          run-up period + r = 3 the stage does a sixth less work, but a soak with group velocities still shows 73
+ *                          of 518 473 roots a float32 step off (1 with two run-up periods): 0 (default) = off.
+ *   "rf_store_hyp"         1: with row peeling, pass A leaves exp / cos / sin of every (layer, band frequency) in HBM for pass B
+ *                          (1.5 GB at 8192 chains): 10 % fewer instructions in pass B, 2.9 GB more traffic per step -- measured
+ *                          3 % SLOWER.  0 (default).
  *   "swd_exact_coop"       1 (default): batches of up to 8192 (group, chain) pairs run the reference-root stage with 16 lanes per
  *                          group -- each lane builds the layer entries of every 16th layer, every lane runs the short vector
  *                          recurrence: the single lane's arithmetic operation for operation, the same roots bit for bit, a third

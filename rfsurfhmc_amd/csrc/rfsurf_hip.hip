@@ -124,6 +124,10 @@ struct rfs_ctx {
     Buf xsp, xspc;             // ... the saved machines of those groups (ExactSpill) and their counts (Rayleigh, Love)
     int exact_redo_runup = 0;  // option "swd_exact_redo_runup": > "swd_exact_runup": a group whose run-up did not contract is done again with this many run-up periods (k_swd_exact_coop over a list) instead of handing its chain back; 0 = hand back
     Buf xredo;                 // ... the lists of those groups
+    int exact_overlap = 0;     // option "swd_exact_overlap": the stage's second launch on the walk stream beside the eigenfunction pass of all items, its groups' eigenfunctions again afterwards (k_swd_eigen_groups; flow entries, background form).  Measured, round 6: 4.55 -> 4.67 ms -- the launch starves beside the pass and the RF sweeps, and the chain ends later than with both in a row: off
+    hipEvent_t ev_x1 = nullptr;
+    struct XGroups { const unsigned long long* item; const int* count; int cap, G; bool on; };
+    XGroups xg[2] = {{nullptr, nullptr, 0, 0, false}, {nullptr, nullptr, 0, 0, false}};   // groups whose eigenfunctions follow the second launch (Rayleigh, Love)
     int exact_coop = 1;        // option "swd_exact_coop": 0 never, 1 (default) 16 lanes per group for small batches (k_swd_exact_coop), 2 always (tests)
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
@@ -1035,6 +1039,11 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             // big batches in rounds ("swd_exact_budget"): a budget of evaluations per lane, the unfinished groups continued with 16
             // lanes each.  Lists of a quarter of the groups; one that overflows is not an error (those groups finish in place).
             const int budget = (!coop && c->exact_budget > 0 && n - 1 <= 64) ? c->exact_budget : 0;
+            // (the second launch on the walk stream, beside the eigenfunction pass: the background form of the flow entries with a
+            // stream to spare -- and no second try of groups (ru2), which would want this launch's results first)
+            const bool x2 = budget > 0 && sw != s && kernels && c->exact_overlap && c->exact_redo_runup <= ru && c->ev_x1 != nullptr &&
+                            !c->swd_water_cur;
+            c->xg[0].on = c->xg[1].on = false;
             const size_t xcap = budget ? std::max<size_t>(4096, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 4) : 1;
             if (budget) {
                 ENSURE(c, c->xsp, xcap * (EXACT_SPILL_ND + 1) * sizeof(double));
@@ -1063,8 +1072,13 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                     hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
                                        nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, sp, budget, rd); \
                     const unsigned gx = (unsigned)std::min<size_t>((xcap + 3) / 4, (size_t)4096);                       \
-                    hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(gx), dim3(64), ldsb, s, nchain, n, QQ, G, ru, ng,    \
+                    /* the second launch beside the eigenfunction pass of all items (x2: the walk stream, idle by now): the   \
+                       groups it finishes get their eigenfunctions afterwards (k_swd_eigen_groups, below) */                \
+                    hipStream_t sx = x2 ? sw : s;                                                                       \
+                    if (x2) { HIPCHK(c, hipEventRecord(c->ev_x1, s)); HIPCHK(c, hipStreamWaitEvent(sx, c->ev_x1, 0)); }    \
+                    hipLaunchKernelGGL((k_swd_exact_coop<FAM>), dim3(gx), dim3(64), ldsb, sx, nchain, n, QQ, G, ru, ng,   \
                                        c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, (const int*)nullptr, (const int*)nullptr, sp, rd); \
+                    if (x2) { c->xg[CI] = rfs_ctx::XGroups{sp.item, sp.count, (int)xcap, G, true}; }                                \
                 } else {                                                                                                \
                     hipLaunchKernelGGL((k_swd_exact<FAM>), dim3((unsigned)(((size_t)ng * nchain + 63) / 64)), dim3(64), 0, s, \
                                        nchain, n, QQ, G, ru, ng, c->exact_origin_tol, MDL, MDLC, c->croot.as<double>(), W, none, 0x7fffffff, rd); \
@@ -1078,6 +1092,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             if (Q.nper_total > 0) RFS_LAUNCH_EXACT(SwdRayFamily, Q, mdlR, c->mdlc.as<double>(), 0);
             if (P.QL.nper_total > 0) RFS_LAUNCH_EXACT(SwdLoveFamily, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), 1);
 #undef RFS_LAUNCH_EXACT
+            if (x2) HIPCHK(c, hipEventRecord(c->ev_wk[1], sw));      // (the walk stream's work now ends with the stage's second launch)
             HIPCHK(c, hipGetLastError());
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
             if (!async) TRY(launch_fallback(W.list3, W.count3, 64));
@@ -1206,6 +1221,24 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         HIPCHK(c, hipGetLastError());
         }
         if (walk_join) HIPCHK(c, hipStreamWaitEvent(s, c->ev_wk[1], 0));      // (the caller joins this stream: k_flow_post needs the walk's verdicts)
+        for (int fi = 0; fi < 2; fi++) {
+            // the groups the reference-root stage's second launch finished beside the pass above: their periods again
+            if (!c->xg[fi].on) continue;
+            c->xg[fi].on = false;
+            const rfs_ctx::XGroups& xg = c->xg[fi];
+            const unsigned gq = (unsigned)std::min<size_t>(((size_t)xg.cap * xg.G + 63) / 64, (size_t)2048);
+            const SwdSeqs& QQ = fi == 0 ? P.QR : P.QL;
+            const int* sfl = fi == 0 ? c->sflag.as<int>() : sflagL;
+            const double* sp_ = sphere ? (fi == 0 ? c->sphR.as<double>() : c->sphL.as<double>()) : (const double*)nullptr;
+#define RFS_LAUNCH_EIGEN_G(LOVE, SPH)                                                                                 \
+            hipLaunchKernelGGL((k_swd_eigen_groups<LOVE, SPH>), dim3(gq), dim3(64), 0, s, nchain, n, QQ, ntot, c->mdl.as<float>(), sp_, \
+                               c->croot.as<double>(), sfl, c->cds.as<double>(), c->krn.as<double>(), c->ugr.as<double>(),      \
+                               xg.item, xg.count, xg.cap, xg.G, crT_arg)
+            if (fi == 0) { if (sphere) RFS_LAUNCH_EIGEN_G(false, true); else RFS_LAUNCH_EIGEN_G(false, false); }
+            else { if (sphere) RFS_LAUNCH_EIGEN_G(true, true); else RFS_LAUNCH_EIGEN_G(true, false); }
+#undef RFS_LAUNCH_EIGEN_G
+            HIPCHK(c, hipGetLastError());
+        }
         if (bg_record) {
             HIPCHK(c, hipEventRecord(c->ev_bg[c->wpar], warm_side));
             c->bg_busy[c->wpar] = true;
@@ -1613,9 +1646,10 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     // (RFS_WALK_STREAM=0 in the environment: the walk stays on the surface-wave stream -- A/B measurements.  Measured at the bench's
     // configuration with the default four hardware queues: 7.05 -> 6.47 ms per step; with GPU_MAX_HW_QUEUES = 6 / 8: 6.8)
     if (ok && !(getenv("RFS_WALK_STREAM") && atoi(getenv("RFS_WALK_STREAM")) == 0))
-        ok = hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) == hipSuccess &&
+        ok = hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) == hipSuccess &&      // (plain priority: with the surface-wave stream's high one the step is 5 % slower, round 6)
              hipEventCreateWithFlags(&c->ev_wk[0], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_wk[1], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&c->ev_wk[1], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_x1, hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete c; return RFS_ERR_HIP; }
     c->own_stream = true;
     hipDeviceProp_t prop;
@@ -1666,6 +1700,7 @@ void rfs_destroy(rfs_ctx* c) {
     for (auto e : c->ev_w) if (e) hipEventDestroy(e);
     for (auto e : c->ev_bg) if (e) hipEventDestroy(e);
     for (auto e : c->ev_wk) if (e) hipEventDestroy(e);
+    if (c->ev_x1) hipEventDestroy(c->ev_x1);
     if (c->stream_w) hipStreamDestroy(c->stream_w);
     drop_plans(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1827,6 +1862,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_redo_runup must be within [0, 64]");
         c->exact_redo_runup = value; return RFS_OK;
     }
+    if (!strcmp(name, "swd_exact_overlap")) { c->exact_overlap = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_exact_budget")) {
         if (value < 0 || value > 100000) return fail(c, RFS_ERR_ARG, "swd_exact_budget must be within [0, 100000]");
         c->exact_budget = value; return RFS_OK;

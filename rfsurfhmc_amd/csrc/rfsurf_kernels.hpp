@@ -2299,6 +2299,45 @@ k_swd_eigen(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__
     if (early && (threadIdx.x & 63) == 0) edone[widx] = 1;
 }
 
+// The eigenfunction pass over a list of GROUPS of the reference-root stage (ExactSpill's items: grp * nchain + chain): the periods
+// of the groups whose machines the stage's second launch finished -- their roots arrive while the pass over all items runs, which
+// therefore goes ahead beside that launch and leaves these few per cent to be done again here.  lane = (group of the list, period
+// of the group).
+template <bool LOVE, bool SPH>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_swd_eigen_groups(int nchain, int n, SwdSeqs Q, size_t ntot, const float* __restrict__ mdl, const double* __restrict__ sph,
+                   const double* __restrict__ croot, const int* __restrict__ sflag, double* __restrict__ cds,
+                   double* __restrict__ krn, double* __restrict__ ugr, const unsigned long long* __restrict__ gitem,
+                   const int* __restrict__ gcount, int gcap, int G, const double* __restrict__ crT)
+{
+    const int nsel = min(*gcount, gcap);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < (size_t)nsel * G; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t slot = g / G;
+        const int kk = (int)(g - slot * G);
+        const unsigned long long gid = gitem[slot];
+        if (gid == ~0ull) continue;
+        const int grp = (int)(gid / (unsigned long long)nchain), chain = (int)(gid - (unsigned long long)grp * nchain);
+        int seq = 0, gl = grp;
+        while (seq + 1 < Q.nseq && gl >= (Q.s[seq].nper + G - 1) / G) { gl -= (Q.s[seq].nper + G - 1) / G; seq++; }
+        const int k = gl * G + kk;
+        if (k >= Q.s[seq].nper) continue;
+        if (!sflag[(size_t)seq * nchain + chain]) continue;
+        const int e = Q.s[seq].croot_off + k;
+        const size_t gi = (size_t)e * nchain + chain;
+        const double cp = croot[gi];
+        const double t = Q.s[seq].t[k] * Q.s[seq].scale;
+        const size_t s = (size_t)n * nchain;
+        double* ko = krn + (size_t)e * 4 * s + chain;
+        if (SPH) {
+            SwdModelD M{sph + chain, sph + s + chain, sph + 2 * s + chain, sph + 3 * s + chain, nchain, n};
+            swd_eigen_lane<LOVE, false>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi, crT ? crT + chain : nullptr, sph + chain);
+        } else {
+            SwdModel M{mdl + chain, mdl + s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+            swd_eigen_lane<LOVE, false>(M, n, nchain, ntot, t, cp, cds + gi, ko, ugr + gi, crT ? crT + chain : nullptr, (const double*)nullptr);
+        }
+    }
+}
+
 // Data rows.  Up to four blocks in data order (Rc, Rg, Lc, Lg); a phase block reads the items of its
 // sequence directly, a group block combines the three passes T, 1.05 T, 0.95 T as sregnpu / slegnpu do
 // (sregn96.f90:1839-1844, slegn96.f90:875-878; first term from the 0.95 T pass: quirk).  With

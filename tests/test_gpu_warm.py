@@ -618,10 +618,26 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
             mis = s.sample_flow(x_init=xb, max_steps=80, async_handback=False)
             rb[budget] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories))
     finally:
-        ctx.set_option("swd_exact_budget", 0); ctx.set_option("swd_exact_coop", 1)
+        ctx.set_option("swd_exact_budget", 44); ctx.set_option("swd_exact_coop", 1)
     for budget in (0, 44, 30, 5):
         for i in range(4):
             assert np.array_equal(rb[budget][i], r[0][i]), (budget, i)
+    # ... and with the second launch BESIDE the eigenfunction pass of all items ("swd_exact_overlap": the background form of the
+    # flow entries -- hand-backs sit steps out --, the groups it finishes get their eigenfunctions again afterwards)
+    try:
+        ctx.set_option("swd_exact_coop", 0); ctx.set_option("swd_exact_budget", 40)
+        ro = {}
+        for ov in (0, 1):
+            ctx.set_option("swd_exact_overlap", ov)
+            s = HamitonianMC(joint, bounds, 0.05, [5, 20], 2, 991206, 30, 4, myrank=0, name="t", outdir=None, nchains=nc, verbose=False)
+            mis = s.sample_flow(x_init=xb, max_steps=80, async_handback=True)
+            ro[ov] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories))
+    finally:
+        ctx.set_option("swd_exact_budget", 44); ctx.set_option("swd_exact_coop", 1); ctx.set_option("swd_exact_overlap", 0)
+    # (stored samples, their misfits and the accept counts: with hand-backs in the background the device step in which a chain's
+    # search is found complete is a matter of timing, so the number of trajectories INSIDE a fixed number of steps may differ)
+    for i in range(3):
+        assert np.array_equal(ro[0][i], ro[1][i]), i
     # configs[0]'s plugin: 10 layers, 36 Rc + 36 Rg periods (four sequences per chain)
     thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
     tt = np.arange(5., 41.)
