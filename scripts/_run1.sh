@@ -1,4 +1,4 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-bash scripts/ab_bench.sh 2 "RFS_OPTS=swd_exact_overlap=0" "RFS_WALK_STREAM_PRIORITY=1" "RFS_WALK_STREAM_PRIORITY=1,RFS_OPTS=swd_exact_overlap=0" > gpurun_out/r06_ab_overlap.txt 2>&1; cat gpurun_out/r06_ab_overlap.txt
-RFS_WALK_STREAM_PRIORITY=1 timeout 300 python3 scripts/event_timeline.py 100 2>&1 | tail -12
+timeout 1700 python3 -m pytest tests -q -m gpu > gpurun_out/r06_gpu_suite.txt 2>&1; tail -4 gpurun_out/r06_gpu_suite.txt
+bash scripts/profile_batch.sh r06 > gpurun_out/r06_profile_batch.log 2>&1; tail -3 gpurun_out/r06_profile_batch.log
