@@ -1,4 +1,5 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1700 python3 -m pytest tests -q -m gpu > gpurun_out/r06_gpu_suite.txt 2>&1; tail -4 gpurun_out/r06_gpu_suite.txt
-bash scripts/profile_batch.sh r06 > gpurun_out/r06_profile_batch.log 2>&1; tail -3 gpurun_out/r06_profile_batch.log
+( time timeout 1700 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_bench_driver.json 2> gpurun_out/r06_bench_driver.err ) 2>&1 | tail -3
+tail -c 2800 gpurun_out/r06_bench_driver.json | head -c 1200; echo; wc -c gpurun_out/r06_bench_driver.json
+python3 __graft_entry__.py > /dev/null 2>&1; python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
