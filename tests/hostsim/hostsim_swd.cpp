@@ -434,6 +434,51 @@ static int exact_roots(int n, const float* thk, const float* vp, const float* vs
     }
     return nfail;
 }
+// The same with every group's machine SAVED and LOADED (ExactGroupT::save / load, the hand-over of k_swd_exact in rounds) after
+// every `budget` evaluations -- into a fresh machine with its own table storage.  Returns the number of hand-overs.
+extern "C" int hs_exact_roots_handover(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
+                                       const double* t, const double* approx, int G, int runup, int budget,
+                                       double* cout, int* status, int* nev)
+{
+    std::vector<SwdLayerC> LC(n);
+    for (int m = 0; m < n; m++)
+        LC[m] = SwdLayerC{(double)thk[m], 1.0 / (double)vp[m], 1.0 / (double)vs[m], (double)vs[m], (double)rho[m], 1.0 / (double)rho[m]};
+    auto loadL = [&](int m) { return LC[m]; };
+    SwdModel M{thk, vp, vs, rho, 1, n};
+    float bmx;
+    const double cc = (double)swd_start_value(M, bmx);
+    auto om = [&](int k) { return (2.0 * 3.141592653589793) / t[k]; };
+    auto ap = [&](int k) { return approx[k]; };
+    int moves = 0, g = 0;
+    for (int k = 0; k < nt; k++) { cout[k] = 0.0; status[k] = 0; }
+    for (int k0 = 0; k0 < nt; k0 += G, g++) {
+        const int k1 = k0 + G < nt ? k0 + G : nt, kr = k0 - runup > 0 ? k0 - runup : 0;
+        ExactGroup* x = new ExactGroup;
+        double* tab = new double[24 * 3];                            // (stride 3: the table's stride travels with load())
+        x->begin(kr, k0, k1, cc, bmx, kr > 0 ? approx[kr - 1] * (1.0 - EXACT_OFFSET) : 0.0, ap, om, tab, 3);
+        bool fin = false;
+        int left = budget;
+        while (x->active() && !fin) {
+            x->advance(swd_secular_family<SwdRayFamily>(n, loadL, x->omega, x->creq));
+            if (x->phase == ExactGroup::X_DONE) {
+                if (x->wanted()) { cout[x->k] = (double)(float)x->root(); status[x->k] = 1; }
+                if (!x->next(ap, om)) fin = true;
+            }
+            if (--left == 0 && x->active() && !fin) {               // hand the machine on
+                std::vector<double> D(EXACT_SPILL_ND * 5, -7.0);
+                x->save(&D[2], 5);                                   // (slot 2 of a list of 5)
+                std::memset((void*)x, 0xA5, sizeof(ExactGroup)); delete x; delete[] tab;
+                x = new ExactGroup; tab = new double[24];
+                x->load(&D[2], 5, tab, 1);
+                left = budget; moves++;
+            }
+        }
+        nev[g] = x->nev;
+        if (x->phase == ExactGroup::X_FAIL) for (int k = k0; k < k1; k++) { status[k] = 0; cout[k] = 0.0; }
+        delete x; delete[] tab;
+    }
+    return moves;
+}
 extern "C" int hs_exact_roots(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nt,
                               const double* t, const double* approx, int love, int sphere, int G, int runup,
                               double* cout, int* status, int* nev, int* cause)

@@ -337,6 +337,41 @@ def test_lazy_nevill_takes_the_same_path_as_the_full_one(hs):
     assert nroot > 10000 and nev_l <= 0.62 * nev_p, (nroot, nev_l, nev_p)
 
 
+@pytest.mark.parametrize("budget", [1, 3, 7])
+def test_reference_root_machine_handed_from_lane_to_lane(hs, budget):
+    """k_swd_exact in rounds (round 6): a lane that has used up its budget of evaluations saves its whole machine --
+    ExactGroupT::save: 68 doubles incl. the Neville table, in the middle of a period if need be -- and k_swd_exact_coop loads and
+    continues it.  The lane code on the host: groups of 4 periods behind 2 run-up periods, handed over every `budget` evaluations
+    into a machine that starts from garbage, give the uninterrupted run's roots, verdicts and evaluation counts."""
+    H = hs["swd"]
+    I = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    from oracle import oracle as O
+    rng = np.random.default_rng(40 + budget)
+    nroots = nmoves = 0
+    for trial in range(10):
+        n = int(rng.integers(4, 20))
+        thk = 2.0 + 6.0 * rng.random(n); thk[-1] = 0.0
+        vs = np.sort(2.6 + 1.9 * rng.random(n))
+        if trial % 3 == 2:
+            vs[1:-1] = rng.permutation(vs[1:-1])
+        vp, rho, _, _ = O.empirical_relation(vs)
+        h, a, b, r = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)) for x in (thk, vp, vs, rho)]
+        t = np.ascontiguousarray(np.sort(5.0 + 30.0 * rng.random(14)))
+        nt = len(t)
+        c0 = np.zeros(nt)
+        if not H.hs_rootsearch_family(n, F(h), F(a), F(b), F(r), nt, P(t), P(c0), 0, 0, 1):
+            continue
+        approx = np.ascontiguousarray((c0 * (1.0 + rng.uniform(5e-7, 1e-6, nt))).astype(np.float32).astype(np.float64))
+        ng = (nt + 3) // 4
+        c1 = np.zeros(nt); s1 = np.zeros(nt, dtype=np.int32); n1 = np.zeros(ng, dtype=np.int32)
+        c2 = np.zeros(nt); s2 = np.zeros(nt, dtype=np.int32); n2 = np.zeros(ng, dtype=np.int32)
+        H.hs_exact_roots_handover(n, F(h), F(a), F(b), F(r), nt, P(t), P(approx), 4, 2, 1 << 30, P(c1), I(s1), I(n1))
+        nmoves += H.hs_exact_roots_handover(n, F(h), F(a), F(b), F(r), nt, P(t), P(approx), 4, 2, budget, P(c2), I(s2), I(n2))
+        assert np.array_equal(c1, c2) and np.array_equal(s1, s2) and np.array_equal(n1, n2), trial
+        nroots += int(s1.sum())
+    assert nroots > 60 and nmoves > 100, (nroots, nmoves)
+
+
 @pytest.mark.parametrize("budget", [1, 2, 3])
 def test_warm_search_handed_from_lane_to_lane(hs, budget):
     """k_swd_warm runs in rounds: a search that has used its budget of evaluations is written out (12 doubles + the word of
