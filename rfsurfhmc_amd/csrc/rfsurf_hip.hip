@@ -1635,7 +1635,7 @@ int rfs_create(rfs_ctx** out, int device, int max_chains, int max_layers) {
     c->device = device; c->max_chains = max_chains; c->max_layers = max_layers;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
               create_swd_stream(&c->stream2) &&
-              hipStreamCreateWithFlags(&c->stream_l, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream_l, hipStreamNonBlocking) == hipSuccess &&      // (plain priority; a high one for the background search: 4.6 -> 4.8 ms per step, round 6)
 
               hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_lj, hipEventDisableTiming) == hipSuccess &&
