@@ -379,9 +379,13 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          eigenfunctions again afterwards (k_swd_eigen_groups).  Same results; measured slower (4.55 -> 4.67 ms:
  *                          the launch starves beside the pass and the RF sweeps).  0 (default): one after the other.
  *   "swd_exact_redo_runup" r > "swd_exact_runup": a group whose run-up did not bring its first origin within the tolerance is not
- *                          handed to the sequential search but done again with r run-up periods (16 lanes per group).  With ONE
- *                          run-up period + r = 3 the stage does a sixth less work, but a soak with group velocities still shows 73
- *                          of 518 473 roots a float32 step off (1 with two run-up periods): 0 (default) = off.
+ *                          handed to the sequential search but done again with r run-up periods (16 lanes per group); only a
+ *                          second failure hands the chain back.  -1 (default) = 4 for the small batches' 16-lane form (ONE
+ *                          configs[0] chain: 59 of 399 evaluations handed back for this cause, none with the second try), 0 for
+ *                          big batches (0.1 chains per step there).  Parity: more run-up is never looser.  NOT a way to one
+ *                          run-up period: with "swd_exact_runup" 1 + r = 3 the stage does a sixth less work, but a soak with
+ *                          group velocities still shows 73 of 518 473 roots a float32 step off (1 with two run-up periods) -- the
+ *                          ordinary groups' 4e-10 c of origin error is enough.  0 = never.
  *   "rf_store_hyp"         1: with row peeling, pass A leaves exp / cos / sin of every (layer, band frequency) in HBM for pass B
  *                          (1.5 GB at 8192 chains): 10 % fewer instructions in pass B, 2.9 GB more traffic per step -- measured
  *                          3 % SLOWER.  0 (default).

@@ -122,7 +122,7 @@ struct rfs_ctx {
     int walk_window = 2;       // option "swd_walk_window": periods around an anomalous one that walk the reference's grid (-1: the whole sequence)
     int exact_budget = 44;     // option "swd_exact_budget": evaluations a lane of k_swd_exact may spend before its group goes on to the 16-lane launch (0: one round)
     Buf xsp, xspc;             // ... the saved machines of those groups (ExactSpill) and their counts (Rayleigh, Love)
-    int exact_redo_runup = 0;  // option "swd_exact_redo_runup": > "swd_exact_runup": a group whose run-up did not contract is done again with this many run-up periods (k_swd_exact_coop over a list) instead of handing its chain back; 0 = hand back
+    int exact_redo_runup = -1; // option "swd_exact_redo_runup": > "swd_exact_runup": a group whose run-up did not contract is done again with this many run-up periods (k_swd_exact_coop over a list) instead of handing its chain back; 0 = hand back
     Buf xredo;                 // ... the lists of those groups
     int exact_overlap = 0;     // option "swd_exact_overlap": the stage's second launch on the walk stream beside the eigenfunction pass of all items, its groups' eigenfunctions again afterwards (k_swd_eigen_groups; flow entries, background form).  Measured, round 6: 4.55 -> 4.67 ms -- the launch starves beside the pass and the RF sweeps, and the chain ends later than with both in a row: off
     hipEvent_t ev_x1 = nullptr;
@@ -1050,7 +1050,11 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             }
             // groups whose run-up did not contract: done again with a longer one ("swd_exact_redo_runup") instead of handing
             // their chain to the sequential search
-            const int ru2 = c->exact_redo_runup > ru ? c->exact_redo_runup : 0;
+            // (-1 = automatic: 4 run-up periods for the second try of the small batches' 16-lane form -- ONE configs[0] chain hands
+            // 15 % of its evaluations back for this cause alone -- and none for big batches, where the cause is 0.1 chains per
+            // step and the list's launch would sit on the step's critical chain)
+            const int ru2_opt = c->exact_redo_runup < 0 ? (coop ? 4 : 0) : c->exact_redo_runup;
+            const int ru2 = ru2_opt > ru ? ru2_opt : 0;
             const size_t rcap = ru2 ? std::max<size_t>(1024, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 8) : 1;
             ENSURE(c, c->xspc, 4 * sizeof(int));
             if (ru2) ENSURE(c, c->xredo, 2 * rcap * sizeof(int));
@@ -1859,7 +1863,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     }
     if (!strcmp(name, "rf_store_hyp")) { c->rf_store_hyp = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_exact_redo_runup")) {
-        if (value < 0 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_redo_runup must be within [0, 64]");
+        if (value < -1 || value > 64) return fail(c, RFS_ERR_ARG, "swd_exact_redo_runup must be within [-1, 64]");
         c->exact_redo_runup = value; return RFS_OK;
     }
     if (!strcmp(name, "swd_exact_overlap")) { c->exact_overlap = value != 0; return RFS_OK; }

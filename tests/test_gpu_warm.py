@@ -589,6 +589,7 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
     def runs_of(model, ctx, bounds, x_init, nchains, dt):
         out = {}
         try:
+            ctx.set_option("swd_exact_redo_runup", 0)       # (the second try of small batches is the 16-lane form's alone: off for the comparison)
             for coop in (0, 2):
                 ctx.set_option("swd_exact_coop", coop)
                 names = ("swd_warm_declined_chains", "swd_exact_declined_chains", "swd_exact_secular_evals", "swd_warm_items")
@@ -598,7 +599,7 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
                 out[coop] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
                              [ctx.stat(k) - v for k, v in zip(names, c0)])
         finally:
-            ctx.set_option("swd_exact_coop", 1)
+            ctx.set_option("swd_exact_coop", 1); ctx.set_option("swd_exact_redo_runup", -1)
         return out
 
     r = runs_of(joint, ctx, bounds, xb, nc, 0.05)
