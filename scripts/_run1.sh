@@ -1,2 +1,3 @@
 export TMPDIR=/tmp
-timeout 900 python3 -m pytest tests/test_gpu_warm.py -q -m gpu -k "16_lanes" 2>&1 | tail -2
+mkdir -p gpurun_out
+timeout 1700 python3 -m pytest tests -q -m gpu > gpurun_out/r06_gpu_suite.txt 2>&1; tail -3 gpurun_out/r06_gpu_suite.txt
