@@ -28,8 +28,10 @@ window, the root-search mode, `roofline` (the kernel group with the largest stan
 measured live over the timed region), `valu_issue` (SQ_INSTS_VALU per step from the committed PMC passes), `root_search`
 (evaluations per item, chains handed back), legs at other step sizes (`dt_sweep`: 0.002 / 0.02 / the reference's 0.1),
 with the converged instead of the reference's roots (`converged_roots`), with the history-free search at every step
-(`full_search_every_step`), rounds 1-3's headline definition (`never_ending_dt0002`), `config4` / `config3` and
-`cpu_baseline`.  Independent chains shard across ranks (weak scaling, no data-path collective); the only collective is the
+(`full_search_every_step`), rounds 1-3's headline definition (`never_ending_dt0002`), with every frequency of the RF row sweep
+in f64 (`all_f64`), `config1_rg` (configs[1] + 40 group periods), `config4` / `config3` (dual averaging, timed in its
+stationary regime: the adapting trajectories run untimed first) / `config0` (one chain), `roofline_fp64` (FP64 vector flops per
+step from the committed counter passes against the measured step time), `host_cpu_ms_per_step` and `cpu_baseline`.  Independent chains shard across ranks (weak scaling, no data-path collective); the only collective is the
 RCCL gather of the per-chain misfits after the timed region (comm.Gather, main_base.py:90).
 """
 import argparse
