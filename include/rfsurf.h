@@ -363,10 +363,10 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          at the point their scan starts from.  A chain marked wide ("swd_warm_widen") and a sequence that
  *                          walks for a root next to the fastest layer still walk whole.  Measured at 8192 chains: 9.6 -> 6.7
  *                          evaluations per item in the warm stage, 4.75 -> 4.54 ms per step (same box; W = 0 / 1 / 4: 4.65 / 4.63 /
- *                          4.56), 29 -> 27 chains per step handed back.  Against the oracle (the sampler run stopped at ten
- *                          device steps, 53 360 mid-trajectory chains + 5 967 end models with W = 2): every root within the
- *                          reference's own 1e-6 c bracket of the oracle's, 94.5 % of the chains with all 40 roots bit-identical
- *                          -- the figures of -1 (profiles/r06_flow_parity_stats*.txt).
+ *                          4.56), 29 -> 27 chains per step handed back.  Against the oracle (the sampler run stopped at eighteen
+ *                          device steps, 108 238 mid-trajectory chains + 10 702 end models with W = 2): every root within the
+ *                          reference's own bracket of the oracle's (<= 1.8e-6 c), 94.3 % of the chains with all 40 roots
+ *                          bit-identical -- the figures of -1 (profiles/r06_flow_parity_stats*.txt).
  *   "swd_exact_budget"     44 (default): the reference-root stage of big batches runs in two launches.  Its wavefronts execute what
  *                          their slowest lane needs (47 evaluations where the lanes need 38.5 on average: the lazy nevill's
  *                          count varies from period to period), and the stage ends with its slowest wavefront.  Every lane gets
