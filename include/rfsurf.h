@@ -395,6 +395,20 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          of the time per evaluation: a stage as long as one lane's ~40 dependent evaluations whatever the
  *                          batch size is what a small batch spends most of its step in.  0 = a lane per
  *                          group always, 2 = 16 lanes per group always (tests).  Models of up to 65 layers.
+ *   "swd_cold_scan"        -1 (default): in batches of up to 64 chains whose hand-backs are searched in the foreground (not
+ *                          "flow_async_handback"), a chain the warm start itself declines -- no previous evaluation, a move the
+ *                          first-order model cannot follow, no sign change inside the trust radius -- takes the search WITHOUT
+ *                          a prediction instead of the sequential one: every period's secular function on one grid (start value
+ *                          + i dc, lane = grid point), each sign change refined to 1e-6 km/s, the reference's scan replayed on
+ *                          those roots period after period (k_swd_cold_scan, k_swd_cold_pick) -- then the branch test on the
+ *                          reference's own grid for every period and the reference-root stage, as for any continued root; what
+ *                          they decline goes to the sequential search after all.  ~0.1 ms where the sequential search of ONE
+ *                          chain takes 2 ms.  Such batches also keep ONE hand-back list and ONE sequential search per step, on
+ *                          the step's own stream (12 launches on the step's chain instead of 19).  0 = off, 1 = batches of up
+ *                          to 512 chains.  Sequences of up to 192 periods, fundamental mode, no water layer.
+ *   "swd_cold_first"       4 (default): batches of up to that many chains skip the warm search and give every chain the search
+ *                          without a prediction (configs[0]: one chain per rank) -- a chain the branch test declines after a
+ *                          continued root would otherwise cost a sequential search.  0..512.
  *   "flow_async_handback"  rfs_flow_step / rfs_flow_step2 with the warm start on: 1 = a chain the warm start hands back to the
  *                          reference-semantics search (a few per step on rough models: ~3 ms of dependent evaluations, during
  *                          which every other chain would wait) sits that step out instead -- its model has drifted, it is not
@@ -513,6 +527,10 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *   "swd_warm_fail_no_change" / "swd_warm_fail_other"   (period, chain) items whose warm search failed: no sign change out to
  *                               the widest bracket / anything else
  *   "swd_warm_passed_on_<r>"    searches round r = 1, 2, 3 of the warm search passed on to the next round
+ *   "swd_cold_chains" / "swd_cold_secular_evals"   chain evaluations that came through the search without a prediction
+ *                          ("swd_cold_scan"; they are taken off "swd_warm_declined_chains", which then counts the sequential
+ *                          searches) and its secular evaluations
+ *   "swd_cold_fail_<c>"    ... and the chains it left on the list, by cause c = 34..39 (rfsurf_kernels.hpp, k_swd_cold_pick)
  *   "swd_warm_search_evals" / "swd_warm_search_evals_slowest_lane" / "swd_warm_search_lanes"   divergence of the warm search
  *                               (k_swd_warm): evaluations of all searches, of each wavefront's slowest search summed over
  *                               the rounds' wavefronts (what the wavefronts execute; a wavefront of the cooperative last round

@@ -24,6 +24,7 @@ using namespace rfs;
 #endif
 namespace {
 
+constexpr int COLD_AUTO_CHAINS = 64, COLD_MAX_CHAINS = 512;   // batches whose declined chains take the search without a prediction (k_swd_cold_scan): by default / with "swd_cold_scan" 1
 constexpr int EXACT_COOP_MAX = 8192;   // (group, chain) pairs of the reference-root stage up to which a group takes 16 lanes (k_swd_exact_coop): ~1 500 wavefronts hold 6 000 groups at once
 constexpr int RFS_BG_SLOTS = 8;      // sets of hand-back flags / lists (and events): background searches of that many steps may be in flight
 
@@ -119,6 +120,10 @@ struct rfs_ctx {
     // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
     // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
+    int cold_first = 4;             // "swd_cold_first": batches of up to that many chains do not try the warm search at all
+    int cold_scan = -1;             // "swd_cold_scan": -1 = for foreground hand-backs of up to COLD_AUTO_CHAINS chains, 0 off, 1 up to COLD_MAX_CHAINS
+    Buf cold_roots, cold_nroot, cold_s0, cold_ticket;
+    bool counters_zeroed = false;   // k_prep_joint of the evaluation being launched cleared the list counters (wspc, xspc)
     int walk_window = 2;       // option "swd_walk_window": periods around an anomalous one that walk the reference's grid (-1: the whole sequence)
     int exact_budget = 44;     // option "swd_exact_budget": evaluations a lane of k_swd_exact may spend before its group goes on to the 16-lane launch (0: one round)
     Buf xsp, xspc;             // ... the saved machines of those groups (ExactSpill) and their counts (Rayleigh, Love)
@@ -847,13 +852,28 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wsg1.as<unsigned char>(),
                   (c->flow_cur && c->flow_skip_idle) ? c->f_rem : (const int*)nullptr, c->f_fresh, c->f_ok,
                   c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0,
-                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr, c->walk_window};
+                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr, c->walk_window, 0};
         (void)0;
 // Rounds (WarmSpill, rfsurf_kernels.hpp): budgets b1, b2, b3 and a last round without one; the unfinished searches of a round
         // are packed into a list for the next.  The lists' lengths are only known on the device: the later rounds' grids are sized for
         // what the bench's chains need several times over, and their blocks stride.
-        const int wb1 = c->warm_budgets % 100, wb2 = (c->warm_budgets / 100) % 100, wb3 = (c->warm_budgets / 10000) % 100;
+        // Small batches whose hand-backs are searched in the foreground (round 6, "swd_cold_scan"): ONE list for the three kinds of
+        // hand-back; the chains the warm search itself declines go through the search without a prediction (k_swd_cold_scan /
+        // k_swd_cold_pick) and on to the branch test with everybody else; what is on the list behind the reference-root stage is
+        // searched sequentially on this very stream, in front of the eigenfunction pass of all chains -- 12 launches on the step's
+        // chain instead of 19 (three searches and three eigenfunction passes over lists that are empty most of the time).
+        const bool would_async = c->flow_cur && c->flow_async && kernels && c->stream_l && s != c->stream_l;
+        const int np_cold = std::max(Q.nper_total, P.QL.nper_total);
+        int npseq_cold = 0;
+        for (int q = 0; q < Q.nseq; q++) npseq_cold = std::max(npseq_cold, Q.s[q].nper);
+        for (int q = 0; q < P.QL.nseq; q++) npseq_cold = std::max(npseq_cold, P.QL.s[q].nper);
+        const bool sb = !would_async && c->cold_scan != 0 && n >= 3 && c->swd_mode_cur == 0 && !c->swd_water_cur &&
+                        nchain <= (c->cold_scan > 0 ? COLD_MAX_CHAINS : COLD_AUTO_CHAINS) && npseq_cold <= 192;     // (k_swd_cold_pick holds a sequence's roots in LDS: 268 B a period)
+        const int wb1 = c->warm_budgets % 100, wb2 = sb ? 0 : (c->warm_budgets / 100) % 100, wb3 = (c->warm_budgets / 10000) % 100;
         const bool rounds = wb1 > 0;
+        if (sb) { W.list2 = W.list3 = W.list; W.count2 = W.count3 = W.count; }
+        const bool cold_first = sb && nchain <= c->cold_first;
+        W.decline_all = cold_first ? 1 : 0;
         const size_t items_max = (size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain;
         // (measured need: a few per cent of the items; a list that overflows is not an error -- the searches it cannot take finish
         // in place, test_warm_search_in_rounds_... runs that path -- so a quarter of the items is plenty: 152 B a slot, two lists)
@@ -885,12 +905,13 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             dim3 grid((unsigned)((nit + 63) / 64));                                                                   \
             const double* sp_ = sphere ? (SPHP) : (const double*)nullptr;                                             \
             WarmSpill none{nullptr, nullptr, nullptr, c->wspc.as<int>() + 3, 0};                                      \
-            if (!rounds) {                                                                                            \
+            if (!rounds || cold_first) {                                                                              \
                 if (sphere) RFS_LAUNCH_WARM1(FAM, true, true, grid, QQ, MDLC, sp_, none, none, NOLIM, -1);            \
                 else RFS_LAUNCH_WARM1(FAM, false, true, grid, QQ, MDLC, sp_, none, none, NOLIM, -1);                  \
                 break;                                                                                                \
             }                                                                                                         \
-            HIPCHK(c, hipMemsetAsync(c->wspc.p, 0, 8 * sizeof(int), s));                                              \
+            if (!c->counters_zeroed || warm_fam > 0) HIPCHK(c, hipMemsetAsync(c->wspc.p, 0, 8 * sizeof(int), s));    /* (k_prep_joint cleared them for the step's first family) */ \
+            warm_fam++;                                                                                               \
             WarmSpill A0 = spill(c->wspA, 0), B1 = spill(c->wspB, 1), A2 = spill(c->wspA, 2);                         \
             const unsigned gw = (unsigned)((nit + 63) / 64);                                                          \
             dim3 g2(std::max(64u, gw / 3)), g3(std::max(32u, gw / 8)), g4(std::max(16u, gw / 24));                    \
@@ -908,18 +929,46 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                 else RFS_LAUNCH_WARM1(FAM, false, false, (wb2 > 0 ? (wb3 > 0 ? g4 : g3) : g2), QQ, MDLC, sp_, (wb2 > 0 ? (wb3 > 0 ? A2 : B1) : A0), none, NOLIM, 3); \
             }                                                                                                         \
         } while (0)
+        int warm_fam = 0;
         if (Q.nper_total > 0) RFS_LAUNCH_WARM(SwdRayFamily, Q, c->mdlc.as<double>(), c->sphR.as<double>());
         if (P.QL.nper_total > 0) RFS_LAUNCH_WARM(SwdLoveFamily, P.QL, c->mdlcL.as<double>(), c->sphL.as<double>());
 #undef RFS_LAUNCH_WARM1
 #undef RFS_LAUNCH_WARMC
 #undef RFS_LAUNCH_WARM
         HIPCHK(c, hipGetLastError());
+        if (sb) {
+            const int cap = nchain;
+            ENSURE(c, c->cold_roots, (size_t)cap * np_cold * COLD_NR * 2 * sizeof(double));
+            ENSURE(c, c->cold_s0, (size_t)cap * np_cold * sizeof(int));
+            {   // (the counts start from zero and k_swd_cold_pick leaves zeros behind)
+                const size_t before = c->cold_nroot.cap;
+                ENSURE(c, c->cold_nroot, (size_t)cap * np_cold * sizeof(int));
+                if (c->cold_nroot.cap != before) HIPCHK(c, hipMemsetAsync(c->cold_nroot.p, 0, c->cold_nroot.cap, s));
+            }
+            if (!c->cold_ticket.p) { ENSURE(c, c->cold_ticket, 4 * sizeof(int)); HIPCHK(c, hipMemsetAsync(c->cold_ticket.p, 0, 4 * sizeof(int), s)); }
+            auto gscan = [&](const SwdSeqs& QQ) { return (unsigned)std::min<size_t>((size_t)cap * QQ.nper_total * COLD_TP, (size_t)8192); };
+            auto gpick = [&](const SwdSeqs& QQ) { return (unsigned)std::min<size_t>((size_t)cap * QQ.nseq, (size_t)2048); };
+            auto lpick = [&](const SwdSeqs& QQ) { int m = 1; for (int q = 0; q < QQ.nseq; q++) m = std::max(m, QQ.s[q].nper);
+                                                  return (size_t)m * (COLD_NR * 2 * sizeof(double) + 3 * sizeof(int)) + 16; };
+            const int nblk = (Q.nper_total > 0 ? (int)gpick(Q) : 0) + (P.QL.nper_total > 0 ? (int)gpick(P.QL) : 0);
+            SwdCold C{c->cold_roots.as<double>(), c->cold_nroot.as<int>(), c->cold_s0.as<int>(), cap, c->cold_ticket.as<int>(), nblk};
+#define RFS_LAUNCH_COLD(FAM, QQ, MDL, MDLC, SFL)                                                                       \
+            do {                                                                                                       \
+                hipLaunchKernelGGL((k_swd_cold_scan<FAM>), dim3(gscan(QQ)), dim3(64), 0, s, nchain, n, QQ, MDL, MDLC, W, C);   \
+                hipLaunchKernelGGL((k_swd_cold_pick<FAM>), dim3(gpick(QQ)), dim3(64), lpick(QQ), s, nchain, n, QQ, MDL, MDLC, \
+                                   c->croot.as<double>(), SFL, W, C);                                                   \
+            } while (0)
+            if (Q.nper_total > 0) RFS_LAUNCH_COLD(SwdRayFamily, Q, mdlR, c->mdlc.as<double>(), c->sflag.as<int>());
+            if (P.QL.nper_total > 0) RFS_LAUNCH_COLD(SwdLoveFamily, P.QL, c->mdlL.as<float>(), c->mdlcL.as<double>(), sflagL);
+#undef RFS_LAUNCH_COLD
+            HIPCHK(c, hipGetLastError());
+        }
         // The hand-back lists are nearly always empty, and when one is not, the full search of even ONE chain takes ~3 ms
         // (about a thousand dependent secular evaluations): it runs on a side stream -- for the chains k_swd_warm itself
         // declines (moves too large for a first-order model: the bulk) from here on, beside the branch test; for the chains
         // the branch test declines behind it -- beside the eigenfunction pass of all chains; only the listed chains'
         // eigenfunctions are redone afterwards (below).
-        hipStream_t sf = (kernels && c->stream_l && s != c->stream_l) ? c->stream_l : s;
+        hipStream_t sf = (!sb && kernels && c->stream_l && s != c->stream_l) ? c->stream_l : s;
         const bool async = c->flow_cur && c->flow_async && kernels && sf != s;
         if (async) {
             // background form: ONE list for the three kinds of hand-back and ONE search behind the reference-root stage.  (On the
@@ -994,12 +1043,14 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         {
             const int gw = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 4 + 15) / 16)));
             const int g1 = std::max(64, std::min(2048, nchain / 4));
-            const int gd = std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 2 + 63) / 64)));   // 64 items per block and trip
+            const int ipb = sb ? 8 : 64;                     // items per block and trip (k_swd_warm_walk_dense)
+            const int gd = sb ? std::max(1, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain + ipb - 1) / ipb)))
+                              : std::max(256, std::min(4096, (int)(((size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain / 2 + 63) / 64)));
             if (Q.nper_total > 0) {
                 hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, true>), dim3(g1), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                    c->croot.as<double>(), W);
                 if (c->walk_dense) hipLaunchKernelGGL((k_swd_warm_walk_dense<SwdRayFamily>), dim3(gd), dim3(64), 0, sw, nchain, n, Q, mdlR,
-                                                      c->mdlc.as<double>(), c->croot.as<double>(), W);
+                                                      c->mdlc.as<double>(), c->croot.as<double>(), W, ipb);
                 else hipLaunchKernelGGL((k_swd_warm_walk<SwdRayFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, Q, mdlR, c->mdlc.as<double>(),
                                         c->croot.as<double>(), W);
             }
@@ -1007,7 +1058,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                 hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, true>), dim3(g1), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
                                    c->mdlcL.as<double>(), c->croot.as<double>(), W);
                 if (c->walk_dense) hipLaunchKernelGGL((k_swd_warm_walk_dense<SwdLoveFamily>), dim3(gd), dim3(64), 0, sw, nchain, n, P.QL,
-                                                      c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W);
+                                                      c->mdlL.as<float>(), c->mdlcL.as<double>(), c->croot.as<double>(), W, ipb);
                 else hipLaunchKernelGGL((k_swd_warm_walk<SwdLoveFamily, false>), dim3(gw), dim3(64), 0, sw, nchain, n, P.QL, c->mdlL.as<float>(),
                                         c->mdlcL.as<double>(), c->croot.as<double>(), W);
             }
@@ -1017,8 +1068,8 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         // the chains the branch test handed back (and, on one stream, those of the first list)
         if (async) {}
         else if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[1], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[1], 0)); }
-        else TRY(launch_fallback(W.list, W.count, est));
-        if (!async) TRY(launch_fallback(W.list2, W.count2, 64));
+        else if (!(sb && c->warm_exact)) TRY(launch_fallback(W.list, W.count, est));      // (sb: one search, behind the reference-root stage)
+        if (!async && !sb) TRY(launch_fallback(W.list2, W.count2, 64));
         delete tw; tw = nullptr;
         if (c->warm_exact) {
             KTimer tx(c, RFS_K_SWD_EXACT, s);
@@ -1058,7 +1109,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             const size_t rcap = ru2 ? std::max<size_t>(1024, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 8) : 1;
             ENSURE(c, c->xspc, 4 * sizeof(int));
             if (ru2) ENSURE(c, c->xredo, 2 * rcap * sizeof(int));
-            HIPCHK(c, hipMemsetAsync(c->xspc.p, 0, 4 * sizeof(int), s));
+            if (!c->counters_zeroed) HIPCHK(c, hipMemsetAsync(c->xspc.p, 0, 4 * sizeof(int), s));      // (k_prep_joint cleared them)
 #define RFS_LAUNCH_EXACT(FAM, QQ, MDL, MDLC, CI)                                                                        \
             do {                                                                                                       \
                 const int ng = ngroups(QQ, G);                                                                          \
@@ -1099,7 +1150,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             if (x2) HIPCHK(c, hipEventRecord(c->ev_wk[1], sw));      // (the walk stream's work now ends with the stage's second launch)
             HIPCHK(c, hipGetLastError());
             if (sf != s) { HIPCHK(c, hipEventRecord(c->ev_w[4], s)); HIPCHK(c, hipStreamWaitEvent(sf, c->ev_w[4], 0)); }
-            if (!async) TRY(launch_fallback(W.list3, W.count3, 64));
+            if (!async) TRY(launch_fallback(W.list3, W.count3, sb ? est : 64));
         }
         walk_join = sw != s;
         if (async) {
@@ -1335,7 +1386,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->wilist, (size_t)nchain * sizeof(int)); ENSURE(c, c->wlist2, RFS_BG_SLOTS * (size_t)nchain * sizeof(int));
         for (auto& e : c->ev_w) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ENSURE(c, c->wlist, RFS_BG_SLOTS * (size_t)nchain * sizeof(int)); ENSURE(c, c->wforce, (size_t)nchain * sizeof(int));
-        ENSURE(c, c->wstats, 32 * sizeof(unsigned long long));
+        ENSURE(c, c->wstats, 40 * sizeof(unsigned long long));
         ENSURE(c, c->wsgn, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain);
         ENSURE(c, c->wslope, (size_t)(4 * (c->ntw[0] + c->ntw[1] + c->ntw[2] + c->ntw[3])) * nchain * sizeof(double));
         ENSURE(c, c->wbetmx, (size_t)2 * nchain * sizeof(float)); ENSURE(c, c->wsg1, (size_t)8 * nchain);
@@ -1489,6 +1540,7 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         ENSURE(c, c->ugr, 3 * ntot * sizeof(double));
         ENSURE(c, c->edone, (ntot / 64 + 1) * sizeof(int));
     }
+    if (warm) { ENSURE(c, c->wspc, 8 * sizeof(int)); ENSURE(c, c->xspc, 4 * sizeof(int)); }
     {   // layer constants, search models -- and, for the early launch, the cleared root buffer (zero = not final) and done map
         KTimer t(c, RFS_K_PREP, c->stream);
         const size_t ntot = (size_t)P.nitems * nchain;
@@ -1501,7 +1553,9 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
                            early_items > 0 ? ntot / 64 + 1 : (warm ? 3 * (size_t)nchain + 4 : (size_t)0),
                            track ? c->xw.as<double>() : (double*)nullptr, c->dxT.as<double>(),
                            c->has_swd ? c->crT.as<double>() : (double*)nullptr,
-                           fpre ? *fpre : FlowPre{});      // (flow entries: the step's drift rides in this kernel)
+                           fpre ? *fpre : FlowPre{},       // (flow entries: the step's drift rides in this kernel)
+                           warm ? c->wspc.as<int>() : (int*)nullptr, warm ? c->xspc.as<int>() : (int*)nullptr);
+        c->counters_zeroed = warm;
         HIPCHK(c, hipGetLastError());
         if (c->has_swd) TRY(launch_family_prep(c, c->stream, nchain, n, P, c->sphere));
     }
@@ -1697,7 +1751,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc, &c->xredo, &c->Hs};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc, &c->xredo, &c->Hs, &c->cold_roots, &c->cold_nroot, &c->cold_s0, &c->cold_ticket};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1871,6 +1925,14 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 100000) return fail(c, RFS_ERR_ARG, "swd_exact_budget must be within [0, 100000]");
         c->exact_budget = value; return RFS_OK;
     }
+    if (!strcmp(name, "swd_cold_first")) {
+        if (value < 0 || value > COLD_MAX_CHAINS) return fail(c, RFS_ERR_ARG, "swd_cold_first must be within [0, 512]");
+        c->cold_first = value; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_cold_scan")) {
+        if (value < -1 || value > 1) return fail(c, RFS_ERR_ARG, "swd_cold_scan must be -1, 0 or 1");
+        c->cold_scan = value; return RFS_OK;
+    }
     if (!strcmp(name, "swd_exact_coop")) {
         if (value < 0 || value > 2) return fail(c, RFS_ERR_ARG, "swd_exact_coop must be 0, 1 or 2");
         c->exact_coop = value; return RFS_OK;
@@ -1980,13 +2042,16 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
     else if (!strcmp(name, "swd_warm_search_evals")) idx = 26;
     else if (!strcmp(name, "swd_warm_search_evals_slowest_lane")) idx = 27;
     else if (!strcmp(name, "swd_warm_search_lanes")) idx = 28;
+    else if (!strcmp(name, "swd_cold_chains")) idx = 32;
+    else if (!strcmp(name, "swd_cold_secular_evals")) idx = 33;
+    else if (!strncmp(name, "swd_cold_fail_", 14)) { idx = atoi(name + 14); idx = (idx < 34 || idx > 39) ? -1 : idx; }
     else if (!strncmp(name, "swd_warm_passed_on_", 19)) { idx = atoi(name + 19); idx = (idx < 1 || idx > 3) ? -1 : 28 + idx; }
     else if (!strncmp(name, "swd_exact_cause_", 16)) { idx = atoi(name + 16); idx = (idx < 1 || idx > 7) ? -1 : 16 + idx; }
     if (idx < 0) return fail(c, RFS_ERR_ARG, std::string("unknown statistic ") + name);
     if (!c->wstats.p) return RFS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     TRY(rfs_synchronize(c));
-    unsigned long long v[32];
+    unsigned long long v[40];
     HIPCHK(c, hipMemcpy(v, c->wstats.p, sizeof(v), hipMemcpyDeviceToHost));
     *value = (int64_t)v[idx];
     return RFS_OK;

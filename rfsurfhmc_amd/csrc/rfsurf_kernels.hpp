@@ -166,9 +166,13 @@ __global__ void k_prep_joint(int nchain, int n, const double* x /* may be fpre.x
                              RfLayer* __restrict__ lc, double* __restrict__ cr, int has_swd,
                              float* __restrict__ mdl, double* __restrict__ mdlc,
                              double* __restrict__ zero_d, size_t nzero_d, int* __restrict__ zero_i, size_t nzero_i,
-                             double* __restrict__ xw, double* __restrict__ dxT, double* __restrict__ crT, FlowPre fpre)
+                             double* __restrict__ xw, double* __restrict__ dxT, double* __restrict__ crT, FlowPre fpre,
+                             int* __restrict__ zero_c1 = nullptr, int* __restrict__ zero_c2 = nullptr)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the list counters of the warm search's rounds and of the reference-root stage: a hipMemsetAsync of 32 bytes in front of
+    // those kernels is a fill launch of 40-80 us on the step's critical chain)
+    if (g < 8) { if (zero_c1) zero_c1[g] = 0; if (zero_c2 && g < 4) zero_c2[g] = 0; }
     // per-step clearing for the early eigenfunction launch (roots: zero = not final; done map), folded in here
     // instead of two memset launches in front of the fork
     for (size_t i = g; i < nzero_d; i += (size_t)gridDim.x * blockDim.x) zero_d[i] = 0.0;
@@ -1131,6 +1135,9 @@ struct SwdWarm {
     // W >= 0 = only the periods within W of an anomalous one (the pair j - 1, j with c(j) <= c(j - 1) - 1.5 dc counts for both)
     // do, the others take the regular sequences' test -- one evaluation at the point their scan starts from
     int walk_window;
+    // "swd_cold_first" (round 6, batches of a few chains): every chain takes the search without a prediction (k_swd_cold_scan) --
+    // k_swd_warm only sorts out the idle chains and lists the others
+    int decline_all;
 };
 // is period k of a sequence (roots cq, stride nchain) within `win` periods of an anomalous pair?
 __device__ __forceinline__ bool swd_walk_near(const double* cq, size_t nchain, int nper, int k, int win, double dcs) {
@@ -1233,7 +1240,7 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (live && W.pend && W.pend[chain]) { W.need[chain] = 2; live = false; }
         if (live && W.f_rem && !W.f_fresh[chain] && (W.f_rem[chain] <= 0 || !W.f_ok[chain])) { W.need[chain] = 2; live = false; }    // idle
         if (live) W.sgn[(size_t)e * nchain + chain] = 2;
-        if (live && (!W.valid[chain] || (W.force && W.force[chain]))) { decline(4); live = false; }
+        if (live && (!W.valid[chain] || (W.force && W.force[chain]) || W.decline_all)) { decline(4); live = false; }
         // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
         // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
         // vtp / dtp / rtp as swd_kernel_value does
@@ -1440,6 +1447,260 @@ k_swd_warm_coop(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, d
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// K3c the search WITHOUT a prediction, all periods at once ("swd_cold_scan", round 6, small batches).  A chain the warm search
+// declines -- no previous evaluation, a move the first-order model cannot follow, no sign change inside the trust radius: one wild
+// configs[0] chain hands 40 % of its steps back for these -- used to go to the reference-semantics search: ~800 dependent rounds
+// of evaluations, 2 ms for one chain whatever the batch.  What the later stages need from the warm search is only a root per
+// period that is probably the reference's pick: the branch test then walks the reference's own grid for EVERY period of such a
+// chain (it is marked `wide`) and the reference-root stage reproduces the reference's refinement, or the chain goes to the
+// sequential search after all.  So:
+//   k_swd_cold_scan   the secular function of every period on ONE grid per (chain, sequence) -- the model's start value + i dc,
+//                     up to the fastest layer + dc, <= COLD_NP points -- lane = grid point, a wavefront = 63 cells, every point
+//                     independent; a wavefront that sees a sign change cuts that cell in 63 twice more (lane = point: 1.3e-6
+//                     km/s) and leaves the secant point of the last bracket in the period's list of roots;
+//   k_swd_cold_pick   a wavefront per (chain, sequence): the reference's scan replayed on those roots, period after period
+//                     (getsol, surfdisp96.f:433-479: from the root before - 1.5 dc, upwards if the sign there is the sign below
+//                     every root, else downwards, in steps of dc to the first step with an odd number of roots in it) -- no
+//                     evaluations, lane = root.
+// A pick the roots cannot decide (the scan's clamp at the start value, no root below the fastest layer, more roots than the list
+// holds, a not-a-number) fails the chain: it stays on the list.  The pick's last block rewrites the list without the chains that
+// came through.
+// ---------------------------------------------------------------------------------------
+constexpr int COLD_NP = 1024;                 // grid points per period (the first-period walk's limit)
+constexpr int COLD_TP = (COLD_NP - 1 + 62) / 63;      // wavefronts (63 cells each, ends shared) per period
+constexpr int COLD_NR = 16;                   // roots kept per period
+struct SwdCold {
+    double* roots;                            // [slot][item of the family][COLD_NR][2]: root, d(secular)/dc there -- in the order they were found;
+                                              // slot = position in the hand-back list
+    int* nroot;                               // [slot][item] roots found (may exceed COLD_NR; negative: a not-a-number in the row); the pick leaves 0 behind
+    int* s0;                                  // [slot][item] sign bit of the function at the start value (below every root)
+    int cap;                                  // slots
+    int* ticket; int nblocks;                 // blocks of the stage's pick launches (both families), counted as they finish
+};
+__device__ __forceinline__ int swd_cold_points(double cc, float bmx) {
+    const double dcs = (double)0.005f;
+    const double m = floor(((double)bmx + dcs - cc) / dcs) + 2.0;
+    return (m >= 2.0 && m <= (double)COLD_NP) ? (int)m : 0;          // 0: the table cannot hold this model's scan
+}
+
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_cold_scan(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc, SwdWarm W, SwdCold C)
+{
+    const int nsel = min(*W.count, C.cap);
+    const int lane = threadIdx.x & 63;
+    const long tiles = (long)nsel * Q.nper_total * COLD_TP;
+    const double dcs = (double)0.005f;
+    int nev = 0;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ti = (int)(tile % COLD_TP);
+        const long r = tile / COLD_TP;
+        const int el = (int)(r % Q.nper_total), pos = (int)(r / Q.nper_total);
+        const int chain = W.list[pos];
+        const int e = Q.s[0].croot_off + el;
+        int seq = 0;
+        while (seq + 1 < Q.nseq && e >= Q.s[seq + 1].croot_off) seq++;
+        const int k = e - Q.s[seq].croot_off;
+        const size_t s = (size_t)n * nchain;
+        SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        float bmx = 0.f;
+        const double cc = (double)swd_start_value(M, bmx);
+        const int np = swd_cold_points(cc, bmx);
+        if (ti * 63 >= np - 1) continue;                                     // (no cell of this wavefront's inside the scan; np = 0: the pick fails the chain)
+        const size_t row = (size_t)pos * Q.nper_total + el;
+        const int pi = ti * 63 + lane;
+        const bool valid = pi < np;
+        const double omega = (2.0 * 3.141592653589793) / (Q.s[seq].t[k] * Q.s[seq].scale);
+        const double* lc0 = mdlc + chain;
+        auto loadL = [&](int m) {
+            const double* o = lc0 + (size_t)m * 6 * nchain;
+            return SwdLayerC{o[0], o[(size_t)nchain], o[(size_t)2 * nchain], o[(size_t)3 * nchain],
+                             o[(size_t)4 * nchain], o[(size_t)5 * nchain]};
+        };
+        const double x = cc + (double)pi * dcs;
+        const double f = valid ? swd_secular_family<F>(n, loadL, omega, x) : 0.0;
+        if (valid) nev++;
+        const int sg = signbit(f) ? 1 : 0;
+        int sgb = __shfl_up(sg, 1, 64);
+        if (lane == 0) sgb = sg;
+        const unsigned long long mn = __ballot(valid && f != f);
+        unsigned long long mf = __ballot(valid && lane > 0 && sg != sgb);           // bit L: a sign change between points L - 1 and L
+        if (ti == 0 && lane == 0) C.s0[row] = sg;
+        if (mn) { if (lane == 0) atomicAdd(&C.nroot[row], -(1 << 20)); continue; }
+        while (mf) {
+            const int L = __ffsll((long long)mf) - 1;
+            mf &= mf - 1ull;
+            double a = __shfl(x, L - 1, 64), b = __shfl(x, L, 64), fa = 0.0, fb = 0.0;
+            bool ok = true;
+            for (int round = 0; round < 2 && ok; round++) {
+                const double xr = lane == 63 ? b : a + (b - a) * ((double)lane / 63.0);
+                const double fr = swd_secular_family<F>(n, loadL, omega, xr);
+                nev++;
+                const int sa = __shfl(signbit(fr) ? 1 : 0, 0, 64);
+                const unsigned long long mn2 = __ballot(fr != fr), mc = __ballot((signbit(fr) ? 1 : 0) != sa);
+                if (mn2 || !mc) { ok = false; break; }
+                const int L2 = __ffsll((long long)mc) - 1;                  // (>= 1: lane 0 has the sign sa)
+                a = __shfl(xr, L2 - 1, 64); b = __shfl(xr, L2, 64); fa = __shfl(fr, L2 - 1, 64); fb = __shfl(fr, L2, 64);
+            }
+            if (lane == 0) {
+                if (!ok) atomicAdd(&C.nroot[row], -(1 << 20));               // (a sign change that could not be refined: the row is no use)
+                else {
+                    const int sl = atomicAdd(&C.nroot[row], 1);
+                    if (sl >= 0 && sl < COLD_NR) {
+                        double root = a - fa * (b - a) / (fb - fa);
+                        if (!(root >= a && root <= b)) root = 0.5 * (a + b);
+                        C.roots[(row * COLD_NR + sl) * 2] = root; C.roots[(row * COLD_NR + sl) * 2 + 1] = (fb - fa) / (b - a);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nev += __shfl_xor(nev, off, 64);
+    if (lane == 0 && nev) { atomicAdd(&W.stats[1], (unsigned long long)nev); atomicAdd(&W.stats[33], (unsigned long long)nev); }
+}
+
+template <class F>
+__global__ void __launch_bounds__(64)
+k_swd_cold_pick(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc,
+                double* __restrict__ croot, int* __restrict__ sflag, SwdWarm W, SwdCold C)
+{
+    // a wavefront per (chain, sequence): the sequence's roots into LDS together, the replay by lane 0 (sequential by nature),
+    // the results written together
+    extern __shared__ double cold_lds[];             // [nper][COLD_NR * 2] roots and slopes, [nper] count, sign at the start value, pick
+    const int nsel = min(*W.count, C.cap);
+    const int lane = threadIdx.x & 63;
+    const double dcs = (double)0.005f;
+    for (long it = blockIdx.x; it < (long)nsel * Q.nseq; it += gridDim.x) {
+        const int seq = (int)(it % Q.nseq), pos = (int)(it / Q.nseq);
+        const int chain = W.list[pos];
+        const int nper = Q.s[seq].nper;
+        const size_t s = (size_t)n * nchain;
+        SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
+        float bmx = 0.f;
+        const double cc = (double)swd_start_value(M, bmx);
+        const int np = swd_cold_points(cc, bmx);
+        float betmx = -1.e20f;
+        for (int m = 0; m < n; m++) betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);       // as k_swd_warm
+        const size_t row0 = (size_t)pos * Q.nper_total + (size_t)(Q.s[seq].croot_off - Q.s[0].croot_off);
+        double* Rl = cold_lds;
+        int* nrl = (int*)(cold_lds + (size_t)nper * COLD_NR * 2);
+        int* s0l = nrl + nper;
+        int* pkl = s0l + nper;
+        __syncthreads();
+        for (int i = lane; i < nper * COLD_NR * 2; i += 64) Rl[i] = C.roots[row0 * COLD_NR * 2 + i];
+        for (int j = lane; j < nper; j += 64) {
+            const int nc = np == 0 ? -1 : C.nroot[row0 + j];
+            C.nroot[row0 + j] = 0;                                           // (for the next scan over this row)
+            nrl[j] = (nc < 0 || nc > COLD_NR) ? -1 : nc;
+            s0l[j] = C.s0[row0 + j];
+            pkl[j] = -1;
+        }
+        __syncthreads();
+        for (int j = lane; j < nper; j += 64) {
+            // the period's roots in ascending order (they arrive in the order the scan's wavefronts finished)
+            double* R = Rl + (size_t)j * COLD_NR * 2;
+            const int nc = nrl[j];
+            for (int i = 1; i < nc; i++) {
+                const double r = R[2 * i], sl = R[2 * i + 1];
+                int q = i - 1;
+                while (q >= 0 && R[2 * q] > r) { R[2 * q + 2] = R[2 * q]; R[2 * q + 3] = R[2 * q + 1]; q--; }
+                R[2 * q + 2] = r; R[2 * q + 3] = sl;
+            }
+        }
+        __syncthreads();
+        // statistics 34-39: why a pick failed (34 no table / forced, 35 start point below the start value, 36 a root too close to a
+        // point of the reference's grid or three roots in one step, 37 no root up to the fastest layer, 38 none down to the start
+        // value, 39 not-a-number / an unrefined root / more roots than the list holds / root above the fastest layer)
+        int why = (np == 0 || (W.force && W.force[chain])) ? 34 : 0;
+        // (sequential in the periods -- every scan starts from the root before -- but within a period lane l takes the l-th root
+        // in scan order: 36 periods in ~10 us)
+        const int s1 = s0l[0];                                                      // del1st: the sequence's first evaluation
+        double rprev = 0.0;
+        for (int j = 0; j < nper && !why; j++) {
+            const int nr = nrl[j];
+            if (nr < 0) { why = 39; break; }                                         // a not-a-number, or more roots than the list holds
+            const double* R = Rl + (size_t)j * COLD_NR * 2;
+            const int s0 = s0l[j];
+            const double c1 = j == 0 ? cc : rprev - 1.5 * dcs;
+            if (j > 0 && !(c1 > cc)) { why = 35; break; }
+            // sign at the scan's start point: roots below it
+            const int nb = __popcll(__ballot(lane < nr && R[2 * (lane < nr ? lane : 0)] < c1));
+            const int dir = (j == 0 || ((s0 ^ (nb & 1)) == s1)) ? +1 : -1;
+            // The first step of the reference's grid (c1 +- m dc, m = 1, 2, ...) with an odd number of roots in it: root l in scan
+            // order, at distance D from the start point, lies in step ceil(D / dc).  (The reference's grid hangs on ITS root of the
+            // period before, which is only good to 1e-6 c: a root that close to a grid point may belong to either step, which
+            // matters where it changes a step's count from odd to even.  Failing every such chain cost more than it saved -- 7 % of a
+            // wild chain's evaluations: the pick goes by this grid, and the branch test and the reference-root stage, which
+            // evaluate the reference's points, have the last word as they have for every root.  Three roots in one step: the
+            // reference's refinement finds one of them, and so does the stage that repeats it.)
+            const int ndir = dir > 0 ? nr - nb : nb;
+            const bool in = lane < ndir;
+            const int qi = in ? (dir > 0 ? nb + lane : nb - 1 - lane) : 0;
+            const double Dl = (double)dir * (R[2 * qi] - c1);
+            const double m = in ? ceil(Dl / dcs) : -1.0 - (double)lane;
+            int cnt = 0;
+            bool first = true;
+            for (int l2 = 0; l2 < COLD_NR; l2++) {
+                const double m2 = __shfl(m, l2, 64);
+                if (l2 < ndir && m2 == m) { cnt++; if (l2 < lane) first = false; }
+            }
+            // getsol's limits: upwards the scan ends once it has moved beyond the fastest layer + dc (:477-479), downwards it is
+            // clamped at the start value (:463-467, left to the sequential search)
+            const bool lim = in && (dir > 0 ? (c1 + (m - 1.0) * dcs >= (double)bmx + dcs) : (c1 - m * dcs <= cc));
+            const unsigned long long me = __ballot(in && first && ((cnt & 1) || lim));
+            if (!me) { why = dir < 0 ? 38 : 37; break; }
+            const int L = __ffsll((long long)me) - 1;
+            if (__shfl(lim ? 1 : 0, L, 64)) { why = dir > 0 ? 37 : 38; break; }
+            const int pick = dir > 0 ? nb + L : nb - 1 - L;
+            if (R[2 * pick] > (double)betmx) { why = 39; break; }                   // getsol :483-485: the reference-semantics search decides the flag
+            rprev = R[2 * pick];
+            if (lane == 0) pkl[j] = pick;
+        }
+        if (lane == 0) {
+        if (why && atomicExch(&W.need[chain], 5) != 5) atomicAdd(&W.stats[why], 1ull);
+        // (a chain whose evaluation before this one failed comes through here like any other: its flags are of THAT model)
+        if (!why) sflag[(size_t)seq * nchain + chain] = 1;
+        }
+        __syncthreads();
+        for (int j = lane; j < nper; j += 64) {
+            const int pick = pkl[j];
+            if (pick < 0) continue;
+            const double root = Rl[((size_t)j * COLD_NR + pick) * 2], slope = Rl[((size_t)j * COLD_NR + pick) * 2 + 1];
+            const size_t o = (size_t)(Q.s[seq].croot_off + j) * nchain + chain;
+            croot[o] = (double)(float)root;                                         // surfdisp96.f:302
+            if (W.cwarm) W.cwarm[o] = (double)(float)root;
+            W.sgn[o] = slope > 0.0 ? 1 : 0;                                         // sign bit of the function just below the root
+            W.slope[o] = slope;
+            if (W.ferr) W.ferr[o] = 0.0;
+            if (j == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
+            atomicAdd(&W.stats[2], 1ull);
+        }
+    }
+    // ---- the stage's last block: the list without the chains that came through
+    __threadfence();
+    int last = 0;
+    if (lane == 0) last = atomicAdd(C.ticket, 1) == C.nblocks - 1 ? 1 : 0;
+    last = __shfl(last, 0, 64);
+    if (!last) return;
+    __threadfence();
+    if (lane == 0) {
+        const int n0 = *W.count;
+        int w = 0, rec = 0;
+        for (int i = 0; i < n0; i++) {
+            const int ch = W.list[i];
+            const int nd = atomicAdd(&W.need[ch], 0);
+            if (i < C.cap && nd == 1) { W.need[ch] = 0; if (atomicExch(&W.wide[ch], 1) == 0) atomicAdd(&W.stats[13], 1ull); rec++; }
+            else { W.need[ch] = 1; W.list[w++] = ch; }
+        }
+        *W.count = w;
+        atomicAdd(&W.stats[0], (unsigned long long)(-(long long)rec));          // (taken back from "chains handed back")
+        atomicAdd(&W.stats[32], (unsigned long long)rec);
+        *C.ticket = 0;
+    }
+}
+
 // The branch test of the warm start (WarmSearch, swd_math.hpp): one secular evaluation per item at the point the
 // reference's scan of this period would start from -- the continued root of the period before minus 1.5 dc, or the
 // model's start value for a sequence's first period (surfdisp96.f:257-276).  mdl: the float32 search model (start value).
@@ -1638,8 +1899,10 @@ k_swd_warm_walk(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
 template <class F>
 __global__ void __launch_bounds__(64)
 k_swd_warm_walk_dense(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, const double* __restrict__ mdlc,
-                      const double* __restrict__ croot, SwdWarm W)
+                      const double* __restrict__ croot, SwdWarm W, int ipb = 64)
 {
+    // ipb: items per block and trip (<= 64).  Small batches take fewer: a block's trips over its items' points come one after the
+    // other, and 64 items of a chain whose sequences all walk are ~450 points -- seven trips where eight blocks make one each
     constexpr int MAXM = 400;                    // (k_swd_warm_walk<., false>'s 50 rounds of 8 points)
     const int lane = threadIdx.x & 63;
     const int nsel = *W.icount;
@@ -1648,10 +1911,10 @@ k_swd_warm_walk_dense(int nchain, int n, SwdSeqs Q, const float* __restrict__ md
     const double dcs = (double)0.005f;
     __shared__ int s_pre[65], s_bad[64], s_chain[64], s_m[64], s_dir[64], s_s1[64];
     __shared__ double s_sk[64], s_om[64], s_cc[64], s_lim[64];
-    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    for (long base = (long)blockIdx.x * ipb; base < total; base += (long)gridDim.x * ipb) {
         // ---- lane = item
         const long it = base + lane;
-        bool live = it < total;
+        bool live = lane < ipb && it < total;
         const int pos = live ? (int)(it / per_chain) : 0, sub_it = live ? (int)(it - (long)pos * per_chain) : 0;
         const int chain = W.ilist[live ? pos : 0];
         const int e0 = Q.s[0].croot_off + sub_it;

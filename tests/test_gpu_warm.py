@@ -565,7 +565,11 @@ def test_warm_search_in_rounds_is_the_one_round_search_bit_for_bit():
     for budgets in ((302, 1), (302, 0), (10101, 1), (303, 1), (4, 1), (5, 0)):
         r = runs[budgets]
         assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), budgets
-        assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]) and r[4] == ref[4], (budgets, r[4], ref[4])
+        assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]), budgets
+        # (hand-backs, items and the stage's evaluations identical; the warm stage's count includes the branch test's, which skips an
+        # item whose chain a sister item has already handed back -- which of the two runs first is a matter of scheduling)
+        assert r[4][0] == ref[4][0] and r[4][2] == ref[4][2] and abs(r[4][1] - ref[4][1]) <= 1e-5 * ref[4][1], (budgets, r[4], ref[4])
+        assert abs(r[4][3] - ref[4][3]) <= 1e-3 * ref[4][3], (budgets, r[4], ref[4])
 
 
 def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_bit_for_bit():
@@ -758,3 +762,78 @@ def test_host_path_restart_in_one_launch_equals_the_scatters():
     assert torch.equal(st["rem"][i2], tt(rem)) and torch.equal(st["dt"][i2], tt(dtn))
     with pytest.raises(RfsError):
         joint.flow_restart(st, buf, nchain + 1, 0, 0, 0, None, None, None, None, 0, None)
+
+
+def test_search_without_a_prediction_for_small_batches(orc):
+    """Round 6 ("swd_cold_scan" / "swd_cold_first"): in a batch of a few chains whose hand-backs are searched in the foreground, a
+    chain the warm start declines takes k_swd_cold_scan / k_swd_cold_pick -- every period's secular function on one grid, its
+    roots refined, the reference's scan replayed on them -- and then the branch test on the reference's own grid and the
+    reference-root stage like everybody else, instead of the sequential search.
+    (1) Wild models evaluated one after the other (each a different random model: nothing to continue) give the oracle's roots
+    and flags; (2) configs[0]'s sampler from its own random start models at dt = 0.1 (one chain of that run hands 40 % of its
+    evaluations back) stores the same samples, misfits and accept counts with the stage on, off, and with the warm search left
+    out altogether -- and the sequential search runs for less than half as many evaluations."""
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    from rfsurfhmc_amd.pyhmc.hmc import HamitonianMC
+    thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
+    tt = np.arange(5., 41.)
+    x0 = np.hstack((vs, thk))
+    m = SurfWD(tRc=tt, tRg=tt, device=0)
+    d0, flag = m.forward(x0); assert flag
+    m.set_obsdata(d0)
+    b0 = bench.bounds_of(x0)
+    ctx = m._ensure(10)
+    o = orc.SurfWD(tRc=tt, tRg=tt)
+    o.set_obsdata(d0)
+    dev = torch.device("cuda")
+    names = ("swd_warm_declined_chains", "swd_cold_chains")
+    try:
+        # (1) nothing to continue: 8 models at a time, every evaluation's models drawn afresh inside the bounds
+        m.set_warm_start(2)
+        rng = np.random.default_rng(11)
+        c0 = [ctx.stat(k) for k in names]
+        nroot = nsame = 0
+        worst = 0.0
+        for it in range(6):
+            xs = b0[:, 0] + (b0[:, 1] - b0[:, 0]) * rng.random((8, 20))
+            xs[:, 19] = 0.0
+            mis, g, d, f = m.misfit_and_grad_device(torch.from_numpy(xs).to(dev))
+            d, f, mis, g = d.cpu().numpy(), f.cpu().numpy() != 0, mis.cpu().numpy(), g.cpu().numpy()
+            for i in range(8):
+                mo, go, do, fo = o.misfit_and_grad(xs[i])
+                assert bool(fo) == bool(f[i]), (it, i)
+                if not fo:
+                    continue
+                # (phase velocities are the roots; a root one float32 step off moves a group velocity by ~1e-4 relative)
+                rel_c = np.abs(d[i, :36] - do[:36]) / do[:36]
+                assert rel_c.max() <= 1.2e-6, (it, i, float(rel_c.max()))
+                nroot += 36; nsame += int((d[i, :36] == do[:36]).sum())
+                worst = max(worst, float(rel_c.max()))
+                if np.array_equal(d[i, :36], do[:36]):
+                    assert abs(mis[i] - mo) <= 1e-5 * abs(mo) + 1e-12, (it, i)
+        took = [ctx.stat(k) - v for k, v in zip(names, c0)]
+        print(f"wild models: {nsame} of {nroot} phase velocities bit-identical, worst {worst:.2e} c; {took[1]} chain evaluations "
+              f"through the search without a prediction, {took[0]} through the sequential search")
+        # (on models this wild the device's own sequential search ends one float32 step beside the oracle's root for 1.2 % of the
+        # roots -- scripts/cold_wild.py: 37 of 3 168 with the stage off, 30 with it on)
+        assert took[1] >= 20 and nsame >= 0.97 * nroot
+        # (2) the sampler
+        m.set_warm_start(1)
+        out = {}
+        for tag, cold, first, nch in (("off", 0, 0, 1), ("on", -1, 0, 1), ("first", -1, 8, 1), ("off8", 0, 0, 8), ("on8", -1, 0, 8), ("first8", -1, 8, 8)):
+            ctx.set_option("swd_cold_scan", cold); ctx.set_option("swd_cold_first", first)
+            c0 = [ctx.stat(k) for k in names]
+            s = HamitonianMC(m, b0, 0.1, [5, 20], 10, 991206, 800, 200, myrank=0, name="c0", outdir=None, nchains=nch, verbose=False, store_syn=False)
+            mis = s.sample_flow(max_steps=240)
+            out[tag] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), [ctx.stat(k) - v for k, v in zip(names, c0)])
+        for a, b in (("off", "on"), ("off", "first"), ("off8", "on8"), ("off8", "first8")):
+            for i in range(3):
+                assert np.array_equal(out[a][i], out[b][i]), (a, b, i)
+        print({k: v[3] for k, v in out.items()})
+        assert out["off"][3][0] >= 40                                   # the chain is a wild one
+        assert out["on"][3][0] <= 0.7 * out["off"][3][0] and out["first"][3][0] <= 0.5 * out["off"][3][0]
+        assert out["on"][3][1] > 0 and out["first8"][3][1] > 0
+    finally:
+        ctx.set_option("swd_cold_scan", -1); ctx.set_option("swd_cold_first", 4); m.set_warm_start(1)
