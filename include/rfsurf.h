@@ -406,6 +406,9 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          chain takes 2 ms.  Such batches also keep ONE hand-back list and ONE sequential search per step, on
  *                          the step's own stream (12 launches on the step's chain instead of 19).  0 = off, 1 = batches of up
  *                          to 512 chains.  Sequences of up to 192 periods, fundamental mode, no water layer.
+ *   "swd_exact_group_small"  2 (default): periods per group of the reference-root stage in those small batches (16 lanes per
+ *                          group; the stage is as long as a group's periods + run-up one after the other, and the groups whose
+ *                          run-up does not contract get a second try behind eight run-up periods there).
  *   "swd_cold_first"       4 (default): batches of up to that many chains skip the warm search and give every chain the search
  *                          without a prediction (configs[0]: one chain per rank) -- a chain the branch test declines after a
  *                          continued root would otherwise cost a sequential search.  0..512.

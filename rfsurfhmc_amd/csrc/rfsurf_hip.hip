@@ -134,6 +134,7 @@ struct rfs_ctx {
     struct XGroups { const unsigned long long* item; const int* count; int cap, G; bool on; };
     XGroups xg[2] = {{nullptr, nullptr, 0, 0, false}, {nullptr, nullptr, 0, 0, false}};   // groups whose eigenfunctions follow the second launch (Rayleigh, Love)
     int exact_coop = 1;        // option "swd_exact_coop": 0 never, 1 (default) 16 lanes per group for small batches (k_swd_exact_coop), 2 always (tests)
+    int exact_group_small = 2; // "swd_exact_group_small": periods per group in the small batches of "swd_cold_scan" (16 lanes per group)
     int exact_group = 4, exact_runup = 2;   // options "swd_exact_group" / "swd_exact_runup": periods per lane of k_swd_exact, run-up periods in front of them
     bool krn_ruled = false;    // the eigenfunction pass of the evaluation being launched stores chain-ruled kernels (joint_eval; B1 keeps the raw classes)
     bool warm_primed = false;  // croot / krn / xw describe the previous evaluation of the same nchain chains
@@ -1076,6 +1077,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             // ... and from the continued roots to the reference's own: its refinement (nevill) inside its scan cell, groups of
             // periods per lane (k_swd_exact); what a lane declines goes to the full search like the branch test's chains
             int G = std::max(1, c->exact_group);
+            // (small batches with the second try below: the stage is as long as a group's periods + run-up, one after the other --
+            // groups of 2 instead of 4: ONE configs[0] chain 0.76 -> 0.68 ms per evaluation)
+            if (sb && c->exact_coop != 0 && n >= 3 && n - 1 <= 64) G = std::max(1, std::min(G, c->exact_group_small));
             const int ru = std::max(0, c->exact_runup);
             auto ngroups = [&](const SwdSeqs& QQ, int g_) { int g = 0; for (int q = 0; q < QQ.nseq; q++) g += (QQ.s[q].nper + g_ - 1) / g_; return g; };
             // Small batches (round 6): a lane per group leaves the chip empty and the stage as long as ever -- its length is one
@@ -1084,8 +1088,9 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             const int np_max = std::max(Q.nper_total, P.QL.nper_total);
             bool coop = c->exact_coop != 0 && n >= 3 && n - 1 <= 64 &&
                         (c->exact_coop > 1 || (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain <= (size_t)EXACT_COOP_MAX);
-            // (shorter groups for very small batches were tried and lose: every group has its own run-up, and a run-up that does
-            // not contract hands the chain to the sequential search -- ONE chain of configs[0]: 27 -> 96 of 299 evaluations)
+            // (shorter groups: every group has its own run-up, and a run-up that does not contract used to hand the chain to the
+            // sequential search -- ONE chain of configs[0]: 27 -> 96 of 299 evaluations; with a second try behind eight run-up
+            // periods none does)
             if (!coop) G = std::max(2, G);
             // big batches in rounds ("swd_exact_budget"): a budget of evaluations per lane, the unfinished groups continued with 16
             // lanes each.  Lists of a quarter of the groups; one that overflows is not an error (those groups finish in place).
@@ -1101,10 +1106,11 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
             }
             // groups whose run-up did not contract: done again with a longer one ("swd_exact_redo_runup") instead of handing
             // their chain to the sequential search
-            // (-1 = automatic: 4 run-up periods for the second try of the small batches' 16-lane form -- ONE configs[0] chain hands
+            // (-1 = automatic: 4 run-up periods -- 8 in the small batches of "swd_cold_scan", whose groups are shorter -- for the second
+            // try of the small batches' 16-lane form -- ONE configs[0] chain hands
             // 15 % of its evaluations back for this cause alone -- and none for big batches, where the cause is 0.1 chains per
             // step and the list's launch would sit on the step's critical chain)
-            const int ru2_opt = c->exact_redo_runup < 0 ? (coop ? 4 : 0) : c->exact_redo_runup;
+            const int ru2_opt = c->exact_redo_runup < 0 ? (coop ? (sb ? 8 : 4) : 0) : c->exact_redo_runup;
             const int ru2 = ru2_opt > ru ? ru2_opt : 0;
             const size_t rcap = ru2 ? std::max<size_t>(1024, (size_t)ngroups(np_max == Q.nper_total ? Q : P.QL, G) * nchain / 8) : 1;
             ENSURE(c, c->xspc, 4 * sizeof(int));
@@ -1569,14 +1575,19 @@ int joint_eval(rfs_ctx* c, int nchain, const double* x, double* misfit, double* 
         const int nt = c->has_rf ? c->f.nt : 0;
         // (row cache in LDS: residual + kernel scales of every data row of the block's 32 chains, while it fits)
         const int rowc = ((size_t)(n + 3 * R.nswd) * 32 * sizeof(double) <= 56 * 1024) ? 1 : 0;
-        const size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
+        size_t lds_c = (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32 * sizeof(double);
+        // (ONE chain: its kernels, scales and roots staged in LDS -- k_swd_combine)
+        const size_t lds_stage = ((size_t)R.nitems * 4 * n + (size_t)4 * R.nitems) * sizeof(double);
+        const int stage = (nchain == 1 && lds_c + lds_stage <= 150 * 1024) ? 1 : 0;
+        if (stage) lds_c += lds_stage;
 #define RFS_LAUNCH_COMBINE(SPH)                                                                                          \
+        if (stage && lds_c > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)k_swd_combine<SPH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c)); \
         hipLaunchKernelGGL(k_swd_combine<SPH>, dim3((nchain + 31) / 32), dim3(64, 8), lds_c,      /* 512-thread blocks = 16 layer slots per chain (round 5: 5.29 -> 5.24 ms per step against 256 threads; 1024 the same, 128 slower: 5.38); same sums in the same order */                             \
                            st, nchain, n, c->mode, nt, R, c->wt, c->mrf.as<double>(),                                    \
                            c->krn.as<double>(), c->croot.as<double>(), c->ugr.as<double>(), c->sflag.as<int>(),          \
                            P.nseq, c->d_dobs.as<double>(), misfit, grad, dsyn, flag,                                      \
-                           track ? c->wvalid.as<int>() : (int*)nullptr, rowc, first)
-        if (c->sphere) RFS_LAUNCH_COMBINE(true); else RFS_LAUNCH_COMBINE(false);
+                           track ? c->wvalid.as<int>() : (int*)nullptr, rowc, first, stage)
+        if (c->sphere) { RFS_LAUNCH_COMBINE(true); } else { RFS_LAUNCH_COMBINE(false); }
 #undef RFS_LAUNCH_COMBINE
         HIPCHK(c, hipGetLastError());
         return RFS_OK;
@@ -1906,6 +1917,10 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
     if (!strcmp(name, "swd_warm_exact")) {
         if (value < 0 || value > 1) return fail(c, RFS_ERR_ARG, "swd_warm_exact must be 0 or 1");
         c->warm_exact = value; c->warm_primed = false; return RFS_OK;
+    }
+    if (!strcmp(name, "swd_exact_group_small")) {
+        if (value < 1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group_small must be within [1, 4096]");
+        c->exact_group_small = value; return RFS_OK;
     }
     if (!strcmp(name, "swd_exact_group")) {
         if (value < 1 || value > 4096) return fail(c, RFS_ERR_ARG, "swd_exact_group must be within [1, 4096]");

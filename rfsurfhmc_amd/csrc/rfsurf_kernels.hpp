@@ -1478,6 +1478,30 @@ struct SwdCold {
     int cap;                                  // slots
     int* ticket; int nblocks;                 // blocks of the stage's pick launches (both families), counted as they finish
 };
+// swd_start_value by a whole wavefront for ONE model of up to 64 layers (every lane the same chain): lane = layer, one load each
+// instead of 2 n dependent ones -- the same comparisons in the same order (the slowest layer: the first index that attains the
+// minimum), the same gtsolh; betmx2: the fastest S velocity of the f64 layer constants, as k_swd_warm forms it.
+__device__ __forceinline__ float swd_start_value_wave(const SwdModel& M, int lane, float& betmx, const double* __restrict__ mdlc, int chain,
+                                                      int nchain, float& betmx2) {
+    const bool in = lane < M.n;
+    const float b = in ? M.Bf(lane) : 0.f, a = in ? M.Af(lane) : 0.f;
+    const float c3 = in ? (float)mdlc[((size_t)lane * 6 + 3) * nchain + chain] : -1.e20f;
+    const bool sol = b > 0.01f;
+    float v = in ? (sol ? b : a) : 1.e20f, bm = in ? b : -1.e20f, b2 = c3;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        v = fminf(v, __shfl_xor(v, off, 64)); bm = fmaxf(bm, __shfl_xor(bm, off, 64)); b2 = fmaxf(b2, __shfl_xor(b2, off, 64));
+    }
+    betmx = bm; betmx2 = b2;
+    // (the serial loop starts from bmn = 1e20 and takes strictly smaller values only)
+    const unsigned long long mm = __ballot(in && (sol ? b : a) == v && v < 1.e20f);
+    const int jmn = mm ? __ffsll((long long)mm) - 1 : 0;
+    const int jsol = mm ? __shfl(sol ? 1 : 0, jmn, 64) : 1;
+    const float bj = __shfl(b, jmn, 64), aj = __shfl(a, jmn, 64);
+    float cc1 = (jsol == 0) ? v : swd_gtsolh(aj, bj);
+    cc1 = 0.95f * cc1; cc1 = 0.90f * cc1;
+    return cc1;
+}
 __device__ __forceinline__ int swd_cold_points(double cc, float bmx) {
     const double dcs = (double)0.005f;
     const double m = floor(((double)bmx + dcs - cc) / dcs) + 2.0;
@@ -1504,8 +1528,8 @@ k_swd_cold_scan(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         const int k = e - Q.s[seq].croot_off;
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
-        float bmx = 0.f;
-        const double cc = (double)swd_start_value(M, bmx);
+        float bmx = 0.f, betmx2 = 0.f;
+        const double cc = (double)(n <= 64 ? swd_start_value_wave(M, lane, bmx, mdlc, chain, nchain, betmx2) : swd_start_value(M, bmx));
         const int np = swd_cold_points(cc, bmx);
         if (ti * 63 >= np - 1) continue;                                     // (no cell of this wavefront's inside the scan; np = 0: the pick fails the chain)
         const size_t row = (size_t)pos * Q.nper_total + el;
@@ -1578,11 +1602,14 @@ k_swd_cold_pick(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
         const int nper = Q.s[seq].nper;
         const size_t s = (size_t)n * nchain;
         SwdModel M{mdl + chain, mdl + (F::LOVE && Q.s[seq].alt_vp ? 4 : 1) * s + chain, mdl + 2 * s + chain, mdl + 3 * s + chain, nchain, n};
-        float bmx = 0.f;
-        const double cc = (double)swd_start_value(M, bmx);
+        float bmx = 0.f, betmx = -1.e20f;
+        double cc;
+        if (n <= 64) cc = (double)swd_start_value_wave(M, lane, bmx, mdlc, chain, nchain, betmx);
+        else {
+            cc = (double)swd_start_value(M, bmx);
+            for (int m = 0; m < n; m++) betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);   // as k_swd_warm
+        }
         const int np = swd_cold_points(cc, bmx);
-        float betmx = -1.e20f;
-        for (int m = 0; m < n; m++) betmx = fmaxf(betmx, (float)mdlc[((size_t)m * 6 + 3) * nchain + chain]);       // as k_swd_warm
         const size_t row0 = (size_t)pos * Q.nper_total + (size_t)(Q.s[seq].croot_off - Q.s[0].croot_off);
         double* Rl = cold_lds;
         int* nrl = (int*)(cold_lds + (size_t)nper * COLD_NR * 2);
@@ -1639,17 +1666,17 @@ k_swd_cold_pick(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
             const bool in = lane < ndir;
             const int qi = in ? (dir > 0 ? nb + lane : nb - 1 - lane) : 0;
             const double Dl = (double)dir * (R[2 * qi] - c1);
-            const double m = in ? ceil(Dl / dcs) : -1.0 - (double)lane;
-            int cnt = 0;
-            bool first = true;
-            for (int l2 = 0; l2 < COLD_NR; l2++) {
-                const double m2 = __shfl(m, l2, 64);
-                if (l2 < ndir && m2 == m) { cnt++; if (l2 < lane) first = false; }
-            }
+            const int m = in ? (int)ceil(Dl * (1.0 / dcs)) : -1 - lane;            // (in scan order the steps do not decrease: a step's roots are neighbours)
+            int mb = __shfl_up(m, 1, 64);
+            const bool first = in && (lane == 0 || mb != m);
+            const unsigned long long mfirst = __ballot(first);
+            // (roots of my step: up to the next lane that starts one)
+            const unsigned long long above = lane >= 63 ? 0ull : (mfirst >> (lane + 1));
+            const int cnt = (above ? __ffsll((long long)above) : ndir - lane);
             // getsol's limits: upwards the scan ends once it has moved beyond the fastest layer + dc (:477-479), downwards it is
             // clamped at the start value (:463-467, left to the sequential search)
-            const bool lim = in && (dir > 0 ? (c1 + (m - 1.0) * dcs >= (double)bmx + dcs) : (c1 - m * dcs <= cc));
-            const unsigned long long me = __ballot(in && first && ((cnt & 1) || lim));
+            const bool lim = in && (dir > 0 ? (c1 + (double)(m - 1) * dcs >= (double)bmx + dcs) : (c1 - (double)m * dcs <= cc));
+            const unsigned long long me = __ballot(first && ((cnt & 1) || lim));
             if (!me) { why = dir < 0 ? 38 : 37; break; }
             const int L = __ffsll((long long)me) - 1;
             if (__shfl(lim ? 1 : 0, L, 64)) { why = dir > 0 ? 37 : 38; break; }
@@ -1675,8 +1702,8 @@ k_swd_cold_pick(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
             W.slope[o] = slope;
             if (W.ferr) W.ferr[o] = 0.0;
             if (j == 0) W.betmx[(size_t)(F::LOVE ? 1 : 0) * nchain + chain] = betmx;
-            atomicAdd(&W.stats[2], 1ull);
         }
+        if (lane == 0 && !why) atomicAdd(&W.stats[2], (unsigned long long)nper);
     }
     // ---- the stage's last block: the list without the chains that came through
     __threadfence();
@@ -2748,14 +2775,30 @@ k_rf_reduce(int nchain, RfReduce R, double* __restrict__ misfit, double* __restr
 template <bool SPH>
 __global__ void __launch_bounds__(1024)
 k_swd_combine(int nchain, int n, int mode, int nt, SwdRows R, double wt, const double* __restrict__ misfit_rf,
-              const double* __restrict__ krn, const double* __restrict__ croot,
-              const double* __restrict__ ugr, const int* __restrict__ sflag, int nseq,
+              const double* krn_g, const double* croot_g,
+              const double* ugr_g, const int* __restrict__ sflag, int nseq,
               const double* __restrict__ dobs, double* __restrict__ misfit, double* __restrict__ grad,
-              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid, int rowc, int first)
+              double* __restrict__ dsyn, int* __restrict__ flag, int* __restrict__ wvalid, int rowc, int first, int stage = 0)
 {
     // first != 0 (joint evaluation, launched beside the RF sweeps): this kernel writes gradient, misfit and flag FIRST and
     // k_rf_reduce adds the RF part behind it (same sums, the other way round); dsyn of a failed chain is left to it as well
-    extern __shared__ double hs[];               // [n][32] interface partial sums (+ [3][nswd][32] row cache when rowc)
+    extern __shared__ double hs[];               // [n][32] interface partial sums (+ [3][nswd][32] row cache when rowc) (+ the staged arrays)
+    // stage (ONE chain, round 6): a layer's thread goes through the data rows one after the other and every row costs it a handful
+    // of dependent loads -- 60 us for 72 rows, the longest kernel of a one-chain step after the reference-root stage.  The chain's
+    // kernels, scales and roots are copied into LDS by all threads first (with one chain the arrays are contiguous as they lie)
+    // and the very same loop reads them there: the same operations on the same numbers.
+    const double* krn = krn_g; const double* croot = croot_g; const double* ugr = ugr_g;
+    if (stage) {
+        double* kl = hs + (size_t)(n + (rowc ? 3 * R.nswd : 0)) * 32;
+        double* ul = kl + (size_t)R.nitems * 4 * n;
+        double* cl = ul + (size_t)3 * R.nitems;
+        const int tid = threadIdx.y * blockDim.x + threadIdx.x, nth = blockDim.x * blockDim.y;
+        for (int i = tid; i < R.nitems * 4 * n; i += nth) kl[i] = krn_g[i];
+        for (int i = tid; i < 3 * R.nitems; i += nth) ul[i] = ugr_g[i];
+        for (int i = tid; i < R.nitems; i += nth) cl[i] = croot_g[i];
+        __syncthreads();
+        krn = kl; ugr = ul; croot = cl;
+    }
     // 32 chains x 32 layer slots per block: a wavefront = 32 consecutive chains (256 B segments of the chain-minor
     // arrays) x 2 layer slots, so the grid has nchain/32 blocks -- one per CU at 8192 chains instead of one per two
     const int tx = threadIdx.x & 31, slot = threadIdx.y * 2 + (threadIdx.x >> 5), NS = blockDim.y * 2;

@@ -594,6 +594,7 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
         out = {}
         try:
             ctx.set_option("swd_exact_redo_runup", 0)       # (the second try of small batches is the 16-lane form's alone: off for the comparison)
+            ctx.set_option("swd_exact_group_small", 4)      # (... and so are their shorter groups: the same groups in both forms)
             for coop in (0, 2):
                 ctx.set_option("swd_exact_coop", coop)
                 names = ("swd_warm_declined_chains", "swd_exact_declined_chains", "swd_exact_secular_evals", "swd_warm_items")
@@ -603,7 +604,7 @@ def test_reference_root_stage_with_16_lanes_per_group_is_the_single_lane_stage_b
                 out[coop] = (np.asarray(mis), np.asarray(s.x_cache), np.asarray(s.naccepted), np.asarray(s.ntrajectories),
                              [ctx.stat(k) - v for k, v in zip(names, c0)])
         finally:
-            ctx.set_option("swd_exact_coop", 1); ctx.set_option("swd_exact_redo_runup", -1)
+            ctx.set_option("swd_exact_coop", 1); ctx.set_option("swd_exact_redo_runup", -1); ctx.set_option("swd_exact_group_small", 2)
         return out
 
     r = runs_of(joint, ctx, bounds, xb, nc, 0.05)
