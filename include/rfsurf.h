@@ -409,9 +409,10 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *   "swd_exact_group_small"  2 (default): periods per group of the reference-root stage in those small batches (16 lanes per
  *                          group; the stage is as long as a group's periods + run-up one after the other, and the groups whose
  *                          run-up does not contract get a second try behind eight run-up periods there).
- *   "swd_cold_first"       4 (default): batches of up to that many chains skip the warm search and give every chain the search
+ *   "swd_cold_first"       8 (default): batches of up to that many chains skip the warm search and give every chain the search
  *                          without a prediction (configs[0]: one chain per rank) -- a chain the branch test declines after a
- *                          continued root would otherwise cost a sequential search.  0..512.
+ *                          continued root would otherwise cost a sequential search (8 wild chains: 0.99 -> 0.91 ms per step;
+ *                          16: the same either way; 32: 1.03 -> 1.24).  0..512.
  *   "flow_async_handback"  rfs_flow_step / rfs_flow_step2 with the warm start on: 1 = a chain the warm start hands back to the
  *                          reference-semantics search (a few per step on rough models: ~3 ms of dependent evaluations, during
  *                          which every other chain would wait) sits that step out instead -- its model has drifted, it is not

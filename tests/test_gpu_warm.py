@@ -837,4 +837,4 @@ def test_search_without_a_prediction_for_small_batches(orc):
         assert out["on"][3][0] <= 0.7 * out["off"][3][0] and out["first"][3][0] <= 0.5 * out["off"][3][0]
         assert out["on"][3][1] > 0 and out["first8"][3][1] > 0
     finally:
-        ctx.set_option("swd_cold_scan", -1); ctx.set_option("swd_cold_first", 4); m.set_warm_start(1)
+        ctx.set_option("swd_cold_scan", -1); ctx.set_option("swd_cold_first", 8); m.set_warm_start(1)
