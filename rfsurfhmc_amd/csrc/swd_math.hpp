@@ -493,6 +493,7 @@ RFS_HD float swd_gtsolh(float a, float b) {
 
 // surfdisp96.f:149-160 extremal velocities, :203-222 start value of the search: 0.95 * 0.90 * (Rayleigh velocity of the
 // half-space made of the slowest layer), all in single precision; betmx = fastest S velocity
+constexpr double SWD_MAX_SCAN = 2000.0;      // km/s between the start value and the fastest layer: 4e5 cells of the scan (RootSearchT::begin)
 template <class Mdl>
 RFS_HD float swd_start_value(const Mdl& M, float& betmx) {
     float bmx = -1.e20f, bmn = 1.e20f; int jmn = 0, jsol = 1;
@@ -562,6 +563,7 @@ struct RootSearchT {
     long nsec;
     // MODES only: mode index, number of modes, cap period of the later modes, fundamental failed; scratch of unrounded c(k)
     int iq = 0, nmode = 1, ift = 1 << 30, fund_failed = 0;
+    int absurd = 0;            // the model's scan would be longer than SWD_MAX_SCAN (begin): the search fails at its first evaluation
     double* cmb = nullptr; long cms = 0;
     RFS_HD double kept(int kk) const { return cmb[(long)kk * cms]; }
 
@@ -637,6 +639,10 @@ struct RootSearchT {
         del1st = 0.0; cprev = 0.0; m = 1; nev = 1; nctrl = 1;
         if (!Tab::kDynamic) for (int i = 0; i < 12; i++) { tab.sx(i, 0.0); tab.sy(i, 0.0); }
         if (kmax <= 0) { done = 1; return; }
+        // (a model whose fastest layer lies SWD_MAX_SCAN above the start value -- velocities that are not velocities, or not
+        // numbers: a position that left its bounds, a caller's mistake -- would have the scan walk millions of cells of 0.005,
+        // minutes on a device whose other chains wait for this one; the reference would walk them.  Such a search fails.)
+        absurd = !((double)betmx - cc < SWD_MAX_SCAN) ? 1 : 0;
         start_period(T);
     }
 
@@ -666,6 +672,7 @@ struct RootSearchT {
     template <class PeriodFn, class OutFn>
     RFS_HD void advance(double del, const PeriodFn& T, const OutFn& out) {
         nsec++;
+        if (absurd) { for (int kk = 0; kk < kmax; kk++) out(kk, 0.0); flag = 0; done = 1; return; }
         // Phase dispatch and the loop head of nevill as PREDICATED updates (selects, no branches): with 64 lanes in a
         // mixture of phases every branch of an if / else chain would be executed anyway, and the structurised control
         // flow cost several times the dozen selects below.  sgn1(a) * sgn1(b) < 0  <=>  the sign bits differ.

@@ -460,3 +460,33 @@ def test_a_chain_whose_momentum_has_blown_up_is_folded_back_inside_its_bounds():
     Hn = out["Hnew"].cpu().numpy()
     assert not np.isfinite(Hn[3]) or Hn[3] > 1e20
     assert not np.isfinite(Hn[4]) or Hn[4] > 1e20
+
+
+def test_a_model_that_is_no_model_fails_at_once():
+    """A model whose fastest layer lies thousands of km/s above the search's start value (a caller's mistake, a position that
+    left its bounds) would have the reference's scan walk millions of cells of 0.005 km/s -- half a minute on the device, during
+    which the other chains of the batch wait.  RootSearchT::begin fails such a search at its first evaluation (SWD_MAX_SCAN):
+    the chain gets the failure return, the others are not touched."""
+    import time
+    import torch
+    from rfsurfhmc_amd.model.model_surf import SurfWD
+    thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
+    tt = np.arange(5., 41.)
+    x0 = np.hstack((vs, thk))
+    m = SurfWD(tRc=tt, tRg=tt, device=0)
+    d0, flag = m.forward(x0); assert flag
+    m.set_obsdata(d0 * 1.01)
+    xs = np.tile(x0, (4, 1))
+    xs[1, :10] *= 2.0e4                     # vs of 6e4 .. 9e4 km/s
+    xs[2, 3] = np.nan
+    dev = torch.device("cuda")
+    base = m.misfit_and_grad_device(torch.from_numpy(np.tile(x0, (4, 1))).to(dev))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mis, g, d, f = m.misfit_and_grad_device(torch.from_numpy(xs).to(dev))
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    assert el < 2.0, el
+    f = f.cpu().numpy()
+    assert f[0] == 1 and f[3] == 1 and f[1] == 0 and f[2] == 0, f
+    assert float(mis[1]) == 0.0 and float(mis[2]) == 0.0 and not g[1].any() and not g[2].any()       # model_surf.py's failure return
+    for i in (0, 3):
+        assert torch.equal(g[i], base[1][i]) and torch.equal(mis[i], base[0][i])
