@@ -1652,9 +1652,9 @@ k_swd_cold_pick(int nchain, int n, SwdSeqs Q, const float* __restrict__ mdl, con
             }
         }
         __syncthreads();
-        // statistics 34-39: why a pick failed (34 no table / forced, 35 start point below the start value, 36 a root too close to a
-        // point of the reference's grid or three roots in one step, 37 no root up to the fastest layer, 38 none down to the start
-        // value, 39 not-a-number / an unrefined root / more roots than the list holds / root above the fastest layer)
+        // statistics 34-39: why a pick failed (34 no table / forced, 35 start point below the start value, 36 unused, 37 no root up
+        // to the fastest layer, 38 none down to the start value, 39 not-a-number / an unrefined root / more roots than the list
+        // holds / root above the fastest layer)
         int why = (np == 0 || (W.force && W.force[chain])) ? 34 : 0;
         // (sequential in the periods -- every scan starts from the root before -- but within a period lane l takes the l-th root
         // in scan order: 36 periods in ~10 us)
