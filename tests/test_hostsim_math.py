@@ -165,6 +165,31 @@ def test_root_search_state_machine(hs, orc, golden, entry):
     assert nexact >= 0.99 * ntot
 
 
+@pytest.mark.parametrize("entry", ["hs_swd_rootsearch", "hs_swd_rootsearch_split"])
+def test_a_model_that_is_no_model_fails_at_the_first_evaluation(hs, orc, entry):
+    """RootSearchT::begin (round 6): a model whose fastest layer lies more than SWD_MAX_SCAN above the start value -- a position
+    that left its bounds -- would have the reference's scan walk millions of cells of 0.005 km/s
+    (half a minute on the device, with every other chain of the batch waiting).  The search fails at its first evaluation: flag
+    0, zeros; an ordinary model beside it is searched as ever."""
+    thk = np.array([3., 3, 4, 5, 5, 6, 7, 8, 10, 0]); vs = np.linspace(2.9, 4.6, 10)
+    t = np.ascontiguousarray(np.arange(5., 41.))
+    for scale, nanat in ((2.0e4, None), (1.0, 3)):
+        v = vs * scale
+        if nanat is not None:
+            v = v.copy(); v[nanat] = np.nan
+        vp, rho, _, _ = orc.empirical_relation(np.where(np.isfinite(v), np.minimum(v, 8.0), 4.0))
+        f = [np.ascontiguousarray(x.astype(np.float32)) for x in (thk, vp, v, rho)]
+        cg = np.full(len(t), -1.0); ns = ctypes.c_long(0)
+        flag = getattr(hs["swd"], entry)(len(v), *[F(x) for x in f], len(t), P(t), P(cg), ctypes.byref(ns))
+        # (a not-a-number among the velocities is not seen by the extremal-velocity comparisons: that search runs, and fails in
+        # bounded time of its own accord)
+        assert flag == 0 and not cg.any() and (ns.value == 1 if nanat is None else ns.value < 20000), (scale, nanat, flag, ns.value)
+    vp, rho, _, _ = orc.empirical_relation(vs)
+    f = [np.ascontiguousarray(x.astype(np.float32)) for x in (thk, vp, vs, rho)]
+    cg = np.zeros(len(t)); ns = ctypes.c_long(0)
+    assert getattr(hs["swd"], entry)(len(vs), *[F(x) for x in f], len(t), P(t), P(cg), ctypes.byref(ns)) == 1 and (cg > 2.0).all()
+
+
 def test_fused_eigenfunction_sweep(hs, orc, golden):
     g = golden["swd_reference"]
     c = ctypes.c_double
