@@ -13,15 +13,31 @@ from ._batched import store_format as resolve_store_format, with_host_threads
 
 
 def _mirror(x, p, boundaries):
-    """pyhmc/hmcda.py:152-168 on [nchain, n] arrays."""
+    """pyhmc/hmcda.py:152-168 on [nchain, n] arrays.  64 reflections as the reference makes them; a point that is still outside
+    then (a momentum that has blown up) is folded in closed form -- the same point up to rounding, where the reference would loop
+    on, for ever if the point is infinite -- and a non-finite one is put in the middle of its bounds (its energy is not finite:
+    the trajectory is rejected).  Same rule as the device's flow_mirror (csrc/rfsurf_kernels.hpp)."""
     x, p = x.copy(), p.copy()
     high, low = boundaries[:, 1][None, :], boundaries[:, 0][None, :]
     idx1, idx2 = x > high, x < low
-    while np.any(idx1 | idx2):
+    it = 0
+    while np.any(idx1 | idx2) and it < 64:
         x = np.where(idx1, 2 * high - x, x); p = np.where(idx1, -p, p)
         idx2 = x < low
         x = np.where(idx2, 2 * low - x, x); p = np.where(idx2, -p, p)
         idx1, idx2 = x > high, x < low
+        it += 1
+    out = (x > high) | (x < low) | ~np.isfinite(x)
+    if np.any(out):
+        w = np.broadcast_to(high - low, x.shape)
+        lo = np.broadcast_to(low, x.shape)
+        fold = out & np.isfinite(x) & (np.abs(x) < 1.0e300) & (w > 0)
+        with np.errstate(invalid="ignore"):
+            y = np.mod(x - lo, 2.0 * w)                      # (numpy's mod: in [0, 2 w) for a positive divisor)
+        odd = y > w
+        x = np.where(fold, lo + np.where(odd, 2.0 * w - y, y), x)
+        p = np.where(fold & odd, -p, p)
+        x = np.where(out & ~fold, lo + 0.5 * w, x)
     return x, p
 
 
