@@ -406,6 +406,11 @@ int rfs_ndata(const rfs_ctx* ctx);      /* nt + ntRc + ntRg + ntLc + ntLg of the
  *                          chain takes 2 ms.  Such batches also keep ONE hand-back list and ONE sequential search per step, on
  *                          the step's own stream (12 launches on the step's chain instead of 19).  0 = off, 1 = batches of up
  *                          to 512 chains.  Sequences of up to 192 periods, fundamental mode, no water layer.
+ *   "swd_cold_again"       1 (default): in those batches (beyond "swd_cold_first") a chain whose last evaluation ended on the
+ *                          hand-back list goes straight to the search without a prediction the next time -- a wild chain is wild
+ *                          for many steps, and the branch test would decline its continued roots again (32 wild chains: 64 -> 48
+ *                          sequential searches in 200 steps, -5 % per step).  Kept per chain across the steps the chain sits
+ *                          out: no result depends on the host's timing.  0 = off.
  *   "swd_exact_group_small"  2 (default): periods per group of the reference-root stage in those small batches (16 lanes per
  *                          group; the stage is as long as a group's periods + run-up one after the other, and the groups whose
  *                          run-up does not contract get a second try behind eight run-up periods there).

@@ -120,6 +120,9 @@ struct rfs_ctx {
     // differ from the sequential search's and the misfit is off by up to 5.1e-5 instead of 6.0e-6 (scripts/warm_fuzz_soak.py
     // 8100..8399).  Parity first: the one-period setting is an option ("swd_exact_runup" 1 + "swd_exact_origin_tol_e9" 500).
     float exact_origin_tol = 1.0e-7f;   // option "swd_exact_origin_tol_e9" (EXACT_ORIGIN_TOL; 5e-7 goes with ONE run-up period)
+    int cold_again = 1;             // "swd_cold_again": a chain handed back in the evaluation before goes straight to the search without a prediction
+    int need_prev_par = -1, need_prev_nchain = 0;
+    Buf wcold;
     int cold_first = 8;             // "swd_cold_first": batches of up to that many chains do not try the warm search at all
     int cold_scan = -1;             // "swd_cold_scan": -1 = for foreground hand-backs of up to COLD_AUTO_CHAINS chains, 0 off, 1 up to COLD_MAX_CHAINS
     Buf cold_roots, cold_nroot, cold_s0, cold_ticket;
@@ -831,6 +834,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
     bool bg_record = false;                  // this step's searches of handed-back chains stay in the background
     bool walk_join = false;                  // the grid walk ran on its own stream: this stream joins it behind the eigenfunction pass
     if (!(warm && roots)) {
+        if (roots) c->need_prev_par = -1;     // (the next warm-started evaluation has no warm-started one before it)
         // whatever comes now rewrites the root buffer: every background search still under way has to be through
         for (int i = 0; i < RFS_BG_SLOTS; i++)
             if (c->bg_busy[i]) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_bg[i], 0)); }
@@ -853,7 +857,7 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
                   c->wsg1.as<unsigned char>(),
                   (c->flow_cur && c->flow_skip_idle) ? c->f_rem : (const int*)nullptr, c->f_fresh, c->f_ok,
                   c->warm_exact ? c->cwarm.as<double>() : c->croot.as<double>(), c->warm_widen ? 1 : 0,
-                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr, c->walk_window, 0};
+                  c->warm_feedback ? c->wferr.as<double>() : (double*)nullptr, c->walk_window, 0, (const int*)nullptr, (int*)nullptr};
         (void)0;
 // Rounds (WarmSpill, rfsurf_kernels.hpp): budgets b1, b2, b3 and a last round without one; the unfinished searches of a round
         // are packed into a list for the next.  The lists' lengths are only known on the device: the later rounds' grids are sized for
@@ -875,6 +879,16 @@ int launch_swd(rfs_ctx* c, hipStream_t s, int nchain, int n, const SwdPlan& P, b
         if (sb) { W.list2 = W.list3 = W.list; W.count2 = W.count3 = W.count; }
         const bool cold_first = sb && nchain <= c->cold_first;
         W.decline_all = cold_first ? 1 : 0;
+        // (the hand-back flags of the evaluation before this one, if that was a warm-started evaluation of the same chains)
+        if (sb && !cold_first && c->cold_again) {
+            const size_t before = c->wcold.cap;
+            ENSURE(c, c->wcold, (size_t)nchain * sizeof(int));
+            if (c->wcold.cap != before) HIPCHK(c, hipMemsetAsync(c->wcold.p, 0, c->wcold.cap, s));
+            W.cold_again = c->wcold.as<int>();
+            if (c->need_prev_par >= 0 && c->need_prev_nchain == nchain)
+                W.need_prev = c->wneed.as<int>() + (size_t)c->need_prev_par * (3 * (size_t)nchain + 4);
+        }
+        c->need_prev_par = c->wpar; c->need_prev_nchain = nchain;
         const size_t items_max = (size_t)std::max(Q.nper_total, P.QL.nper_total) * nchain;
         // (measured need: a few per cent of the items; a list that overflows is not an error -- the searches it cannot take finish
         // in place, test_warm_search_in_rounds_... runs that path -- so a quarter of the items is plenty: 152 B a slot, two lists)
@@ -1762,7 +1776,7 @@ void rfs_destroy(rfs_ctx* c) {
                    &c->croot, &c->sflag, &c->edone, &c->cds, &c->krn, &c->ugr, &c->b1a, &c->b1b, &c->b1c, &c->b1d, &c->b1e,
                    &c->b1f, &c->b1g, &c->specp, &c->tserp, &c->klbuf, &c->bt, &c->lx, &c->lp, &c->lU, &c->lgrad,
                    &c->ldsyn, &c->lflag, &c->mdlc, &c->xw, &c->dxT, &c->crT, &c->wvalid, &c->wneed, &c->wlist, &c->wforce,
-                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc, &c->xredo, &c->Hs, &c->cold_roots, &c->cold_nroot, &c->cold_s0, &c->cold_ticket};
+                   &c->wstats, &c->wsgn, &c->crs, &c->craw, &c->wilist, &c->wlist2, &c->wlist3, &c->cwarm, &c->fpend, &c->twid, &c->gtab, &c->etab, &c->fstat, &c->RT, &c->wslope, &c->rstat, &c->wbetmx, &c->wsg1, &c->slist, &c->scount, &c->hi32, &c->stat32, &c->wferr, &c->wspA, &c->wspB, &c->wspc, &c->frec, &c->xsp, &c->xspc, &c->xredo, &c->Hs, &c->cold_roots, &c->cold_nroot, &c->cold_s0, &c->cold_ticket, &c->wcold};
     for (Buf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_wcount) hipHostFree(c->h_wcount);
     if (c->h_scount) hipHostFree(c->h_scount);
@@ -1940,6 +1954,7 @@ int rfs_set_option(rfs_ctx* c, const char* name, int value) {
         if (value < 0 || value > 100000) return fail(c, RFS_ERR_ARG, "swd_exact_budget must be within [0, 100000]");
         c->exact_budget = value; return RFS_OK;
     }
+    if (!strcmp(name, "swd_cold_again")) { c->cold_again = value != 0; return RFS_OK; }
     if (!strcmp(name, "swd_cold_first")) {
         if (value < 0 || value > COLD_MAX_CHAINS) return fail(c, RFS_ERR_ARG, "swd_cold_first must be within [0, 512]");
         c->cold_first = value; return RFS_OK;

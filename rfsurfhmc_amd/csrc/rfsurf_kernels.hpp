@@ -1153,6 +1153,14 @@ struct SwdWarm {
     // "swd_cold_first" (round 6, batches of a few chains): every chain takes the search without a prediction (k_swd_cold_scan) --
     // k_swd_warm only sorts out the idle chains and lists the others
     int decline_all;
+    // ... and in the larger of those small batches, a chain that ended the evaluation BEFORE this one on the hand-back list (a wild
+    // chain is wild for many steps: the branch test declines its continued roots again and again, 2 ms of sequential search each
+    // time) goes straight to the search without a prediction this time.  [chain] the previous evaluation's `need`, or nullptr.
+    const int* need_prev;
+    // (what counts is the chain's last EVALUATION, not the device step before this one -- a chain that waited a step for the host has
+    // a 2 there, and how often it waits is a matter of timing, which no result may depend on: [chain] the flag as the chain's last
+    // evaluation left it, kept here across the steps it sits out; nullptr: off)
+    int* cold_again;
 };
 // is period k of a sequence (roots cq, stride nchain) within `win` periods of an anomalous pair?
 __device__ __forceinline__ bool swd_walk_near(const double* cq, size_t nchain, int nper, int k, int win, double dcs) {
@@ -1255,7 +1263,13 @@ k_swd_warm(int nchain, int n, SwdSeqs Q, const double* __restrict__ mdlc, const 
         if (live && W.pend && W.pend[chain]) { W.need[chain] = 2; live = false; }
         if (live && W.f_rem && !W.f_fresh[chain] && (W.f_rem[chain] <= 0 || !W.f_ok[chain])) { W.need[chain] = 2; live = false; }    // idle
         if (live) W.sgn[(size_t)e * nchain + chain] = 2;
-        if (live && (!W.valid[chain] || (W.force && W.force[chain]) || W.decline_all)) { decline(4); live = false; }
+        bool again = false;
+        if (W.cold_again && g < (size_t)Q.nper_total * nchain) {
+            const int np_ = W.need_prev ? W.need_prev[chain] : 0;           // (no warm-started evaluation before this one: start afresh)
+            again = np_ == 2 ? W.cold_again[chain] != 0 : np_ == 1;
+            if (el == 0 && np_ != 2) W.cold_again[chain] = again ? 1 : 0;     // (readers of the old value are the lanes that saw a 2: no write then)
+        }
+        if (live && (!W.valid[chain] || (W.force && W.force[chain]) || W.decline_all || again)) { decline(4); live = false; }
         // first-order prediction from the previous model's kernels (model_surf.py:184's chain rule; thickness kernel =
         // suffix sum of the interface partials, sregn96.f90:1727-1731); SPH: kernels of the flattened model mapped with
         // vtp / dtp / rtp as swd_kernel_value does
