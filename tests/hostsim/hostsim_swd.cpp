@@ -493,3 +493,26 @@ extern "C" int hs_exact_roots2(int n, const float* thk, const float* vp, const f
     return lazy ? exact_roots<true>(n, thk, vp, vs, rho, nt, t, approx, love, sphere, G, runup, cout, status, nev, cause, nsupplied)
                 : exact_roots<false>(n, thk, vp, vs, rho, nt, t, approx, love, sphere, G, runup, cout, status, nev, cause, nsupplied);
 }
+
+// The table of k_swd_cold_scan (round 6) with the device's own secular function and start value: out[k * np + i] = the Rayleigh /
+// Love secular function of period t[k] at c0 + i dc; hs_start_value: the model's start value and fastest S velocity.
+extern "C" double hs_start_value(int n, const float* thk, const float* vp, const float* vs, const float* rho, float* bmx)
+{
+    SwdModel M{thk, vp, vs, rho, 1, n};
+    float b = 0.f;
+    const float cc = swd_start_value(M, b);
+    *bmx = b;
+    return (double)cc;
+}
+extern "C" void hs_secular_table(int n, const float* thk, const float* vp, const float* vs, const float* rho, int nper, const double* t,
+                                 int np, double c0, double dc, int love, double* out)
+{
+    SwdModel M{thk, vp, vs, rho, 1, n};
+    for (int k = 0; k < nper; k++) {
+        const double omega = (2.0 * 3.141592653589793) / t[k];
+        for (int i = 0; i < np; i++) {
+            const double c = c0 + (double)i * dc;
+            out[(size_t)k * np + i] = love ? swd_secular_love(M, omega / c, omega) : swd_secular(M, omega / c, omega);
+        }
+    }
+}
