@@ -540,6 +540,7 @@ int rfs_set_option(rfs_ctx* ctx, const char* name, int value);
  *                          ("swd_cold_scan"; they are taken off "swd_warm_declined_chains", which then counts the sequential
  *                          searches) and its secular evaluations
  *   "swd_cold_fail_<c>"    ... and the chains it left on the list, by cause c = 34..39 (rfsurf_kernels.hpp, k_swd_cold_pick)
+ *   "wstat_<i>"            slot i = 0..39 of the warm start's counter array as it is (what the names above read; diagnostics)
  *   "swd_warm_search_evals" / "swd_warm_search_evals_slowest_lane" / "swd_warm_search_lanes"   divergence of the warm search
  *                               (k_swd_warm): evaluations of all searches, of each wavefront's slowest search summed over
  *                               the rounds' wavefronts (what the wavefronts execute; a wavefront of the cooperative last round

@@ -2056,7 +2056,7 @@ int rfs_get_stat(rfs_ctx* c, const char* name, int64_t* value) {
         for (int i = 0; i < 64; i++) *value += (int64_t)v[i];
         return RFS_OK;
     }
-    if (!strncmp(name, "wstat_", 6)) { idx = atoi(name + 6); if (idx < 0 || idx > 31) idx = -1; }      // (raw slot: debug builds)
+    if (!strncmp(name, "wstat_", 6)) { idx = atoi(name + 6); if (idx < 0 || idx > 39) idx = -1; }      // (raw slot of the warm start's counters)
     else if (!strcmp(name, "swd_warm_declined_chains")) idx = 0;
     else if (!strcmp(name, "swd_warm_secular_evals")) idx = 1;
     else if (!strcmp(name, "swd_warm_items")) idx = 2;

@@ -118,3 +118,16 @@ def test_rngbatch_selftest_rejects_a_library_that_disagrees_with_numpy():
     assert not B._rngbatch_selftest(Off())
     rng = B.ChainRNG(7, 0, 2)                   # and the real one reproduces RandomState(seed + chain)
     assert np.array_equal(rng.randn([0, 1], 3), np.stack([np.random.RandomState(7 + c).randn(3) for c in range(2)]))
+
+
+def test_every_option_and_statistic_the_library_knows_is_described_in_the_header():
+    """rfs_set_option / rfs_stat take names; a name the source accepts and include/rfsurf.h does not mention is a setting nobody
+    can find (and one whose default may change unnoticed)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rfsurfhmc_amd", "csrc", "rfsurf_hip.hip")).read()
+    hdr = open(os.path.join(root, "include", "rfsurf.h")).read()
+    names = set(re.findall(r'!strcmp\(name, "([a-z_0-9]+)"\)', src)) | set(re.findall(r'!strncmp\(name, "([a-z_0-9]+)"', src))
+    assert len(names) > 50
+    missing = sorted(n for n in names if n not in hdr)
+    assert not missing, missing
