@@ -23,7 +23,8 @@ DC = float(np.float32(0.005))
 @pytest.fixture(scope="module")
 def hs():
     so = os.path.join(HERE, "libhostsim_swd.so")
-    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so, os.path.join(HERE, "hostsim_swd.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17"] + os.environ.get("RFS_HOSTSIM_CXXFLAGS", "").split() +
+                   ["-o", so, os.path.join(HERE, "hostsim_swd.cpp")], check=True)
     lib = ctypes.CDLL(so)
     lib.hs_start_value.restype = ctypes.c_double
     lib.hs_secular.restype = ctypes.c_double

@@ -16,8 +16,10 @@ def hs():
     libs = {}
     for name in ("rf", "swd"):
         so = os.path.join(HERE, f"libhostsim_{name}.so")
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so,
-                        os.path.join(HERE, f"hostsim_{name}.cpp")], check=True)
+        # (RFS_HOSTSIM_CXXFLAGS="-fsanitize=undefined -fno-sanitize-recover=undefined": the device math under the CPU's sanitizer --
+        # the GPU pool has none)
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17"] + os.environ.get("RFS_HOSTSIM_CXXFLAGS", "").split() +
+                       ["-o", so, os.path.join(HERE, f"hostsim_{name}.cpp")], check=True)
         libs[name] = ctypes.CDLL(so)
     libs["swd"].hs_sregn96.restype = ctypes.c_double
     return libs
